@@ -1,0 +1,104 @@
+"""ctypes binding of the C ABI declared in ``include/bgs.h`` (libbgs.so).
+
+The product path has NO CPU fallback: if the HIP library has not been built, every
+entry point raises ``BgsLibraryError`` — a GPU run can never silently execute
+something other than the hand-written kernels.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+
+c_i64p = ctypes.c_void_p
+c_f32p = ctypes.c_void_p
+c_ptr = ctypes.c_void_p
+
+BGS_OK = 0
+BGS_MAX_BINS = 16
+
+
+class BgsLibraryError(RuntimeError):
+    pass
+
+
+class BgsCallError(RuntimeError):
+    def __init__(self, fn, code, text):
+        super().__init__('%s failed with code %d: %s' % (fn, code, text))
+        self.code = code
+
+
+# name -> (restype, argtypes); mirrors include/bgs.h one-to-one (checked by tests/test_capi.py)
+SIGNATURES = {
+    'bgs_version': (ctypes.c_int, []),
+    'bgs_error_string': (ctypes.c_char_p, [ctypes.c_int]),
+    'bgs_selftest_wave_reduce': (ctypes.c_int, [c_f32p, c_f32p, c_ptr]),
+    'bgs_gs_prepare': (ctypes.c_int, [c_i64p, c_i64p, c_f32p, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                      ctypes.c_uint64, c_ptr, c_i64p, c_f32p, c_f32p, c_ptr]),
+    'bgs_gs_loss_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    'bgs_gs_loss_fwd_bwd': (ctypes.c_int, [c_f32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           c_f32p, c_f32p, c_ptr, c_ptr]),
+    'bgs_gs_loss_reduce': (ctypes.c_int, [c_ptr, ctypes.c_int, ctypes.c_int, c_f32p, c_ptr]),
+    'bgs_gs_scale_grad': (ctypes.c_int, [c_f32p, c_i64p, c_f32p, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, c_ptr]),
+    'bgs_gs_merge_score': (ctypes.c_int, [c_f32p, c_i64p, c_ptr, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, c_f32p, c_ptr]),
+    'bgs_bbox_loss_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int]),
+    'bgs_bbox_smooth_l1_fwd_bwd': (ctypes.c_int, [c_f32p, c_i64p, c_f32p, c_f32p, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                                  ctypes.c_float, c_f32p, c_f32p, c_ptr, c_ptr]),
+}
+
+_LIB = None
+
+
+def lib_filename():
+    """``BGS_LIB_VARIANT=nodpp`` selects the ds_bpermute build (A/B and safety net)."""
+    variant = os.environ.get('BGS_LIB_VARIANT', '')
+    return 'libbgs_%s.so' % variant if variant else 'libbgs.so'
+
+
+def lib_path():
+    return os.environ.get('BGS_LIB_PATH', os.path.join(_PKG, lib_filename()))
+
+
+def load():
+    """dlopen libbgs.so (once) and attach the prototypes."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise BgsLibraryError(
+            '%s not found. Build the HIP kernels first: '
+            '`python -m balancedgroupsoftmax_amd.csrc.build` (or __graft_entry__.build()). '
+            'There is deliberately no CPU fallback.' % path)
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise BgsLibraryError('cannot load %s: %s' % (path, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise BgsLibraryError('%s does not export %s (stale build?)' % (path, name))
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(fn_name, code):
+    if code != BGS_OK:
+        raise BgsCallError(fn_name, code, load().bgs_error_string(code).decode())
+
+
+def ptr(t):
+    """Device (or host) address of a tensor, NULL for None."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

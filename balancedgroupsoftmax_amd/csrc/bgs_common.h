@@ -1,0 +1,129 @@
+// Device-side helpers shared by the libbgs kernels (gfx950 / CDNA4, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bgs.h"
+
+#define BGS_WAVE 64
+
+// Every launch is checked the way the reference checks its own
+// (THCudaCheck(cudaGetLastError()), roi_align_kernel.cu:145) — but reported through
+// the return code instead of aborting.
+#define BGS_RETURN_LAUNCH_STATUS()                         \
+  do {                                                     \
+    return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH; \
+  } while (0)
+
+namespace bgs {
+
+// ---- wave64 all-reduce -------------------------------------------------------------
+// Default: DPP row operations (quad_perm / row_ror / row_bcast, the gfx9 recipe also used by
+// rocPRIM's warp_reduce_dpp) — 6 dependent VALU ops, then v_readlane of lane 63; the result
+// is wave-uniform (SGPR).  -DBGS_NO_DPP builds the ds_bpermute butterfly instead (A/B + safety).
+#ifndef BGS_NO_DPP
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+#define BGS_DPP_REDUCE(v, OP)                                   \
+  do {                                                          \
+    v = OP(v, dpp_mov<0xb1>(v));  /* quad_perm:[1,0,3,2] */     \
+    v = OP(v, dpp_mov<0x4e>(v));  /* quad_perm:[2,3,0,1] */     \
+    v = OP(v, dpp_mov<0x124>(v)); /* row_ror:4 */               \
+    v = OP(v, dpp_mov<0x128>(v)); /* row_ror:8 */               \
+    v = OP(v, dpp_mov<0x142>(v)); /* row_bcast:15 */            \
+    v = OP(v, dpp_mov<0x143>(v)); /* row_bcast:31 */            \
+    v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); \
+  } while (0)
+__device__ __forceinline__ float op_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float wave_max(float v) {
+  BGS_DPP_REDUCE(v, fmaxf);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  BGS_DPP_REDUCE(v, op_add);
+  return v;
+}
+#else
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, BGS_WAVE));
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, BGS_WAVE);
+  return v;
+}
+#endif
+
+// ds_bpermute butterflies (always available; used by the self-test and for int/double).
+__device__ __forceinline__ float wave_max_shfl(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, BGS_WAVE));
+  return v;
+}
+__device__ __forceinline__ float wave_sum_shfl(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, BGS_WAVE);
+  return v;
+}
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, BGS_WAVE);
+  return v;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, BGS_WAVE);
+  return v;
+}
+
+// Wave-uniform value -> SGPR (lets the compiler use scalar loads / uniform branches).
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<4> { using type = float4; };
+template <>
+struct VecT<2> { using type = float2; };
+template <>
+struct VecT<1> { using type = float; };
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&out)[VEC]) {
+  using V = typename VecT<VEC>::type;
+  V v = *reinterpret_cast<const V*>(p);
+  const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) out[j] = f[j];
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&in)[VEC]) {
+  using V = typename VecT<VEC>::type;
+  V v;
+  float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) f[j] = in[j];
+  *reinterpret_cast<V*>(p) = v;
+}
+
+// splitmix64 finaliser: counter-based RNG keyed by (seed, stream, index).
+__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint32_t stream, uint32_t idx) {
+  uint64_t x = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)idx + 1ull) +
+               0xD1B54A32D192ED03ull * ((uint64_t)stream + 1ull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}
+
+}  // namespace bgs

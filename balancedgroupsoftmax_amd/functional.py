@@ -1,0 +1,229 @@
+"""Tensor-level wrappers over the C ABI (``include/bgs.h``).
+
+PyTorch is plumbing here: device memory, the current HIP stream and autograd graph
+edges.  All arithmetic happens in the hand-written gfx950 kernels of ``libbgs.so``.
+Every wrapper requires CUDA(ROCm) tensors and raises otherwise — there is no CPU
+path in the product.
+"""
+import itertools
+
+import torch
+
+from . import capi
+
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    """Per (device, stream) scratch buffer; kernels of one stream are serialised."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                'balancedgroupsoftmax_amd ops run only on the GPU (hand-written HIP kernels); '
+                'got a %s tensor. There is no CPU fallback.' % t.device)
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+# ----------------------------------------------------------------------------------------
+# label remap + sampling  (GSBBoxHeadWith0._remap_labels, gs_bbox_head_with0.py:91-112)
+# ----------------------------------------------------------------------------------------
+_seed_counter = itertools.count(1)
+
+
+def gs_prepare(labels, label2binlabel, others_sample_ratio, seed=None, cls_weight=None,
+               return_bin_labels=False, seed_offset=None):
+    """Device-side ``_remap_labels``: returns ``weights [B,N] f32``, ``avg [B] f32``
+    (and ``bin_labels [B,N] i64`` when asked).  No host sync.
+
+    ``seed``: draw identifier of the counter-based RNG; ``None`` takes the next value of
+    a process-wide counter mixed with ``torch.initial_seed()`` (reproducible runs).
+    ``seed_offset``: optional device int64 ``[1]`` draw counter added to the seed on the
+    device (bump it with a tensor op; needed under hipGraph replay where ``seed`` is frozen).
+    """
+    _require_cuda(labels, label2binlabel, cls_weight)
+    lib = capi.load()
+    labels = labels.contiguous()
+    assert labels.dtype == torch.int64 and label2binlabel.dtype == torch.int64
+    B, C = label2binlabel.shape
+    N = labels.numel()
+    dev = labels.device
+    if seed is None:
+        seed = (torch.initial_seed() * 0x9E3779B1 + next(_seed_counter)) & 0xFFFFFFFFFFFFFFFF
+    weights = torch.empty((B, N), dtype=torch.float32, device=dev)
+    avg = torch.empty((B,), dtype=torch.float32, device=dev)
+    bl = torch.empty((B, N), dtype=torch.int64, device=dev) if return_bin_labels else None
+    cw_stride = 0
+    if cls_weight is not None:
+        assert cls_weight.dtype == torch.float32 and cls_weight.dim() == 2
+        assert cls_weight.shape[0] == B - 1 and cls_weight.is_contiguous()
+        cw_stride = cls_weight.shape[1]
+    rc = lib.bgs_gs_prepare(capi.ptr(labels), capi.ptr(label2binlabel), capi.ptr(cls_weight),
+                            cw_stride, N, C, B, float(others_sample_ratio), int(seed),
+                            capi.ptr(seed_offset), capi.ptr(bl), capi.ptr(weights), capi.ptr(avg),
+                            capi.current_stream(dev))
+    capi.check('bgs_gs_prepare', rc)
+    if return_bin_labels:
+        return weights, avg, bl
+    return weights, avg
+
+
+# ----------------------------------------------------------------------------------------
+# fused group-softmax loss  (GSBBoxHeadWith0.loss classification part, :160-171)
+# ----------------------------------------------------------------------------------------
+def _gs_loss_launch(logits, labels, l2b, pred_slice, weights, avg, want_grad):
+    lib = capi.load()
+    N, W = logits.shape
+    B, C = l2b.shape
+    dev = logits.device
+    loss = torch.empty((B,), dtype=torch.float32, device=dev)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    ws = _workspace(lib.bgs_gs_loss_workspace_bytes(N, B), dev)
+    rc = lib.bgs_gs_loss_fwd_bwd(capi.ptr(logits), capi.ptr(labels), capi.ptr(l2b),
+                                 capi.ptr(pred_slice), capi.ptr(weights), capi.ptr(avg),
+                                 N, C, B, W, capi.ptr(loss), capi.ptr(dlogits), capi.ptr(ws),
+                                 capi.current_stream(dev))
+    capi.check('bgs_gs_loss_fwd_bwd', rc)
+    return loss, dlogits
+
+
+class _GroupSoftmaxLoss(torch.autograd.Function):
+    """losses[B] = fused kernel; the gradient w.r.t. the logits is produced by the SAME
+    launch and only rescaled by the upstream scalars in backward (early-out when they are 1)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, l2b, pred_slice, weights, avg):
+        want_grad = logits.requires_grad
+        z = _f32c(logits)
+        loss, dlogits = _gs_loss_launch(z, labels, l2b, pred_slice, weights, avg, want_grad)
+        ctx.dlogits = dlogits
+        ctx.pred_slice = pred_slice
+        ctx.in_dtype = logits.dtype
+        ctx.prev_g = None
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_loss):
+        dl = ctx.dlogits
+        if dl is None:
+            return None, None, None, None, None, None
+        lib = capi.load()
+        g = grad_loss.detach().to(torch.float32).contiguous()
+        if ctx.prev_g is not None:  # a second backward through a retained graph
+            g_eff = torch.where(ctx.prev_g == 0, torch.zeros_like(g), g / ctx.prev_g)
+        else:
+            g_eff = g
+        N, W = dl.shape
+        B = ctx.pred_slice.shape[0]
+        rc = lib.bgs_gs_scale_grad(capi.ptr(dl), capi.ptr(ctx.pred_slice), capi.ptr(g_eff),
+                                   N, B, W, capi.current_stream(dl.device))
+        capi.check('bgs_gs_scale_grad', rc)
+        ctx.prev_g = g
+        out = dl if ctx.in_dtype == torch.float32 else dl.to(ctx.in_dtype)
+        return out, None, None, None, None, None
+
+
+def group_softmax_loss(cls_score, labels, label2binlabel, pred_slice, weights=None, avg=None):
+    """Per-bin weighted CE of the ``[N, W]`` logits -> ``[B]`` losses (differentiable
+    w.r.t. ``cls_score``).  ``weights [B,N]`` / ``avg [B]`` as produced by ``gs_prepare``."""
+    _require_cuda(cls_score, labels, label2binlabel, pred_slice, weights, avg)
+    assert cls_score.dim() == 2 and labels.dtype == torch.int64
+    assert label2binlabel.is_contiguous() and pred_slice.is_contiguous()
+    labels = labels.contiguous()
+    if weights is not None:
+        weights = _f32c(weights)
+        assert weights.shape == (label2binlabel.shape[0], cls_score.shape[0])
+    if avg is not None:
+        avg = _f32c(avg)
+    return _GroupSoftmaxLoss.apply(cls_score, labels, label2binlabel, pred_slice, weights, avg)
+
+
+# ----------------------------------------------------------------------------------------
+# inference score merge  (GSBBoxHeadWith0._merge_score, :239-273)
+# ----------------------------------------------------------------------------------------
+def gs_merge_score(cls_score, pred_slice, cls2col, num_classes):
+    _require_cuda(cls_score, pred_slice, cls2col)
+    lib = capi.load()
+    z = _f32c(cls_score)
+    N, W = z.shape
+    B = pred_slice.shape[0]
+    assert cls2col.dtype == torch.int32 and cls2col.numel() == num_classes
+    out = torch.empty((N, num_classes), dtype=torch.float32, device=z.device)
+    rc = lib.bgs_gs_merge_score(capi.ptr(z), capi.ptr(pred_slice), capi.ptr(cls2col), N,
+                                num_classes, B, W, capi.ptr(out), capi.current_stream(z.device))
+    capi.check('bgs_gs_merge_score', rc)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# box regression loss  (loss_bbox branch, :173-185)
+# ----------------------------------------------------------------------------------------
+class _BBoxSmoothL1(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, bbox_pred, labels, bbox_targets, bbox_weights, num_reg_classes, beta,
+                avg_factor, loss_weight):
+        lib = capi.load()
+        p = _f32c(bbox_pred)
+        N = p.shape[0]
+        R = int(num_reg_classes)
+        assert p.shape[1] == 4 * R
+        dev = p.device
+        want_grad = bbox_pred.requires_grad
+        loss = torch.empty((1,), dtype=torch.float32, device=dev)
+        dpred = torch.empty_like(p) if want_grad else None
+        ws = _workspace(lib.bgs_bbox_loss_workspace_bytes(N), dev)
+        rc = lib.bgs_bbox_smooth_l1_fwd_bwd(
+            capi.ptr(p), capi.ptr(labels), capi.ptr(bbox_targets), capi.ptr(bbox_weights), N, R,
+            float(beta), float(avg_factor), float(loss_weight), capi.ptr(loss), capi.ptr(dpred),
+            capi.ptr(ws), capi.current_stream(dev))
+        capi.check('bgs_bbox_smooth_l1_fwd_bwd', rc)
+        ctx.dpred = dpred
+        ctx.in_dtype = bbox_pred.dtype
+        return loss[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_loss):
+        if ctx.dpred is None:
+            return (None,) * 8
+        g = ctx.dpred * grad_loss  # upstream scalar; dense like the autograd result
+        if ctx.in_dtype != torch.float32:
+            g = g.to(ctx.in_dtype)
+        return (g,) + (None,) * 7
+
+
+def bbox_smooth_l1_loss(bbox_pred, labels, bbox_targets, bbox_weights, num_reg_classes,
+                        beta=1.0, avg_factor=None, loss_weight=1.0):
+    """``loss_weight * sum(smooth_l1(pred[pos, labels[pos]] - targets[pos]) * w[pos]) / avg``."""
+    _require_cuda(bbox_pred, labels, bbox_targets, bbox_weights)
+    if avg_factor is None:
+        avg_factor = bbox_targets.shape[0]
+    return _BBoxSmoothL1.apply(bbox_pred, labels.contiguous(), _f32c(bbox_targets),
+                               _f32c(bbox_weights), num_reg_classes, beta, avg_factor,
+                               loss_weight)
+
+
+def selftest_wave_reduce(values):
+    """Runs the device self-test of the wave reduction primitive (64 floats in)."""
+    _require_cuda(values)
+    lib = capi.load()
+    v = _f32c(values)
+    assert v.numel() == 64
+    out = torch.empty(4, dtype=torch.float32, device=v.device)
+    capi.check('bgs_selftest_wave_reduce',
+               lib.bgs_selftest_wave_reduce(capi.ptr(v), capi.ptr(out),
+                                            capi.current_stream(v.device)))
+    return out

@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X-native Balanced Group Softmax hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gs_head]
+
+Contract: W untimed warm-up steps, then exactly K timed steps bracketed by barrier +
+``torch.cuda.synchronize()``; the MAX over ranks is taken and rank 0 prints ONE JSON line.
+
+Workload ``gs_head`` (this round): the RoI-head loss of BASELINE.json config[1]
+(Faster R-CNN R50-FPN + BAGS, 2 img/GPU x 512 RoI = 1024 RoIs x 1236 logits, 25 % fg):
+one step = ``_remap_labels`` (device sampling) + fused GroupSoftmax loss forward+backward
+(+ the reduce / scale kernels) + the box-regression loss, inputs resident in HBM.
+The JSON line carries ``roofline`` for the dominant kernel (the fused streaming kernel,
+HIP-event timed on its own stream) and ``cpu_baseline`` = the torch-CPU port of the
+reference's loss()+backward() timed on this host (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from balancedgroupsoftmax_amd import capi  # noqa: E402
+from balancedgroupsoftmax_amd import functional as BF  # noqa: E402
+from balancedgroupsoftmax_amd import gs_tables  # noqa: E402
+
+NUM_CLASSES = 1231
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='gs_head', choices=['gs_head'])
+    ap.add_argument('--rois', type=int, default=1024, help='RoIs per GPU per step (2 img x 512)')
+    ap.add_argument('--no-graph', action='store_true', help='time eager launches, not hipGraph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    return ap.parse_args()
+
+
+def init_dist(args):
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world)   # RCCL on ROCm
+    return rank, local, world
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def make_inputs(n, seed, dev):
+    rs = np.random.RandomState(seed)
+    counts = gs_tables.synthetic_instance_counts(NUM_CLASSES, seed=0)
+    l2b, ps, _ = gs_tables.build_group_tables(counts)
+    W = int(ps[:, 1].sum())
+    labels = np.zeros(n, dtype=np.int64)
+    nfg = n // 4
+    labels[:nfg] = rs.randint(1, NUM_CLASSES, size=nfg)     # positives first (bbox_target_single)
+    d = dict(
+        logits=torch.from_numpy(rs.standard_normal((n, W)).astype(np.float32)).to(dev),
+        bbox_pred=torch.from_numpy(rs.standard_normal((n, 4 * NUM_CLASSES)).astype(np.float32)).to(dev),
+        labels=torch.from_numpy(labels).to(dev),
+        bbox_targets=torch.from_numpy(rs.standard_normal((n, 4)).astype(np.float32)).to(dev),
+        bbox_weights=torch.from_numpy(np.repeat((labels > 0)[:, None], 4, 1).astype(np.float32)).to(dev),
+        l2b=torch.from_numpy(l2b).to(dev), ps=torch.from_numpy(ps).to(dev))
+    d['l2b_np'], d['ps_np'], d['W'] = l2b, ps, W
+    return d
+
+
+class GsHeadStep(object):
+    """One step of the BAGS RoI-head loss: everything the reference's
+    GSBBoxHeadWith0.loss() + backward() does for a 1024-RoI batch (selectp=1: the box branch
+    contributes its loss value only; cls_score gets its full gradient)."""
+
+    def __init__(self, inp):
+        self.inp = inp
+        self.logits = inp['logits'].clone().requires_grad_(True)
+        self.draw = torch.zeros(1, dtype=torch.int64, device=inp['logits'].device)
+
+    def __call__(self):
+        i = self.inp
+        self.logits.grad = None
+        self.draw += 1            # device-side draw counter: a new sample every step, also under graph replay
+        w, avg = BF.gs_prepare(i['labels'], i['l2b'], 8.0, seed=12345, seed_offset=self.draw)
+        per_bin = BF.group_softmax_loss(self.logits, i['labels'], i['l2b'], i['ps'], w, avg)
+        lbox = BF.bbox_smooth_l1_loss(i['bbox_pred'], i['labels'], i['bbox_targets'],
+                                      i['bbox_weights'], NUM_CLASSES, beta=1.0,
+                                      avg_factor=i['labels'].numel())
+        total = per_bin.sum() + lbox
+        total.backward()
+        return total
+
+
+def timed_loop(fn, steps, warmup, world):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    barrier(world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    barrier(world)
+    t1 = time.perf_counter()
+    dt = t1 - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def try_graph(step):
+    """Capture one step into a hipGraph (the loop is launch-bound: ~10 short kernels)."""
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        torch.cuda.synchronize()
+        return g
+    except Exception as e:  # pragma: no cover
+        sys.stderr.write('hipGraph capture failed (%s); timing eager launches\n' % (e,))
+        return None
+
+
+def kernel_roofline(inp, n, iters=300):
+    """HIP-event timing of the dominant kernel alone (the fused streaming kernel: main launch
+    of bgs_gs_loss_fwd_bwd with loss_out=NULL), back to back on the current stream.
+    Algorithmic bytes per RoI: W*4 read + W*4 written + 8 (label) + B*4 (weights)."""
+    lib = capi.load()
+    W, B = inp['W'], inp['ps'].shape[0]
+    dev = inp['logits'].device
+    w, avg = BF.gs_prepare(inp['labels'], inp['l2b'], 8.0, seed=1)
+    dl = torch.empty_like(inp['logits'])
+    ws = torch.empty(lib.bgs_gs_loss_workspace_bytes(n, B), dtype=torch.uint8, device=dev)
+    st = capi.current_stream(dev)
+
+    def launch():
+        rc = lib.bgs_gs_loss_fwd_bwd(capi.ptr(inp['logits']), capi.ptr(inp['labels']),
+                                     capi.ptr(inp['l2b']), capi.ptr(inp['ps']), capi.ptr(w),
+                                     capi.ptr(avg), n, NUM_CLASSES, B, W, None, capi.ptr(dl),
+                                     capi.ptr(ws), st)
+        capi.check('bgs_gs_loss_fwd_bwd', rc)
+
+    for _ in range(20):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    bytes_per_roi = W * 4 + W * 4 + 8 + B * 4
+    achieved = bytes_per_roi * n / (us * 1e-6) / 1e9
+    return dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                kernel='gs_loss_rowblock_kernel<4,1,true>', us_per_launch=round(us, 3),
+                algorithmic_bytes_per_roi=bytes_per_roi, rois_per_launch=n,
+                timing='hipEvent over %d back-to-back launches (includes the ~1.5 us '
+                       'inter-kernel boundary)' % iters)
+
+
+def cpu_baseline(n, seconds):
+    """Reference CPU path (torch-CPU port, oracle/gs_torch_port.py) on this host's cores."""
+    from oracle import gs_oracle, gs_torch_port
+    counts = gs_tables.synthetic_instance_counts(NUM_CLASSES, seed=0)
+    l2b, ps, _ = gs_tables.build_group_tables(counts)
+    batch = gs_oracle.make_roi_batch(n, int(ps[:, 1].sum()), NUM_CLASSES, seed=0)
+    z, lab = torch.from_numpy(batch['logits']), torch.from_numpy(batch['labels'])
+    l2b_t, ps_t = torch.from_numpy(l2b), torch.from_numpy(ps)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    for _ in range(5):
+        gs_torch_port.gs_loss_fwd_bwd(z, lab, l2b_t, ps_t, 8.0)
+    times = []
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end and len(times) < 2000:
+        np.random.seed(len(times))
+        t0 = time.perf_counter()
+        gs_torch_port.gs_loss_fwd_bwd(z, lab, l2b_t, ps_t, 8.0)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return dict(value=round(med * 1e6 / n, 4), unit='us/RoI', cores=cores, kind='port',
+                sample='%d x (loss+backward) of the torch-CPU port of GSBBoxHeadWith0.loss on '
+                       'N=%d RoIs x 1236 logits (cls branch, numpy sampling incl.), median; '
+                       'torch %s, %d threads' % (len(times), n, torch.__version__, cores))
+
+
+def main():
+    args = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the product has no CPU path)')
+    rank, local, world = init_dist(args)
+    if world != args.gpus:
+        sys.stderr.write('note: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)\n'
+                         % (args.gpus, world))
+    dev = torch.device('cuda', local)
+    n = args.rois
+    inp = make_inputs(n, seed=1000 + rank, dev=dev)
+    step = GsHeadStep(inp)
+    graph = None if args.no_graph else try_graph(step)
+    fn = graph.replay if graph is not None else step
+    dt = timed_loop(fn, args.steps, args.warmup, world)
+    ms_per_step = dt * 1e3 / args.steps
+    us_per_roi = dt * 1e6 / (args.steps * n * world)
+
+    if rank == 0:
+        # eager (python launch overhead included) for reference
+        dt_eager = None
+        if graph is not None and world == 1:
+            dt_eager = timed_loop(step, min(args.steps, 100), 5, 1) * 1e3 / min(args.steps, 100)
+        out = {
+            'metric': 'GroupSoftmax us/RoI (loss fwd+bwd; BASELINE metric: img/s/GPU fwd+bwd '
+                      'R50-FPN+BAGS 1333x800, 512 RoI; GroupSoftmax us/RoI)',
+            'value': round(us_per_roi, 6), 'unit': 'us/RoI', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 5),
+            'higher_is_better': False, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'gs_head: RoI-head loss of gs_faster_rcnn_r50_fpn_1x_lvis_'
+                                   'with0_bg8 (cfg[1]): %d RoIs/GPU (2 img x 512) x 1236 logits, '
+                                   '1231 classes, 5 bins, 25%% fg; _remap_labels + fused '
+                                   'GroupSoftmax loss fwd+bwd + loss_bbox' % n,
+                       'rois_per_gpu': n, 'launch': 'hipGraph replay' if graph else 'eager',
+                       'parallelism': 'dp%d (independent RoI batches, no data-path collective)'
+                                      % world},
+            'rois_per_s': round(n * world * args.steps / dt, 1),
+        }
+        if dt_eager is not None:
+            out['ms_per_step_eager'] = round(dt_eager, 5)
+        out['roofline'] = kernel_roofline(inp, n)
+        big = make_inputs(65536, seed=7, dev=dev)
+        out['roofline_n65536'] = kernel_roofline(big, 65536, iters=30)
+        del big
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(n, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    barrier(world)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,174 @@
+"""CPU: registry / config / group tables / box coding — the host-side mirror of the
+reference interface (no kernels involved)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import balancedgroupsoftmax_amd as bgs
+from balancedgroupsoftmax_amd import box_ops, gs_tables, losses
+from balancedgroupsoftmax_amd.registry import Registry, build_from_cfg
+
+REF_CFG = '/root/reference/configs/bags/gs_faster_rcnn_r50_fpn_1x_lvis_with0_bg8.py'
+
+
+def test_registry_keys_present():
+    for k in ['GSBBoxHeadWith0', 'GSBBoxHeadWith0Reweight', 'GSBBoxHead', 'SharedFCBBoxHead',
+              'ConvFCBBoxHead', 'BBoxHead']:
+        assert k in bgs.HEADS, k
+    for k in ['CrossEntropyLoss', 'SmoothL1Loss']:
+        assert k in bgs.LOSSES, k
+    assert bgs.HEADS.get('GSBBoxHead') is bgs.HEADS.get('GSBBoxHeadWith0')
+
+
+def test_registry_error_behaviour():
+    r = Registry('thing')
+
+    @r.register_module
+    class A(object):
+        def __init__(self, x=1, y=2):
+            self.x, self.y = x, y
+
+    with pytest.raises(KeyError):
+        r.register_module(A)
+    with pytest.raises(TypeError):
+        r.register_module(3)
+    with pytest.raises(KeyError):
+        build_from_cfg(dict(type='Nope'), r)
+    a = build_from_cfg(dict(type='A', x=5), r, default_args=dict(x=7, y=9))
+    assert (a.x, a.y) == (5, 9)           # default_args never override the config
+    assert build_from_cfg(dict(type=A), r).x == 1
+
+
+def test_weight_reduce_known_answers():
+    """reference doctest mmdet/models/losses/utils.py:67-83."""
+    p, t, w = torch.tensor([0., 2, 3]), torch.tensor([1., 1, 1]), torch.tensor([1., 0, 1])
+    el = (p - t).abs()
+    assert losses.reduce_weighted(el).item() == pytest.approx(1.3333, abs=1e-4)
+    assert losses.reduce_weighted(el, w).item() == pytest.approx(1.0)
+    assert losses.reduce_weighted(el, reduction='none').tolist() == [1., 1., 2.]
+    assert losses.reduce_weighted(el, w, avg_factor=2).item() == pytest.approx(1.5)
+    with pytest.raises(ValueError):
+        losses.reduce_weighted(el, w, reduction='sum', avg_factor=2)
+
+
+def test_delta2bbox_known_answers():
+    """reference doctest mmdet/core/bbox/transforms.py:64-77."""
+    rois = torch.tensor([[0., 0., 1., 1.], [0., 0., 1., 1.], [0., 0., 1., 1.], [5., 5., 5., 5.]])
+    deltas = torch.tensor([[0., 0., 0., 0.], [1., 1., 1., 1.], [0., 0., 2., -1.],
+                           [0.7, -1.9, -0.5, 0.3]])
+    out = box_ops.delta2bbox(rois, deltas, max_shape=(32, 32))
+    exp = torch.tensor([[0.0000, 0.0000, 1.0000, 1.0000], [0.2817, 0.2817, 4.7183, 4.7183],
+                        [0.0000, 0.6321, 7.3891, 0.3679], [5.8967, 2.9251, 5.5033, 3.2749]])
+    assert torch.allclose(out, exp, atol=1e-4)
+
+
+def test_bbox2delta_roundtrip():
+    g = torch.Generator().manual_seed(0)
+    xy = torch.rand(50, 2, generator=g) * 500
+    wh = torch.rand(50, 2, generator=g) * 200 + 4
+    props = torch.cat([xy, xy + wh], 1)
+    gts = props + torch.randn(50, 4, generator=g) * 3
+    stds = (0.1, 0.1, 0.2, 0.2)
+    d = box_ops.bbox2delta(props, gts, stds=stds)
+    back = box_ops.delta2bbox(props, d, stds=stds)
+    assert torch.allclose(back, gts, atol=2e-3)
+
+
+def test_group_tables_rule_and_roundtrip(tmp_path):
+    counts = gs_tables.synthetic_instance_counts(1231, seed=0)
+    l2b, ps, split = gs_tables.build_group_tables(counts)
+    assert l2b.shape == (5, 1231) and ps.shape == (5, 2)
+    assert l2b[0, 0] == 0 and (l2b[0, 1:] == 1).all()
+    assert int(ps[:, 1].sum()) == 1231 + 5 and ps[0].tolist() == [0, 2]
+    thr = [10, 100, 1000]
+    for c in range(1, 1231):
+        b = 1 + int(np.searchsorted(thr, counts[c], side='right'))
+        assert l2b[b, c] > 0 and (np.delete(l2b[1:, c], b - 1) == 0).all()
+    # valsplit[key][k-1] == c  <=>  label2binlabel[b, c] == k   (tools/lvis_analyse.py:76-91)
+    for b, key in enumerate(gs_tables.FG_SPLIT_KEYS_5, start=1):
+        ids = split[key]
+        assert (l2b[b, ids] == np.arange(1, len(ids) + 1)).all()
+    paths = gs_tables.save_group_tables(str(tmp_path), l2b, ps, split)
+    l2b_t, ps_t, fg = gs_tables.load_group_tables(paths['label2binlabel'], paths['pred_slice'],
+                                                  paths['fg_split'])
+    assert l2b_t.dtype == torch.int64 and (l2b_t.numpy() == l2b).all()
+    assert [f.numel() for f in fg] == (ps[1:, 1] - 1).tolist()
+    col = gs_tables.class_to_column(l2b_t, ps_t)
+    assert col[0] == 0 and col.min() >= 0 and col.max() < 1236
+    assert len(set(col.tolist())) == 1231   # injective: every class has its own column
+    # 3-bin and 9-bin variants (tools/lvis_analyse.py:487-526, 564-621)
+    assert gs_tables.build_group_tables(counts, (100,))[1][:, 1].sum() == 1231 + 3
+    assert gs_tables.build_group_tables(counts, (5, 10, 50, 100, 500, 1000, 5000))[1][:, 1].sum() \
+        == 1231 + 9
+
+
+def _gs_head_cfg(tmp_path, **over):
+    counts = gs_tables.synthetic_instance_counts(1231, seed=0)
+    l2b, ps, split = gs_tables.build_group_tables(counts)
+    bcw = gs_tables.bin_class_weights(counts, l2b)
+    paths = gs_tables.save_group_tables(str(tmp_path), l2b, ps, split, bcw)
+    ce = dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)
+    cfg = dict(type='GSBBoxHeadWith0', num_fcs=2, in_channels=256, fc_out_channels=1024,
+               gs_config=dict(label2binlabel=paths['label2binlabel'],
+                              pred_slice=paths['pred_slice'], fg_split=paths['fg_split'],
+                              others_sample_ratio=8.0, loss_bg=dict(ce), num_bins=5,
+                              loss_bin=dict(ce)),
+               roi_feat_size=7, num_classes=1231, target_means=[0., 0., 0., 0.],
+               target_stds=[0.1, 0.1, 0.2, 0.2], reg_class_agnostic=False, loss_cls=dict(ce),
+               loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0))
+    cfg.update(over)
+    return bgs.config.to_config_dict(cfg), paths
+
+
+def test_gs_head_construction_and_state_dict_keys(tmp_path):
+    cfg, paths = _gs_head_cfg(tmp_path)
+    head = bgs.build_head(cfg)
+    sd = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+    # the checkpoint compatibility surface: names AND shapes
+    assert sd == {'fc_cls.weight': (1236, 1024), 'fc_cls.bias': (1236,),
+                  'fc_reg.weight': (4924, 1024), 'fc_reg.bias': (4924,),
+                  'shared_fcs.0.weight': (1024, 12544), 'shared_fcs.0.bias': (1024,),
+                  'shared_fcs.1.weight': (1024, 1024), 'shared_fcs.1.bias': (1024,)}
+    assert head.num_classes == 1231 and head.reg_class_agnostic is False
+    assert head.fp16_enabled is False and isinstance(head.fc_cls, torch.nn.Linear)
+    head.init_weights()
+    cls, reg = head(torch.randn(3, 256, 7, 7))
+    assert cls.shape == (3, 1236) and reg.shape == (3, 4924)
+    # the loss itself has no CPU path: it must refuse, not silently compute on the host
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        head.loss(cls, reg, torch.zeros(3, dtype=torch.long), torch.ones(3), torch.zeros(3, 4),
+                  torch.zeros(3, 4))
+    # class -> column table equals the table-derived one
+    col = gs_tables.class_to_column(head.label2binlabel, head.pred_slice)
+    assert torch.equal(col, head.cls2col)
+
+
+def test_gs_head_reweight_and_alias(tmp_path):
+    cfg, paths = _gs_head_cfg(tmp_path, type='GSBBoxHeadWith0Reweight')
+    cfg['gs_config']['bin_cls_weight'] = paths['bin_cls_weight']
+    head = bgs.build_head(cfg)
+    assert head.cls_weight_table.shape[0] == 4
+    with open(paths['bin_cls_weight'], 'rb') as f:
+        w = pickle.load(f)
+    assert torch.allclose(head.cls_weight_table[1, :len(w[1])], torch.tensor(w[1]).float())
+    cfg2, _ = _gs_head_cfg(tmp_path, type='GSBBoxHead')
+    assert type(bgs.build_head(cfg2)).__name__ == 'GSBBoxHeadWith0'
+    bad, _ = _gs_head_cfg(tmp_path)
+    bad['gs_config']['num_bins'] = 4
+    with pytest.raises(ValueError):
+        bgs.build_head(bad)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason='reference tree not present')
+def test_reference_config_loads_unmodified():
+    cfg = bgs.Config.fromfile(REF_CFG)
+    assert cfg.model.type == 'GroupSoftmax'
+    assert cfg.model.bbox_head.type == 'GSBBoxHeadWith0'
+    assert cfg.model.bbox_head.gs_config.num_bins == 5          # attribute access
+    assert cfg.model.bbox_head.gs_config.others_sample_ratio == 8.0
+    assert cfg.selectp == 1 and cfg.data.imgs_per_gpu == 2
+    assert cfg.train_cfg.rcnn.sampler.num == 512
+    assert cfg.optimizer_config.grad_clip.max_norm == 35

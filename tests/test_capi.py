@@ -1,0 +1,64 @@
+"""CPU: the C-ABI library loads and exports every symbol include/bgs.h declares."""
+import os
+import re
+
+import pytest
+
+from balancedgroupsoftmax_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, 'include', 'bgs.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(bgs_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    assert header_functions() == sorted(capi.SIGNATURES.keys())
+
+
+def test_library_exports_all_symbols():
+    lib = capi.load()
+    for name in header_functions():
+        assert hasattr(lib, name), name
+    assert lib.bgs_version() >= 100
+    assert lib.bgs_error_string(0) == b'ok'
+    assert b'unsupported' in lib.bgs_error_string(2)
+
+
+@pytest.mark.parametrize('variant', ['', 'nodpp'])
+def test_variant_files_present(variant):
+    from balancedgroupsoftmax_amd.csrc import build as B
+    assert os.path.exists(B.lib_path(variant)), 'run python -m balancedgroupsoftmax_amd.csrc.build --all'
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching the device."""
+    lib = capi.load()
+    assert lib.bgs_gs_loss_fwd_bwd(None, None, None, None, None, None, 4, 10, 3, 13, None, None,
+                                   None, None) == 1
+    assert lib.bgs_gs_loss_fwd_bwd(None, None, None, None, None, None, 4, 10, 99, 13, None, None,
+                                   None, None) in (1, 2)
+    assert lib.bgs_gs_merge_score(None, None, None, -1, 10, 3, 13, None, None) == 1
+    assert lib.bgs_gs_prepare(None, None, None, 0, 4, 10, 3, 8.0, 1, None, None, None, None, None) == 1
+    assert lib.bgs_bbox_smooth_l1_fwd_bwd(None, None, None, None, 4, 10, 0.0, 4.0, 1.0, None,
+                                          None, None, None) == 1
+    assert lib.bgs_gs_loss_workspace_bytes(1024, 5) >= 1024 * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(capi, '_LIB', None)
+    monkeypatch.setenv('BGS_LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(capi.BgsLibraryError):
+        capi.load()
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from balancedgroupsoftmax_amd import functional as BF
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        BF.group_softmax_loss(torch.zeros(2, 8), torch.zeros(2, dtype=torch.long),
+                              torch.zeros(2, 4, dtype=torch.long),
+                              torch.tensor([[0, 2], [2, 6]]))

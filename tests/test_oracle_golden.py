@@ -74,3 +74,19 @@ def test_reference_observed_values_cfg1():
     assert int(ps[-1].sum()) == 1236
     # every fg class lives in exactly one fg bin
     assert ((l2b[1:, 1:] > 0).sum(0) == 1).all()
+
+
+@pytest.mark.parametrize('name', ['n512_cfg1', 'n1024_cfg2', 'n256_ratio2', 'n96_3bins'])
+def test_torch_port_matches_reference_fixtures(name):
+    """The torch-CPU port timed as cpu_baseline reproduces the executed reference."""
+    import torch
+    from oracle import gs_torch_port
+    case, l2b, ps, fg_splits, cls_w, batch = case_setup(name)
+    g = golden()
+    np.random.seed(case['seed'])
+    losses, grad = gs_torch_port.gs_loss_fwd_bwd(
+        torch.from_numpy(batch['logits']), torch.from_numpy(batch['labels']),
+        torch.from_numpy(l2b), torch.from_numpy(ps), case.get('ratio', 8.0))
+    np.testing.assert_allclose(losses.numpy(), g.get(name, 'losses'), rtol=1e-6, atol=1e-6)
+    rows = g.get(name, 'grad_rows')
+    np.testing.assert_allclose(grad.numpy()[rows], g.get(name, 'grad_sub'), rtol=1e-6, atol=1e-9)
