@@ -311,6 +311,8 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
         # plain attributes in the reference (not in its state_dict) -> non-persistent buffers
         self.register_buffer('label2binlabel', l2b, persistent=False)
         self.register_buffer('pred_slice', ps, persistent=False)
+        self.pred_slice_host = ps.numpy().copy()    # static metadata: passed by value to kernels
+        self.label2binlabel_host = l2b.numpy().copy()
         self.fg_splits = fg_splits
         self.register_buffer('cls2col', self._class_columns(ps, fg_splits), persistent=False)
         self.register_buffer('bin_loss_weight', torch.tensor(
@@ -351,30 +353,32 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
         return w
 
     def _remap_labels(self, labels):
-        """Bin labels are implied by the table gather inside the kernels; this returns the
-        per-bin sample weights ``[B, N]`` and avg factors ``[B]`` as device tensors
-        (gs_bbox_head_with0.py:91-112 returned Python lists + floats via .item())."""
+        """gs_bbox_head_with0.py:91-112 returned Python lists + floats via .item(); here the
+        three results are device tensors: bin labels ``[B, N]`` i32, sample weights ``[B, N]``
+        f32 and avg factors ``[B]`` f32."""
         if self.sampler == 'device':
             return BF.gs_prepare(labels, self.label2binlabel, self.others_sample_ratio,
                                  cls_weight=self.cls_weight_table)
         if self.sampler != 'numpy':
             raise ValueError('gs_config.sampler must be "device" or "numpy"')
-        l2b = self.label2binlabel.cpu().numpy()
+        l2b = self.label2binlabel_host
         lab = labels.detach().cpu().numpy()
         B = l2b.shape[0]
+        bl = l2b[:, lab]
         w = np.ones((B, lab.shape[0]), dtype=np.float64)
         for i in range(1, B):
             cw = None if self.cls_weights is None else self.cls_weights[i - 1]
-            w[i] = self._sample_others_numpy(l2b[i][lab], cw)
+            w[i] = self._sample_others_numpy(bl[i], cw)
         avg = np.maximum(w.sum(axis=1).astype(np.float32), np.float32(1.0))
         dev = labels.device
-        return (torch.from_numpy(w.astype(np.float32)).to(dev),
+        return (torch.from_numpy(np.ascontiguousarray(bl, dtype=np.int32)).to(dev),
+                torch.from_numpy(w.astype(np.float32)).to(dev),
                 torch.from_numpy(avg.astype(np.float32)).to(dev))
 
     def _slice_preds(self, cls_score):
         """Column views per bin (gs_bbox_head_with0.py:134-145); not used by ``loss`` (the
         kernel reads ``pred_slice`` itself) but kept for API parity / debugging."""
-        ps = self.pred_slice.tolist()
+        ps = self.pred_slice_host.tolist()
         return [cls_score.narrow(1, s, n) for s, n in ps]
 
     @force_fp32(apply_to=('cls_score', 'bbox_pred'))
@@ -388,9 +392,9 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
                                       'kernel (no detector on the BAGS path requests it)')
         losses = dict()
         if cls_score is not None:
-            weights, avg = self._remap_labels(labels)
-            per_bin = BF.group_softmax_loss(cls_score, labels, self.label2binlabel,
-                                            self.pred_slice, weights, avg)
+            bin_labels, weights, avg = self._remap_labels(labels)
+            per_bin = BF.group_softmax_loss(cls_score, bin_labels, self.pred_slice_host,
+                                            weights, avg)
             per_bin = per_bin * self.bin_loss_weight
             for i in range(self.num_bins):
                 losses['loss_cls_bin{}'.format(i)] = per_bin[i]
@@ -402,7 +406,7 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
     @force_fp32(apply_to=('cls_score', ))
     def _merge_score(self, cls_score):
         """gs_bbox_head_with0.py:239-273, one HIP launch."""
-        return BF.gs_merge_score(cls_score, self.pred_slice, self.cls2col, self.num_classes)
+        return BF.gs_merge_score(cls_score, self.pred_slice_host, self.cls2col, self.num_classes)
 
     def _scores(self, cls_score):
         return self._merge_score(cls_score)

@@ -36,8 +36,8 @@ SIGNATURES = {
                                       ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                       ctypes.c_uint64, c_ptr, c_i64p, c_f32p, c_f32p, c_ptr]),
     'bgs_gs_loss_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
-    'bgs_gs_loss_fwd_bwd': (ctypes.c_int, [c_f32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p,
-                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+    'bgs_gs_loss_fwd_bwd': (ctypes.c_int, [c_f32p, c_ptr, c_i64p, c_f32p, c_f32p,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            c_f32p, c_f32p, c_ptr, c_ptr]),
     'bgs_gs_loss_reduce': (ctypes.c_int, [c_ptr, ctypes.c_int, ctypes.c_int, c_f32p, c_ptr]),
     'bgs_gs_scale_grad': (ctypes.c_int, [c_f32p, c_i64p, c_f32p, ctypes.c_int, ctypes.c_int,
@@ -92,6 +92,13 @@ def load():
 def check(fn_name, code):
     if code != BGS_OK:
         raise BgsCallError(fn_name, code, load().bgs_error_string(code).decode())
+
+
+def host_i64(a):
+    """Host int64 array (numpy, contiguous) -> pointer for ``host_*`` parameters."""
+    import numpy as np
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
 
 
 def ptr(t):

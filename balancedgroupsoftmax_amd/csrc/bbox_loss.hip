@@ -19,6 +19,8 @@
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int kBlock = 256;
 constexpr int kMaxGrid = 4096;
 
@@ -48,20 +50,20 @@ __global__ __launch_bounds__(kBlock) void bbox_sl1_kernel(
     // slot of this row's positive class (agnostic regression: slot 0)
     const int64_t slot = (R == 1) ? 0 : y;
     const bool pos = (y > 0) && (slot < R);
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
     if (pos && (!WRITE_GRAD || c == (int)slot)) {
-      const float4 p =
-          *reinterpret_cast<const float4*>(bbox_pred + ((size_t)r * R + (size_t)slot) * 4);
-      const float4 t = *reinterpret_cast<const float4*>(targets + (size_t)r * 4);
-      const float4 w = *reinterpret_cast<const float4*>(bweights + (size_t)r * 4);
+      const f32x4 p =
+          *reinterpret_cast<const f32x4*>(bbox_pred + ((size_t)r * R + (size_t)slot) * 4);
+      const f32x4 t = *reinterpret_cast<const f32x4*>(targets + (size_t)r * 4);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(bweights + (size_t)r * 4);
       float gx, gy, gz, gw;
       acc += sl1(p.x - t.x, beta, gx) * w.x;
       acc += sl1(p.y - t.y, beta, gy) * w.y;
       acc += sl1(p.z - t.z, beta, gz) * w.z;
       acc += sl1(p.w - t.w, beta, gw) * w.w;
-      g = make_float4(gx * w.x * scale, gy * w.y * scale, gz * w.z * scale, gw * w.w * scale);
+      g = f32x4{gx * w.x * scale, gy * w.y * scale, gz * w.z * scale, gw * w.w * scale};
     }
-    if (WRITE_GRAD) *reinterpret_cast<float4*>(dpred + i * 4) = g;
+    if (WRITE_GRAD) *reinterpret_cast<f32x4*>(dpred + i * 4) = g;
   }
   // block reduce (fixed order) -> partial[blockIdx.x]
   __shared__ float sm[kBlock / BGS_WAVE];

@@ -88,31 +88,39 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // Wave-uniform value -> SGPR (lets the compiler use scalar loads / uniform branches).
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Native clang vectors: a 16-byte access is ONE global_load/store_dwordx4 or ds_read/write_b128
+// (HIP's float4 struct assigns member-wise and its stores were split into 4 dword stores).
 template <int VEC>
 struct VecT;
 template <>
-struct VecT<4> { using type = float4; };
+struct VecT<4> { typedef float type __attribute__((ext_vector_type(4))); };
 template <>
-struct VecT<2> { using type = float2; };
+struct VecT<2> { typedef float type __attribute__((ext_vector_type(2))); };
 template <>
-struct VecT<1> { using type = float; };
+struct VecT<1> { typedef float type; };
 
 template <int VEC>
 __device__ __forceinline__ void load_vec(const float* p, float (&out)[VEC]) {
   using V = typename VecT<VEC>::type;
-  V v = *reinterpret_cast<const V*>(p);
-  const float* f = reinterpret_cast<const float*>(&v);
+  const V v = *reinterpret_cast<const V*>(p);
+  if constexpr (VEC == 1) {
+    out[0] = v;
+  } else {
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) out[j] = f[j];
+    for (int j = 0; j < VEC; ++j) out[j] = v[j];
+  }
 }
 
 template <int VEC>
 __device__ __forceinline__ void store_vec(float* p, const float (&in)[VEC]) {
   using V = typename VecT<VEC>::type;
   V v;
-  float* f = reinterpret_cast<float*>(&v);
+  if constexpr (VEC == 1) {
+    v = in[0];
+  } else {
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) f[j] = in[j];
+    for (int j = 0; j < VEC; ++j) v[j] = in[j];
+  }
   *reinterpret_cast<V*>(p) = v;
 }
 

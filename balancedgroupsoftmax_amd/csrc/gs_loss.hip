@@ -9,16 +9,23 @@
 // and the autograd backward of the above (B x {log_softmax, nll, mul, sum, div} kernels
 // forward + the same backward in the reference).
 //
-// Mapping (HBM-bound streaming op, 9.9 KB algorithmic traffic per RoI): see gs_rowblock.h —
-//   one workgroup per RoI row (grid-stride), 16-byte coalesced loads/stores, the row is
-//   read ONCE and its gradient row written ONCE (no atomics: every column has one owner
-//   bin); per-bin max / sum-exp by masked DPP wave reductions + one LDS hop; per-workgroup
-//   partial losses are reduced in a fixed order by a second tiny kernel (reproducible).
+// Mapping (HBM-bound streaming op, 9.9 KB algorithmic traffic per RoI): see gs_rowwave.h —
+//   one 4-wave workgroup per RoI row (grid-stride over rows); the row is read ONCE (16-byte
+//   coalesced loads -> LDS) and its gradient row written ONCE (LDS -> 16-byte coalesced
+//   stores; no atomics: every column has one owner bin); each bin is swept by one wave with
+//   bin-aligned lane indexing so that max / sum / target / weight are wave-uniform scalars and
+//   the reductions are DPP wave all-reduces; the bins of a row run concurrently on the 4 waves.
+//   * bin geometry arrives by value in the kernarg segment and the bin labels were gathered
+//     by the prepare kernel: the only memory round trip before the math is the row load;
+//   * (row, bin) pairs with zero sample weight skip the softmax entirely (wave-uniform);
+//   * the loss term of a (row, bin) needs no extra global load (target logit read from LDS).
+// Per-workgroup partial losses are reduced in a fixed order by a second tiny kernel
+// (bitwise reproducible, no atomics).
 #include <math.h>
 #include <stdlib.h>
 
 #include "bgs_common.h"
-#include "gs_rowblock.h"
+#include "gs_rowwave.h"
 
 namespace {
 
@@ -26,96 +33,64 @@ constexpr int kBlock = 256;   // generic fallback + helper kernels
 constexpr int kWaves = kBlock / BGS_WAVE;
 constexpr int kMaxGrid = 2048;
 
-template <int VEC, int KPT, bool WRITE_GRAD>
-__global__ __launch_bounds__(1024) void gs_loss_rowblock_kernel(
-    const float* __restrict__ logits, const int64_t* __restrict__ labels,
-    const int64_t* __restrict__ l2b, const int64_t* __restrict__ pslice,
-    const float* __restrict__ weights, const float* __restrict__ avg, int N, int C, int B,
-    int W, int nchunks, float* __restrict__ partial, float* __restrict__ dlogits) {
-  __shared__ bgs::RowShared sh;
-  bgs::RowLanes<VEC, KPT> L;
-  bgs::init_row_lanes<VEC, KPT>(L, sh, pslice, B, W, nchunks);
+template <int VEC, bool WRITE_GRAD>
+__global__ __launch_bounds__(kBlock) void gs_loss_rowwave_kernel(
+    const float* __restrict__ logits, const int32_t* __restrict__ bin_labels,
+    const float* __restrict__ weights, const float* __restrict__ avg, bgs::BinGeom geom, int N,
+    int B, int W, int wpad, float* __restrict__ partial, float* __restrict__ dlogits) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][wpad] double-buffered row
+                                                                // (+ read slack, see launcher)
   const int tid = threadIdx.x;
-  const int nw = blockDim.x >> 6;
+  const int lane = tid & 63;
+  const int wave = bgs::uniform(tid >> 6);
 
-  // thread b < B owns the scalar bookkeeping of bin b
-  int my_s = 0, my_n = 0;
+  // lane b < B of every wave keeps the per-bin constants / per-row scalars of bin b
   float my_inv_avg = 0.f;
-  if (tid < B) {
-    bgs::bin_range(pslice, tid, W, my_s, my_n);
-    const float a = avg ? avg[tid] : fmaxf((float)N, 1.f);
-    my_inv_avg = 1.f / a;
-  }
-  float acc = 0.f;
+  if (lane < B) my_inv_avg = 1.f / (avg ? avg[lane] : fmaxf((float)N, 1.f));
+  float lacc = 0.f;  // wave (b % kWaves), lane b accumulates the loss of bin b
+
   int par = 0;
   for (int r = blockIdx.x; r < N; r += gridDim.x, par ^= 1) {
-    const float* zr = logits + (size_t)r * W;
-    float v[KPT][VEC];
-    bgs::load_row<VEC, KPT>(L, zr, v);
-
-    float my_coef = 0.f, my_zt = 0.f;
-    if (tid < B) {
-      int t = -1;
-      if (my_n > 0) {
-        int64_t y = labels[r];
-        y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
-        int bl = (int)l2b[(size_t)tid * C + y];
-        bl = min(max(bl, 0), my_n - 1);
-        t = my_s + bl;
-        const float w = weights ? weights[(size_t)tid * N + r] : 1.f;
-        my_coef = w * my_inv_avg;
-        my_zt = zr[t];
+    float* row = smem + (size_t)par * wpad;
+    bgs::stage_row<VEC>(logits + (size_t)r * W, row, W, tid, kBlock);
+    int my_bl = 0;
+    float my_coef = 0.f;
+    if (lane < B) {
+      my_bl = bin_labels[(size_t)lane * N + r];
+      const float w = weights ? weights[(size_t)lane * N + r] : 1.f;
+      my_coef = w * my_inv_avg;
+    }
+    __syncthreads();
+    for (int b = wave; b < B; b += kWaves) {  // bins are independent: one wave each
+      const int s = geom.start[b], n = geom.len[b];
+      const float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_coef), b));
+      const int tgt = min(max(__builtin_amdgcn_readlane(my_bl, b), 0), n - 1);
+      float* seg = row + s;
+      if (coef == 0.f) {  // wave-uniform: this (row, bin) carries no weight -> zero gradient
+        if (WRITE_GRAD)
+          for (int j = lane; j < n; j += BGS_WAVE) seg[j] = 0.f;
+        continue;
       }
-      sh.tgt[par][tid] = t;
-      sh.coef[par][tid] = my_coef;
+      float term;
+      if (n <= BGS_WAVE * bgs::kSweep) {  // wave-uniform; true for every shipped table
+        term = bgs::bin_loss_registers<WRITE_GRAD>(seg, n, lane, coef, tgt);
+      } else {
+        const float zt = seg[tgt];  // target logit, read before the in-place exp
+        float m, S;
+        bgs::bin_softmax_inplace(seg, n, lane, m, S);
+        term = coef * ((m + logf(S)) - zt);
+        if (WRITE_GRAD) bgs::bin_grad_inplace(seg, n, lane, coef / S, coef, tgt);
+      }
+      if (lane == b) lacc += term;
     }
-
-    bgs::bin_max_pass<VEC, KPT>(L, sh, B, v);
-    __syncthreads();
-    // red_max of this row may be overwritten by a faster wave right after the next barrier:
-    // the bin owner reads it now.
-    const float my_m = (tid < B) ? bgs::lookup_max(sh, tid, nw) : 0.f;
-    float e[KPT][VEC];
-    bgs::bin_exp_sum_pass<VEC, KPT>(L, sh, B, nw, v, e);
-    __syncthreads();
-
-    if (tid < B && my_coef != 0.f) {
-      const float S = bgs::lookup_sum(sh, tid, nw);
-      acc += my_coef * ((my_m + logf(S)) - my_zt);
-    }
-
     if (WRITE_GRAD) {
-      float* gr = dlogits + (size_t)r * W;
-#pragma unroll
-      for (int q = 0; q < KPT; ++q) {
-        if (!L.valid[q]) continue;
-        float g[VEC];
-        const int b0 = L.binid[q][0];
-        float invS0 = 0.f, coef0 = 0.f;
-        int tgt0 = -1;
-        if (b0 >= 0) {
-          invS0 = 1.f / bgs::lookup_sum(sh, b0, nw);
-          coef0 = sh.coef[par][b0];
-          tgt0 = sh.tgt[par][b0];
-        }
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          const int b = L.binid[q][j];
-          float invS = invS0, coef = coef0;
-          int tgt = tgt0;
-          if (b != b0 && b >= 0) {  // chunk straddles a bin boundary
-            invS = 1.f / bgs::lookup_sum(sh, b, nw);
-            coef = sh.coef[par][b];
-            tgt = sh.tgt[par][b];
-          }
-          const int col = L.col0[q] + j;
-          g[j] = b >= 0 ? coef * (e[q][j] * invS - (col == tgt ? 1.f : 0.f)) : 0.f;
-        }
-        bgs::store_vec<VEC>(gr + L.col0[q], g);
-      }
+      __syncthreads();
+      bgs::unstage_row<VEC>(row, dlogits + (size_t)r * W, W, tid, kBlock);
     }
   }
-  if (tid < B) partial[(size_t)blockIdx.x * B + tid] = acc;
+  // bin b lives in wave b % kWaves, lane b: no cross-wave reduction needed
+  if (lane < B && (lane % kWaves) == wave)
+    partial[(size_t)lane * gridDim.x + blockIdx.x] = lacc;
 }
 
 __device__ __forceinline__ float block_max(float v, float* sm) {
@@ -143,10 +118,9 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
 // cross-check of the register-resident kernel in the GPU tests.
 template <bool WRITE_GRAD>
 __global__ __launch_bounds__(kBlock) void gs_loss_generic_kernel(
-    const float* __restrict__ logits, const int64_t* __restrict__ labels,
-    const int64_t* __restrict__ l2b, const int64_t* __restrict__ pslice,
-    const float* __restrict__ weights, const float* __restrict__ avg, int N, int C, int B,
-    int W, float* __restrict__ partial, float* __restrict__ dlogits) {
+    const float* __restrict__ logits, const int32_t* __restrict__ bin_labels,
+    const float* __restrict__ weights, const float* __restrict__ avg, bgs::BinGeom geom, int N,
+    int B, int W, float* __restrict__ partial, float* __restrict__ dlogits) {
   __shared__ float sm[kWaves];
   __shared__ float acc[BGS_MAX_BINS];
   const int tid = threadIdx.x;
@@ -159,19 +133,14 @@ __global__ __launch_bounds__(kBlock) void gs_loss_generic_kernel(
       for (int j = tid; j < W; j += kBlock) gr[j] = 0.f;
       __syncthreads();
     }
-    int64_t y = labels[r];
-    y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
     for (int b = 0; b < B; ++b) {
-      int s = (int)pslice[2 * b], n = (int)pslice[2 * b + 1];
-      s = min(max(s, 0), W);
-      n = min(max(n, 0), W - s);
+      const int s = geom.start[b], n = geom.len[b];  // validated on the host
       if (n == 0) continue;
       const float a = avg ? avg[b] : fmaxf((float)N, 1.f);
       const float w = weights ? weights[(size_t)b * N + r] : 1.f;
       const float coef = w * (1.f / a);
       if (coef == 0.f) continue;  // block-uniform
-      int bl = (int)l2b[(size_t)b * C + y];
-      bl = min(max(bl, 0), n - 1);
+      const int bl = min(max(bin_labels[(size_t)b * N + r], 0), n - 1);
       float pm = -INFINITY;
       for (int j = tid; j < n; j += kBlock) pm = fmaxf(pm, zr[s + j]);
       const float m = block_max(pm, sm);
@@ -188,26 +157,44 @@ __global__ __launch_bounds__(kBlock) void gs_loss_generic_kernel(
     __syncthreads();
   }
   __syncthreads();
-  if (tid < B) partial[(size_t)blockIdx.x * B + tid] = acc[tid];
+  if (tid < B) partial[(size_t)tid * gridDim.x + blockIdx.x] = acc[tid];
 }
 
-// loss[b] = sum_g partial[g, b] in a fixed order (wave w handles bins w, w+4, ...).
-__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __restrict__ partial,
-                                                                 int G, int B,
-                                                                 float* __restrict__ out,
-                                                                 float scale) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int b = wave; b < B; b += kWaves) {
+// loss[b] = sum_g partial[b, g] in a fixed order.  1024 threads: all loads of a bin are issued
+// at once (one memory round trip per bin, the bins' loads overlap), then wave + LDS reduction.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial,
+                                                               int G, int B,
+                                                               float* __restrict__ out,
+                                                               float scale) {
+  __shared__ float sm[BGS_MAX_BINS][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float acc[BGS_MAX_BINS];
+#pragma unroll
+  for (int b = 0; b < BGS_MAX_BINS; ++b) {
+    acc[b] = 0.f;
+    if (b < B) {
+      for (int g = tid; g < G; g += 1024) acc[b] += partial[(size_t)b * G + g];
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < BGS_MAX_BINS; ++b) {
+    if (b < B) {
+      const float s = bgs::wave_sum(acc[b]);
+      if (lane == 0) sm[b][wave] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < B) {
     float s = 0.f;
-    for (int g = lane; g < G; g += BGS_WAVE) s += partial[(size_t)g * B + b];
-    s = bgs::wave_sum(s);
-    if (lane == 0) out[b] = s * scale;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += sm[tid][w];
+    out[tid] = s * scale;
   }
 }
 
 // dlogits[:, bin b] *= g[b]; early-out when every g[b] == 1 (the plain Faster R-CNN case).
 __global__ __launch_bounds__(kBlock) void gs_scale_grad_kernel(float* __restrict__ dlogits,
-                                                               const int64_t* __restrict__ pslice,
+                                                               bgs::BinGeom geom,
                                                                const float* __restrict__ g, int N,
                                                                int B, int W) {
   bool all_one = true;
@@ -217,8 +204,7 @@ __global__ __launch_bounds__(kBlock) void gs_scale_grad_kernel(float* __restrict
   for (int c = threadIdx.x; c < W; c += kBlock) {
     float sc = 0.f;
     for (int b = 0; b < B; ++b) {
-      const int s = (int)pslice[2 * b], n = (int)pslice[2 * b + 1];
-      if (c >= s && c < s + n) sc = g[b];
+      if (c >= geom.start[b] && c < geom.start[b] + geom.len[b]) sc = g[b];
     }
     scale[c] = sc;
   }
@@ -231,18 +217,23 @@ __global__ __launch_bounds__(kBlock) void gs_scale_grad_kernel(float* __restrict
   }
 }
 
-template <int VEC, int KPT>
-void launch_rowblock(bool grad, int grid, int block, hipStream_t st, const float* logits,
-                     const int64_t* labels, const int64_t* l2b, const int64_t* ps, const float* w,
-                     const float* avg, int N, int C, int B, int W, int nchunks, float* partial,
-                     float* dlogits) {
+template <int VEC>
+void launch_rowwave(bool grad, int grid, hipStream_t st, const float* logits, const int32_t* bl,
+                    const float* w, const float* avg, const bgs::BinGeom& geom, int N, int B,
+                    int W, float* partial, float* dlogits) {
+  const int wpad = (W + 3) & ~3;
+  // + slack: the register sweep reads up to 64*kSweep floats from a bin's start
+  const size_t lds = sizeof(float) * (2 * (size_t)wpad + BGS_WAVE * bgs::kSweep);
   if (grad)
-    hipLaunchKernelGGL((gs_loss_rowblock_kernel<VEC, KPT, true>), dim3(grid), dim3(block), 0, st,
-                       logits, labels, l2b, ps, w, avg, N, C, B, W, nchunks, partial, dlogits);
+    hipLaunchKernelGGL((gs_loss_rowwave_kernel<VEC, true>), dim3(grid), dim3(kBlock), lds, st,
+                       logits, bl, w, avg, geom, N, B, W, wpad, partial, dlogits);
   else
-    hipLaunchKernelGGL((gs_loss_rowblock_kernel<VEC, KPT, false>), dim3(grid), dim3(block), 0, st,
-                       logits, labels, l2b, ps, w, avg, N, C, B, W, nchunks, partial, dlogits);
+    hipLaunchKernelGGL((gs_loss_rowwave_kernel<VEC, false>), dim3(grid), dim3(kBlock), lds, st,
+                       logits, bl, w, avg, geom, N, B, W, wpad, partial, dlogits);
 }
+
+// one workgroup per row; at most kMaxGrid workgroups (grid-stride beyond)
+inline int loss_grid(int N) { return N <= 0 ? 1 : (N < kMaxGrid ? N : kMaxGrid); }
 
 }  // namespace
 
@@ -258,19 +249,22 @@ static bool force_generic() {
   return e && e[0] == '1';
 }
 
-extern "C" int bgs_gs_loss_fwd_bwd(const float* logits, const int64_t* labels,
-                                   const int64_t* label2binlabel, const int64_t* pred_slice,
-                                   const float* weights, const float* avg, int N, int C, int B,
-                                   int W, float* loss_out, float* dlogits, void* workspace,
-                                   bgs_stream_t stream) {
-  if (N < 0 || C <= 0 || B <= 0 || W <= 0) return BGS_ERR_INVALID_ARG;
+extern "C" int bgs_gs_loss_fwd_bwd(const float* logits, const int32_t* bin_labels,
+                                   const int64_t* host_pred_slice, const float* weights,
+                                   const float* avg, int N, int B, int W, float* loss_out,
+                                   float* dlogits, void* workspace, bgs_stream_t stream) {
+  if (N < 0 || B <= 0 || W <= 0) return BGS_ERR_INVALID_ARG;
   if (B > BGS_MAX_BINS) return BGS_ERR_UNSUPPORTED;
-  if (!workspace || !pred_slice) return BGS_ERR_INVALID_ARG;
-  if (N > 0 && (!logits || !labels || !label2binlabel)) return BGS_ERR_INVALID_ARG;
+  if (!workspace || !host_pred_slice) return BGS_ERR_INVALID_ARG;
+  if (N > 0 && (!logits || !bin_labels)) return BGS_ERR_INVALID_ARG;
+  bgs::BinGeom geom;
+  int tiles = 0;
+  const int rc = bgs::make_bin_geom(host_pred_slice, B, W, &geom, &tiles);
+  if (rc != BGS_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
   const bool grad = dlogits != nullptr;
-  int grid = 1;
+  const int grid = loss_grid(N);
   if (N == 0) {
     (void)hipMemsetAsync(partial, 0, sizeof(float) * B, st);
   } else {
@@ -278,41 +272,25 @@ extern "C" int bgs_gs_loss_fwd_bwd(const float* logits, const int64_t* labels,
     int vec = 1;
     if (W % 4 == 0 && al % 16 == 0) vec = 4;
     else if (W % 2 == 0 && al % 8 == 0) vec = 2;
-    const int nchunks = W / vec;
-    int kpt = 1;
-    int block = ((nchunks + 63) / 64) * 64;
-    if (block > 1024) {
-      kpt = 2;
-      block = (((nchunks + 1) / 2 + 63) / 64) * 64;
-    }
-    if (!force_generic() && block <= 1024) {
-      grid = N < kMaxGrid ? N : kMaxGrid;
-#define BGS_GS_LAUNCH(V, K)                                                                    \
-  launch_rowblock<V, K>(grad, grid, block, st, logits, labels, label2binlabel, pred_slice,     \
-                        weights, avg, N, C, B, W, nchunks, partial, dlogits)
-      if (vec == 4 && kpt == 1) BGS_GS_LAUNCH(4, 1);
-      else if (vec == 4) BGS_GS_LAUNCH(4, 2);
-      else if (vec == 2 && kpt == 1) BGS_GS_LAUNCH(2, 1);
-      else if (vec == 2) BGS_GS_LAUNCH(2, 2);
-      else if (kpt == 1) BGS_GS_LAUNCH(1, 1);
-      else BGS_GS_LAUNCH(1, 2);
-#undef BGS_GS_LAUNCH
+    // wave kernel: bins must tile [0, W) (true for tables built by tools/lvis_analyse.py) and
+    // two staged rows must fit the 64 KB default LDS window
+    if (!force_generic() && tiles && W <= 7936) {
+      if (vec == 4) launch_rowwave<4>(grad, grid, st, logits, bin_labels, weights, avg, geom, N, B, W, partial, dlogits);
+      else if (vec == 2) launch_rowwave<2>(grad, grid, st, logits, bin_labels, weights, avg, geom, N, B, W, partial, dlogits);
+      else launch_rowwave<1>(grad, grid, st, logits, bin_labels, weights, avg, geom, N, B, W, partial, dlogits);
     } else {
-      grid = N < kMaxGrid ? N : kMaxGrid;
       if (grad)
         hipLaunchKernelGGL((gs_loss_generic_kernel<true>), dim3(grid), dim3(kBlock), 0, st, logits,
-                           labels, label2binlabel, pred_slice, weights, avg, N, C, B, W, partial,
-                           dlogits);
+                           bin_labels, weights, avg, geom, N, B, W, partial, dlogits);
       else
         hipLaunchKernelGGL((gs_loss_generic_kernel<false>), dim3(grid), dim3(kBlock), 0, st,
-                           logits, labels, label2binlabel, pred_slice, weights, avg, N, C, B, W,
-                           partial, dlogits);
+                           logits, bin_labels, weights, avg, geom, N, B, W, partial, dlogits);
     }
   }
   // loss_out == NULL: leave the per-workgroup partials in the workspace (bgs_gs_loss_reduce
   // finishes the job) — lets a profiler time the streaming kernel on its own.
   if (loss_out)
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, st, partial, grid, B,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, st, partial, grid, B,
                        loss_out, 1.0f);
   BGS_RETURN_LAUNCH_STATUS();
 }
@@ -320,22 +298,23 @@ extern "C" int bgs_gs_loss_fwd_bwd(const float* logits, const int64_t* labels,
 extern "C" int bgs_gs_loss_reduce(const void* workspace, int N, int B, float* loss_out,
                                   bgs_stream_t stream) {
   if (N < 0 || B <= 0 || B > BGS_MAX_BINS || !workspace || !loss_out) return BGS_ERR_INVALID_ARG;
-  const int grid = N == 0 ? 1 : (N < kMaxGrid ? N : kMaxGrid);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
-                     (const float*)workspace, grid, B, loss_out, 1.0f);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream,
+                     (const float*)workspace, loss_grid(N), B, loss_out, 1.0f);
   BGS_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int bgs_gs_scale_grad(float* dlogits, const int64_t* pred_slice, const float* g, int N,
-                                 int B, int W, bgs_stream_t stream) {
+extern "C" int bgs_gs_scale_grad(float* dlogits, const int64_t* host_pred_slice, const float* g,
+                                 int N, int B, int W, bgs_stream_t stream) {
   if (N < 0 || B <= 0 || W <= 0 || B > BGS_MAX_BINS) return BGS_ERR_INVALID_ARG;
   if (N == 0) return BGS_OK;
-  if (!dlogits || !pred_slice || !g) return BGS_ERR_INVALID_ARG;
+  if (!dlogits || !host_pred_slice || !g) return BGS_ERR_INVALID_ARG;
+  bgs::BinGeom geom;
+  const int rc = bgs::make_bin_geom(host_pred_slice, B, W, &geom, nullptr);
+  if (rc != BGS_OK) return rc;
   const size_t total = (size_t)N * W;
   size_t blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(gs_scale_grad_kernel, dim3((unsigned)blocks), dim3(kBlock),
-                     sizeof(float) * (size_t)W, (hipStream_t)stream, dlogits, pred_slice, g, N, B,
-                     W);
+                     sizeof(float) * (size_t)W, (hipStream_t)stream, dlogits, geom, g, N, B, W);
   BGS_RETURN_LAUNCH_STATUS();
 }

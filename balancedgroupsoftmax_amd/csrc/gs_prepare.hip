@@ -52,7 +52,7 @@ __device__ __forceinline__ double block_sum_d(double v, double* sm) {
 __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
     const int64_t* __restrict__ labels, const int64_t* __restrict__ l2b,
     const float* __restrict__ cls_weight, int cw_stride, int N, int C, int B, double ratio,
-    uint64_t seed, const uint64_t* __restrict__ seed_offset, int64_t* __restrict__ bl_out,
+    uint64_t seed, const uint64_t* __restrict__ seed_offset, int32_t* __restrict__ bl_out,
     float* __restrict__ w_out, float* __restrict__ avg_out) {
   __shared__ PrepShared sh;
   const int b = blockIdx.x;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
     int64_t y = labels[r];
     y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
     const int64_t bl = map[y];
-    if (bl_out) bl_out[(size_t)b * N + r] = bl;
+    if (bl_out) bl_out[(size_t)b * N + r] = (int32_t)bl;
     nfg_local += (bl > 0) ? 1 : 0;
   }
   const int n_fg = block_sum_i(nfg_local, sh.wsum_i);
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
 extern "C" int bgs_gs_prepare(const int64_t* labels, const int64_t* label2binlabel,
                               const float* cls_weight, int cls_weight_stride, int N, int C, int B,
                               double others_sample_ratio, uint64_t seed,
-                              const uint64_t* seed_offset, int64_t* bin_labels_out,
+                              const uint64_t* seed_offset, int32_t* bin_labels_out,
                               float* weights_out, float* avg_out, bgs_stream_t stream) {
   if (N < 0 || C <= 0 || B <= 0) return BGS_ERR_INVALID_ARG;
   if (B > BGS_MAX_BINS) return BGS_ERR_UNSUPPORTED;

@@ -43,9 +43,9 @@ _seed_counter = itertools.count(1)
 
 
 def gs_prepare(labels, label2binlabel, others_sample_ratio, seed=None, cls_weight=None,
-               return_bin_labels=False, seed_offset=None):
-    """Device-side ``_remap_labels``: returns ``weights [B,N] f32``, ``avg [B] f32``
-    (and ``bin_labels [B,N] i64`` when asked).  No host sync.
+               seed_offset=None):
+    """Device-side ``_remap_labels``: returns ``bin_labels [B,N] i32`` (the
+    ``label2binlabel[b][labels]`` gather), ``weights [B,N] f32``, ``avg [B] f32``.  No host sync.
 
     ``seed``: draw identifier of the counter-based RNG; ``None`` takes the next value of
     a process-wide counter mixed with ``torch.initial_seed()`` (reproducible runs).
@@ -63,7 +63,7 @@ def gs_prepare(labels, label2binlabel, others_sample_ratio, seed=None, cls_weigh
         seed = (torch.initial_seed() * 0x9E3779B1 + next(_seed_counter)) & 0xFFFFFFFFFFFFFFFF
     weights = torch.empty((B, N), dtype=torch.float32, device=dev)
     avg = torch.empty((B,), dtype=torch.float32, device=dev)
-    bl = torch.empty((B, N), dtype=torch.int64, device=dev) if return_bin_labels else None
+    bl = torch.empty((B, N), dtype=torch.int32, device=dev)
     cw_stride = 0
     if cls_weight is not None:
         assert cls_weight.dtype == torch.float32 and cls_weight.dim() == 2
@@ -74,26 +74,24 @@ def gs_prepare(labels, label2binlabel, others_sample_ratio, seed=None, cls_weigh
                             capi.ptr(seed_offset), capi.ptr(bl), capi.ptr(weights), capi.ptr(avg),
                             capi.current_stream(dev))
     capi.check('bgs_gs_prepare', rc)
-    if return_bin_labels:
-        return weights, avg, bl
-    return weights, avg
+    return bl, weights, avg
 
 
 # ----------------------------------------------------------------------------------------
 # fused group-softmax loss  (GSBBoxHeadWith0.loss classification part, :160-171)
 # ----------------------------------------------------------------------------------------
-def _gs_loss_launch(logits, labels, l2b, pred_slice, weights, avg, want_grad):
+def _gs_loss_launch(logits, bin_labels, pred_slice_host, weights, avg, want_grad):
     lib = capi.load()
     N, W = logits.shape
-    B, C = l2b.shape
+    B = bin_labels.shape[0]
     dev = logits.device
     loss = torch.empty((B,), dtype=torch.float32, device=dev)
     dlogits = torch.empty_like(logits) if want_grad else None
     ws = _workspace(lib.bgs_gs_loss_workspace_bytes(N, B), dev)
-    rc = lib.bgs_gs_loss_fwd_bwd(capi.ptr(logits), capi.ptr(labels), capi.ptr(l2b),
-                                 capi.ptr(pred_slice), capi.ptr(weights), capi.ptr(avg),
-                                 N, C, B, W, capi.ptr(loss), capi.ptr(dlogits), capi.ptr(ws),
-                                 capi.current_stream(dev))
+    ps_keep, ps_ptr = capi.host_i64(pred_slice_host)
+    rc = lib.bgs_gs_loss_fwd_bwd(capi.ptr(logits), capi.ptr(bin_labels), ps_ptr,
+                                 capi.ptr(weights), capi.ptr(avg), N, B, W, capi.ptr(loss),
+                                 capi.ptr(dlogits), capi.ptr(ws), capi.current_stream(dev))
     capi.check('bgs_gs_loss_fwd_bwd', rc)
     return loss, dlogits
 
@@ -103,12 +101,12 @@ class _GroupSoftmaxLoss(torch.autograd.Function):
     launch and only rescaled by the upstream scalars in backward (early-out when they are 1)."""
 
     @staticmethod
-    def forward(ctx, logits, labels, l2b, pred_slice, weights, avg):
+    def forward(ctx, logits, bin_labels, pred_slice_host, weights, avg):
         want_grad = logits.requires_grad
         z = _f32c(logits)
-        loss, dlogits = _gs_loss_launch(z, labels, l2b, pred_slice, weights, avg, want_grad)
+        loss, dlogits = _gs_loss_launch(z, bin_labels, pred_slice_host, weights, avg, want_grad)
         ctx.dlogits = dlogits
-        ctx.pred_slice = pred_slice
+        ctx.pred_slice_host = pred_slice_host
         ctx.in_dtype = logits.dtype
         ctx.prev_g = None
         return loss
@@ -118,7 +116,7 @@ class _GroupSoftmaxLoss(torch.autograd.Function):
     def backward(ctx, grad_loss):
         dl = ctx.dlogits
         if dl is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None
         lib = capi.load()
         g = grad_loss.detach().to(torch.float32).contiguous()
         if ctx.prev_g is not None:  # a second backward through a retained graph
@@ -126,42 +124,58 @@ class _GroupSoftmaxLoss(torch.autograd.Function):
         else:
             g_eff = g
         N, W = dl.shape
-        B = ctx.pred_slice.shape[0]
-        rc = lib.bgs_gs_scale_grad(capi.ptr(dl), capi.ptr(ctx.pred_slice), capi.ptr(g_eff),
-                                   N, B, W, capi.current_stream(dl.device))
+        ps_keep, ps_ptr = capi.host_i64(ctx.pred_slice_host)
+        rc = lib.bgs_gs_scale_grad(capi.ptr(dl), ps_ptr, capi.ptr(g_eff), N, ps_keep.shape[0], W,
+                                   capi.current_stream(dl.device))
         capi.check('bgs_gs_scale_grad', rc)
         ctx.prev_g = g
         out = dl if ctx.in_dtype == torch.float32 else dl.to(ctx.in_dtype)
-        return out, None, None, None, None, None
+        return out, None, None, None, None
 
 
-def group_softmax_loss(cls_score, labels, label2binlabel, pred_slice, weights=None, avg=None):
+def group_softmax_loss(cls_score, bin_labels, pred_slice, weights=None, avg=None):
     """Per-bin weighted CE of the ``[N, W]`` logits -> ``[B]`` losses (differentiable
-    w.r.t. ``cls_score``).  ``weights [B,N]`` / ``avg [B]`` as produced by ``gs_prepare``."""
-    _require_cuda(cls_score, labels, label2binlabel, pred_slice, weights, avg)
-    assert cls_score.dim() == 2 and labels.dtype == torch.int64
-    assert label2binlabel.is_contiguous() and pred_slice.is_contiguous()
-    labels = labels.contiguous()
+    w.r.t. ``cls_score``).
+
+    ``bin_labels [B,N] i32`` / ``weights [B,N]`` / ``avg [B]`` as produced by ``gs_prepare``;
+    ``pred_slice``: HOST ``[B,2]`` (start, length) table (numpy / list / CPU tensor).
+    """
+    _require_cuda(cls_score, bin_labels, weights, avg)
+    assert cls_score.dim() == 2 and bin_labels.dtype == torch.int32
+    assert bin_labels.is_contiguous() and bin_labels.shape[1] == cls_score.shape[0]
+    ps = _host_pred_slice(pred_slice)
+    assert ps.shape == (bin_labels.shape[0], 2)
     if weights is not None:
         weights = _f32c(weights)
-        assert weights.shape == (label2binlabel.shape[0], cls_score.shape[0])
+        assert weights.shape == tuple(bin_labels.shape)
     if avg is not None:
         avg = _f32c(avg)
-    return _GroupSoftmaxLoss.apply(cls_score, labels, label2binlabel, pred_slice, weights, avg)
+    return _GroupSoftmaxLoss.apply(cls_score, bin_labels, ps, weights, avg)
+
+
+def _host_pred_slice(pred_slice):
+    import numpy as np
+    if isinstance(pred_slice, torch.Tensor):
+        if pred_slice.is_cuda:
+            raise RuntimeError('pred_slice must live on the host (static metadata passed by '
+                               'value to the kernels); keep a CPU copy instead of syncing')
+        pred_slice = pred_slice.numpy()
+    return np.ascontiguousarray(pred_slice, dtype=np.int64)
 
 
 # ----------------------------------------------------------------------------------------
 # inference score merge  (GSBBoxHeadWith0._merge_score, :239-273)
 # ----------------------------------------------------------------------------------------
 def gs_merge_score(cls_score, pred_slice, cls2col, num_classes):
-    _require_cuda(cls_score, pred_slice, cls2col)
+    _require_cuda(cls_score, cls2col)
     lib = capi.load()
     z = _f32c(cls_score)
     N, W = z.shape
-    B = pred_slice.shape[0]
+    ps_keep, ps_ptr = capi.host_i64(_host_pred_slice(pred_slice))
+    B = ps_keep.shape[0]
     assert cls2col.dtype == torch.int32 and cls2col.numel() == num_classes
     out = torch.empty((N, num_classes), dtype=torch.float32, device=z.device)
-    rc = lib.bgs_gs_merge_score(capi.ptr(z), capi.ptr(pred_slice), capi.ptr(cls2col), N,
+    rc = lib.bgs_gs_merge_score(capi.ptr(z), ps_ptr, capi.ptr(cls2col), N,
                                 num_classes, B, W, capi.ptr(out), capi.current_stream(z.device))
     capi.check('bgs_gs_merge_score', rc)
     return out

@@ -98,8 +98,8 @@ class GsHeadStep(object):
         i = self.inp
         self.logits.grad = None
         self.draw += 1            # device-side draw counter: a new sample every step, also under graph replay
-        w, avg = BF.gs_prepare(i['labels'], i['l2b'], 8.0, seed=12345, seed_offset=self.draw)
-        per_bin = BF.group_softmax_loss(self.logits, i['labels'], i['l2b'], i['ps'], w, avg)
+        bl, w, avg = BF.gs_prepare(i['labels'], i['l2b'], 8.0, seed=12345, seed_offset=self.draw)
+        per_bin = BF.group_softmax_loss(self.logits, bl, i['ps_np'], w, avg)
         lbox = BF.bbox_smooth_l1_loss(i['bbox_pred'], i['labels'], i['bbox_targets'],
                                       i['bbox_weights'], NUM_CLASSES, beta=1.0,
                                       avg_factor=i['labels'].numel())
@@ -154,18 +154,17 @@ def kernel_roofline(inp, n, iters=300):
     of bgs_gs_loss_fwd_bwd with loss_out=NULL), back to back on the current stream.
     Algorithmic bytes per RoI: W*4 read + W*4 written + 8 (label) + B*4 (weights)."""
     lib = capi.load()
-    W, B = inp['W'], inp['ps'].shape[0]
+    W, B = inp['W'], inp['ps_np'].shape[0]
     dev = inp['logits'].device
-    w, avg = BF.gs_prepare(inp['labels'], inp['l2b'], 8.0, seed=1)
+    bl, w, avg = BF.gs_prepare(inp['labels'], inp['l2b'], 8.0, seed=1)
+    ps_keep, ps_ptr = capi.host_i64(inp['ps_np'])
     dl = torch.empty_like(inp['logits'])
     ws = torch.empty(lib.bgs_gs_loss_workspace_bytes(n, B), dtype=torch.uint8, device=dev)
     st = capi.current_stream(dev)
 
     def launch():
-        rc = lib.bgs_gs_loss_fwd_bwd(capi.ptr(inp['logits']), capi.ptr(inp['labels']),
-                                     capi.ptr(inp['l2b']), capi.ptr(inp['ps']), capi.ptr(w),
-                                     capi.ptr(avg), n, NUM_CLASSES, B, W, None, capi.ptr(dl),
-                                     capi.ptr(ws), st)
+        rc = lib.bgs_gs_loss_fwd_bwd(capi.ptr(inp['logits']), capi.ptr(bl), ps_ptr, capi.ptr(w),
+                                     capi.ptr(avg), n, B, W, None, capi.ptr(dl), capi.ptr(ws), st)
         capi.check('bgs_gs_loss_fwd_bwd', rc)
 
     for _ in range(20):
@@ -182,7 +181,7 @@ def kernel_roofline(inp, n, iters=300):
     achieved = bytes_per_roi * n / (us * 1e-6) / 1e9
     return dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
-                kernel='gs_loss_rowblock_kernel<4,1,true>', us_per_launch=round(us, 3),
+                kernel='gs_loss_rowwave_kernel<4,true>', us_per_launch=round(us, 3),
                 algorithmic_bytes_per_roi=bytes_per_roi, rois_per_launch=n,
                 timing='hipEvent over %d back-to-back launches (includes the ~1.5 us '
                        'inter-kernel boundary)' % iters)
@@ -197,21 +196,31 @@ def cpu_baseline(n, seconds):
     z, lab = torch.from_numpy(batch['logits']), torch.from_numpy(batch['labels'])
     l2b_t, ps_t = torch.from_numpy(l2b), torch.from_numpy(ps)
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    for _ in range(5):
-        gs_torch_port.gs_loss_fwd_bwd(z, lab, l2b_t, ps_t, 8.0)
-    times = []
-    t_end = time.perf_counter() + seconds
-    while time.perf_counter() < t_end and len(times) < 2000:
-        np.random.seed(len(times))
-        t0 = time.perf_counter()
-        gs_torch_port.gs_loss_fwd_bwd(z, lab, l2b_t, ps_t, 8.0)
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    return dict(value=round(med * 1e6 / n, 4), unit='us/RoI', cores=cores, kind='port',
-                sample='%d x (loss+backward) of the torch-CPU port of GSBBoxHeadWith0.loss on '
-                       'N=%d RoIs x 1236 logits (cls branch, numpy sampling incl.), median; '
-                       'torch %s, %d threads' % (len(times), n, torch.__version__, cores))
+    best = None
+    # torch-CPU oversubscribes badly on many-core hosts: report the best thread count tried
+    for nt in sorted(set([1, 8, 32, min(cores, 64)])):
+        if nt > cores:
+            continue
+        torch.set_num_threads(nt)
+        for _ in range(3):
+            gs_torch_port.gs_loss_fwd_bwd(z, lab, l2b_t, ps_t, 8.0)
+        times = []
+        t_end = time.perf_counter() + seconds / 4.0
+        while time.perf_counter() < t_end and len(times) < 500:
+            np.random.seed(len(times))
+            t0 = time.perf_counter()
+            gs_torch_port.gs_loss_fwd_bwd(z, lab, l2b_t, ps_t, 8.0)
+            times.append(time.perf_counter() - t0)
+        med = float(np.median(times))
+        if best is None or med < best[0]:
+            best = (med, nt, len(times))
+    med, nt, cnt = best
+    return dict(value=round(med * 1e6 / n, 4), unit='us/RoI', cores=nt, kind='port',
+                host_cores=cores,
+                sample='%d x (loss+backward) of the torch-CPU port of GSBBoxHeadWith0.loss '
+                       '(oracle/gs_torch_port.py) on N=%d RoIs x 1236 logits (cls branch, numpy '
+                       'sampling incl.), median; best of 1/8/32/64 threads = %d; torch %s'
+                       % (cnt, n, nt, torch.__version__))
 
 
 def main():

@@ -56,14 +56,15 @@ int bgs_selftest_wave_reduce(const float* in, float* out, bgs_stream_t stream);
  *                   (seed, bin, row); same (seed) => same draw; no host RNG, no sync)
  *   seed_offset     device uint64 [1] or NULL: a draw counter the caller bumps on the device
  *                   (e.g. inside a captured hipGraph, where `seed` itself is frozen)
- *   bin_labels_out  [B,N]  int64 or NULL
+ *   bin_labels_out  [B,N]  int32 or NULL: label2binlabel[b, labels[r]] (the integer gather,
+ *                   bit-exact); consumed by bgs_gs_loss_fwd_bwd
  *   weights_out     [B,N]  float
  *   avg_out         [B]    float  = max(sum_r weights[b,r], 1)
  * ---------------------------------------------------------------------------------- */
 int bgs_gs_prepare(const int64_t* labels, const int64_t* label2binlabel,
                    const float* cls_weight, int cls_weight_stride,
                    int N, int C, int B, double others_sample_ratio, uint64_t seed,
-                   const uint64_t* seed_offset, int64_t* bin_labels_out, float* weights_out, float* avg_out,
+                   const uint64_t* seed_offset, int32_t* bin_labels_out, float* weights_out, float* avg_out,
                    bgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
@@ -72,11 +73,13 @@ int bgs_gs_prepare(const int64_t* labels, const int64_t* label2binlabel,
  *   = _slice_preds (:134-145) + CrossEntropyLoss.forward (losses/cross_entropy_loss.py:86-103)
  *   + cross_entropy (:9-19) + weight_reduce_loss (losses/utils.py:26-52) and the autograd
  *   backward of all of it, in ONE pass over the logits:
- *     loss[b]      = sum_r w[b,r] * (logsumexp(z[r, s_b:s_b+n_b]) - z[r, s_b + L[b,y_r]]) / avg[b]
- *     dlogits[r,s_b+j] = (w[b,r]/avg[b]) * (softmax_j(z[r, s_b:s_b+n_b]) - [j == L[b,y_r]])
+ *     loss[b]      = sum_r w[b,r] * (logsumexp(z[r, s_b:s_b+n_b]) - z[r, s_b + bl[b,r]]) / avg[b]
+ *     dlogits[r,s_b+j] = (w[b,r]/avg[b]) * (softmax_j(z[r, s_b:s_b+n_b]) - [j == bl[b,r]])
  *
- *   logits      [N,W]  float (row stride W), labels [N] int64
- *   pred_slice  [B,2]  int64 (start, length) (pred_slice_with0.pt); bins must not overlap
+ *   logits      [N,W]  float (row stride W)
+ *   bin_labels  [B,N]  int32 = label2binlabel[b, labels[r]] (output of bgs_gs_prepare)
+ *   host_pred_slice [B,2] int64 (start, length) ON THE HOST (pred_slice_with0.pt); it is static
+ *               metadata and travels by value in the kernel arguments.  Bins must not overlap.
  *   weights     [B,N]  float or NULL (= all ones);  avg [B] float or NULL (= max(N,1))
  *   loss_out    [B]    float, or NULL: stop after the streaming kernel and leave the per-
  *               workgroup partial sums in the workspace (bgs_gs_loss_reduce finishes the job)
@@ -85,10 +88,10 @@ int bgs_gs_prepare(const int64_t* labels, const int64_t* label2binlabel,
  *               reduced in a fixed order => bitwise reproducible, no atomics)
  * ---------------------------------------------------------------------------------- */
 size_t bgs_gs_loss_workspace_bytes(int N, int B);
-int bgs_gs_loss_fwd_bwd(const float* logits, const int64_t* labels,
-                        const int64_t* label2binlabel, const int64_t* pred_slice,
+int bgs_gs_loss_fwd_bwd(const float* logits, const int32_t* bin_labels,
+                        const int64_t* host_pred_slice,
                         const float* weights, const float* avg,
-                        int N, int C, int B, int W,
+                        int N, int B, int W,
                         float* loss_out, float* dlogits, void* workspace,
                         bgs_stream_t stream);
 
@@ -99,7 +102,7 @@ int bgs_gs_loss_reduce(const void* workspace, int N, int B, float* loss_out, bgs
  * (d total / d loss_b; 1 for plain Faster R-CNN, stage_loss_weights for Cascade,
  * mmdet/models/detectors/cascade_rcnn.py:248-250):  dlogits[:, bin b] *= g[b].
  * Early-outs on the device when every g[b] == 1.  g [B] float (device). */
-int bgs_gs_scale_grad(float* dlogits, const int64_t* pred_slice, const float* g,
+int bgs_gs_scale_grad(float* dlogits, const int64_t* host_pred_slice, const float* g,
                       int N, int B, int W, bgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
@@ -107,9 +110,11 @@ int bgs_gs_scale_grad(float* dlogits, const int64_t* pred_slice, const float* g,
  *   (gs_bbox_head_with0.py:239-273): softmax inside every bin, then
  *     scores[r,0] = p_0[r,0];  scores[r,c] = p_0[r,1] * p_b[r, k]  for the column
  *     cls2col[c] = s_b + k of class c (k >= 1);  cls2col[c] < 0  => scores[r,c] = 0.
- *   logits [N,W] float, pred_slice [B,2] int64, cls2col [C] int32, scores_out [N,C] float.
+ *   logits [N,W] float, host_pred_slice [B,2] int64 (host), cls2col [C] int32,
+ *   scores_out [N,C] float.
  * ---------------------------------------------------------------------------------- */
-int bgs_gs_merge_score(const float* logits, const int64_t* pred_slice, const int32_t* cls2col,
+int bgs_gs_merge_score(const float* logits, const int64_t* host_pred_slice,
+                       const int32_t* cls2col,
                        int N, int C, int B, int W, float* scores_out, bgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

@@ -37,10 +37,16 @@ def test_variant_files_present(variant):
 def test_argument_validation_without_gpu():
     """Entry points reject bad arguments before touching the device."""
     lib = capi.load()
-    assert lib.bgs_gs_loss_fwd_bwd(None, None, None, None, None, None, 4, 10, 3, 13, None, None,
-                                   None, None) == 1
-    assert lib.bgs_gs_loss_fwd_bwd(None, None, None, None, None, None, 4, 10, 99, 13, None, None,
-                                   None, None) in (1, 2)
+    assert lib.bgs_gs_loss_fwd_bwd(None, None, None, None, None, 4, 3, 13, None, None, None,
+                                   None) == 1
+    assert lib.bgs_gs_loss_fwd_bwd(None, None, None, None, None, 4, 99, 13, None, None, None,
+                                   None) in (1, 2)
+    import ctypes
+    import numpy as np
+    bad = np.array([[0, 2], [2, 20]], dtype=np.int64)        # bin 1 runs past W=13
+    ws = ctypes.create_string_buffer(16)
+    assert lib.bgs_gs_loss_fwd_bwd(None, None, bad.ctypes.data_as(ctypes.c_void_p), None, None,
+                                   0, 2, 13, None, None, ws, None) == 1
     assert lib.bgs_gs_merge_score(None, None, None, -1, 10, 3, 13, None, None) == 1
     assert lib.bgs_gs_prepare(None, None, None, 0, 4, 10, 3, 8.0, 1, None, None, None, None, None) == 1
     assert lib.bgs_bbox_smooth_l1_fwd_bwd(None, None, None, None, 4, 10, 0.0, 4.0, 1.0, None,
@@ -59,6 +65,5 @@ def test_ops_refuse_cpu_tensors():
     import torch
     from balancedgroupsoftmax_amd import functional as BF
     with pytest.raises(RuntimeError, match='no CPU fallback'):
-        BF.group_softmax_loss(torch.zeros(2, 8), torch.zeros(2, dtype=torch.long),
-                              torch.zeros(2, 4, dtype=torch.long),
+        BF.group_softmax_loss(torch.zeros(2, 8), torch.zeros((2, 2), dtype=torch.int32),
                               torch.tensor([[0, 2], [2, 6]]))

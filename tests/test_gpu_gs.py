@@ -39,9 +39,15 @@ def test_wave_reduce_selftest():
         assert abs(out[1] - v.astype(np.float64).sum()) < 1e-3
 
 
+def _bl(batch, l2b):
+    """int32 bin labels on the device (the gather itself is tested against the oracle in
+    test_device_sampling_matches_reference_rule / test_large_batch_properties)."""
+    return dev(gs_oracle.remap_labels(batch['labels'], l2b).astype(np.int32))
+
+
 def _run_loss(batch, l2b, ps, w, avg, grad=True):
     z = dev(batch['logits']).requires_grad_(grad)
-    losses = BF.group_softmax_loss(z, dev(batch['labels']), dev(l2b), dev(ps),
+    losses = BF.group_softmax_loss(z, _bl(batch, l2b), ps,
                                    None if w is None else dev(w), None if avg is None else dev(avg))
     g = None
     if grad:
@@ -90,7 +96,7 @@ def test_default_weights_and_upstream_scale():
     case, l2b, ps, _, _, batch = case_setup('n7')
     n = case['n']
     z = dev(batch['logits']).requires_grad_(True)
-    losses = BF.group_softmax_loss(z, dev(batch['labels']), dev(l2b), dev(ps))
+    losses = BF.group_softmax_loss(z, _bl(batch, l2b), ps)
     gs = np.array([1.0, 0.5, 0.25, 2.0, 0.0], dtype=np.float32)
     (losses * dev(gs)).sum().backward(retain_graph=True)
     bl = gs_oracle.remap_labels(batch['labels'], l2b)
@@ -105,7 +111,7 @@ def test_half_and_bf16_logits_are_computed_in_fp32():
     for dt in (torch.float16, torch.bfloat16):
         zq = dev(batch['logits']).to(dt)
         z = zq.clone().requires_grad_(True)
-        losses = BF.group_softmax_loss(z, dev(batch['labels']), dev(l2b), dev(ps))
+        losses = BF.group_softmax_loss(z, _bl(batch, l2b), ps)
         losses.sum().backward()
         assert z.grad.dtype == dt
         bl = gs_oracle.remap_labels(batch['labels'], l2b)
@@ -118,8 +124,7 @@ def test_half_and_bf16_logits_are_computed_in_fp32():
 def test_empty_batch():
     case, l2b, ps, _, _, batch = case_setup('n7')
     z = torch.zeros((0, 1236), device=DEV, requires_grad=True)
-    losses = BF.group_softmax_loss(z, torch.zeros(0, dtype=torch.long, device=DEV), dev(l2b),
-                                   dev(ps))
+    losses = BF.group_softmax_loss(z, torch.zeros((5, 0), dtype=torch.int32, device=DEV), ps)
     assert losses.cpu().tolist() == [0.0] * 5
 
 
@@ -161,7 +166,7 @@ def test_misaligned_view_falls_back_to_narrow_loads():
     buf[1:] = dev(batch['logits']).reshape(-1)
     z = buf[1:].view(n, 1236)            # 4-byte aligned only
     assert z.data_ptr() % 16 != 0
-    losses = BF.group_softmax_loss(z, dev(batch['labels']), dev(l2b), dev(ps))
+    losses = BF.group_softmax_loss(z, _bl(batch, l2b), ps)
     bl = gs_oracle.remap_labels(batch['labels'], l2b)
     ol, _ = gs_oracle.group_softmax_loss(batch['logits'], bl, np.ones((5, n)), np.full(5, n), ps)
     np.testing.assert_allclose(losses.cpu().numpy(), ol, rtol=1e-5)
@@ -176,9 +181,9 @@ def test_large_batch_properties():
     N = 65536
     batch = gs_oracle.make_roi_batch(N, 1236, C, seed=77)
     lab = dev(batch['labels'])
-    w, avg, bl_dev = BF.gs_prepare(lab, dev(l2b), 8.0, seed=5, return_bin_labels=True)
+    bl_dev, w, avg = BF.gs_prepare(lab, dev(l2b), 8.0, seed=5)
     z = dev(batch['logits']).requires_grad_(True)
-    losses = BF.group_softmax_loss(z, lab, dev(l2b), dev(ps), w, avg)
+    losses = BF.group_softmax_loss(z, bl_dev, ps, w, avg)
     losses.sum().backward()
     grad = z.grad
     wn, an = w.cpu().numpy(), avg.cpu().numpy()
@@ -228,8 +233,7 @@ def test_device_sampling_matches_reference_rule(name):
         for i, x in enumerate(cls_w):
             tab[i, :len(x)] = x
         cw = dev(tab)
-    w, avg, bl = BF.gs_prepare(lab, dev(l2b), ratio, seed=123, cls_weight=cw,
-                               return_bin_labels=True)
+    bl, w, avg = BF.gs_prepare(lab, dev(l2b), ratio, seed=123, cls_weight=cw)
     w, avg, bl = w.cpu().numpy(), avg.cpu().numpy(), bl.cpu().numpy()
     np.testing.assert_array_equal(bl, gs_oracle.remap_labels(batch['labels'], l2b))
     B, N = bl.shape
@@ -246,7 +250,7 @@ def test_device_sampling_matches_reference_rule(name):
         np.testing.assert_allclose(w[b][sel], expect[sel].astype(np.float32), rtol=1e-6)
         assert avg[b] == pytest.approx(max(float(w[b].astype(np.float64).sum()), 1.0), rel=1e-6)
     # same seed -> same draw, different seed -> different draw (when anything is sampled)
-    w2, _ = BF.gs_prepare(lab, dev(l2b), ratio, seed=123, cls_weight=cw)
+    _, w2, _ = BF.gs_prepare(lab, dev(l2b), ratio, seed=123, cls_weight=cw)
     np.testing.assert_array_equal(w2.cpu().numpy(), w)
 
 
@@ -258,7 +262,7 @@ def test_device_sampling_is_uniform():
     T = 400
     acc = torch.zeros((5, 512), device=DEV)
     for s in range(T):
-        w, _ = BF.gs_prepare(lab, l2b_d, 2.0, seed=1000 + s)
+        _, w, _ = BF.gs_prepare(lab, l2b_d, 2.0, seed=1000 + s)
         acc += w
     acc = acc.cpu().numpy() / T
     bl = gs_oracle.remap_labels(batch['labels'], l2b)
@@ -270,8 +274,8 @@ def test_device_sampling_is_uniform():
         assert abs(f.mean() - p) < 1e-6                   # exactly k per draw
         sigma = np.sqrt(p * (1 - p) / T)
         assert np.abs(f - p).max() < 6 * sigma            # no row is favoured
-    w_a, _ = BF.gs_prepare(lab, l2b_d, 2.0, seed=1)
-    w_b, _ = BF.gs_prepare(lab, l2b_d, 2.0, seed=2)
+    _, w_a, _ = BF.gs_prepare(lab, l2b_d, 2.0, seed=1)
+    _, w_b, _ = BF.gs_prepare(lab, l2b_d, 2.0, seed=2)
     assert not torch.equal(w_a, w_b)
 
 
@@ -311,7 +315,7 @@ def test_merge_score_vs_reference_fixtures(name):
     g = golden()
     z = dev(batch['logits']) * 2.0
     cls2col = gs_tables.class_to_column(l2b, ps).to(DEV)
-    ms = BF.gs_merge_score(z, dev(ps), cls2col, C).cpu().numpy()
+    ms = BF.gs_merge_score(z, ps, cls2col, C).cpu().numpy()
     rows = g.get(name, 'grad_rows')
     np.testing.assert_allclose(ms[rows], g.get(name, 'merge_sub'), rtol=1e-4, atol=1e-9)
     np.testing.assert_allclose(ms.astype(np.float64).sum(1), g.get(name, 'merge_rowsum'),
@@ -327,7 +331,7 @@ def test_merge_score_1000_rois_properties():
     l2b, ps, split = gs_tables.build_group_tables(counts)
     batch = gs_oracle.make_roi_batch(1000, 1236, C, seed=4, logit_scale=3.0)
     z = dev(batch['logits'])
-    ms = BF.gs_merge_score(z, dev(ps), gs_tables.class_to_column(l2b, ps).to(DEV), C)
+    ms = BF.gs_merge_score(z, ps, gs_tables.class_to_column(l2b, ps).to(DEV), C)
     p0 = torch.softmax(z[:, 0:2], dim=1)
     assert torch.allclose(ms[:, 0], p0[:, 0], atol=1e-6)
     for b, key in enumerate(gs_tables.FG_SPLIT_KEYS_5, start=1):
