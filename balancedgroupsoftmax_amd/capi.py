@@ -48,6 +48,16 @@ SIGNATURES = {
     'bgs_bbox_smooth_l1_fwd_bwd': (ctypes.c_int, [c_f32p, c_i64p, c_f32p, c_f32p, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                                   ctypes.c_float, c_f32p, c_f32p, c_ptr, c_ptr]),
+    'bgs_conv2d_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 11
+                            + [c_ptr]),
+    'bgs_maxpool3x3s2_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p] + [ctypes.c_int] * 4 + [c_ptr]),
+    'bgs_roi_align_nhwc_fwd': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, c_f32p, c_ptr, c_ptr]),
+    'bgs_nms_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    'bgs_nms_batched': (ctypes.c_int, [c_f32p, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                       ctypes.c_int, ctypes.c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
 }
 
 _LIB = None

@@ -1,0 +1,147 @@
+// Batched greedy NMS entirely on the device, for gfx950 (MI355X).
+//
+// Replaces ops.nms (mmdet/ops/nms/nms_wrapper.py:8-49) -> nms_cuda
+// (mmdet/ops/nms/src/nms_kernel.cu:23-131): the reference computes a 64x64-tiled suppression
+// bitmask on the GPU, copies it to the host (512 KB D2H + sync per call), runs the greedy
+// scan on the CPU and copies the kept indices back — 10 times per training iteration
+// (5 FPN levels x 2 images, mmdet/models/anchor_heads/rpn_head.py:92).
+// Here all P problems (image x level) go through ONE pair of launches and nothing leaves
+// the device:
+//   1. nms_mask_kernel   grid (cb, cb, P): same 64x64 bitmask tiles (upper triangle only),
+//      legacy "+1" IoU (nms_kernel.cu:13-21);
+//   2. nms_scan_kernel   grid P, one wave per problem: boxes are consumed in chunks of 64;
+//      inside a chunk the greedy decision is a 64-step bit recurrence on the diagonal mask
+//      word (registers only), then lane j ORs the kept rows' word j into its running
+//      "removed" word.  Kept indices are emitted in ascending (= score) order.
+// Boxes must already be sorted by descending score per problem (the callers' topk does that).
+// iou_mode 0: suppress when IoU >  thr (nms_kernel.cu:60);  1: IoU >= thr (nms_cpu.cpp:55).
+#include "bgs_common.h"
+
+namespace {
+
+constexpr int kTile = 64;
+
+__device__ __forceinline__ float iou_legacy(const float* a, const float* b) {
+  const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+  const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+  const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
+  const float inter = width * height;
+  const float sa = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f);
+  const float sb = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
+  return inter / (sa + sb - inter);
+}
+
+// boxes [P, nmax, 5] (x1,y1,x2,y2,score), counts [P]; mask [P, nmax, cb] u64.
+__global__ __launch_bounds__(kTile) void nms_mask_kernel(const float* __restrict__ boxes,
+                                                         const int* __restrict__ counts,
+                                                         int nmax, int cb, float thr,
+                                                         int iou_mode,
+                                                         unsigned long long* __restrict__ mask) {
+  const int p = blockIdx.z;
+  const int n = min(counts[p], nmax);
+  const int row_start = blockIdx.y, col_start = blockIdx.x;
+  if (row_start > col_start) return;  // only j > i can be suppressed by i
+  if (row_start * kTile >= n || col_start * kTile >= n) return;
+  const int row_size = min(n - row_start * kTile, kTile);
+  const int col_size = min(n - col_start * kTile, kTile);
+  const float* pb = boxes + (size_t)p * nmax * 5;
+  __shared__ float cbx[kTile * 4];
+  if ((int)threadIdx.x < col_size) {
+    const float* s = pb + (size_t)(col_start * kTile + threadIdx.x) * 5;
+    cbx[threadIdx.x * 4 + 0] = s[0];
+    cbx[threadIdx.x * 4 + 1] = s[1];
+    cbx[threadIdx.x * 4 + 2] = s[2];
+    cbx[threadIdx.x * 4 + 3] = s[3];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < row_size) {
+    const int i = row_start * kTile + threadIdx.x;
+    const float* s = pb + (size_t)i * 5;
+    const float cur[4] = {s[0], s[1], s[2], s[3]};
+    unsigned long long t = 0ull;
+    const int start = (row_start == col_start) ? threadIdx.x + 1 : 0;
+    for (int j = start; j < col_size; ++j) {
+      const float v = iou_legacy(cur, cbx + j * 4);
+      const bool sup = iou_mode ? (v >= thr) : (v > thr);
+      if (sup) t |= 1ull << j;
+    }
+    mask[((size_t)p * nmax + i) * cb + col_start] = t;
+  }
+}
+
+// one wave per problem.  keep [P, nmax] int32 (ascending), keep_count [P].
+__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                      const int* __restrict__ counts, int nmax,
+                                                      int cb, int max_keep,
+                                                      int* __restrict__ keep,
+                                                      int* __restrict__ keep_count) {
+  const int p = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int n = min(counts[p], nmax);
+  const unsigned long long* pm = mask + (size_t)p * nmax * cb;
+  int* pk = keep + (size_t)p * nmax;
+  __shared__ unsigned long long rows[kTile][kTile + 1];  // rows of the current chunk x words
+  // lane j (j < cb, cb <= 64) keeps the running removed-bits of column block j
+  unsigned long long remv = 0ull;
+  int nkeep = 0;
+  const int nchunks = (n + kTile - 1) / kTile;
+  for (int c = 0; c < nchunks && nkeep < max_keep; ++c) {
+    const int base = c * kTile;
+    const int rows_here = min(n - base, kTile);
+    // stage the chunk's mask rows (words c..cb-1; words < c are never written) in LDS
+    for (int r = 0; r < rows_here; ++r) {
+      if (lane >= c && lane < cb) rows[r][lane] = pm[(size_t)(base + r) * cb + lane];
+    }
+    __syncthreads();
+    // greedy recurrence inside the chunk on the diagonal word (all lanes compute it redundantly)
+    unsigned long long dead = __shfl(remv, c, 64);  // removed bits of this chunk so far
+    unsigned long long kept = 0ull;
+    for (int r = 0; r < rows_here; ++r) {
+      if (!((dead >> r) & 1ull)) {
+        kept |= 1ull << r;
+        dead |= rows[r][c];
+      }
+    }
+    // fold the kept rows into the running removed words of the later blocks
+    if (lane > c && lane < cb) {
+      unsigned long long acc = 0ull;
+      for (int r = 0; r < rows_here; ++r)
+        if ((kept >> r) & 1ull) acc |= rows[r][lane];
+      remv |= acc;
+    }
+    // emit kept indices in ascending order: lane r writes at its rank among the kept bits
+    if (lane < rows_here && ((kept >> lane) & 1ull)) {
+      const int rank = __popcll(kept & ((1ull << lane) - 1ull));
+      if (nkeep + rank < max_keep) pk[nkeep + rank] = base + lane;
+    }
+    nkeep += __popcll(kept);
+    __syncthreads();
+  }
+  if (lane == 0) keep_count[p] = min(nkeep, max_keep);
+}
+
+}  // namespace
+
+extern "C" size_t bgs_nms_workspace_bytes(int P, int nmax) {
+  if (P <= 0 || nmax <= 0) return 0;
+  const size_t cb = (size_t)(nmax + kTile - 1) / kTile;
+  return (size_t)P * nmax * cb * sizeof(unsigned long long);
+}
+
+extern "C" int bgs_nms_batched(const float* boxes, const int* counts, int P, int nmax,
+                               float iou_thr, int iou_mode, int max_keep, int* keep,
+                               int* keep_count, void* workspace, bgs_stream_t stream) {
+  if (P < 0 || nmax <= 0) return BGS_ERR_INVALID_ARG;
+  if (P == 0) return BGS_OK;
+  if (!boxes || !counts || !keep || !keep_count || !workspace) return BGS_ERR_INVALID_ARG;
+  const int cb = (nmax + kTile - 1) / kTile;
+  if (cb > 64) return BGS_ERR_UNSUPPORTED;  // nmax <= 4096 (RPN uses nms_pre = 2000)
+  if (max_keep <= 0 || max_keep > nmax) max_keep = nmax;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* mask = (unsigned long long*)workspace;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, P), dim3(kTile), 0, st, boxes, counts, nmax, cb,
+                     iou_thr, iou_mode, mask);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(P), dim3(64), 0, st, mask, counts, nmax, cb, max_keep,
+                     keep, keep_count);
+  BGS_RETURN_LAUNCH_STATUS();
+}

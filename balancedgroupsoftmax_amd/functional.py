@@ -230,6 +230,105 @@ def bbox_smooth_l1_loss(bbox_pred, labels, bbox_targets, bbox_weights, num_reg_c
                                loss_weight)
 
 
+# ----------------------------------------------------------------------------------------
+# conv / linear on the fp32 matrix cores (NHWC activations, [Cout,R,S,Cin] weights)
+# ----------------------------------------------------------------------------------------
+def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None,
+                residual_mode=0, out=None):
+    """``y = act(conv(x, w) + bias + residual)``; x ``[N,H,W,Cin]``, w ``[Cout,R,S,Cin]``.
+    Forward only (the shipped BAGS configs freeze every conv: selectp=1, tools/train.py:49-57)."""
+    _require_cuda(x, w_krsc, bias, residual)
+    lib = capi.load()
+    assert x.dtype == torch.float32 and w_krsc.dtype == torch.float32
+    assert x.is_contiguous() and w_krsc.is_contiguous() and x.dim() == 4 and w_krsc.dim() == 4
+    N, H, W, Cin = x.shape
+    Cout, R, S, Cin2 = w_krsc.shape
+    assert Cin == Cin2, (x.shape, w_krsc.shape)
+    Ho = (H + 2 * pad - R) // stride + 1
+    Wo = (W + 2 * pad - S) // stride + 1
+    if residual is not None and residual_mode == 0:
+        residual_mode = 1
+    if residual is not None:
+        exp = (N, Ho, Wo, Cout) if residual_mode == 1 else (N, Ho // 2, Wo // 2, Cout)
+        assert tuple(residual.shape) == exp and residual.is_contiguous(), (residual.shape, exp)
+    if out is None:
+        out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    rc = lib.bgs_conv2d_nhwc_f32(capi.ptr(x), capi.ptr(w_krsc), capi.ptr(bias),
+                                 capi.ptr(residual), capi.ptr(out), N, H, W, Cin, Cout, R, S,
+                                 stride, pad, int(bool(relu)), residual_mode,
+                                 capi.current_stream(x.device))
+    capi.check('bgs_conv2d_nhwc_f32', rc)
+    return out
+
+
+def linear(x, weight, bias=None, relu=False):
+    """``act(x @ weight.T + bias)`` for ``x [M,K]``, ``weight [Cout,K]`` (nn.Linear layout)."""
+    M, K = x.shape
+    y = conv2d_nhwc(x.view(M, 1, 1, K), weight.view(weight.shape[0], 1, 1, K), bias, relu=relu)
+    return y.view(M, weight.shape[0])
+
+
+def maxpool3x3s2_nhwc(x):
+    _require_cuda(x)
+    lib = capi.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    N, H, W, C = x.shape
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float32,
+                      device=x.device)
+    rc = lib.bgs_maxpool3x3s2_nhwc_f32(capi.ptr(x), capi.ptr(out), N, H, W, C,
+                                       capi.current_stream(x.device))
+    capi.check('bgs_maxpool3x3s2_nhwc_f32', rc)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# RoIAlign (multi-level, NHWC) and batched NMS
+# ----------------------------------------------------------------------------------------
+def roi_align_nhwc(feats, rois, featmap_strides, out_size=7, sample_num=2, finest_scale=56,
+                   return_levels=False):
+    """feats: list of ``[N,H_l,W_l,C]`` maps; rois ``[K,5]`` -> ``[K, out, out, C]``."""
+    import ctypes
+    _require_cuda(rois, *feats)
+    lib = capi.load()
+    L = len(feats)
+    N, _, _, C = feats[0].shape
+    for f in feats:
+        assert f.dtype == torch.float32 and f.is_contiguous() and f.shape[0] == N and f.shape[3] == C
+    rois = _f32c(rois)
+    K = rois.shape[0]
+    ph, pw = (out_size, out_size) if isinstance(out_size, int) else tuple(out_size)
+    out = torch.empty((K, ph, pw, C), dtype=torch.float32, device=rois.device)
+    lv = torch.empty((K,), dtype=torch.int32, device=rois.device) if return_levels else None
+    ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+    hs = (ctypes.c_int * L)(*[int(f.shape[1]) for f in feats])
+    ws = (ctypes.c_int * L)(*[int(f.shape[2]) for f in feats])
+    sc = (ctypes.c_float * L)(*[1.0 / s for s in featmap_strides])
+    rc = lib.bgs_roi_align_nhwc_fwd(ptrs, hs, ws, sc, L, N, float(finest_scale), capi.ptr(rois),
+                                    K, C, ph, pw, sample_num, capi.ptr(out), capi.ptr(lv),
+                                    capi.current_stream(rois.device))
+    capi.check('bgs_roi_align_nhwc_fwd', rc)
+    return (out, lv) if return_levels else out
+
+
+def nms_batched(boxes, counts, iou_thr, iou_mode=0, max_keep=0):
+    """boxes ``[P,nmax,5]`` sorted by descending score per problem, counts ``[P]`` i32 ->
+    ``keep [P,nmax]`` i32 (ascending indices), ``keep_count [P]`` i32.  No host sync."""
+    _require_cuda(boxes, counts)
+    lib = capi.load()
+    boxes = _f32c(boxes)
+    assert boxes.dim() == 3 and boxes.shape[2] == 5 and counts.dtype == torch.int32
+    P, nmax, _ = boxes.shape
+    dev = boxes.device
+    keep = torch.empty((P, nmax), dtype=torch.int32, device=dev)
+    keep_count = torch.empty((P,), dtype=torch.int32, device=dev)
+    ws = _workspace(lib.bgs_nms_workspace_bytes(P, nmax), dev)
+    rc = lib.bgs_nms_batched(capi.ptr(boxes), capi.ptr(counts), P, nmax, float(iou_thr),
+                             int(iou_mode), int(max_keep), capi.ptr(keep), capi.ptr(keep_count),
+                             capi.ptr(ws), capi.current_stream(dev))
+    capi.check('bgs_nms_batched', rc)
+    return keep, keep_count
+
+
 def selftest_wave_reduce(values):
     """Runs the device self-test of the wave reduction primitive (64 floats in)."""
     _require_cuda(values)

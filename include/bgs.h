@@ -134,6 +134,67 @@ int bgs_bbox_smooth_l1_fwd_bwd(const float* bbox_pred, const int64_t* labels,
                                float* loss_out, float* dbbox_pred, void* workspace,
                                bgs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Convolution / linear layer as an implicit GEMM on the fp32 matrix cores.
+ * Replaces what the reference delegates to cuDNN/cuBLAS via nn.Conv2d (+ eval-mode
+ * BatchNorm2d folded into w/bias, + ReLU, + residual add) and nn.Linear:
+ *   mmdet/models/backbones/resnet.py:220-266, mmdet/models/necks/fpn.py:101-141,
+ *   mmdet/models/anchor_heads/rpn_head.py:30-35, mmdet/models/bbox_heads/convfc_bbox_head.py:132-168.
+ *     y[n,ho,wo,j] = act( sum_{r,s,c} x[n, ho*stride-pad+r, wo*stride-pad+s, c] * w[j,r,s,c]
+ *                         + bias[j] + residual )
+ *   x [N,H,W,Cin] NHWC float (Cin % 4 == 0), w [Cout,R,S,Cin] float, bias [Cout] or NULL,
+ *   y [N,Ho,Wo,Cout] with Ho = (H + 2*pad - R)/stride + 1.
+ *   residual_mode 0: none; 1: residual [N,Ho,Wo,Cout] (bottleneck identity);
+ *                 2: residual [N,Ho/2,Wo/2,Cout] read with nearest-2x upsampling (FPN top-down,
+ *                    fpn.py:117-121).   relu != 0 applies max(.,0) last.
+ *   A linear layer is the H = W = R = S = 1 case: x [M,K], w [Cout,K].
+ *   Arithmetic: v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate, exact fma chain).
+ * ---------------------------------------------------------------------------------- */
+int bgs_conv2d_nhwc_f32(const float* x, const float* w, const float* bias, const float* residual,
+                        float* y, int N, int H, int W, int Cin, int Cout, int R, int S,
+                        int stride, int pad, int relu, int residual_mode, bgs_stream_t stream);
+
+/* 3x3 / stride 2 / pad 1 max pooling, NHWC (ResNet stem, resnet.py:452). C % 4 == 0.
+ * y [N, (H-1)/2+1, (W-1)/2+1, C]. */
+int bgs_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C,
+                              bgs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-level RoIAlign forward (NHWC).  Replaces SingleRoIExtractor.forward
+ *   (mmdet/models/roi_extractors/single_level.py:54-73,89-107) + RoIAlignFunction.forward
+ *   (mmdet/ops/roi_align/roi_align.py:12-29 -> src/roi_align_kernel.cu:16-124): level
+ *   = clamp(floor(log2(sqrt(w*h)/finest_scale + 1e-6)), 0, L-1) is evaluated in the kernel,
+ *   legacy box semantics (roi_end = (x2+1)*scale, samples outside [-1, H] x [-1, W] give 0),
+ *   sample_num = 2.
+ *   host_feats   [L] HOST array of device pointers to [num_images, H_l, W_l, C] float maps
+ *   host_heights/host_widths/host_scales [L] HOST arrays (H_l, W_l, 1/stride_l)
+ *   rois [K,5] float (batch_ind, x1, y1, x2, y2);  out [K, pooled_h, pooled_w, C] float
+ *   (bin-major, channels contiguous; the reference's [K,C,ph,pw] is the transpose);
+ *   levels_out [K] int32 or NULL (the level chosen per RoI, for tests).
+ * ---------------------------------------------------------------------------------- */
+int bgs_roi_align_nhwc_fwd(const float* const* host_feats, const int* host_heights,
+                           const int* host_widths, const float* host_scales, int num_levels,
+                           int num_images, float finest_scale, const float* rois, int K, int C,
+                           int pooled_h, int pooled_w, int sample_num, float* out,
+                           int* levels_out, bgs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Batched greedy NMS, entirely on the device.  Replaces ops.nms / nms_cuda
+ *   (mmdet/ops/nms/nms_wrapper.py:8-49, src/nms_kernel.cu:13-131; CPU variant nms_cpu.cpp:5-59)
+ *   for P independent problems at once (image x FPN level in the RPN,
+ *   mmdet/models/anchor_heads/rpn_head.py:92).
+ *   boxes [P, nmax, 5] float (x1,y1,x2,y2,score), each problem sorted by DESCENDING score;
+ *   counts [P] int32 (valid boxes per problem);  legacy +1 IoU;
+ *   iou_mode 0: suppress when IoU > thr (nms_cuda), 1: IoU >= thr (nms_cpu);
+ *   keep [P, nmax] int32: kept indices (into the sorted order, ascending), first
+ *   keep_count[p] entries valid, at most max_keep (<= 0: no limit);
+ *   workspace: bgs_nms_workspace_bytes(P, nmax).   nmax <= 4096.
+ * ---------------------------------------------------------------------------------- */
+size_t bgs_nms_workspace_bytes(int P, int nmax);
+int bgs_nms_batched(const float* boxes, const int* counts, int P, int nmax, float iou_thr,
+                    int iou_mode, int max_keep, int* keep, int* keep_count, void* workspace,
+                    bgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

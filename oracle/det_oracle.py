@@ -1,0 +1,156 @@
+"""TEST INFRASTRUCTURE ONLY (CPU oracle) — numpy restatements of the reference's native ops
+on the detector path.  Never imported by the product package.
+
+* ``roi_align_forward``  mmdet/ops/roi_align/src/roi_align_kernel.cu:16-124 (the reference has
+  NO CPU RoIAlign: roi_align.py:27-28 raises; CUDA is not compilable here) — parity of this
+  restatement is pinned only by analytic properties (tests/test_oracle_det.py), i.e.
+  "parity unpinned" against an executed reference.
+* ``map_roi_levels``     mmdet/models/roi_extractors/single_level.py:54-73
+* ``nms``                mmdet/ops/nms/src/nms_cpu.cpp:5-59 (``>=``) and
+                         mmdet/ops/nms/src/nms_kernel.cu:13-131 (``>``); the ``>=`` flavour is
+                         pinned against the COMPILED reference (oracle/_ref/nms_cpu_ref.so).
+* ``conv2d_nhwc``        the reference delegates to nn.Conv2d (torch); the oracle is torch-CPU
+                         F.conv2d in fp32 (fp64 for the "truth").
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+def map_roi_levels(rois, num_levels, finest_scale=56):
+    rois = np.asarray(rois, dtype=F32)
+    scale = np.sqrt((rois[:, 3] - rois[:, 1] + F32(1)) * (rois[:, 4] - rois[:, 2] + F32(1)))
+    lv = np.floor(np.log2(scale / F32(finest_scale) + F32(1e-6)))
+    return np.clip(lv, 0, num_levels - 1).astype(np.int64)
+
+
+def _bilinear(feat, H, W, y, x):
+    """feat [H, W, C] -> [C]; roi_align_kernel.cu:16-61 in fp32."""
+    if y < -1.0 or y > H or x < -1.0 or x > W:
+        return np.zeros(feat.shape[2], dtype=F32)
+    y = F32(max(y, 0.0))
+    x = F32(max(x, 0.0))
+    y_low, x_low = int(y), int(x)
+    if y_low >= H - 1:
+        y_high = y_low = H - 1
+        y = F32(y_low)
+    else:
+        y_high = y_low + 1
+    if x_low >= W - 1:
+        x_high = x_low = W - 1
+        x = F32(x_low)
+    else:
+        x_high = x_low + 1
+    ly, lx = F32(y - F32(y_low)), F32(x - F32(x_low))
+    hy, hx = F32(1.0) - ly, F32(1.0) - lx
+    w1, w2, w3, w4 = hy * hx, hy * lx, ly * hx, ly * lx
+    return (w1 * feat[y_low, x_low] + w2 * feat[y_low, x_high] + w3 * feat[y_high, x_low] +
+            w4 * feat[y_high, x_high]).astype(F32)
+
+
+def roi_align_forward(feat_nhwc, rois, spatial_scale, out_h=7, out_w=7, sample_num=2):
+    """Single level.  feat ``[N,H,W,C]`` fp32, rois ``[K,5]`` -> ``[K,out_h,out_w,C]``
+    (the reference's ``[K,C,ph,pw]`` is the (0,3,1,2) transpose of this)."""
+    feat = np.asarray(feat_nhwc, dtype=F32)
+    rois = np.asarray(rois, dtype=F32)
+    N, H, W, C = feat.shape
+    K = rois.shape[0]
+    ss = F32(spatial_scale)
+    out = np.zeros((K, out_h, out_w, C), dtype=F32)
+    for k in range(K):
+        b = int(rois[k, 0])
+        start_w, start_h = rois[k, 1] * ss, rois[k, 2] * ss
+        end_w, end_h = (rois[k, 3] + F32(1)) * ss, (rois[k, 4] + F32(1)) * ss
+        rw = F32(max(end_w - start_w, 0.0))
+        rh = F32(max(end_h - start_h, 0.0))
+        bh, bw = F32(rh / F32(out_h)), F32(rw / F32(out_w))
+        for ph in range(out_h):
+            for pw in range(out_w):
+                acc = np.zeros(C, dtype=F32)
+                for iy in range(sample_num):
+                    y = F32(start_h + F32(ph) * bh + F32(iy + 0.5) * bh / F32(sample_num))
+                    for ix in range(sample_num):
+                        x = F32(start_w + F32(pw) * bw + F32(ix + 0.5) * bw / F32(sample_num))
+                        acc += _bilinear(feat[b], H, W, y, x)
+                out[k, ph, pw] = acc / F32(sample_num * sample_num)
+    return out
+
+
+def roi_align_multilevel(feats_nhwc, rois, strides, out_size=7, sample_num=2, finest_scale=56):
+    """SingleRoIExtractor.forward (single_level.py:89-107)."""
+    lv = map_roi_levels(rois, len(feats_nhwc), finest_scale)
+    K = rois.shape[0]
+    C = feats_nhwc[0].shape[3]
+    out = np.zeros((K, out_size, out_size, C), dtype=F32)
+    for i, (f, s) in enumerate(zip(feats_nhwc, strides)):
+        idx = np.nonzero(lv == i)[0]
+        if idx.size:
+            out[idx] = roi_align_forward(f, rois[idx], 1.0 / s, out_size, out_size, sample_num)
+    return out, lv
+
+
+def nms(dets, thr, mode='cuda'):
+    """Greedy NMS on ``[n,5]`` (x1,y1,x2,y2,score), legacy +1 areas.  ``mode='cuda'``:
+    suppress on IoU > thr (nms_kernel.cu:60); ``'cpu'``: IoU >= thr (nms_cpu.cpp:55).
+    Returns kept ORIGINAL indices in ascending order (nms_kernel.cu:127-130, nms_cpu.cpp:58)."""
+    dets = np.asarray(dets, dtype=F32)
+    n = dets.shape[0]
+    if n == 0:
+        return np.zeros(0, dtype=np.int64)
+    x1, y1, x2, y2, sc = (dets[:, i] for i in range(5))
+    areas = (x2 - x1 + F32(1)) * (y2 - y1 + F32(1))
+    order = np.argsort(-sc, kind='stable')
+    suppressed = np.zeros(n, dtype=bool)
+    thr = F32(thr)
+    for _i in range(n):
+        i = order[_i]
+        if suppressed[i]:
+            continue
+        rest = order[_i + 1:]
+        xx1 = np.maximum(x1[i], x1[rest])
+        yy1 = np.maximum(y1[i], y1[rest])
+        xx2 = np.minimum(x2[i], x2[rest])
+        yy2 = np.minimum(y2[i], y2[rest])
+        w = np.maximum(F32(0), xx2 - xx1 + F32(1))
+        h = np.maximum(F32(0), yy2 - yy1 + F32(1))
+        inter = w * h
+        ovr = inter / (areas[i] + areas[rest] - inter)
+        hit = (ovr > thr) if mode == 'cuda' else (ovr >= thr)
+        suppressed[rest[hit]] = True
+    return np.nonzero(~suppressed)[0].astype(np.int64)
+
+
+def conv2d_nhwc(x_nhwc, w_oihw, bias=None, stride=1, pad=0, relu=False, residual=None,
+                dtype='float32'):
+    """torch-CPU reference of the fused conv (what nn.Conv2d + folded BN + ReLU compute)."""
+    import torch
+    import torch.nn.functional as Fn
+    dt = getattr(torch, dtype)
+    x = torch.from_numpy(np.ascontiguousarray(x_nhwc)).to(dt).permute(0, 3, 1, 2)
+    w = torch.from_numpy(np.ascontiguousarray(w_oihw)).to(dt)
+    b = None if bias is None else torch.from_numpy(np.ascontiguousarray(bias)).to(dt)
+    y = Fn.conv2d(x, w, b, stride=stride, padding=pad)
+    if residual is not None:
+        y = y + torch.from_numpy(np.ascontiguousarray(residual)).to(dt).permute(0, 3, 1, 2)
+    if relu:
+        y = torch.relu(y)
+    return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+def make_boxes(n, seed, img_w=1333, img_h=800, cluster=True):
+    """Score-unsorted synthetic detections with heavy overlaps (clustered around few centres)."""
+    rs = np.random.RandomState(seed)
+    if cluster:
+        nc = max(1, n // 12)
+        cx = rs.uniform(0, img_w, nc)[rs.randint(0, nc, n)] + rs.normal(0, 12, n)
+        cy = rs.uniform(0, img_h, nc)[rs.randint(0, nc, n)] + rs.normal(0, 12, n)
+    else:
+        cx, cy = rs.uniform(0, img_w, n), rs.uniform(0, img_h, n)
+    w = np.exp(rs.uniform(np.log(16), np.log(400), n))
+    h = np.exp(rs.uniform(np.log(16), np.log(400), n))
+    x1 = np.clip(cx - w / 2, 0, img_w - 1)
+    y1 = np.clip(cy - h / 2, 0, img_h - 1)
+    x2 = np.clip(cx + w / 2, 0, img_w - 1)
+    y2 = np.clip(cy + h / 2, 0, img_h - 1)
+    sc = rs.uniform(0, 1, n)
+    return np.stack([x1, y1, x2, y2, sc], 1).astype(F32)

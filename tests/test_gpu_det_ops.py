@@ -1,0 +1,153 @@
+"""GPU parity tests of the detector ops behind the C ABI: fp32-MFMA implicit-GEMM conv /
+linear, max pooling, multi-level RoIAlign, batched NMS — against the CPU oracles
+(oracle/det_oracle.py; torch-CPU conv; the compiled reference nms_cpu.cpp)."""
+import numpy as np
+import pytest
+import torch
+
+from balancedgroupsoftmax_amd import functional as BF
+from oracle import build_ref, det_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def krsc(w_oihw):
+    return np.ascontiguousarray(np.transpose(w_oihw, (0, 2, 3, 1)))
+
+
+CONV_CASES = [
+    # name, N, H, W, Cin, Cout, R, stride, pad, bias, relu, res_mode
+    ('1x1_small', 2, 25, 42, 64, 128, 1, 1, 0, True, True, 0),
+    ('3x3_res_relu', 2, 20, 30, 32, 96, 3, 1, 1, True, True, 1),
+    ('3x3_s2', 1, 33, 47, 16, 40, 3, 2, 1, False, False, 0),
+    ('7x7_stem', 1, 64, 96, 4, 64, 7, 2, 3, True, True, 0),
+    ('1x1_s2_downsample', 2, 28, 28, 64, 256, 1, 2, 0, True, False, 0),
+    ('fpn_lateral_upsample_add', 2, 16, 24, 48, 64, 1, 1, 0, True, False, 2),
+    ('tile_128x128', 2, 64, 128, 32, 512, 3, 1, 1, True, True, 0),
+    ('tile_128x64', 2, 128, 256, 16, 64, 1, 1, 0, True, False, 0),
+    ('ragged_cout_k', 1, 9, 11, 12, 70, 3, 1, 1, True, False, 0),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_vs_torch_cpu(case):
+    name, N, H, W, Cin, Cout, R, stride, pad, use_bias, relu, res_mode = case
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(name.encode()))
+    x = rs.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rs.standard_normal((Cout, Cin, R, R)) / np.sqrt(Cin * R * R)).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32) if use_bias else None
+    Ho = (H + 2 * pad - R) // stride + 1
+    Wo = (W + 2 * pad - R) // stride + 1
+    res = res_full = None
+    if res_mode == 1:
+        res = res_full = rs.standard_normal((N, Ho, Wo, Cout)).astype(np.float32)
+    elif res_mode == 2:
+        res = rs.standard_normal((N, Ho // 2, Wo // 2, Cout)).astype(np.float32)
+        res_full = np.repeat(np.repeat(res, 2, axis=1), 2, axis=2)   # F.interpolate(nearest, 2x)
+    y = BF.conv2d_nhwc(dev(x), dev(krsc(w)), None if b is None else dev(b), stride=stride, pad=pad,
+                       relu=relu, residual=None if res is None else dev(res),
+                       residual_mode=res_mode).cpu().numpy()
+    exp = det_oracle.conv2d_nhwc(x, w, b, stride, pad, relu, res_full, dtype='float64')
+    assert y.shape == exp.shape
+    err = np.abs(y - exp).max()
+    assert err < 2e-5 * max(1.0, np.abs(exp).max()), err
+    exp32 = det_oracle.conv2d_nhwc(x, w, b, stride, pad, relu, res_full)
+    assert np.abs(y - exp32).max() < 1e-4 * max(1.0, np.abs(exp32).max())
+
+
+def test_linear_matches_fc_shapes():
+    """RoI-head FC shapes (convfc_bbox_head.py): 12544 -> 1024 (+ReLU), 1024 -> 1236."""
+    rs = np.random.RandomState(5)
+    x = rs.standard_normal((130, 12544)).astype(np.float32)
+    w1 = (rs.standard_normal((1024, 12544)) / 112).astype(np.float32)
+    b1 = rs.standard_normal(1024).astype(np.float32)
+    h = BF.linear(dev(x), dev(w1), dev(b1), relu=True)
+    exp = np.maximum(x.astype(np.float64) @ w1.astype(np.float64).T + b1, 0)
+    assert np.abs(h.cpu().numpy() - exp).max() < 5e-5 * np.abs(exp).max()
+    w2 = (rs.standard_normal((1236, 1024)) / 32).astype(np.float32)
+    z = BF.linear(h, dev(w2), None)
+    exp2 = exp @ w2.astype(np.float64).T
+    assert np.abs(z.cpu().numpy() - exp2).max() < 5e-5 * np.abs(exp2).max()
+
+
+def test_maxpool3x3s2():
+    rs = np.random.RandomState(6)
+    for (N, H, W, C) in [(2, 17, 23, 8), (1, 64, 96, 64)]:
+        x = rs.standard_normal((N, H, W, C)).astype(np.float32)
+        y = BF.maxpool3x3s2_nhwc(dev(x)).cpu().numpy()
+        exp = torch.nn.functional.max_pool2d(torch.from_numpy(x).permute(0, 3, 1, 2), 3, 2, 1)
+        np.testing.assert_array_equal(y, exp.permute(0, 2, 3, 1).numpy())
+
+
+@pytest.mark.parametrize('C', [16, 256])
+def test_roi_align_multilevel_vs_oracle(C):
+    rs = np.random.RandomState(7 + C)
+    strides = [4, 8, 16, 32]
+    feats = [rs.standard_normal((2, 200 // (s // 4), 336 // (s // 4), C)).astype(np.float32)
+             for s in strides]
+    K = 48
+    wh = np.exp(rs.uniform(np.log(8), np.log(700), (K, 2)))
+    xy = np.stack([rs.uniform(-20, 1300, K), rs.uniform(-20, 780, K)], 1)
+    rois = np.concatenate([rs.randint(0, 2, (K, 1)), xy, xy + wh], 1).astype(np.float32)
+    rois[0] = [0, 5000, 5000, 5100, 5100]          # completely outside -> zeros
+    rois[1] = [1, 10, 10, 5, 5]                     # malformed (x2 < x1): width clamps to >= 0
+    rois[2:6] = [[0, 30, 40, 80, 100], [1, 30, 40, 180, 200], [0, 30, 40, 330, 360],
+                 [1, 30, 40, 700, 650]]             # one RoI for each of the four levels
+    out, lv = BF.roi_align_nhwc([dev(f) for f in feats], dev(rois), strides, return_levels=True)
+    exp, exp_lv = det_oracle.roi_align_multilevel(feats, rois, strides)
+    np.testing.assert_array_equal(lv.cpu().numpy(), exp_lv)
+    assert set(exp_lv.tolist()) == {0, 1, 2, 3}
+    err = np.abs(out.cpu().numpy() - exp).max()
+    # sample coordinates are fp32 chains whose fma contraction is compiler-defined (also in the
+    # reference's nvcc build): 1-ulp coordinate differences move a bilinear tap by ~1e-5
+    assert err < 1e-4 * max(1.0, np.abs(exp).max()), err
+    assert not out[0].any()
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_nms_batched_vs_oracle_and_reference(mode):
+    counts = [2000, 1337, 64, 65, 1, 0, 500]
+    nmax = 2000
+    P = len(counts)
+    boxes = np.zeros((P, nmax, 5), np.float32)
+    sorted_dets = []
+    for p, n in enumerate(counts):
+        d = det_oracle.make_boxes(n, seed=100 + p) if n else np.zeros((0, 5), np.float32)
+        d = d[np.argsort(-d[:, 4], kind='stable')]
+        boxes[p, :n] = d
+        sorted_dets.append(d)
+    thr = 0.7
+    keep, kc = BF.nms_batched(dev(boxes), torch.tensor(counts, dtype=torch.int32, device=DEV), thr,
+                              iou_mode=mode)
+    keep, kc = keep.cpu().numpy(), kc.cpu().numpy()
+    ref = build_ref.load_nms_cpu()
+    for p, n in enumerate(counts):
+        exp = det_oracle.nms(sorted_dets[p], thr, mode='cpu' if mode else 'cuda')
+        assert kc[p] == len(exp), (p, kc[p], len(exp))
+        np.testing.assert_array_equal(keep[p, :kc[p]], exp)
+        if mode == 1 and ref is not None and n:
+            r = ref.nms(torch.from_numpy(sorted_dets[p]), thr).numpy()
+            np.testing.assert_array_equal(keep[p, :kc[p]], r)
+
+
+def test_nms_properties_and_max_keep():
+    """Idempotence: NMS of the kept set keeps everything; max_keep truncates the prefix."""
+    d = det_oracle.make_boxes(1500, seed=9)
+    d = d[np.argsort(-d[:, 4], kind='stable')]
+    cnt = torch.tensor([1500], dtype=torch.int32, device=DEV)
+    keep, kc = BF.nms_batched(dev(d[None]), cnt, 0.5)
+    k = keep[0, :int(kc[0])].cpu().numpy()
+    kept = np.zeros((1, 1500, 5), np.float32)
+    kept[0, :len(k)] = d[k]
+    keep2, kc2 = BF.nms_batched(dev(kept), torch.tensor([len(k)], dtype=torch.int32, device=DEV), 0.5)
+    assert int(kc2[0]) == len(k)
+    np.testing.assert_array_equal(keep2[0, :len(k)].cpu().numpy(), np.arange(len(k)))
+    keep3, kc3 = BF.nms_batched(dev(d[None]), cnt, 0.5, max_keep=10)
+    assert int(kc3[0]) == 10
+    np.testing.assert_array_equal(keep3[0, :10].cpu().numpy(), k[:10])

@@ -1,0 +1,72 @@
+"""CPU: pins of the detector-op oracles (oracle/det_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import build_ref, det_oracle
+
+
+@pytest.fixture(scope='module')
+def ref_nms():
+    m = build_ref.load_nms_cpu()
+    if m is None:
+        pytest.skip('oracle/_ref/nms_cpu_ref.so not built and reference tree absent')
+    return m
+
+
+@pytest.mark.parametrize('n,seed', [(1, 0), (2, 1), (50, 2), (300, 3), (1000, 4)])
+@pytest.mark.parametrize('thr', [0.3, 0.5, 0.7])
+def test_nms_restatement_vs_compiled_reference(ref_nms, n, seed, thr):
+    """oracle nms(mode='cpu') == the reference's own nms_cpu.cpp compiled from source."""
+    dets = det_oracle.make_boxes(n, seed)
+    exp = ref_nms.nms(torch.from_numpy(dets), float(thr)).numpy()
+    got = det_oracle.nms(dets, thr, mode='cpu')
+    np.testing.assert_array_equal(got, exp)
+
+
+def test_nms_tie_semantics_differ_between_cpu_and_cuda(ref_nms):
+    """F8: IoU exactly == thr is suppressed by nms_cpu (>=) but kept by nms_cuda (>)."""
+    dets = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 4, 0.8]], dtype=np.float32)  # IoU = 0.5
+    assert ref_nms.nms(torch.from_numpy(dets), 0.5).tolist() == [0]
+    assert det_oracle.nms(dets, 0.5, 'cpu').tolist() == [0]
+    assert det_oracle.nms(dets, 0.5, 'cuda').tolist() == [0, 1]
+
+
+def test_nms_empty():
+    assert det_oracle.nms(np.zeros((0, 5), np.float32), 0.5).shape == (0,)
+
+
+def test_roi_align_analytic_properties():
+    """No executed reference exists for RoIAlign; the restatement must satisfy what the CUDA
+    kernel's formulas imply: constant map -> constant; f(y,x) = a*y + b*x + c -> value at the
+    mean sample position (interior RoIs); fully-outside RoI -> 0."""
+    H, W, C = 40, 50, 3
+    const = np.full((1, H, W, C), 2.5, np.float32)
+    rois = np.array([[0, 10, 8, 60, 70], [0, 0, 0, 30, 20]], np.float32)
+    out = det_oracle.roi_align_forward(const, rois, 0.25)
+    assert np.allclose(out, 2.5, atol=1e-6)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+    ramp = np.stack([0.5 * yy + 0.25 * xx + 1.0, yy * 1.0, xx * 1.0], -1)[None].astype(np.float32)
+    roi = np.array([[0, 40, 32, 120, 100]], np.float32)
+    out = det_oracle.roi_align_forward(ramp, roi, 0.25)
+    sw, sh = 40 * 0.25, 32 * 0.25
+    bw, bh = ((120 + 1) * 0.25 - sw) / 7, ((100 + 1) * 0.25 - sh) / 7
+    for ph in range(7):
+        for pw in range(7):
+            y = sh + (ph + 0.5) * bh
+            x = sw + (pw + 0.5) * bw
+            assert np.allclose(out[0, ph, pw], [0.5 * y + 0.25 * x + 1.0, y, x], atol=1e-4)
+    far = np.array([[0, 4000, 4000, 4100, 4100]], np.float32)
+    assert not det_oracle.roi_align_forward(ramp, far, 0.25).any()
+
+
+def test_map_roi_levels_matches_torch_formula():
+    rs = np.random.RandomState(0)
+    wh = np.exp(rs.uniform(np.log(4), np.log(900), (500, 2)))
+    xy = rs.uniform(0, 400, (500, 2))
+    rois = np.concatenate([np.zeros((500, 1)), xy, xy + wh], 1).astype(np.float32)
+    t = torch.from_numpy(rois)
+    scale = torch.sqrt((t[:, 3] - t[:, 1] + 1) * (t[:, 4] - t[:, 2] + 1))
+    exp = torch.floor(torch.log2(scale / 56 + 1e-6)).clamp(min=0, max=3).long().numpy()
+    np.testing.assert_array_equal(det_oracle.map_roi_levels(rois, 4), exp)
+    assert set(exp.tolist()) == {0, 1, 2, 3}
