@@ -3,7 +3,7 @@
 Hand-written gfx950 HIP kernels behind a C ABI (``include/bgs.h`` -> ``libbgs.so``), driven
 from PyTorch-ROCm through the reference's own registry keys and config schema.
 """
-from . import bbox_heads, losses  # noqa: F401  (populate the registries)
+from . import backbone, bbox_heads, detectors, losses, roi_extractor, rpn  # noqa: F401  (populate the registries)
 from .builder import (build_backbone, build_detector, build_head, build_loss, build_neck,
                       build_roi_extractor, build_shared_head)
 from .config import Config, ConfigDict

@@ -1,0 +1,262 @@
+"""ResNet trunk + FPN neck behind the reference's ``BACKBONES`` / ``NECKS`` registry keys.
+
+* ``ResNet``  mmdet/models/backbones/resnet.py:332-542 (Bottleneck :86-266, style='pytorch':
+  stride on the 3x3 conv; ``frozen_stages``; ``norm_eval=True`` => BatchNorm always uses its
+  running statistics, :535-542)
+* ``FPN``     mmdet/models/necks/fpn.py:9-141
+
+Parameter *names and shapes* are the reference's (``conv1.weight``, ``layer2.0.bn1.running_var``,
+``layer1.0.downsample.0.weight``, ``lateral_convs.1.conv.bias`` ...), so reference checkpoints
+load unchanged — the ``nn.Conv2d`` / ``nn.BatchNorm2d`` objects are parameter containers only.
+The arithmetic runs in the fp32-MFMA implicit-GEMM kernel (csrc/conv_igemm.hip):
+
+* activations are NHWC end to end (channels = GEMM K axis contiguous);
+* eval-mode BatchNorm is folded into the conv weights/bias (legal because ``norm_eval=True``),
+  weights are re-laid-out once to ``[Cout, R, S, Cin]``; the fold is cached and refreshed
+  when a parameter's version counter changes (load_state_dict, optimizer step);
+* bias, residual add and ReLU are fused into the conv epilogue; the FPN top-down
+  ``lateral + nearest_2x(upper)`` is the epilogue's upsampled-residual mode.
+
+Scope: forward only.  Every shipped BAGS config trains only ``bbox_head.fc_cls``
+(``selectp=1``, tools/train.py:49-57); a backbone parameter that requires grad raises.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as BF
+from .registry import BACKBONES, NECKS
+
+
+def _fold_conv_bn(conv, bn, pad_cin_to=None):
+    """-> (w [Cout,R,S,Cin] contiguous, bias [Cout]) with the eval-mode BN folded in."""
+    w = conv.weight.detach().float()
+    cout = w.shape[0]
+    if bn is not None:
+        scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+        shift = bn.bias.detach().float() - bn.running_mean.float() * scale
+        w = w * scale.view(-1, 1, 1, 1)
+        b = shift if conv.bias is None else shift + conv.bias.detach().float() * scale
+    else:
+        b = conv.bias.detach().float() if conv.bias is not None else w.new_zeros(cout)
+    w = w.permute(0, 2, 3, 1)
+    if pad_cin_to is not None and w.shape[3] < pad_cin_to:
+        w = torch.nn.functional.pad(w, (0, pad_cin_to - w.shape[3]))
+    return w.contiguous(), b.contiguous()
+
+
+class _FoldCache(object):
+    """Folded weights keyed by parameter version counters."""
+
+    def __init__(self):
+        self.key = None
+        self.data = None
+
+    def get(self, module, build):
+        key = tuple((id(t), t._version, t.device) for t in
+                    list(module.parameters()) + list(module.buffers()))
+        if key != self.key:
+            self.data = build()
+            self.key = key
+        return self.data
+
+
+def _check_frozen(module, what):
+    if torch.is_grad_enabled():
+        for n, p in module.named_parameters():
+            if p.requires_grad:
+                raise NotImplementedError(
+                    '%s.%s requires grad: backward through the conv stack is not implemented '
+                    '(the shipped BAGS configs train fc_cls only: selectp=1). Freeze it or run '
+                    'under torch.no_grad().' % (what, n))
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.stride = stride
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * 4))
+
+    def folded(self):
+        f = dict(c1=_fold_conv_bn(self.conv1, self.bn1), c2=_fold_conv_bn(self.conv2, self.bn2),
+                 c3=_fold_conv_bn(self.conv3, self.bn3))
+        if self.downsample is not None:
+            f['ds'] = _fold_conv_bn(self.downsample[0], self.downsample[1])
+        return f
+
+    def run(self, x, f):
+        identity = x
+        if 'ds' in f:
+            identity = BF.conv2d_nhwc(x, f['ds'][0], f['ds'][1], stride=self.stride)
+        out = BF.conv2d_nhwc(x, f['c1'][0], f['c1'][1], relu=True)
+        out = BF.conv2d_nhwc(out, f['c2'][0], f['c2'][1], stride=self.stride, pad=1, relu=True)
+        return BF.conv2d_nhwc(out, f['c3'][0], f['c3'][1], relu=True, residual=identity)
+
+
+@BACKBONES.register_module
+class ResNet(nn.Module):
+    arch_settings = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+    def __init__(self, depth, num_stages=4, strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1),
+                 out_indices=(0, 1, 2, 3), style='pytorch', frozen_stages=-1, conv_cfg=None,
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, dcn=None,
+                 stage_with_dcn=(False, False, False, False), gcb=None,
+                 stage_with_gcb=(False, False, False, False), gen_attention=None,
+                 stage_with_gen_attention=((), (), (), ()), with_cp=False,
+                 zero_init_residual=True):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError('invalid depth {} for resnet (bottleneck depths only)'.format(depth))
+        if style != 'pytorch' or tuple(dilations) != (1, 1, 1, 1) or dcn or gcb or gen_attention:
+            raise NotImplementedError('only the plain pytorch-style trunk of the BAGS configs')
+        if norm_cfg.get('type', 'BN') != 'BN' or not norm_eval:
+            raise NotImplementedError('BatchNorm in eval mode only (norm_eval=True is what every '
+                                      'BAGS config uses); it is folded into the convs')
+        self.depth, self.num_stages = depth, num_stages
+        self.out_indices, self.frozen_stages, self.norm_eval = out_indices, frozen_stages, norm_eval
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        blocks = self.arch_settings[depth][:num_stages]
+        inplanes = 64
+        self.res_layers = []
+        for i, nb in enumerate(blocks):
+            planes = 64 * 2 ** i
+            layers = []
+            for j in range(nb):
+                stride = strides[i] if j == 0 else 1
+                layers.append(Bottleneck(inplanes, planes, stride,
+                                         downsample=(j == 0 and (stride != 1 or
+                                                                 inplanes != planes * 4))))
+                inplanes = planes * 4
+            name = 'layer{}'.format(i + 1)
+            self.add_module(name, nn.Sequential(*layers))
+            self.res_layers.append(name)
+        self.feat_dim = inplanes
+        self._cache = _FoldCache()
+        self._freeze_stages()
+
+    def _freeze_stages(self):
+        """resnet.py:483-494."""
+        if self.frozen_stages >= 0:
+            for m in (self.conv1, self.bn1):
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            for p in getattr(self, 'layer{}'.format(i)).parameters():
+                p.requires_grad = False
+
+    def init_weights(self, pretrained=None):
+        """resnet.py:496-520 (kaiming for convs, BN = 1/0, zero-init of the last BN)."""
+        if pretrained is not None:
+            raise NotImplementedError('no network / model zoo in this environment: load a '
+                                      'state_dict explicitly')
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        for m in self.modules():
+            if isinstance(m, Bottleneck):
+                nn.init.constant_(m.bn3.weight, 0)
+
+    def _build_fold(self):
+        f = dict(stem=_fold_conv_bn(self.conv1, self.bn1, pad_cin_to=4), blocks=[])
+        for name in self.res_layers:
+            f['blocks'].append([blk.folded() for blk in getattr(self, name)])
+        return f
+
+    @staticmethod
+    def to_nhwc4(img):
+        """NCHW image batch -> NHWC with the channel axis zero-padded to 4 (16-byte pixels)."""
+        x = img.float().permute(0, 2, 3, 1)
+        return torch.nn.functional.pad(x, (0, 4 - x.shape[3])).contiguous()
+
+    def forward(self, img):
+        """img ``[N,3,H,W]`` (as the reference) -> tuple of NHWC feature maps."""
+        _check_frozen(self, 'backbone')
+        f = self._cache.get(self, self._build_fold)
+        x = self.to_nhwc4(img)
+        x = BF.conv2d_nhwc(x, f['stem'][0], f['stem'][1], stride=2, pad=3, relu=True)
+        x = BF.maxpool3x3s2_nhwc(x)
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            for blk, bf in zip(getattr(self, name), f['blocks'][i]):
+                x = blk.run(x, bf)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        return self
+
+
+class ConvModule(nn.Module):
+    """Container with the reference's ``.conv`` attribute name (mmdet/models/utils/conv_module.py)."""
+
+    def __init__(self, cin, cout, k, padding=0):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=padding)
+        self.padding = padding
+
+
+@NECKS.register_module
+class FPN(nn.Module):
+
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1,
+                 add_extra_convs=False, extra_convs_on_inputs=True,
+                 relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None,
+                 norm_cfg=None, activation=None):
+        super().__init__()
+        assert isinstance(in_channels, list)
+        if add_extra_convs or norm_cfg is not None or activation is not None or start_level != 0 \
+                or end_level != -1:
+            raise NotImplementedError('FPN variant outside the BAGS configs')
+        self.in_channels, self.out_channels, self.num_outs = in_channels, out_channels, num_outs
+        self.num_ins = len(in_channels)
+        self.lateral_convs = nn.ModuleList(ConvModule(c, out_channels, 1) for c in in_channels)
+        self.fpn_convs = nn.ModuleList(ConvModule(out_channels, out_channels, 3, padding=1)
+                                       for _ in in_channels)
+        self._cache = _FoldCache()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.constant_(m.bias, 0)
+
+    def _build_fold(self):
+        return dict(lat=[_fold_conv_bn(m.conv, None) for m in self.lateral_convs],
+                    out=[_fold_conv_bn(m.conv, None) for m in self.fpn_convs])
+
+    def forward(self, inputs):
+        """inputs: NHWC C2..C5 -> NHWC P2..P6 (fpn.py:101-141)."""
+        assert len(inputs) == self.num_ins
+        _check_frozen(self, 'neck')
+        f = self._cache.get(self, self._build_fold)
+        n = self.num_ins
+        lat = [None] * n
+        lat[n - 1] = BF.conv2d_nhwc(inputs[n - 1], *f['lat'][n - 1])
+        for i in range(n - 2, -1, -1):   # lateral_i + nearest_2x(lateral_{i+1}), fused
+            lat[i] = BF.conv2d_nhwc(inputs[i], *f['lat'][i], residual=lat[i + 1], residual_mode=2)
+        outs = [BF.conv2d_nhwc(lat[i], *f['out'][i], pad=1) for i in range(n)]
+        for _ in range(self.num_outs - n):   # F.max_pool2d(x, 1, stride=2) == subsampling
+            outs.append(outs[-1][:, ::2, ::2, :].contiguous())
+        return tuple(outs)

@@ -248,24 +248,54 @@ class ConvFCBBoxHead(BBoxHead):
                 nn.init.xavier_uniform_(m.weight)
                 nn.init.constant_(m.bias, 0)
 
-    def forward(self, x):
-        if self.num_shared_fcs > 0:
-            if self.with_avg_pool:
-                x = self.avg_pool(x)
-            x = x.view(x.size(0), -1)
-            for fc in self.shared_fcs:
-                x = self.relu(fc(x))
+    def _fc1_weight(self, fc, nhwc):
+        """First FC weight as seen by a bin-major ``[K, h, w, C]`` RoI feature (our RoIAlign
+        layout): column ``(h*w_ + w)*C + c`` <- reference column ``c*h_*w_ + h*w_ + w``.
+        Cached per parameter version."""
+        if not nhwc:
+            return fc.weight
+        key = (id(fc.weight), fc.weight._version, fc.weight.device)
+        if getattr(self, '_fc1_key', None) != key:
+            O = fc.weight.shape[0]
+            C = self.in_channels
+            w = fc.weight.detach().view(O, C, self.roi_feat_area).permute(0, 2, 1)
+            self._fc1_perm = w.reshape(O, -1).contiguous()
+            self._fc1_key = key
+        if fc.weight.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError('training the first shared FC with NHWC RoI features')
+        return self._fc1_perm
+
+    def forward(self, x, nhwc=False):
+        """``x``: RoI features ``[K, C, h, w]`` (reference layout) or, with ``nhwc=True``,
+        ``[K, h, w, C]`` as produced by our RoIAlign.  On the GPU every FC runs in the fp32-MFMA
+        GEMM kernel (bias + ReLU fused); on the CPU (shape checks only) plain nn.Linear."""
+        hip = x.is_cuda
+        if self.with_avg_pool:
+            if nhwc:
+                raise NotImplementedError('with_avg_pool on NHWC RoI features')
+            x = self.avg_pool(x)
+        x = x.reshape(x.size(0), -1)
+
+        def fc_apply(fc, t, relu, first=False):
+            if not hip:
+                y = fc(t)
+                return self.relu(y) if relu else y
+            w = self._fc1_weight(fc, nhwc) if first else fc.weight
+            return BF.linear_autograd(t, w, fc.bias, relu=relu)
+
+        first = True
+        for fc in self.shared_fcs:
+            x = fc_apply(fc, x, True, first)
+            first = False
         x_cls = x_reg = x
-        if x_cls.dim() > 2:
-            if self.with_avg_pool:
-                x_cls = x_reg = self.avg_pool(x)
-            x_cls = x_reg = x_cls.view(x_cls.size(0), -1)
         for fc in self.cls_fcs:
-            x_cls = self.relu(fc(x_cls))
+            x_cls = fc_apply(fc, x_cls, True, first and self.num_shared_fcs == 0)
         for fc in self.reg_fcs:
-            x_reg = self.relu(fc(x_reg))
-        cls_score = self.fc_cls(x_cls) if self.with_cls else None
-        bbox_pred = self.fc_reg(x_reg) if self.with_reg else None
+            x_reg = fc_apply(fc, x_reg, True, first and self.num_shared_fcs == 0)
+        if nhwc and self.num_shared_fcs == 0:
+            raise NotImplementedError('NHWC RoI features need a shared first FC')
+        cls_score = fc_apply(self.fc_cls, x_cls, False) if self.with_cls else None
+        bbox_pred = fc_apply(self.fc_reg, x_reg, False) if self.with_reg else None
         return cls_score, bbox_pred
 
 

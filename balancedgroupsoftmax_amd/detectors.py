@@ -1,0 +1,145 @@
+"""Two-stage detectors behind the reference's ``DETECTORS`` registry keys.
+
+* ``TwoStageDetector``  mmdet/models/detectors/two_stage.py:12-290 (forward_train :134-265)
+* ``FasterRCNN``        mmdet/models/detectors/faster_rcnn.py
+* ``GroupSoftmax``      mmdet/models/detectors/group_softmax.py:7-29 (an empty subclass)
+
+``forward_train`` returns the reference's loss dict (``loss_rpn_cls``/``loss_rpn_bbox``: lists
+over the 5 levels, ``loss_cls_bin0..B-1``, ``loss_bbox``).  The orchestration differs where the
+reference synchronises with the host: proposals, RoI assignment and sampling are fixed-shape
+device tensors here (assign.py), so one training iteration issues no ``.item()`` /
+``nonzero()`` / D2H copy at all.
+"""
+import torch
+import torch.nn as nn
+
+from . import assign as A
+from . import builder
+from .box_ops import bbox2delta
+from .registry import DETECTORS
+
+
+@DETECTORS.register_module
+class TwoStageDetector(nn.Module):
+
+    def __init__(self, backbone, neck=None, shared_head=None, rpn_head=None,
+                 bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None,
+                 train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        if shared_head is not None or mask_head is not None or mask_roi_extractor is not None:
+            raise NotImplementedError('shared_head / mask branch: not built in this round '
+                                      '(SURVEY.md §8f rank 3)')
+        self.backbone = builder.build_backbone(backbone)
+        self.neck = builder.build_neck(neck) if neck is not None else None
+        self.rpn_head = builder.build_head(rpn_head) if rpn_head is not None else None
+        self.bbox_roi_extractor = builder.build_roi_extractor(bbox_roi_extractor) \
+            if bbox_head is not None else None
+        self.bbox_head = builder.build_head(bbox_head) if bbox_head is not None else None
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.fp16_enabled = False
+        self.init_weights(pretrained=pretrained)
+
+    with_neck = property(lambda self: self.neck is not None)
+    with_rpn = property(lambda self: self.rpn_head is not None)
+    with_bbox = property(lambda self: self.bbox_head is not None)
+    with_mask = property(lambda self: False)
+    with_shared_head = property(lambda self: False)
+
+    def init_weights(self, pretrained=None):
+        if isinstance(pretrained, str):
+            # 'torchvision://resnet50' etc.: there is no network here; weights stay at their
+            # random init until a state_dict is loaded explicitly.
+            pretrained = None
+        self.backbone.init_weights(pretrained=pretrained)
+        if self.with_neck:
+            self.neck.init_weights()
+        if self.with_rpn:
+            self.rpn_head.init_weights()
+        if self.with_bbox:
+            self.bbox_roi_extractor.init_weights()
+            self.bbox_head.init_weights()
+
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        return self.neck(x) if self.with_neck else x
+
+    # -- RoI assignment + sampling (two_stage.py:192-210), fixed shape ---------------------
+    def _assign_and_sample(self, proposals, prop_valid, gt_bboxes, gt_labels, generator=None):
+        """One image.  Returns dict of fixed-size tensors for ``num`` sampled RoIs:
+        ``bboxes [num,4]``, ``is_pos``, ``valid``, ``labels``, ``gt_bboxes`` (of positives)."""
+        rc = self.train_cfg.rcnn
+        ac, sc = rc.assigner, rc.sampler
+        boxes = proposals[:, :4]
+        overlaps = A.bbox_overlaps(gt_bboxes, boxes)
+        assigned, _ = A.max_iou_assign(overlaps, ac.pos_iou_thr, ac.neg_iou_thr,
+                                       ac.get('min_pos_iou', 0.0),
+                                       ac.get('gt_max_assign_all', True), valid=prop_valid)
+        G = gt_bboxes.size(0)
+        if sc.get('add_gt_as_proposals', True):
+            # base_sampler.py:49-53 + AssignResult.add_gt_: GTs are prepended and own themselves
+            boxes = torch.cat([gt_bboxes, boxes], 0)
+            assigned = torch.cat([torch.arange(1, G + 1, device=boxes.device), assigned])
+        inds, is_pos, valid = A.sample_fixed(assigned, sc.num, sc.pos_fraction, generator)
+        a = assigned[inds]
+        gi = (a - 1).clamp(min=0)
+        labels = torch.where(is_pos, gt_labels[gi], torch.zeros_like(gt_labels[gi]))
+        return dict(bboxes=boxes[inds], is_pos=is_pos, valid=valid, labels=labels,
+                    gt_bboxes=gt_bboxes[gi])
+
+    def _bbox_targets(self, samples):
+        """``bbox_target`` (mmdet/core/bbox/bbox_target.py:7-61) on the fixed-size samples."""
+        rc = self.train_cfg.rcnn
+        head = self.bbox_head
+        labels, lw, bt, bw = [], [], [], []
+        for s in samples:
+            pos = s['is_pos'] & s['valid']
+            posf = pos.float()
+            d = bbox2delta(s['bboxes'], s['gt_bboxes'], head.target_means, head.target_stds)
+            labels.append(torch.where(pos, s['labels'], torch.zeros_like(s['labels'])))
+            pw = 1.0 if rc.pos_weight <= 0 else rc.pos_weight
+            lw.append(posf * pw + (s['valid'] & ~s['is_pos']).float())
+            bt.append(d * posf[:, None])
+            bw.append(posf[:, None].expand(-1, 4).contiguous())
+        return torch.cat(labels), torch.cat(lw), torch.cat(bt), torch.cat(bw)
+
+    def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
+                      gt_masks=None, proposals=None, generator=None):
+        x = self.extract_feat(img)
+        losses = dict()
+        if self.with_rpn:
+            cls_scores, bbox_preds = self.rpn_head(x)
+            losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
+                                             self.train_cfg.rpn, generator=generator))
+            proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
+            proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_meta, proposal_cfg)
+        else:
+            proposal_list = [(p, torch.ones(p.size(0), dtype=torch.bool, device=p.device))
+                             for p in proposals]
+        if self.with_bbox:
+            samples = [self._assign_and_sample(proposal_list[i][0], proposal_list[i][1],
+                                               gt_bboxes[i], gt_labels[i], generator)
+                       for i in range(img.size(0))]
+            rois = torch.cat([torch.cat([s['bboxes'].new_full((s['bboxes'].size(0), 1), i),
+                                         s['bboxes']], 1) for i, s in enumerate(samples)], 0)
+            bbox_feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
+            cls_score, bbox_pred = self.bbox_head(bbox_feats, nhwc=True)
+            targets = self._bbox_targets(samples)
+            losses.update(self.bbox_head.loss(cls_score, bbox_pred, *targets))
+        return losses
+
+    def forward(self, img, img_meta, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_meta, **kwargs)
+        raise NotImplementedError('test-time path (simple_test / multiclass NMS) is a later row '
+                                  '(SURVEY.md §8f rank 2)')
+
+
+@DETECTORS.register_module
+class FasterRCNN(TwoStageDetector):
+    pass
+
+
+@DETECTORS.register_module
+class GroupSoftmax(TwoStageDetector):
+    """group_softmax.py:7-29: identical orchestration; the BAGS logic lives in the bbox head."""
+    pass

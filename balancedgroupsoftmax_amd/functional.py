@@ -264,8 +264,50 @@ def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None
 def linear(x, weight, bias=None, relu=False):
     """``act(x @ weight.T + bias)`` for ``x [M,K]``, ``weight [Cout,K]`` (nn.Linear layout)."""
     M, K = x.shape
-    y = conv2d_nhwc(x.view(M, 1, 1, K), weight.view(weight.shape[0], 1, 1, K), bias, relu=relu)
+    x = _f32c(x)
+    weight = _f32c(weight)
+    y = conv2d_nhwc(x.view(M, 1, 1, K), weight.view(weight.shape[0], 1, 1, K),
+                    None if bias is None else _f32c(bias), relu=relu)
     return y.view(M, weight.shape[0])
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b on the fp32 matrix cores, with gradients for x, W, b.
+
+    dW = dY^T X and dX = dY W are the same implicit-GEMM kernel fed with transposed copies
+    (both operands must be K-contiguous).  Under selectp=1 only ``fc_cls`` takes this path:
+    dW_cls = dlogits^T x is 1.3 GMAC."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return linear(x.detach(), weight.detach(), None if bias is None else bias.detach())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous().float()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = linear(gy, weight.detach().t().contiguous())            # [M,N] x [K,N]^T
+        if ctx.needs_input_grad[1]:
+            gw = linear(gy.t().contiguous(), x.detach().t().contiguous())  # [N,M] x [K,M]^T
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb
+
+
+def linear_autograd(x, weight, bias=None, relu=False):
+    """``act(x @ weight.T + bias)``: fused forward-only kernel when nothing requires grad,
+    otherwise the differentiable path (ReLU applied outside the kernel)."""
+    needs = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or
+                                         (bias is not None and bias.requires_grad))
+    if not needs:
+        return linear(x, weight, bias, relu=relu)
+    y = _LinearFn.apply(x, weight, bias)
+    return torch.relu(y) if relu else y
 
 
 def maxpool3x3s2_nhwc(x):

@@ -57,11 +57,9 @@ def sigmoid_bce(pred, label, weight=None, reduction='mean', avg_factor=None):
     """RPN objectness mode.  Integer class labels are expanded to one-hot over
     ``pred.size(-1)`` channels with label c>=1 -> channel c-1 (cross_entropy_loss.py:22-32)."""
     if pred.dim() != label.dim():
-        onehot = label.new_zeros((label.size(0), pred.size(-1)))
-        rows = (label >= 1).nonzero(as_tuple=True)[0]
-        if rows.numel() > 0:
-            onehot[rows, label[rows] - 1] = 1
-        label = onehot
+        # label c >= 1 -> channel c-1 (no nonzero(): that would be a host sync)
+        chan = torch.arange(1, pred.size(-1) + 1, device=label.device, dtype=label.dtype)
+        label = (label.view(-1, 1) == chan.view(1, -1)).to(label.dtype)
         if weight is not None:
             weight = weight.view(-1, 1).expand(weight.size(0), pred.size(-1))
     w = None if weight is None else weight.float()

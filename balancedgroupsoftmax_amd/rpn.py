@@ -1,0 +1,271 @@
+"""Region proposal network behind the reference's ``RPNHead`` registry key.
+
+* ``AnchorGenerator``  mmdet/core/anchor/anchor_generator.py:4-83 (known-answer doctest :7-14)
+* ``RPNHead``          mmdet/models/anchor_heads/rpn_head.py:12-104 on top of
+  ``AnchorHead`` mmdet/models/anchor_heads/anchor_head.py:15-276 and ``anchor_target``
+  mmdet/core/anchor/anchor_target.py:7-159
+
+Differences in *how*, not *what*:
+* the shared 3x3 conv (+ReLU) and the two 1x1 heads run in the fp32-MFMA conv kernel; the
+  1x1 ``rpn_cls`` / ``rpn_reg`` are evaluated as ONE conv with concatenated output channels;
+* outputs stay NHWC ``[N,H,W,A]`` / ``[N,H,W,4A]`` — exactly the ``permute(0,2,3,1)`` order the
+  reference flattens to (anchor_head.py:150-158, rpn_head.py:69-77);
+* targets: all anchors of an image are assigned in one vectorised pass on the device
+  (assign.py), no CPU fallback for >50 GTs, no numpy shuffles, no ``nonzero``;
+* proposals: the 5 levels x N images go through ONE batched on-device NMS launch pair
+  (csrc/nms.hip) instead of 10 ``nms_cuda`` calls with a D2H copy each (rpn_head.py:92).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import assign as A
+from . import functional as BF
+from .backbone import _check_frozen, _fold_conv_bn, _FoldCache
+from .box_ops import bbox2delta, delta2bbox
+from .builder import build_loss
+from .registry import HEADS
+
+
+class AnchorGenerator(object):
+    """Known answer (reference doctest): ``AnchorGenerator(9, [1.], [1.]).grid_anchors((2, 2),
+    stride=16)`` -> [[0,0,8,8],[16,0,24,8],[0,16,8,24],[16,16,24,24]]."""
+
+    def __init__(self, base_size, scales, ratios, scale_major=True, ctr=None):
+        self.base_size = base_size
+        self.scales = torch.tensor(scales, dtype=torch.float32)
+        self.ratios = torch.tensor(ratios, dtype=torch.float32)
+        self.scale_major = scale_major
+        self.ctr = ctr
+        self.base_anchors = self.gen_base_anchors()
+
+    @property
+    def num_base_anchors(self):
+        return self.base_anchors.size(0)
+
+    def gen_base_anchors(self):
+        w = h = float(self.base_size)
+        x_ctr, y_ctr = (0.5 * (w - 1), 0.5 * (h - 1)) if self.ctr is None else self.ctr
+        h_ratios = torch.sqrt(self.ratios)
+        w_ratios = 1 / h_ratios
+        if self.scale_major:
+            ws = (w * w_ratios[:, None] * self.scales[None, :]).view(-1)
+            hs = (h * h_ratios[:, None] * self.scales[None, :]).view(-1)
+        else:
+            ws = (w * self.scales[:, None] * w_ratios[None, :]).view(-1)
+            hs = (h * self.scales[:, None] * h_ratios[None, :]).view(-1)
+        return torch.stack([x_ctr - 0.5 * (ws - 1), y_ctr - 0.5 * (hs - 1),
+                            x_ctr + 0.5 * (ws - 1), y_ctr + 0.5 * (hs - 1)], dim=-1).round()
+
+    def grid_anchors(self, featmap_size, stride=16, device='cuda'):
+        """``[H*W*A, 4]`` ordered (y, x, anchor)."""
+        base = self.base_anchors.to(device)
+        fh, fw = featmap_size
+        sx = torch.arange(0, fw, device=device, dtype=torch.float32) * stride
+        sy = torch.arange(0, fh, device=device, dtype=torch.float32) * stride
+        yy, xx = torch.meshgrid(sy, sx, indexing='ij')
+        shifts = torch.stack([xx, yy, xx, yy], dim=-1).view(-1, 1, 4)
+        return (base[None] + shifts).view(-1, 4)
+
+    def valid_flags(self, featmap_size, valid_size, device='cuda'):
+        fh, fw = featmap_size
+        vh, vw = valid_size
+        assert vh <= fh and vw <= fw
+        vx = torch.arange(fw, device=device) < vw
+        vy = torch.arange(fh, device=device) < vh
+        valid = (vy[:, None] & vx[None, :]).view(-1)
+        return valid[:, None].expand(valid.size(0), self.num_base_anchors).reshape(-1)
+
+
+@HEADS.register_module
+class RPNHead(nn.Module):
+
+    def __init__(self, in_channels, feat_channels=256, anchor_scales=[8, 16, 32],
+                 anchor_ratios=[0.5, 1.0, 2.0], anchor_strides=[4, 8, 16, 32, 64],
+                 anchor_base_sizes=None, target_means=(.0, .0, .0, .0),
+                 target_stds=(1.0, 1.0, 1.0, 1.0),
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0)):
+        super().__init__()
+        self.in_channels, self.feat_channels = in_channels, feat_channels
+        self.num_classes = 2
+        self.anchor_scales, self.anchor_ratios = anchor_scales, anchor_ratios
+        self.anchor_strides = anchor_strides
+        self.anchor_base_sizes = list(anchor_strides) if anchor_base_sizes is None \
+            else anchor_base_sizes
+        self.target_means, self.target_stds = target_means, target_stds
+        self.use_sigmoid_cls = loss_cls.get('use_sigmoid', False)
+        if not self.use_sigmoid_cls:
+            raise NotImplementedError('RPN objectness: sigmoid mode only (all BAGS configs)')
+        self.sampling = True
+        self.cls_out_channels = 1
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.fp16_enabled = False
+        self.anchor_generators = [AnchorGenerator(b, anchor_scales, anchor_ratios)
+                                  for b in self.anchor_base_sizes]
+        self.num_anchors = len(anchor_ratios) * len(anchor_scales)
+        self.rpn_conv = nn.Conv2d(in_channels, feat_channels, 3, padding=1)
+        self.rpn_cls = nn.Conv2d(feat_channels, self.num_anchors * self.cls_out_channels, 1)
+        self.rpn_reg = nn.Conv2d(feat_channels, self.num_anchors * 4, 1)
+        self._cache = _FoldCache()
+        self._anchor_cache = {}
+
+    def init_weights(self):
+        for m in (self.rpn_conv, self.rpn_cls, self.rpn_reg):
+            nn.init.normal_(m.weight, 0, 0.01)
+            nn.init.constant_(m.bias, 0)
+
+    # -- forward ------------------------------------------------------------------------
+    def _build_fold(self):
+        wc, bc = _fold_conv_bn(self.rpn_cls, None)
+        wr, br = _fold_conv_bn(self.rpn_reg, None)
+        return dict(conv=_fold_conv_bn(self.rpn_conv, None),
+                    head=(torch.cat([wc, wr], 0).contiguous(), torch.cat([bc, br], 0).contiguous()))
+
+    def forward(self, feats):
+        """NHWC feature maps -> (cls_scores, bbox_preds): per level ``[N,H,W,A]``, ``[N,H,W,4A]``."""
+        _check_frozen(self, 'rpn_head')
+        f = self._cache.get(self, self._build_fold)
+        cls_scores, bbox_preds = [], []
+        na = self.num_anchors * self.cls_out_channels
+        for x in feats:
+            h = BF.conv2d_nhwc(x, f['conv'][0], f['conv'][1], pad=1, relu=True)
+            o = BF.conv2d_nhwc(h, f['head'][0], f['head'][1])
+            cls_scores.append(o[..., :na])
+            bbox_preds.append(o[..., na:])
+        return cls_scores, bbox_preds
+
+    # -- anchors ------------------------------------------------------------------------
+    def _level_anchors(self, featmap_sizes, device):
+        key = (tuple(featmap_sizes), str(device))
+        if key not in self._anchor_cache:
+            self._anchor_cache[key] = [
+                g.grid_anchors(s, st, device=device)
+                for g, s, st in zip(self.anchor_generators, featmap_sizes, self.anchor_strides)]
+        return self._anchor_cache[key]
+
+    def get_anchors(self, featmap_sizes, img_metas, device='cuda'):
+        """anchor_head.py:101-140: (anchors per image, valid flags per image), per level."""
+        mlvl = self._level_anchors([tuple(s) for s in featmap_sizes], device)
+        anchor_list = [mlvl for _ in img_metas]
+        valid_flag_list = []
+        for meta in img_metas:
+            flags = []
+            h, w = meta['pad_shape'][:2]
+            for i, (fh, fw) in enumerate(featmap_sizes):
+                st = self.anchor_strides[i]
+                vh = min(int(np.ceil(h / st)), fh)
+                vw = min(int(np.ceil(w / st)), fw)
+                flags.append(self.anchor_generators[i].valid_flags((fh, fw), (vh, vw), device))
+            valid_flag_list.append(flags)
+        return anchor_list, valid_flag_list
+
+    # -- loss ---------------------------------------------------------------------------
+    def anchor_targets(self, anchors, valid, gt_bboxes, img_shape, cfg, generator=None):
+        """``anchor_target_single`` (anchor_target.py:94-159) for one image, dense outputs over
+        ALL anchors: labels, label_weights ``[A]``, bbox_targets, bbox_weights ``[A,4]`` and the
+        device scalars n_pos, n_neg."""
+        ab = cfg.allowed_border
+        inside = valid
+        if ab >= 0:
+            img_h, img_w = img_shape[:2]
+            inside = valid & (anchors[:, 0] >= -ab) & (anchors[:, 1] >= -ab) & \
+                (anchors[:, 2] < img_w + ab) & (anchors[:, 3] < img_h + ab)
+        ac = cfg.assigner
+        overlaps = A.bbox_overlaps(gt_bboxes, anchors)
+        assigned, _ = A.max_iou_assign(overlaps, ac.pos_iou_thr, ac.neg_iou_thr,
+                                       ac.get('min_pos_iou', 0.0),
+                                       ac.get('gt_max_assign_all', True), valid=inside)
+        sc = cfg.sampler
+        pos, neg = A.sample_pos_neg_masks(assigned, sc.num, sc.pos_fraction,
+                                          sc.get('neg_pos_ub', -1), generator)
+        gt_of = gt_bboxes[(assigned - 1).clamp(min=0)]
+        deltas = bbox2delta(anchors, gt_of, self.target_means, self.target_stds)
+        posf = pos.to(anchors.dtype)
+        bbox_targets = deltas * posf[:, None]
+        bbox_weights = posf[:, None].expand(-1, 4)
+        labels = pos.long()
+        pw = 1.0 if cfg.pos_weight <= 0 else cfg.pos_weight
+        label_weights = posf * pw + neg.to(anchors.dtype)
+        return labels, label_weights, bbox_targets, bbox_weights, pos.sum(), neg.sum()
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, img_metas, cfg, gt_bboxes_ignore=None,
+             generator=None):
+        """Keys ``loss_rpn_cls`` / ``loss_rpn_bbox``: lists with one scalar per level
+        (rpn_head.py:37-53, anchor_head.py:163-207)."""
+        featmap_sizes = [tuple(c.shape[1:3]) for c in cls_scores]
+        dev = cls_scores[0].device
+        anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, dev)
+        n_lvl = [a.size(0) for a in anchor_list[0]]
+        per_img = []
+        n_pos_tot = n_neg_tot = 0
+        for i, meta in enumerate(img_metas):
+            anchors = torch.cat(anchor_list[i])
+            valid = torch.cat(valid_flag_list[i])
+            t = self.anchor_targets(anchors, valid, gt_bboxes[i], meta['img_shape'], cfg,
+                                    generator)
+            per_img.append(t[:4])
+            n_pos_tot = n_pos_tot + t[4].clamp(min=1)      # max(inds.numel(), 1) per image
+            n_neg_tot = n_neg_tot + t[5].clamp(min=1)
+        num_total_samples = (n_pos_tot + n_neg_tot).to(torch.float32)
+        stacked = [torch.stack([p[k] for p in per_img]) for k in range(4)]   # [N, A(,4)]
+        losses_cls, losses_bbox = [], []
+        start = 0
+        for lvl, n in enumerate(n_lvl):
+            sl = slice(start, start + n)
+            start += n
+            cs = cls_scores[lvl].reshape(-1, self.cls_out_channels).float()
+            bp = bbox_preds[lvl].reshape(-1, 4).float()
+            labels = stacked[0][:, sl].reshape(-1)
+            lw = stacked[1][:, sl].reshape(-1)
+            bt = stacked[2][:, sl].reshape(-1, 4)
+            bw = stacked[3][:, sl].reshape(-1, 4)
+            losses_cls.append(self.loss_cls(cs, labels, lw, avg_factor=num_total_samples))
+            losses_bbox.append(self.loss_bbox(bp, bt, bw, avg_factor=num_total_samples))
+        return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox)
+
+    # -- proposals ----------------------------------------------------------------------
+    @torch.no_grad()
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg, rescale=False):
+        """Per image ``[max_num, 5]`` proposals sorted by score + ``valid [max_num]`` mask
+        (rpn_head.py:55-104).  Everything stays on the device."""
+        if cfg.nms_across_levels or cfg.min_bbox_size > 0:
+            raise NotImplementedError('nms_across_levels / min_bbox_size > 0 are not used by the '
+                                      'BAGS configs')
+        featmap_sizes = [tuple(c.shape[1:3]) for c in cls_scores]
+        dev = cls_scores[0].device
+        mlvl_anchors = self._level_anchors(featmap_sizes, dev)
+        N = cls_scores[0].shape[0]
+        L = len(cls_scores)
+        nmax = cfg.nms_pre
+        boxes = torch.zeros((N, L, nmax, 5), dtype=torch.float32, device=dev)
+        counts = []
+        for lvl in range(L):
+            scores = cls_scores[lvl].reshape(N, -1).float().sigmoid()
+            deltas = bbox_preds[lvl].reshape(N, -1, 4).float()
+            n = scores.shape[1]
+            k = min(n, nmax)
+            top_s, top_i = scores.topk(k, dim=1)                    # sorted, descending
+            anchors = mlvl_anchors[lvl][top_i]                      # [N,k,4]
+            d = torch.gather(deltas, 1, top_i[..., None].expand(-1, -1, 4))
+            for i in range(N):
+                boxes[i, lvl, :k, :4] = delta2bbox(anchors[i], d[i], self.target_means,
+                                                   self.target_stds, img_metas[i]['img_shape'])
+            boxes[:, lvl, :k, 4] = top_s
+            counts.append(k)
+        cnt = torch.tensor(counts * N, dtype=torch.int32, device=dev)
+        keep, keep_n = BF.nms_batched(boxes.view(N * L, nmax, 5), cnt, cfg.nms_thr, iou_mode=0,
+                                      max_keep=cfg.nms_post)
+        keep = keep.view(N, L, nmax).long()
+        keep_n = keep_n.view(N, L, 1)
+        slot_ok = torch.arange(nmax, device=dev).view(1, 1, nmax) < keep_n
+        kept = torch.gather(boxes, 2, keep.clamp(min=0, max=nmax - 1)[..., None].expand(-1, -1, -1, 5))
+        kept_scores = torch.where(slot_ok, kept[..., 4], kept.new_full((), -1.0))
+        flat = kept.view(N, L * nmax, 5)
+        flat_s = kept_scores.view(N, L * nmax)
+        num = min(cfg.max_num, L * nmax)
+        top_s, top_i = flat_s.topk(num, dim=1)
+        props = torch.gather(flat, 1, top_i[..., None].expand(-1, -1, 5))
+        valid = top_s >= 0
+        return [(props[i], valid[i]) for i in range(N)]

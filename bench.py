@@ -37,14 +37,20 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--workload', default='gs_head', choices=['gs_head'])
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--workload', default='detector', choices=['detector', 'gs_head'])
+    ap.add_argument('--imgs', type=int, default=2, help='images per GPU per step (cfg: imgs_per_gpu=2)')
     ap.add_argument('--rois', type=int, default=1024, help='RoIs per GPU per step (2 img x 512)')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches, not hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 30 if a.workload == 'detector' else 200
+    if a.warmup is None:
+        a.warmup = 5 if a.workload == 'detector' else 20
+    return a
 
 
 def init_dist(args):
@@ -106,6 +112,123 @@ class GsHeadStep(object):
         total = per_bin.sum() + lbox
         total.backward()
         return total
+
+
+# ---------------------------------------------------------------------------------------------
+# detector workload: BASELINE.json configs[1]
+# ---------------------------------------------------------------------------------------------
+def detector_cfg(table_dir):
+    """gs_faster_rcnn_r50_fpn_1x_lvis_with0_bg8 (reference configs/bags/...), with the three
+    absent data files replaced by synthetic tables built with the same rule."""
+    paths = gs_tables.save_group_tables(table_dir, *gs_tables.synthetic_group_tables())
+    ce = dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)
+    model = dict(
+        type='GroupSoftmax', pretrained=None,
+        backbone=dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3),
+                      frozen_stages=1, style='pytorch'),
+        neck=dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=256, num_outs=5),
+        rpn_head=dict(type='RPNHead', in_channels=256, feat_channels=256, anchor_scales=[8],
+                      anchor_ratios=[0.5, 1.0, 2.0], anchor_strides=[4, 8, 16, 32, 64],
+                      target_means=[.0, .0, .0, .0], target_stds=[1.0, 1.0, 1.0, 1.0],
+                      loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                      loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0)),
+        bbox_roi_extractor=dict(type='SingleRoIExtractor',
+                                roi_layer=dict(type='RoIAlign', out_size=7, sample_num=2),
+                                out_channels=256, featmap_strides=[4, 8, 16, 32]),
+        bbox_head=dict(type='GSBBoxHeadWith0', num_fcs=2, in_channels=256, fc_out_channels=1024,
+                       gs_config=dict(label2binlabel=paths['label2binlabel'],
+                                      pred_slice=paths['pred_slice'], fg_split=paths['fg_split'],
+                                      others_sample_ratio=8.0, loss_bg=dict(ce), num_bins=5,
+                                      loss_bin=dict(ce)),
+                       roi_feat_size=7, num_classes=NUM_CLASSES, target_means=[0., 0., 0., 0.],
+                       target_stds=[0.1, 0.1, 0.2, 0.2], reg_class_agnostic=False,
+                       loss_cls=dict(ce),
+                       loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0)))
+    train_cfg = dict(
+        rpn=dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.7, neg_iou_thr=0.3,
+                               min_pos_iou=0.3, ignore_iof_thr=-1),
+                 sampler=dict(type='RandomSampler', num=256, pos_fraction=0.5, neg_pos_ub=-1,
+                              add_gt_as_proposals=False),
+                 allowed_border=0, pos_weight=-1, debug=False),
+        rpn_proposal=dict(nms_across_levels=False, nms_pre=2000, nms_post=2000, max_num=2000,
+                          nms_thr=0.7, min_bbox_size=0),
+        rcnn=dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.5,
+                                min_pos_iou=0.5, ignore_iof_thr=-1),
+                  sampler=dict(type='RandomSampler', num=512, pos_fraction=0.25, neg_pos_ub=-1,
+                               add_gt_as_proposals=True),
+                  pos_weight=-1, debug=False))
+    return model, train_cfg
+
+
+class DetectorStep(object):
+    """One training iteration of cfg[1] as shipped (selectp=1: full forward, backward through
+    fc_cls, gradient all-reduce, clip, SGD) on synthetic 800x1344 inputs, 512 RoIs/img."""
+
+    def __init__(self, dev, rank, world, imgs):
+        import tempfile
+        import balancedgroupsoftmax_amd as bgs
+        from balancedgroupsoftmax_amd import train
+        from balancedgroupsoftmax_amd.config import to_config_dict
+        self.train = train
+        torch.manual_seed(0)                      # identical weights on every rank
+        tmp = tempfile.mkdtemp(prefix='bgs_tables_')
+        model_cfg, train_cfg = detector_cfg(tmp)
+        self.model = bgs.build_detector(to_config_dict(model_cfg),
+                                        train_cfg=to_config_dict(train_cfg), test_cfg=None).to(dev)
+        self.params = train.select_training_param(self.model, 1)
+        self.model.train()
+        opt = train.build_optimizer(self.params, dict(type='SGD', lr=0.01, momentum=0.9,
+                                                      weight_decay=0.0001))
+        self.step_fn = train.DistOptimizerStep(self.params, opt, dict(max_norm=35, norm_type=2),
+                                               world_size=world)
+        g = torch.Generator().manual_seed(1000 + rank)          # different data per rank
+        H, W = 800, 1344                                        # 1333 padded to /32 (Pad(size_divisor=32))
+        self.img = torch.randn(imgs, 3, H, W, generator=g).to(dev)
+        self.metas = [dict(img_shape=(800, 1333, 3), pad_shape=(H, W, 3), ori_shape=(800, 1333, 3),
+                           scale_factor=1.0, flip=False) for _ in range(imgs)]
+        self.gt_bboxes, self.gt_labels = [], []
+        for _ in range(imgs):                                   # G = 20 boxes / image
+            wh = torch.exp(torch.rand(20, 2, generator=g) * (np.log(400) - np.log(16)) + np.log(16))
+            xy = torch.rand(20, 2, generator=g) * (torch.tensor([1333., 800.]) - wh).clamp(min=1)
+            self.gt_bboxes.append(torch.cat([xy, (xy + wh)], 1).to(dev))
+            self.gt_labels.append(torch.randint(1, NUM_CLASSES, (20,), generator=g).to(dev))
+        self.last = None
+
+    def __call__(self):
+        losses = self.model(self.img, self.metas, return_loss=True, gt_bboxes=self.gt_bboxes,
+                            gt_labels=self.gt_labels)
+        loss, log_vars = self.train.parse_losses(losses)
+        self.step_fn(loss)
+        self.last = log_vars
+        return loss
+
+
+def conv_roofline(dev, iters=20):
+    """Dominant kernel of the detector step: the fp32-MFMA implicit-GEMM conv.  Timed on the
+    largest single layer (FPN output conv on P2: 2x200x336 pixels, 3x3, 256->256 = 158.6 GFLOP)
+    with HIP events on the launch stream.  Peak: 157.3 TFLOP/s fp32 matrix (MI355X_MICROARCH.md)."""
+    x = torch.randn(2, 200, 336, 256, device=dev)
+    w = torch.randn(256, 3, 3, 256, device=dev) * 0.02
+    b = torch.randn(256, device=dev)
+    out = torch.empty(2, 200, 336, 256, device=dev)
+    for _ in range(3):
+        BF.conv2d_nhwc(x, w, b, pad=1, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        BF.conv2d_nhwc(x, w, b, pad=1, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * 2 * 200 * 336 * 256 * 256 * 9
+    tf = flops / (ms * 1e-3) / 1e12
+    return dict(bound='mfma', achieved=round(tf, 2), peak=157.3, unit='TFLOP/s',
+                frac=round(tf / 157.3, 4), traffic=None,
+                kernel='conv_igemm_f32_kernel<2,2> (v_mfma_f32_32x32x2_f32)',
+                ms_per_launch=round(ms, 4), flops_per_launch=flops,
+                layer='FPN output conv P2: N=2, 200x336, 3x3, 256->256 (M=134400, K=2304)',
+                timing='hipEvent over %d back-to-back launches' % iters)
 
 
 def timed_loop(fn, steps, warmup, world):
@@ -223,6 +346,45 @@ def cpu_baseline(n, seconds):
                        % (cnt, n, nt, torch.__version__))
 
 
+def main_detector(args, rank, local, world, dev):
+    step = DetectorStep(dev, rank, world, args.imgs)
+    dt = timed_loop(step, args.steps, args.warmup, world)
+    ms_per_step = dt * 1e3 / args.steps
+    imgs_per_s = args.imgs * world * args.steps / dt
+    if rank == 0:
+        lv = {k: round(float(v), 5) for k, v in step.last.items()}
+        out = {
+            'metric': 'img/s fwd+bwd R50-FPN+BAGS 1333x800, 512 RoI (BASELINE metric: img/s/GPU '
+                      'fwd+bwd R50-FPN+BAGS 1333x800, 512 RoI; GroupSoftmax us/RoI)',
+            'value': round(imgs_per_s, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'gs_faster_rcnn_r50_fpn_1x_lvis_with0_bg8 (cfg[1]) training '
+                                   'iteration as shipped (selectp=1: full forward incl. RPN '
+                                   'losses/proposals/NMS/assign/sample/RoIAlign/FC heads/GroupSoftmax '
+                                   'loss, backward through fc_cls, grad all-reduce, clip 35, SGD): '
+                                   '%d img/GPU, 3x800x1344 (1333x800 padded /32), 20 GT/img, '
+                                   '512 RoI/img, 1231 classes, 5 bins; random-init weights'
+                                   % args.imgs,
+                       'imgs_per_gpu': args.imgs, 'rois_per_img': 512, 'launch': 'eager',
+                       'parallelism': 'dp%d (one process per GPU; flat fp32 all-reduce of the '
+                                      '1,266,900 fc_cls grads over RCCL)' % world},
+            'img_per_s_per_gpu': round(imgs_per_s / world, 3),
+            'last_losses': lv,
+        }
+        out['roofline'] = conv_roofline(dev)
+        gs_inp = make_inputs(1024, seed=1000, dev=dev)
+        out['roofline_gs_loss'] = kernel_roofline(gs_inp, 1024)
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(1024, args.cpu_seconds)
+            cb['note'] = ('GroupSoftmax loss()+backward() only: the reference cannot run the whole '
+                          'detector on CPU (its RoIAlign has no CPU path, roi_align.py:27-28)')
+            out['cpu_baseline'] = cb
+        print(json.dumps(out), flush=True)
+    barrier(world)
+
+
 def main():
     args = parse()
     if not torch.cuda.is_available():
@@ -232,6 +394,8 @@ def main():
         sys.stderr.write('note: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)\n'
                          % (args.gpus, world))
     dev = torch.device('cuda', local)
+    if args.workload == 'detector':
+        return main_detector(args, rank, local, world, dev)
     n = args.rois
     inp = make_inputs(n, seed=1000 + rank, dev=dev)
     step = GsHeadStep(inp)

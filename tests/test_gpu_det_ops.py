@@ -76,6 +76,29 @@ def test_linear_matches_fc_shapes():
     assert np.abs(z.cpu().numpy() - exp2).max() < 5e-5 * np.abs(exp2).max()
 
 
+def test_linear_autograd_vs_torch():
+    """dX, dW, db of the MFMA linear (what trains fc_cls under selectp=1) vs torch autograd."""
+    rs = np.random.RandomState(8)
+    x = rs.standard_normal((200, 1024)).astype(np.float32)
+    w = (rs.standard_normal((1236, 1024)) / 32).astype(np.float32)
+    b = rs.standard_normal(1236).astype(np.float32)
+    gy = rs.standard_normal((200, 1236)).astype(np.float32)
+    xt, wt, bt = (torch.from_numpy(a).double().requires_grad_(True) for a in (x, w, b))
+    (torch.nn.functional.linear(xt, wt, bt) * torch.from_numpy(gy).double()).sum().backward()
+    xd, wd, bd = (dev(a).requires_grad_(True) for a in (x, w, b))
+    y = BF.linear_autograd(xd, wd, bd)
+    (y * dev(gy)).sum().backward()
+    for got, exp in ((xd.grad, xt.grad), (wd.grad, wt.grad), (bd.grad, bt.grad)):
+        assert float((got.cpu().double() - exp).abs().max()) < 5e-5 * float(exp.abs().max())
+    # frozen input / bias-free variants
+    xd2 = dev(x)
+    wd2 = dev(w).requires_grad_(True)
+    BF.linear_autograd(xd2, wd2, None, relu=True).sum().backward()
+    exp = (torch.relu(torch.from_numpy(x).double() @ torch.from_numpy(w).double().t()) > 0).double()
+    expw = exp.t() @ torch.from_numpy(x).double()
+    assert float((wd2.grad.cpu().double() - expw).abs().max()) < 5e-5 * float(expw.abs().max())
+
+
 def test_maxpool3x3s2():
     rs = np.random.RandomState(6)
     for (N, H, W, C) in [(2, 17, 23, 8), (1, 64, 96, 64)]:
