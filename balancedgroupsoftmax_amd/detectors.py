@@ -110,7 +110,9 @@ class TwoStageDetector(nn.Module):
             cls_scores, bbox_preds = self.rpn_head(x)
             losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
                                              self.train_cfg.rpn, generator=generator))
-            proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
+            proposal_cfg = self.train_cfg.get('rpn_proposal', None)
+            if proposal_cfg is None:
+                proposal_cfg = self.test_cfg.rpn
             proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_meta, proposal_cfg)
         else:
             proposal_list = [(p, torch.ones(p.size(0), dtype=torch.bool, device=p.device))
