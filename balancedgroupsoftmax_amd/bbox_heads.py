@@ -351,6 +351,9 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
         self.others_sample_ratio = gs.others_sample_ratio
         self.sampler = gs.get('sampler', 'device') if hasattr(gs, 'get') else 'device'
         self.cls_weights = None        # Reweight variant: list of per-bin arrays
+        # device-side draw counter: a fresh 'others' sample every call, also under hipGraph replay
+        self.register_buffer('_draw', torch.zeros(1, dtype=torch.int64), persistent=False)
+        self._seed = None
         self.register_buffer('cls_weight_table', None, persistent=False)
 
     def _class_columns(self, ps, fg_splits):
@@ -387,7 +390,11 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
         three results are device tensors: bin labels ``[B, N]`` i32, sample weights ``[B, N]``
         f32 and avg factors ``[B]`` f32."""
         if self.sampler == 'device':
+            if self._seed is None:
+                self._seed = (torch.initial_seed() * 0x9E3779B1) & 0xFFFFFFFFFFFFFFFF
+            self._draw += 1
             return BF.gs_prepare(labels, self.label2binlabel, self.others_sample_ratio,
+                                 seed=self._seed, seed_offset=self._draw,
                                  cls_weight=self.cls_weight_table)
         if self.sampler != 'numpy':
             raise ValueError('gs_config.sampler must be "device" or "numpy"')

@@ -24,11 +24,9 @@ def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
     assert proposals.size() == gt.size()
     px, py, pw, ph = _centre_size(proposals.float())
     gx, gy, gw, gh = _centre_size(gt.float())
-    deltas = torch.stack([(gx - px) / pw, (gy - py) / ph, torch.log(gw / pw), torch.log(gh / ph)],
-                         dim=-1)
-    m = deltas.new_tensor(means).unsqueeze(0)
-    s = deltas.new_tensor(stds).unsqueeze(0)
-    return (deltas - m) / s
+    comps = [(gx - px) / pw, (gy - py) / ph, torch.log(gw / pw), torch.log(gh / ph)]
+    # (x - mean) / std with Python scalars: no host->device constant upload (hipGraph-safe)
+    return torch.stack([(c - float(m)) / float(s) for c, m, s in zip(comps, means, stds)], dim=-1)
 
 
 def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None,
@@ -40,11 +38,12 @@ def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_
     [[0,0,1,1],[0.2817,0.2817,4.7183,4.7183],[0,0.6321,7.3891,0.3679],[5.8967,2.9251,5.5033,3.2749]].
     """
     n, k4 = deltas.shape
-    d = deltas.view(n, k4 // 4, 4) * deltas.new_tensor(stds) + deltas.new_tensor(means)
+    d = deltas.view(n, k4 // 4, 4)
     max_ratio = abs(math.log(wh_ratio_clip))
-    dx, dy = d[..., 0], d[..., 1]
-    dw = d[..., 2].clamp(min=-max_ratio, max=max_ratio)
-    dh = d[..., 3].clamp(min=-max_ratio, max=max_ratio)
+    dx = d[..., 0] * float(stds[0]) + float(means[0])
+    dy = d[..., 1] * float(stds[1]) + float(means[1])
+    dw = (d[..., 2] * float(stds[2]) + float(means[2])).clamp(min=-max_ratio, max=max_ratio)
+    dh = (d[..., 3] * float(stds[3]) + float(means[3])).clamp(min=-max_ratio, max=max_ratio)
     px, py, pw, ph = (t.unsqueeze(1) for t in _centre_size(rois))
     gw, gh = pw * dw.exp(), ph * dh.exp()
     gx, gy = px + pw * dx, py + ph * dy

@@ -19,6 +19,8 @@
 //     double-buffered LDS + register prefetch of the next K tile: one barrier per K tile;
 //   * epilogue fuses the folded-BN bias, the residual add (same-shape for bottlenecks,
 //     nearest-2x-upsampled for the FPN top-down path) and ReLU, and writes NHWC directly.
+#include <stdlib.h>
+
 #include "bgs_common.h"
 
 namespace {
@@ -270,13 +272,21 @@ extern "C" int bgs_conv2d_nhwc_f32(const float* x, const float* w, const float* 
   p.relu = relu;
   p.res_mode = residual_mode;
   hipStream_t st = (hipStream_t)stream;
-  // tile choice: 128x128 when the grid fills the chip, narrower N for thin layers, 64x64 for
-  // small problems (the RoI-head FCs: M = 1024)
-  const long long t128 = ((M + 127) / 128) * ((Cout + 127) / 128);
-  if (Cout > 64 && t128 >= 512) {
+  // Tile choice, from the per-layer sweep of the R50-FPN shapes (tools/conv_sweep.py,
+  // profiles/r1i_conv_sweep.txt): the 128x128 tile only pays for the two huge-M, deep-K 3x3
+  // convs on the stride-4 maps (111 vs 103 TFLOP/s); everywhere else the 64x64 tile wins or
+  // ties because it exposes 4x more workgroups (latency hiding across workgroups matters more
+  // than operand reuse at these sizes); thin outputs (Cout <= 64) with a huge M use 128x64.
+  int force = 0;  // tuning hook: BGS_CONV_TILE=22|21|11 forces a tile configuration
+  if (const char* e = getenv("BGS_CONV_TILE")) force = atoi(e);
+  int tile = 11;
+  if (Cout > 64 && p.K >= 1152 && M >= 100000) tile = 22;
+  else if (Cout <= 64 && M >= 400000) tile = 21;
+  if (force == 22 || force == 21 || force == 11) tile = force;
+  if (tile == 22) {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Cout + 127) / 128));
     hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 2>), grid, dim3(kThreads), 0, st, p);
-  } else if (Cout <= 64 && ((M + 127) / 128) >= 512) {
+  } else if (tile == 21) {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Cout + 63) / 64));
     hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 1>), grid, dim3(kThreads), 0, st, p);
   } else {

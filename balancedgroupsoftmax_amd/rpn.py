@@ -254,7 +254,10 @@ class RPNHead(nn.Module):
                                                    self.target_stds, img_metas[i]['img_shape'])
             boxes[:, lvl, :k, 4] = top_s
             counts.append(k)
-        cnt = torch.tensor(counts * N, dtype=torch.int32, device=dev)
+        ckey = ('cnt', tuple(counts), N, str(dev))
+        if ckey not in self._anchor_cache:        # uploaded once (no H2D copy per iteration)
+            self._anchor_cache[ckey] = torch.tensor(counts * N, dtype=torch.int32, device=dev)
+        cnt = self._anchor_cache[ckey]
         keep, keep_n = BF.nms_batched(boxes.view(N * L, nmax, 5), cnt, cfg.nms_thr, iou_mode=0,
                                       max_keep=cfg.nms_post)
         keep = keep.view(N, L, nmax).long()
