@@ -103,7 +103,7 @@ def sample_pos_neg_masks(assigned, num, pos_fraction, neg_pos_ub=-1, generator=N
     neg_keys = torch.where(is_neg, keys, big)
     srt = torch.topk(neg_keys, kn, largest=False, sorted=True).values
     idx = (n_exp_neg - 1).clamp(min=0, max=kn - 1)
-    thr_neg = srt[idx]
+    thr_neg = srt.gather(0, idx.view(1))[0]     # (srt[idx] would call .item(): a host sync)
     neg_s = is_neg & (neg_keys <= thr_neg) & (n_exp_neg > 0)
     return pos_s, neg_s
 

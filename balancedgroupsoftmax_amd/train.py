@@ -95,11 +95,15 @@ class DistOptimizerStep(object):
         self.grad_clip = grad_clip
         self.world_size = world_size
 
-    def __call__(self, loss):
-        self.optimizer.zero_grad(set_to_none=False)
-        loss.backward()
+    def exchange_and_update(self):
+        """all-reduce -> clip -> step, for gradients already produced by backward."""
         allreduce_grads(self.params, self.world_size)
         if self.grad_clip is not None:
             torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip['max_norm'],
                                            self.grad_clip.get('norm_type', 2))
         self.optimizer.step()
+
+    def __call__(self, loss):
+        self.optimizer.zero_grad(set_to_none=False)
+        loss.backward()
+        self.exchange_and_update()
