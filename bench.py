@@ -317,8 +317,17 @@ def kernel_roofline(inp, n, iters=300):
     us = e0.elapsed_time(e1) * 1e3 / iters
     bytes_per_roi = W * 4 + W * 4 + 8 + B * 4
     achieved = bytes_per_roi * n / (us * 1e-6) / 1e9
+    # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 passes of this
+    # same command (tools/pmc_traffic.sh), corrected as the microarch guide prescribes, and
+    # committed under profiles/ — bench.py itself cannot run the profiler.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            traffic = json.load(f)['gs_loss_rowwave_kernel<4,true>'][str(n)]['traffic_bytes_per_launch']
+    except Exception:
+        pass
     return dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                 kernel='gs_loss_rowwave_kernel<4,true>', us_per_launch=round(us, 3),
                 algorithmic_bytes_per_roi=bytes_per_roi, rois_per_launch=n,
                 timing='hipEvent over %d back-to-back launches (includes the ~1.5 us '
