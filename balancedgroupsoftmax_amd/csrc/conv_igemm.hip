@@ -14,8 +14,8 @@
 //   * v_mfma_f32_32x32x2_f32: f32 in / f32 accumulate, bit-exact fma chain (no TF32 on gfx950)
 //     -> the 1e-4 parity budget of the detector is met by construction;
 //   * workgroup = 4 waves (2 x 2), each wave owns MB x NB tiles of 32 x 32 (64 accumulator
-//     registers for the 128 x 128 tile), BK = 16, LDS tiles [rows][BK+1] (odd stride: the
-//     per-lane fragment reads As[row = lane&31][k = lane>>5] are bank-conflict free),
+//     registers for the 128 x 128 tile), BK = 16, LDS rows hold the even-k then the odd-k
+//     values so that a lane's 8 fragment operands of a K tile are two ds_read_b128,
 //     double-buffered LDS + register prefetch of the next K tile: one barrier per K tile;
 //   * epilogue fuses the folded-BN bias, the residual add (same-shape for bottlenecks,
 //     nearest-2x-upsampled for the FPN top-down path) and ReLU, and writes NHWC directly.
@@ -25,12 +25,18 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
 constexpr int BK = 16;
-constexpr int LDK = BK + 1;  // LDS row stride in floats
+// LDS row = [k even: 8 floats][k odd: 8 floats][4 pad] = 20 floats.  The A/B fragment of
+// v_mfma_f32_32x32x2_f32 wants, in lane l, k = 2*kk + (l >> 5) for kk = 0..7: lanes 0-31 need
+// the even k of their row and lanes 32-63 the odd k — 8 contiguous floats each, fetched with two
+// ds_read_b128 per K tile (instead of 8 ds_read_b32: the 64x64 tile was LDS-bandwidth bound).
+// Stride 20 floats makes the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots.
+constexpr int LDK = 20;
 
 struct ConvArgs {
   const float* x;     // [N, H, W, Cin]
@@ -47,8 +53,8 @@ template <int MB, int NB>
 __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
   constexpr int BM = 64 * MB, BN = 64 * NB;
   constexpr int PA = BM / 64, PB = BN / 64;  // staging passes (64 rows per pass)
-  __shared__ float As[2][BM * LDK];
-  __shared__ float Bs[2][BN * LDK];
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -123,20 +129,17 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
+    // k = 4*kq + {0,1,2,3}: evens (k = 4kq, 4kq+2) -> slots 2kq, 2kq+1; odds -> 8 + 2kq, 8 + 2kq+1
     for (int q = 0; q < PA; ++q) {
-      float* d = &As[buf][(srow + 64 * q) * LDK + kq * 4];
-      d[0] = ra[q][0];
-      d[1] = ra[q][1];
-      d[2] = ra[q][2];
-      d[3] = ra[q][3];
+      float* d = &As[buf][(srow + 64 * q) * LDK + kq * 2];
+      *reinterpret_cast<f32x2*>(d) = f32x2{ra[q][0], ra[q][2]};
+      *reinterpret_cast<f32x2*>(d + 8) = f32x2{ra[q][1], ra[q][3]};
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
-      float* d = &Bs[buf][(srow + 64 * q) * LDK + kq * 4];
-      d[0] = rb[q][0];
-      d[1] = rb[q][1];
-      d[2] = rb[q][2];
-      d[3] = rb[q][3];
+      float* d = &Bs[buf][(srow + 64 * q) * LDK + kq * 2];
+      *reinterpret_cast<f32x2*>(d) = f32x2{rb[q][0], rb[q][2]};
+      *reinterpret_cast<f32x2*>(d + 8) = f32x2{rb[q][1], rb[q][3]};
     }
   };
 
@@ -156,20 +159,28 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tile();  // global loads in flight under the MFMAs below
-    const float* Ab = &As[buf][(wm * 32 * MB + frow) * LDK + fk];
-    const float* Bb = &Bs[buf][(wn * 32 * NB + frow) * LDK + fk];
+    const float* Ab = &As[buf][(wm * 32 * MB + frow) * LDK + fk * 8];
+    const float* Bb = &Bs[buf][(wn * 32 * NB + frow) * LDK + fk * 8];
+    f32x4 av[MB][2], bv[NB][2];
+#pragma unroll
+    for (int a = 0; a < MB; ++a) {
+      av[a][0] = *reinterpret_cast<const f32x4*>(Ab + a * 32 * LDK);
+      av[a][1] = *reinterpret_cast<const f32x4*>(Ab + a * 32 * LDK + 4);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      bv[b][0] = *reinterpret_cast<const f32x4*>(Bb + b * 32 * LDK);
+      bv[b][1] = *reinterpret_cast<const f32x4*>(Bb + b * 32 * LDK + 4);
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float av[MB], bv[NB];
-#pragma unroll
-      for (int a = 0; a < MB; ++a) av[a] = Ab[a * 32 * LDK + kk * 2];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) bv[b] = Bb[b * 32 * LDK + kk * 2];
 #pragma unroll
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][kk >> 2][kk & 3],
+                                                            bv[b][kk >> 2][kk & 3], acc[a][b], 0,
+                                                            0, 0);
     }
     if (kt + 1 < nk) store_tile(buf ^ 1);
     __syncthreads();

@@ -47,6 +47,9 @@ def bench(fn, iters=10):
 
 def main():
     dev = 'cuda:0'
+    pf = os.environ.get('SWEEP_PF', '2')
+    os.environ['BGS_CONV_PF'] = pf
+    print('register prefetch depth PF =', pf)
     tiles = ['0', '22', '21', '11']
     tot = {t: 0.0 for t in tiles}
     tot['best'] = 0.0
