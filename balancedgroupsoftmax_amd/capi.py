@@ -58,6 +58,21 @@ SIGNATURES = {
     'bgs_nms_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     'bgs_nms_batched': (ctypes.c_int, [c_f32p, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                        ctypes.c_int, ctypes.c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'bgs_iou_assign_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 3),
+    'bgs_iou_assign': (ctypes.c_int, [c_f32p, ctypes.c_longlong, ctypes.c_int, c_ptr, c_f32p, c_ptr,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                      ctypes.c_float, ctypes.c_float, c_ptr, c_f32p, c_ptr, c_ptr]),
+    'bgs_rpn_loss_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 3),
+    'bgs_rpn_loss': (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, c_f32p, c_ptr, c_ptr,
+                                    c_ptr, c_f32p, c_ptr, ctypes.c_int, c_ptr, c_ptr,
+                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                    c_f32p, c_f32p, c_f32p, c_ptr, c_ptr]),
+    'bgs_decode_proposals': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, c_f32p,
+                                            c_ptr, c_f32p, ctypes.c_int, c_ptr, c_ptr, c_ptr,
+                                            ctypes.c_float, ctypes.c_int, c_f32p, c_ptr]),
+    'bgs_rcnn_targets': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32p, c_ptr,
+                                        ctypes.c_int, ctypes.c_int, c_ptr, c_ptr, ctypes.c_float,
+                                        c_f32p, c_ptr, c_f32p, c_f32p, c_f32p, c_ptr]),
 }
 
 _LIB = None

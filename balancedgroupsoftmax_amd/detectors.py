@@ -86,6 +86,40 @@ class TwoStageDetector(nn.Module):
         return dict(bboxes=boxes[inds], is_pos=is_pos, valid=valid, labels=labels,
                     gt_bboxes=gt_bboxes[gi])
 
+    def _sample_rois_fused(self, proposal_list, gt_bboxes, gt_labels, generator=None):
+        """GPU path of two_stage.py:192-222: one batched assignment launch pair, the fixed-shape
+        sampler, and one kernel that emits rois / labels / box targets for all images."""
+        from . import functional as BF
+        rc = self.train_cfg.rcnn
+        ac, sc = rc.assigner, rc.sampler
+        N = len(proposal_list)
+        props = torch.stack([p for p, _ in proposal_list]).contiguous()            # [N, P, 5]
+        pvalid = torch.stack([v for _, v in proposal_list]).to(torch.uint8).contiguous()
+        gt_cat = torch.cat([g[:, :4] for g in gt_bboxes]).float().contiguous()
+        offs = [0]
+        for g in gt_bboxes:
+            offs.append(offs[-1] + int(g.size(0)))
+        assigned = BF.iou_assign(props, gt_cat, offs, ac.pos_iou_thr, ac.neg_iou_thr,
+                                 ac.get('min_pos_iou', 0.0), valid=pvalid, shared_boxes=False)
+        add_gt = sc.get('add_gt_as_proposals', True)
+        boxes_l, assigned_l, inds_l, valid_l = [], [], [], []
+        for i in range(N):
+            b, a = props[i, :, :4], assigned[i]
+            if add_gt:      # base_sampler.py:49-53 + AssignResult.add_gt_
+                G = gt_bboxes[i].size(0)
+                b = torch.cat([gt_bboxes[i][:, :4].float(), b], 0)
+                a = torch.cat([torch.arange(1, G + 1, device=a.device, dtype=torch.int32), a])
+            inds, _, valid = A.sample_fixed(a, sc.num, sc.pos_fraction, generator)
+            boxes_l.append(b.contiguous())
+            assigned_l.append(a.contiguous())
+            inds_l.append(inds.contiguous())
+            valid_l.append(valid)
+        head = self.bbox_head
+        rois, labels, lw, bt, bw = BF.rcnn_targets(
+            boxes_l, assigned_l, inds_l, valid_l, [g.contiguous() for g in gt_labels], gt_cat, offs,
+            sc.num, head.target_means, head.target_stds, rc.pos_weight)
+        return rois, (labels, lw, bt, bw)
+
     def _bbox_targets(self, samples):
         """``bbox_target`` (mmdet/core/bbox/bbox_target.py:7-61) on the fixed-size samples."""
         rc = self.train_cfg.rcnn
@@ -118,14 +152,18 @@ class TwoStageDetector(nn.Module):
             proposal_list = [(p, torch.ones(p.size(0), dtype=torch.bool, device=p.device))
                              for p in proposals]
         if self.with_bbox:
-            samples = [self._assign_and_sample(proposal_list[i][0], proposal_list[i][1],
-                                               gt_bboxes[i], gt_labels[i], generator)
-                       for i in range(img.size(0))]
-            rois = torch.cat([torch.cat([s['bboxes'].new_full((s['bboxes'].size(0), 1), i),
-                                         s['bboxes']], 1) for i, s in enumerate(samples)], 0)
+            if img.is_cuda and self.train_cfg.rcnn.assigner.get('gt_max_assign_all', True):
+                rois, targets = self._sample_rois_fused(proposal_list, gt_bboxes, gt_labels,
+                                                        generator)
+            else:   # tensor-op form (device-agnostic; what the CPU tests check vs the reference)
+                samples = [self._assign_and_sample(proposal_list[i][0], proposal_list[i][1],
+                                                   gt_bboxes[i], gt_labels[i], generator)
+                           for i in range(img.size(0))]
+                rois = torch.cat([torch.cat([s['bboxes'].new_full((s['bboxes'].size(0), 1), i),
+                                             s['bboxes']], 1) for i, s in enumerate(samples)], 0)
+                targets = self._bbox_targets(samples)
             bbox_feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
             cls_score, bbox_pred = self.bbox_head(bbox_feats, nhwc=True)
-            targets = self._bbox_targets(samples)
             losses.update(self.bbox_head.loss(cls_score, bbox_pred, *targets))
         return losses
 

@@ -371,6 +371,146 @@ def nms_batched(boxes, counts, iou_thr, iou_mode=0, max_keep=0):
     return keep, keep_count
 
 
+# ----------------------------------------------------------------------------------------
+# fused target assignment / RPN loss / proposal decode / RoI targets (csrc/det_targets.hip)
+# ----------------------------------------------------------------------------------------
+def _c_int_array(vals):
+    import ctypes
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def _c_float_array(vals):
+    import ctypes
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def _c_ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def iou_assign(boxes, gt_cat, gt_offsets, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, valid=None,
+               shared_boxes=False, return_max_overlaps=False):
+    """``MaxIoUAssigner`` for N images at once -> ``assigned [N,A]`` int32.
+
+    boxes: ``[A, >=4]`` with ``shared_boxes=True`` (the same anchors for every image) or
+    ``[N, A, >=4]``; gt_cat ``[sum G, 4]`` with python ``gt_offsets`` (len N+1); valid ``[N,A]`` u8."""
+    _require_cuda(boxes, gt_cat, valid)
+    lib = capi.load()
+    boxes = boxes if boxes.dtype == torch.float32 and boxes.is_contiguous() else _f32c(boxes)
+    gt_cat = _f32c(gt_cat)
+    N = len(gt_offsets) - 1
+    if shared_boxes:
+        A, bs = boxes.shape[0], boxes.shape[1]
+        img_stride = 0
+    else:
+        assert boxes.shape[0] == N
+        A, bs = boxes.shape[1], boxes.shape[2]
+        img_stride = A * bs
+    if isinstance(neg_iou_thr, (tuple, list)):
+        lo, hi = neg_iou_thr
+    else:
+        lo, hi = 0.0, neg_iou_thr
+    dev = boxes.device
+    if valid is not None:
+        assert valid.dtype == torch.uint8 and tuple(valid.shape) == (N, A) and valid.is_contiguous()
+    assigned = torch.empty((N, A), dtype=torch.int32, device=dev)
+    mo = torch.empty((N, A), dtype=torch.float32, device=dev) if return_max_overlaps else None
+    ws = _workspace(lib.bgs_iou_assign_workspace_bytes(N, A, int(gt_offsets[-1])), dev)
+    rc = lib.bgs_iou_assign(capi.ptr(boxes), img_stride, bs, capi.ptr(valid), capi.ptr(gt_cat),
+                            _c_int_array(gt_offsets), N, A, float(pos_iou_thr), float(lo),
+                            float(hi), float(min_pos_iou), capi.ptr(assigned), capi.ptr(mo),
+                            capi.ptr(ws), capi.current_stream(dev))
+    capi.check('bgs_iou_assign', rc)
+    return (assigned, mo) if return_max_overlaps else assigned
+
+
+def rpn_loss(level_outs, num_anchors, anchors, assigned, pos_mask, neg_mask, gt_cat, gt_offsets,
+             means, stds, beta, pos_weight=-1, loss_weight_cls=1.0, loss_weight_bbox=1.0):
+    """Per-level RPN losses ``(loss_cls [L], loss_bbox [L], num_total_samples [1])`` from the
+    fused head outputs ``[N,H,W,A+4A]`` of every level and the sampled-anchor masks."""
+    _require_cuda(anchors, assigned, pos_mask, neg_mask, gt_cat, *level_outs)
+    lib = capi.load()
+    L = len(level_outs)
+    N = level_outs[0].shape[0]
+    for o in level_outs:
+        assert o.dtype == torch.float32 and o.is_contiguous() and o.shape[-1] == 5 * num_anchors
+    hw = [int(o.shape[1] * o.shape[2]) for o in level_outs]
+    A = sum(hw) * num_anchors
+    assert tuple(assigned.shape) == (N, A) and assigned.dtype == torch.int32
+    assert pos_mask.dtype == torch.uint8 and neg_mask.dtype == torch.uint8
+    assert anchors.shape == (A, 4) and anchors.is_contiguous()
+    dev = anchors.device
+    lc = torch.empty((L,), dtype=torch.float32, device=dev)
+    lb = torch.empty((L,), dtype=torch.float32, device=dev)
+    nt = torch.empty((1,), dtype=torch.float32, device=dev)
+    ws = _workspace(lib.bgs_rpn_loss_workspace_bytes(N, A, L), dev)
+    rc = lib.bgs_rpn_loss(_c_ptr_array(level_outs), _c_int_array(hw), L, num_anchors,
+                          capi.ptr(anchors), capi.ptr(assigned), capi.ptr(pos_mask.contiguous()),
+                          capi.ptr(neg_mask.contiguous()), capi.ptr(_f32c(gt_cat)),
+                          _c_int_array(gt_offsets), N, _c_float_array(means), _c_float_array(stds),
+                          float(beta), float(pos_weight), float(loss_weight_cls),
+                          float(loss_weight_bbox), capi.ptr(lc), capi.ptr(lb), capi.ptr(nt),
+                          capi.ptr(ws), capi.current_stream(dev))
+    capi.check('bgs_rpn_loss', rc)
+    return lc, lb, nt
+
+
+def decode_proposals(level_outs, level_counts, num_anchors, anchors, top_idx, top_logit, img_hw,
+                     means, stds, wh_ratio_clip=16 / 1000):
+    """``[N,L,nmax,5]`` decoded + clamped proposals (score = sigmoid of the top logit)."""
+    _require_cuda(anchors, top_idx, top_logit, *level_outs)
+    lib = capi.load()
+    L = len(level_outs)
+    N, L2, nmax = top_idx.shape
+    assert L2 == L and top_idx.dtype == torch.int64 and top_idx.is_contiguous()
+    assert top_logit.dtype == torch.float32 and top_logit.is_contiguous()
+    hw = [int(o.shape[1] * o.shape[2]) for o in level_outs]
+    out = torch.empty((N, L, nmax, 5), dtype=torch.float32, device=anchors.device)
+    flat_hw = []
+    for h, w in img_hw:
+        flat_hw += [int(h), int(w)]
+    rc = lib.bgs_decode_proposals(_c_ptr_array(level_outs), _c_int_array(hw),
+                                  _c_int_array(level_counts), L, num_anchors, capi.ptr(anchors),
+                                  capi.ptr(top_idx), capi.ptr(top_logit), N, _c_int_array(flat_hw),
+                                  _c_float_array(means), _c_float_array(stds),
+                                  float(wh_ratio_clip), nmax, capi.ptr(out),
+                                  capi.current_stream(anchors.device))
+    capi.check('bgs_decode_proposals', rc)
+    return out
+
+
+def rcnn_targets(boxes_list, assigned_list, inds_list, valid_list, gt_labels_list, gt_cat,
+                 gt_offsets, num, means, stds, pos_weight=-1):
+    """Sampled RoIs -> ``rois [N*num,5]``, ``labels`` i64, ``label_weights``, ``bbox_targets``,
+    ``bbox_weights`` (positives first per image, as bbox_target_single lays them out)."""
+    _require_cuda(gt_cat, *boxes_list)
+    lib = capi.load()
+    N = len(boxes_list)
+    dev = gt_cat.device
+    for b, a, i, g in zip(boxes_list, assigned_list, inds_list, gt_labels_list):
+        assert b.dtype == torch.float32 and b.is_contiguous() and b.dim() == 2
+        assert a.dtype == torch.int32 and a.is_contiguous()
+        assert i.dtype == torch.int64 and i.is_contiguous() and i.numel() == num
+        assert g.dtype == torch.int64 and g.is_contiguous()
+    valid_u8 = [None if v is None else v.to(torch.uint8).contiguous() for v in valid_list]
+    rois = torch.empty((N * num, 5), dtype=torch.float32, device=dev)
+    labels = torch.empty((N * num,), dtype=torch.int64, device=dev)
+    lw = torch.empty((N * num,), dtype=torch.float32, device=dev)
+    bt = torch.empty((N * num, 4), dtype=torch.float32, device=dev)
+    bw = torch.empty((N * num, 4), dtype=torch.float32, device=dev)
+    rc = lib.bgs_rcnn_targets(_c_ptr_array(boxes_list), _c_int_array([b.shape[1] for b in boxes_list]),
+                              _c_ptr_array(assigned_list), _c_ptr_array(inds_list),
+                              _c_ptr_array(valid_u8) if any(v is not None for v in valid_u8) else None,
+                              _c_ptr_array(gt_labels_list), capi.ptr(_f32c(gt_cat)),
+                              _c_int_array(gt_offsets), N, num, _c_float_array(means),
+                              _c_float_array(stds), float(pos_weight), capi.ptr(rois),
+                              capi.ptr(labels), capi.ptr(lw), capi.ptr(bt), capi.ptr(bw),
+                              capi.current_stream(dev))
+    capi.check('bgs_rcnn_targets', rc)
+    return rois, labels, lw, bt, bw
+
+
 def selftest_wave_reduce(values):
     """Runs the device self-test of the wave reduction primitive (64 floats in)."""
     _require_cuda(values)

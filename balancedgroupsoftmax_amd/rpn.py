@@ -127,13 +127,15 @@ class RPNHead(nn.Module):
         """NHWC feature maps -> (cls_scores, bbox_preds): per level ``[N,H,W,A]``, ``[N,H,W,4A]``."""
         _check_frozen(self, 'rpn_head')
         f = self._cache.get(self, self._build_fold)
-        cls_scores, bbox_preds = [], []
+        cls_scores, bbox_preds, fused = [], [], []
         na = self.num_anchors * self.cls_out_channels
         for x in feats:
             h = BF.conv2d_nhwc(x, f['conv'][0], f['conv'][1], pad=1, relu=True)
             o = BF.conv2d_nhwc(h, f['head'][0], f['head'][1])
+            fused.append(o)
             cls_scores.append(o[..., :na])
             bbox_preds.append(o[..., na:])
+        self._fused = fused      # [N,H,W,A+4A] per level: what the fused loss / decode kernels read
         return cls_scores, bbox_preds
 
     # -- anchors ------------------------------------------------------------------------
@@ -196,6 +198,8 @@ class RPNHead(nn.Module):
         (rpn_head.py:37-53, anchor_head.py:163-207)."""
         featmap_sizes = [tuple(c.shape[1:3]) for c in cls_scores]
         dev = cls_scores[0].device
+        if self._use_fused(cls_scores):
+            return self._loss_fused(featmap_sizes, gt_bboxes, img_metas, cfg, generator)
         anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, dev)
         n_lvl = [a.size(0) for a in anchor_list[0]]
         per_img = []
@@ -225,6 +229,70 @@ class RPNHead(nn.Module):
             losses_bbox.append(self.loss_bbox(bp, bt, bw, avg_factor=num_total_samples))
         return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox)
 
+    # -- fused HIP path (csrc/det_targets.hip) -------------------------------------------------
+    def _use_fused(self, cls_scores):
+        """The fused kernels read the head's own output buffers and produce loss VALUES; they
+        apply when running on the GPU with the RPN frozen (every shipped BAGS config)."""
+        fused = getattr(self, '_fused', None)
+        if fused is None or not cls_scores[0].is_cuda or len(fused) != len(cls_scores):
+            return False
+        if any(c.data_ptr() != o.data_ptr() for c, o in zip(cls_scores, fused)):
+            return False
+        return not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+
+    def _all_anchors(self, featmap_sizes, dev):
+        key = ('all', tuple(featmap_sizes), str(dev))
+        if key not in self._anchor_cache:
+            self._anchor_cache[key] = torch.cat(self._level_anchors(featmap_sizes, dev)).contiguous()
+        return self._anchor_cache[key]
+
+    def _inside_flags(self, featmap_sizes, img_metas, allowed_border, dev):
+        """anchor_inside_flags (anchor_target.py:162-174) for every image, ``[N,A]`` uint8; depends
+        only on the image geometry, so it is cached."""
+        key = ('inside', tuple(featmap_sizes), allowed_border, str(dev),
+               tuple((tuple(m['pad_shape'][:2]), tuple(m['img_shape'][:2])) for m in img_metas))
+        if key not in self._anchor_cache:
+            anchors = self._all_anchors(featmap_sizes, dev)
+            _, flags = self.get_anchors(featmap_sizes, img_metas, dev)
+            rows = []
+            for meta, fl in zip(img_metas, flags):
+                inside = torch.cat(fl)
+                if allowed_border >= 0:
+                    h, w = meta['img_shape'][:2]
+                    inside = inside & (anchors[:, 0] >= -allowed_border) & \
+                        (anchors[:, 1] >= -allowed_border) & (anchors[:, 2] < w + allowed_border) & \
+                        (anchors[:, 3] < h + allowed_border)
+                rows.append(inside)
+            self._anchor_cache[key] = torch.stack(rows).to(torch.uint8).contiguous()
+        return self._anchor_cache[key]
+
+    def _loss_fused(self, featmap_sizes, gt_bboxes, img_metas, cfg, generator=None):
+        dev = self._fused[0].device
+        anchors = self._all_anchors(featmap_sizes, dev)
+        inside = self._inside_flags(featmap_sizes, img_metas, cfg.allowed_border, dev)
+        gt_cat = torch.cat([g[:, :4] for g in gt_bboxes]).float().contiguous()
+        offs = [0]
+        for g in gt_bboxes:
+            offs.append(offs[-1] + int(g.size(0)))
+        ac, sc = cfg.assigner, cfg.sampler
+        if not ac.get('gt_max_assign_all', True):
+            raise NotImplementedError('gt_max_assign_all=False')
+        assigned = BF.iou_assign(anchors, gt_cat, offs, ac.pos_iou_thr, ac.neg_iou_thr,
+                                 ac.get('min_pos_iou', 0.0), valid=inside, shared_boxes=True)
+        pos, neg = [], []
+        for i in range(len(img_metas)):
+            p, n = A.sample_pos_neg_masks(assigned[i], sc.num, sc.pos_fraction,
+                                          sc.get('neg_pos_ub', -1), generator)
+            pos.append(p)
+            neg.append(n)
+        lc, lb, _ = BF.rpn_loss(self._fused, self.num_anchors, anchors, assigned,
+                                torch.stack(pos).to(torch.uint8), torch.stack(neg).to(torch.uint8),
+                                gt_cat, offs, self.target_means, self.target_stds,
+                                self.loss_bbox.beta, cfg.pos_weight, self.loss_cls.loss_weight,
+                                self.loss_bbox.loss_weight)
+        L = len(self._fused)
+        return dict(loss_rpn_cls=[lc[i] for i in range(L)], loss_rpn_bbox=[lb[i] for i in range(L)])
+
     # -- proposals ----------------------------------------------------------------------
     @torch.no_grad()
     def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg, rescale=False):
@@ -239,8 +307,23 @@ class RPNHead(nn.Module):
         N = cls_scores[0].shape[0]
         L = len(cls_scores)
         nmax = cfg.nms_pre
-        boxes = torch.zeros((N, L, nmax, 5), dtype=torch.float32, device=dev)
         counts = []
+        if self._use_fused(cls_scores):
+            top_i = torch.zeros((N, L, nmax), dtype=torch.int64, device=dev)
+            top_l = torch.zeros((N, L, nmax), dtype=torch.float32, device=dev)
+            for lvl in range(L):
+                logits = cls_scores[lvl].reshape(N, -1)          # sigmoid is monotone: top-k on logits
+                k = min(logits.shape[1], nmax)
+                v, i = logits.topk(k, dim=1)
+                top_i[:, lvl, :k] = i
+                top_l[:, lvl, :k] = v
+                counts.append(k)
+            boxes = BF.decode_proposals(self._fused, counts, self.num_anchors,
+                                        self._all_anchors(featmap_sizes, dev), top_i, top_l,
+                                        [m['img_shape'][:2] for m in img_metas],
+                                        self.target_means, self.target_stds)
+            return self._nms_and_select(boxes, counts, cfg, N, L, nmax, dev)
+        boxes = torch.zeros((N, L, nmax, 5), dtype=torch.float32, device=dev)
         for lvl in range(L):
             scores = cls_scores[lvl].reshape(N, -1).float().sigmoid()
             deltas = bbox_preds[lvl].reshape(N, -1, 4).float()
@@ -254,6 +337,9 @@ class RPNHead(nn.Module):
                                                    self.target_stds, img_metas[i]['img_shape'])
             boxes[:, lvl, :k, 4] = top_s
             counts.append(k)
+        return self._nms_and_select(boxes, counts, cfg, N, L, nmax, dev)
+
+    def _nms_and_select(self, boxes, counts, cfg, N, L, nmax, dev):
         ckey = ('cnt', tuple(counts), N, str(dev))
         if ckey not in self._anchor_cache:        # uploaded once (no H2D copy per iteration)
             self._anchor_cache[ckey] = torch.tensor(counts * N, dtype=torch.int32, device=dev)

@@ -195,6 +195,78 @@ int bgs_nms_batched(const float* boxes, const int* counts, int P, int nmax, floa
                     int iou_mode, int max_keep, int* keep, int* keep_count, void* workspace,
                     bgs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Target assignment without the [G, A] IoU matrix.  Replaces MaxIoUAssigner.assign /
+ *   assign_wrt_overlaps (mmdet/core/bbox/assigners/max_iou_assigner.py:47-180, incl. its CPU
+ *   fallback for > 50 GTs and the Python loop over GTs) and bbox_overlaps
+ *   (mmdet/core/bbox/geometry.py:4-63, legacy +1 sizes), for N images at once.
+ *   boxes: image n reads box i at boxes + n*box_img_stride + i*box_stride floats
+ *          (box_img_stride = 0: the same anchors for every image);
+ *   valid [N,A] uint8 or NULL (anchors outside the image take no part and get -1);
+ *   gt [sum G,4] concatenated GT boxes, host_gt_offsets [N+1] (HOST);
+ *   assigned [N,A] int32: -1 ignore, 0 negative (neg_iou_lo <= max IoU < neg_iou_hi),
+ *   g+1 positive (max IoU >= pos_iou_thr -> argmax gt; then every gt with max >= min_pos_iou
+ *   claims all boxes attaining its maximum, later gts overriding earlier ones);
+ *   max_overlaps_out [N,A] float or NULL.  workspace: bgs_iou_assign_workspace_bytes().
+ * ---------------------------------------------------------------------------------- */
+size_t bgs_iou_assign_workspace_bytes(int N, int A, int G_total);
+int bgs_iou_assign(const float* boxes, long long box_img_stride, int box_stride,
+                   const uint8_t* valid, const float* gt, const int* host_gt_offsets, int N, int A,
+                   float pos_iou_thr, float neg_iou_lo, float neg_iou_hi, float min_pos_iou,
+                   int* assigned, float* max_overlaps_out, void* workspace, bgs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * RPN loss over the sampled anchors.  Replaces the target encoding of anchor_target_single
+ *   (mmdet/core/anchor/anchor_target.py:118-152) + AnchorHead.loss / loss_single
+ *   (mmdet/models/anchor_heads/anchor_head.py:142-207) for the sigmoid-objectness RPN:
+ *     loss_cls[l]  = w_cls  * sum BCEWithLogits(x, is_pos) * label_weight / num_total_samples
+ *     loss_bbox[l] = w_bbox * sum SmoothL1(pred - bbox2delta(anchor, gt); beta) / num_total_samples
+ *     num_total_samples = sum_n max(n_pos_n, 1) + max(n_neg_n, 1)
+ *   host_level_outs [L] HOST array of device pointers to the fused head output of each level,
+ *   [N, H_l*W_l, A + 4A] float (objectness logits first, then 4 deltas per anchor);
+ *   host_level_hw [L] (H_l*W_l); anchors [A_total,4]; assigned [N,A_total] int32;
+ *   pos_mask / neg_mask [N,A_total] uint8 (the sampled anchors); gt as in bgs_iou_assign.
+ *   Outputs loss_cls_out [L], loss_bbox_out [L], num_total_out [1] or NULL.  Values only
+ *   (the RPN is frozen in every shipped BAGS config).
+ * ---------------------------------------------------------------------------------- */
+size_t bgs_rpn_loss_workspace_bytes(int N, int A_total, int L);
+int bgs_rpn_loss(const float* const* host_level_outs, const int* host_level_hw, int L,
+                 int num_anchors, const float* anchors, const int* assigned,
+                 const uint8_t* pos_mask, const uint8_t* neg_mask, const float* gt,
+                 const int* host_gt_offsets, int N, const float* host_means,
+                 const float* host_stds, float beta, float pos_weight, float loss_weight_cls,
+                 float loss_weight_bbox, float* loss_cls_out, float* loss_bbox_out,
+                 float* num_total_out, void* workspace, bgs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Proposal decode: gather + delta2bbox + clamp + sigmoid for the top-k anchors of every
+ *   (image, level).  Replaces rpn_head.py:62-90 + transforms.py:34-111.
+ *   top_idx / top_logit [N,L,nmax] (int64 / float; entries >= host_level_counts[l] ignored);
+ *   host_img_hw [N,2] (img_shape h, w); boxes_out [N,L,nmax,5] (x1,y1,x2,y2,score; zero padded).
+ * ---------------------------------------------------------------------------------- */
+int bgs_decode_proposals(const float* const* host_level_outs, const int* host_level_hw,
+                         const int* host_level_counts, int L, int num_anchors,
+                         const float* anchors, const long long* top_idx, const float* top_logit,
+                         int N, const int* host_img_hw, const float* host_means,
+                         const float* host_stds, float wh_ratio_clip, int nmax, float* boxes_out,
+                         bgs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * RoI-head targets of the sampled RoIs.  Replaces bbox2roi (transforms.py:149-168) +
+ *   bbox_target_single (mmdet/core/bbox/bbox_target.py:35-61).  Per image n (HOST pointer
+ *   arrays): candidate boxes (row stride host_box_strides[n] floats), assigned [cand] int32,
+ *   inds [num] int64 (sampled candidates, positives first), valid [num] uint8 or NULL,
+ *   gt_labels [G_n] int64.  Outputs rois [N*num,5], labels [N*num] int64, label_weights,
+ *   bbox_targets [N*num,4], bbox_weights [N*num,4].
+ * ---------------------------------------------------------------------------------- */
+int bgs_rcnn_targets(const float* const* host_boxes, const int* host_box_strides,
+                     const int* const* host_assigned, const long long* const* host_inds,
+                     const uint8_t* const* host_valid, const long long* const* host_gt_labels,
+                     const float* gt, const int* host_gt_offsets, int N, int num,
+                     const float* host_means, const float* host_stds, float pos_weight,
+                     float* rois, long long* labels, float* label_weights, float* bbox_targets,
+                     float* bbox_weights, bgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,3 +202,109 @@ def test_full_training_iteration(tmp_path):
     # log-loss of 5 bins at random init: bin0 ~ log 2, fg bins ~ log(n_b)
     assert 0.3 < float(log_vars['loss_cls_bin0']) < 1.5
     assert 3.0 < float(log_vars['loss_cls_bin4']) < 9.0
+
+
+# ---------------------------------------------------------------------------------------------
+# fused target kernels (csrc/det_targets.hip) vs the tensor-op forms (which tests/
+# test_detector_host_cpu.py pins against the reference's own classes)
+# ---------------------------------------------------------------------------------------------
+def _rand_boxes(n, seed, w=640, h=400):
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([w - 60., h - 60.])
+    wh = torch.rand(n, 2, generator=g) * 150 + 4
+    return torch.cat([xy, xy + wh], 1)
+
+
+@pytest.mark.parametrize('thr', [(0.7, 0.3, 0.3), (0.5, 0.5, 0.5)])
+def test_iou_assign_kernel_equals_tensor_form(thr):
+    from balancedgroupsoftmax_amd import assign as A
+    from balancedgroupsoftmax_amd import functional as BF
+    pos, neg, minpos = thr
+    gts = [_rand_boxes(23, 1), _rand_boxes(300, 2), _rand_boxes(1, 3)]      # incl. G > 256 chunking
+    offs = [0, 23, 323, 324]
+    boxes = _rand_boxes(5000, 10)
+    boxes[:60] = gts[0][torch.arange(60) % 23] + torch.randn(60, 4, generator=torch.Generator(
+    ).manual_seed(4))
+    boxes[60:70] = boxes[:10]                       # exact ties between boxes
+    boxes[70:75] = gts[1][:5]                       # IoU exactly 1
+    valid = (torch.rand(3, 5000, generator=torch.Generator().manual_seed(5)) > 0.1)
+    gt_cat = torch.cat(gts).to(DEV)
+    got, mo = BF.iou_assign(boxes.to(DEV), gt_cat, offs, pos, neg, minpos,
+                            valid=valid.to(torch.uint8).to(DEV), shared_boxes=True,
+                            return_max_overlaps=True)
+    for i, g in enumerate(gts):
+        ov = A.bbox_overlaps(g, boxes)                                       # CPU tensor form
+        exp, exp_mo = A.max_iou_assign(ov, pos, neg, minpos, valid=valid[i])
+        assert torch.equal(got[i].cpu().long(), exp), i
+        assert torch.equal(mo[i].cpu()[valid[i]], exp_mo[valid[i]])
+    # per-image boxes with a row stride of 5 (proposals carry their score)
+    per = torch.stack([torch.cat([_rand_boxes(700, 20 + i), torch.rand(700, 1)], 1) for i in range(3)])
+    got2 = BF.iou_assign(per.to(DEV), gt_cat, offs, pos, neg, minpos, shared_boxes=False)
+    for i, g in enumerate(gts):
+        exp, _ = A.max_iou_assign(A.bbox_overlaps(g, per[i, :, :4]), pos, neg, minpos)
+        assert torch.equal(got2[i].cpu().long(), exp)
+
+
+def test_rpn_fused_loss_and_proposals_equal_tensor_form(tmp_path):
+    model = _detector(tmp_path).to(DEV)
+    for p in model.parameters():
+        p.requires_grad = False
+    rpn = model.rpn_head
+    torch.manual_seed(5)
+    feats = [torch.randn(2, h, w, 256, device=DEV) for h, w in
+             [(80, 120), (40, 60), (20, 30), (10, 15), (5, 8)]]
+    metas = [dict(img_shape=(320, 475, 3), pad_shape=(320, 480, 3)),
+             dict(img_shape=(310, 480, 3), pad_shape=(320, 480, 3))]
+    gts = [_rand_boxes(9, 1, 470, 310).to(DEV), _rand_boxes(14, 2, 470, 310).to(DEV)]
+    with torch.no_grad():
+        rpn.rpn_cls.bias.fill_(-1.0)
+        rpn.rpn_cls.weight.normal_(0, 0.05)
+        rpn.rpn_reg.weight.normal_(0, 0.02)
+    cls, reg = rpn(feats)
+    cfg = model.train_cfg
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(11)
+    assert rpn._use_fused(cls)
+    fused = rpn.loss(cls, reg, gts, metas, cfg.rpn, generator=gen)
+    props_f = rpn.get_bboxes(cls, reg, metas, cfg.rpn_proposal)
+    saved = rpn._fused
+    rpn._fused = None                                   # forces the tensor-op path
+    gen.manual_seed(11)
+    plain = rpn.loss(cls, reg, gts, metas, cfg.rpn, generator=gen)
+    props_p = rpn.get_bboxes(cls, reg, metas, cfg.rpn_proposal)
+    rpn._fused = saved
+    for k in ('loss_rpn_cls', 'loss_rpn_bbox'):
+        a = torch.stack(fused[k]).cpu()
+        b = torch.stack([v.reshape(()) for v in plain[k]]).cpu()
+        assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), (k, a, b)
+    assert float(torch.stack(fused['loss_rpn_bbox']).sum()) > 0
+    for (pf, vf), (pp, vp) in zip(props_f, props_p):
+        assert torch.equal(vf, vp) and int(vf.sum()) > 500
+        assert torch.allclose(pf[vf], pp[vp], rtol=1e-5, atol=1e-3)
+
+
+def test_rcnn_fused_sampling_targets_equal_tensor_form(tmp_path):
+    model = _detector(tmp_path).to(DEV)
+    gts = [_rand_boxes(12, 1).to(DEV), _rand_boxes(7, 2).to(DEV)]
+    labels = [torch.randint(1, 1231, (12,), device=DEV), torch.randint(1, 1231, (7,), device=DEV)]
+    props = []
+    for i in range(2):
+        b = _rand_boxes(2000, 30 + i)
+        b[:200] = gts[i].cpu()[torch.arange(200) % gts[i].size(0)] + torch.randn(200, 4) * 3
+        p = torch.cat([b, torch.rand(2000, 1)], 1).to(DEV)
+        v = torch.ones(2000, dtype=torch.bool, device=DEV)
+        v[1990:] = False
+        props.append((p, v))
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(3)
+    rois, (lab, lw, bt, bw) = model._sample_rois_fused(props, gts, labels, gen)
+    gen.manual_seed(3)
+    samples = [model._assign_and_sample(props[i][0], props[i][1], gts[i], labels[i], gen)
+               for i in range(2)]
+    exp_rois = torch.cat([torch.cat([s['bboxes'].new_full((512, 1), i), s['bboxes']], 1)
+                          for i, s in enumerate(samples)], 0)
+    exp = model._bbox_targets(samples)
+    assert torch.equal(rois, exp_rois)
+    assert torch.equal(lab, exp[0]) and torch.equal(lw, exp[1]) and torch.equal(bw, exp[3])
+    assert torch.allclose(bt, exp[2], rtol=1e-5, atol=1e-6)
+    assert int((lab > 0).sum()) == 256 and (lab.view(2, 512)[:, :128] > 0).all()
