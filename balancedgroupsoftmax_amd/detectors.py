@@ -132,7 +132,7 @@ class TwoStageDetector(nn.Module):
             labels.append(torch.where(pos, s['labels'], torch.zeros_like(s['labels'])))
             pw = 1.0 if rc.pos_weight <= 0 else rc.pos_weight
             lw.append(posf * pw + (s['valid'] & ~s['is_pos']).float())
-            bt.append(d * posf[:, None])
+            bt.append(torch.where(pos[:, None], d, torch.zeros_like(d)))   # (not d*0: NaN-safe)
             bw.append(posf[:, None].expand(-1, 4).contiguous())
         return torch.cat(labels), torch.cat(lw), torch.cat(bt), torch.cat(bw)
 

@@ -185,7 +185,7 @@ class RPNHead(nn.Module):
         gt_of = gt_bboxes[(assigned - 1).clamp(min=0)]
         deltas = bbox2delta(anchors, gt_of, self.target_means, self.target_stds)
         posf = pos.to(anchors.dtype)
-        bbox_targets = deltas * posf[:, None]
+        bbox_targets = torch.where(pos[:, None], deltas, torch.zeros_like(deltas))
         bbox_weights = posf[:, None].expand(-1, 4)
         labels = pos.long()
         pw = 1.0 if cfg.pos_weight <= 0 else cfg.pos_weight
