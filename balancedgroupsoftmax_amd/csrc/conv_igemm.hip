@@ -30,13 +30,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
-constexpr int BK = 16;
 // LDS row = [k even: 8 floats][k odd: 8 floats][4 pad] = 20 floats.  The A/B fragment of
 // v_mfma_f32_32x32x2_f32 wants, in lane l, k = 2*kk + (l >> 5) for kk = 0..7: lanes 0-31 need
 // the even k of their row and lanes 32-63 the odd k — 8 contiguous floats each, fetched with two
 // ds_read_b128 per K tile (instead of 8 ds_read_b32: the 64x64 tile was LDS-bandwidth bound).
 // Stride 20 floats makes the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots.
-constexpr int LDK = 20;
+// (BK = 16: stride 20 floats; BK = 32: stride 36 floats — both spread 16 consecutive rows over
+// 16 distinct 16-byte slots of the 256-byte bank row.)
 
 struct ConvArgs {
   const float* x;     // [N, H, W, Cin]
@@ -49,10 +49,13 @@ struct ConvArgs {
   int relu, res_mode;
 };
 
-template <int MB, int NB>
+template <int MB, int NB, int BK>
 __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
   constexpr int BM = 64 * MB, BN = 64 * NB;
-  constexpr int PA = BM / 64, PB = BN / 64;  // staging passes (64 rows per pass)
+  constexpr int LDK = BK + 4;            // LDS row stride in floats
+  constexpr int KQ = BK / 4;             // 16-byte quads per row of a K tile
+  constexpr int RP = kThreads / KQ;      // rows staged per pass
+  constexpr int PA = BM / RP, PB = BN / RP;
   __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
 
@@ -63,14 +66,14 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
   // ---- staging role of this thread: 4 consecutive k (one 16-byte load) of rows srow + 64*pass
-  const int kq = tid & 3;
-  const int srow = tid >> 2;
+  const int kq = tid % KQ;
+  const int srow = tid / KQ;
   int a_hi0[PA], a_wi0[PA];
   const float* a_base[PA];
   bool a_ok[PA];
 #pragma unroll
   for (int q = 0; q < PA; ++q) {
-    const int m = m0 + srow + 64 * q;
+    const int m = m0 + srow + RP * q;
     a_ok[q] = m < p.M;
     const int mm = a_ok[q] ? m : 0;
     const int hw = p.Ho * p.Wo;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
   bool b_ok[PB];
 #pragma unroll
   for (int q = 0; q < PB; ++q) {
-    const int j = n0 + srow + 64 * q;
+    const int j = n0 + srow + RP * q;
     b_ok[q] = j < p.Cout;
     b_base[q] = p.w + (size_t)(b_ok[q] ? j : 0) * p.K;
   }
@@ -129,17 +132,17 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    // k = 4*kq + {0,1,2,3}: evens (k = 4kq, 4kq+2) -> slots 2kq, 2kq+1; odds -> 8 + 2kq, 8 + 2kq+1
+    // k = 4*kq + {0,1,2,3}: evens (k = 4kq, 4kq+2) -> slots 2kq, 2kq+1; odds -> BK/2 + 2kq, +1
     for (int q = 0; q < PA; ++q) {
-      float* d = &As[buf][(srow + 64 * q) * LDK + kq * 2];
+      float* d = &As[buf][(srow + RP * q) * LDK + kq * 2];
       *reinterpret_cast<f32x2*>(d) = f32x2{ra[q][0], ra[q][2]};
-      *reinterpret_cast<f32x2*>(d + 8) = f32x2{ra[q][1], ra[q][3]};
+      *reinterpret_cast<f32x2*>(d + BK / 2) = f32x2{ra[q][1], ra[q][3]};
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
-      float* d = &Bs[buf][(srow + 64 * q) * LDK + kq * 2];
+      float* d = &Bs[buf][(srow + RP * q) * LDK + kq * 2];
       *reinterpret_cast<f32x2*>(d) = f32x2{rb[q][0], rb[q][2]};
-      *reinterpret_cast<f32x2*>(d + 8) = f32x2{rb[q][1], rb[q][3]};
+      *reinterpret_cast<f32x2*>(d + BK / 2) = f32x2{rb[q][1], rb[q][3]};
     }
   };
 
@@ -159,19 +162,19 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tile();  // global loads in flight under the MFMAs below
-    const float* Ab = &As[buf][(wm * 32 * MB + frow) * LDK + fk * 8];
-    const float* Bb = &Bs[buf][(wn * 32 * NB + frow) * LDK + fk * 8];
-    f32x4 av[MB][2], bv[NB][2];
+    const float* Ab = &As[buf][(wm * 32 * MB + frow) * LDK + fk * (BK / 2)];
+    const float* Bb = &Bs[buf][(wn * 32 * NB + frow) * LDK + fk * (BK / 2)];
+    f32x4 av[MB][BK / 8], bv[NB][BK / 8];
 #pragma unroll
-    for (int a = 0; a < MB; ++a) {
-      av[a][0] = *reinterpret_cast<const f32x4*>(Ab + a * 32 * LDK);
-      av[a][1] = *reinterpret_cast<const f32x4*>(Ab + a * 32 * LDK + 4);
-    }
+    for (int a = 0; a < MB; ++a)
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      bv[b][0] = *reinterpret_cast<const f32x4*>(Bb + b * 32 * LDK);
-      bv[b][1] = *reinterpret_cast<const f32x4*>(Bb + b * 32 * LDK + 4);
-    }
+      for (int v = 0; v < BK / 8; ++v)
+        av[a][v] = *reinterpret_cast<const f32x4*>(Ab + a * 32 * LDK + 4 * v);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int v = 0; v < BK / 8; ++v)
+        bv[b][v] = *reinterpret_cast<const f32x4*>(Bb + b * 32 * LDK + 4 * v);
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
 #pragma unroll
@@ -294,16 +297,22 @@ extern "C" int bgs_conv2d_nhwc_f32(const float* x, const float* w, const float* 
   if (Cout > 64 && p.K >= 1152 && M >= 100000) tile = 22;
   else if (Cout <= 64 && M >= 400000) tile = 21;
   if (force == 22 || force == 21 || force == 11) tile = force;
-  if (tile == 22) {
-    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Cout + 127) / 128));
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 2>), grid, dim3(kThreads), 0, st, p);
-  } else if (tile == 21) {
-    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Cout + 63) / 64));
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 1>), grid, dim3(kThreads), 0, st, p);
-  } else {
-    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((Cout + 63) / 64));
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 1>), grid, dim3(kThreads), 0, st, p);
-  }
+  // K tile: 32 for deep reductions (fewer barriers per flop: +5-15 % on K >= 512 with the 64x64
+  // tile), 16 for shallow ones and for the 128x128 tile (profiles/r1q_conv_sweep_bk*.txt)
+  int bk = (p.K >= 512 && tile == 11) ? 32 : 16;
+  if (const char* e = getenv("BGS_CONV_BK")) bk = atoi(e) == 32 ? 32 : (atoi(e) == 16 ? 16 : bk);
+#define BGS_CONV_LAUNCH(MB_, NB_, BM_, BN_)                                                      \
+  do {                                                                                           \
+    dim3 grid((unsigned)((M + BM_ - 1) / BM_), (unsigned)((Cout + BN_ - 1) / BN_));              \
+    if (bk == 32)                                                                                \
+      hipLaunchKernelGGL((conv_igemm_f32_kernel<MB_, NB_, 32>), grid, dim3(kThreads), 0, st, p); \
+    else                                                                                         \
+      hipLaunchKernelGGL((conv_igemm_f32_kernel<MB_, NB_, 16>), grid, dim3(kThreads), 0, st, p); \
+  } while (0)
+  if (tile == 22) BGS_CONV_LAUNCH(2, 2, 128, 128);
+  else if (tile == 21) BGS_CONV_LAUNCH(2, 1, 128, 64);
+  else BGS_CONV_LAUNCH(1, 1, 64, 64);
+#undef BGS_CONV_LAUNCH
   BGS_RETURN_LAUNCH_STATUS();
 }
 
