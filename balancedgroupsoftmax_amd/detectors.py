@@ -167,11 +167,53 @@ class TwoStageDetector(nn.Module):
             losses.update(self.bbox_head.loss(cls_score, bbox_pred, *targets))
         return losses
 
+    # ------------------------------------------------------------------ test-time path
+    def simple_test_rpn(self, x, img_meta, rpn_test_cfg):
+        """test_mixins.py:8-12; proposals stay fixed-shape ``([max_num,5], valid)`` per image."""
+        cls_scores, bbox_preds = self.rpn_head(x)
+        return self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_meta, rpn_test_cfg)
+
+    def simple_test_bboxes(self, x, img_meta, proposals, rcnn_test_cfg, rescale=False):
+        """test_mixins.py:39-67 for ONE image (the reference tests with imgs_per_gpu=1):
+        RoIAlign -> head -> merged scores + decoded boxes -> one batched 1230-class NMS."""
+        from .post_processing import multiclass_nms
+        props, valid = proposals[0] if isinstance(proposals[0], tuple) else (proposals[0], None)
+        rois = torch.cat([props.new_zeros((props.size(0), 1)), props[:, :4]], dim=1)
+        feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
+        cls_score, bbox_pred = self.bbox_head(feats, nhwc=True)
+        bboxes, scores = self.bbox_head.get_det_bboxes(
+            rois, cls_score, bbox_pred, img_meta[0]['img_shape'], img_meta[0]['scale_factor'],
+            rescale=rescale, cfg=None)
+        if valid is not None:        # padding rows of the fixed-shape proposal list never survive
+            scores = torch.where(valid[:, None], scores, scores.new_full((), -1.0))
+        det_bboxes, det_labels = multiclass_nms(bboxes, scores, rcnn_test_cfg.score_thr,
+                                                rcnn_test_cfg.nms, rcnn_test_cfg.max_per_img)
+        return det_bboxes, det_labels, scores
+
+    def simple_test(self, img, img_meta, proposals=None, rescale=False):
+        """two_stage.py:267-289 (bbox branch): list of ``num_classes-1`` ``[k_c, 5]`` arrays."""
+        from .post_processing import bbox2result
+        assert self.with_bbox, 'Bbox head must be implemented.'
+        x = self.extract_feat(img)
+        proposal_list = (self.simple_test_rpn(x, img_meta, self.test_cfg.rpn)
+                         if proposals is None else proposals)
+        det_bboxes, det_labels, _ = self.simple_test_bboxes(x, img_meta, proposal_list,
+                                                            self.test_cfg.rcnn, rescale=rescale)
+        return bbox2result(det_bboxes, det_labels, self.bbox_head.num_classes)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        """base.py forward_test: one scale only (aug_test / TTA is not on the BAGS path)."""
+        if isinstance(imgs, (list, tuple)):
+            if len(imgs) != 1:
+                raise NotImplementedError('multi-scale aug_test is not part of the BAGS path')
+            imgs, img_metas = imgs[0], img_metas[0]
+        with torch.no_grad():
+            return self.simple_test(imgs, img_metas, **kwargs)
+
     def forward(self, img, img_meta, return_loss=True, **kwargs):
         if return_loss:
             return self.forward_train(img, img_meta, **kwargs)
-        raise NotImplementedError('test-time path (simple_test / multiclass NMS) is a later row '
-                                  '(SURVEY.md §8f rank 2)')
+        return self.forward_test(img, img_meta, **kwargs)
 
 
 @DETECTORS.register_module

@@ -154,3 +154,54 @@ def make_boxes(n, seed, img_w=1333, img_h=800, cluster=True):
     y2 = np.clip(cy + h / 2, 0, img_h - 1)
     sc = rs.uniform(0, 1, n)
     return np.stack([x1, y1, x2, y2, sc], 1).astype(F32)
+
+
+def make_multiclass_case(n, C, seed, agnostic=False, clusters=12, img=(800, 1333), peak=0.6):
+    """Seeded test-time inputs: ``n`` RoIs clustered around ``clusters`` objects, class-specific
+    (or agnostic) decoded boxes ``[n, 4C]`` and softmax-like scores ``[n, C]`` (column 0 = bg)."""
+    rs = np.random.RandomState(seed)
+    H, W = img
+    ctr = rs.uniform(0.15, 0.85, size=(clusters, 2)) * np.array([W, H])
+    size = rs.uniform(40, 300, size=(clusters, 2))
+    which = rs.randint(0, clusters, size=n)
+    c = ctr[which] + rs.normal(0, 6, size=(n, 2))
+    s = size[which] * np.exp(rs.normal(0, 0.08, size=(n, 2)))
+    base = np.concatenate([c - s / 2, c + s / 2], axis=1)                   # [n,4]
+    if agnostic:
+        boxes = base.astype(F32)
+    else:
+        boxes = (base[:, None, :] + rs.normal(0, 2.0, size=(n, C, 4))).reshape(n, 4 * C).astype(F32)
+    logits = rs.normal(0, 1, size=(n, C))
+    fav = rs.randint(1, C, size=clusters)[which]
+    logits[np.arange(n), fav] += rs.uniform(2, 8, size=n) * peak / 0.6
+    logits[:, 0] += 2.0
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    scores = (e / e.sum(1, keepdims=True)).astype(F32)
+    return boxes, scores
+
+
+def multiclass_nms(multi_bboxes, multi_scores, score_thr, iou_thr, max_num=-1, mode='cuda'):
+    """Restatement of mmdet/core/post_processing/bbox_nms.py:31-66 on numpy: classes 1..C-1 in
+    order; per class the rows with score > thr, NMS, survivors in ORIGINAL row order (what both
+    nms_cpu.cpp:58 and nms_kernel.cu:127-130 return); concatenated class-major; if more than
+    ``max_num`` survive, the top ``max_num`` by score (descending)."""
+    multi_bboxes = np.asarray(multi_bboxes, F32)
+    multi_scores = np.asarray(multi_scores, F32)
+    n, C = multi_scores.shape
+    out_b, out_l = [], []
+    for i in range(1, C):
+        sel = multi_scores[:, i] > F32(score_thr)
+        if not sel.any():
+            continue
+        b = multi_bboxes[sel] if multi_bboxes.shape[1] == 4 else multi_bboxes[sel, 4 * i:4 * i + 4]
+        d = np.concatenate([b, multi_scores[sel, i][:, None]], axis=1)
+        keep = nms(d, iou_thr, mode)
+        out_b.append(d[keep])
+        out_l.append(np.full(keep.shape[0], i - 1, dtype=np.int64))
+    if not out_b:
+        return np.zeros((0, 5), F32), np.zeros((0,), np.int64)
+    bb, ll = np.concatenate(out_b), np.concatenate(out_l)
+    if max_num >= 0 and bb.shape[0] > max_num:
+        order = np.argsort(-bb[:, 4], kind='stable')[:max_num]
+        bb, ll = bb[order], ll[order]
+    return bb, ll

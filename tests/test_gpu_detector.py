@@ -312,3 +312,56 @@ def test_rcnn_fused_sampling_targets_equal_tensor_form(tmp_path):
     assert bool((diff <= tol).all()), (float(diff.max()), bt.view(-1)[worst].item(),
                                        exp[2].view(-1)[worst].item())
     assert int((lab > 0).sum()) == 256 and (lab.view(2, 512)[:, :128] > 0).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# test-time path: simple_test = backbone/FPN/RPN proposals -> RoIAlign -> head -> merged scores
+# -> one batched 1230-class NMS -> bbox2result
+# ---------------------------------------------------------------------------------------------
+def test_simple_test_matches_stepwise_oracle(tmp_path):
+    from oracle import det_oracle, gs_oracle
+    torch.manual_seed(0)
+    model = _detector(tmp_path)
+    model.test_cfg = to_config_dict(dict(
+        rpn=dict(nms_across_levels=False, nms_pre=1000, nms_post=1000, max_num=1000, nms_thr=0.7,
+                 min_bbox_size=0),
+        rcnn=dict(score_thr=0.0, nms=dict(type='nms', iou_thr=0.5), max_per_img=300)))
+    model = model.to(DEV).eval()
+    # make the class scores peaky so that the result is not 300 near-ties
+    with torch.no_grad():
+        model.bbox_head.fc_cls.weight.mul_(30.0)
+    H, W = 320, 480
+    img = torch.randn(1, 3, H, W, device=DEV)
+    metas = [dict(img_shape=(H, W - 7, 3), pad_shape=(H, W, 3), ori_shape=(H * 2, (W - 7) * 2, 3),
+                  scale_factor=0.5, flip=False)]
+    result = model(img, metas, return_loss=False, rescale=True)
+    assert isinstance(result, list) and len(result) == 1230
+    assert sum(r.shape[0] for r in result) == 300
+    assert all(r.dtype == np.float32 and r.shape[1] == 5 for r in result)
+    # stepwise: the same network pieces; numpy oracles for the score merge and the 1230-class NMS
+    with torch.no_grad():
+        x = model.extract_feat(img)
+        props, valid = model.simple_test_rpn(x, metas, model.test_cfg.rpn)[0]
+        assert props.shape == (1000, 5)
+        rois = torch.cat([props.new_zeros((1000, 1)), props[:, :4]], 1)
+        feats = model.bbox_roi_extractor(x[:4], rois)
+        cls_score, bbox_pred = model.bbox_head(feats, nhwc=True)
+        head = model.bbox_head
+        bboxes, scores = head.get_det_bboxes(rois, cls_score, bbox_pred, metas[0]['img_shape'],
+                                             0.5, rescale=True, cfg=None)
+    merged = gs_oracle.merge_score(cls_score.cpu().numpy(), head.pred_slice.cpu().numpy(),
+                                   head.fg_splits, 1231)
+    np.testing.assert_allclose(scores.cpu().numpy(), merged, rtol=2e-5, atol=1e-7)
+    from balancedgroupsoftmax_amd.box_ops import delta2bbox
+    exp_boxes = delta2bbox(rois[:, 1:].cpu(), bbox_pred.cpu(), head.target_means,
+                           head.target_stds, metas[0]['img_shape']) / 0.5
+    np.testing.assert_allclose(bboxes.cpu().numpy(), exp_boxes.numpy(), rtol=1e-4, atol=1e-3)
+    v = valid.cpu().numpy()
+    eb, el = det_oracle.multiclass_nms(bboxes.cpu().numpy()[v], scores.cpu().numpy()[v], 0.0, 0.5,
+                                       300, mode='cuda')
+    got_b = np.concatenate(result)
+    got_l = np.concatenate([np.full(r.shape[0], c) for c, r in enumerate(result)])
+    order_e = np.lexsort((-eb[:, 4], el))            # bbox2result regroups by class
+    order_g = np.lexsort((-got_b[:, 4], got_l))
+    np.testing.assert_array_equal(got_l[order_g], el[order_e])
+    np.testing.assert_array_equal(got_b[order_g], eb[order_e])

@@ -70,3 +70,27 @@ def test_map_roi_levels_matches_torch_formula():
     exp = torch.floor(torch.log2(scale / 56 + 1e-6)).clamp(min=0, max=3).long().numpy()
     np.testing.assert_array_equal(det_oracle.map_roi_levels(rois, 4), exp)
     assert set(exp.tolist()) == {0, 1, 2, 3}
+
+
+# ---------------------------------------------------------------- multiclass NMS (test-time path)
+def _mc_golden():
+    import json
+    import os
+    from tests.golden import make_golden_det
+    z = np.load(os.path.join(os.path.dirname(make_golden_det.__file__), 'multiclass_nms_golden.npz'))
+    cases = json.loads(bytes(z['__cases__']).decode())
+    return z, cases, make_golden_det.case_inputs
+
+
+@pytest.mark.parametrize('name', ['c31_cut', 'c11_agnostic_all', 'c1231_thr', 'c21_empty',
+                                  'c5_nocap', 'c1231_lvis'])
+def test_multiclass_nms_restatement_vs_executed_reference(name):
+    """oracle.multiclass_nms(mode='cpu') == the reference's multiclass_nms run on CPU with its own
+    compiled nms_cpu.cpp (golden vectors; tests/golden/make_golden_det.py)."""
+    z, cases, case_inputs = _mc_golden()
+    case = [c for c in cases if c['name'] == name][0]
+    boxes, scores = case_inputs(case)
+    bb, ll = det_oracle.multiclass_nms(boxes, scores, case['score_thr'], case['iou_thr'],
+                                       case['max_num'], mode='cpu')
+    np.testing.assert_array_equal(ll, z[name + '/det_labels'])
+    np.testing.assert_array_equal(bb, z[name + '/det_bboxes'])

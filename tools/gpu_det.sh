@@ -17,4 +17,5 @@ if [ "${2:-}" = "prof" ]; then
   python tools/prof_summary.py $(find $OUT/prof -name "*kernel_trace.csv" | head -1) > $OUT/prof_summary.md 2>/dev/null; head -30 $OUT/prof_summary.md | cut -c1-180
   find $OUT/prof -name "*kernel_trace.csv" -size +30M -delete
 fi
+if [ "${3:-}" = "infer" ]; then timeout 600 python tools/infer_time.py 20 > $OUT/infer_time.json 2> $OUT/infer.err; echo "infer rc=$?"; cat $OUT/infer_time.json; tail -3 $OUT/infer.err; fi
 du -sh $OUT
