@@ -42,14 +42,18 @@ struct ConvArgs {
   const float* x;     // [N, H, W, Cin]
   const float* w;     // [Cout, R, S, Cin]
   const float* bias;  // [Cout] or null
-  const float* res;   // residual or null: [N, Ho, Wo, Cout] (mode 1) / [N, Ho/2, Wo/2, Cout] (mode 2)
+  const float* res;   // residual or null: [N, Ho, Wo, Cout] (mode 1) / [N, Ho/2, Wo/2, Cout] (mode 2:
+                      // nearest-2x upsampled) / [N, 2Ho, 2Wo, Cout] (mode 3: 2x2 sum-pooled)
+  const float* mask;  // null, or [N, Ho, Wo, Cout]: y = mask > 0 ? y : 0 (ReLU backward)
   float* y;           // [N, Ho, Wo, Cout]
   int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
   int M, K;           // M = N*Ho*Wo, K = R*S*Cin
   int relu, res_mode;
 };
 
-template <int MB, int NB, int BK>
+// UP = 1: plain convolution.  UP = 2: the input is read as if it had been zero-upsampled by 2
+// (x_virtual[2h, 2w] = x[h, w], zeros elsewhere) — the data gradient of a stride-2 convolution.
+template <int MB, int NB, int BK, int UP>
 __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
   constexpr int BM = 64 * MB, BN = 64 * NB;
   constexpr int LDK = BK + 4;            // LDS row stride in floats
@@ -108,8 +112,14 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
     const bool kok = kg < p.K;
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
-      const int hi = a_hi0[q] + kr, wi = a_wi0[q] + ks;
-      const bool ok = a_ok[q] && kok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+      int hi = a_hi0[q] + kr, wi = a_wi0[q] + ks;
+      bool ok = a_ok[q] && kok && hi >= 0 && wi >= 0;
+      if (UP == 2) {
+        ok = ok && !((hi | wi) & 1);
+        hi >>= 1;
+        wi >>= 1;
+      }
+      ok = ok && hi < p.H && wi < p.W;
       ra[q] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (ok)
         ra[q] = *reinterpret_cast<const f32x4*>(a_base[q] + ((size_t)hi * p.W + wi) * p.Cin + kc);
@@ -206,6 +216,11 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
         const int rem = m - n * hw;
         const int ho = rem / p.Wo, wo = rem - (rem / p.Wo) * p.Wo;
         res_row = (((size_t)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout;
+      } else if (p.res_mode == 3) {
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        const int ho = rem / p.Wo, wo = rem - (rem / p.Wo) * p.Wo;
+        res_row = (((size_t)n * (p.Ho * 2) + ho * 2) * (p.Wo * 2) + wo * 2) * p.Cout;
       }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -213,8 +228,15 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
         if (j >= p.Cout) continue;
         float v = acc[a][b][r];
         if (p.bias) v += p.bias[j];
-        if (p.res_mode) v += p.res[res_row + j];
+        if (p.res_mode == 3) {
+          const size_t down = (size_t)p.Wo * 2 * p.Cout;
+          v += (p.res[res_row + j] + p.res[res_row + p.Cout + j]) +
+               (p.res[res_row + down + j] + p.res[res_row + down + p.Cout + j]);
+        } else if (p.res_mode) {
+          v += p.res[res_row + j];
+        }
         if (p.relu) v = fmaxf(v, 0.f);
+        if (p.mask) v = p.mask[(size_t)m * p.Cout + j] > 0.f ? v : 0.f;
         p.y[(size_t)m * p.Cout + j] = v;
       }
     }
@@ -259,6 +281,42 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const float* __r
 
 }  // namespace
 
+// Shared launcher: tile / K-tile choice from the per-layer sweeps of the R50-FPN shapes
+// (tools/conv_sweep.py, profiles/r1i_conv_sweep.txt, r1q_conv_sweep_bk*.txt): the 128x128 tile
+// only pays for the two huge-M, deep-K 3x3 convs on the stride-4 maps; everywhere else the 64x64
+// tile wins or ties because it exposes 4x more workgroups; thin outputs (Cout <= 64) with a huge
+// M use 128x64.  K tile: 32 for deep reductions with the 64x64 tile (+5-15 % on K >= 512).
+static int launch_conv(ConvArgs& p, int up, hipStream_t st) {
+  const long long M = p.M;
+  int force = 0;  // tuning hook: BGS_CONV_TILE=22|21|11 forces a tile configuration
+  if (const char* e = getenv("BGS_CONV_TILE")) force = atoi(e);
+  int tile = 11;
+  if (p.Cout > 64 && p.K >= 1152 && M >= 100000) tile = 22;
+  else if (p.Cout <= 64 && M >= 400000) tile = 21;
+  if (force == 22 || force == 21 || force == 11) tile = force;
+  int bk = (p.K >= 512 && tile == 11) ? 32 : 16;
+  if (const char* e = getenv("BGS_CONV_BK")) bk = atoi(e) == 32 ? 32 : (atoi(e) == 16 ? 16 : bk);
+#define BGS_CONV_LAUNCH2(MB_, NB_, BK_, UP_)                                                     \
+  hipLaunchKernelGGL((conv_igemm_f32_kernel<MB_, NB_, BK_, UP_>), grid, dim3(kThreads), 0, st, p)
+#define BGS_CONV_LAUNCH(MB_, NB_, BM_, BN_)                                                      \
+  do {                                                                                           \
+    dim3 grid((unsigned)((M + BM_ - 1) / BM_), (unsigned)((p.Cout + BN_ - 1) / BN_));            \
+    if (up == 2) {                                                                               \
+      if (bk == 32) BGS_CONV_LAUNCH2(MB_, NB_, 32, 2);                                           \
+      else BGS_CONV_LAUNCH2(MB_, NB_, 16, 2);                                                    \
+    } else {                                                                                     \
+      if (bk == 32) BGS_CONV_LAUNCH2(MB_, NB_, 32, 1);                                           \
+      else BGS_CONV_LAUNCH2(MB_, NB_, 16, 1);                                                    \
+    }                                                                                            \
+  } while (0)
+  if (tile == 22) BGS_CONV_LAUNCH(2, 2, 128, 128);
+  else if (tile == 21) BGS_CONV_LAUNCH(2, 1, 128, 64);
+  else BGS_CONV_LAUNCH(1, 1, 64, 64);
+#undef BGS_CONV_LAUNCH
+#undef BGS_CONV_LAUNCH2
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int bgs_conv2d_nhwc_f32(const float* x, const float* w, const float* bias,
                                    const float* residual, float* y, int N, int H, int W, int Cin,
                                    int Cout, int R, int S, int stride, int pad, int relu,
@@ -272,7 +330,7 @@ extern "C" int bgs_conv2d_nhwc_f32(const float* x, const float* w, const float* 
   if (residual_mode < 0 || residual_mode > 2 || (residual_mode != 0 && !residual))
     return BGS_ERR_INVALID_ARG;
   ConvArgs p;
-  p.x = x; p.w = w; p.bias = bias; p.res = residual; p.y = y;
+  p.x = x; p.w = w; p.bias = bias; p.res = residual; p.mask = nullptr; p.y = y;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S;
   p.stride = stride; p.pad = pad;
   p.Ho = (H + 2 * pad - R) / stride + 1;
@@ -285,35 +343,45 @@ extern "C" int bgs_conv2d_nhwc_f32(const float* x, const float* w, const float* 
   p.K = R * S * Cin;
   p.relu = relu;
   p.res_mode = residual_mode;
-  hipStream_t st = (hipStream_t)stream;
-  // Tile choice, from the per-layer sweep of the R50-FPN shapes (tools/conv_sweep.py,
-  // profiles/r1i_conv_sweep.txt): the 128x128 tile only pays for the two huge-M, deep-K 3x3
-  // convs on the stride-4 maps (111 vs 103 TFLOP/s); everywhere else the 64x64 tile wins or
-  // ties because it exposes 4x more workgroups (latency hiding across workgroups matters more
-  // than operand reuse at these sizes); thin outputs (Cout <= 64) with a huge M use 128x64.
-  int force = 0;  // tuning hook: BGS_CONV_TILE=22|21|11 forces a tile configuration
-  if (const char* e = getenv("BGS_CONV_TILE")) force = atoi(e);
-  int tile = 11;
-  if (Cout > 64 && p.K >= 1152 && M >= 100000) tile = 22;
-  else if (Cout <= 64 && M >= 400000) tile = 21;
-  if (force == 22 || force == 21 || force == 11) tile = force;
-  // K tile: 32 for deep reductions (fewer barriers per flop: +5-15 % on K >= 512 with the 64x64
-  // tile), 16 for shallow ones and for the 128x128 tile (profiles/r1q_conv_sweep_bk*.txt)
-  int bk = (p.K >= 512 && tile == 11) ? 32 : 16;
-  if (const char* e = getenv("BGS_CONV_BK")) bk = atoi(e) == 32 ? 32 : (atoi(e) == 16 ? 16 : bk);
-#define BGS_CONV_LAUNCH(MB_, NB_, BM_, BN_)                                                      \
-  do {                                                                                           \
-    dim3 grid((unsigned)((M + BM_ - 1) / BM_), (unsigned)((Cout + BN_ - 1) / BN_));              \
-    if (bk == 32)                                                                                \
-      hipLaunchKernelGGL((conv_igemm_f32_kernel<MB_, NB_, 32>), grid, dim3(kThreads), 0, st, p); \
-    else                                                                                         \
-      hipLaunchKernelGGL((conv_igemm_f32_kernel<MB_, NB_, 16>), grid, dim3(kThreads), 0, st, p); \
-  } while (0)
-  if (tile == 22) BGS_CONV_LAUNCH(2, 2, 128, 128);
-  else if (tile == 21) BGS_CONV_LAUNCH(2, 1, 128, 64);
-  else BGS_CONV_LAUNCH(1, 1, 64, 64);
-#undef BGS_CONV_LAUNCH
-  BGS_RETURN_LAUNCH_STATUS();
+  return launch_conv(p, 1, (hipStream_t)stream);
+}
+
+// Data gradient of bgs_conv2d_nhwc_f32: dx[n,h,w,ci] = sum_{r,s,co} dy[n,ho,wo,co] W[co,r,s,ci]
+// over the (ho, wo) with ho*stride - pad + r == h.  Same implicit-GEMM kernel with the roles of
+// the channel axes swapped: "input" = dy [N,Ho,Wo,Cout] (virtually zero-upsampled by the
+// stride), filter = wt[ci][R-1-r][S-1-s][co] (the caller passes this re-laid-out copy), padding
+// R-1-pad, unit stride, output H x W x Cin.  Epilogue: + residual (mode 1 same shape; mode 3 =
+// 2x2 sum-pool of a twice-as-large map: the backward of the FPN nearest-2x top-down add), then
+// the ReLU-backward mask of the tensor that fed the forward conv.
+extern "C" int bgs_conv2d_dgrad_nhwc_f32(const float* dy, const float* wt, const float* residual,
+                                         const float* mask, float* dx, int N, int H, int W,
+                                         int Cin, int Cout, int R, int S, int stride, int pad,
+                                         int residual_mode, bgs_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || pad < 0)
+    return BGS_ERR_INVALID_ARG;
+  if (!dy || !wt || !dx) return BGS_ERR_INVALID_ARG;
+  if (stride != 1 && stride != 2) return BGS_ERR_UNSUPPORTED;
+  if (Cout % 4 != 0) return BGS_ERR_UNSUPPORTED;
+  if (((uintptr_t)dy | (uintptr_t)wt) % 16 != 0) return BGS_ERR_INVALID_ARG;
+  if (!(residual_mode == 0 || residual_mode == 1 || residual_mode == 3) ||
+      (residual_mode != 0 && !residual))
+    return BGS_ERR_INVALID_ARG;
+  if (R - 1 - pad < 0 || S - 1 - pad < 0) return BGS_ERR_UNSUPPORTED;
+  const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return BGS_ERR_INVALID_ARG;
+  ConvArgs p;
+  p.x = dy; p.w = wt; p.bias = nullptr; p.res = residual; p.mask = mask; p.y = dx;
+  p.N = N; p.H = Ho; p.W = Wo; p.Cin = Cout; p.Cout = Cin; p.R = R; p.S = S;
+  p.stride = 1; p.pad = R - 1 - pad;   // square filters on this path: R == S, same padding
+  if (R != S) return BGS_ERR_UNSUPPORTED;
+  p.Ho = H; p.Wo = W;
+  const long long M = (long long)N * H * W;
+  if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  p.M = (int)M;
+  p.K = R * S * Cout;
+  p.relu = 0;
+  p.res_mode = residual_mode;
+  return launch_conv(p, stride, (hipStream_t)stream);
 }
 
 extern "C" int bgs_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C,

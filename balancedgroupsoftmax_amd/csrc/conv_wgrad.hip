@@ -1,0 +1,352 @@
+// Weight gradient of the NHWC implicit-GEMM convolution (and of nn.Linear) on the fp32 matrix
+// cores of gfx950 — the `selectp = 0` (train everything) backward pass of the BAGS detector:
+// what the reference gets from cuDNN's backward-filter through autograd for
+//   ResNet bottlenecks     mmdet/models/backbones/resnet.py:220-266
+//   FPN laterals / outputs mmdet/models/necks/fpn.py:101-141
+//   RPN head               mmdet/models/anchor_heads/rpn_head.py:30-35
+//   RoI head FCs           mmdet/models/bbox_heads/convfc_bbox_head.py:132-168
+//
+//   dW[co][r][s][ci] = sum_m dy[m][co] * x[n(m), ho(m)*stride - pad + r, wo(m)*stride - pad + s][ci]
+//
+// GEMM view: D[co][k] = sum_m A[m][co] * B[m][k], k = (r, s, ci): BOTH operands are stored with
+// the reduction index m as the slow axis and the output index contiguous.  That is the layout
+// v_mfma_f32_32x32x2_f32 wants if a lane's output rows are INTERLEAVED: lane l holds, for the
+// two m of a K step (m parity = l >> 5), MB consecutive co starting at MB * (l & 31) — one
+// ds_read_b64/b128 from the [m][co] tile feeds MB row tiles at once, and the global 16-byte loads
+// go to LDS untransposed.  D row i of row tile t is co = co0 + MB * i + t; likewise for k.
+//
+// The reduction (M = N*Ho*Wo, up to 134,400 at cfg[1]) is split over gridDim.z; partial tiles go
+// to a workspace [splits][Cout][K] and are summed in a fixed order by wgrad_reduce_kernel
+// (bitwise reproducible, no atomics), which can also accumulate into dW (weights shared across
+// the five RPN levels).
+#include <stdlib.h>
+
+#include "bgs_common.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int kBKM = 16;  // reduction rows (m) per stage
+
+struct WgradArgs {
+  const float* x;   // [N, H, W, Cin]
+  const float* dy;  // [N, Ho, Wo, Cout]
+  float* out;       // workspace [splits][Cout][K] or dW itself when splits == 1 && !accumulate
+  int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
+  int M, K, m_per_split;
+};
+
+template <int T>
+struct FragVec;
+template <>
+struct FragVec<1> {
+  typedef float type;
+};
+template <>
+struct FragVec<2> {
+  typedef f32x2 type;
+};
+template <>
+struct FragVec<4> {
+  typedef f32x4 type;
+};
+
+template <int T>
+__device__ __forceinline__ float frag_get(const typename FragVec<T>::type& v, int t) {
+  return v[t];
+}
+template <>
+__device__ __forceinline__ float frag_get<1>(const float& v, int) {
+  return v;
+}
+
+// Workgroup = 4 waves (2 x 2); wave tile = (32*MB co) x (32*NB k); block tile 64*MB x 64*NB.
+template <int MB, int NB>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_f32_kernel(WgradArgs p) {
+  constexpr int BM = 64 * MB, BN = 64 * NB;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int QA = BM / 4, QB = BN / 4;          // 16-byte quads per m row
+  constexpr int PA = (kBKM * QA) / kThreads;        // quads per thread per stage (1 or 2)
+  constexpr int PB = (kBKM * QB) / kThreads;
+  constexpr int RA = kThreads / QA, RB = kThreads / QB;  // m rows covered per pass
+  __shared__ __attribute__((aligned(16))) float As[2][kBKM * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][kBKM * LDB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int co0 = blockIdx.x * BM, k0 = blockIdx.y * BN;
+  const int m_begin = blockIdx.z * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+
+  // ---- A staging: quad qa of m row (ra + RA*q)
+  const int qa = tid % QA, ra = tid / QA;
+  const bool a_col_ok = co0 + qa * 4 < p.Cout;     // Cout % 4 == 0: whole quad in or out
+  // ---- B staging: quad qb (fixed filter tap / input channel for the whole kernel)
+  const int qb = tid % QB, rb = tid / QB;
+  const int kg = k0 + qb * 4;
+  const bool b_col_ok = kg < p.K;
+  int kr, ks, kc;
+  {
+    const int kk = b_col_ok ? kg : 0;
+    const int rs = kk / p.Cin;
+    kc = kk - rs * p.Cin;
+    kr = rs / p.S;
+    ks = rs - kr * p.S;
+  }
+  // (n, ho, wo) of this thread's B rows, advanced incrementally by kBKM per stage
+  int bn_[PB], bho[PB], bwo[PB];
+#pragma unroll
+  for (int q = 0; q < PB; ++q) {
+    const int m = m_begin + rb + RB * q;
+    const int hw = p.Ho * p.Wo;
+    bn_[q] = m / hw;
+    const int rem = m - bn_[q] * hw;
+    bho[q] = rem / p.Wo;
+    bwo[q] = rem - bho[q] * p.Wo;
+  }
+
+  f32x4 va[PA], vb[PB];
+  int m_stage = m_begin;
+  auto load_stage = [&]() {
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const int m = m_stage + ra + RA * q;
+      va[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a_col_ok && m < m_end)
+        va[q] = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + co0 + qa * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int m = m_stage + rb + RB * q;
+      const int hi = bho[q] * p.stride - p.pad + kr, wi = bwo[q] * p.stride - p.pad + ks;
+      vb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (b_col_ok && m < m_end && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
+        vb[q] = *reinterpret_cast<const f32x4*>(
+            p.x + (((size_t)bn_[q] * p.H + hi) * p.W + wi) * p.Cin + kc);
+      // advance this row by kBKM output pixels
+      bwo[q] += kBKM;
+      while (bwo[q] >= p.Wo) {
+        bwo[q] -= p.Wo;
+        if (++bho[q] == p.Ho) {
+          bho[q] = 0;
+          ++bn_[q];
+        }
+      }
+    }
+    m_stage += kBKM;
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < PA; ++q)
+      *reinterpret_cast<f32x4*>(&As[buf][(ra + RA * q) * LDA + qa * 4]) = va[q];
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      *reinterpret_cast<f32x4*>(&Bs[buf][(rb + RB * q) * LDB + qb * 4]) = vb[q];
+  };
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nst = (m_end - m_begin + kBKM - 1) / kBKM;
+  const int fi = lane & 31, fk = lane >> 5;
+  typedef typename FragVec<MB>::type AV;
+  typedef typename FragVec<NB>::type BV;
+  if (nst > 0) {
+    load_stage();
+    store_stage(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nst) load_stage();
+    const float* Ab = &As[buf][fk * LDA + wm * 32 * MB + fi * MB];
+    const float* Bb = &Bs[buf][fk * LDB + wn * 32 * NB + fi * NB];
+#pragma unroll
+    for (int kk = 0; kk < kBKM / 2; ++kk) {
+      const AV av = *reinterpret_cast<const AV*>(Ab + 2 * kk * LDA);
+      const BV bv = *reinterpret_cast<const BV*>(Bb + 2 * kk * LDB);
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag_get<MB>(av, a), frag_get<NB>(bv, b),
+                                                            acc[a][b], 0, 0, 0);
+    }
+    if (st + 1 < nst) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- write the partial tile: D row i of row tile a -> co = co0 + wm*32*MB + MB*i + a,
+  //      D col (lane & 31) of col tile b -> k = k0 + wn*32*NB + NB*(lane & 31) + b
+  float* out = p.out + (size_t)blockIdx.z * p.Cout * p.K;
+  const int kcol = k0 + wn * 32 * NB + NB * (lane & 31);
+#pragma unroll
+  for (int a = 0; a < MB; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int co = co0 + wm * 32 * MB + MB * i + a;
+      if (co >= p.Cout) continue;
+      float* row = out + (size_t)co * p.K;
+      if (NB == 2 && kcol + 1 < p.K) {
+        *reinterpret_cast<f32x2*>(row + kcol) = f32x2{acc[a][0][r], acc[a][NB - 1][r]};
+      } else {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          if (kcol + b < p.K) row[kcol + b] = acc[a][b][r];
+      }
+    }
+  }
+}
+
+// dW[i] (+)= scale-free sum over the splits, fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws,
+                                                           float* __restrict__ dw, size_t n4,
+                                                           int splits, int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(ws + i * 4);
+    for (int z = 1; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(ws + (z * n4 + i) * 4);
+    if (accumulate) s += *reinterpret_cast<const f32x4*>(dw + i * 4);
+    *reinterpret_cast<f32x4*>(dw + i * 4) = s;
+  }
+}
+
+// Column sums of a row-major [M, C] matrix (bias gradient: db[c] = sum_m dy[m][c]).  Stage 1:
+// gridDim.y row chunks x (C/4 quads per 64 threads); stage 2 reuses wgrad_reduce_kernel.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, int M,
+                                                             int C, int rows_per_chunk,
+                                                             float* __restrict__ part) {
+  // 256 threads = 4 row lanes x 64 column quads
+  const int cq = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * rows_per_chunk;
+  const int m1 = min(M, m0 + rows_per_chunk);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (cq * 4 < C)
+    for (int m = m0 + rl; m < m1; m += 4) s += *reinterpret_cast<const f32x4*>(a + (size_t)m * C + cq * 4);
+  __shared__ f32x4 red[4][64];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && cq * 4 < C) {
+    s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.y * C + cq * 4) = s;
+  }
+}
+
+struct WgradPlan {
+  int tile;     // 22 / 11
+  int splits, m_per_split;
+};
+
+WgradPlan plan_wgrad(int M, int Cout, int K) {
+  WgradPlan pl;
+  pl.tile = (Cout >= 128 && K >= 128) ? 22 : 11;
+  if (const char* e = getenv("BGS_WGRAD_TILE")) {
+    const int f = atoi(e);
+    if (f == 22 || f == 11) pl.tile = f;
+  }
+  const int bm = pl.tile == 22 ? 128 : 64;
+  const long long tiles = (long long)((Cout + bm - 1) / bm) * ((K + bm - 1) / bm);
+  // aim at ~4 workgroups per CU (1024 in flight) with at least 512 reduction rows each
+  long long splits = (1024 + tiles - 1) / tiles;
+  const long long max_splits = (M + 511) / 512;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  if (splits > 512) splits = 512;
+  if (const char* e = getenv("BGS_WGRAD_SPLITS")) {
+    const int f = atoi(e);
+    if (f >= 1 && f <= 4096) splits = f;
+  }
+  int mps = (int)((M + splits - 1) / splits);
+  mps = (mps + kBKM - 1) / kBKM * kBKM;
+  pl.m_per_split = mps;
+  pl.splits = (M + mps - 1) / mps;
+  return pl;
+}
+
+}  // namespace
+
+extern "C" size_t bgs_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int R,
+                                                   int S, int stride, int pad) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0)
+    return 0;
+  const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return 0;
+  const long long M = (long long)N * Ho * Wo;
+  const int K = R * S * Cin;
+  const WgradPlan pl = plan_wgrad((int)M, Cout, K);
+  // weight partials + bias partials (colsum: up to 256 row chunks)
+  return ((size_t)pl.splits * Cout * K + (size_t)256 * Cout) * sizeof(float) + 256;
+}
+
+extern "C" int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, float* db,
+                                         int N, int H, int W, int Cin, int Cout, int R, int S,
+                                         int stride, int pad, int accumulate, void* workspace,
+                                         bgs_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
+      pad < 0)
+    return BGS_ERR_INVALID_ARG;
+  if (!x || !dy || !dw || !workspace) return BGS_ERR_INVALID_ARG;
+  if (Cin % 4 != 0 || Cout % 4 != 0) return BGS_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)workspace) % 16 != 0)
+    return BGS_ERR_INVALID_ARG;
+  WgradArgs p;
+  p.x = x; p.dy = dy;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S;
+  p.stride = stride; p.pad = pad;
+  p.Ho = (H + 2 * pad - R) / stride + 1;
+  p.Wo = (W + 2 * pad - S) / stride + 1;
+  if (p.Ho <= 0 || p.Wo <= 0) return BGS_ERR_INVALID_ARG;
+  const long long M = (long long)N * p.Ho * p.Wo;
+  if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  p.M = (int)M;
+  p.K = R * S * Cin;
+  const WgradPlan pl = plan_wgrad(p.M, Cout, p.K);
+  p.m_per_split = pl.m_per_split;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  const bool direct = pl.splits == 1 && !accumulate;
+  p.out = direct ? dw : ws;
+  const int bm = pl.tile == 22 ? 128 : 64;
+  dim3 grid((unsigned)((Cout + bm - 1) / bm), (unsigned)((p.K + bm - 1) / bm), (unsigned)pl.splits);
+  if (pl.tile == 22)
+    hipLaunchKernelGGL((conv_wgrad_f32_kernel<2, 2>), grid, dim3(kThreads), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_f32_kernel<1, 1>), grid, dim3(kThreads), 0, st, p);
+  if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
+  const size_t n = (size_t)Cout * p.K;
+  if (!direct) {
+    const size_t n4 = n / 4;   // Cin % 4 == 0 -> n % 4 == 0
+    size_t g = (n4 + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, ws, dw, n4,
+                       pl.splits, accumulate);
+    if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
+  }
+  if (db) {
+    float* part = ws + (size_t)pl.splits * n;
+    int chunks = (p.M + 2047) / 2048;
+    if (chunks > 256) chunks = 256;
+    if (chunks < 1) chunks = 1;
+    int rows = (p.M + chunks - 1) / chunks;
+    chunks = (p.M + rows - 1) / rows;
+    dim3 g2((unsigned)((Cout / 4 + 63) / 64), (unsigned)chunks);
+    hipLaunchKernelGGL(colsum_partial_kernel, g2, dim3(256), 0, st, dy, p.M, Cout, rows, part);
+    if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
+    const size_t c4 = (size_t)Cout / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, st,
+                       part, db, c4, chunks, accumulate);
+  }
+  BGS_RETURN_LAUNCH_STATUS();
+}

@@ -261,6 +261,70 @@ def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None
     return out
 
 
+def dgrad_filter(w_krsc):
+    """``[Cout,R,S,Cin]`` -> ``[Cin,R,S,Cout]`` with both spatial axes flipped: the filter layout
+    ``bgs_conv2d_dgrad_nhwc_f32`` streams (K-major for the transposed problem)."""
+    return w_krsc.detach().permute(3, 1, 2, 0).flip(1, 2).contiguous()
+
+
+def conv2d_dgrad_nhwc(dy, w_krsc, in_hw, stride=1, pad=0, residual=None, residual_mode=0,
+                      mask=None, wt=None):
+    """Data gradient of :func:`conv2d_nhwc`: ``dy [N,Ho,Wo,Cout]`` -> ``dx [N,H,W,Cin]``.
+    ``residual`` is added (mode 1 same shape, mode 3: ``[N,2H,2W,Cin]`` 2x2-sum-pooled), then
+    ``mask > 0`` gates the result (ReLU backward of the conv's input)."""
+    _require_cuda(dy, w_krsc, residual, mask)
+    lib = capi.load()
+    assert dy.dtype == torch.float32 and dy.is_contiguous() and dy.dim() == 4
+    Cout, R, S, Cin = w_krsc.shape
+    N, Ho, Wo, Cout2 = dy.shape
+    H, W = in_hw
+    assert Cout == Cout2 and Ho == (H + 2 * pad - R) // stride + 1 and \
+        Wo == (W + 2 * pad - S) // stride + 1, (dy.shape, w_krsc.shape, in_hw)
+    if wt is None:
+        wt = dgrad_filter(w_krsc)
+    if residual is not None and residual_mode == 0:
+        residual_mode = 1
+    if residual is not None:
+        exp = (N, H, W, Cin) if residual_mode == 1 else (N, 2 * H, 2 * W, Cin)
+        assert tuple(residual.shape) == exp and residual.is_contiguous(), (residual.shape, exp)
+    if mask is not None:
+        assert tuple(mask.shape) == (N, H, W, Cin) and mask.is_contiguous()
+    dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dy.device)
+    rc = lib.bgs_conv2d_dgrad_nhwc_f32(capi.ptr(dy), capi.ptr(wt), capi.ptr(residual),
+                                       capi.ptr(mask), capi.ptr(dx), N, H, W, Cin, Cout, R, S,
+                                       stride, pad, residual_mode, capi.current_stream(dy.device))
+    capi.check('bgs_conv2d_dgrad_nhwc_f32', rc)
+    return dx
+
+
+def conv2d_wgrad_nhwc(x, dy, ksize, stride=1, pad=0, bias=False, dw=None, db=None,
+                      accumulate=False):
+    """Weight (and bias) gradient of :func:`conv2d_nhwc`: ``x [N,H,W,Cin]``, ``dy [N,Ho,Wo,Cout]``
+    -> ``dw [Cout,R,S,Cin]`` (``db [Cout]``).  ``accumulate`` adds into the given ``dw``/``db``."""
+    _require_cuda(x, dy)
+    lib = capi.load()
+    assert x.dtype == torch.float32 and dy.dtype == torch.float32
+    assert x.is_contiguous() and dy.is_contiguous() and x.dim() == 4 and dy.dim() == 4
+    N, H, W, Cin = x.shape
+    R = S = int(ksize)
+    Cout = dy.shape[3]
+    assert tuple(dy.shape[:3]) == (N, (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1)
+    dev = x.device
+    if dw is None:
+        assert not accumulate
+        dw = torch.empty((Cout, R, S, Cin), dtype=torch.float32, device=dev)
+    if bias and db is None:
+        assert not accumulate
+        db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+    ws = _workspace(lib.bgs_conv2d_wgrad_workspace_bytes(N, H, W, Cin, Cout, R, S, stride, pad), dev)
+    rc = lib.bgs_conv2d_wgrad_nhwc_f32(capi.ptr(x), capi.ptr(dy), capi.ptr(dw),
+                                       capi.ptr(db) if bias else None, N, H, W, Cin, Cout, R, S,
+                                       stride, pad, int(bool(accumulate)), capi.ptr(ws),
+                                       capi.current_stream(dev))
+    capi.check('bgs_conv2d_wgrad_nhwc_f32', rc)
+    return (dw, db) if bias else dw
+
+
 def linear(x, weight, bias=None, relu=False):
     """``act(x @ weight.T + bias)`` for ``x [M,K]``, ``weight [Cout,K]`` (nn.Linear layout)."""
     M, K = x.shape

@@ -154,6 +154,34 @@ int bgs_conv2d_nhwc_f32(const float* x, const float* w, const float* bias, const
                         float* y, int N, int H, int W, int Cin, int Cout, int R, int S,
                         int stride, int pad, int relu, int residual_mode, bgs_stream_t stream);
 
+/* Backward of bgs_conv2d_nhwc_f32 for the `selectp = 0` mode (train everything; the reference
+ * gets these from cuDNN backward-data / backward-filter through autograd of the nn.Conv2d /
+ * nn.Linear call sites listed above; tools/train.py:49-57 selects what trains).
+ *
+ * bgs_conv2d_dgrad_nhwc_f32: dx[n,h,w,ci] = sum_{r,s,co} dy[n,ho,wo,co] * W[co,r,s,ci] over the
+ *   (ho,wo,r,s) with ho*stride-pad+r == h, wo*stride-pad+s == w.  stride 1 or 2, R == S.
+ *   dy [N,Ho,Wo,Cout] (Cout % 4 == 0); wt = the filter re-laid-out by the caller as
+ *   wt[ci][R-1-r][S-1-s][co] (so that the kernel streams it K-major); dx [N,H,W,Cin].
+ *   Epilogue: dx += residual (mode 1: [N,H,W,Cin]; mode 3: a [N,2H,2W,Cin] map summed over 2x2
+ *   blocks = backward of the FPN nearest-2x top-down add, fpn.py:117-121), then, when mask !=
+ *   NULL, dx = mask[n,h,w,ci] > 0 ? dx : 0 (backward of the ReLU that produced the conv input).
+ *
+ * bgs_conv2d_wgrad_nhwc_f32: dw[co,r,s,ci] (+)= sum_m dy[m,co] * x[n, ho*stride-pad+r,
+ *   wo*stride-pad+s, ci];  db[co] (+)= sum_m dy[m,co] when db != NULL.  Cin % 4 == 0,
+ *   Cout % 4 == 0.  The reduction over m is split across workgroups; partials are summed in a
+ *   fixed order (bitwise reproducible).  accumulate != 0 adds to the existing dw/db (weights
+ *   shared by the five RPN levels).  workspace >= bgs_conv2d_wgrad_workspace_bytes(...).
+ * ---------------------------------------------------------------------------------- */
+int bgs_conv2d_dgrad_nhwc_f32(const float* dy, const float* wt, const float* residual,
+                              const float* mask, float* dx, int N, int H, int W, int Cin,
+                              int Cout, int R, int S, int stride, int pad, int residual_mode,
+                              bgs_stream_t stream);
+size_t bgs_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int R, int S,
+                                        int stride, int pad);
+int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, float* db, int N, int H,
+                              int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                              int accumulate, void* workspace, bgs_stream_t stream);
+
 /* 3x3 / stride 2 / pad 1 max pooling, NHWC (ResNet stem, resnet.py:452). C % 4 == 0.
  * y [N, (H-1)/2+1, (W-1)/2+1, C]. */
 int bgs_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C,

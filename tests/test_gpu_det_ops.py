@@ -229,3 +229,76 @@ def test_multiclass_nms_score_factors_and_padding_rows():
     eb, el = det_oracle.multiclass_nms(boxes[:100], scores[:100], 0.0, 0.5, 1000, mode='cuda')
     np.testing.assert_array_equal(db.cpu().numpy(), eb)
     np.testing.assert_array_equal(dl.cpu().numpy(), el)
+
+
+# ---------------------------------------------------------------- conv backward (selectp = 0)
+BWD_CASES = [
+    # name, N, H, W, Cin, Cout, k, stride, pad
+    ('3x3s1', 2, 20, 28, 128, 128, 3, 1, 1),
+    ('3x3s2_odd', 2, 21, 27, 128, 64, 3, 2, 1),
+    ('3x3s2_even', 1, 24, 32, 64, 128, 3, 2, 1),
+    ('1x1s1', 2, 25, 42, 256, 64, 1, 1, 0),
+    ('1x1s2', 2, 26, 40, 256, 128, 1, 2, 0),
+    ('1x1_thin16', 2, 50, 84, 256, 16, 1, 1, 0),
+    ('linear', 1, 1, 300, 512, 132, 1, 1, 0),
+    ('3x3s1_wide', 1, 13, 21, 256, 256, 3, 1, 1),
+]
+
+
+def _torch_conv_grads(x, w_oihw, dy, stride, pad):
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).double().requires_grad_(True)
+    wt = torch.from_numpy(w_oihw).double().requires_grad_(True)
+    y = torch.nn.functional.conv2d(xt, wt, None, stride=stride, padding=pad)
+    y.backward(torch.from_numpy(dy).permute(0, 3, 1, 2).double())
+    return (xt.grad.permute(0, 2, 3, 1).contiguous().numpy(),
+            wt.grad.permute(0, 2, 3, 1).contiguous().numpy())
+
+
+@pytest.mark.parametrize('case', BWD_CASES, ids=[c[0] for c in BWD_CASES])
+def test_conv2d_dgrad_wgrad_vs_torch_autograd(case):
+    """dx / dw / db of the implicit-GEMM conv against fp64 torch-CPU autograd of F.conv2d."""
+    name, N, H, W, Cin, Cout, k, stride, pad = case
+    rs = np.random.RandomState(hash(name) % 1000)
+    x = rs.randn(N, H, W, Cin).astype(np.float32)
+    w = (rs.randn(Cout, Cin, k, k) / np.sqrt(Cin * k * k)).astype(np.float32)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dy = rs.randn(N, Ho, Wo, Cout).astype(np.float32)
+    edx, edw = _torch_conv_grads(x, w, dy, stride, pad)
+    wk = dev(krsc(w))
+    dx = BF.conv2d_dgrad_nhwc(dev(dy), wk, (H, W), stride=stride, pad=pad)
+    assert np.abs(dx.cpu().numpy() - edx).max() <= 2e-5 * max(1.0, np.abs(edx).max())
+    dw, db = BF.conv2d_wgrad_nhwc(dev(x), dev(dy), k, stride=stride, pad=pad, bias=True)
+    assert dw.shape == (Cout, k, k, Cin)
+    assert np.abs(dw.cpu().numpy() - edw).max() <= 2e-5 * np.abs(edw).max()
+    edb = dy.astype(np.float64).sum((0, 1, 2))
+    assert np.abs(db.cpu().numpy() - edb).max() <= 2e-5 * max(1.0, np.abs(edb).max())
+    # accumulate: second call doubles
+    BF.conv2d_wgrad_nhwc(dev(x), dev(dy), k, stride=stride, pad=pad, bias=True, dw=dw, db=db,
+                         accumulate=True)
+    assert np.abs(dw.cpu().numpy() - 2 * edw).max() <= 4e-5 * np.abs(edw).max()
+    assert np.abs(db.cpu().numpy() - 2 * edb).max() <= 4e-5 * max(1.0, np.abs(edb).max())
+
+
+def test_conv2d_dgrad_epilogues_and_wgrad_reproducibility():
+    """residual (same-shape / 2x2 sum-pooled) + ReLU-backward mask in the dgrad epilogue; the
+    split-reduction wgrad is bitwise reproducible run to run."""
+    rs = np.random.RandomState(5)
+    N, H, W, Cin, Cout = 2, 12, 18, 64, 128
+    dy = rs.randn(N, H, W, Cout).astype(np.float32)
+    w = (rs.randn(Cout, Cin, 3, 3) * 0.05).astype(np.float32)
+    x = rs.randn(N, H, W, Cin).astype(np.float32)
+    res1 = rs.randn(N, H, W, Cin).astype(np.float32)
+    res3 = rs.randn(N, 2 * H, 2 * W, Cin).astype(np.float32)
+    edx, _ = _torch_conv_grads(x, w, dy, 1, 1)
+    wk = dev(krsc(w))
+    got = BF.conv2d_dgrad_nhwc(dev(dy), wk, (H, W), 1, 1, residual=dev(res1), mask=dev(x)).cpu().numpy()
+    exp = np.where(x > 0, edx + res1, 0)
+    assert np.abs(got - exp).max() < 5e-5
+    got = BF.conv2d_dgrad_nhwc(dev(dy), wk, (H, W), 1, 1, residual=dev(res3), residual_mode=3).cpu().numpy()
+    pooled = res3.reshape(N, H, 2, W, 2, Cin).sum((2, 4))
+    assert np.abs(got - (edx + pooled)).max() < 5e-5
+    big_x = dev(rs.randn(2, 60, 84, 64).astype(np.float32))
+    big_dy = dev(rs.randn(2, 60, 84, 32).astype(np.float32))
+    a = BF.conv2d_wgrad_nhwc(big_x, big_dy, 3, 1, 1)
+    b = BF.conv2d_wgrad_nhwc(big_x, big_dy, 3, 1, 1)
+    assert torch.equal(a, b)
