@@ -17,9 +17,16 @@ The arithmetic runs in the fp32-MFMA implicit-GEMM kernel (csrc/conv_igemm.hip):
 * bias, residual add and ReLU are fused into the conv epilogue; the FPN top-down
   ``lateral + nearest_2x(upper)`` is the epilogue's upsampled-residual mode.
 
-Scope: forward only.  Every shipped BAGS config trains only ``bbox_head.fc_cls``
-(``selectp=1``, tools/train.py:49-57); a backbone parameter that requires grad raises.
+Training modes (tools/train.py:49-57): the shipped BAGS configs train only
+``bbox_head.fc_cls`` (``selectp=1``) — then every conv here is a plain forward launch on cached
+folded weights.  With trainable trunk parameters (``selectp=0``) the fold is recomputed per step
+as differentiable tensor code (so autograd unfolds ``dW', db'`` into the conv weight and the BN
+affine parameters) and every conv records ``functional._ConvFn`` (dgrad / wgrad kernels,
+csrc/conv_igemm.hip + csrc/conv_wgrad.hip).  The stem + max-pool have no backward here: they are
+frozen in every BAGS config (``frozen_stages=1``).
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -27,21 +34,30 @@ from . import functional as BF
 from .registry import BACKBONES, NECKS
 
 
+def _trainable(*modules):
+    """True when gradients are being recorded and some parameter of ``modules`` wants one."""
+    return torch.is_grad_enabled() and any(
+        p.requires_grad for m in modules if m is not None for p in m.parameters())
+
+
 def _fold_conv_bn(conv, bn, pad_cin_to=None):
-    """-> (w [Cout,R,S,Cin] contiguous, bias [Cout]) with the eval-mode BN folded in."""
-    w = conv.weight.detach().float()
-    cout = w.shape[0]
-    if bn is not None:
-        scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
-        shift = bn.bias.detach().float() - bn.running_mean.float() * scale
-        w = w * scale.view(-1, 1, 1, 1)
-        b = shift if conv.bias is None else shift + conv.bias.detach().float() * scale
-    else:
-        b = conv.bias.detach().float() if conv.bias is not None else w.new_zeros(cout)
-    w = w.permute(0, 2, 3, 1)
-    if pad_cin_to is not None and w.shape[3] < pad_cin_to:
-        w = torch.nn.functional.pad(w, (0, pad_cin_to - w.shape[3]))
-    return w.contiguous(), b.contiguous()
+    """-> (w [Cout,R,S,Cin] contiguous, bias [Cout]) with the eval-mode BN folded in.  When the
+    conv / BN parameters are being trained the fold stays on the autograd tape."""
+    ctx = contextlib.nullcontext() if _trainable(conv, bn) else torch.no_grad()
+    with ctx:
+        w = conv.weight.float()
+        cout = w.shape[0]
+        if bn is not None:
+            scale = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+            shift = bn.bias.float() - bn.running_mean.float() * scale
+            w = w * scale.view(-1, 1, 1, 1)
+            b = shift if conv.bias is None else shift + conv.bias.float() * scale
+        else:
+            b = conv.bias.float() if conv.bias is not None else w.new_zeros(cout)
+        w = w.permute(0, 2, 3, 1)
+        if pad_cin_to is not None and w.shape[3] < pad_cin_to:
+            w = torch.nn.functional.pad(w, (0, pad_cin_to - w.shape[3]))
+        return w.contiguous(), b.contiguous()
 
 
 class _FoldCache(object):
@@ -52,6 +68,8 @@ class _FoldCache(object):
         self.data = None
 
     def get(self, module, build):
+        if _trainable(module):       # trained parameters: the fold must be on this step's tape
+            return build()
         key = tuple((id(t), t._version, t.device) for t in
                     list(module.parameters()) + list(module.buffers()))
         if key != self.key:
@@ -65,9 +83,9 @@ def _check_frozen(module, what):
         for n, p in module.named_parameters():
             if p.requires_grad:
                 raise NotImplementedError(
-                    '%s.%s requires grad: backward through the conv stack is not implemented '
-                    '(the shipped BAGS configs train fc_cls only: selectp=1). Freeze it or run '
-                    'under torch.no_grad().' % (what, n))
+                    '%s.%s requires grad: no backward for the stem conv + max-pool (frozen in '
+                    'every BAGS config: frozen_stages=1). Freeze it or run under torch.no_grad().'
+                    % (what, n))
 
 
 class Bottleneck(nn.Module):
@@ -87,8 +105,12 @@ class Bottleneck(nn.Module):
             self.downsample = nn.Sequential(
                 nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
                 nn.BatchNorm2d(planes * 4))
+        self._cache = _FoldCache()
 
     def folded(self):
+        return self._cache.get(self, self._build_fold)
+
+    def _build_fold(self):
         f = dict(c1=_fold_conv_bn(self.conv1, self.bn1), c2=_fold_conv_bn(self.conv2, self.bn2),
                  c3=_fold_conv_bn(self.conv3, self.bn3))
         if self.downsample is not None:
@@ -98,10 +120,10 @@ class Bottleneck(nn.Module):
     def run(self, x, f):
         identity = x
         if 'ds' in f:
-            identity = BF.conv2d_nhwc(x, f['ds'][0], f['ds'][1], stride=self.stride)
-        out = BF.conv2d_nhwc(x, f['c1'][0], f['c1'][1], relu=True)
-        out = BF.conv2d_nhwc(out, f['c2'][0], f['c2'][1], stride=self.stride, pad=1, relu=True)
-        return BF.conv2d_nhwc(out, f['c3'][0], f['c3'][1], relu=True, residual=identity)
+            identity = BF.conv2d_autograd(x, f['ds'][0], f['ds'][1], stride=self.stride)
+        out = BF.conv2d_autograd(x, f['c1'][0], f['c1'][1], relu=True)
+        out = BF.conv2d_autograd(out, f['c2'][0], f['c2'][1], stride=self.stride, pad=1, relu=True)
+        return BF.conv2d_autograd(out, f['c3'][0], f['c3'][1], relu=True, residual=identity)
 
 
 @BACKBONES.register_module
@@ -171,11 +193,8 @@ class ResNet(nn.Module):
             if isinstance(m, Bottleneck):
                 nn.init.constant_(m.bn3.weight, 0)
 
-    def _build_fold(self):
-        f = dict(stem=_fold_conv_bn(self.conv1, self.bn1, pad_cin_to=4), blocks=[])
-        for name in self.res_layers:
-            f['blocks'].append([blk.folded() for blk in getattr(self, name)])
-        return f
+    def _build_stem(self):
+        return _fold_conv_bn(self.conv1, self.bn1, pad_cin_to=4)
 
     @staticmethod
     def to_nhwc4(img):
@@ -185,15 +204,15 @@ class ResNet(nn.Module):
 
     def forward(self, img):
         """img ``[N,3,H,W]`` (as the reference) -> tuple of NHWC feature maps."""
-        _check_frozen(self, 'backbone')
-        f = self._cache.get(self, self._build_fold)
+        _check_frozen(nn.ModuleList([self.conv1, self.bn1]), 'backbone stem')
+        stem = self._cache.get(nn.ModuleList([self.conv1, self.bn1]), self._build_stem)
         x = self.to_nhwc4(img)
-        x = BF.conv2d_nhwc(x, f['stem'][0], f['stem'][1], stride=2, pad=3, relu=True)
+        x = BF.conv2d_nhwc(x, stem[0], stem[1], stride=2, pad=3, relu=True)
         x = BF.maxpool3x3s2_nhwc(x)
         outs = []
         for i, name in enumerate(self.res_layers):
-            for blk, bf in zip(getattr(self, name), f['blocks'][i]):
-                x = blk.run(x, bf)
+            for blk in getattr(self, name):
+                x = blk.run(x, blk.folded())
             if i in self.out_indices:
                 outs.append(x)
         return tuple(outs)
@@ -249,14 +268,14 @@ class FPN(nn.Module):
     def forward(self, inputs):
         """inputs: NHWC C2..C5 -> NHWC P2..P6 (fpn.py:101-141)."""
         assert len(inputs) == self.num_ins
-        _check_frozen(self, 'neck')
         f = self._cache.get(self, self._build_fold)
         n = self.num_ins
         lat = [None] * n
-        lat[n - 1] = BF.conv2d_nhwc(inputs[n - 1], *f['lat'][n - 1])
+        lat[n - 1] = BF.conv2d_autograd(inputs[n - 1], *f['lat'][n - 1])
         for i in range(n - 2, -1, -1):   # lateral_i + nearest_2x(lateral_{i+1}), fused
-            lat[i] = BF.conv2d_nhwc(inputs[i], *f['lat'][i], residual=lat[i + 1], residual_mode=2)
-        outs = [BF.conv2d_nhwc(lat[i], *f['out'][i], pad=1) for i in range(n)]
+            lat[i] = BF.conv2d_autograd(inputs[i], *f['lat'][i], residual=lat[i + 1],
+                                        residual_mode=2)
+        outs = [BF.conv2d_autograd(lat[i], *f['out'][i], pad=1) for i in range(n)]
         for _ in range(self.num_outs - n):   # F.max_pool2d(x, 1, stride=2) == subsampling
             outs.append(outs[-1][:, ::2, ::2, :].contiguous())
         return tuple(outs)

@@ -254,6 +254,11 @@ class ConvFCBBoxHead(BBoxHead):
         Cached per parameter version."""
         if not nhwc:
             return fc.weight
+        if fc.weight.requires_grad and torch.is_grad_enabled():
+            # trained (selectp 0 / 2): the permutation stays on the autograd tape
+            O = fc.weight.shape[0]
+            return fc.weight.view(O, self.in_channels, self.roi_feat_area).permute(0, 2, 1) \
+                .reshape(O, -1)
         key = (id(fc.weight), fc.weight._version, fc.weight.device)
         if getattr(self, '_fc1_key', None) != key:
             O = fc.weight.shape[0]
@@ -261,8 +266,6 @@ class ConvFCBBoxHead(BBoxHead):
             w = fc.weight.detach().view(O, C, self.roi_feat_area).permute(0, 2, 1)
             self._fc1_perm = w.reshape(O, -1).contiguous()
             self._fc1_key = key
-        if fc.weight.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError('training the first shared FC with NHWC RoI features')
         return self._fc1_perm
 
     def forward(self, x, nhwc=False):

@@ -60,6 +60,10 @@ SIGNATURES = {
                                               ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, c_f32p, c_ptr, c_ptr]),
+    'bgs_roi_align_nhwc_bwd': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, c_f32p, c_ptr]),
     'bgs_nms_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     'bgs_nms_batched': (ctypes.c_int, [c_f32p, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                        ctypes.c_int, ctypes.c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
@@ -72,6 +76,10 @@ SIGNATURES = {
                                     c_ptr, c_f32p, c_ptr, ctypes.c_int, c_ptr, c_ptr,
                                     ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                     c_f32p, c_f32p, c_f32p, c_ptr, c_ptr]),
+    'bgs_rpn_loss_grad': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, c_f32p,
+                                         c_ptr, c_ptr, c_ptr, c_f32p, c_ptr, ctypes.c_int, c_ptr,
+                                         c_ptr, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                         ctypes.c_float, c_f32p, c_f32p, c_f32p, c_ptr]),
     'bgs_decode_proposals': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, c_f32p,
                                             c_ptr, c_f32p, ctypes.c_int, c_ptr, c_ptr, c_ptr,
                                             ctypes.c_float, ctypes.c_int, c_f32p, c_ptr]),

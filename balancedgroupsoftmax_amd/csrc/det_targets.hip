@@ -295,6 +295,56 @@ __global__ __launch_bounds__(256) void rpn_loss_finalize_kernel(const float* __r
   }
 }
 
+// Gradient of the per-level RPN losses w.r.t. the fused head outputs (selectp = 0 path):
+//   d cls logit = g_cls[l] * w_cls * w * (sigmoid(x) - t) / num      (sampled anchors)
+//   d delta_c   = g_bbox[l] * w_bbox * sl1'(x_c - d_c) / num         (sampled positives)
+// everything else 0 (the caller zero-fills dout).  One thread per anchor, distinct addresses.
+struct GradTable {
+  float* dout[kMaxLevels];
+};
+
+__global__ __launch_bounds__(256) void rpn_loss_grad_kernel(
+    LevelTable Lv, GradTable G, ImgTable T, const float* __restrict__ anchors,
+    const int* __restrict__ assigned, const uint8_t* __restrict__ pos_mask,
+    const uint8_t* __restrict__ neg_mask, const float* __restrict__ gt, Coding cod, float beta,
+    float pos_weight, int A, const float* __restrict__ num_total, float w_cls, float w_bbox,
+    const float* __restrict__ g_cls, const float* __restrict__ g_bbox) {
+  const int n = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= A) return;
+  const bool ps = pos_mask[(size_t)n * A + i] != 0, ns = neg_mask[(size_t)n * A + i] != 0;
+  if (!(ps || ns)) return;
+  int lvl = 0;
+  while (lvl + 1 < Lv.num_levels && i >= Lv.start[lvl + 1]) ++lvl;
+  const int p = i - Lv.start[lvl];
+  const int na = Lv.num_anchors, ch = 5 * na;
+  const int loc = p / na, a = p - loc * na;
+  const size_t row = ((size_t)n * Lv.hw[lvl] + loc) * ch;
+  const float* o = Lv.out[lvl] + row;
+  float* d_o = G.dout[lvl] + row;
+  const float inv = 1.f / num_total[0];
+  const float x = o[a];
+  const float t = ps ? 1.f : 0.f;
+  const float w = ps ? pos_weight : 1.f;
+  const float sig = 1.f / (1.f + expf(-x));
+  d_o[a] = g_cls[lvl] * w_cls * w * (sig - t) * inv;
+  if (ps) {
+    const int g = T.gt_off[n] + assigned[(size_t)n * A + i] - 1;
+    const float* an = anchors + (size_t)i * 4;
+    const float* gb = gt + (size_t)g * 4;
+    float d[4];
+    encode_delta(an[0], an[1], an[2], an[3], gb[0], gb[1], gb[2], gb[3], cod, d);
+    const float sc = g_bbox[lvl] * w_bbox * inv;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float df = o[na + a * 4 + c] - d[c];
+      const float ad = fabsf(df);
+      const float gr = ad < beta ? df / beta : (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+      d_o[na + a * 4 + c] = sc * gr;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // boxes_out [N, L, nmax, 5] = decode(anchor[top_idx], delta) clamped to the image, score =
 // sigmoid(top logit).  top_idx / top_logit: [N, L, nmax] (entries >= count[l] are ignored).
@@ -497,6 +547,44 @@ extern "C" int bgs_rpn_loss(const float* const* host_level_outs, const int* host
   hipLaunchKernelGGL(rpn_loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace,
                      N, blocks, L, loss_weight_cls, loss_weight_bbox, loss_cls_out, loss_bbox_out,
                      num_total_out);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int bgs_rpn_loss_grad(const float* const* host_level_outs,
+                                 float* const* host_level_douts, const int* host_level_hw, int L,
+                                 int num_anchors, const float* anchors, const int* assigned,
+                                 const uint8_t* pos_mask, const uint8_t* neg_mask, const float* gt,
+                                 const int* host_gt_offsets, int N, const float* host_means,
+                                 const float* host_stds, float beta, float pos_weight,
+                                 float loss_weight_cls, float loss_weight_bbox,
+                                 const float* num_total, const float* grad_loss_cls,
+                                 const float* grad_loss_bbox, bgs_stream_t stream) {
+  if (!anchors || !assigned || !pos_mask || !neg_mask || !gt || !num_total || !grad_loss_cls ||
+      !grad_loss_bbox || !host_level_douts || !host_means || !host_stds || !(beta > 0.f))
+    return BGS_ERR_INVALID_ARG;
+  LevelTable Lv;
+  int rc = fill_level_table(&Lv, host_level_outs, host_level_hw, L, num_anchors);
+  if (rc != BGS_OK) return rc;
+  GradTable G;
+  for (int l = 0; l < kMaxLevels; ++l) G.dout[l] = nullptr;
+  for (int l = 0; l < L; ++l) {
+    if (!host_level_douts[l]) return BGS_ERR_INVALID_ARG;
+    G.dout[l] = host_level_douts[l];
+  }
+  ImgTable T;
+  rc = fill_img_table(&T, host_gt_offsets, nullptr, N);
+  if (rc != BGS_OK) return rc;
+  Coding cod;
+  for (int c = 0; c < 4; ++c) {
+    cod.mean[c] = host_means[c];
+    cod.stdv[c] = host_stds[c];
+  }
+  const int A = Lv.start[kMaxLevels];
+  const int blocks = (A + 255) / 256;
+  hipLaunchKernelGGL(rpn_loss_grad_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, Lv,
+                     G, T, anchors, assigned, pos_mask, neg_mask, gt, cod, beta,
+                     pos_weight <= 0.f ? 1.f : pos_weight, A, num_total, loss_weight_cls,
+                     loss_weight_bbox, grad_loss_cls, grad_loss_bbox);
   BGS_RETURN_LAUNCH_STATUS();
 }
 

@@ -1,4 +1,4 @@
-// Multi-level RoIAlign forward for gfx950 (MI355X), NHWC features.
+// Multi-level RoIAlign forward + backward for gfx950 (MI355X), NHWC features.
 //
 // Replaces SingleRoIExtractor.forward (mmdet/models/roi_extractors/single_level.py:89-107:
 // map_roi_levels :54-73, then per level a boolean mask, `inds.any()` host sync, a kernel launch
@@ -14,6 +14,11 @@
 // Output layout [K, PH, PW, C] (bin-major, channels contiguous) — the FC that consumes it
 // permutes its weight columns once instead.
 // Algorithmic bytes per RoI (C=256, 7x7): 50,176 B written + the unique input footprint.
+//
+// Backward (roi_align_kernel.cu:149-266, only on the `selectp = 0` path): the same wave-per-bin
+// mapping scatters g * w / 4 into the level's gradient map with hardware fp32 atomics
+// (global_atomic_add_f32), 16 taps x C channels per bin; the maps are accumulated INTO (the RPN
+// head's data gradient is already there), so no separate zero-fill + add pass.
 #include <math.h>
 
 #include "bgs_common.h"
@@ -76,7 +81,9 @@ __device__ __forceinline__ Tap make_tap(float y, float x, int H, int W) {
 }
 
 // one wave per (roi, ph, pw); lanes stride over channel quads.
-template <int SAMPLES>
+// BWD = false: out[k,bin,:] = mean of the bilinear samples.  BWD = true: `out` is the incoming
+// gradient and L.feat are the per-level gradient maps that receive the scattered taps.
+template <int SAMPLES, bool BWD>
 __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(RoiLevels L,
                                                              const float* __restrict__ rois,
                                                              int K, int C, int PH, int PW,
@@ -120,6 +127,27 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(RoiLevels L,
     }
   }
   float* o = out + ((size_t)k * bins + bin) * C;
+  if (BWD) {
+    float* dfeat = const_cast<float*>(feat);
+    for (int c = lane * 4; c < C; c += 256) {
+      f32x4 g = *reinterpret_cast<const f32x4*>(o + c);
+      g /= (float)(SAMPLES * SAMPLES);
+#pragma unroll
+      for (int s = 0; s < SAMPLES * SAMPLES; ++s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float w = taps[s].w[q];
+          if (w == 0.f) continue;      // out-of-bounds sample or a degenerate (clamped) tap
+          float* d = dfeat + (size_t)taps[s].o[q] * C + c;
+          unsafeAtomicAdd(d + 0, g[0] * w);
+          unsafeAtomicAdd(d + 1, g[1] * w);
+          unsafeAtomicAdd(d + 2, g[2] * w);
+          unsafeAtomicAdd(d + 3, g[3] * w);
+        }
+      }
+    }
+    return;
+  }
   for (int c = lane * 4; c < C; c += 256) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -172,7 +200,44 @@ extern "C" int bgs_roi_align_nhwc_fwd(const float* const* host_feats, const int*
   L.finest_scale = finest_scale;
   const long long waves = (long long)K * pooled_h * pooled_w;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  hipLaunchKernelGGL((roi_align_nhwc_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, L,
-                     rois, K, C, pooled_h, pooled_w, out, levels_out);
+  hipLaunchKernelGGL((roi_align_nhwc_kernel<2, false>), dim3(grid), dim3(256), 0,
+                     (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w, out, levels_out);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int bgs_roi_align_nhwc_bwd(float* const* host_dfeats, const int* host_heights,
+                                      const int* host_widths, const float* host_scales,
+                                      int num_levels, int num_images, float finest_scale,
+                                      const float* rois, int K, int C, int pooled_h, int pooled_w,
+                                      int sample_num, const float* dout, bgs_stream_t stream) {
+  if (num_levels <= 0 || num_levels > kMaxLevels || num_images <= 0 || K < 0 || C <= 0 ||
+      pooled_h <= 0 || pooled_w <= 0)
+    return BGS_ERR_INVALID_ARG;
+  if (!host_dfeats || !host_heights || !host_widths || !host_scales) return BGS_ERR_INVALID_ARG;
+  if (K == 0) return BGS_OK;
+  if (!rois || !dout) return BGS_ERR_INVALID_ARG;
+  if (C % 4 != 0 || (uintptr_t)dout % 16 != 0) return BGS_ERR_UNSUPPORTED;
+  if (sample_num != 2) return BGS_ERR_UNSUPPORTED;
+  RoiLevels L;
+  for (int i = 0; i < kMaxLevels; ++i) {
+    L.feat[i] = nullptr;
+    L.H[i] = L.W[i] = 1;
+    L.scale[i] = 1.f;
+  }
+  for (int i = 0; i < num_levels; ++i) {
+    if (!host_dfeats[i]) return BGS_ERR_INVALID_ARG;
+    L.feat[i] = host_dfeats[i];
+    L.H[i] = host_heights[i];
+    L.W[i] = host_widths[i];
+    L.scale[i] = host_scales[i];
+  }
+  L.num_levels = num_levels;
+  L.num_images = num_images;
+  L.finest_scale = finest_scale;
+  const long long waves = (long long)K * pooled_h * pooled_w;
+  const unsigned grid = (unsigned)((waves + 3) / 4);
+  hipLaunchKernelGGL((roi_align_nhwc_kernel<2, true>), dim3(grid), dim3(256), 0,
+                     (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w,
+                     const_cast<float*>(dout), nullptr);
   BGS_RETURN_LAUNCH_STATUS();
 }

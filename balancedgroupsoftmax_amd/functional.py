@@ -280,6 +280,12 @@ def conv2d_dgrad_nhwc(dy, w_krsc, in_hw, stride=1, pad=0, residual=None, residua
     H, W = in_hw
     assert Cout == Cout2 and Ho == (H + 2 * pad - R) // stride + 1 and \
         Wo == (W + 2 * pad - S) // stride + 1, (dy.shape, w_krsc.shape, in_hw)
+    if Cout % 4 != 0:      # e.g. the fused RPN head (15 outputs): zero-pad the reduction axis
+        padc = 4 - Cout % 4
+        dy = torch.nn.functional.pad(dy, (0, padc))
+        w_krsc = torch.nn.functional.pad(w_krsc.detach(), (0, 0, 0, 0, 0, 0, 0, padc))
+        Cout += padc
+        wt = None
     if wt is None:
         wt = dgrad_filter(w_krsc)
     if residual is not None and residual_mode == 0:
@@ -310,6 +316,13 @@ def conv2d_wgrad_nhwc(x, dy, ksize, stride=1, pad=0, bias=False, dw=None, db=Non
     Cout = dy.shape[3]
     assert tuple(dy.shape[:3]) == (N, (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1)
     dev = x.device
+    if Cout % 4 != 0:      # pad the output-channel axis, slice the result
+        assert dw is None and db is None and not accumulate
+        padc = 4 - Cout % 4
+        res = conv2d_wgrad_nhwc(x, torch.nn.functional.pad(dy, (0, padc)), ksize, stride, pad, bias)
+        if bias:
+            return res[0][:Cout].contiguous(), res[1][:Cout].contiguous()
+        return res[:Cout].contiguous()
     if dw is None:
         assert not accumulate
         dw = torch.empty((Cout, R, S, Cin), dtype=torch.float32, device=dev)
@@ -323,6 +336,60 @@ def conv2d_wgrad_nhwc(x, dy, ksize, stride=1, pad=0, bias=False, dw=None, db=Non
                                        capi.current_stream(dev))
     capi.check('bgs_conv2d_wgrad_nhwc_f32', rc)
     return (dw, db) if bias else dw
+
+
+class _ConvFn(torch.autograd.Function):
+    """Differentiable fused conv: ``y = act(conv(x, w) + b + residual)`` with gradients for
+    x, w, b and the residual (the `selectp = 0` path).
+
+    backward: ``dz = dy * (y > 0)`` (ReLU), ``dx = dgrad(dz, w)``, ``dw, db = wgrad(x, dz)``,
+    ``dresidual = dz`` (mode 1) or its 2x2 sum-pool (mode 2: nearest-2x upsampled residual)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, stride, pad, relu, residual_mode):
+        y = conv2d_nhwc(x.detach(), w.detach(), None if bias is None else bias.detach(),
+                        stride=stride, pad=pad, relu=relu,
+                        residual=None if residual is None else residual.detach(),
+                        residual_mode=residual_mode)
+        ctx.cfg = (stride, pad, relu, residual_mode if residual is not None else 0,
+                   bias is not None)
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, relu, res_mode, has_bias = ctx.cfg
+        dz = dy.contiguous()
+        if relu:
+            dz = torch.where(y > 0, dz, torch.zeros((), dtype=dz.dtype, device=dz.device))
+        need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
+        dx = dw = db = dres = None
+        if need_x:
+            dx = conv2d_dgrad_nhwc(dz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad)
+        if need_w or (has_bias and need_b):
+            out = conv2d_wgrad_nhwc(x, dz, w.shape[1], stride=stride, pad=pad, bias=has_bias)
+            dw, db = out if has_bias else (out, None)
+        if res_mode and need_r:
+            if res_mode == 1:
+                dres = dz
+            else:
+                n, h, wd, c = dz.shape
+                dres = dz.view(n, h // 2, 2, wd // 2, 2, c).sum(dim=(2, 4))
+        return dx, dw, db, dres, None, None, None, None
+
+
+def conv2d_autograd(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None,
+                    residual_mode=0):
+    """:func:`conv2d_nhwc` that records an autograd node when any input requires grad."""
+    ts = [t for t in (x, w_krsc, bias, residual) if t is not None]
+    if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
+        if residual is not None and residual_mode == 0:
+            residual_mode = 1
+        return _ConvFn.apply(x, w_krsc, bias, residual, stride, pad, bool(relu), residual_mode)
+    return conv2d_nhwc(x, w_krsc, bias, stride=stride, pad=pad, relu=relu, residual=residual,
+                       residual_mode=residual_mode)
 
 
 def linear(x, weight, bias=None, relu=False):
@@ -354,12 +421,21 @@ class _LinearFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous().float()
         gx = gw = gb = None
+        M, K = x.shape
+        Nout = weight.shape[0]
         if ctx.needs_input_grad[0]:
             gx = linear(gy, weight.detach().t().contiguous())            # [M,N] x [K,N]^T
-        if ctx.needs_input_grad[1]:
-            gw = linear(gy.t().contiguous(), x.detach().t().contiguous())  # [N,M] x [K,M]^T
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum(0)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            # dW[n,k] = sum_m gy[m,n] x[m,k]: the split-reduction wgrad kernel, no transposes
+            if Nout % 4 == 0 and K % 4 == 0:
+                out = conv2d_wgrad_nhwc(_f32c(x).view(M, 1, 1, K), gy.view(M, 1, 1, Nout), 1,
+                                        bias=want_b)
+                gw, gb = (out[0], out[1]) if want_b else (out, None)
+                gw = gw.view(Nout, K)
+            else:
+                gw = linear(gy.t().contiguous(), x.detach().t().contiguous())
+                gb = gy.sum(0) if want_b else None
         return gx, gw, gb
 
 
@@ -370,8 +446,12 @@ def linear_autograd(x, weight, bias=None, relu=False):
                                          (bias is not None and bias.requires_grad))
     if not needs:
         return linear(x, weight, bias, relu=relu)
-    y = _LinearFn.apply(x, weight, bias)
-    return torch.relu(y) if relu else y
+    M, K = x.shape
+    Nout = weight.shape[0]
+    y = _ConvFn.apply(x.float().contiguous().view(M, 1, 1, K),
+                      weight.float().contiguous().view(Nout, 1, 1, K),
+                      None if bias is None else bias.float(), None, 1, 0, bool(relu), 0)
+    return y.view(M, Nout)
 
 
 def maxpool3x3s2_nhwc(x):
@@ -414,6 +494,60 @@ def roi_align_nhwc(feats, rois, featmap_strides, out_size=7, sample_num=2, fines
                                     capi.current_stream(rois.device))
     capi.check('bgs_roi_align_nhwc_fwd', rc)
     return (out, lv) if return_levels else out
+
+
+def roi_align_nhwc_bwd(dout, rois, dfeats, featmap_strides, sample_num=2, finest_scale=56):
+    """Scatter ``dout [K,ph,pw,C]`` into the per-level gradient maps ``dfeats`` (accumulated
+    into, in place, with fp32 atomics)."""
+    import ctypes
+    _require_cuda(dout, rois, *dfeats)
+    lib = capi.load()
+    L = len(dfeats)
+    N, _, _, C = dfeats[0].shape
+    for f in dfeats:
+        assert f.dtype == torch.float32 and f.is_contiguous() and f.shape[0] == N and f.shape[3] == C
+    rois = _f32c(rois)
+    dout = _f32c(dout)
+    K, ph, pw, C2 = dout.shape
+    assert C2 == C and rois.shape[0] == K
+    ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in dfeats])
+    hs = (ctypes.c_int * L)(*[int(f.shape[1]) for f in dfeats])
+    ws = (ctypes.c_int * L)(*[int(f.shape[2]) for f in dfeats])
+    sc = (ctypes.c_float * L)(*[1.0 / s for s in featmap_strides])
+    rc = lib.bgs_roi_align_nhwc_bwd(ptrs, hs, ws, sc, L, N, float(finest_scale), capi.ptr(rois),
+                                    K, C, ph, pw, sample_num, capi.ptr(dout),
+                                    capi.current_stream(rois.device))
+    capi.check('bgs_roi_align_nhwc_bwd', rc)
+    return dfeats
+
+
+class _RoIAlignFn(torch.autograd.Function):
+    """Differentiable multi-level RoIAlign (w.r.t. the feature maps; RoIs carry no gradient, as
+    in the reference: roi_align.py:52)."""
+
+    @staticmethod
+    def forward(ctx, rois, strides, out_size, sample_num, finest_scale, *feats):
+        ctx.save_for_backward(rois)
+        ctx.cfg = (tuple(strides), sample_num, finest_scale, [tuple(f.shape) for f in feats])
+        return roi_align_nhwc([f.detach() for f in feats], rois, strides, out_size, sample_num,
+                              finest_scale)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        rois, = ctx.saved_tensors
+        strides, sample_num, finest_scale, shapes = ctx.cfg
+        dfeats = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in shapes]
+        roi_align_nhwc_bwd(dout.contiguous(), rois, dfeats, strides, sample_num, finest_scale)
+        return (None, None, None, None, None) + tuple(dfeats)
+
+
+def roi_align_nhwc_autograd(feats, rois, featmap_strides, out_size=7, sample_num=2,
+                            finest_scale=56):
+    if torch.is_grad_enabled() and any(f.requires_grad for f in feats):
+        return _RoIAlignFn.apply(rois, tuple(featmap_strides), out_size, sample_num, finest_scale,
+                                 *feats)
+    return roi_align_nhwc(feats, rois, featmap_strides, out_size, sample_num, finest_scale)
 
 
 def nms_batched(boxes, counts, iou_thr, iou_mode=0, max_keep=0):
@@ -489,11 +623,8 @@ def iou_assign(boxes, gt_cat, gt_offsets, pos_iou_thr, neg_iou_thr, min_pos_iou=
     return (assigned, mo) if return_max_overlaps else assigned
 
 
-def rpn_loss(level_outs, num_anchors, anchors, assigned, pos_mask, neg_mask, gt_cat, gt_offsets,
-             means, stds, beta, pos_weight=-1, loss_weight_cls=1.0, loss_weight_bbox=1.0):
-    """Per-level RPN losses ``(loss_cls [L], loss_bbox [L], num_total_samples [1])`` from the
-    fused head outputs ``[N,H,W,A+4A]`` of every level and the sampled-anchor masks."""
-    _require_cuda(anchors, assigned, pos_mask, neg_mask, gt_cat, *level_outs)
+def _rpn_loss_launch(level_outs, num_anchors, anchors, assigned, pos_mask, neg_mask, gt_cat,
+                     gt_offsets, means, stds, beta, pos_weight, loss_weight_cls, loss_weight_bbox):
     lib = capi.load()
     L = len(level_outs)
     N = level_outs[0].shape[0]
@@ -510,14 +641,65 @@ def rpn_loss(level_outs, num_anchors, anchors, assigned, pos_mask, neg_mask, gt_
     nt = torch.empty((1,), dtype=torch.float32, device=dev)
     ws = _workspace(lib.bgs_rpn_loss_workspace_bytes(N, A, L), dev)
     rc = lib.bgs_rpn_loss(_c_ptr_array(level_outs), _c_int_array(hw), L, num_anchors,
-                          capi.ptr(anchors), capi.ptr(assigned), capi.ptr(pos_mask.contiguous()),
-                          capi.ptr(neg_mask.contiguous()), capi.ptr(_f32c(gt_cat)),
+                          capi.ptr(anchors), capi.ptr(assigned), capi.ptr(pos_mask),
+                          capi.ptr(neg_mask), capi.ptr(gt_cat),
                           _c_int_array(gt_offsets), N, _c_float_array(means), _c_float_array(stds),
                           float(beta), float(pos_weight), float(loss_weight_cls),
                           float(loss_weight_bbox), capi.ptr(lc), capi.ptr(lb), capi.ptr(nt),
                           capi.ptr(ws), capi.current_stream(dev))
     capi.check('bgs_rpn_loss', rc)
     return lc, lb, nt
+
+
+class _RpnLossFn(torch.autograd.Function):
+    """Differentiable (w.r.t. the fused head outputs) form of the fused RPN loss."""
+
+    @staticmethod
+    def forward(ctx, cfg, anchors, assigned, pos_mask, neg_mask, gt_cat, *level_outs):
+        outs = [o.detach() for o in level_outs]
+        lc, lb, nt = _rpn_loss_launch(outs, cfg[0], anchors, assigned, pos_mask, neg_mask, gt_cat,
+                                      *cfg[1:])
+        ctx.cfg = cfg
+        ctx.save_for_backward(anchors, assigned, pos_mask, neg_mask, gt_cat, nt, *outs)
+        ctx.mark_non_differentiable(nt)
+        return lc, lb, nt
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_lc, g_lb, _g_nt):
+        anchors, assigned, pos_mask, neg_mask, gt_cat, nt = ctx.saved_tensors[:6]
+        outs = list(ctx.saved_tensors[6:])
+        (num_anchors, gt_offsets, means, stds, beta, pos_weight, w_cls, w_bbox) = ctx.cfg
+        lib = capi.load()
+        L = len(outs)
+        N = outs[0].shape[0]
+        hw = [int(o.shape[1] * o.shape[2]) for o in outs]
+        douts = [torch.zeros_like(o) for o in outs]
+        rc = lib.bgs_rpn_loss_grad(_c_ptr_array(outs), _c_ptr_array(douts), _c_int_array(hw), L,
+                                   num_anchors, capi.ptr(anchors), capi.ptr(assigned),
+                                   capi.ptr(pos_mask), capi.ptr(neg_mask), capi.ptr(gt_cat),
+                                   _c_int_array(gt_offsets), N, _c_float_array(means),
+                                   _c_float_array(stds), float(beta), float(pos_weight),
+                                   float(w_cls), float(w_bbox), capi.ptr(nt),
+                                   capi.ptr(_f32c(g_lc)), capi.ptr(_f32c(g_lb)),
+                                   capi.current_stream(anchors.device))
+        capi.check('bgs_rpn_loss_grad', rc)
+        return (None,) * 6 + tuple(douts)
+
+
+def rpn_loss(level_outs, num_anchors, anchors, assigned, pos_mask, neg_mask, gt_cat, gt_offsets,
+             means, stds, beta, pos_weight=-1, loss_weight_cls=1.0, loss_weight_bbox=1.0):
+    """Per-level RPN losses ``(loss_cls [L], loss_bbox [L], num_total_samples [1])`` from the
+    fused head outputs ``[N,H,W,A+4A]`` of every level and the sampled-anchor masks.
+    Differentiable w.r.t. ``level_outs`` when they require grad."""
+    _require_cuda(anchors, assigned, pos_mask, neg_mask, gt_cat, *level_outs)
+    pos_mask, neg_mask, gt_cat = pos_mask.contiguous(), neg_mask.contiguous(), _f32c(gt_cat)
+    args = (num_anchors, tuple(int(o) for o in gt_offsets), tuple(means), tuple(stds), beta,
+            pos_weight, loss_weight_cls, loss_weight_bbox)
+    if torch.is_grad_enabled() and any(o.requires_grad for o in level_outs):
+        return _RpnLossFn.apply(args, anchors, assigned, pos_mask, neg_mask, gt_cat, *level_outs)
+    return _rpn_loss_launch(list(level_outs), num_anchors, anchors, assigned, pos_mask, neg_mask,
+                            gt_cat, *args[1:])
 
 
 def decode_proposals(level_outs, level_counts, num_anchors, anchors, top_idx, top_logit, img_hw,

@@ -39,6 +39,7 @@ class SingleRoIExtractor(nn.Module):
     def forward(self, feats, rois, roi_scale_factor=None):
         if roi_scale_factor is not None:
             raise NotImplementedError('roi_scale_factor (HTC variants) is outside this round')
-        return BF.roi_align_nhwc(list(feats[:self.num_inputs]), rois, self.featmap_strides,
-                                 out_size=self.out_size, sample_num=self.sample_num,
-                                 finest_scale=self.finest_scale)
+        return BF.roi_align_nhwc_autograd(list(feats[:self.num_inputs]), rois,
+                                          self.featmap_strides, out_size=self.out_size,
+                                          sample_num=self.sample_num,
+                                          finest_scale=self.finest_scale)

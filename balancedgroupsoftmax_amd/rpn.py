@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import assign as A
 from . import functional as BF
-from .backbone import _check_frozen, _fold_conv_bn, _FoldCache
+from .backbone import _fold_conv_bn, _FoldCache
 from .box_ops import bbox2delta, delta2bbox
 from .builder import build_loss
 from .registry import HEADS
@@ -125,13 +125,12 @@ class RPNHead(nn.Module):
 
     def forward(self, feats):
         """NHWC feature maps -> (cls_scores, bbox_preds): per level ``[N,H,W,A]``, ``[N,H,W,4A]``."""
-        _check_frozen(self, 'rpn_head')
         f = self._cache.get(self, self._build_fold)
         cls_scores, bbox_preds, fused = [], [], []
         na = self.num_anchors * self.cls_out_channels
         for x in feats:
-            h = BF.conv2d_nhwc(x, f['conv'][0], f['conv'][1], pad=1, relu=True)
-            o = BF.conv2d_nhwc(h, f['head'][0], f['head'][1])
+            h = BF.conv2d_autograd(x, f['conv'][0], f['conv'][1], pad=1, relu=True)
+            o = BF.conv2d_autograd(h, f['head'][0], f['head'][1])
             fused.append(o)
             cls_scores.append(o[..., :na])
             bbox_preds.append(o[..., na:])
@@ -231,14 +230,13 @@ class RPNHead(nn.Module):
 
     # -- fused HIP path (csrc/det_targets.hip) -------------------------------------------------
     def _use_fused(self, cls_scores):
-        """The fused kernels read the head's own output buffers and produce loss VALUES; they
-        apply when running on the GPU with the RPN frozen (every shipped BAGS config)."""
+        """The fused kernels read the head's own output buffers (``bgs_rpn_loss`` is
+        differentiable w.r.t. them: ``bgs_rpn_loss_grad``); they apply whenever the scores passed
+        in are the ones this head just produced on the GPU."""
         fused = getattr(self, '_fused', None)
         if fused is None or not cls_scores[0].is_cuda or len(fused) != len(cls_scores):
             return False
-        if any(c.data_ptr() != o.data_ptr() for c, o in zip(cls_scores, fused)):
-            return False
-        return not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+        return not any(c.data_ptr() != o.data_ptr() for c, o in zip(cls_scores, fused))
 
     def _all_anchors(self, featmap_sizes, dev):
         key = ('all', tuple(featmap_sizes), str(dev))

@@ -42,6 +42,9 @@ def parse():
     ap.add_argument('--workload', default='detector', choices=['detector', 'gs_head'])
     ap.add_argument('--imgs', type=int, default=2, help='images per GPU per step (cfg: imgs_per_gpu=2)')
     ap.add_argument('--rois', type=int, default=1024, help='RoIs per GPU per step (2 img x 512)')
+    ap.add_argument('--selectp', type=int, default=1, choices=[0, 1],
+                    help='1 (as shipped): train bbox_head.fc_cls only; 0: train everything '
+                         '(tools/train.py:49-57)')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches, not hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -164,7 +167,7 @@ class DetectorStep(object):
     """One training iteration of cfg[1] as shipped (selectp=1: full forward, backward through
     fc_cls, gradient all-reduce, clip, SGD) on synthetic 800x1344 inputs, 512 RoIs/img."""
 
-    def __init__(self, dev, rank, world, imgs):
+    def __init__(self, dev, rank, world, imgs, selectp=1):
         import tempfile
         import balancedgroupsoftmax_amd as bgs
         from balancedgroupsoftmax_amd import train
@@ -175,7 +178,8 @@ class DetectorStep(object):
         model_cfg, train_cfg = detector_cfg(tmp)
         self.model = bgs.build_detector(to_config_dict(model_cfg),
                                         train_cfg=to_config_dict(train_cfg), test_cfg=None).to(dev)
-        self.params = train.select_training_param(self.model, 1)
+        self.selectp = selectp
+        self.params = train.select_training_param(self.model, selectp)
         self.model.train()
         opt = train.build_optimizer(self.params, dict(type='SGD', lr=0.01, momentum=0.9,
                                                       weight_decay=0.0001))
@@ -371,7 +375,7 @@ def cpu_baseline(n, seconds):
 
 
 def main_detector(args, rank, local, world, dev):
-    step = DetectorStep(dev, rank, world, args.imgs)
+    step = DetectorStep(dev, rank, world, args.imgs, args.selectp)
     # The iteration is free of host synchronisation by construction, so the whole step
     # (forward, losses, backward, all-reduce, clip, SGD: ~1600 launches) is captured into one
     # hipGraph; eager launches are the fallback (and --no-graph).
@@ -395,17 +399,24 @@ def main_detector(args, rank, local, world, dev):
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': 'gs_faster_rcnn_r50_fpn_1x_lvis_with0_bg8 (cfg[1]) training '
-                                   'iteration as shipped (selectp=1: full forward incl. RPN '
-                                   'losses/proposals/NMS/assign/sample/RoIAlign/FC heads/GroupSoftmax '
-                                   'loss, backward through fc_cls, grad all-reduce, clip 35, SGD): '
+                                   'iteration %s, grad all-reduce, clip 35, SGD): '
                                    '%d img/GPU, 3x800x1344 (1333x800 padded /32), 20 GT/img, '
                                    '512 RoI/img, 1231 classes, 5 bins; random-init weights'
-                                   % args.imgs,
+                                   % (('as shipped (selectp=1: full forward incl. RPN '
+                                       'losses/proposals/NMS/assign/sample/RoIAlign/FC heads/'
+                                       'GroupSoftmax loss, backward through fc_cls')
+                                      if args.selectp == 1 else
+                                      ('with selectp=0 (train everything but the frozen stem + '
+                                       'layer1: full forward and full backward through heads, '
+                                       'RoIAlign, RPN, FPN, ResNet layer2-4'), args.imgs),
+                       'selectp': args.selectp,
+                       'trainable_params': int(sum(p.numel() for p in step.params)),
                        'imgs_per_gpu': args.imgs, 'rois_per_img': 512,
                        'launch': ('hipGraph replay of forward+losses+backward, then eager '
                                   'all-reduce/clip/SGD') if graph else 'eager',
                        'parallelism': 'dp%d (one process per GPU; flat fp32 all-reduce of the '
-                                      '1,266,900 fc_cls grads over RCCL)' % world},
+                                      '%d trainable grads over RCCL)'
+                                      % (world, sum(p.numel() for p in step.params))},
             'img_per_s_per_gpu': round(imgs_per_s / world, 3),
             'last_losses': lv,
         }

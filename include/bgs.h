@@ -206,6 +206,17 @@ int bgs_roi_align_nhwc_fwd(const float* const* host_feats, const int* host_heigh
                            int pooled_h, int pooled_w, int sample_num, float* out,
                            int* levels_out, bgs_stream_t stream);
 
+/* RoIAlign backward (RoIAlignFunction.backward, mmdet/ops/roi_align/roi_align.py:31-53 ->
+ *   src/roi_align_kernel.cu:149-266), `selectp = 0` path only.  dout [K,pooled_h,pooled_w,C];
+ *   host_dfeats [L] HOST array of device pointers to the per-level gradient maps
+ *   [num_images,H_l,W_l,C], which are ACCUMULATED INTO with fp32 hardware atomics (zero them
+ *   first if nothing else contributed).  Same level rule / box semantics as the forward. */
+int bgs_roi_align_nhwc_bwd(float* const* host_dfeats, const int* host_heights,
+                           const int* host_widths, const float* host_scales, int num_levels,
+                           int num_images, float finest_scale, const float* rois, int K, int C,
+                           int pooled_h, int pooled_w, int sample_num, const float* dout,
+                           bgs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Batched greedy NMS, entirely on the device.  Replaces ops.nms / nms_cuda
  *   (mmdet/ops/nms/nms_wrapper.py:8-49, src/nms_kernel.cu:13-131; CPU variant nms_cpu.cpp:5-59)
@@ -265,6 +276,19 @@ int bgs_rpn_loss(const float* const* host_level_outs, const int* host_level_hw, 
                  const float* host_stds, float beta, float pos_weight, float loss_weight_cls,
                  float loss_weight_bbox, float* loss_cls_out, float* loss_bbox_out,
                  float* num_total_out, void* workspace, bgs_stream_t stream);
+
+/* Gradient of bgs_rpn_loss w.r.t. the fused head outputs (autograd of AnchorHead.loss_single,
+ *   anchor_head.py:131-161; `selectp = 0` path).  host_level_douts [L] HOST array of device
+ *   pointers to ZERO-FILLED maps shaped like the outputs; num_total = the normaliser written
+ *   by bgs_rpn_loss; grad_loss_cls / grad_loss_bbox [L] device arrays (upstream gradients of
+ *   the 2L loss scalars).  Only the sampled anchors' entries are written. */
+int bgs_rpn_loss_grad(const float* const* host_level_outs, float* const* host_level_douts,
+                      const int* host_level_hw, int L, int num_anchors, const float* anchors,
+                      const int* assigned, const uint8_t* pos_mask, const uint8_t* neg_mask,
+                      const float* gt, const int* host_gt_offsets, int N, const float* host_means,
+                      const float* host_stds, float beta, float pos_weight, float loss_weight_cls,
+                      float loss_weight_bbox, const float* num_total, const float* grad_loss_cls,
+                      const float* grad_loss_bbox, bgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Proposal decode: gather + delta2bbox + clamp + sigmoid for the top-k anchors of every

@@ -5,6 +5,8 @@ on the detector path.  Never imported by the product package.
   NO CPU RoIAlign: roi_align.py:27-28 raises; CUDA is not compilable here) — parity of this
   restatement is pinned only by analytic properties (tests/test_oracle_det.py), i.e.
   "parity unpinned" against an executed reference.
+* ``roi_align_backward`` roi_align_kernel.cu:149-266 (same status; additionally checked as the
+  exact adjoint of the forward restatement).
 * ``map_roi_levels``     mmdet/models/roi_extractors/single_level.py:54-73
 * ``nms``                mmdet/ops/nms/src/nms_cpu.cpp:5-59 (``>=``) and
                          mmdet/ops/nms/src/nms_kernel.cu:13-131 (``>``); the ``>=`` flavour is
@@ -74,6 +76,54 @@ def roi_align_forward(feat_nhwc, rois, spatial_scale, out_h=7, out_w=7, sample_n
                         acc += _bilinear(feat[b], H, W, y, x)
                 out[k, ph, pw] = acc / F32(sample_num * sample_num)
     return out
+
+
+def roi_align_backward(dout, rois, spatial_scale, feat_shape, sample_num=2):
+    """Restatement of ROIAlignBackward (roi_align_kernel.cu:149-266), single level, fp64
+    accumulation (the reference accumulates with fp32 atomics in arbitrary order).
+    ``dout [K,out_h,out_w,C]`` -> ``dfeat [N,H,W,C]``."""
+    dout = np.asarray(dout, dtype=np.float64)
+    rois = np.asarray(rois, dtype=F32)
+    N, H, W, C = feat_shape
+    K, out_h, out_w, _ = dout.shape
+    ss = F32(spatial_scale)
+    dfeat = np.zeros(feat_shape, dtype=np.float64)
+    count = float(sample_num * sample_num)
+    for k in range(K):
+        b = int(rois[k, 0])
+        start_w, start_h = rois[k, 1] * ss, rois[k, 2] * ss
+        end_w, end_h = (rois[k, 3] + F32(1)) * ss, (rois[k, 4] + F32(1)) * ss
+        rw = F32(max(end_w - start_w, 0.0))
+        rh = F32(max(end_h - start_h, 0.0))
+        bh, bw = F32(rh / F32(out_h)), F32(rw / F32(out_w))
+        for ph in range(out_h):
+            for pw in range(out_w):
+                g = dout[k, ph, pw]
+                for iy in range(sample_num):
+                    y = F32(start_h + F32(ph) * bh + F32(iy + 0.5) * bh / F32(sample_num))
+                    for ix in range(sample_num):
+                        x = F32(start_w + F32(pw) * bw + F32(ix + 0.5) * bw / F32(sample_num))
+                        if y < -1.0 or y > H or x < -1.0 or x > W:
+                            continue
+                        yy, xx = F32(max(y, 0.0)), F32(max(x, 0.0))
+                        y_low, x_low = int(yy), int(xx)
+                        if y_low >= H - 1:
+                            y_high = y_low = H - 1
+                            yy = F32(y_low)
+                        else:
+                            y_high = y_low + 1
+                        if x_low >= W - 1:
+                            x_high = x_low = W - 1
+                            xx = F32(x_low)
+                        else:
+                            x_high = x_low + 1
+                        ly, lx = F32(yy - F32(y_low)), F32(xx - F32(x_low))
+                        hy, hx = F32(1.0) - ly, F32(1.0) - lx
+                        dfeat[b, y_low, x_low] += g * float(hy * hx) / count
+                        dfeat[b, y_low, x_high] += g * float(hy * lx) / count
+                        dfeat[b, y_high, x_low] += g * float(ly * hx) / count
+                        dfeat[b, y_high, x_high] += g * float(ly * lx) / count
+    return dfeat
 
 
 def roi_align_multilevel(feats_nhwc, rois, strides, out_size=7, sample_num=2, finest_scale=56):

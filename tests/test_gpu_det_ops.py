@@ -302,3 +302,47 @@ def test_conv2d_dgrad_epilogues_and_wgrad_reproducibility():
     a = BF.conv2d_wgrad_nhwc(big_x, big_dy, 3, 1, 1)
     b = BF.conv2d_wgrad_nhwc(big_x, big_dy, 3, 1, 1)
     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------- RoIAlign backward (selectp = 0)
+def _ml_case(seed, C=16):
+    rs = np.random.RandomState(seed)
+    strides = [4, 8, 16, 32]
+    feats = [rs.randn(2, 64 // (s // 4), 96 // (s // 4), C).astype(np.float32) for s in strides]
+    K = 60
+    ctr = rs.uniform(0, 1, (K, 2)) * np.array([384, 256])
+    size = np.exp(rs.uniform(np.log(8), np.log(500), (K, 2)))
+    rois = np.concatenate([rs.randint(0, 2, (K, 1)), ctr - size / 2, ctr + size / 2], 1).astype(np.float32)
+    return strides, feats, rois
+
+
+def test_roi_align_backward_vs_oracle_and_adjoint():
+    strides, feats, rois = _ml_case(11)
+    rs = np.random.RandomState(12)
+    g = rs.randn(rois.shape[0], 7, 7, feats[0].shape[3]).astype(np.float32)
+    dfeats = [torch.zeros(f.shape, device=DEV) for f in feats]
+    BF.roi_align_nhwc_bwd(dev(g), dev(rois), dfeats, strides)
+    lv = det_oracle.map_roi_levels(rois, 4)
+    for i, s in enumerate(strides):
+        idx = np.nonzero(lv == i)[0]
+        exp = det_oracle.roi_align_backward(g[idx], rois[idx], 1.0 / s, feats[i].shape, 2)
+        got = dfeats[i].cpu().numpy()
+        assert np.abs(got - exp).max() <= 1e-4 * max(1.0, np.abs(exp).max()), i
+    # adjoint identity with the HIP forward
+    out = BF.roi_align_nhwc([dev(f) for f in feats], dev(rois), strides).cpu().numpy().astype(np.float64)
+    lhs = (out * g).sum()
+    rhs = sum((f.astype(np.float64) * d.cpu().numpy()).sum() for f, d in zip(feats, dfeats))
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+
+
+def test_roi_align_autograd_accumulates_into_feature_grads():
+    strides, feats, rois = _ml_case(13)
+    ft = [dev(f).requires_grad_(True) for f in feats]
+    out = BF.roi_align_nhwc_autograd(ft, dev(rois), strides)
+    (out * 2.0).sum().backward()
+    ones = np.ones((rois.shape[0], 7, 7, feats[0].shape[3]), np.float32) * 2.0
+    lv = det_oracle.map_roi_levels(rois, 4)
+    for i, s in enumerate(strides):
+        idx = np.nonzero(lv == i)[0]
+        exp = det_oracle.roi_align_backward(ones[idx], rois[idx], 1.0 / s, feats[i].shape, 2)
+        assert np.abs(ft[i].grad.cpu().numpy() - exp).max() <= 1e-4 * max(1.0, np.abs(exp).max())

@@ -365,3 +365,183 @@ def test_simple_test_matches_stepwise_oracle(tmp_path):
     order_g = np.lexsort((-got_b[:, 4], got_l))
     np.testing.assert_array_equal(got_l[order_g], el[order_e])
     np.testing.assert_array_equal(got_b[order_g], eb[order_e])
+
+
+# ---------------------------------------------------------------------------------------------
+# selectp = 0 (train everything): backward through RPN head, FPN, ResNet layer2-4 (conv dgrad /
+# wgrad kernels + differentiable BN fold) against torch-CPU autograd of the reference arithmetic
+# ---------------------------------------------------------------------------------------------
+def test_trunk_backward_vs_torch_cpu_autograd():
+    torch.manual_seed(0)
+    backbone = bgs.build_backbone(dict(type='ResNet', depth=50, num_stages=4,
+                                       out_indices=(0, 1, 2, 3), frozen_stages=1, style='pytorch'))
+    neck = bgs.build_neck(dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=256,
+                               num_outs=5))
+    rpn = bgs.build_head(dict(type='RPNHead', in_channels=256, feat_channels=256,
+                              anchor_scales=[8], anchor_ratios=[0.5, 1.0, 2.0],
+                              anchor_strides=[4, 8, 16, 32, 64]))
+    backbone.init_weights(), neck.init_weights(), rpn.init_weights()
+    for b in backbone.modules():
+        if hasattr(b, 'bn3'):
+            torch.nn.init.constant_(b.bn3.weight, 0.5)
+    randomize_bn(backbone)
+    mods = [backbone, neck, rpn]
+    img = torch.randn(2, 3, 128, 192)
+    # random cotangents for every output (P2..P6 consumed by a second head + the RPN outputs)
+    g = torch.Generator().manual_seed(1)
+
+    def run_ref():
+        c = ref_resnet(backbone, img)
+        p = ref_fpn(neck, c)
+        outs = list(p)
+        for x in p:
+            h = F.relu(F.conv2d(x, rpn.rpn_conv.weight, rpn.rpn_conv.bias, padding=1))
+            outs.append(F.conv2d(h, rpn.rpn_cls.weight, rpn.rpn_cls.bias))
+            outs.append(F.conv2d(h, rpn.rpn_reg.weight, rpn.rpn_reg.bias))
+        return outs
+    outs = run_ref()
+    cots = [torch.randn(o.shape, generator=g) / o[0].numel() ** 0.5 for o in outs]
+    sum((o * c).sum() for o, c in zip(outs, cots)).backward()
+    names, exp = [], []
+    for mi, m in enumerate(mods):
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                assert p.grad is not None, n
+                names.append('%d.%s' % (mi, n))
+                exp.append(p.grad.clone())
+                p.grad = None
+    assert not any(n.startswith('0.layer1') or n.startswith('0.conv1') for n in names)
+    assert any(n.startswith('0.layer2.0.bn1') for n in names)
+    for m in mods:
+        m.to(DEV)
+    got_c = backbone(img.to(DEV))
+    got_p = neck(got_c)
+    cls, reg = rpn(got_p)
+    got = list(got_p)
+    for c_, r_ in zip(cls, reg):
+        got += [c_, r_]
+    to_nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)      # noqa: E731
+    sum((o * to_nhwc(c)).sum() for o, c in zip(got, cots)).backward()
+    i = 0
+    bad = []
+    for mi, m in enumerate(mods):
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                e = exp[i]
+                i += 1
+                assert p.grad is not None, n
+                err = float((p.grad.cpu() - e).abs().max() / e.abs().max().clamp(min=1e-8))
+                # RPN conv: its ReLU sits on small pre-activations (weights ~ N(0, 0.01)), so the
+                # 1e-4 forward difference of the two trunks flips a few mask bits; it is checked
+                # tightly below on identical inputs instead
+                if err >= (2e-2 if (mi == 2 and n.startswith('rpn_conv')) else 5e-4):
+                    bad.append((mi, n, err))
+    assert i == len(exp)
+    assert not bad, bad
+    # RPN head alone, reference evaluated on the SAME (GPU-computed) pyramid
+    for p in rpn.parameters():
+        p.grad = None
+    feats = [t.detach() for t in got_p]
+    cls, reg = rpn(feats)
+    k = len(got_p)
+    sum((c_ * to_nhwc(cots[k + 2 * j])).sum() + (r_ * to_nhwc(cots[k + 2 * j + 1])).sum()
+        for j, (c_, r_) in enumerate(zip(cls, reg))).backward()
+    got_rpn = {n: p.grad.cpu().clone() for n, p in rpn.named_parameters()}
+    rpn.cpu()
+    for p in rpn.parameters():
+        p.grad = None
+    tot = 0
+    for j, x in enumerate(feats):
+        h = F.relu(F.conv2d(nchw(x), rpn.rpn_conv.weight, rpn.rpn_conv.bias, padding=1))
+        tot = tot + (F.conv2d(h, rpn.rpn_cls.weight, rpn.rpn_cls.bias) * cots[k + 2 * j]).sum() \
+            + (F.conv2d(h, rpn.rpn_reg.weight, rpn.rpn_reg.bias) * cots[k + 2 * j + 1]).sum()
+    tot.backward()
+    for n, p in rpn.named_parameters():
+        err = float((got_rpn[n] - p.grad).abs().max() / p.grad.abs().max().clamp(min=1e-8))
+        assert err < 5e-4, (n, err)
+
+
+def test_rpn_fused_loss_gradient_equals_tensor_form(tmp_path):
+    model = _detector(tmp_path).to(DEV)
+    rpn = model.rpn_head
+    torch.manual_seed(5)
+    feats = [torch.randn(2, h, w, 256, device=DEV) for h, w in
+             [(80, 120), (40, 60), (20, 30), (10, 15), (5, 8)]]
+    metas = [dict(img_shape=(320, 475, 3), pad_shape=(320, 480, 3)),
+             dict(img_shape=(310, 480, 3), pad_shape=(320, 480, 3))]
+    gts = [_rand_boxes(9, 1, 470, 310).to(DEV), _rand_boxes(14, 2, 470, 310).to(DEV)]
+    with torch.no_grad():
+        rpn.rpn_cls.bias.fill_(-1.0)
+        rpn.rpn_cls.weight.normal_(0, 0.05)
+        rpn.rpn_reg.weight.normal_(0, 0.02)
+    cfg = model.train_cfg
+    gen = torch.Generator(device=DEV)
+    lw = torch.linspace(0.5, 1.5, 10, device=DEV)           # distinct upstream grads per loss
+
+    def total(losses):
+        vals = [v.reshape(()) for v in losses['loss_rpn_cls']] + \
+               [v.reshape(()) for v in losses['loss_rpn_bbox']]
+        return (torch.stack(vals) * lw).sum()
+
+    def grads():
+        out = {n: p.grad.clone() for n, p in rpn.named_parameters() if p.grad is not None}
+        for p in rpn.parameters():
+            p.grad = None
+        return out
+    cls, reg = rpn(feats)
+    assert rpn._use_fused(cls) and cls[0].requires_grad
+    gen.manual_seed(11)
+    total(rpn.loss(cls, reg, gts, metas, cfg.rpn, generator=gen)).backward()
+    g_fused = grads()
+    cls, reg = rpn(feats)
+    rpn._fused = None                                        # tensor-op path (torch autograd)
+    gen.manual_seed(11)
+    total(rpn.loss(cls, reg, gts, metas, cfg.rpn, generator=gen)).backward()
+    g_plain = grads()
+    assert set(g_fused) == set(g_plain) and len(g_fused) == 6
+    for n in g_fused:
+        e = g_plain[n]
+        err = float((g_fused[n] - e).abs().max() / e.abs().max().clamp(min=1e-12))
+        assert err < 2e-4, (n, err)
+
+
+def test_full_training_iteration_selectp0(tmp_path):
+    """selectp = 0: every non-frozen parameter receives a finite gradient; stem + layer1 stay
+    frozen; the step changes the weights."""
+    torch.manual_seed(0)
+    model = _detector(tmp_path).to(DEV)
+    params = train.select_training_param(model, 0)
+    model.train()
+    H, W = 320, 480
+    img = torch.randn(2, 3, H, W, device=DEV)
+    metas = [dict(img_shape=(H, W - 5, 3), pad_shape=(H, W, 3), ori_shape=(H, W - 5, 3),
+                  scale_factor=1.0, flip=False)] * 2
+    g = torch.Generator().manual_seed(3)
+    gt_bboxes, gt_labels = [], []
+    for _ in range(2):
+        xy = torch.rand(12, 2, generator=g) * torch.tensor([W - 120., H - 120.])
+        wh = torch.rand(12, 2, generator=g) * 100 + 16
+        gt_bboxes.append(torch.cat([xy, xy + wh], 1).to(DEV))
+        gt_labels.append(torch.randint(1, 1231, (12,), generator=g).to(DEV))
+    losses = model(img, metas, return_loss=True, gt_bboxes=gt_bboxes, gt_labels=gt_labels)
+    loss, log_vars = train.parse_losses(losses)
+    opt = train.build_optimizer(params, dict(type='SGD', lr=0.01, momentum=0.9, weight_decay=1e-4))
+    step = train.DistOptimizerStep(params, opt, dict(max_norm=35, norm_type=2), world_size=1)
+    w0 = model.backbone.layer3[2].conv2.weight.detach().clone()
+    step(loss)
+    missing = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
+    assert not missing, missing[:5]
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert torch.isfinite(p.grad).all(), n
+    assert model.backbone.conv1.weight.grad is None
+    assert model.backbone.layer1[0].conv1.weight.grad is None
+    # (zero_init_residual: bn3.weight = 0 at init, so conv1/conv2 of a block see zero gradients)
+    for n in ('backbone.layer2.0.bn3.weight', 'backbone.layer2.0.downsample.0.weight',
+              'backbone.layer4.2.bn3.bias',
+              'neck.lateral_convs.0.conv.weight', 'neck.fpn_convs.3.conv.bias',
+              'rpn_head.rpn_conv.weight', 'rpn_head.rpn_reg.bias',
+              'bbox_head.shared_fcs.0.weight', 'bbox_head.fc_reg.weight', 'bbox_head.fc_cls.bias'):
+        gsum = float(dict(model.named_parameters())[n].grad.abs().sum())
+        assert gsum > 0, n
+    assert not torch.equal(w0, model.backbone.layer3[2].conv2.weight)

@@ -94,3 +94,18 @@ def test_multiclass_nms_restatement_vs_executed_reference(name):
                                        case['max_num'], mode='cpu')
     np.testing.assert_array_equal(ll, z[name + '/det_labels'])
     np.testing.assert_array_equal(bb, z[name + '/det_bboxes'])
+
+
+def test_roi_align_backward_restatement_is_the_adjoint_of_the_forward():
+    """<RoIAlign(x), g> == <x, RoIAlign^T(g)> for the two numpy restatements (the reference's
+    gradcheck recipe, ops/roi_align/gradcheck.py:11-30, states the same property numerically)."""
+    rs = np.random.RandomState(3)
+    feat = rs.randn(2, 9, 11, 3).astype(np.float32)
+    rois = np.array([[0, 1.5, 2.0, 30.0, 25.5], [1, -6.0, -3.0, 12.0, 40.0],
+                     [1, 20.0, 10.0, 47.0, 38.0], [0, 5.0, 5.0, 5.0, 5.0]], np.float32)
+    g = rs.randn(4, 3, 3, 3).astype(np.float32)
+    out = det_oracle.roi_align_forward(feat, rois, 0.25, 3, 3, 2)
+    dfeat = det_oracle.roi_align_backward(g, rois, 0.25, feat.shape, 2)
+    lhs = float((out.astype(np.float64) * g).sum())
+    rhs = float((feat.astype(np.float64) * dfeat).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
