@@ -121,9 +121,13 @@ class Bottleneck(nn.Module):
         identity = x
         if 'ds' in f:
             identity = BF.conv2d_autograd(x, f['ds'][0], f['ds'][1], stride=self.stride)
-        out = BF.conv2d_autograd(x, f['c1'][0], f['c1'][1], relu=True)
-        out = BF.conv2d_autograd(out, f['c2'][0], f['c2'][1], stride=self.stride, pad=1, relu=True)
-        return BF.conv2d_autograd(out, f['c3'][0], f['c3'][1], relu=True, residual=identity)
+        # conv1 -> conv2 -> conv3 is a chain of single consumers: the ReLU backward of o1 / o2
+        # rides in the epilogue of the next conv's dgrad (relu='consumers' + mask_input)
+        out = BF.conv2d_autograd(x, f['c1'][0], f['c1'][1], relu='consumers')
+        out = BF.conv2d_autograd(out, f['c2'][0], f['c2'][1], stride=self.stride, pad=1,
+                                 relu='consumers', mask_input=True)
+        return BF.conv2d_autograd(out, f['c3'][0], f['c3'][1], relu=True, residual=identity,
+                                  mask_input=True)
 
 
 @BACKBONES.register_module

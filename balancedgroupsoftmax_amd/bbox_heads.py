@@ -279,26 +279,33 @@ class ConvFCBBoxHead(BBoxHead):
             x = self.avg_pool(x)
         x = x.reshape(x.size(0), -1)
 
-        def fc_apply(fc, t, relu, first=False):
+        def fc_apply(fc, t, relu, first=False, t_is_relu=False):
             if not hip:
                 y = fc(t)
                 return self.relu(y) if relu else y
             w = self._fc1_weight(fc, nhwc) if first else fc.weight
-            return BF.linear_autograd(t, w, fc.bias, relu=relu)
+            # every consumer of a hidden FC output is another FC of this head: the ReLU backward
+            # rides in the consumers' dgrad epilogue
+            return BF.linear_autograd(t, w, fc.bias, relu='consumers' if relu else False,
+                                      mask_input=t_is_relu)
 
         first = True
+        hidden = False          # is the running activation the ReLU output of a hidden FC?
         for fc in self.shared_fcs:
-            x = fc_apply(fc, x, True, first)
-            first = False
-        x_cls = x_reg = x
-        for fc in self.cls_fcs:
-            x_cls = fc_apply(fc, x_cls, True, first and self.num_shared_fcs == 0)
-        for fc in self.reg_fcs:
-            x_reg = fc_apply(fc, x_reg, True, first and self.num_shared_fcs == 0)
+            x = fc_apply(fc, x, True, first, hidden)
+            first, hidden = False, True
         if nhwc and self.num_shared_fcs == 0:
             raise NotImplementedError('NHWC RoI features need a shared first FC')
-        cls_score = fc_apply(self.fc_cls, x_cls, False) if self.with_cls else None
-        bbox_pred = fc_apply(self.fc_reg, x_reg, False) if self.with_reg else None
+        x_cls = x_reg = x
+        h_cls = h_reg = hidden
+        for fc in self.cls_fcs:
+            x_cls = fc_apply(fc, x_cls, True, False, h_cls)
+            h_cls = True
+        for fc in self.reg_fcs:
+            x_reg = fc_apply(fc, x_reg, True, False, h_reg)
+            h_reg = True
+        cls_score = fc_apply(self.fc_cls, x_cls, False, False, h_cls) if self.with_cls else None
+        bbox_pred = fc_apply(self.fc_reg, x_reg, False, False, h_reg) if self.with_reg else None
         return cls_score, bbox_pred
 
 

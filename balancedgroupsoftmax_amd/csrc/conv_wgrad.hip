@@ -36,6 +36,8 @@ struct WgradArgs {
   const float* x;   // [N, H, W, Cin]
   const float* dy;  // [N, Ho, Wo, Cout]
   float* out;       // workspace [splits][Cout][K] or dW itself when splits == 1 && !accumulate
+  float* db_part;   // null, or [splits][Cout]: per-split column sums of dy (bias gradient), produced
+                    // by the k-tile-0 workgroups from the dy tiles they stage anyway
   int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
   int M, K, m_per_split;
 };
@@ -112,6 +114,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_f32_kernel(WgradArgs p) {
   }
 
   f32x4 va[PA], vb[PB];
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const bool want_db = p.db_part != nullptr && blockIdx.y == 0;
   int m_stage = m_begin;
   auto load_stage = [&]() {
 #pragma unroll
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_f32_kernel(WgradArgs p) {
       va[q] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (a_col_ok && m < m_end)
         va[q] = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + co0 + qa * 4);
+      if (want_db) bsum += va[q];
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
@@ -187,6 +192,17 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_f32_kernel(WgradArgs p) {
     __syncthreads();
   }
 
+  if (want_db) {   // block-uniform; the last loop iteration ended with a barrier: As is free
+    f32x4* red = reinterpret_cast<f32x4*>(&As[0][0]);     // [RA][QA] quads (RA*QA = 256)
+    red[ra * QA + qa] = bsum;
+    __syncthreads();
+    if (ra == 0 && a_col_ok) {
+      f32x4 t = red[qa];
+      for (int r = 1; r < RA; ++r) t += red[r * QA + qa];
+      *reinterpret_cast<f32x4*>(p.db_part + (size_t)blockIdx.z * p.Cout + co0 + qa * 4) = t;
+    }
+  }
+
   // ---- write the partial tile: D row i of row tile a -> co = co0 + wm*32*MB + MB*i + a,
   //      D col (lane & 31) of col tile b -> k = k0 + wn*32*NB + NB*(lane & 31) + b
   float* out = p.out + (size_t)blockIdx.z * p.Cout * p.K;
@@ -219,28 +235,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (int z = 1; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(ws + (z * n4 + i) * 4);
     if (accumulate) s += *reinterpret_cast<const f32x4*>(dw + i * 4);
     *reinterpret_cast<f32x4*>(dw + i * 4) = s;
-  }
-}
-
-// Column sums of a row-major [M, C] matrix (bias gradient: db[c] = sum_m dy[m][c]).  Stage 1:
-// gridDim.y row chunks x (C/4 quads per 64 threads); stage 2 reuses wgrad_reduce_kernel.
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, int M,
-                                                             int C, int rows_per_chunk,
-                                                             float* __restrict__ part) {
-  // 256 threads = 4 row lanes x 64 column quads
-  const int cq = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
-  const int m0 = blockIdx.y * rows_per_chunk;
-  const int m1 = min(M, m0 + rows_per_chunk);
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (cq * 4 < C)
-    for (int m = m0 + rl; m < m1; m += 4) s += *reinterpret_cast<const f32x4*>(a + (size_t)m * C + cq * 4);
-  __shared__ f32x4 red[4][64];
-  red[rl][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (rl == 0 && cq * 4 < C) {
-    s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.y * C + cq * 4) = s;
   }
 }
 
@@ -286,8 +280,8 @@ extern "C" size_t bgs_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin,
   const long long M = (long long)N * Ho * Wo;
   const int K = R * S * Cin;
   const WgradPlan pl = plan_wgrad((int)M, Cout, K);
-  // weight partials + bias partials (colsum: up to 256 row chunks)
-  return ((size_t)pl.splits * Cout * K + (size_t)256 * Cout) * sizeof(float) + 256;
+  // weight partials + bias partials
+  return ((size_t)pl.splits * Cout * K + (size_t)pl.splits * Cout) * sizeof(float) + 256;
 }
 
 extern "C" int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, float* db,
@@ -318,6 +312,8 @@ extern "C" int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float*
   float* ws = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   const bool direct = pl.splits == 1 && !accumulate;
   p.out = direct ? dw : ws;
+  const size_t n = (size_t)Cout * p.K;
+  p.db_part = db ? ws + (size_t)pl.splits * n : nullptr;
   const int bm = pl.tile == 22 ? 128 : 64;
   dim3 grid((unsigned)((Cout + bm - 1) / bm), (unsigned)((p.K + bm - 1) / bm), (unsigned)pl.splits);
   if (pl.tile == 22)
@@ -325,7 +321,6 @@ extern "C" int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float*
   else
     hipLaunchKernelGGL((conv_wgrad_f32_kernel<1, 1>), grid, dim3(kThreads), 0, st, p);
   if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
-  const size_t n = (size_t)Cout * p.K;
   if (!direct) {
     const size_t n4 = n / 4;   // Cin % 4 == 0 -> n % 4 == 0
     size_t g = (n4 + 255) / 256;
@@ -335,18 +330,9 @@ extern "C" int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float*
     if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
   }
   if (db) {
-    float* part = ws + (size_t)pl.splits * n;
-    int chunks = (p.M + 2047) / 2048;
-    if (chunks > 256) chunks = 256;
-    if (chunks < 1) chunks = 1;
-    int rows = (p.M + chunks - 1) / chunks;
-    chunks = (p.M + rows - 1) / rows;
-    dim3 g2((unsigned)((Cout / 4 + 63) / 64), (unsigned)chunks);
-    hipLaunchKernelGGL(colsum_partial_kernel, g2, dim3(256), 0, st, dy, p.M, Cout, rows, part);
-    if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
     const size_t c4 = (size_t)Cout / 4;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, st,
-                       part, db, c4, chunks, accumulate);
+                       p.db_part, db, c4, pl.splits, accumulate);
   }
   BGS_RETURN_LAUNCH_STATUS();
 }

@@ -343,31 +343,37 @@ class _ConvFn(torch.autograd.Function):
     x, w, b and the residual (the `selectp = 0` path).
 
     backward: ``dz = dy * (y > 0)`` (ReLU), ``dx = dgrad(dz, w)``, ``dw, db = wgrad(x, dz)``,
-    ``dresidual = dz`` (mode 1) or its 2x2 sum-pool (mode 2: nearest-2x upsampled residual)."""
+    ``dresidual = dz`` (mode 1) or its 2x2 sum-pool (mode 2: nearest-2x upsampled residual).
+
+    ReLU-backward placement: ``relu='consumers'`` declares that EVERY consumer of ``y`` is a
+    ``_ConvFn`` called with ``mask_input=True`` — each of them gates its own ``dx`` with
+    ``(y > 0)`` inside the dgrad kernel's epilogue (the mask is linear, so gating the addends
+    equals gating their sum) and this node skips the separate masking pass over ``dy``."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, stride, pad, relu, residual_mode):
+    def forward(ctx, x, w, bias, residual, stride, pad, relu, residual_mode, mask_input):
         y = conv2d_nhwc(x.detach(), w.detach(), None if bias is None else bias.detach(),
-                        stride=stride, pad=pad, relu=relu,
+                        stride=stride, pad=pad, relu=bool(relu),
                         residual=None if residual is None else residual.detach(),
                         residual_mode=residual_mode)
         ctx.cfg = (stride, pad, relu, residual_mode if residual is not None else 0,
-                   bias is not None)
-        ctx.save_for_backward(x, w, y if relu else None)
+                   bias is not None, mask_input)
+        ctx.save_for_backward(x, w, y if relu is True else None)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
-        stride, pad, relu, res_mode, has_bias = ctx.cfg
+        stride, pad, relu, res_mode, has_bias, mask_input = ctx.cfg
         dz = dy.contiguous()
-        if relu:
-            dz = torch.where(y > 0, dz, torch.zeros((), dtype=dz.dtype, device=dz.device))
+        if relu is True:          # one fused pass: dy * (y > 0)
+            dz = torch.ops.aten.threshold_backward(dz, y, 0.0)
         need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
         dx = dw = db = dres = None
         if need_x:
-            dx = conv2d_dgrad_nhwc(dz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad)
+            dx = conv2d_dgrad_nhwc(dz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad,
+                                   mask=x if mask_input else None)
         if need_w or (has_bias and need_b):
             out = conv2d_wgrad_nhwc(x, dz, w.shape[1], stride=stride, pad=pad, bias=has_bias)
             dw, db = out if has_bias else (out, None)
@@ -377,19 +383,22 @@ class _ConvFn(torch.autograd.Function):
             else:
                 n, h, wd, c = dz.shape
                 dres = dz.view(n, h // 2, 2, wd // 2, 2, c).sum(dim=(2, 4))
-        return dx, dw, db, dres, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None
 
 
 def conv2d_autograd(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None,
-                    residual_mode=0):
-    """:func:`conv2d_nhwc` that records an autograd node when any input requires grad."""
+                    residual_mode=0, mask_input=False):
+    """:func:`conv2d_nhwc` that records an autograd node when any input requires grad.
+    ``relu``: False / True / ``'consumers'`` (see :class:`_ConvFn`); ``mask_input``: ``x`` is the
+    output of a ``relu='consumers'`` conv."""
     ts = [t for t in (x, w_krsc, bias, residual) if t is not None]
     if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
         if residual is not None and residual_mode == 0:
             residual_mode = 1
-        return _ConvFn.apply(x, w_krsc, bias, residual, stride, pad, bool(relu), residual_mode)
-    return conv2d_nhwc(x, w_krsc, bias, stride=stride, pad=pad, relu=relu, residual=residual,
-                       residual_mode=residual_mode)
+        return _ConvFn.apply(x, w_krsc, bias, residual, stride, pad, relu, residual_mode,
+                             bool(mask_input))
+    return conv2d_nhwc(x, w_krsc, bias, stride=stride, pad=pad, relu=bool(relu),
+                       residual=residual, residual_mode=residual_mode)
 
 
 def linear(x, weight, bias=None, relu=False):
@@ -439,18 +448,19 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw, gb
 
 
-def linear_autograd(x, weight, bias=None, relu=False):
+def linear_autograd(x, weight, bias=None, relu=False, mask_input=False):
     """``act(x @ weight.T + bias)``: fused forward-only kernel when nothing requires grad,
-    otherwise the differentiable path (ReLU applied outside the kernel)."""
+    otherwise the differentiable path (``relu`` / ``mask_input`` as in :func:`conv2d_autograd`)."""
     needs = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or
                                          (bias is not None and bias.requires_grad))
     if not needs:
-        return linear(x, weight, bias, relu=relu)
+        return linear(x, weight, bias, relu=bool(relu))
     M, K = x.shape
     Nout = weight.shape[0]
     y = _ConvFn.apply(x.float().contiguous().view(M, 1, 1, K),
                       weight.float().contiguous().view(Nout, 1, 1, K),
-                      None if bias is None else bias.float(), None, 1, 0, bool(relu), 0)
+                      None if bias is None else bias.float(), None, 1, 0, relu, 0,
+                      bool(mask_input))
     return y.view(M, Nout)
 
 

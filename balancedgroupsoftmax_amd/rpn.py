@@ -129,8 +129,8 @@ class RPNHead(nn.Module):
         cls_scores, bbox_preds, fused = [], [], []
         na = self.num_anchors * self.cls_out_channels
         for x in feats:
-            h = BF.conv2d_autograd(x, f['conv'][0], f['conv'][1], pad=1, relu=True)
-            o = BF.conv2d_autograd(h, f['head'][0], f['head'][1])
+            h = BF.conv2d_autograd(x, f['conv'][0], f['conv'][1], pad=1, relu='consumers')
+            o = BF.conv2d_autograd(h, f['head'][0], f['head'][1], mask_input=True)
             fused.append(o)
             cls_scores.append(o[..., :na])
             bbox_preds.append(o[..., na:])
