@@ -64,6 +64,15 @@ SIGNATURES = {
                                               ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, c_f32p, c_ptr]),
+    'bgs_mask_target': (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
+                                       ctypes.c_int, c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, c_f32p,
+                                       c_ptr]),
+    'bgs_mask_gt_logits': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, c_f32p, c_ptr]),
+    'bgs_mask_bce_partials': (ctypes.c_int, [ctypes.c_int]),
+    'bgs_mask_bce': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, c_f32p, c_ptr, c_f32p,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
+                                    c_f32p, c_f32p, c_f32p, c_ptr]),
     'bgs_nms_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     'bgs_nms_batched': (ctypes.c_int, [c_f32p, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                        ctypes.c_int, ctypes.c_int, c_ptr, c_ptr, c_ptr, c_ptr]),

@@ -156,6 +156,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
     }
   };
 
+  // (Tried: two accumulators per wave for the single-tile configuration, to break the dependent
+  //  MFMA chain — no gain: with 4 workgroups per CU the other waves already fill those bubbles.)
   f32x16 acc[MB][NB];
 #pragma unroll
   for (int a = 0; a < MB; ++a)
@@ -191,9 +193,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][kk >> 2][kk & 3],
-                                                            bv[b][kk >> 2][kk & 3], acc[a][b], 0,
-                                                            0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+              av[a][kk >> 2][kk & 3], bv[b][kk >> 2][kk & 3], acc[a][b], 0, 0, 0);
     }
     if (kt + 1 < nk) store_tile(buf ^ 1);
     __syncthreads();

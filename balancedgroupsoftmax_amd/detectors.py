@@ -26,15 +26,23 @@ class TwoStageDetector(nn.Module):
                  bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None,
                  train_cfg=None, test_cfg=None, pretrained=None):
         super().__init__()
-        if shared_head is not None or mask_head is not None or mask_roi_extractor is not None:
-            raise NotImplementedError('shared_head / mask branch: not built in this round '
-                                      '(SURVEY.md §8f rank 3)')
+        if shared_head is not None:
+            raise NotImplementedError('shared_head (C4 heads) is not on the BAGS path')
         self.backbone = builder.build_backbone(backbone)
         self.neck = builder.build_neck(neck) if neck is not None else None
         self.rpn_head = builder.build_head(rpn_head) if rpn_head is not None else None
         self.bbox_roi_extractor = builder.build_roi_extractor(bbox_roi_extractor) \
             if bbox_head is not None else None
         self.bbox_head = builder.build_head(bbox_head) if bbox_head is not None else None
+        self.mask_head = None
+        if mask_head is not None:
+            if mask_roi_extractor is not None:
+                self.mask_roi_extractor = builder.build_roi_extractor(mask_roi_extractor)
+                self.share_roi_extractor = False
+            else:
+                self.share_roi_extractor = True
+                self.mask_roi_extractor = self.bbox_roi_extractor
+            self.mask_head = builder.build_head(mask_head)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
         self.fp16_enabled = False
         self.init_weights(pretrained=pretrained)
@@ -42,7 +50,7 @@ class TwoStageDetector(nn.Module):
     with_neck = property(lambda self: self.neck is not None)
     with_rpn = property(lambda self: self.rpn_head is not None)
     with_bbox = property(lambda self: self.bbox_head is not None)
-    with_mask = property(lambda self: False)
+    with_mask = property(lambda self: self.mask_head is not None)
     with_shared_head = property(lambda self: False)
 
     def init_weights(self, pretrained=None):
@@ -58,6 +66,10 @@ class TwoStageDetector(nn.Module):
         if self.with_bbox:
             self.bbox_roi_extractor.init_weights()
             self.bbox_head.init_weights()
+        if self.with_mask:
+            self.mask_head.init_weights()
+            if not self.share_roi_extractor:
+                self.mask_roi_extractor.init_weights()
 
     def extract_feat(self, img):
         x = self.backbone(img)
@@ -114,6 +126,9 @@ class TwoStageDetector(nn.Module):
             assigned_l.append(a.contiguous())
             inds_l.append(inds.contiguous())
             valid_l.append(valid)
+        # gt index of every sampled RoI (pos_assigned_gt_inds for the mask targets), -1 = none
+        self._sampled_gt_inds = torch.stack(
+            [assigned_l[i].gather(0, inds_l[i]).to(torch.int32) - 1 for i in range(N)])
         head = self.bbox_head
         rois, labels, lw, bt, bw = BF.rcnn_targets(
             boxes_l, assigned_l, inds_l, valid_l, [g.contiguous() for g in gt_labels], gt_cat, offs,
@@ -165,7 +180,38 @@ class TwoStageDetector(nn.Module):
             bbox_feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
             cls_score, bbox_pred = self.bbox_head(bbox_feats, nhwc=True)
             losses.update(self.bbox_head.loss(cls_score, bbox_pred, *targets))
+        if self.with_mask:
+            losses.update(self._mask_forward_train(x, rois, targets[0], gt_masks, img.size(0)))
         return losses
+
+    def _mask_forward_train(self, x, rois, labels, gt_masks, num_imgs):
+        """two_stage.py:228-263 with a FIXED number of mask RoIs: the sampler puts the positives
+        first (at most ``int(num * pos_fraction)`` per image), so the first ``max_pos`` slots of
+        every image are the candidates and ``labels > 0`` says which of them are real; padding
+        slots get zero weight in the mean instead of being filtered out on the host."""
+        if gt_masks is None:
+            raise ValueError('the mask branch needs gt_masks (per image a uint8 [G, H, W] tensor)')
+        if not rois.is_cuda:
+            raise NotImplementedError('the mask branch runs on the GPU path only')
+        sc = self.train_cfg.rcnn.sampler
+        max_pos = int(sc.num * sc.pos_fraction)
+        num = sc.num
+        sel = (torch.arange(num_imgs, device=rois.device).view(-1, 1) * num +
+               torch.arange(max_pos, device=rois.device).view(1, -1)).reshape(-1)
+        pos_rois = rois[sel].contiguous()
+        pos_labels = labels[sel].contiguous()
+        valid = pos_labels > 0
+        gt_inds = self._sampled_gt_inds[:, :max_pos].reshape(-1).contiguous()
+        masks = [torch.as_tensor(m).to(device=rois.device, dtype=torch.uint8).contiguous()
+                 for m in gt_masks]
+        if self.share_roi_extractor:
+            raise NotImplementedError('share_roi_extractor=True (7x7 features for the mask head) '
+                                      'is not used by the BAGS configs')
+        mask_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], pos_rois)
+        feats = self.mask_head.features(mask_feats, nhwc=True)
+        mask_targets = self.mask_head.get_target_fixed(pos_rois, gt_inds, valid, masks,
+                                                       self.train_cfg.rcnn)
+        return self.mask_head.loss_from_features(feats, mask_targets, pos_labels, valid)
 
     # ------------------------------------------------------------------ test-time path
     def simple_test_rpn(self, x, img_meta, rpn_test_cfg):
@@ -199,7 +245,22 @@ class TwoStageDetector(nn.Module):
                          if proposals is None else proposals)
         det_bboxes, det_labels, _ = self.simple_test_bboxes(x, img_meta, proposal_list,
                                                             self.test_cfg.rcnn, rescale=rescale)
-        return bbox2result(det_bboxes, det_labels, self.bbox_head.num_classes)
+        bbox_results = bbox2result(det_bboxes, det_labels, self.bbox_head.num_classes)
+        if not self.with_mask:
+            return bbox_results
+        return bbox_results, self.simple_test_mask(x, img_meta, det_bboxes, det_labels,
+                                                   rescale=rescale)
+
+    def simple_test_mask(self, x, img_meta, det_bboxes, det_labels, rescale=False):
+        """test_mixins.py:153-180 up to the per-detection mask probabilities ``[k, 28, 28]`` of
+        each detection's own class (device tensor).  Pasting into the image + RLE encoding
+        (``get_seg_masks``, pycocotools) is evaluation tooling outside the hot path."""
+        if det_bboxes.shape[0] == 0:
+            return det_bboxes.new_zeros((0, 28, 28))
+        boxes = det_bboxes[:, :4] * img_meta[0]['scale_factor'] if rescale else det_bboxes[:, :4]
+        rois = torch.cat([boxes.new_zeros((boxes.size(0), 1)), boxes], dim=1)
+        feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], rois)
+        return self.mask_head.get_mask_probs(self.mask_head.features(feats, nhwc=True), det_labels)
 
     def forward_test(self, imgs, img_metas, **kwargs):
         """base.py forward_test: one scale only (aug_test / TTA is not on the BAGS path)."""
@@ -218,6 +279,13 @@ class TwoStageDetector(nn.Module):
 
 @DETECTORS.register_module
 class FasterRCNN(TwoStageDetector):
+    pass
+
+
+@DETECTORS.register_module
+class MaskRCNN(TwoStageDetector):
+    """mmdet/models/detectors/mask_rcnn.py: the two-stage detector with the mask branch
+    (configs/bags/gs_mask_rcnn_r50_fpn_1x_lvis.py = cfg 4)."""
     pass
 
 

@@ -778,3 +778,92 @@ def selftest_wave_reduce(values):
                lib.bgs_selftest_wave_reduce(capi.ptr(v), capi.ptr(out),
                                             capi.current_stream(v.device)))
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# mask branch (csrc/mask_head.hip): targets, single-channel logits, fused BCE
+# ----------------------------------------------------------------------------------------
+def mask_target(gt_masks, rois, gt_inds, valid, mask_size):
+    """``gt_masks``: per image a uint8 device tensor ``[G_n, H, W]``; ``rois [P, >=5]`` float
+    (batch_ind, x1, y1, x2, y2); ``gt_inds [P]`` int32; ``valid [P]`` bool/uint8 or None ->
+    ``[P, S, S]`` float targets (mask_target.py:16-38 incl. the cv2 INTER_LINEAR uint8 resize)."""
+    import ctypes
+    _require_cuda(rois, gt_inds, valid, *gt_masks)
+    lib = capi.load()
+    N = len(gt_masks)
+    Hm, Wm = int(gt_masks[0].shape[1]), int(gt_masks[0].shape[2])
+    for m in gt_masks:
+        assert m.dtype == torch.uint8 and m.is_contiguous() and tuple(m.shape[1:]) == (Hm, Wm)
+    rois = _f32c(rois)
+    P = rois.shape[0]
+    gt_inds = gt_inds.to(torch.int32).contiguous()
+    v8 = None if valid is None else valid.to(torch.uint8).contiguous()
+    out = torch.empty((P, mask_size, mask_size), dtype=torch.float32, device=rois.device)
+    ptrs = (ctypes.c_void_p * N)(*[m.data_ptr() if m.numel() else None for m in gt_masks])
+    ng = (ctypes.c_int * N)(*[int(m.shape[0]) for m in gt_masks])
+    rc = lib.bgs_mask_target(ptrs, ng, N, Hm, Wm, capi.ptr(rois), int(rois.shape[1]),
+                             capi.ptr(gt_inds), capi.ptr(v8), P, int(mask_size), capi.ptr(out),
+                             capi.current_stream(rois.device))
+    capi.check('bgs_mask_target', rc)
+    return out
+
+
+def mask_gt_logits(feat, weight, bias, labels):
+    """``feat [P, pixels, C]``, ``weight [K, C]``, ``labels [P]`` -> ``[P, pixels]`` logits of each
+    RoI's own class channel (no gradient: test-time / inspection path)."""
+    _require_cuda(feat, weight, bias, labels)
+    lib = capi.load()
+    feat, weight = _f32c(feat), _f32c(weight)
+    P, pix, C = feat.shape
+    out = torch.empty((P, pix), dtype=torch.float32, device=feat.device)
+    rc = lib.bgs_mask_gt_logits(capi.ptr(feat), capi.ptr(weight),
+                                capi.ptr(None if bias is None else _f32c(bias)),
+                                capi.ptr(labels.to(torch.int64).contiguous()), P, pix, C,
+                                weight.shape[0], capi.ptr(out), capi.current_stream(feat.device))
+    capi.check('bgs_mask_gt_logits', rc)
+    return out
+
+
+class _MaskBceFn(torch.autograd.Function):
+    """loss[1] = mean over (valid RoIs x pixels) of BCE(<feat, W[label]> + b[label], target);
+    gradients for feat, W, b come from the same launch (scaled by the upstream scalar after)."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, labels, target, valid):
+        lib = capi.load()
+        f, w = _f32c(feat), _f32c(weight)
+        b = None if bias is None else _f32c(bias)
+        P, pix, C = f.shape
+        dev = f.device
+        lab = labels.to(torch.int64).contiguous()
+        tgt = _f32c(target)
+        v8 = None if valid is None else valid.to(torch.uint8).contiguous()
+        nvalid = torch.full((), float(P), device=dev) if v8 is None else v8.sum().float()
+        norm = (1.0 / (nvalid.clamp(min=1.0) * pix)).reshape(1).contiguous()
+        need = [feat.requires_grad, weight.requires_grad, bias is not None and bias.requires_grad]
+        dfeat = torch.empty_like(f) if need[0] else None
+        dw = torch.zeros_like(w) if (need[1] or need[2]) else None
+        db = torch.zeros(w.shape[0], dtype=torch.float32, device=dev) if dw is not None else None
+        part = torch.empty((lib.bgs_mask_bce_partials(P),), dtype=torch.float32, device=dev)
+        rc = lib.bgs_mask_bce(capi.ptr(f), capi.ptr(w), capi.ptr(b), capi.ptr(lab), capi.ptr(tgt),
+                              capi.ptr(v8), capi.ptr(norm), P, pix, C, w.shape[0], capi.ptr(part),
+                              capi.ptr(dfeat), capi.ptr(dw), capi.ptr(db),
+                              capi.current_stream(dev))
+        capi.check('bgs_mask_bce', rc)
+        ctx.grads = (dfeat, dw, db if bias is not None else None)
+        return (part.sum() * norm[0]).reshape(1)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        dfeat, dw, db = ctx.grads
+        s = g.reshape(())
+        return (None if dfeat is None else dfeat * s, None if dw is None else dw * s,
+                None if db is None else db * s, None, None, None)
+
+
+def mask_bce(feat, weight, bias, labels, target, valid=None):
+    """Fused single-channel ``conv_logits`` + ``mask_cross_entropy`` -> loss ``[1]``."""
+    _require_cuda(feat, weight, bias, labels, target, valid)
+    assert feat.dim() == 3 and weight.dim() == 2 and feat.shape[2] == weight.shape[1]
+    return _MaskBceFn.apply(feat, weight, bias, labels, target, valid)

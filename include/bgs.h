@@ -319,6 +319,39 @@ int bgs_rcnn_targets(const float* const* host_boxes, const int* host_box_strides
                      float* rois, long long* labels, float* label_weights, float* bbox_targets,
                      float* bbox_weights, bgs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Mask branch (cfg 4: gs_mask_rcnn_r50_fpn_1x_lvis).
+ *
+ * bgs_mask_target: mask_target_single (mmdet/core/mask/mask_target.py:16-38) for all positive
+ *   RoIs in one launch.  host_masks [num_images] HOST array of device pointers to the uint8 GT
+ *   bitmaps [G_n, mask_h, mask_w] of each image; host_num_gt [num_images]; rois [P, roi_stride]
+ *   float (batch_ind, x1, y1, x2, y2, ...); gt_inds [P] int32 = pos_assigned_gt_inds; valid [P]
+ *   uint8 or NULL (fixed-shape padding slots -> all-zero target); out [P, S, S] float in {0,1}
+ *   = cv2.resize(crop, (S, S), INTER_LINEAR) on uint8 (what mmcv.imresize calls).
+ *
+ * bgs_mask_gt_logits: logits_out[p, pix] = <feat[p,pix,:], weight[labels[p],:]> + bias[labels[p]]
+ *   — FCNMaskHead.conv_logits (fcn_mask_head.py:82,101) restricted to the channel that
+ *   mask_cross_entropy (cross_entropy_loss.py:54-61) / get_seg_masks (:162-165) read.
+ *   feat [P, pixels, C] NHWC float (C % 4 == 0), weight [num_classes, C], bias or NULL.
+ *
+ * bgs_mask_bce: the same single-channel conv fused with binary_cross_entropy_with_logits and
+ *   its backward.  partial_out [bgs_mask_bce_partials(P)] per-workgroup loss sums (the loss is
+ *   norm * sum(partials)); norm [1] device float = 1 / (#valid RoIs * pixels) (the 'mean'
+ *   reduction); dfeat [P,pixels,C] / dweight [num_classes,C] / dbias [num_classes] or NULL —
+ *   dweight/dbias are ACCUMULATED INTO with fp32 atomics (zero them first).
+ * ---------------------------------------------------------------------------------- */
+int bgs_mask_target(const uint8_t* const* host_masks, const int* host_num_gt, int num_images,
+                    int mask_h, int mask_w, const float* rois, int roi_stride, const int* gt_inds,
+                    const uint8_t* valid, int P, int mask_size, float* out, bgs_stream_t stream);
+int bgs_mask_gt_logits(const float* feat, const float* weight, const float* bias,
+                       const long long* labels, int P, int pixels, int C, int num_classes,
+                       float* logits_out, bgs_stream_t stream);
+int bgs_mask_bce_partials(int P);
+int bgs_mask_bce(const float* feat, const float* weight, const float* bias, const long long* labels,
+                 const float* target, const uint8_t* valid, const float* norm, int P, int pixels,
+                 int C, int num_classes, float* partial_out, float* dfeat, float* dweight,
+                 float* dbias, bgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
