@@ -163,6 +163,11 @@ class TwoStageDetector(nn.Module):
             if proposal_cfg is None:
                 proposal_cfg = self.test_cfg.rpn
             proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_meta, proposal_cfg)
+            # the head's stash of its own outputs carries this iteration's autograd graph when
+            # the trunk trains (selectp=0): drop it, or the graph (and its AccumulateGrad nodes,
+            # bound to the stream they were created on) would outlive the iteration
+            self.rpn_head._fused = None
+            del cls_scores, bbox_preds
         else:
             proposal_list = [(p, torch.ones(p.size(0), dtype=torch.bool, device=p.device))
                              for p in proposals]

@@ -24,6 +24,13 @@ def _workspace(nbytes, device):
     return buf
 
 
+def reset_workspaces():
+    """Drop every cached scratch buffer.  Call before capturing a NEW hipGraph in a process that
+    already captured one: a buffer handed out during an earlier capture lives in that graph's
+    private memory pool and must not be baked into another graph."""
+    _WS.clear()
+
+
 def _require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

@@ -45,6 +45,10 @@ def parse():
     ap.add_argument('--selectp', type=int, default=1, choices=[0, 1],
                     help='1 (as shipped): train bbox_head.fc_cls only; 0: train everything '
                          '(tools/train.py:49-57)')
+    ap.add_argument('--mask', action='store_true',
+                    help='cfg[3]: add the Mask R-CNN branch (gs_mask_rcnn_r50_fpn_1x_lvis)')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the secondary measurements (selectp=0, Mask R-CNN) of the N=1 run')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches, not hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -167,7 +171,7 @@ class DetectorStep(object):
     """One training iteration of cfg[1] as shipped (selectp=1: full forward, backward through
     fc_cls, gradient all-reduce, clip, SGD) on synthetic 800x1344 inputs, 512 RoIs/img."""
 
-    def __init__(self, dev, rank, world, imgs, selectp=1):
+    def __init__(self, dev, rank, world, imgs, selectp=1, mask=False):
         import tempfile
         import balancedgroupsoftmax_amd as bgs
         from balancedgroupsoftmax_amd import train
@@ -176,6 +180,17 @@ class DetectorStep(object):
         torch.manual_seed(0)                      # identical weights on every rank
         tmp = tempfile.mkdtemp(prefix='bgs_tables_')
         model_cfg, train_cfg = detector_cfg(tmp)
+        if mask:        # cfg[3] = configs/bags/gs_mask_rcnn_r50_fpn_1x_lvis.py
+            model_cfg['type'] = 'MaskRCNN'
+            model_cfg['mask_roi_extractor'] = dict(
+                type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', out_size=14, sample_num=2),
+                out_channels=256, featmap_strides=[4, 8, 16, 32])
+            model_cfg['mask_head'] = dict(
+                type='FCNMaskHead', num_convs=4, in_channels=256, conv_out_channels=256,
+                num_classes=NUM_CLASSES,
+                loss_mask=dict(type='CrossEntropyLoss', use_mask=True, loss_weight=1.0))
+            train_cfg['rcnn']['mask_size'] = 28
+        self.mask = mask
         self.model = bgs.build_detector(to_config_dict(model_cfg),
                                         train_cfg=to_config_dict(train_cfg), test_cfg=None).to(dev)
         self.selectp = selectp
@@ -196,12 +211,23 @@ class DetectorStep(object):
             xy = torch.rand(20, 2, generator=g) * (torch.tensor([1333., 800.]) - wh).clamp(min=1)
             self.gt_bboxes.append(torch.cat([xy, (xy + wh)], 1).to(dev))
             self.gt_labels.append(torch.randint(1, NUM_CLASSES, (20,), generator=g).to(dev))
+        self.gt_masks = None
+        if mask:          # an axis-aligned ellipse inside every GT box (SURVEY.md §8d cfg 4)
+            self.gt_masks = []
+            yy = torch.arange(H, device=dev).view(1, H, 1).float()
+            xx = torch.arange(W, device=dev).view(1, 1, W).float()
+            for b in self.gt_bboxes:
+                cx, cy = ((b[:, 0] + b[:, 2]) / 2).view(-1, 1, 1), ((b[:, 1] + b[:, 3]) / 2).view(-1, 1, 1)
+                rx = ((b[:, 2] - b[:, 0]) / 2).clamp(min=1).view(-1, 1, 1)
+                ry = ((b[:, 3] - b[:, 1]) / 2).clamp(min=1).view(-1, 1, 1)
+                self.gt_masks.append(((((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2) <= 1.0)
+                                     .to(torch.uint8).contiguous())
         self.last = None
 
     def compute(self):
         """forward + losses + backward: free of host synchronisation -> hipGraph-capturable."""
         losses = self.model(self.img, self.metas, return_loss=True, gt_bboxes=self.gt_bboxes,
-                            gt_labels=self.gt_labels)
+                            gt_labels=self.gt_labels, gt_masks=self.gt_masks)
         loss, log_vars = self.train.parse_losses(losses)
         self.step_fn.optimizer.zero_grad(set_to_none=False)
         loss.backward()
@@ -278,6 +304,8 @@ def try_graph(step):
                 step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        from balancedgroupsoftmax_amd import functional as BF
+        BF.reset_workspaces()      # scratch buffers of an earlier capture belong to ITS pool
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             step()
@@ -374,8 +402,37 @@ def cpu_baseline(n, seconds):
                        % (cnt, n, nt, torch.__version__))
 
 
+def extras(dev, args):
+    """Secondary single-GPU measurements of the same step in the other §8 configurations (not the
+    headline value): selectp=0 (train everything but the frozen stem+layer1) and the Mask R-CNN
+    config (cfg[3], selectp=1).  Failures here never hide the headline number."""
+    res = {}
+    for key, kw in (('selectp0', dict(selectp=0)), ('mask_rcnn_selectp1', dict(selectp=1, mask=True)),
+                    ('mask_rcnn_selectp0', dict(selectp=0, mask=True))):
+        try:
+            sys.stderr.write('extras: %s\n' % key)
+            sys.stderr.flush()
+            st = DetectorStep(dev, 0, 1, args.imgs, **kw)
+            g = None if args.no_graph else try_graph(st.compute)
+            if g is not None:
+                def fn(g=g, st=st):
+                    g.replay()
+                    st.apply()
+            else:
+                fn = st
+            dt = timed_loop(fn, 10, 3, 1)
+            res[key] = {'img_per_s': round(args.imgs * 10 / dt, 2), 'ms_per_step': round(dt * 100, 3),
+                        'trainable_params': int(sum(p.numel() for p in st.params)),
+                        'loss': round(float(st.last['loss']), 4)}
+            del st, g, fn
+            torch.cuda.empty_cache()
+        except Exception as e:  # pragma: no cover
+            res[key] = {'error': repr(e)[:200]}
+    return res
+
+
 def main_detector(args, rank, local, world, dev):
-    step = DetectorStep(dev, rank, world, args.imgs, args.selectp)
+    step = DetectorStep(dev, rank, world, args.imgs, args.selectp, args.mask)
     # The iteration is free of host synchronisation by construction, so the whole step
     # (forward, losses, backward, all-reduce, clip, SGD: ~1600 launches) is captured into one
     # hipGraph; eager launches are the fallback (and --no-graph).
@@ -409,7 +466,7 @@ def main_detector(args, rank, local, world, dev):
                                       ('with selectp=0 (train everything but the frozen stem + '
                                        'layer1: full forward and full backward through heads, '
                                        'RoIAlign, RPN, FPN, ResNet layer2-4'), args.imgs),
-                       'selectp': args.selectp,
+                       'selectp': args.selectp, 'mask_branch': bool(args.mask),
                        'trainable_params': int(sum(p.numel() for p in step.params)),
                        'imgs_per_gpu': args.imgs, 'rois_per_img': 512,
                        'launch': ('hipGraph replay of forward+losses+backward, then eager '
@@ -423,6 +480,8 @@ def main_detector(args, rank, local, world, dev):
         if graph is not None and world == 1:
             dte = timed_loop(step, 5, 2, 1)
             out['ms_per_step_eager'] = round(dte * 1e3 / 5, 3)
+        if world == 1 and not args.no_extras and args.selectp == 1 and not args.mask:
+            out['also_measured'] = extras(dev, args)
         out['roofline'] = conv_roofline(dev)
         gs_inp = make_inputs(1024, seed=1000, dev=dev)
         out['roofline_gs_loss'] = kernel_roofline(gs_inp, 1024)
