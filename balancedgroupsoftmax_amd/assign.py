@@ -75,6 +75,12 @@ def max_iou_assign(overlaps, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, gt_max_a
 
 
 def _random_keys(n, device, generator=None):
+    """62-bit random integer keys.  On the GPU without an explicit generator: the counter-based
+    device RNG of the C ABI (``bgs_random_keys``) — one launch, hipGraph-replayable; with a
+    generator (reproducible tests) or on the CPU: ``torch.randint``."""
+    if generator is None and torch.device(device).type == 'cuda':
+        from . import functional as BF
+        return BF.random_keys(n, device)
     return torch.randint(0, _KEY_MAX, (n,), device=device, dtype=torch.int64,
                          generator=generator)
 

@@ -550,6 +550,33 @@ extern "C" int bgs_rpn_loss(const float* const* host_level_outs, const int* host
   BGS_RETURN_LAUNCH_STATUS();
 }
 
+// Counter-based 62-bit sampling keys: out[i] = splitmix64(seed, draw, i) >> 2.  `draw` is a device
+// counter the caller bumps with a tensor op per call, so the kernel arguments stay constant under
+// hipGraph replay while every replay draws fresh keys (RandomSampler's shuffle,
+// mmdet/core/bbox/samplers/random_sampler.py:19-33, as a top-k over random keys: assign.py).
+__global__ __launch_bounds__(256) void random_keys_kernel(uint64_t seed,
+                                                          const long long* __restrict__ draw, int n,
+                                                          long long* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t d = draw ? (uint64_t)draw[0] : 0ull;
+  uint64_t x = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)i + 1ull) + 0xD1B54A32D192ED03ull * (d + 1ull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  out[i] = (long long)(x >> 2);
+}
+
+extern "C" int bgs_random_keys(uint64_t seed, const long long* draw_counter, int n, long long* out,
+                               bgs_stream_t stream) {
+  if (n < 0) return BGS_ERR_INVALID_ARG;
+  if (n == 0) return BGS_OK;
+  if (!out) return BGS_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(random_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     seed, draw_counter, n, out);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int bgs_rpn_loss_grad(const float* const* host_level_outs,
                                  float* const* host_level_douts, const int* host_level_hw, int L,
                                  int num_anchors, const float* anchors, const int* assigned,

@@ -719,6 +719,28 @@ def rpn_loss(level_outs, num_anchors, anchors, assigned, pos_mask, neg_mask, gt_
                             gt_cat, *args[1:])
 
 
+_KEY_COUNTERS = {}
+
+
+def random_keys(n, device):
+    """``[n]`` int64 sampling keys in ``[0, 2^62)`` from the counter-based device RNG
+    (``bgs_random_keys``).  A per-device draw counter is advanced with a tensor op per call, so
+    the launch is hipGraph-replayable and still draws fresh keys every replay."""
+    lib = capi.load()
+    device = torch.device(device)
+    ctr = _KEY_COUNTERS.get(device.index)
+    if ctr is None:
+        ctr = torch.zeros(1, dtype=torch.int64, device=device)
+        _KEY_COUNTERS[device.index] = ctr
+    ctr.add_(1)
+    out = torch.empty((n,), dtype=torch.int64, device=device)
+    seed = (torch.initial_seed() * 0x9E3779B1 + 0x5851F42D) & 0xFFFFFFFFFFFFFFFF
+    rc = lib.bgs_random_keys(seed, capi.ptr(ctr), int(n), capi.ptr(out),
+                             capi.current_stream(device))
+    capi.check('bgs_random_keys', rc)
+    return out
+
+
 def decode_proposals(level_outs, level_counts, num_anchors, anchors, top_idx, top_logit, img_hw,
                      means, stds, wh_ratio_clip=16 / 1000):
     """``[N,L,nmax,5]`` decoded + clamped proposals (score = sigmoid of the top logit)."""

@@ -413,13 +413,8 @@ def extras(dev, args):
             sys.stderr.write('extras: %s\n' % key)
             sys.stderr.flush()
             st = DetectorStep(dev, 0, 1, args.imgs, **kw)
-            g = None if args.no_graph else try_graph(st.compute)
-            if g is not None:
-                def fn(g=g, st=st):
-                    g.replay()
-                    st.apply()
-            else:
-                fn = st
+            g = None if args.no_graph else try_graph(st)
+            fn = g.replay if g is not None else st
             dt = timed_loop(fn, 10, 3, 1)
             res[key] = {'img_per_s': round(args.imgs * 10 / dt, 2), 'ms_per_step': round(dt * 100, 3),
                         'trainable_params': int(sum(p.numel() for p in st.params)),
@@ -433,16 +428,19 @@ def extras(dev, args):
 
 def main_detector(args, rank, local, world, dev):
     step = DetectorStep(dev, rank, world, args.imgs, args.selectp, args.mask)
-    # The iteration is free of host synchronisation by construction, so the whole step
-    # (forward, losses, backward, all-reduce, clip, SGD: ~1600 launches) is captured into one
-    # hipGraph; eager launches are the fallback (and --no-graph).
-    graph = None if args.no_graph else try_graph(step.compute)
-    if graph is not None:
-        def fn():
-            graph.replay()
-            step.apply()
-    else:
-        fn = step
+    # Launch policy.  The iteration is free of host synchronisation, so on ONE GPU the whole
+    # step (forward, losses, backward, clip, SGD: ~560 launches) is captured into a single
+    # hipGraph and replayed.  The graph must own the ENTIRE step: on ROCm 7.2 a large graph whose
+    # replays are interleaved with eager launches (an eager optimizer step, or the host-side
+    # philox bookkeeping of torch.randint inside a captured region) faults after a few dozen
+    # replays (tools/debug/two_graphs.py reproduces it: "variants plain" vs "variants whole";
+    # DESIGN.md §5).  With N > 1 the gradient all-reduce (RCCL) sits between backward and the
+    # optimizer, so multi-GPU runs launch eagerly — the step is GPU-bound and eager launches
+    # cost < 1 % (14.08 vs 13.98 ms).
+    graph = None
+    if world == 1 and not args.no_graph:
+        graph = try_graph(step)
+    fn = graph.replay if graph is not None else step
     dt = timed_loop(fn, args.steps, args.warmup, world)
     ms_per_step = dt * 1e3 / args.steps
     imgs_per_s = args.imgs * world * args.steps / dt
@@ -469,8 +467,8 @@ def main_detector(args, rank, local, world, dev):
                        'selectp': args.selectp, 'mask_branch': bool(args.mask),
                        'trainable_params': int(sum(p.numel() for p in step.params)),
                        'imgs_per_gpu': args.imgs, 'rois_per_img': 512,
-                       'launch': ('hipGraph replay of forward+losses+backward, then eager '
-                                  'all-reduce/clip/SGD') if graph else 'eager',
+                       'launch': ('hipGraph replay of the whole step (forward+losses+backward+'
+                                  'clip+SGD)') if graph else 'eager launches',
                        'parallelism': 'dp%d (one process per GPU; flat fp32 all-reduce of the '
                                       '%d trainable grads over RCCL)'
                                       % (world, sum(p.numel() for p in step.params))},
@@ -508,13 +506,8 @@ def main():
     n = args.rois
     inp = make_inputs(n, seed=1000 + rank, dev=dev)
     step = GsHeadStep(inp)
-    graph = None if args.no_graph else try_graph(step.compute)
-    if graph is not None:
-        def fn():
-            graph.replay()
-            step.apply()
-    else:
-        fn = step
+    graph = None if args.no_graph else try_graph(step)
+    fn = graph.replay if graph is not None else step
     dt = timed_loop(fn, args.steps, args.warmup, world)
     ms_per_step = dt * 1e3 / args.steps
     us_per_roi = dt * 1e6 / (args.steps * n * world)

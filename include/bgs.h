@@ -277,6 +277,13 @@ int bgs_rpn_loss(const float* const* host_level_outs, const int* host_level_hw, 
                  float loss_weight_bbox, float* loss_cls_out, float* loss_bbox_out,
                  float* num_total_out, void* workspace, bgs_stream_t stream);
 
+/* Sampling keys for RandomSampler (mmdet/core/bbox/samplers/random_sampler.py:19-53) drawn on the
+ *   device: out[i] = 62-bit splitmix64(seed, *draw_counter, i), i < n.  draw_counter: device int64
+ *   [1] (or NULL = 0) that the caller advances between draws — constant kernel arguments under
+ *   hipGraph replay, fresh keys every replay. */
+int bgs_random_keys(uint64_t seed, const long long* draw_counter, int n, long long* out,
+                    bgs_stream_t stream);
+
 /* Gradient of bgs_rpn_loss w.r.t. the fused head outputs (autograd of AnchorHead.loss_single,
  *   anchor_head.py:131-161; `selectp = 0` path).  host_level_douts [L] HOST array of device
  *   pointers to ZERO-FILLED maps shaped like the outputs; num_total = the normaliser written

@@ -544,7 +544,7 @@ def test_full_training_iteration_selectp0(tmp_path):
     # (zero_init_residual: bn3.weight = 0 at init, so conv1/conv2 of a block see zero gradients)
     for n in ('backbone.layer2.0.bn3.weight', 'backbone.layer2.0.downsample.0.weight',
               'backbone.layer4.2.bn3.bias',
-              'neck.lateral_convs.0.conv.weight', 'neck.fpn_convs.3.conv.bias',
+              'neck.lateral_convs.0.conv.weight', 'neck.fpn_convs.1.conv.bias',
               'rpn_head.rpn_conv.weight', 'rpn_head.rpn_reg.bias',
               'bbox_head.shared_fcs.0.weight', 'bbox_head.fc_reg.weight', 'bbox_head.fc_cls.bias'):
         gsum = float(dict(model.named_parameters())[n].grad.abs().sum())
