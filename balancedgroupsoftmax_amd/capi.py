@@ -50,6 +50,11 @@ SIGNATURES = {
                                                   ctypes.c_float, c_f32p, c_f32p, c_ptr, c_ptr]),
     'bgs_conv2d_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 11
                             + [c_ptr]),
+    'bgs_conv2d_workspace_bytes': (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int]),
+    'bgs_conv2d_nhwc_f32_ws': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]
+                               + [ctypes.c_int] * 11 + [c_ptr, ctypes.c_size_t, c_ptr]),
+    'bgs_conv2d_dgrad_nhwc_f32_ws': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]
+                                     + [ctypes.c_int] * 10 + [c_ptr, ctypes.c_size_t, c_ptr]),
     'bgs_conv2d_dgrad_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]
                                   + [ctypes.c_int] * 10 + [c_ptr]),
     'bgs_conv2d_wgrad_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 9),

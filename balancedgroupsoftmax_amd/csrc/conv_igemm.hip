@@ -49,6 +49,11 @@ struct ConvArgs {
   int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
   int M, K;           // M = N*Ho*Wo, K = R*S*Cin
   int relu, res_mode;
+  // split-K (small-M layers expose too few workgroups to fill 256 CUs): gridDim.z slices of
+  // `kt_per_split` K tiles each write raw partial sums to partial[z][M][Cout]; the epilogue
+  // (bias / residual / ReLU / mask) then runs in conv_splitk_epilogue_kernel.
+  float* partial;
+  int kt_per_split;
 };
 
 // UP = 1: plain convolution.  UP = 2: the input is read as if it had been zero-upsampled by 2
@@ -98,7 +103,10 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
     b_base[q] = p.w + (size_t)(b_ok[q] ? j : 0) * p.K;
   }
   // (r, s, c) of this thread's k-quad, advanced incrementally from tile to tile
-  int kg = kq * 4;
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kt_begin = p.partial ? blockIdx.z * p.kt_per_split : 0;
+  const int kt_end = p.partial ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
+  int kg = kt_begin * BK + kq * 4;
   int kc, kr, ks;
   {
     const int rs = kg / p.Cin;
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int nk = (p.K + BK - 1) / BK;
+  const int nk = kt_end - kt_begin;
   load_tile();
   store_tile(0);
   __syncthreads();
@@ -201,6 +209,23 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (p.partial) {
+    float* part = p.partial + (size_t)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m0 + wm * 32 * MB + a * 32 + i;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int j = n0 + wn * 32 * NB + b * 32 + (lane & 31);
+          if (j < p.Cout) part[(size_t)m * p.Cout + j] = acc[a][b][r];
+        }
+      }
+    return;
+  }
   const int hw = p.Ho * p.Wo;
 #pragma unroll
   for (int a = 0; a < MB; ++a) {
@@ -241,6 +266,37 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
         p.y[(size_t)m * p.Cout + j] = v;
       }
     }
+  }
+}
+
+// y[m][j] = epilogue( sum_z partial[z][m][j] ): fixed summation order (bitwise reproducible).
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs p, int splits) {
+  const size_t total = (size_t)p.M * p.Cout;
+  const int hw = p.Ho * p.Wo;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * 256) {
+    const int m = (int)(e / p.Cout);
+    const int j = (int)(e - (size_t)m * p.Cout);
+    float v = p.partial[e];
+    for (int z = 1; z < splits; ++z) v += p.partial[(size_t)z * total + e];
+    if (p.bias) v += p.bias[j];
+    if (p.res_mode == 1) {
+      v += p.res[e];
+    } else if (p.res_mode == 2 || p.res_mode == 3) {
+      const int n = m / hw;
+      const int rem = m - n * hw;
+      const int ho = rem / p.Wo, wo = rem - (rem / p.Wo) * p.Wo;
+      if (p.res_mode == 2) {
+        v += p.res[(((size_t)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + j];
+      } else {
+        const size_t r0 = (((size_t)n * (p.Ho * 2) + ho * 2) * (p.Wo * 2) + wo * 2) * p.Cout + j;
+        const size_t down = (size_t)p.Wo * 2 * p.Cout;
+        v += (p.res[r0] + p.res[r0 + p.Cout]) + (p.res[r0 + down] + p.res[r0 + down + p.Cout]);
+      }
+    }
+    if (p.relu) v = fmaxf(v, 0.f);
+    if (p.mask) v = p.mask[e] > 0.f ? v : 0.f;
+    p.y[e] = v;
   }
 }
 
@@ -287,7 +343,8 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const float* __r
 // only pays for the two huge-M, deep-K 3x3 convs on the stride-4 maps; everywhere else the 64x64
 // tile wins or ties because it exposes 4x more workgroups; thin outputs (Cout <= 64) with a huge
 // M use 128x64.  K tile: 32 for deep reductions with the 64x64 tile (+5-15 % on K >= 512).
-static int launch_conv(ConvArgs& p, int up, hipStream_t st) {
+static int launch_conv(ConvArgs& p, int up, hipStream_t st, void* workspace = nullptr,
+                       size_t workspace_bytes = 0) {
   const long long M = p.M;
   int force = 0;  // tuning hook: BGS_CONV_TILE=22|21|11 forces a tile configuration
   if (const char* e = getenv("BGS_CONV_TILE")) force = atoi(e);
@@ -297,11 +354,38 @@ static int launch_conv(ConvArgs& p, int up, hipStream_t st) {
   if (force == 22 || force == 21 || force == 11) tile = force;
   int bk = (p.K >= 512 && tile == 11) ? 32 : 16;
   if (const char* e = getenv("BGS_CONV_BK")) bk = atoi(e) == 32 ? 32 : (atoi(e) == 16 ? 16 : bk);
+  // split-K: only for the 64x64 tile when the grid cannot fill the chip (< ~2 workgroups per CU)
+  // and the reduction is deep enough to share out (>= 8 K tiles per slice)
+  int splits = 1;
+  p.partial = nullptr;
+  p.kt_per_split = 0;
+  if (tile == 11 && workspace) {
+    const long long wgs = ((M + 63) / 64) * ((p.Cout + 63) / 64);
+    const int nk = (p.K + bk - 1) / bk;
+    // measured on the cfg[1] shapes (profiles/r1z_splitk_sweep*.txt): < 600 workgroups: aim at
+    // ~1100 (l4.c2 49 -> 80, fpn.out3 34 -> 56, fc1 70 -> 93 TFLOP/s); 600..1500: 2 slices (+5 %)
+    int want = 1;
+    if (wgs < 600) want = (int)((1100 + wgs - 1) / wgs);
+    else if (wgs < 1500) want = 2;
+    if (want > nk / 8) want = nk / 8;
+    if (want > 8) want = 8;
+    if (const char* e = getenv("BGS_CONV_SPLITK")) {
+      const int f = atoi(e);
+      if (f >= 1 && f <= 16) want = f < nk ? f : nk;
+    }
+    while (want > 1 && (size_t)want * (size_t)M * p.Cout * sizeof(float) > workspace_bytes) --want;
+    if (want > 1) {
+      p.kt_per_split = (nk + want - 1) / want;
+      splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
+      p.partial = reinterpret_cast<float*>(workspace);
+    }
+  }
 #define BGS_CONV_LAUNCH2(MB_, NB_, BK_, UP_)                                                     \
   hipLaunchKernelGGL((conv_igemm_f32_kernel<MB_, NB_, BK_, UP_>), grid, dim3(kThreads), 0, st, p)
 #define BGS_CONV_LAUNCH(MB_, NB_, BM_, BN_)                                                      \
   do {                                                                                           \
-    dim3 grid((unsigned)((M + BM_ - 1) / BM_), (unsigned)((p.Cout + BN_ - 1) / BN_));            \
+    dim3 grid((unsigned)((M + BM_ - 1) / BM_), (unsigned)((p.Cout + BN_ - 1) / BN_),             \
+              (unsigned)splits);                                                                 \
     if (up == 2) {                                                                               \
       if (bk == 32) BGS_CONV_LAUNCH2(MB_, NB_, 32, 2);                                           \
       else BGS_CONV_LAUNCH2(MB_, NB_, 16, 2);                                                    \
@@ -315,13 +399,43 @@ static int launch_conv(ConvArgs& p, int up, hipStream_t st) {
   else BGS_CONV_LAUNCH(1, 1, 64, 64);
 #undef BGS_CONV_LAUNCH
 #undef BGS_CONV_LAUNCH2
+  if (splits > 1) {
+    if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
+    const size_t total = (size_t)p.M * p.Cout;
+    size_t g = (total + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)g), dim3(256), 0, st, p, splits);
+  }
   BGS_RETURN_LAUNCH_STATUS();
 }
+
+// Scratch for the split-K path of the two entry points below (0 is always legal: no split).
+extern "C" size_t bgs_conv2d_workspace_bytes(long long M, int Cout) {
+  if (M <= 0 || Cout <= 0) return 0;
+  const long long wgs = ((M + 63) / 64) * ((Cout + 63) / 64);
+  if (wgs >= 1500) return 0;
+  return (size_t)(wgs < 600 ? 8 : 2) * (size_t)M * Cout * sizeof(float);
+}
+
+extern "C" int bgs_conv2d_nhwc_f32_ws(const float* x, const float* w, const float* bias,
+                                      const float* residual, float* y, int N, int H, int W,
+                                      int Cin, int Cout, int R, int S, int stride, int pad,
+                                      int relu, int residual_mode, void* workspace,
+                                      size_t workspace_bytes, bgs_stream_t stream);
 
 extern "C" int bgs_conv2d_nhwc_f32(const float* x, const float* w, const float* bias,
                                    const float* residual, float* y, int N, int H, int W, int Cin,
                                    int Cout, int R, int S, int stride, int pad, int relu,
                                    int residual_mode, bgs_stream_t stream) {
+  return bgs_conv2d_nhwc_f32_ws(x, w, bias, residual, y, N, H, W, Cin, Cout, R, S, stride, pad,
+                                relu, residual_mode, nullptr, 0, stream);
+}
+
+extern "C" int bgs_conv2d_nhwc_f32_ws(const float* x, const float* w, const float* bias,
+                                      const float* residual, float* y, int N, int H, int W,
+                                      int Cin, int Cout, int R, int S, int stride, int pad,
+                                      int relu, int residual_mode, void* workspace,
+                                      size_t workspace_bytes, bgs_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
       pad < 0)
     return BGS_ERR_INVALID_ARG;
@@ -344,7 +458,7 @@ extern "C" int bgs_conv2d_nhwc_f32(const float* x, const float* w, const float* 
   p.K = R * S * Cin;
   p.relu = relu;
   p.res_mode = residual_mode;
-  return launch_conv(p, 1, (hipStream_t)stream);
+  return launch_conv(p, 1, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
 // Data gradient of bgs_conv2d_nhwc_f32: dx[n,h,w,ci] = sum_{r,s,co} dy[n,ho,wo,co] W[co,r,s,ci]
@@ -354,10 +468,25 @@ extern "C" int bgs_conv2d_nhwc_f32(const float* x, const float* w, const float* 
 // R-1-pad, unit stride, output H x W x Cin.  Epilogue: + residual (mode 1 same shape; mode 3 =
 // 2x2 sum-pool of a twice-as-large map: the backward of the FPN nearest-2x top-down add), then
 // the ReLU-backward mask of the tensor that fed the forward conv.
+extern "C" int bgs_conv2d_dgrad_nhwc_f32_ws(const float* dy, const float* wt,
+                                            const float* residual, const float* mask, float* dx,
+                                            int N, int H, int W, int Cin, int Cout, int R, int S,
+                                            int stride, int pad, int residual_mode, void* workspace,
+                                            size_t workspace_bytes, bgs_stream_t stream);
+
 extern "C" int bgs_conv2d_dgrad_nhwc_f32(const float* dy, const float* wt, const float* residual,
                                          const float* mask, float* dx, int N, int H, int W,
                                          int Cin, int Cout, int R, int S, int stride, int pad,
                                          int residual_mode, bgs_stream_t stream) {
+  return bgs_conv2d_dgrad_nhwc_f32_ws(dy, wt, residual, mask, dx, N, H, W, Cin, Cout, R, S, stride,
+                                      pad, residual_mode, nullptr, 0, stream);
+}
+
+extern "C" int bgs_conv2d_dgrad_nhwc_f32_ws(const float* dy, const float* wt,
+                                            const float* residual, const float* mask, float* dx,
+                                            int N, int H, int W, int Cin, int Cout, int R, int S,
+                                            int stride, int pad, int residual_mode, void* workspace,
+                                            size_t workspace_bytes, bgs_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || pad < 0)
     return BGS_ERR_INVALID_ARG;
   if (!dy || !wt || !dx) return BGS_ERR_INVALID_ARG;
@@ -382,7 +511,7 @@ extern "C" int bgs_conv2d_dgrad_nhwc_f32(const float* dy, const float* wt, const
   p.K = R * S * Cout;
   p.relu = 0;
   p.res_mode = residual_mode;
-  return launch_conv(p, stride, (hipStream_t)stream);
+  return launch_conv(p, stride, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
 extern "C" int bgs_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C,

@@ -260,11 +260,13 @@ def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None
         assert tuple(residual.shape) == exp and residual.is_contiguous(), (residual.shape, exp)
     if out is None:
         out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-    rc = lib.bgs_conv2d_nhwc_f32(capi.ptr(x), capi.ptr(w_krsc), capi.ptr(bias),
-                                 capi.ptr(residual), capi.ptr(out), N, H, W, Cin, Cout, R, S,
-                                 stride, pad, int(bool(relu)), residual_mode,
-                                 capi.current_stream(x.device))
-    capi.check('bgs_conv2d_nhwc_f32', rc)
+    wsb = lib.bgs_conv2d_workspace_bytes(N * Ho * Wo, Cout)      # split-K scratch (small-M layers)
+    ws = _workspace(wsb, x.device) if wsb else None
+    rc = lib.bgs_conv2d_nhwc_f32_ws(capi.ptr(x), capi.ptr(w_krsc), capi.ptr(bias),
+                                    capi.ptr(residual), capi.ptr(out), N, H, W, Cin, Cout, R, S,
+                                    stride, pad, int(bool(relu)), residual_mode, capi.ptr(ws),
+                                    wsb, capi.current_stream(x.device))
+    capi.check('bgs_conv2d_nhwc_f32_ws', rc)
     return out
 
 
@@ -303,10 +305,13 @@ def conv2d_dgrad_nhwc(dy, w_krsc, in_hw, stride=1, pad=0, residual=None, residua
     if mask is not None:
         assert tuple(mask.shape) == (N, H, W, Cin) and mask.is_contiguous()
     dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dy.device)
-    rc = lib.bgs_conv2d_dgrad_nhwc_f32(capi.ptr(dy), capi.ptr(wt), capi.ptr(residual),
-                                       capi.ptr(mask), capi.ptr(dx), N, H, W, Cin, Cout, R, S,
-                                       stride, pad, residual_mode, capi.current_stream(dy.device))
-    capi.check('bgs_conv2d_dgrad_nhwc_f32', rc)
+    wsb = lib.bgs_conv2d_workspace_bytes(N * H * W, Cin)
+    ws = _workspace(wsb, dy.device) if wsb else None
+    rc = lib.bgs_conv2d_dgrad_nhwc_f32_ws(capi.ptr(dy), capi.ptr(wt), capi.ptr(residual),
+                                          capi.ptr(mask), capi.ptr(dx), N, H, W, Cin, Cout, R, S,
+                                          stride, pad, residual_mode, capi.ptr(ws), wsb,
+                                          capi.current_stream(dy.device))
+    capi.check('bgs_conv2d_dgrad_nhwc_f32_ws', rc)
     return dx
 
 

@@ -154,6 +154,22 @@ int bgs_conv2d_nhwc_f32(const float* x, const float* w, const float* bias, const
                         float* y, int N, int H, int W, int Cin, int Cout, int R, int S,
                         int stride, int pad, int relu, int residual_mode, bgs_stream_t stream);
 
+/* Same two operations with a caller-provided scratch buffer, which enables the split-K path for
+ * layers whose output is too small to fill the 256 CUs (M*Cout/4096 < ~600 workgroups: ResNet
+ * layer3/4, the top FPN/RPN levels, the FC heads): gridDim.z slices of the reduction write raw
+ * partial sums to the scratch, a second launch sums them in a fixed order and applies the
+ * epilogue.  workspace may be NULL / 0 bytes (no split); bgs_conv2d_workspace_bytes(M, Cout) with
+ * M = N*Ho*Wo (output pixels; for the data gradient N*H*W and Cin) is always sufficient. */
+size_t bgs_conv2d_workspace_bytes(long long M, int Cout);
+int bgs_conv2d_nhwc_f32_ws(const float* x, const float* w, const float* bias, const float* residual,
+                           float* y, int N, int H, int W, int Cin, int Cout, int R, int S,
+                           int stride, int pad, int relu, int residual_mode, void* workspace,
+                           size_t workspace_bytes, bgs_stream_t stream);
+int bgs_conv2d_dgrad_nhwc_f32_ws(const float* dy, const float* wt, const float* residual,
+                                 const float* mask, float* dx, int N, int H, int W, int Cin,
+                                 int Cout, int R, int S, int stride, int pad, int residual_mode,
+                                 void* workspace, size_t workspace_bytes, bgs_stream_t stream);
+
 /* Backward of bgs_conv2d_nhwc_f32 for the `selectp = 0` mode (train everything; the reference
  * gets these from cuDNN backward-data / backward-filter through autograd of the nn.Conv2d /
  * nn.Linear call sites listed above; tools/train.py:49-57 selects what trains).

@@ -346,3 +346,34 @@ def test_roi_align_autograd_accumulates_into_feature_grads():
         idx = np.nonzero(lv == i)[0]
         exp = det_oracle.roi_align_backward(ones[idx], rois[idx], 1.0 / s, feats[i].shape, 2)
         assert np.abs(ft[i].grad.cpu().numpy() - exp).max() <= 1e-4 * max(1.0, np.abs(exp).max())
+
+
+def test_conv_split_k_matches_single_pass(monkeypatch):
+    """Split-K (small-M layers) == the single-pass kernel for every epilogue: bias+ReLU, same-shape
+    and upsampled residuals (forward), sum-pooled residual + ReLU mask (data gradient)."""
+    rs = np.random.RandomState(9)
+    N, H, W, Cin, Cout = 2, 10, 14, 512, 128                  # 5 x 2 workgroups, 16..144 K tiles
+    x = dev(rs.randn(N, H, W, Cin).astype(np.float32))
+    w = dev((rs.randn(Cout, 3, 3, Cin) * 0.02).astype(np.float32))
+    b = dev(rs.randn(Cout).astype(np.float32))
+    res1 = dev(rs.randn(N, H, W, Cout).astype(np.float32))
+    res2 = dev(rs.randn(N, H // 2, W // 2, Cout).astype(np.float32))
+    dy = dev(rs.randn(N, H, W, Cout).astype(np.float32))
+    res3 = dev(rs.randn(N, 2 * H, 2 * W, Cin).astype(np.float32))
+    mask = dev(rs.randn(N, H, W, Cin).astype(np.float32))
+
+    def run():
+        return [BF.conv2d_nhwc(x, w, b, pad=1, relu=True),
+                BF.conv2d_nhwc(x, w, b, pad=1, residual=res1),
+                BF.conv2d_nhwc(x, w, None, pad=1, residual=res2, residual_mode=2),
+                BF.conv2d_dgrad_nhwc(dy, w, (H, W), 1, 1, residual=res3, residual_mode=3, mask=mask),
+                BF.conv2d_dgrad_nhwc(dy, w, (H, W), 1, 1, residual=mask, mask=mask)]
+    monkeypatch.setenv('BGS_CONV_SPLITK', '1')
+    ref = run()
+    for f in ('2', '5', '8'):
+        monkeypatch.setenv('BGS_CONV_SPLITK', f)
+        for a, e in zip(run(), ref):
+            assert float((a - e).abs().max()) <= 2e-5 * float(e.abs().max())
+    monkeypatch.delenv('BGS_CONV_SPLITK')
+    for a, e in zip(run(), ref):                              # the library's own choice
+        assert float((a - e).abs().max()) <= 2e-5 * float(e.abs().max())
