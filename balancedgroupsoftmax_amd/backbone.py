@@ -91,13 +91,16 @@ def _check_frozen(module, what):
 class Bottleneck(nn.Module):
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride=1, downsample=False):
+    def __init__(self, inplanes, planes, stride=1, downsample=False, groups=1, base_width=4):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        # ResNeXt (resnext.py:19-22): width = floor(planes * base_width / 64) * groups
+        width = planes if groups == 1 else (planes * base_width // 64) * groups
+        self.groups, self.width = groups, width
+        self.conv1 = nn.Conv2d(inplanes, width, 1, stride=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, groups=groups, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, planes * 4, 1, bias=False)
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.stride = stride
         self.downsample = None
@@ -123,6 +126,11 @@ class Bottleneck(nn.Module):
             identity = BF.conv2d_autograd(x, f['ds'][0], f['ds'][1], stride=self.stride)
         # conv1 -> conv2 -> conv3 is a chain of single consumers: the ReLU backward of o1 / o2
         # rides in the epilogue of the next conv's dgrad (relu='consumers' + mask_input)
+        if self.groups > 1:      # ResNeXt: grouped 3x3 (csrc/grouped_conv.hip), forward only
+            out = BF.conv2d_autograd(x, f['c1'][0], f['c1'][1], relu=True)
+            out = BF.grouped_conv3x3_nhwc(out, f['c2'][0], f['c2'][1], self.groups,
+                                          stride=self.stride, relu=True)
+            return BF.conv2d_autograd(out, f['c3'][0], f['c3'][1], relu=True, residual=identity)
         out = BF.conv2d_autograd(x, f['c1'][0], f['c1'][1], relu='consumers')
         out = BF.conv2d_autograd(out, f['c2'][0], f['c2'][1], stride=self.stride, pad=1,
                                  relu='consumers', mask_input=True)
@@ -140,7 +148,7 @@ class ResNet(nn.Module):
                  stage_with_dcn=(False, False, False, False), gcb=None,
                  stage_with_gcb=(False, False, False, False), gen_attention=None,
                  stage_with_gen_attention=((), (), (), ()), with_cp=False,
-                 zero_init_residual=True):
+                 zero_init_residual=True, groups=1, base_width=4):
         super().__init__()
         if depth not in self.arch_settings:
             raise KeyError('invalid depth {} for resnet (bottleneck depths only)'.format(depth))
@@ -163,7 +171,8 @@ class ResNet(nn.Module):
                 stride = strides[i] if j == 0 else 1
                 layers.append(Bottleneck(inplanes, planes, stride,
                                          downsample=(j == 0 and (stride != 1 or
-                                                                 inplanes != planes * 4))))
+                                                                 inplanes != planes * 4)),
+                                         groups=groups, base_width=base_width))
                 inplanes = planes * 4
             name = 'layer{}'.format(i + 1)
             self.add_module(name, nn.Sequential(*layers))
@@ -229,6 +238,17 @@ class ResNet(nn.Module):
                 if isinstance(m, nn.BatchNorm2d):
                     m.eval()
         return self
+
+
+@BACKBONES.register_module
+class ResNeXt(ResNet):
+    """mmdet/models/backbones/resnext.py:95-222: the ResNet layout with grouped 3x3 convs
+    (``groups=64, base_width=4`` = X101-64x4d in configs/bags/gs_cascade_rcnn_x101_64x4d_*.py).
+    Parameter names / shapes are the reference's; forward only on the grouped convs."""
+
+    def __init__(self, groups=1, base_width=4, **kwargs):
+        super().__init__(groups=groups, base_width=base_width, **kwargs)
+        self.groups, self.base_width = groups, base_width
 
 
 class ConvModule(nn.Module):

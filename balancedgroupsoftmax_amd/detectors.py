@@ -98,11 +98,14 @@ class TwoStageDetector(nn.Module):
         return dict(bboxes=boxes[inds], is_pos=is_pos, valid=valid, labels=labels,
                     gt_bboxes=gt_bboxes[gi])
 
-    def _sample_rois_fused(self, proposal_list, gt_bboxes, gt_labels, generator=None):
+    def _sample_rois_fused(self, proposal_list, gt_bboxes, gt_labels, generator=None, rc=None,
+                           head=None):
         """GPU path of two_stage.py:192-222: one batched assignment launch pair, the fixed-shape
-        sampler, and one kernel that emits rois / labels / box targets for all images."""
+        sampler, and one kernel that emits rois / labels / box targets for all images.
+        ``rc`` / ``head``: the stage's rcnn config and bbox head (cascade); defaults: the
+        detector's own."""
         from . import functional as BF
-        rc = self.train_cfg.rcnn
+        rc = self.train_cfg.rcnn if rc is None else rc
         ac, sc = rc.assigner, rc.sampler
         N = len(proposal_list)
         props = torch.stack([p for p, _ in proposal_list]).contiguous()            # [N, P, 5]
@@ -129,7 +132,13 @@ class TwoStageDetector(nn.Module):
         # gt index of every sampled RoI (pos_assigned_gt_inds for the mask targets), -1 = none
         self._sampled_gt_inds = torch.stack(
             [assigned_l[i].gather(0, inds_l[i]).to(torch.int32) - 1 for i in range(N)])
-        head = self.bbox_head
+        # which sampled RoIs are GT boxes added as proposals (SamplingResult.pos_is_gt), and
+        # which slots are real (fewer candidates than `num` leaves padding slots)
+        self._sampled_valid = torch.stack(valid_l)
+        self._sampled_is_gt = torch.stack(
+            [(inds_l[i] < gt_bboxes[i].size(0)) if add_gt else torch.zeros_like(valid_l[i])
+             for i in range(N)])
+        head = self.bbox_head if head is None else head
         rois, labels, lw, bt, bw = BF.rcnn_targets(
             boxes_l, assigned_l, inds_l, valid_l, [g.contiguous() for g in gt_labels], gt_cat, offs,
             sc.num, head.target_means, head.target_stds, rc.pos_weight)
@@ -292,6 +301,123 @@ class MaskRCNN(TwoStageDetector):
     """mmdet/models/detectors/mask_rcnn.py: the two-stage detector with the mask branch
     (configs/bags/gs_mask_rcnn_r50_fpn_1x_lvis.py = cfg 4)."""
     pass
+
+
+@DETECTORS.register_module
+class CascadeRCNN(TwoStageDetector):
+    """mmdet/models/detectors/cascade_rcnn.py:15-420 (bbox branch; cfg 5 =
+    configs/bags/gs_cascade_rcnn_x101_64x4d_fpn_1x_lvis.py): ``num_stages`` RoI heads trained at
+    increasing IoU thresholds, each stage re-sampling from the boxes the previous stage refined.
+
+    Fixed-shape differences: stage ``i+1``'s proposals are ALL ``sampler.num`` refined RoIs of
+    stage ``i`` with a validity mask (``pos_is_gt`` rows and padding slots masked out) instead of
+    a filtered list, so the stage loop issues no host synchronisation either."""
+
+    def __init__(self, num_stages, backbone, neck=None, shared_head=None, rpn_head=None,
+                 bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None,
+                 train_cfg=None, test_cfg=None, pretrained=None):
+        assert bbox_roi_extractor is not None and bbox_head is not None
+        if shared_head is not None or mask_head is not None or mask_roi_extractor is not None:
+            raise NotImplementedError('cascade mask branch / shared head (HTC) are not built')
+        nn.Module.__init__(self)
+        self.num_stages = num_stages
+        self.backbone = builder.build_backbone(backbone)
+        self.neck = builder.build_neck(neck) if neck is not None else None
+        self.rpn_head = builder.build_head(rpn_head) if rpn_head is not None else None
+        if not isinstance(bbox_roi_extractor, (list, tuple)):
+            bbox_roi_extractor = [bbox_roi_extractor] * num_stages
+        if not isinstance(bbox_head, (list, tuple)):
+            bbox_head = [bbox_head] * num_stages
+        assert len(bbox_roi_extractor) == len(bbox_head) == num_stages
+        self.bbox_roi_extractor = nn.ModuleList(builder.build_roi_extractor(r)
+                                                for r in bbox_roi_extractor)
+        self.bbox_head = nn.ModuleList(builder.build_head(h) for h in bbox_head)
+        self.mask_head = None
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.fp16_enabled = False
+        self.init_weights(pretrained=pretrained)
+
+    def init_weights(self, pretrained=None):
+        if isinstance(pretrained, str):
+            pretrained = None
+        self.backbone.init_weights(pretrained=pretrained)
+        if self.with_neck:
+            self.neck.init_weights()
+        if self.with_rpn:
+            self.rpn_head.init_weights()
+        for ext, head in zip(self.bbox_roi_extractor, self.bbox_head):
+            ext.init_weights()
+            head.init_weights()
+
+    def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
+                      gt_masks=None, proposals=None, generator=None):
+        if not img.is_cuda:
+            raise NotImplementedError('CascadeRCNN.forward_train runs on the GPU path only')
+        x = self.extract_feat(img)
+        losses = dict()
+        if self.with_rpn:
+            cls_scores, bbox_preds = self.rpn_head(x)
+            losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
+                                             self.train_cfg.rpn, generator=generator))
+            proposal_cfg = self.train_cfg.get('rpn_proposal', None)
+            if proposal_cfg is None:
+                proposal_cfg = self.test_cfg.rpn
+            proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_meta, proposal_cfg)
+            self.rpn_head._fused = None
+            del cls_scores, bbox_preds
+        else:
+            proposal_list = [(p, torch.ones(p.size(0), dtype=torch.bool, device=p.device))
+                             for p in proposals]
+        n_img = img.size(0)
+        for i in range(self.num_stages):
+            rc = self.train_cfg.rcnn[i]
+            lw = self.train_cfg.stage_loss_weights[i]
+            head, ext = self.bbox_head[i], self.bbox_roi_extractor[i]
+            rois, targets = self._sample_rois_fused(proposal_list, gt_bboxes, gt_labels, generator,
+                                                    rc=rc, head=head)
+            feats = ext(x[:ext.num_inputs], rois)
+            cls_score, bbox_pred = head(feats, nhwc=True)
+            for name, value in head.loss(cls_score, bbox_pred, *targets).items():
+                losses['s{}.{}'.format(i, name)] = value * lw if 'loss' in name else value
+            if i < self.num_stages - 1:       # refine (cascade_rcnn.py:291-296), fixed shape
+                with torch.no_grad():
+                    num = rc.sampler.num
+                    bp = bbox_pred.detach()
+                    boxes = torch.cat([head.regress_by_class(
+                        rois[j * num:(j + 1) * num, 1:], targets[0][j * num:(j + 1) * num],
+                        bp[j * num:(j + 1) * num], img_meta[j]) for j in range(n_img)])
+                    keep = self._sampled_valid & ~self._sampled_is_gt
+                    proposal_list = [(boxes[j * num:(j + 1) * num], keep[j]) for j in range(n_img)]
+        return losses
+
+    def simple_test(self, img, img_meta, proposals=None, rescale=False):
+        """cascade_rcnn.py:300-393 (bbox branch, ensemble result): every stage re-regresses the
+        1000 RoIs with its arg-max class, the class logits are averaged over the stages."""
+        from .post_processing import bbox2result, multiclass_nms
+        x = self.extract_feat(img)
+        proposal_list = (self.simple_test_rpn(x, img_meta, self.test_cfg.rpn)
+                         if proposals is None else proposals)
+        props, valid = proposal_list[0] if isinstance(proposal_list[0], tuple) \
+            else (proposal_list[0], None)
+        rois = torch.cat([props.new_zeros((props.size(0), 1)), props[:, :4]], dim=1)
+        ms_scores = []
+        for i in range(self.num_stages):
+            head, ext = self.bbox_head[i], self.bbox_roi_extractor[i]
+            cls_score, bbox_pred = head(ext(x[:ext.num_inputs], rois), nhwc=True)
+            ms_scores.append(cls_score)
+            if i < self.num_stages - 1:
+                bbox_label = cls_score.argmax(dim=1)
+                rois = head.regress_by_class(rois, bbox_label, bbox_pred, img_meta[0])
+        cls_score = sum(ms_scores) / float(self.num_stages)
+        bboxes, scores = self.bbox_head[-1].get_det_bboxes(
+            rois, cls_score, bbox_pred, img_meta[0]['img_shape'], img_meta[0]['scale_factor'],
+            rescale=rescale, cfg=None)
+        if valid is not None:
+            scores = torch.where(valid[:, None], scores, scores.new_full((), -1.0))
+        cfg = self.test_cfg.rcnn
+        det_bboxes, det_labels = multiclass_nms(bboxes, scores, cfg.score_thr, cfg.nms,
+                                                cfg.max_per_img)
+        return bbox2result(det_bboxes, det_labels, self.bbox_head[-1].num_classes)
 
 
 @DETECTORS.register_module

@@ -476,6 +476,26 @@ def linear_autograd(x, weight, bias=None, relu=False, mask_input=False):
     return y.view(M, Nout)
 
 
+def grouped_conv3x3_nhwc(x, w, bias, groups, stride=1, relu=False):
+    """Grouped 3x3 / pad 1 conv (ResNeXt conv2): x ``[N,H,W,C]``, w ``[C,3,3,C/groups]``.
+    Forward only (selectp 1 / 3 freeze the trunk)."""
+    _require_cuda(x, w, bias)
+    lib = capi.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and w.is_contiguous()
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        raise NotImplementedError('no backward for the grouped conv (ResNeXt trunks train with '
+                                  'selectp = 1 / 3 only)')
+    N, H, W, C = x.shape
+    assert tuple(w.shape) == (C, 3, 3, C // groups), (w.shape, C, groups)
+    out = torch.empty((N, (H - 1) // stride + 1, (W - 1) // stride + 1, C), dtype=torch.float32,
+                      device=x.device)
+    rc = lib.bgs_grouped_conv3x3_nhwc_f32(capi.ptr(x), capi.ptr(w), capi.ptr(bias), capi.ptr(out),
+                                          N, H, W, C, int(groups), int(stride), int(bool(relu)),
+                                          capi.current_stream(x.device))
+    capi.check('bgs_grouped_conv3x3_nhwc_f32', rc)
+    return out
+
+
 def maxpool3x3s2_nhwc(x):
     _require_cuda(x)
     lib = capi.load()

@@ -198,6 +198,14 @@ int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, float*
                               int W, int Cin, int Cout, int R, int S, int stride, int pad,
                               int accumulate, void* workspace, bgs_stream_t stream);
 
+/* Grouped 3x3 convolution (pad 1, stride 1 or 2) + bias + ReLU, NHWC: conv2 of the ResNeXt
+ * bottleneck (mmdet/models/backbones/resnext.py:47-57, cfg 5 = X101-64x4d).  x [N,H,W,C],
+ * w [C,3,3,C/groups] (output channel, tap, input channel within the group), bias [C] or NULL,
+ * y [N,Ho,Wo,C].  C/groups in {4, 8, 16, 32}.  Forward only. */
+int bgs_grouped_conv3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y,
+                                 int N, int H, int W, int C, int groups, int stride, int relu,
+                                 bgs_stream_t stream);
+
 /* 3x3 / stride 2 / pad 1 max pooling, NHWC (ResNet stem, resnet.py:452). C % 4 == 0.
  * y [N, (H-1)/2+1, (W-1)/2+1, C]. */
 int bgs_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C,

@@ -1,0 +1,138 @@
+"""GPU: ResNeXt grouped conv + Cascade R-CNN (cfg 5 pieces) through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import balancedgroupsoftmax_amd as bgs
+from balancedgroupsoftmax_amd import functional as BF
+from balancedgroupsoftmax_amd import gs_tables, train
+from balancedgroupsoftmax_amd.config import to_config_dict
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('cg,stride', [(4, 1), (8, 2), (16, 1), (32, 2), (32, 1)])
+def test_grouped_conv3x3_vs_torch_cpu(cg, stride):
+    rs = np.random.RandomState(cg + stride)
+    groups = 8
+    C = cg * groups
+    x = rs.randn(2, 13, 18, C).astype(np.float32)
+    w = (rs.randn(C, cg, 3, 3) * 0.2).astype(np.float32)
+    b = rs.randn(C).astype(np.float32)
+    exp = F.relu(F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w),
+                          torch.from_numpy(b), stride=stride, padding=1, groups=groups))
+    wk = torch.from_numpy(np.ascontiguousarray(w.transpose(0, 2, 3, 1))).to(DEV)
+    got = BF.grouped_conv3x3_nhwc(torch.from_numpy(x).to(DEV), wk, torch.from_numpy(b).to(DEV),
+                                  groups, stride=stride, relu=True)
+    assert tuple(got.shape) == (2, exp.shape[2], exp.shape[3], C)
+    assert float((got.permute(0, 3, 1, 2).cpu() - exp).abs().max()) < 1e-4 * float(exp.abs().max())
+
+
+def test_resnext_stage_forward_vs_torch_cpu():
+    from tests.test_gpu_detector import randomize_bn, ref_bottleneck, nchw, rel_err
+    torch.manual_seed(0)
+    m = bgs.build_backbone(dict(type='ResNeXt', depth=50, groups=64, base_width=4, num_stages=4,
+                                out_indices=(0, 1, 2, 3), frozen_stages=4, style='pytorch'))
+    m.init_weights()
+    for b in m.modules():
+        if hasattr(b, 'bn3'):
+            torch.nn.init.constant_(b.bn3.weight, 0.5)
+    randomize_bn(m)
+    assert m.layer1[0].conv2.groups == 64 and tuple(m.layer1[0].conv2.weight.shape) == (256, 4, 3, 3)
+    img = torch.randn(1, 3, 96, 128)
+    with torch.no_grad():
+        x = F.conv2d(img, m.conv1.weight, None, 2, 3)
+        x = F.relu(F.batch_norm(x, m.bn1.running_mean, m.bn1.running_var, m.bn1.weight, m.bn1.bias,
+                                False, 0., m.bn1.eps))
+        x = F.max_pool2d(x, 3, 2, 1)
+        exp = []
+        for name in m.res_layers:
+            for blk in getattr(m, name):
+                def cbn(conv, bn, t, relu):
+                    t = F.conv2d(t, conv.weight, None, conv.stride, conv.padding, 1, conv.groups)
+                    t = F.batch_norm(t, bn.running_mean, bn.running_var, bn.weight, bn.bias, False,
+                                     0., bn.eps)
+                    return F.relu(t) if relu else t
+                idt = x if blk.downsample is None else cbn(blk.downsample[0], blk.downsample[1], x, False)
+                o = cbn(blk.conv1, blk.bn1, x, True)
+                o = cbn(blk.conv2, blk.bn2, o, True)
+                o = cbn(blk.conv3, blk.bn3, o, False)
+                x = F.relu(o + idt)
+            exp.append(x)
+        m.to(DEV)
+        got = m(img.to(DEV))
+    for g, e in zip(got, exp):
+        assert rel_err(nchw(g), e) < 1e-4
+
+
+def _cascade(tmp_path, depth=50):
+    paths = gs_tables.save_group_tables(str(tmp_path), *gs_tables.synthetic_group_tables())
+    from tests.test_gpu_detector import _detector_cfg
+    model, train_cfg = _detector_cfg(paths)
+    head = model['bbox_head']
+    head['reg_class_agnostic'] = True
+    heads = []
+    for stds in ([0.1, 0.1, 0.2, 0.2], [0.05, 0.05, 0.1, 0.1], [0.033, 0.033, 0.067, 0.067]):
+        h = dict(head)
+        h['gs_config'] = dict(head['gs_config'])
+        h['target_stds'] = stds
+        heads.append(h)
+    model.update(type='CascadeRCNN', num_stages=3, bbox_head=heads)
+    rcnn = train_cfg['rcnn']
+    stages = []
+    for iou in (0.5, 0.6, 0.7):
+        r = dict(rcnn)
+        r['assigner'] = dict(rcnn['assigner'], pos_iou_thr=iou, neg_iou_thr=iou, min_pos_iou=iou)
+        stages.append(r)
+    train_cfg['rcnn'] = stages
+    train_cfg['stage_loss_weights'] = [1, 0.5, 0.25]
+    test_cfg = dict(rpn=dict(nms_across_levels=False, nms_pre=1000, nms_post=1000, max_num=1000,
+                             nms_thr=0.7, min_bbox_size=0),
+                    rcnn=dict(score_thr=0.0, nms=dict(type='nms', iou_thr=0.5), max_per_img=300),
+                    keep_all_stages=False)
+    return bgs.build_detector(to_config_dict(model), train_cfg=to_config_dict(train_cfg),
+                              test_cfg=to_config_dict(test_cfg))
+
+
+def test_cascade_rcnn_training_iteration_and_test(tmp_path):
+    torch.manual_seed(0)
+    model = _cascade(tmp_path).to(DEV)
+    params = train.select_training_param(model, 3)               # the three fc_cls (cfg 5: selectp=3)
+    assert len(params) == 6
+    model.train()
+    H, W = 320, 480
+    img = torch.randn(2, 3, H, W, device=DEV)
+    metas = [dict(img_shape=(H, W - 5, 3), pad_shape=(H, W, 3), ori_shape=(H, W - 5, 3),
+                  scale_factor=1.0, flip=False)] * 2
+    g = torch.Generator().manual_seed(3)
+    gtb, gtl = [], []
+    for _ in range(2):
+        xy = torch.rand(10, 2, generator=g) * torch.tensor([W - 160., H - 160.])
+        wh = torch.rand(10, 2, generator=g) * 120 + 30
+        gtb.append(torch.cat([xy, xy + wh], 1).to(DEV))
+        gtl.append(torch.randint(1, 1231, (10,), generator=g).to(DEV))
+    losses = model(img, metas, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
+    keys = set(losses.keys())
+    for i in range(3):
+        assert {'s%d.loss_cls_bin%d' % (i, b) for b in range(5)} <= keys
+        assert 's%d.loss_bbox' % i in keys
+    assert {'loss_rpn_cls', 'loss_rpn_bbox'} <= keys and len(keys) == 2 + 3 * 6
+    # stage loss weights 1 / 0.5 / 0.25 (cascade_rcnn.py:248-250): bg bins at init ~ w * log 2-ish
+    b0 = [float(losses['s%d.loss_cls_bin0' % i]) for i in range(3)]
+    assert b0[0] > b0[1] > b0[2] > 0 and 0.2 < b0[1] / b0[0] < 0.8
+    loss, _ = train.parse_losses(losses)
+    assert torch.isfinite(loss)
+    loss.backward()
+    for h in model.bbox_head:
+        assert h.fc_cls.weight.grad is not None and float(h.fc_cls.weight.grad.abs().sum()) > 0
+        assert h.fc_reg.weight.grad is None
+    # stage 2 / 3 re-sample from the refined boxes: the kept refined proposals exclude GT rows
+    assert model._sampled_valid.shape == (2, 512) and model._sampled_is_gt.shape == (2, 512)
+    model.eval()
+    with torch.no_grad():
+        for h in model.bbox_head:
+            h.fc_cls.weight.mul_(30.0)
+    res = model(img[:1], metas[:1], return_loss=False, rescale=False)
+    assert len(res) == 1230 and sum(r.shape[0] for r in res) == 300
