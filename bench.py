@@ -42,7 +42,9 @@ def parse():
     ap.add_argument('--workload', default='detector', choices=['detector', 'gs_head'])
     ap.add_argument('--imgs', type=int, default=2, help='images per GPU per step (cfg: imgs_per_gpu=2)')
     ap.add_argument('--rois', type=int, default=1024, help='RoIs per GPU per step (2 img x 512)')
-    ap.add_argument('--selectp', type=int, default=1, choices=[0, 1],
+    ap.add_argument('--cascade', action='store_true',
+                    help='cfg[4]: Cascade R-CNN X101-64x4d-FPN + BAGS, 3 stages (fp32)')
+    ap.add_argument('--selectp', type=int, default=1, choices=[0, 1, 3],
                     help='1 (as shipped): train bbox_head.fc_cls only; 0: train everything '
                          '(tools/train.py:49-57)')
     ap.add_argument('--mask', action='store_true',
@@ -171,7 +173,7 @@ class DetectorStep(object):
     """One training iteration of cfg[1] as shipped (selectp=1: full forward, backward through
     fc_cls, gradient all-reduce, clip, SGD) on synthetic 800x1344 inputs, 512 RoIs/img."""
 
-    def __init__(self, dev, rank, world, imgs, selectp=1, mask=False):
+    def __init__(self, dev, rank, world, imgs, selectp=1, mask=False, cascade=False):
         import tempfile
         import balancedgroupsoftmax_amd as bgs
         from balancedgroupsoftmax_amd import train
@@ -190,6 +192,23 @@ class DetectorStep(object):
                 num_classes=NUM_CLASSES,
                 loss_mask=dict(type='CrossEntropyLoss', use_mask=True, loss_weight=1.0))
             train_cfg['rcnn']['mask_size'] = 28
+        if cascade:     # cfg[4] = configs/bags/gs_cascade_rcnn_x101_64x4d_fpn_1x_lvis.py (fp32 here)
+            model_cfg['type'] = 'CascadeRCNN'
+            model_cfg['num_stages'] = 3
+            model_cfg['backbone'] = dict(type='ResNeXt', depth=101, groups=64, base_width=4,
+                                         num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                                         style='pytorch')
+            base = model_cfg['bbox_head']
+            heads = []
+            for stds in ([0.1, 0.1, 0.2, 0.2], [0.05, 0.05, 0.1, 0.1], [0.033, 0.033, 0.067, 0.067]):
+                h = dict(base, reg_class_agnostic=True, target_stds=stds)
+                h['gs_config'] = dict(base['gs_config'])
+                heads.append(h)
+            model_cfg['bbox_head'] = heads
+            rc = train_cfg['rcnn']
+            train_cfg['rcnn'] = [dict(rc, assigner=dict(rc['assigner'], pos_iou_thr=t, neg_iou_thr=t,
+                                                        min_pos_iou=t)) for t in (0.5, 0.6, 0.7)]
+            train_cfg['stage_loss_weights'] = [1, 0.5, 0.25]
         self.mask = mask
         self.model = bgs.build_detector(to_config_dict(model_cfg),
                                         train_cfg=to_config_dict(train_cfg), test_cfg=None).to(dev)
@@ -408,7 +427,8 @@ def extras(dev, args):
     config (cfg[3], selectp=1).  Failures here never hide the headline number."""
     res = {}
     for key, kw in (('selectp0', dict(selectp=0)), ('mask_rcnn_selectp1', dict(selectp=1, mask=True)),
-                    ('mask_rcnn_selectp0', dict(selectp=0, mask=True))):
+                    ('mask_rcnn_selectp0', dict(selectp=0, mask=True)),
+                    ('cascade_x101_64x4d_selectp3_fp32', dict(selectp=3, cascade=True))):
         try:
             sys.stderr.write('extras: %s\n' % key)
             sys.stderr.flush()
@@ -427,7 +447,7 @@ def extras(dev, args):
 
 
 def main_detector(args, rank, local, world, dev):
-    step = DetectorStep(dev, rank, world, args.imgs, args.selectp, args.mask)
+    step = DetectorStep(dev, rank, world, args.imgs, args.selectp, args.mask, args.cascade)
     # Launch policy.  The iteration is free of host synchronisation, so on ONE GPU the whole
     # step (forward, losses, backward, clip, SGD: ~560 launches) is captured into a single
     # hipGraph and replayed.  The graph must own the ENTIRE step: on ROCm 7.2 a large graph whose
@@ -465,6 +485,7 @@ def main_detector(args, rank, local, world, dev):
                                        'layer1: full forward and full backward through heads, '
                                        'RoIAlign, RPN, FPN, ResNet layer2-4'), args.imgs),
                        'selectp': args.selectp, 'mask_branch': bool(args.mask),
+                       'cascade_x101': bool(args.cascade),
                        'trainable_params': int(sum(p.numel() for p in step.params)),
                        'imgs_per_gpu': args.imgs, 'rois_per_img': 512,
                        'launch': ('hipGraph replay of the whole step (forward+losses+backward+'
@@ -478,7 +499,8 @@ def main_detector(args, rank, local, world, dev):
         if graph is not None and world == 1:
             dte = timed_loop(step, 5, 2, 1)
             out['ms_per_step_eager'] = round(dte * 1e3 / 5, 3)
-        if world == 1 and not args.no_extras and args.selectp == 1 and not args.mask:
+        if world == 1 and not args.no_extras and args.selectp == 1 and not args.mask \
+                and not args.cascade:
             out['also_measured'] = extras(dev, args)
         out['roofline'] = conv_roofline(dev)
         gs_inp = make_inputs(1024, seed=1000, dev=dev)
