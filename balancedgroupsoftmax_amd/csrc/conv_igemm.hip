@@ -54,6 +54,12 @@ struct ConvArgs {
   // (bias / residual / ReLU / mask) then runs in conv_splitk_epilogue_kernel.
   float* partial;
   int kt_per_split;
+  // XCD-aware tile order: the launch is 1-D; workgroup b runs on XCD b % 8 (round-robin dispatch),
+  // and is given tile (b % 8) * chunk + b / 8 — every XCD walks its own contiguous band of the
+  // image, with the Cout tiles of one pixel tile back to back, so the 3x3 halo rows and the
+  // re-read of the same pixels for the next Cout tile hit that XCD's L2 (PMC: 2.46 GB fetched per
+  // 158-GFLOP layer before, profiles/r2d_pmc_conv.md).
+  int tiles_m, tiles_n, chunk;
 };
 
 // UP = 1: plain convolution.  UP = 2: the input is read as if it had been zero-upsampled by 2
@@ -72,7 +78,9 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int vtile = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if (vtile >= p.tiles_m * p.tiles_n) return;          // workgroup-uniform
+  const int m0 = (vtile / p.tiles_n) * BM, n0 = (vtile % p.tiles_n) * BN;
 
   // ---- staging role of this thread: 4 consecutive k (one 16-byte load) of rows srow + 64*pass
   const int kq = tid % KQ;
@@ -384,8 +392,11 @@ static int launch_conv(ConvArgs& p, int up, hipStream_t st, void* workspace = nu
   hipLaunchKernelGGL((conv_igemm_f32_kernel<MB_, NB_, BK_, UP_>), grid, dim3(kThreads), 0, st, p)
 #define BGS_CONV_LAUNCH(MB_, NB_, BM_, BN_)                                                      \
   do {                                                                                           \
-    dim3 grid((unsigned)((M + BM_ - 1) / BM_), (unsigned)((p.Cout + BN_ - 1) / BN_),             \
-              (unsigned)splits);                                                                 \
+    p.tiles_m = (int)((M + BM_ - 1) / BM_);                                                      \
+    p.tiles_n = (p.Cout + BN_ - 1) / BN_;                                                        \
+    p.chunk = (p.tiles_m * p.tiles_n + 7) / 8;                                                   \
+    if (getenv("BGS_CONV_NOSWIZZLE")) p.chunk = 0;                                               \
+    dim3 grid((unsigned)(p.chunk ? 8 * p.chunk : p.tiles_m * p.tiles_n), 1u, (unsigned)splits);   \
     if (up == 2) {                                                                               \
       if (bk == 32) BGS_CONV_LAUNCH2(MB_, NB_, 32, 2);                                           \
       else BGS_CONV_LAUNCH2(MB_, NB_, 16, 2);                                                    \
