@@ -56,10 +56,10 @@ __global__ __launch_bounds__(256) void iou_gtmax_kernel(const float* __restrict_
                                                         int* __restrict__ box_arg,
                                                         int* __restrict__ gt_max_bits) {
   __shared__ float sgt[kGtChunk][4];
-  __shared__ int sred[4];
+  __shared__ int smax[kGtChunk];     // per-gt maximum over this block's boxes (float bits)
   const int n = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   const int g0 = T.gt_off[n], G = T.gt_off[n + 1] - g0;
   const bool live = i < A;
   const bool ok = live && (valid ? valid[(size_t)n * A + i] != 0 : true);
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void iou_gtmax_kernel(const float* __restrict_
     const int cn = min(kGtChunk, G - c0);
     __syncthreads();
     for (int t = threadIdx.x; t < cn * 4; t += 256) sgt[t >> 2][t & 3] = gt[(size_t)(g0 + c0) * 4 + t];
+    for (int t = threadIdx.x; t < cn; t += 256) smax[t] = (int)0xBF800000;   // -1.0f
     __syncthreads();
     for (int g = 0; g < cn; ++g) {
       const float v = ok ? iou1(x1, y1, x2, y2, area, sgt[g][0], sgt[g][1], sgt[g][2], sgt[g][3])
@@ -83,19 +84,15 @@ __global__ __launch_bounds__(256) void iou_gtmax_kernel(const float* __restrict_
         best = v;
         barg = c0 + g;
       }
-      // per-gt maximum over this block's boxes -> one atomic per block
+      // per-gt maximum: wave reduction, one LDS atomic per wave (no block barrier per gt).
+      // signed-int order == float order for the values used here: -1.0f (negative int) < any
+      // IoU >= 0 (non-negative ints, monotone in the float value)
       const float wm = bgs::wave_max(v);
-      if (lane == 0) sred[wave] = __float_as_int(wm);
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        float m = __int_as_float(sred[0]);
-        for (int w = 1; w < 4; ++w) m = fmaxf(m, __int_as_float(sred[w]));
-        // signed-int order == float order for the values used here: -1.0f (negative int) < any
-        // IoU >= 0 (non-negative ints, monotone in the float value)
-        atomicMax(&gt_max_bits[(size_t)n * gmax_stride + c0 + g], __float_as_int(m));
-      }
-      __syncthreads();
+      if (lane == 0 && wm >= 0.f) atomicMax(&smax[g], __float_as_int(wm));
     }
+    __syncthreads();
+    for (int t = threadIdx.x; t < cn; t += 256)
+      if (smax[t] >= 0) atomicMax(&gt_max_bits[(size_t)n * gmax_stride + c0 + t], smax[t]);
   }
   if (live) {
     box_max[(size_t)n * A + i] = best;
