@@ -176,3 +176,36 @@ elif mode == 'variants':
             print(i, 'loss %.4f' % float(st.last['loss']), flush=True)
     torch.cuda.synchronize()
     print('done', v, flush=True)
+elif mode == 'sidestream':
+    st = bench.DetectorStep(dev, 0, 1, 2, selectp=1)
+    g = bench.try_graph(st.compute)
+    s2 = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    for i in range(int(sys.argv[2])):
+        g.replay()
+        s2.wait_stream(cur)
+        with torch.cuda.stream(s2):
+            st.apply()
+        cur.wait_stream(s2)
+        if i % 20 == 0:
+            torch.cuda.synchronize()
+            print(i, 'loss %.4f' % float(st.last['loss']), flush=True)
+    torch.cuda.synchronize()
+    print('done sidestream', flush=True)
+elif mode == 'graphstream':
+    # replay the graph on a dedicated stream, eager work stays on the default stream
+    st = bench.DetectorStep(dev, 0, 1, 2, selectp=1)
+    g = bench.try_graph(st.compute)
+    s2 = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    for i in range(int(sys.argv[2])):
+        s2.wait_stream(cur)
+        with torch.cuda.stream(s2):
+            g.replay()
+        cur.wait_stream(s2)
+        st.apply()
+        if i % 20 == 0:
+            torch.cuda.synchronize()
+            print(i, 'loss %.4f' % float(st.last['loss']), flush=True)
+    torch.cuda.synchronize()
+    print('done graphstream', flush=True)
