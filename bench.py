@@ -51,6 +51,8 @@ def parse():
                     help='cfg[3]: add the Mask R-CNN branch (gs_mask_rcnn_r50_fpn_1x_lvis)')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the secondary measurements (selectp=0, Mask R-CNN) of the N=1 run')
+    ap.add_argument('--no-roofline', action='store_true',
+                    help='skip the per-kernel roofline timings (used by the extras sub-runs)')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches, not hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -431,24 +433,29 @@ def cpu_baseline(n, seconds):
 
 def extras(dev, args):
     """Secondary single-GPU measurements of the same step in the other §8 configurations (not the
-    headline value): selectp=0 (train everything but the frozen stem+layer1) and the Mask R-CNN
-    config (cfg[3], selectp=1).  Failures here never hide the headline number."""
+    headline value): selectp=0 (train everything but the frozen stem+layer1), the Mask R-CNN
+    config (cfg[3]) and the X101-64x4d cascade (cfg[4], fp32).  Each runs in its OWN process
+    (this script with --no-extras), so a failure there can never take the headline line down."""
+    import subprocess
     res = {}
-    for key, kw in (('selectp0', dict(selectp=0)), ('mask_rcnn_selectp1', dict(selectp=1, mask=True)),
-                    ('mask_rcnn_selectp0', dict(selectp=0, mask=True)),
-                    ('cascade_x101_64x4d_selectp3_fp32', dict(selectp=3, cascade=True))):
+    runs = (('selectp0', ['--selectp', '0']),
+            ('mask_rcnn_selectp1', ['--mask']),
+            ('mask_rcnn_selectp0', ['--mask', '--selectp', '0']),
+            ('cascade_x101_64x4d_selectp3_fp32', ['--cascade', '--selectp', '3']))
+    for key, flags in runs:
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'detector', '--steps', '10',
+               '--warmup', '3', '--imgs', str(args.imgs), '--no-extras', '--no-cpu-baseline',
+               '--no-roofline'] + flags + (['--no-graph'] if args.no_graph else [])
         try:
-            sys.stderr.write('extras: %s\n' % key)
-            sys.stderr.flush()
-            st = DetectorStep(dev, 0, 1, args.imgs, **kw)
-            g = None if args.no_graph else try_graph(st)
-            fn = g.replay if g is not None else st
-            dt = timed_loop(fn, 10, 3, 1)
-            res[key] = {'img_per_s': round(args.imgs * 10 / dt, 2), 'ms_per_step': round(dt * 100, 3),
-                        'trainable_params': int(sum(p.numel() for p in st.params)),
-                        'loss': round(float(st.last['loss']), 4)}
-            del st, g, fn
-            torch.cuda.empty_cache()
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')]
+            if out.returncode != 0 or not line:
+                res[key] = {'error': 'rc=%d %s' % (out.returncode, out.stderr.decode()[-160:])}
+                continue
+            d = json.loads(line[-1])
+            res[key] = {'img_per_s': d['value'], 'ms_per_step': d['ms_per_step'],
+                        'trainable_params': d['config']['trainable_params'],
+                        'loss': d['last_losses']['loss'], 'launch': d['config']['launch']}
         except Exception as e:  # pragma: no cover
             res[key] = {'error': repr(e)[:200]}
     return res
@@ -510,9 +517,10 @@ def main_detector(args, rank, local, world, dev):
         if world == 1 and not args.no_extras and args.selectp == 1 and not args.mask \
                 and not args.cascade:
             out['also_measured'] = extras(dev, args)
-        out['roofline'] = conv_roofline(dev)
-        gs_inp = make_inputs(1024, seed=1000, dev=dev)
-        out['roofline_gs_loss'] = kernel_roofline(gs_inp, 1024)
+        if not args.no_roofline:
+            out['roofline'] = conv_roofline(dev)
+            gs_inp = make_inputs(1024, seed=1000, dev=dev)
+            out['roofline_gs_loss'] = kernel_roofline(gs_inp, 1024)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(1024, args.cpu_seconds)
             cb['note'] = ('GroupSoftmax loss()+backward() only: the reference cannot run the whole '
