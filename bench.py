@@ -79,7 +79,7 @@ def init_dist(args):
 def barrier(world):
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()
+        dist.barrier(device_ids=[torch.cuda.current_device()])
 
 
 def make_inputs(n, seed, dev):
