@@ -70,3 +70,66 @@ def test_single_process_is_noop():
     p = torch.nn.Parameter(torch.ones(3))
     p.grad = torch.full((3,), 2.0)
     assert train.allreduce_grads([p], 1) is None and torch.equal(p.grad, torch.full((3,), 2.0))
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(12, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32),
+                                  torch.nn.ReLU(), torch.nn.Linear(32, 4))
+        unused = torch.nn.Linear(3, 3)                      # never receives a gradient
+        params = list(net.parameters()) + list(unused.parameters())
+        opt = train.build_optimizer(params, dict(type='SGD', lr=0.1, momentum=0.9, weight_decay=1e-4))
+        # tiny buckets: 5 of them, launched from the backward hooks while backward still runs
+        step = train.DistOptimizerStep(params, opt, dict(max_norm=35, norm_type=2), world_size=world,
+                                       overlap=True, bucket_bytes=256)
+        assert step.overlap is not None and len(step.overlap.buckets) >= 3
+        g = torch.Generator().manual_seed(200 + rank)
+        for it in range(2):                                  # two iterations: state resets
+            x = torch.randn(16, 12, generator=g)
+            step(net(x).pow(2).mean())
+        torch.save(dict(w=[p.detach().clone() for p in params]),
+                   os.path.join(out_dir, 'ov_rank%d.pt' % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def _flat_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(12, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32),
+                                  torch.nn.ReLU(), torch.nn.Linear(32, 4))
+        params = list(net.parameters())
+        opt = train.build_optimizer(params, dict(type='SGD', lr=0.1, momentum=0.9, weight_decay=1e-4))
+        step = train.DistOptimizerStep(params, opt, dict(max_norm=35, norm_type=2), world_size=world,
+                                       overlap=False)
+        g = torch.Generator().manual_seed(200 + rank)
+        for it in range(2):
+            x = torch.randn(16, 12, generator=g)
+            step(net(x).pow(2).mean())
+        torch.save(dict(w=[p.detach().clone() for p in params]),
+                   os.path.join(out_dir, 'flat_rank%d.pt' % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_bucketed_exchange_equals_flat_allreduce(tmp_path):
+    """The backward-overlapped bucketed exchange ends in the same weights as the reference-style
+    flat all-reduce after backward, on every rank, incl. parameters that get no gradient."""
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_overlap_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_flat_worker, args=(world, port + 1, str(tmp_path)), nprocs=world, join=True)
+    ov = [torch.load(os.path.join(str(tmp_path), 'ov_rank%d.pt' % r)) for r in range(world)]
+    fl = [torch.load(os.path.join(str(tmp_path), 'flat_rank%d.pt' % r)) for r in range(world)]
+    n = len(fl[0]['w'])
+    for a, b in zip(ov[0]['w'], ov[1]['w']):
+        assert torch.allclose(a, b, atol=1e-7)
+    for a, b in zip(ov[0]['w'][:n], fl[0]['w']):
+        assert torch.allclose(a, b, atol=1e-6)
