@@ -183,37 +183,58 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int nk = kt_end - kt_begin;
-  load_tile();
-  store_tile(0);
-  __syncthreads();
+  // Software pipeline (one barrier per K tile, placed MID-tile): the fragments are read one
+  // half K tile ahead of the MFMAs that consume them, so the LDS latency, the global->LDS
+  // staging of the next tile and the barrier all sit behind 16+ in-flight MFMAs instead of in
+  // front of them:
+  //     [read frags (t, half 1)] [MFMA half 0] [stage tile t+1 -> LDS] [barrier]
+  //     [read frags (t+1, half 0)] [MFMA half 1] ...
+  // (measured before: ds_read x8 -> wait -> 32 MFMAs -> vmcnt wait -> ds_write -> barrier, all
+  //  serial inside a wave: 0.71 of the sustained MFMA rate.)
+  constexpr int NV = BK / 8;      // f32x4 fragments per tile row per K tile
+  constexpr int HV = NV / 2;      // ... per half
   const int frow = lane & 31, fk = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile();  // global loads in flight under the MFMAs below
-    const float* Ab = &As[buf][(wm * 32 * MB + frow) * LDK + fk * (BK / 2)];
-    const float* Bb = &Bs[buf][(wn * 32 * NB + frow) * LDK + fk * (BK / 2)];
-    f32x4 av[MB][BK / 8], bv[NB][BK / 8];
+  f32x4 fa[2][MB][HV], fb[2][NB][HV];
+  auto read_half = [&](int buf, int h, int slot) {
+    const float* Ab = &As[buf][(wm * 32 * MB + frow) * LDK + fk * (BK / 2) + 4 * h * HV];
+    const float* Bb = &Bs[buf][(wn * 32 * NB + frow) * LDK + fk * (BK / 2) + 4 * h * HV];
 #pragma unroll
     for (int a = 0; a < MB; ++a)
 #pragma unroll
-      for (int v = 0; v < BK / 8; ++v)
-        av[a][v] = *reinterpret_cast<const f32x4*>(Ab + a * 32 * LDK + 4 * v);
+      for (int v = 0; v < HV; ++v)
+        fa[slot][a][v] = *reinterpret_cast<const f32x4*>(Ab + a * 32 * LDK + 4 * v);
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int v = 0; v < BK / 8; ++v)
-        bv[b][v] = *reinterpret_cast<const f32x4*>(Bb + b * 32 * LDK + 4 * v);
+      for (int v = 0; v < HV; ++v)
+        fb[slot][b][v] = *reinterpret_cast<const f32x4*>(Bb + b * 32 * LDK + 4 * v);
+  };
+  auto mfma_half = [&](int slot) {
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
+    for (int v = 0; v < HV; ++v)
 #pragma unroll
-      for (int a = 0; a < MB; ++a)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-              av[a][kk >> 2][kk & 3], bv[b][kk >> 2][kk & 3], acc[a][b], 0, 0, 0);
-    }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+        for (int a = 0; a < MB; ++a)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][a][v][j], fb[slot][b][v][j],
+                                                              acc[a][b], 0, 0, 0);
+  };
+  load_tile();
+  store_tile(0);
+  __syncthreads();
+  read_half(0, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) load_tile();            // global loads of tile kt+1 in flight under the MFMAs
+    read_half(buf, 1, 1);
+    mfma_half(0);
+    if (more) store_tile(buf ^ 1);
     __syncthreads();
+    if (more) read_half(buf ^ 1, 0, 0);
+    mfma_half(1);
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

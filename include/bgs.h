@@ -41,6 +41,10 @@ const char* bgs_error_string(int code);
  * {max, sum} by the build's primitive (DPP) followed by {max, sum} by a ds_bpermute butterfly. */
 int bgs_selftest_wave_reduce(const float* in, float* out, bgs_stream_t stream);
 
+/* Calibration: `blocks` workgroups x 4 waves x (4 * iters) v_mfma_f32_32x32x2_f32 with register
+ * operands (4096 flop each) — the fp32 matrix rate the chip sustains under its power limit. */
+int bgs_selftest_mfma_peak(int blocks, int iters, float* out, bgs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Group-softmax label remap + "others" sampling.
  * Replaces GSBBoxHeadWith0._remap_labels / _sample_others
