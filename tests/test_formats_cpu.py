@@ -1,0 +1,135 @@
+"""CPU: the on-disk formats either side of the path: the intermediate-file
+generator against the reference's rule, and checkpoint I/O in the mmcv/mmdet layout."""
+import collections
+import json
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import balancedgroupsoftmax_amd as bgs
+from balancedgroupsoftmax_amd import checkpoint, gs_tables
+from oracle import ref_import
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fake_lvis_json(path, C=1231, seed=0):
+    counts = gs_tables.synthetic_instance_counts(C, seed=seed)
+    cats = [dict(id=i, name='c%d' % i, instance_count=int(counts[i]), image_count=1)
+            for i in range(1, C)]
+    with open(path, 'w') as f:
+        json.dump(dict(categories=cats, images=[], annotations=[]), f)
+    return counts
+
+
+def test_make_group_tables_tool_follows_the_reference_rule(tmp_path):
+    ann = str(tmp_path / 'lvis_train.json')
+    counts = _fake_lvis_json(ann)
+    out = str(tmp_path / 'lvis')
+    subprocess.run([sys.executable, os.path.join(ROOT, 'tools/make_group_tables.py'), '--ann', ann,
+                    '--out', out], check=True, stdout=subprocess.PIPE)
+    l2b = torch.load(os.path.join(out, 'label2binlabel.pt')).numpy()
+    ps = torch.load(os.path.join(out, 'pred_slice_with0.pt')).numpy()
+    with open(os.path.join(out, 'valsplit.pkl'), 'rb') as f:
+        split = pickle.load(f)
+    # literal restatement of tools/lvis_analyse.py:17-54 / 76-91
+    exp = np.zeros((5, 1231), dtype=np.int64)
+    cnt = [1, 1, 1, 1, 1]
+    exp[0, 1:] = 1
+    cnt[0] += 1
+    bins = [[], [], [], []]
+    for cid in range(1, 1231):
+        c = counts[cid]
+        b = 1 if c < 10 else 2 if c < 100 else 3 if c < 1000 else 4
+        exp[b, cid] = cnt[b]
+        cnt[b] += 1
+        bins[b - 1].append(cid)
+    assert l2b.dtype == np.int64 and np.array_equal(l2b, exp)
+    assert np.array_equal(ps[:, 1], np.array(cnt)) and ps[:, 1].sum() == 1236
+    assert np.array_equal(ps[:, 0], np.concatenate([[0], np.cumsum(cnt)[:-1]]))
+    for key, b in zip(['(0, 10)', '[10, 100)', '[100, 1000)', '[1000, ~)'], bins):
+        assert np.array_equal(np.asarray(split[key]), np.array(b))
+    assert np.array_equal(split['normal'], np.arange(1, 1231)) and split['all'].shape == (1231,)
+    with open(os.path.join(out, 'bins_cls_weight.pkl'), 'rb') as f:
+        w = pickle.load(f)
+    assert len(w) == 4 and all(x[0] == 1.0 and x.min() >= 0.1 and x.max() <= 5.0 for x in w)
+    # and the head loads them
+    from balancedgroupsoftmax_amd.config import to_config_dict
+    head = bgs.build_head(to_config_dict(dict(
+        type='GSBBoxHeadWith0', num_fcs=2, in_channels=256, fc_out_channels=64, roi_feat_size=7,
+        num_classes=1231, target_means=[0., 0., 0., 0.], target_stds=[0.1, 0.1, 0.2, 0.2],
+        gs_config=dict(label2binlabel=os.path.join(out, 'label2binlabel.pt'),
+                       pred_slice=os.path.join(out, 'pred_slice_with0.pt'),
+                       fg_split=os.path.join(out, 'valsplit.pkl'), others_sample_ratio=8.0,
+                       loss_bg=dict(type='CrossEntropyLoss'), num_bins=5,
+                       loss_bin=dict(type='CrossEntropyLoss')),
+        loss_cls=dict(type='CrossEntropyLoss'), loss_bbox=dict(type='SmoothL1Loss'))))
+    assert tuple(head.fc_cls.weight.shape) == (1236, 64)
+
+
+def test_checkpoint_roundtrip_and_mmcv_layout(tmp_path):
+    model = bgs.build_backbone(dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3),
+                                    frozen_stages=1, style='pytorch'))
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.1, momentum=0.9)
+    path = str(tmp_path / 'epoch_1.pth')
+    checkpoint.save_checkpoint(model, path, optimizer=opt, meta=dict(epoch=1, iter=100))
+    raw = torch.load(path)
+    assert set(raw.keys()) == {'meta', 'state_dict', 'optimizer'} and raw['meta']['epoch'] == 1
+    assert isinstance(raw['state_dict'], collections.OrderedDict)
+    other = bgs.build_backbone(dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3),
+                                    frozen_stages=1, style='pytorch'))
+    rep = checkpoint.load_checkpoint(other, path)['load_report']
+    assert rep == dict(missing=[], unexpected=[], mismatched=[])
+    for (k, a), (_, b) in zip(model.state_dict().items(), other.state_dict().items()):
+        assert torch.equal(a, b), k
+    # DDP-style 'module.' prefix, an extra key, a size mismatch: reported, not fatal (mmcv semantics)
+    sd = collections.OrderedDict(('module.' + k, v) for k, v in model.state_dict().items())
+    sd['module.fc.weight'] = torch.zeros(1000, 2048)
+    sd['module.conv1.weight'] = torch.zeros(64, 3, 3, 3)
+    torch.save(dict(state_dict=sd, meta={}), path)
+    rep = checkpoint.load_checkpoint(other, path)['load_report']
+    assert rep['unexpected'] == ['fc.weight'] and rep['missing'] == []
+    assert rep['mismatched'] == [('conv1.weight', (64, 3, 7, 7), (64, 3, 3, 3))]
+    with pytest.raises(RuntimeError):
+        checkpoint.load_checkpoint(other, path, strict=True)
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason='reference tree absent')
+def test_reference_module_checkpoint_loads_into_the_detector(tmp_path):
+    """A checkpoint written from the REFERENCE's own modules (ResNet-50 + FPN + RPNHead, the
+    'pretrained Faster R-CNN' BAGS starts from) loads key-for-key; only the 1231-row fc_cls of a
+    plain head mismatches the 1236-row BAGS head — what the reference re-initialises, too."""
+    ref_import.install_stubs()
+    from mmdet.models.anchor_heads.rpn_head import RPNHead as RefRPN
+    from mmdet.models.backbones.resnet import ResNet as RefResNet
+    from mmdet.models.necks.fpn import FPN as RefFPN
+    sd = collections.OrderedDict()
+    for prefix, m in (('backbone', RefResNet(depth=50, num_stages=4, out_indices=(0, 1, 2, 3),
+                                            frozen_stages=1, style='pytorch')),
+                      ('neck', RefFPN(in_channels=[256, 512, 1024, 2048], out_channels=256, num_outs=5)),
+                      ('rpn_head', RefRPN(in_channels=256, feat_channels=256, anchor_scales=[8],
+                                          anchor_ratios=[0.5, 1.0, 2.0],
+                                          anchor_strides=[4, 8, 16, 32, 64]))):
+        for k, v in m.state_dict().items():
+            sd['%s.%s' % (prefix, k)] = v
+    sd['bbox_head.fc_cls.weight'] = torch.zeros(1231, 1024)      # plain Faster R-CNN classifier
+    sd['bbox_head.fc_cls.bias'] = torch.zeros(1231)
+    path = str(tmp_path / 'faster_rcnn_r50_fpn_1x_lvis.pth')
+    torch.save(dict(meta=dict(mmdet_version='1.0.rc0'), state_dict=sd), path)
+    cfg = bgs.Config.fromfile(os.path.join(ref_import.REFERENCE_ROOT,
+                                           'configs/bags/gs_faster_rcnn_r50_fpn_1x_lvis_with0_bg8.py'))
+    paths = gs_tables.save_group_tables(str(tmp_path), *gs_tables.synthetic_group_tables())
+    gs = cfg.model.bbox_head.gs_config
+    gs.label2binlabel, gs.pred_slice, gs.fg_split = (paths['label2binlabel'], paths['pred_slice'],
+                                                     paths['fg_split'])
+    model = bgs.build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    rep = checkpoint.load_checkpoint(model, path)['load_report']
+    assert rep['unexpected'] == []
+    assert [m[0] for m in rep['mismatched']] == ['bbox_head.fc_cls.weight', 'bbox_head.fc_cls.bias']
+    assert all(k.startswith('bbox_head.') for k in rep['missing'])
+    assert torch.equal(model.backbone.layer3[2].conv2.weight, sd['backbone.layer3.2.conv2.weight'])
