@@ -2,10 +2,11 @@
 on the detector path.  Never imported by the product package.
 
 * ``roi_align_forward``  mmdet/ops/roi_align/src/roi_align_kernel.cu:16-124 (the reference has
-  NO CPU RoIAlign: roi_align.py:27-28 raises; CUDA is not compilable here) — parity of this
-  restatement is pinned only by analytic properties (tests/test_oracle_det.py), i.e.
-  "parity unpinned" against an executed reference.
-* ``roi_align_backward`` roi_align_kernel.cu:149-266 (same status; additionally checked as the
+  NO CPU RoIAlign: roi_align.py:27-28 raises).  PINNED: oracle/build_ref.py compiles the
+  reference's own ``ROIAlignForward`` / ``ROIAlignBackward`` templates from that file as host
+  code (oracle/_ref/roi_align_ref.so) and tests/test_oracle_det.py checks this restatement
+  against them (forward 1e-6, backward 1e-4).
+* ``roi_align_backward`` roi_align_kernel.cu:149-266 (pinned as above; additionally checked as the
   exact adjoint of the forward restatement).
 * ``map_roi_levels``     mmdet/models/roi_extractors/single_level.py:54-73
 * ``nms``                mmdet/ops/nms/src/nms_cpu.cpp:5-59 (``>=``) and

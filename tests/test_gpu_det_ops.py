@@ -377,3 +377,30 @@ def test_conv_split_k_matches_single_pass(monkeypatch):
     monkeypatch.delenv('BGS_CONV_SPLITK')
     for a, e in zip(run(), ref):                              # the library's own choice
         assert float((a - e).abs().max()) <= 2e-5 * float(e.abs().max())
+
+
+@pytest.mark.parametrize('out_size', [7, 14])
+def test_roi_align_hip_vs_compiled_reference_kernels(out_size):
+    """HIP RoIAlign forward + backward against the reference's own ROIAlignForward/Backward
+    templates (roi_align_kernel.cu) compiled as host code into oracle/_ref/roi_align_ref.so."""
+    if build_ref.load_roi_align() is None:
+        pytest.skip('oracle/_ref/roi_align_ref.so not available')
+    rs = np.random.RandomState(out_size)
+    H, W, C = 23, 31, 8
+    feat = rs.randn(2, H, W, C).astype(np.float32)
+    K = 50
+    ctr = rs.uniform(-0.1, 1.1, (K, 2)) * np.array([W * 8, H * 8])
+    size = np.exp(rs.uniform(np.log(2), np.log(400), (K, 2)))
+    rois = np.concatenate([rs.randint(0, 2, (K, 1)), ctr - size / 2, ctr + size / 2], 1).astype(np.float32)
+    rois[0] = [0, 5.0, 5.0, 5.0, 5.0]
+    rois[1] = [1, -40.0, -30.0, 20.0, 10.0]
+    rois[2] = [0, W * 8 - 10.0, H * 8 - 12.0, W * 8 + 60.0, H * 8 + 50.0]
+    exp = build_ref.roi_align_reference(feat.transpose(0, 3, 1, 2), rois, 0.125, out_size)
+    # single level with stride 8: finest_scale huge -> every RoI maps to level 0
+    got = BF.roi_align_nhwc([dev(feat)], dev(rois), [8], out_size=out_size, finest_scale=1e9)
+    np.testing.assert_allclose(got.cpu().numpy().transpose(0, 3, 1, 2), exp, rtol=1e-4, atol=1e-5)
+    g = rs.randn(K, out_size, out_size, C).astype(np.float32)
+    eb = build_ref.roi_align_reference_backward(g.transpose(0, 3, 1, 2), rois, 0.125, (2, C, H, W))
+    d = [torch.zeros(2, H, W, C, device=DEV)]
+    BF.roi_align_nhwc_bwd(dev(g), dev(rois), d, [8], finest_scale=1e9)
+    np.testing.assert_allclose(d[0].cpu().numpy().transpose(0, 3, 1, 2), eb, rtol=1e-3, atol=1e-4)

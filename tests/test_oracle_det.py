@@ -109,3 +109,45 @@ def test_roi_align_backward_restatement_is_the_adjoint_of_the_forward():
     lhs = float((out.astype(np.float64) * g).sum())
     rhs = float((feat.astype(np.float64) * dfeat).sum())
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+
+
+# ---------------------------------------------------------------- RoIAlign pinned to the reference
+@pytest.fixture(scope='module')
+def ref_roi():
+    if build_ref.load_roi_align() is None:
+        pytest.skip('oracle/_ref/roi_align_ref.so not built and reference tree absent')
+    return build_ref
+
+
+def _roi_cases(seed, K=40, H=23, W=31):
+    rs = np.random.RandomState(seed)
+    ctr = rs.uniform(-0.1, 1.1, (K, 2)) * np.array([W * 8, H * 8])
+    size = np.exp(rs.uniform(np.log(2), np.log(400), (K, 2)))
+    rois = np.concatenate([rs.randint(0, 2, (K, 1)), ctr - size / 2, ctr + size / 2], 1).astype(np.float32)
+    rois[0] = [0, 5.0, 5.0, 5.0, 5.0]                 # degenerate 1-pixel box
+    rois[1] = [1, -40.0, -30.0, 20.0, 10.0]           # hangs over the top-left corner
+    rois[2] = [0, W * 8 - 10.0, H * 8 - 12.0, W * 8 + 60.0, H * 8 + 50.0]   # over the bottom-right
+    rois[3] = [1, 30.0, 30.0, 10.0, 10.0]             # malformed (x2 < x1): width clamps to 0
+    return rois
+
+
+@pytest.mark.parametrize('out_size', [7, 14])
+def test_roi_align_forward_restatement_vs_compiled_reference(ref_roi, out_size):
+    """oracle.roi_align_forward == the reference's own ROIAlignForward<float> (roi_align_kernel.cu
+    :63-124, compiled as host code by oracle/build_ref.py)."""
+    rs = np.random.RandomState(out_size)
+    feat = rs.randn(2, 23, 31, 6).astype(np.float32)
+    rois = _roi_cases(out_size)
+    exp = ref_roi.roi_align_reference(feat.transpose(0, 3, 1, 2), rois, 0.125, out_size)
+    got = det_oracle.roi_align_forward(feat, rois, 0.125, out_size, out_size, 2)
+    np.testing.assert_allclose(got.transpose(0, 3, 1, 2), exp, rtol=1e-6, atol=1e-6)
+    assert np.abs(exp).max() > 0.1
+
+
+def test_roi_align_backward_restatement_vs_compiled_reference(ref_roi):
+    rs = np.random.RandomState(2)
+    rois = _roi_cases(5, K=25)
+    g = rs.randn(25, 7, 7, 4).astype(np.float32)
+    exp = ref_roi.roi_align_reference_backward(g.transpose(0, 3, 1, 2), rois, 0.125, (2, 4, 23, 31))
+    got = det_oracle.roi_align_backward(g, rois, 0.125, (2, 23, 31, 4), 2)
+    np.testing.assert_allclose(got.transpose(0, 3, 1, 2), exp, rtol=1e-4, atol=1e-5)
