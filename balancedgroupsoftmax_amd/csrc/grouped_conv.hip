@@ -2,12 +2,17 @@
 // mmdet/models/backbones/resnext.py:12-92: groups = 64, 4/8/16/32 channels per group in
 // layer1..4), with the folded eval-mode BN bias and ReLU in the epilogue.
 //
-// A group is a tiny dense conv (cg x cg x 9 MACs per pixel: 144 .. 9216), far below an MFMA tile
-// for cg = 4/8 and < 3 % of the network's flops in total, so this kernel stays on the vector
-// ALUs: one thread = one output pixel x 4 consecutive output channels (always inside one group:
-// cg % 4 == 0); a wave covers 64 consecutive channel quads of a pixel, so the input loads of a
-// group are shared by its cg/4 threads through the L1 and the weight rows [co][r][s][0..cg) are
-// contiguous 16-byte loads that stay cache-resident across pixels.
+// v_mfma_f32_16x16x4_f32 per (64 output pixels x 16 output channels) wave tile: a 16-channel
+// output tile is one group (cg = 16), half a group (cg = 32: two K halves) or several whole
+// groups (cg = 4 / 8: the B operand is block-diagonal — lanes whose input quad belongs to
+// another group feed zeros; 4x / 2x redundant MACs on layers that are < 1 % of the flops).
+// Per filter tap every lane makes ONE 16-byte load of the input (pixel i, channel quad j) per
+// 16-pixel sub-tile and ONE 16-byte load of the weights (output channel n, quad j); the four
+// floats are the A / B operands of four consecutive MFMAs (k index = lane group j):
+//     acc[a] += x[pix(a,i)+tap][16*slab + 4j + u] * w[n][tap][.. 4j + u ..],  u = 0..3
+// A workgroup = 4 waves = the same 64 pixels x 4 neighbouring channel tiles (input reuse in L1).
+// (First version: one thread per pixel x 4 channels on the vector ALUs re-read its 4 x 9 x cg
+//  weights per pixel: 0.69 ms per layer3 conv = 3.6 TFLOP/s, 47 % of the X101 step.)
 #include "bgs_common.h"
 
 namespace {
@@ -15,50 +20,85 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int CG>
-__global__ __launch_bounds__(256) void grouped_conv3x3_kernel(
+__global__ __launch_bounds__(256) void grouped_conv3x3_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, int stride, int relu) {
-  const int quads = C >> 2;
-  const size_t total = (size_t)N * Ho * Wo * quads;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int q = (int)(e % quads);
-    size_t t = e / quads;
-    const int wo = (int)(t % Wo);
-    t /= Wo;
-    const int ho = (int)(t % Ho);
-    const int n = (int)(t / Ho);
-    const int co = q * 4;
-    const int g0 = (co / CG) * CG;            // first input channel of this group
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int KH = CG >= 16 ? CG / 16 : 1;       // 16-channel K slabs per tap
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, j = lane >> 4;
+  const int M = N * Ho * Wo;
+  const int m0 = blockIdx.x * 64;
+  const int ct = blockIdx.y * 4 + wave;            // 16-channel output tile of this wave
+  if (ct * 16 >= C) return;
+  const int n_out = ct * 16 + i;                   // this lane's B column (output channel)
+  // input channel slab read by this tile: the group(s) of its 16 output channels
+  const int grp_first = (ct * 16) / CG;            // first group touched
+  const int in0 = (CG >= 16) ? grp_first * CG : ct * 16;   // first input channel of the slab(s)
+  // block-diagonal mask for CG < 16: lane's input quad j belongs to group (in0 + 4j) / CG
+  bool w_live = true;
+  int w_off = 4 * j;                               // offset of the quad inside the group's cg inputs
+  if (CG < 16) {
+    const int g_in = (in0 + 4 * j) / CG, g_out = n_out / CG;
+    w_live = g_in == g_out;
+    w_off = (in0 + 4 * j) - g_in * CG;
+  }
+  // geometry of the 4 pixels this lane feeds as A rows (sub-tile a, row i)
+  int hi0[4], wi0[4];
+  const float* xb[4];
+  bool ok[4];
+  const int hw = Ho * Wo;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int hi = ho * stride - 1 + r;
-      if (hi < 0 || hi >= H) continue;
+  for (int a = 0; a < 4; ++a) {
+    const int m = m0 + a * 16 + i;
+    ok[a] = m < M;
+    const int mm = ok[a] ? m : 0;
+    const int n = mm / hw, rem = mm - n * hw;
+    const int ho = rem / Wo, wo = rem - ho * Wo;
+    hi0[a] = ho * stride - 1;
+    wi0[a] = wo * stride - 1;
+    xb[a] = x + (size_t)n * H * W * C;
+  }
+  f32x4 acc[4];
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int wi = wo * stride - 1 + s;
-        if (wi < 0 || wi >= W) continue;
-        const float* xp = x + (((size_t)n * H + hi) * W + wi) * C + g0;
-        const float* wp = w + ((size_t)co * 9 + r * 3 + s) * CG;
+  for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* wrow = w + (size_t)n_out * 9 * CG;
 #pragma unroll
-        for (int c = 0; c < CG; c += 4) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + c);
+  for (int r = 0; r < 3; ++r) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + (size_t)k * 9 * CG + c);
-            acc[k] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
-          }
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (w_live) bv = *reinterpret_cast<const f32x4*>(wrow + (r * 3 + s) * CG + kh * 16 + w_off);
+        f32x4 av[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int hi = hi0[a] + r, wi = wi0[a] + s;
+          av[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (ok[a] && hi >= 0 && hi < H && wi >= 0 && wi < W)
+            av[a] = *reinterpret_cast<const f32x4*>(xb[a] + ((size_t)hi * W + wi) * C + in0 +
+                                                    kh * 16 + 4 * j);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][u], bv[u], acc[a], 0, 0, 0);
       }
     }
-    if (bias) acc += *reinterpret_cast<const f32x4*>(bias + co);
-    if (relu) {
-      acc[0] = fmaxf(acc[0], 0.f);
-      acc[1] = fmaxf(acc[1], 0.f);
-      acc[2] = fmaxf(acc[2], 0.f);
-      acc[3] = fmaxf(acc[3], 0.f);
+  }
+  // D layout of the 16x16 MFMA: column = lane & 15 (output channel), rows 4*(lane>>4) + t
+  const float bsv = bias ? bias[n_out] : 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int m = m0 + a * 16 + 4 * j + t;
+      if (m >= M) continue;
+      float v = acc[a][t] + bsv;
+      if (relu) v = fmaxf(v, 0.f);
+      y[(size_t)m * C + n_out] = v;
     }
-    *reinterpret_cast<f32x4*>(y + e * 4) = acc;
   }
 }
 
@@ -70,18 +110,17 @@ extern "C" int bgs_grouped_conv3x3_nhwc_f32(const float* x, const float* w, cons
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || groups <= 0 || (stride != 1 && stride != 2))
     return BGS_ERR_INVALID_ARG;
   if (!x || !w || !y) return BGS_ERR_INVALID_ARG;
-  if (C % groups != 0) return BGS_ERR_INVALID_ARG;
+  if (C % groups != 0 || C % 16 != 0) return BGS_ERR_UNSUPPORTED;
   const int cg = C / groups;
-  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias) % 16 != 0)
-    return BGS_ERR_INVALID_ARG;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) % 16 != 0) return BGS_ERR_INVALID_ARG;
   const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-  const size_t total = (size_t)N * Ho * Wo * (C / 4);
-  size_t grid = (total + 255) / 256;
-  if (grid > 65536) grid = 65536;
+  const long long M = (long long)N * Ho * Wo;
+  if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)((M + 63) / 64), (unsigned)((C / 16 + 3) / 4));
   hipStream_t st = (hipStream_t)stream;
-#define BGS_GC_LAUNCH(CG_)                                                                       \
-  hipLaunchKernelGGL((grouped_conv3x3_kernel<CG_>), dim3((unsigned)grid), dim3(256), 0, st, x, w, \
-                     bias, y, N, H, W, C, Ho, Wo, stride, relu)
+#define BGS_GC_LAUNCH(CG_)                                                                        \
+  hipLaunchKernelGGL((grouped_conv3x3_mfma_kernel<CG_>), grid, dim3(256), 0, st, x, w, bias, y, N, \
+                     H, W, C, Ho, Wo, stride, relu)
   if (cg == 4) BGS_GC_LAUNCH(4);
   else if (cg == 8) BGS_GC_LAUNCH(8);
   else if (cg == 16) BGS_GC_LAUNCH(16);
