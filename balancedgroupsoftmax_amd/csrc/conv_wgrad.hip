@@ -252,12 +252,24 @@ WgradPlan plan_wgrad(int M, int Cout, int K) {
   }
   const int bm = pl.tile == 22 ? 128 : 64;
   const long long tiles = (long long)((Cout + bm - 1) / bm) * ((K + bm - 1) / bm);
-  // aim at ~4 workgroups per CU (1024 in flight) with at least 512 reduction rows each
-  long long splits = (1024 + tiles - 1) / tiles;
-  const long long max_splits = (M + 511) / 512;
+  // Split count from the per-layer sweep of the cfg[1] shapes (tools/wgrad_sweep.py,
+  // profiles/r2q_wgrad_sweep.txt): aim at ~2300 workgroups (9 per CU), but keep >= 512 reduction
+  // rows per slice on the big maps (>= 256 on maps below 16k pixels, where there are few tiles
+  // to begin with), never more than 128 slices (partial-sum traffic), and at most 2 when the
+  // output alone already gives >= 256 tiles (fc1).
+  long long splits = (2304 + tiles - 1) / tiles;
+  const long long min_rows = M >= 16384 ? 512 : 256;
+  const long long max_splits = (M + min_rows - 1) / min_rows;
   if (splits > max_splits) splits = max_splits;
+  if (splits > 128) splits = 128;
+  if (tiles >= 256 && splits > 2) splits = 2;
+  // few rounds of workgroups: a total just above a multiple of the 256 CUs costs a whole extra
+  // round (l2.c1: 264 workgroups 0.125 ms, 256 workgroups 0.104 ms) -> round down
+  if (tiles * splits > 256 && tiles * splits < 2048) {
+    const long long rounded = (tiles * splits / 256) * 256 / tiles;
+    if (rounded >= 1) splits = rounded;
+  }
   if (splits < 1) splits = 1;
-  if (splits > 512) splits = 512;
   if (const char* e = getenv("BGS_WGRAD_SPLITS")) {
     const int f = atoi(e);
     if (f >= 1 && f <= 4096) splits = f;
