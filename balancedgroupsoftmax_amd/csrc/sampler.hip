@@ -1,0 +1,148 @@
+// RandomSampler for the RPN (mmdet/core/bbox/samplers/base_sampler.py:35-78 +
+// random_sampler.py:19-53) in ONE launch per batch: from the assigner's result for all 268,569
+// anchors of an image pick exactly min(int(num * pos_fraction), #pos) positives and
+// min(num - #pos_sampled [, neg_pos_ub * max(#pos_sampled, 1)], #neg) negatives, uniformly without
+// replacement, and emit them as byte masks.  The reference shuffles index lists with numpy on the
+// host (4 synchronisations per image); the tensor-op form of this package (assign.py) needed a key
+// tensor, two top-k's over 268k int64 keys and a dozen element-wise launches per image.
+//
+// One 1024-thread workgroup per image.  Every anchor gets a 32-bit key from a BIJECTIVE mixer of
+// (index + per-draw offset): keys of different anchors differ, so "the k anchors with the smallest
+// keys" is a uniform k-subset with no ties to break; the k-th smallest key is found by a 3-pass
+// radix select (11 + 11 + 10 bits) with LDS histograms (uniform keys -> no bin contention).
+#include "bgs_common.h"
+
+namespace {
+
+constexpr int kThreadsS = 1024;
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {   // lowbias32: every step is a bijection
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+// k-th smallest key (1-based k) among the anchors of class `want` (1: assigned > 0, 0: == 0).
+// Returns through shared memory; all threads call it.  k >= 1 and k <= count of that class.
+__device__ uint32_t kth_smallest_key(const int* __restrict__ assigned, int A, int want, int k,
+                                     uint32_t offset, int* hist, int* s_tmp) {
+  const int tid = threadIdx.x;
+  uint32_t prefix = 0, pmask = 0;
+  const int shifts[3] = {21, 10, 0};
+  const int bits[3] = {11, 11, 10};
+  int kk = k;
+  for (int pass = 0; pass < 3; ++pass) {
+    const int nb = 1 << bits[pass];
+    for (int b = tid; b < 2048; b += kThreadsS) hist[b] = 0;
+    __syncthreads();
+    for (int i = tid; i < A; i += kThreadsS) {
+      const int a = assigned[i];
+      const bool in = want ? (a > 0) : (a == 0);
+      if (!in) continue;
+      const uint32_t key = mix32((uint32_t)i + offset);
+      if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & (nb - 1)], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {   // one wave walks the bins upwards until the running count reaches kk
+      int acc = 0, found = -1, before = 0;
+      for (int base = 0; base < nb && found < 0; base += 64) {
+        const int c = hist[base + tid];
+        int inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int t = __shfl_up(inc, off, 64);
+          if (tid >= off) inc += t;
+        }
+        const int total = __shfl(inc, 63, 64);
+        const unsigned long long m = __ballot(acc + inc >= kk);
+        if (m) {
+          const int lane = __ffsll((long long)m) - 1;
+          found = base + lane;
+          before = acc + __shfl(inc - c, lane, 64);
+        }
+        acc += total;
+      }
+      if (tid == 0) {
+        s_tmp[0] = found;
+        s_tmp[1] = kk - before;
+      }
+    }
+    __syncthreads();
+    prefix |= (uint32_t)s_tmp[0] << shifts[pass];
+    pmask |= (uint32_t)(nb - 1) << shifts[pass];
+    kk = s_tmp[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+__global__ __launch_bounds__(kThreadsS) void sample_pos_neg_kernel(
+    const int* __restrict__ assigned_all, int A, int num, int n_exp_pos, float neg_pos_ub,
+    uint64_t seed, const long long* __restrict__ draw, uint8_t* __restrict__ pos_mask,
+    uint8_t* __restrict__ neg_mask) {
+  __shared__ int hist[2048];
+  __shared__ int s_tmp[2];
+  __shared__ int s_cnt[2];
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int* assigned = assigned_all + (size_t)n * A;
+  uint8_t* pm = pos_mask + (size_t)n * A;
+  uint8_t* nm = neg_mask + (size_t)n * A;
+  // per (seed, draw, image) offset of the bijection's argument
+  const uint64_t d = draw ? (uint64_t)draw[0] : 0ull;
+  uint64_t h = seed + 0x9E3779B97F4A7C15ull * (d + 1ull) + 0xD1B54A32D192ED03ull * ((uint64_t)n + 1ull);
+  h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27;
+  const uint32_t offset = (uint32_t)(h >> 16);
+
+  if (tid < 2) s_cnt[tid] = 0;
+  __syncthreads();
+  int c_pos = 0, c_neg = 0;
+  for (int i = tid; i < A; i += kThreadsS) {
+    const int a = assigned[i];
+    c_pos += a > 0;
+    c_neg += a == 0;
+  }
+  c_pos = bgs::wave_sum_i(c_pos);
+  c_neg = bgs::wave_sum_i(c_neg);
+  if ((tid & 63) == 0) {
+    atomicAdd(&s_cnt[0], c_pos);
+    atomicAdd(&s_cnt[1], c_neg);
+  }
+  __syncthreads();
+  const int n_pos = s_cnt[0], n_neg = s_cnt[1];
+  const int k_pos = min(n_exp_pos, n_pos);
+  int n_exp_neg = num - k_pos;
+  if (neg_pos_ub >= 0.f) {
+    const int ub = (int)(neg_pos_ub * (float)max(k_pos, 1));
+    n_exp_neg = min(n_exp_neg, ub);
+  }
+  const int k_neg = max(0, min(n_exp_neg, n_neg));
+  // thresholds (only when a strict subset is wanted)
+  uint32_t thr_pos = 0xffffffffu, thr_neg = 0xffffffffu;
+  if (k_pos > 0 && k_pos < n_pos) thr_pos = kth_smallest_key(assigned, A, 1, k_pos, offset, hist, s_tmp);
+  if (k_neg > 0 && k_neg < n_neg) thr_neg = kth_smallest_key(assigned, A, 0, k_neg, offset, hist, s_tmp);
+  for (int i = tid; i < A; i += kThreadsS) {
+    const int a = assigned[i];
+    const uint32_t key = mix32((uint32_t)i + offset);
+    pm[i] = (a > 0 && k_pos > 0 && key <= thr_pos) ? 1 : 0;
+    nm[i] = (a == 0 && k_neg > 0 && key <= thr_neg) ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+extern "C" int bgs_sample_pos_neg(const int* assigned, int N, int A, int num, float pos_fraction,
+                                  float neg_pos_ub, uint64_t seed, const long long* draw_counter,
+                                  uint8_t* pos_mask, uint8_t* neg_mask, bgs_stream_t stream) {
+  if (N < 0 || A <= 0 || num <= 0 || !(pos_fraction >= 0.f && pos_fraction <= 1.f))
+    return BGS_ERR_INVALID_ARG;
+  if (N == 0) return BGS_OK;
+  if (!assigned || !pos_mask || !neg_mask) return BGS_ERR_INVALID_ARG;
+  const int n_exp_pos = (int)((double)num * (double)pos_fraction);
+  hipLaunchKernelGGL(sample_pos_neg_kernel, dim3(N), dim3(kThreadsS), 0, (hipStream_t)stream,
+                     assigned, A, num, n_exp_pos, neg_pos_ub, seed, draw_counter, pos_mask, neg_mask);
+  BGS_RETURN_LAUNCH_STATUS();
+}

@@ -766,6 +766,29 @@ def random_keys(n, device):
     return out
 
 
+def sample_pos_neg(assigned, num, pos_fraction, neg_pos_ub=-1):
+    """RPN RandomSampler for a whole batch in one launch: ``assigned [N, A]`` int32 ->
+    ``(pos_mask, neg_mask) [N, A]`` uint8 with the exact counts of base_sampler.py:56-73."""
+    _require_cuda(assigned)
+    lib = capi.load()
+    assert assigned.dim() == 2 and assigned.dtype == torch.int32 and assigned.is_contiguous()
+    N, A = assigned.shape
+    dev = assigned.device
+    ctr = _KEY_COUNTERS.get(dev.index)
+    if ctr is None:
+        ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        _KEY_COUNTERS[dev.index] = ctr
+    ctr.add_(1)
+    pos = torch.empty((N, A), dtype=torch.uint8, device=dev)
+    neg = torch.empty((N, A), dtype=torch.uint8, device=dev)
+    seed = (torch.initial_seed() * 0x9E3779B1 + 0x2545F491) & 0xFFFFFFFFFFFFFFFF
+    rc = lib.bgs_sample_pos_neg(capi.ptr(assigned), N, A, int(num), float(pos_fraction),
+                                float(neg_pos_ub), seed, capi.ptr(ctr), capi.ptr(pos), capi.ptr(neg),
+                                capi.current_stream(dev))
+    capi.check('bgs_sample_pos_neg', rc)
+    return pos, neg
+
+
 def decode_proposals(level_outs, level_counts, num_anchors, anchors, top_idx, top_logit, img_hw,
                      means, stds, wh_ratio_clip=16 / 1000):
     """``[N,L,nmax,5]`` decoded + clamped proposals (score = sigmoid of the top logit)."""

@@ -277,14 +277,18 @@ class RPNHead(nn.Module):
             raise NotImplementedError('gt_max_assign_all=False')
         assigned = BF.iou_assign(anchors, gt_cat, offs, ac.pos_iou_thr, ac.neg_iou_thr,
                                  ac.get('min_pos_iou', 0.0), valid=inside, shared_boxes=True)
-        pos, neg = [], []
-        for i in range(len(img_metas)):
-            p, n = A.sample_pos_neg_masks(assigned[i], sc.num, sc.pos_fraction,
-                                          sc.get('neg_pos_ub', -1), generator)
-            pos.append(p)
-            neg.append(n)
-        lc, lb, _ = BF.rpn_loss(self._fused, self.num_anchors, anchors, assigned,
-                                torch.stack(pos).to(torch.uint8), torch.stack(neg).to(torch.uint8),
+        if generator is None:     # one launch for the batch (csrc/sampler.hip)
+            pos_m, neg_m = BF.sample_pos_neg(assigned, sc.num, sc.pos_fraction,
+                                             sc.get('neg_pos_ub', -1))
+        else:                     # explicit generator (reproducible tests): tensor-op sampler
+            pos, neg = [], []
+            for i in range(len(img_metas)):
+                p, n = A.sample_pos_neg_masks(assigned[i], sc.num, sc.pos_fraction,
+                                              sc.get('neg_pos_ub', -1), generator)
+                pos.append(p)
+                neg.append(n)
+            pos_m, neg_m = torch.stack(pos).to(torch.uint8), torch.stack(neg).to(torch.uint8)
+        lc, lb, _ = BF.rpn_loss(self._fused, self.num_anchors, anchors, assigned, pos_m, neg_m,
                                 gt_cat, offs, self.target_means, self.target_stds,
                                 self.loss_bbox.beta, cfg.pos_weight, self.loss_cls.loss_weight,
                                 self.loss_bbox.loss_weight)

@@ -305,6 +305,16 @@ int bgs_rpn_loss(const float* const* host_level_outs, const int* host_level_hw, 
                  float loss_weight_bbox, float* loss_cls_out, float* loss_bbox_out,
                  float* num_total_out, void* workspace, bgs_stream_t stream);
 
+/* RandomSampler of the RPN in one launch (mmdet/core/bbox/samplers/base_sampler.py:35-78,
+ *   random_sampler.py:19-53): assigned [N, A] int32 (-1 ignore / 0 negative / > 0 positive) ->
+ *   pos_mask, neg_mask [N, A] uint8 with EXACTLY min(int(num * pos_fraction), #pos) positives and
+ *   min(num - #pos_sampled [, int(neg_pos_ub * max(#pos_sampled, 1)) when neg_pos_ub >= 0], #neg)
+ *   negatives per image, uniformly without replacement (radix select over bijective 32-bit
+ *   keys of (seed, *draw_counter, image, anchor)).  draw_counter: device int64 [1] or NULL. */
+int bgs_sample_pos_neg(const int* assigned, int N, int A, int num, float pos_fraction,
+                       float neg_pos_ub, uint64_t seed, const long long* draw_counter,
+                       uint8_t* pos_mask, uint8_t* neg_mask, bgs_stream_t stream);
+
 /* Sampling keys for RandomSampler (mmdet/core/bbox/samplers/random_sampler.py:19-53) drawn on the
  *   device: out[i] = 62-bit splitmix64(seed, *draw_counter, i), i < n.  draw_counter: device int64
  *   [1] (or NULL = 0) that the caller advances between draws — constant kernel arguments under

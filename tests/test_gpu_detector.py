@@ -552,3 +552,41 @@ def test_full_training_iteration_selectp0(tmp_path):
         gsum = float(dict(model.named_parameters())[n].grad.abs().sum())
         assert gsum > 0, n
     assert not torch.equal(w0, model.backbone.layer3[2].conv2.weight)
+
+
+def test_rpn_sampler_kernel_counts_uniformity_and_reproducibility():
+    """bgs_sample_pos_neg: exact counts of base_sampler.py:56-73 (incl. neg_pos_ub and the
+    fewer-than-asked cases), subsets of the right classes, fresh draws per call, uniform."""
+    from balancedgroupsoftmax_amd import functional as BF
+    g = torch.Generator().manual_seed(0)
+    A_ = 268569
+    assigned = torch.zeros(4, A_, dtype=torch.int32)
+    assigned[:, ::3] = -1                                        # ignored
+    assigned[0, torch.randperm(A_, generator=g)[:57]] = 5        # 57 positives (< 128)
+    assigned[1, torch.randperm(A_, generator=g)[:900]] = 2       # 900 positives (> 128)
+    assigned[2] = -1
+    assigned[2, :40] = 1                                          # 40 pos, 0 neg
+    assigned[3, torch.randperm(A_, generator=g)[:10]] = 7
+    a = assigned.to(DEV)
+    pos, neg = BF.sample_pos_neg(a, 256, 0.5)
+    pos, neg = pos.cpu().bool(), neg.cpu().bool()
+    assert pos.sum(1).tolist() == [57, 128, 40, 10]
+    assert neg.sum(1).tolist() == [256 - 57, 128, 0, 246]
+    assert not (pos & ~(assigned > 0)).any() and not (neg & ~(assigned == 0)).any()
+    p2, n2 = BF.sample_pos_neg(a, 256, 0.5)
+    assert not torch.equal(n2.cpu().bool(), neg)                 # the draw counter advanced
+    assert torch.equal(p2.cpu().bool()[0], pos[0])               # all 57 positives every time
+    # neg_pos_ub = 1: at most as many negatives as sampled positives (>= 1)
+    _, n3 = BF.sample_pos_neg(a, 256, 0.5, neg_pos_ub=1)
+    assert n3.cpu().sum(1).tolist() == [57, 128, 0, 10]
+    # uniformity: over many draws every negative of a small problem is picked about equally often
+    small = torch.zeros(1, 4000, dtype=torch.int32, device=DEV)
+    hits = torch.zeros(4000, device=DEV)
+    for _ in range(400):
+        _, nn = BF.sample_pos_neg(small, 256, 0.5)
+        hits += nn[0].float()
+    freq = hits.cpu() / 400.0                                     # expected 256 / 4000 = 0.064
+    assert abs(float(freq.mean()) - 0.064) < 1e-6
+    # binomial(400, 0.064): sigma = 0.012; the extremes of 4000 cells sit near +-3.7 sigma
+    assert float(freq.min()) > 0.005 and float(freq.max()) < 0.14
+    assert abs(float(freq.std()) - 0.01224) < 0.002              # binomial spread, not clumped
