@@ -99,6 +99,8 @@ SIGNATURES = {
                                          ctypes.c_float, c_f32p, c_f32p, c_f32p, c_ptr]),
     'bgs_sample_pos_neg': (ctypes.c_int, [c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                           ctypes.c_float, ctypes.c_uint64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'bgs_sample_rois': (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                       ctypes.c_uint64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'bgs_random_keys': (ctypes.c_int, [ctypes.c_uint64, c_ptr, ctypes.c_int, c_ptr, c_ptr]),
     'bgs_decode_proposals': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, c_f32p,
                                             c_ptr, c_f32p, ctypes.c_int, c_ptr, c_ptr, c_ptr,

@@ -146,3 +146,122 @@ extern "C" int bgs_sample_pos_neg(const int* assigned, int N, int A, int num, fl
                      assigned, A, num, n_exp_pos, neg_pos_ub, seed, draw_counter, pos_mask, neg_mask);
   BGS_RETURN_LAUNCH_STATUS();
 }
+
+// ---------------------------------------------------------------------------------------------
+// RandomSampler for the RoI head (two_stage.py:192-210 with add_gt_as_proposals): per image a
+// FIXED-SIZE index list into the candidate array (GT boxes first, then the proposals): the sampled
+// positives (at most int(num * pos_fraction), a uniform subset when there are more) first, then
+// uniformly sampled negatives, then padding (index of slot 0, valid = 0) when fewer than `num`
+// candidates exist.  One workgroup per image sorts (class, bijective key) composites of the
+// <= 4096 candidates in LDS (bitonic) — replaces a key tensor, two top-k's and ~15 element-wise
+// launches per image of the tensor-op form (assign.sample_fixed).
+namespace {
+
+constexpr int kMaxCand = 4096;
+constexpr int kMaxImgsS = 16;
+
+struct CandTable {
+  const int* assigned[kMaxImgsS];   // [count] int32: -1 / 0 / gt index + 1
+  int count[kMaxImgsS];
+};
+
+__global__ __launch_bounds__(kThreadsS) void sample_rois_kernel(CandTable T, int num, int n_exp_pos,
+                                                                uint64_t seed,
+                                                                const long long* __restrict__ draw,
+                                                                long long* __restrict__ inds,
+                                                                uint8_t* __restrict__ is_pos,
+                                                                uint8_t* __restrict__ valid) {
+  __shared__ unsigned long long buf[kMaxCand];
+  __shared__ int s_cnt[2];
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int A = T.count[n];
+  const int* assigned = T.assigned[n];
+  const uint64_t d = draw ? (uint64_t)draw[0] : 0ull;
+  uint64_t h = seed + 0x9E3779B97F4A7C15ull * (d + 1ull) + 0xD1B54A32D192ED03ull * ((uint64_t)n + 1ull);
+  h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27;
+  const uint32_t offset = (uint32_t)(h >> 16);
+  if (tid < 2) s_cnt[tid] = 0;
+  __syncthreads();
+  // composite = class (0 pos, 1 neg, 2 other / padding) : 2 | key : 32 | index : 16 .. unique
+  int c_pos = 0, c_neg = 0;
+  for (int i = tid; i < kMaxCand; i += kThreadsS) {
+    unsigned long long comp = ~0ull;
+    if (i < A) {
+      const int a = assigned[i];
+      const unsigned long long cls = a > 0 ? 0ull : (a == 0 ? 1ull : 2ull);
+      comp = (cls << 60) | ((unsigned long long)mix32((uint32_t)i + offset) << 16) |
+             (unsigned long long)i;
+      c_pos += a > 0;
+      c_neg += a == 0;
+    }
+    buf[i] = comp;
+  }
+  c_pos = bgs::wave_sum_i(c_pos);
+  c_neg = bgs::wave_sum_i(c_neg);
+  if ((tid & 63) == 0) {
+    atomicAdd(&s_cnt[0], c_pos);
+    atomicAdd(&s_cnt[1], c_neg);
+  }
+  __syncthreads();
+  // bitonic sort, ascending, kMaxCand composites (2 compare-exchanges per thread and stage)
+  for (int size = 2; size <= kMaxCand; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int j = tid; j < kMaxCand / 2; j += kThreadsS) {
+        const int lo = 2 * j - (j & (stride - 1));
+        const int hi = lo + stride;
+        const bool asc = ((lo & size) == 0);
+        const unsigned long long a = buf[lo], b = buf[hi];
+        if ((a > b) == asc) {
+          buf[lo] = b;
+          buf[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int n_pos = s_cnt[0], n_neg = s_cnt[1];
+  const int k_pos = min(n_exp_pos, n_pos);
+  const long long first = (long long)(buf[0] & 0xffffull);
+  for (int j = tid; j < num; j += kThreadsS) {
+    long long idx = first;
+    uint8_t p = 0, v = 0;
+    if (j < k_pos) {
+      idx = (long long)(buf[j] & 0xffffull);
+      p = 1;
+      v = 1;
+    } else if (j - k_pos < n_neg) {
+      idx = (long long)(buf[n_pos + (j - k_pos)] & 0xffffull);
+      v = 1;
+    }
+    inds[(size_t)n * num + j] = idx;
+    is_pos[(size_t)n * num + j] = p;
+    valid[(size_t)n * num + j] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int bgs_sample_rois(const int* const* host_assigned, const int* host_counts, int N,
+                               int num, float pos_fraction, uint64_t seed,
+                               const long long* draw_counter, long long* inds, uint8_t* is_pos,
+                               uint8_t* valid, bgs_stream_t stream) {
+  if (N < 0 || N > kMaxImgsS || num <= 0 || !(pos_fraction >= 0.f && pos_fraction <= 1.f))
+    return BGS_ERR_INVALID_ARG;
+  if (N == 0) return BGS_OK;
+  if (!host_assigned || !host_counts || !inds || !is_pos || !valid) return BGS_ERR_INVALID_ARG;
+  CandTable T;
+  for (int i = 0; i < kMaxImgsS; ++i) {
+    T.assigned[i] = nullptr;
+    T.count[i] = 0;
+  }
+  for (int i = 0; i < N; ++i) {
+    if (host_counts[i] <= 0 || host_counts[i] > kMaxCand || !host_assigned[i]) return BGS_ERR_UNSUPPORTED;
+    T.assigned[i] = host_assigned[i];
+    T.count[i] = host_counts[i];
+  }
+  const int n_exp_pos = (int)((double)num * (double)pos_fraction);
+  hipLaunchKernelGGL(sample_rois_kernel, dim3(N), dim3(kThreadsS), 0, (hipStream_t)stream, T, num,
+                     n_exp_pos, seed, draw_counter, inds, is_pos, valid);
+  BGS_RETURN_LAUNCH_STATUS();
+}

@@ -124,11 +124,22 @@ class TwoStageDetector(nn.Module):
                 G = gt_bboxes[i].size(0)
                 b = torch.cat([gt_bboxes[i][:, :4].float(), b], 0)
                 a = torch.cat([torch.arange(1, G + 1, device=a.device, dtype=torch.int32), a])
-            inds, _, valid = A.sample_fixed(a, sc.num, sc.pos_fraction, generator)
             boxes_l.append(b.contiguous())
             assigned_l.append(a.contiguous())
-            inds_l.append(inds.contiguous())
-            valid_l.append(valid)
+            if generator is not None:      # reproducible tests: the tensor-op sampler
+                inds, _, valid = A.sample_fixed(a, sc.num, sc.pos_fraction, generator)
+                inds_l.append(inds.contiguous())
+                valid_l.append(valid)
+        if generator is None and all(a.numel() <= 4096 for a in assigned_l):
+            # one launch for the batch (csrc/sampler.hip: sort of (class, random key) composites)
+            inds_all, _, valid_all = BF.sample_rois(assigned_l, sc.num, sc.pos_fraction)
+            inds_l = [inds_all[i] for i in range(N)]
+            valid_l = [valid_all[i].bool() for i in range(N)]
+        elif generator is None:
+            for a in assigned_l:
+                inds, _, valid = A.sample_fixed(a, sc.num, sc.pos_fraction, None)
+                inds_l.append(inds.contiguous())
+                valid_l.append(valid)
         # gt index of every sampled RoI (pos_assigned_gt_inds for the mask targets), -1 = none
         self._sampled_gt_inds = torch.stack(
             [assigned_l[i].gather(0, inds_l[i]).to(torch.int32) - 1 for i in range(N)])

@@ -789,6 +789,33 @@ def sample_pos_neg(assigned, num, pos_fraction, neg_pos_ub=-1):
     return pos, neg
 
 
+def sample_rois(assigned_list, num, pos_fraction):
+    """RoI-head RandomSampler for a batch: per image ``assigned [A_n]`` int32 (candidates = GT
+    boxes then proposals) -> ``inds [N, num]`` int64 (positives first), ``is_pos``, ``valid``
+    ``[N, num]`` uint8.  One launch; ``A_n <= 4096``."""
+    _require_cuda(*assigned_list)
+    lib = capi.load()
+    N = len(assigned_list)
+    dev = assigned_list[0].device
+    for a in assigned_list:
+        assert a.dtype == torch.int32 and a.is_contiguous() and a.dim() == 1
+    ctr = _KEY_COUNTERS.get(dev.index)
+    if ctr is None:
+        ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        _KEY_COUNTERS[dev.index] = ctr
+    ctr.add_(1)
+    inds = torch.empty((N, num), dtype=torch.int64, device=dev)
+    is_pos = torch.empty((N, num), dtype=torch.uint8, device=dev)
+    valid = torch.empty((N, num), dtype=torch.uint8, device=dev)
+    seed = (torch.initial_seed() * 0x9E3779B1 + 0x68E31DA4) & 0xFFFFFFFFFFFFFFFF
+    rc = lib.bgs_sample_rois(_c_ptr_array(assigned_list),
+                             _c_int_array([int(a.numel()) for a in assigned_list]), N, int(num),
+                             float(pos_fraction), seed, capi.ptr(ctr), capi.ptr(inds),
+                             capi.ptr(is_pos), capi.ptr(valid), capi.current_stream(dev))
+    capi.check('bgs_sample_rois', rc)
+    return inds, is_pos, valid
+
+
 def decode_proposals(level_outs, level_counts, num_anchors, anchors, top_idx, top_logit, img_hw,
                      means, stds, wh_ratio_clip=16 / 1000):
     """``[N,L,nmax,5]`` decoded + clamped proposals (score = sigmoid of the top logit)."""

@@ -315,6 +315,16 @@ int bgs_sample_pos_neg(const int* assigned, int N, int A, int num, float pos_fra
                        float neg_pos_ub, uint64_t seed, const long long* draw_counter,
                        uint8_t* pos_mask, uint8_t* neg_mask, bgs_stream_t stream);
 
+/* RandomSampler of the RoI head (two_stage.py:192-210; add_gt_as_proposals candidates = GT boxes
+ *   followed by the proposals): host_assigned [N] HOST array of device pointers to each image's
+ *   assignment vector (int32, host_counts[n] <= 4096 entries); per image inds [num] int64 into
+ *   that vector: sampled positives first (<= int(num * pos_fraction), a uniform subset if there
+ *   are more), then uniformly sampled negatives, then padding (valid = 0).  is_pos, valid
+ *   [N, num] uint8. */
+int bgs_sample_rois(const int* const* host_assigned, const int* host_counts, int N, int num,
+                    float pos_fraction, uint64_t seed, const long long* draw_counter, long long* inds,
+                    uint8_t* is_pos, uint8_t* valid, bgs_stream_t stream);
+
 /* Sampling keys for RandomSampler (mmdet/core/bbox/samplers/random_sampler.py:19-53) drawn on the
  *   device: out[i] = 62-bit splitmix64(seed, *draw_counter, i), i < n.  draw_counter: device int64
  *   [1] (or NULL = 0) that the caller advances between draws — constant kernel arguments under

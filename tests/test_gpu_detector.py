@@ -590,3 +590,41 @@ def test_rpn_sampler_kernel_counts_uniformity_and_reproducibility():
     # binomial(400, 0.064): sigma = 0.012; the extremes of 4000 cells sit near +-3.7 sigma
     assert float(freq.min()) > 0.005 and float(freq.max()) < 0.14
     assert abs(float(freq.std()) - 0.01224) < 0.002              # binomial spread, not clumped
+
+
+def test_roi_sampler_kernel_order_counts_and_padding():
+    """bgs_sample_rois: positives first (<= int(num * pos_fraction)), then negatives, padding
+    flagged invalid; indices unique, of the right class, and a fresh draw every call."""
+    from balancedgroupsoftmax_amd import functional as BF
+    g = torch.Generator().manual_seed(1)
+    a0 = torch.zeros(2020, dtype=torch.int32)
+    a0[torch.randperm(2020, generator=g)[:300]] = 3          # 300 positives (> 128)
+    a0[torch.randperm(2020, generator=g)[:100]] = -1
+    a1 = torch.zeros(2007, dtype=torch.int32)
+    a1[:7] = torch.arange(1, 8, dtype=torch.int32)           # only the 7 GT rows are positive
+    a2 = torch.full((300,), -1, dtype=torch.int32)           # fewer candidates than num
+    a2[:40] = 0
+    a2[40:50] = 2
+    al = [a0.to(DEV), a1.to(DEV), a2.to(DEV)]
+    inds, is_pos, valid = BF.sample_rois(al, 512, 0.25)
+    for n, a in enumerate([a0, a1, a2]):
+        i, p, v = inds[n].cpu(), is_pos[n].cpu().bool(), valid[n].cpu().bool()
+        n_pos, n_neg = int((a > 0).sum()), int((a == 0).sum())
+        k_pos = min(128, n_pos)
+        k_neg = min(512 - k_pos, n_neg)
+        assert int(p.sum()) == k_pos and p[:k_pos].all() and not p[k_pos:].any()
+        assert int(v.sum()) == k_pos + k_neg and v[:k_pos + k_neg].all()
+        assert (a[i[:k_pos]] > 0).all() and (a[i[k_pos:k_pos + k_neg]] == 0).all()
+        assert len(set(i[:k_pos + k_neg].tolist())) == k_pos + k_neg
+    assert int(valid[2].sum()) == 50
+    inds2, _, _ = BF.sample_rois(al, 512, 0.25)
+    assert not torch.equal(inds2[0], inds[0])
+    assert sorted(inds2[1][:7].tolist()) == list(range(7))    # all 7 positives every time
+    # every positive of image 0 is picked with the same probability 128 / n_pos
+    n_pos0 = int((a0 > 0).sum())
+    hits = torch.zeros(2020)
+    for _ in range(300):
+        ii, pp, _ = BF.sample_rois(al[:1], 512, 0.25)
+        hits[ii[0][:128].cpu()] += 1
+    f = hits[a0 > 0] / 300.0
+    assert abs(float(f.mean()) - 128.0 / n_pos0) < 1e-6 and float(f.min()) > 0.25 and float(f.max()) < 0.65
