@@ -70,18 +70,27 @@ def init_dist(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # (test hooks: BGS_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and BGS_DIST_BACKEND=gloo
+    #  swaps the collective backend, so the multi-process code path can be exercised on a
+    #  single-GPU box; the real runs use one GPU per rank over RCCL)
+    if os.environ.get('BGS_BENCH_ONE_DEVICE'):
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world)   # RCCL on ROCm
+        backend = os.environ.get('BGS_DIST_BACKEND', 'nccl')                   # nccl = RCCL on ROCm
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
 
 def barrier(world):
     if world > 1:
         import torch.distributed as dist
-        dist.barrier(device_ids=[torch.cuda.current_device()])
+        if dist.get_backend() == 'nccl':
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def make_inputs(n, seed, dev):
