@@ -4,7 +4,7 @@ Hand-written gfx950 HIP kernels behind a C ABI (``include/bgs.h`` -> ``libbgs.so
 from PyTorch-ROCm through the reference's own registry keys and config schema.
 """
 from . import (backbone, bbox_heads, checkpoint, config, detectors, gs_tables, losses,  # noqa: F401
-               mask_heads, roi_extractor, rpn, train)  # (imports populate the registries)
+               mask_heads, roi_extractor, rpn, semantic_head, train)  # (imports populate the registries)
 from .builder import (build_backbone, build_detector, build_head, build_loss, build_neck,
                       build_roi_extractor, build_shared_head)
 from .config import Config, ConfigDict

@@ -152,7 +152,10 @@ class ResNet(nn.Module):
         super().__init__()
         if depth not in self.arch_settings:
             raise KeyError('invalid depth {} for resnet (bottleneck depths only)'.format(depth))
-        if style != 'pytorch' or tuple(dilations) != (1, 1, 1, 1) or dcn or gcb or gen_attention:
+        if dcn:
+            raise NotImplementedError('dcn (deformable convolution, gs_htc_dconv_* config) has no '
+                                      'kernel in this build')
+        if style != 'pytorch' or tuple(dilations) != (1, 1, 1, 1) or gcb or gen_attention:
             raise NotImplementedError('only the plain pytorch-style trunk of the BAGS configs')
         if norm_cfg.get('type', 'BN') != 'BN' or not norm_eval:
             raise NotImplementedError('BatchNorm in eval mode only (norm_eval=True is what every '

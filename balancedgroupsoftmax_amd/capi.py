@@ -72,6 +72,18 @@ SIGNATURES = {
                                               ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, c_f32p, c_ptr]),
+    'bgs_roi_align_nhwc_fwd_ex': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
+                                                 c_ptr, c_ptr]),
+    'bgs_roi_align_nhwc_bwd_ex': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_int, c_f32p, c_ptr]),
+    'bgs_resize_bilinear_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p] + [ctypes.c_int] * 7 + [c_ptr]),
+    'bgs_resize_bilinear_nhwc_bwd_f32': (ctypes.c_int, [c_f32p, c_f32p] + [ctypes.c_int] * 7
+                                         + [c_ptr]),
     'bgs_mask_target': (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
                                        ctypes.c_int, c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, c_f32p,
                                        c_ptr]),

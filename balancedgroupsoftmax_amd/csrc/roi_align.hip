@@ -19,6 +19,12 @@
 // mapping scatters g * w / 4 into the level's gradient map with hardware fp32 atomics
 // (global_atomic_add_f32), 16 taps x C channels per bin; the maps are accumulated INTO (the RPN
 // head's data gradient is already there), so no separate zero-fill + add pass.
+//
+// HTC semantic fusion (mmdet/models/detectors/htc.py:57-64,88-96): the pooled semantic feature is
+// RoIAligned at 14x14, `F.adaptive_avg_pool2d`-ed to the box head's 7x7 and ADDED to the box
+// features.  POOL = 2 evaluates the 2x2 block of fine bins (same sample coordinates as the 14x14
+// grid) inside the wave and `accumulate` adds into the existing output: the 14x14 intermediate
+// (205 MB for 1024 RoIs), the pooling pass and the add pass never touch HBM.
 #include <math.h>
 
 #include "bgs_common.h"
@@ -81,9 +87,11 @@ __device__ __forceinline__ Tap make_tap(float y, float x, int H, int W) {
 }
 
 // one wave per (roi, ph, pw); lanes stride over channel quads.
-// BWD = false: out[k,bin,:] = mean of the bilinear samples.  BWD = true: `out` is the incoming
+// BWD = false: out[k,bin,:] (+)= mean of the bilinear samples.  BWD = true: `out` is the incoming
 // gradient and L.feat are the per-level gradient maps that receive the scattered taps.
-template <int SAMPLES, bool BWD>
+// POOL: every output bin is the average of POOL x POOL bins of the (PH*POOL) x (PW*POOL) RoIAlign
+// grid (adaptive_avg_pool2d of an exact multiple), each with SAMPLES x SAMPLES sample points.
+template <int SAMPLES, bool BWD, int POOL, bool ACC>
 __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(RoiLevels L,
                                                              const float* __restrict__ rois,
                                                              int K, int C, int PH, int PW,
@@ -114,64 +122,103 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(RoiLevels L,
   const float roi_end_w = (x2 + 1.f) * ss, roi_end_h = (y2 + 1.f) * ss;
   const float roi_width = fmaxf(roi_end_w - roi_start_w, 0.f);
   const float roi_height = fmaxf(roi_end_h - roi_start_h, 0.f);
-  const float bin_size_h = roi_height / PH, bin_size_w = roi_width / PW;
-
-  Tap taps[SAMPLES * SAMPLES];
-#pragma unroll
-  for (int iy = 0; iy < SAMPLES; ++iy) {
-    const float y = roi_start_h + ph * bin_size_h + (iy + .5f) * bin_size_h / (float)SAMPLES;
-#pragma unroll
-    for (int ix = 0; ix < SAMPLES; ++ix) {
-      const float x = roi_start_w + pw * bin_size_w + (ix + .5f) * bin_size_w / (float)SAMPLES;
-      taps[iy * SAMPLES + ix] = make_tap(y, x, H, W);
-    }
-  }
+  const float bin_size_h = roi_height / (PH * POOL), bin_size_w = roi_width / (PW * POOL);
   float* o = out + ((size_t)k * bins + bin) * C;
-  if (BWD) {
-    float* dfeat = const_cast<float*>(feat);
-    // consecutive lanes -> consecutive channels: one atomic wave-instruction covers 64
-    // consecutive floats = two full 128-byte lines (a lane-owns-a-quad mapping touches eight
-    // quarter-used lines per instruction: 2.67 -> measured below in profiles/r2p)
-    for (int c = lane; c < C; c += 64) {
-      const float g = o[c] / (float)(SAMPLES * SAMPLES);
+
+  f32x4 total = {0.f, 0.f, 0.f, 0.f};     // forward, POOL > 1 (C <= 256: one quad per lane)
+#pragma unroll 1
+  for (int sub = 0; sub < POOL * POOL; ++sub) {
+    const int fh = ph * POOL + sub / POOL, fw = pw * POOL + sub % POOL;   // fine-grid bin
+    Tap taps[SAMPLES * SAMPLES];
 #pragma unroll
-      for (int s = 0; s < SAMPLES * SAMPLES; ++s) {
+    for (int iy = 0; iy < SAMPLES; ++iy) {
+      const float y = roi_start_h + fh * bin_size_h + (iy + .5f) * bin_size_h / (float)SAMPLES;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float w = taps[s].w[q];
-          if (w == 0.f) continue;      // out-of-bounds sample or a degenerate (clamped) tap
-          unsafeAtomicAdd(dfeat + (size_t)taps[s].o[q] * C + c, g * w);
+      for (int ix = 0; ix < SAMPLES; ++ix) {
+        const float x = roi_start_w + fw * bin_size_w + (ix + .5f) * bin_size_w / (float)SAMPLES;
+        taps[iy * SAMPLES + ix] = make_tap(y, x, H, W);
+      }
+    }
+    if (BWD) {
+      float* dfeat = const_cast<float*>(feat);
+      // consecutive lanes -> consecutive channels: one atomic wave-instruction covers 64
+      // consecutive floats = two full 128-byte lines (a lane-owns-a-quad mapping touches eight
+      // quarter-used lines per instruction: 2.67 -> measured below in profiles/r2p)
+      for (int c = lane; c < C; c += 64) {
+        const float g = o[c] / (float)(SAMPLES * SAMPLES * POOL * POOL);
+#pragma unroll
+        for (int s = 0; s < SAMPLES * SAMPLES; ++s) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float w = taps[s].w[q];
+            if (w == 0.f) continue;      // out-of-bounds sample or a degenerate (clamped) tap
+            unsafeAtomicAdd(dfeat + (size_t)taps[s].o[q] * C + c, g * w);
+          }
         }
       }
+      continue;
     }
-    return;
-  }
-  for (int c = lane * 4; c < C; c += 256) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c = lane * 4; c < C; c += 256) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < SAMPLES * SAMPLES; ++s) {
-      // val = w1*lt + w2*rt + w3*lb + w4*rb, summed over the samples in the reference's order
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < SAMPLES * SAMPLES; ++s) {
+        // val = w1*lt + w2*rt + w3*lb + w4*rb, summed over the samples in the reference's order
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 d = *reinterpret_cast<const f32x4*>(feat + (size_t)taps[s].o[q] * C + c);
-        v += taps[s].w[q] * d;
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 d = *reinterpret_cast<const f32x4*>(feat + (size_t)taps[s].o[q] * C + c);
+          v += taps[s].w[q] * d;
+        }
+        acc += v;
       }
-      acc += v;
+      acc /= (float)(SAMPLES * SAMPLES);
+      if (POOL == 1) {
+        if (ACC) acc += *reinterpret_cast<const f32x4*>(o + c);
+        *reinterpret_cast<f32x4*>(o + c) = acc;
+      } else {
+        total += acc;      // the launcher guarantees C <= 256 here: a single quad per lane
+      }
     }
-    acc /= (float)(SAMPLES * SAMPLES);
-    *reinterpret_cast<f32x4*>(o + c) = acc;
+  }
+  if (!BWD && POOL > 1) {
+    const int c = lane * 4;
+    if (c < C) {
+      total /= (float)(POOL * POOL);
+      if (ACC) total += *reinterpret_cast<const f32x4*>(o + c);
+      *reinterpret_cast<f32x4*>(o + c) = total;
+    }
   }
 }
 
 }  // namespace
 
-extern "C" int bgs_roi_align_nhwc_fwd(const float* const* host_feats, const int* host_heights,
-                                      const int* host_widths, const float* host_scales,
-                                      int num_levels, int num_images, float finest_scale,
-                                      const float* rois,
-                                      int K, int C, int pooled_h, int pooled_w, int sample_num,
-                                      float* out, int* levels_out, bgs_stream_t stream) {
+static int fill_levels(RoiLevels& L, const float* const* feats, const int* host_heights,
+                       const int* host_widths, const float* host_scales, int num_levels,
+                       int num_images, float finest_scale, bool need_align) {
+  for (int i = 0; i < kMaxLevels; ++i) {
+    L.feat[i] = nullptr;
+    L.H[i] = L.W[i] = 1;
+    L.scale[i] = 1.f;
+  }
+  for (int i = 0; i < num_levels; ++i) {
+    if (!feats[i] || (need_align && (uintptr_t)feats[i] % 16 != 0)) return BGS_ERR_INVALID_ARG;
+    L.feat[i] = feats[i];
+    L.H[i] = host_heights[i];
+    L.W[i] = host_widths[i];
+    L.scale[i] = host_scales[i];
+  }
+  L.num_levels = num_levels;
+  L.num_images = num_images;
+  L.finest_scale = finest_scale;
+  return BGS_OK;
+}
+
+extern "C" int bgs_roi_align_nhwc_fwd_ex(const float* const* host_feats, const int* host_heights,
+                                         const int* host_widths, const float* host_scales,
+                                         int num_levels, int num_images, float finest_scale,
+                                         const float* rois, int K, int C, int pooled_h,
+                                         int pooled_w, int sample_num, int pool, int accumulate,
+                                         float* out, int* levels_out, bgs_stream_t stream) {
   if (num_levels <= 0 || num_levels > kMaxLevels || num_images <= 0 || K < 0 || C <= 0 || pooled_h <= 0 ||
       pooled_w <= 0)
     return BGS_ERR_INVALID_ARG;
@@ -180,26 +227,63 @@ extern "C" int bgs_roi_align_nhwc_fwd(const float* const* host_feats, const int*
   if (!rois || !out) return BGS_ERR_INVALID_ARG;
   if (C % 4 != 0 || (uintptr_t)out % 16 != 0) return BGS_ERR_UNSUPPORTED;
   if (sample_num != 2) return BGS_ERR_UNSUPPORTED;  // every shipped config uses sample_num=2
+  if (pool != 1 && !(pool == 2 && C <= 256)) return BGS_ERR_UNSUPPORTED;
   RoiLevels L;
-  for (int i = 0; i < kMaxLevels; ++i) {
-    L.feat[i] = nullptr;
-    L.H[i] = L.W[i] = 1;
-    L.scale[i] = 1.f;
-  }
-  for (int i = 0; i < num_levels; ++i) {
-    if (!host_feats[i] || (uintptr_t)host_feats[i] % 16 != 0) return BGS_ERR_INVALID_ARG;
-    L.feat[i] = host_feats[i];
-    L.H[i] = host_heights[i];
-    L.W[i] = host_widths[i];
-    L.scale[i] = host_scales[i];
-  }
-  L.num_levels = num_levels;
-  L.num_images = num_images;
-  L.finest_scale = finest_scale;
+  const int rc = fill_levels(L, host_feats, host_heights, host_widths, host_scales, num_levels,
+                             num_images, finest_scale, true);
+  if (rc != BGS_OK) return rc;
   const long long waves = (long long)K * pooled_h * pooled_w;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  hipLaunchKernelGGL((roi_align_nhwc_kernel<2, false>), dim3(grid), dim3(256), 0,
-                     (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w, out, levels_out);
+#define BGS_ROI_FWD(POOL_, ACC_)                                                              \
+  hipLaunchKernelGGL((roi_align_nhwc_kernel<2, false, POOL_, ACC_>), dim3(grid), dim3(256), 0,   \
+                     (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w, out, levels_out)
+  if (pool == 1 && !accumulate) BGS_ROI_FWD(1, false);
+  else if (pool == 1) BGS_ROI_FWD(1, true);
+  else if (!accumulate) BGS_ROI_FWD(2, false);
+  else BGS_ROI_FWD(2, true);
+#undef BGS_ROI_FWD
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int bgs_roi_align_nhwc_fwd(const float* const* host_feats, const int* host_heights,
+                                      const int* host_widths, const float* host_scales,
+                                      int num_levels, int num_images, float finest_scale,
+                                      const float* rois,
+                                      int K, int C, int pooled_h, int pooled_w, int sample_num,
+                                      float* out, int* levels_out, bgs_stream_t stream) {
+  return bgs_roi_align_nhwc_fwd_ex(host_feats, host_heights, host_widths, host_scales, num_levels,
+                                   num_images, finest_scale, rois, K, C, pooled_h, pooled_w,
+                                   sample_num, 1, 0, out, levels_out, stream);
+}
+
+extern "C" int bgs_roi_align_nhwc_bwd_ex(float* const* host_dfeats, const int* host_heights,
+                                         const int* host_widths, const float* host_scales,
+                                         int num_levels, int num_images, float finest_scale,
+                                         const float* rois, int K, int C, int pooled_h,
+                                         int pooled_w, int sample_num, int pool, const float* dout,
+                                         bgs_stream_t stream) {
+  if (num_levels <= 0 || num_levels > kMaxLevels || num_images <= 0 || K < 0 || C <= 0 ||
+      pooled_h <= 0 || pooled_w <= 0)
+    return BGS_ERR_INVALID_ARG;
+  if (!host_dfeats || !host_heights || !host_widths || !host_scales) return BGS_ERR_INVALID_ARG;
+  if (K == 0) return BGS_OK;
+  if (!rois || !dout) return BGS_ERR_INVALID_ARG;
+  if (C % 4 != 0 || (uintptr_t)dout % 16 != 0) return BGS_ERR_UNSUPPORTED;
+  if (sample_num != 2 || (pool != 1 && pool != 2)) return BGS_ERR_UNSUPPORTED;
+  RoiLevels L;
+  const int rc = fill_levels(L, host_dfeats, host_heights, host_widths, host_scales, num_levels,
+                             num_images, finest_scale, false);
+  if (rc != BGS_OK) return rc;
+  const long long waves = (long long)K * pooled_h * pooled_w;
+  const unsigned grid = (unsigned)((waves + 3) / 4);
+  if (pool == 1)
+    hipLaunchKernelGGL((roi_align_nhwc_kernel<2, true, 1, false>), dim3(grid), dim3(256), 0,
+                       (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w,
+                       const_cast<float*>(dout), nullptr);
+  else
+    hipLaunchKernelGGL((roi_align_nhwc_kernel<2, true, 2, false>), dim3(grid), dim3(256), 0,
+                       (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w,
+                       const_cast<float*>(dout), nullptr);
   BGS_RETURN_LAUNCH_STATUS();
 }
 
@@ -208,34 +292,7 @@ extern "C" int bgs_roi_align_nhwc_bwd(float* const* host_dfeats, const int* host
                                       int num_levels, int num_images, float finest_scale,
                                       const float* rois, int K, int C, int pooled_h, int pooled_w,
                                       int sample_num, const float* dout, bgs_stream_t stream) {
-  if (num_levels <= 0 || num_levels > kMaxLevels || num_images <= 0 || K < 0 || C <= 0 ||
-      pooled_h <= 0 || pooled_w <= 0)
-    return BGS_ERR_INVALID_ARG;
-  if (!host_dfeats || !host_heights || !host_widths || !host_scales) return BGS_ERR_INVALID_ARG;
-  if (K == 0) return BGS_OK;
-  if (!rois || !dout) return BGS_ERR_INVALID_ARG;
-  if (C % 4 != 0 || (uintptr_t)dout % 16 != 0) return BGS_ERR_UNSUPPORTED;
-  if (sample_num != 2) return BGS_ERR_UNSUPPORTED;
-  RoiLevels L;
-  for (int i = 0; i < kMaxLevels; ++i) {
-    L.feat[i] = nullptr;
-    L.H[i] = L.W[i] = 1;
-    L.scale[i] = 1.f;
-  }
-  for (int i = 0; i < num_levels; ++i) {
-    if (!host_dfeats[i]) return BGS_ERR_INVALID_ARG;
-    L.feat[i] = host_dfeats[i];
-    L.H[i] = host_heights[i];
-    L.W[i] = host_widths[i];
-    L.scale[i] = host_scales[i];
-  }
-  L.num_levels = num_levels;
-  L.num_images = num_images;
-  L.finest_scale = finest_scale;
-  const long long waves = (long long)K * pooled_h * pooled_w;
-  const unsigned grid = (unsigned)((waves + 3) / 4);
-  hipLaunchKernelGGL((roi_align_nhwc_kernel<2, true>), dim3(grid), dim3(256), 0,
-                     (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w,
-                     const_cast<float*>(dout), nullptr);
-  BGS_RETURN_LAUNCH_STATUS();
+  return bgs_roi_align_nhwc_bwd_ex(host_dfeats, host_heights, host_widths, host_scales, num_levels,
+                                   num_images, finest_scale, rois, K, C, pooled_h, pooled_w,
+                                   sample_num, 1, dout, stream);
 }

@@ -328,25 +328,40 @@ class CascadeRCNN(TwoStageDetector):
                  bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None,
                  train_cfg=None, test_cfg=None, pretrained=None):
         assert bbox_roi_extractor is not None and bbox_head is not None
-        if shared_head is not None or mask_head is not None or mask_roi_extractor is not None:
-            raise NotImplementedError('cascade mask branch / shared head (HTC) are not built')
+        if shared_head is not None:
+            raise NotImplementedError('shared_head (C4 heads) is not on the BAGS path')
         nn.Module.__init__(self)
         self.num_stages = num_stages
         self.backbone = builder.build_backbone(backbone)
         self.neck = builder.build_neck(neck) if neck is not None else None
         self.rpn_head = builder.build_head(rpn_head) if rpn_head is not None else None
-        if not isinstance(bbox_roi_extractor, (list, tuple)):
-            bbox_roi_extractor = [bbox_roi_extractor] * num_stages
-        if not isinstance(bbox_head, (list, tuple)):
-            bbox_head = [bbox_head] * num_stages
-        assert len(bbox_roi_extractor) == len(bbox_head) == num_stages
+
+        def per_stage(cfg):
+            cfg = list(cfg) if isinstance(cfg, (list, tuple)) else [cfg] * num_stages
+            assert len(cfg) == num_stages
+            return cfg
         self.bbox_roi_extractor = nn.ModuleList(builder.build_roi_extractor(r)
-                                                for r in bbox_roi_extractor)
-        self.bbox_head = nn.ModuleList(builder.build_head(h) for h in bbox_head)
+                                                for r in per_stage(bbox_roi_extractor))
+        self.bbox_head = nn.ModuleList(builder.build_head(h) for h in per_stage(bbox_head))
         self.mask_head = None
+        if mask_head is not None:       # cascade_rcnn.py:67-92 (used by HybridTaskCascade)
+            self.mask_head = nn.ModuleList(builder.build_head(h) for h in per_stage(mask_head))
+            if mask_roi_extractor is not None:
+                self.share_roi_extractor = False
+                self.mask_roi_extractor = nn.ModuleList(builder.build_roi_extractor(r)
+                                                        for r in per_stage(mask_roi_extractor))
+            else:
+                self.share_roi_extractor = True
+                self.mask_roi_extractor = self.bbox_roi_extractor
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
         self.fp16_enabled = False
+        self._build_extra()
         self.init_weights(pretrained=pretrained)
+
+    def _build_extra(self):
+        if self.mask_head is not None:
+            raise NotImplementedError('Cascade Mask R-CNN is not among the BAGS configs; the '
+                                      'cascade mask branch is built as HybridTaskCascade')
 
     def init_weights(self, pretrained=None):
         if isinstance(pretrained, str):
@@ -359,6 +374,35 @@ class CascadeRCNN(TwoStageDetector):
         for ext, head in zip(self.bbox_roi_extractor, self.bbox_head):
             ext.init_weights()
             head.init_weights()
+        if self.mask_head is not None:
+            for head in self.mask_head:
+                head.init_weights()
+
+    def _rpn_forward_train(self, x, img_meta, gt_bboxes, proposals, generator, losses):
+        """RPN losses + the fixed-shape proposal list (two_stage.py:157-176)."""
+        if not self.with_rpn:
+            return [(p, torch.ones(p.size(0), dtype=torch.bool, device=p.device)) for p in proposals]
+        cls_scores, bbox_preds = self.rpn_head(x)
+        losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
+                                         self.train_cfg.rpn, generator=generator))
+        proposal_cfg = self.train_cfg.get('rpn_proposal', None)
+        if proposal_cfg is None:
+            proposal_cfg = self.test_cfg.rpn
+        proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_meta, proposal_cfg)
+        self.rpn_head._fused = None
+        return proposal_list
+
+    def _refined_proposals(self, head, rois, labels, bbox_pred, img_meta, num):
+        """``refine_bboxes`` (bbox_head.py:169-208) in fixed shape: every sampled RoI re-regressed
+        with its target class; GT rows and padding slots are masked instead of removed."""
+        n_img = len(img_meta)
+        with torch.no_grad():
+            bp = bbox_pred.detach()
+            boxes = torch.cat([head.regress_by_class(
+                rois[j * num:(j + 1) * num, 1:], labels[j * num:(j + 1) * num],
+                bp[j * num:(j + 1) * num], img_meta[j]) for j in range(n_img)])
+            keep = self._sampled_valid & ~self._sampled_is_gt
+            return [(boxes[j * num:(j + 1) * num], keep[j]) for j in range(n_img)]
 
     def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
                       gt_masks=None, proposals=None, generator=None):
@@ -366,20 +410,7 @@ class CascadeRCNN(TwoStageDetector):
             raise NotImplementedError('CascadeRCNN.forward_train runs on the GPU path only')
         x = self.extract_feat(img)
         losses = dict()
-        if self.with_rpn:
-            cls_scores, bbox_preds = self.rpn_head(x)
-            losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
-                                             self.train_cfg.rpn, generator=generator))
-            proposal_cfg = self.train_cfg.get('rpn_proposal', None)
-            if proposal_cfg is None:
-                proposal_cfg = self.test_cfg.rpn
-            proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_meta, proposal_cfg)
-            self.rpn_head._fused = None
-            del cls_scores, bbox_preds
-        else:
-            proposal_list = [(p, torch.ones(p.size(0), dtype=torch.bool, device=p.device))
-                             for p in proposals]
-        n_img = img.size(0)
+        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, generator, losses)
         for i in range(self.num_stages):
             rc = self.train_cfg.rcnn[i]
             lw = self.train_cfg.stage_loss_weights[i]
@@ -391,14 +422,8 @@ class CascadeRCNN(TwoStageDetector):
             for name, value in head.loss(cls_score, bbox_pred, *targets).items():
                 losses['s{}.{}'.format(i, name)] = value * lw if 'loss' in name else value
             if i < self.num_stages - 1:       # refine (cascade_rcnn.py:291-296), fixed shape
-                with torch.no_grad():
-                    num = rc.sampler.num
-                    bp = bbox_pred.detach()
-                    boxes = torch.cat([head.regress_by_class(
-                        rois[j * num:(j + 1) * num, 1:], targets[0][j * num:(j + 1) * num],
-                        bp[j * num:(j + 1) * num], img_meta[j]) for j in range(n_img)])
-                    keep = self._sampled_valid & ~self._sampled_is_gt
-                    proposal_list = [(boxes[j * num:(j + 1) * num], keep[j]) for j in range(n_img)]
+                proposal_list = self._refined_proposals(head, rois, targets[0], bbox_pred, img_meta,
+                                                        rc.sampler.num)
         return losses
 
     def simple_test(self, img, img_meta, proposals=None, rescale=False):
@@ -429,6 +454,183 @@ class CascadeRCNN(TwoStageDetector):
         det_bboxes, det_labels = multiclass_nms(bboxes, scores, cfg.score_thr, cfg.nms,
                                                 cfg.max_per_img)
         return bbox2result(det_bboxes, det_labels, self.bbox_head[-1].num_classes)
+
+
+@DETECTORS.register_module
+class HybridTaskCascade(CascadeRCNN):
+    """mmdet/models/detectors/htc.py:12-561 (configs/bags/gs_htc_x101_64x4d_fpn_20e_16gpu_lvis.py):
+    the cascade with (a) interleaved execution — stage ``i``'s mask head trains on the boxes stage
+    ``i``'s box head just refined, (b) mask information flow — ``HTCMaskHead.conv_res`` feeds the
+    previous stage's mask feature forward, (c) a semantic-segmentation branch whose embedded
+    feature is RoI-pooled and added to the box and mask RoI features.
+
+    GPU specifics: the semantic fusion of the box branch (RoIAlign 14x14 on the stride-8 map ->
+    ``adaptive_avg_pool2d`` to 7x7 -> ``bbox_feats +=``) is ONE kernel launch that accumulates into
+    the box features (``bgs_roi_align_nhwc_fwd_ex`` with ``pool=2``); mask logits exist only for
+    each RoI's own class channel; all sampling is fixed shape (no host synchronisation)."""
+
+    def __init__(self, num_stages, backbone, semantic_roi_extractor=None, semantic_head=None,
+                 semantic_fusion=('bbox', 'mask'), interleaved=True, mask_info_flow=True, **kwargs):
+        nn.Module.__init__(self)
+        self._semantic_cfg = (semantic_roi_extractor, semantic_head)
+        self.semantic_fusion = tuple(semantic_fusion)
+        self.interleaved = interleaved
+        self.mask_info_flow = mask_info_flow
+        super().__init__(num_stages, backbone, **kwargs)
+        assert self.with_bbox and self.with_mask
+
+    def _build_extra(self):
+        ext, head = self._semantic_cfg
+        self.semantic_head = None
+        if head is not None:
+            self.semantic_roi_extractor = builder.build_roi_extractor(ext)
+            self.semantic_head = builder.build_head(head)
+        if self.mask_head is None or self.share_roi_extractor:
+            raise NotImplementedError('HTC without its own mask_roi_extractor / mask_head is '
+                                      'outside the BAGS configs')
+
+    with_semantic = property(lambda self: self.semantic_head is not None)
+
+    def init_weights(self, pretrained=None):
+        super().init_weights(pretrained=pretrained)
+        if self.with_semantic:
+            self.semantic_head.init_weights()
+
+    # -- RoI features with the semantic fusion ---------------------------------------------
+    def _fused_roi_feats(self, ext, x, rois, semantic_feat, branch):
+        feats = ext(x[:ext.num_inputs], rois)
+        if semantic_feat is not None and branch in self.semantic_fusion:
+            sext = self.semantic_roi_extractor
+            pool, rem = divmod(sext.out_size, ext.out_size)
+            if rem != 0 or pool not in (1, 2):
+                raise NotImplementedError('semantic RoI size %d vs %d' % (sext.out_size, ext.out_size))
+            # htc.py:57-64 / 88-96: RoIAlign (+ adaptive_avg_pool2d) + in-place add, one launch
+            feats = sext([semantic_feat], rois, out_size=ext.out_size, pool=pool, add_to=feats)
+        return feats
+
+    def _mask_features(self, stage, mask_feats, upto_logits=True):
+        """Mask information flow (htc.py:98-107): heads ``0..stage-1`` contribute their conv
+        features through ``conv_res``; returns stage ``stage``'s pre-logit features."""
+        head = self.mask_head[stage]
+        if not self.mask_info_flow:
+            return head.upsample_features(head.conv_features(mask_feats))
+        last = None
+        for i in range(stage):
+            last = self.mask_head[i].res_features(mask_feats, last)
+        return head.upsample_features(head.res_features(mask_feats, last))
+
+    def _htc_mask_forward_train(self, stage, x, rois, labels, gt_masks, rc, semantic_feat):
+        """htc.py:75-112 on the fixed-shape positives (the first ``int(num * pos_fraction)``
+        sampler slots of every image; ``labels > 0`` marks the real ones)."""
+        sc = rc.sampler
+        n_img = len(gt_masks)
+        max_pos = int(sc.num * sc.pos_fraction)
+        sel = (torch.arange(n_img, device=rois.device).view(-1, 1) * sc.num +
+               torch.arange(max_pos, device=rois.device).view(1, -1)).reshape(-1)
+        pos_rois = rois[sel].contiguous()
+        pos_labels = labels[sel].contiguous()
+        valid = pos_labels > 0
+        gt_inds = self._sampled_gt_inds[:, :max_pos].reshape(-1).contiguous()
+        masks = [torch.as_tensor(m).to(device=rois.device, dtype=torch.uint8).contiguous()
+                 for m in gt_masks]
+        ext, head = self.mask_roi_extractor[stage], self.mask_head[stage]
+        mask_feats = self._fused_roi_feats(ext, x, pos_rois, semantic_feat, 'mask')
+        feats = self._mask_features(stage, mask_feats)
+        mask_targets = head.get_target_fixed(pos_rois, gt_inds, valid, masks, rc)
+        return head.loss_from_features(feats, mask_targets, pos_labels, valid)
+
+    def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
+                      gt_masks=None, gt_semantic_seg=None, proposals=None, generator=None):
+        if not img.is_cuda:
+            raise NotImplementedError('HybridTaskCascade.forward_train runs on the GPU path only')
+        if gt_masks is None:
+            raise ValueError('HTC needs gt_masks (per image a uint8 [G, H, W] tensor)')
+        x = self.extract_feat(img)
+        losses = dict()
+        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, generator, losses)
+        semantic_feat = None
+        if self.with_semantic:
+            if gt_semantic_seg is None:
+                raise ValueError('the semantic branch needs gt_semantic_seg [N, 1, H/8, W/8]')
+            semantic_pred, semantic_feat = self.semantic_head(x)
+            losses['loss_semantic_seg'] = self.semantic_head.loss(semantic_pred, gt_semantic_seg)
+        for i in range(self.num_stages):
+            rc = self.train_cfg.rcnn[i]
+            lw = self.train_cfg.stage_loss_weights[i]
+            head, ext = self.bbox_head[i], self.bbox_roi_extractor[i]
+            num = rc.sampler.num
+            rois, targets = self._sample_rois_fused(proposal_list, gt_bboxes, gt_labels, generator,
+                                                    rc=rc, head=head)
+            feats = self._fused_roi_feats(ext, x, rois, semantic_feat, 'bbox')
+            cls_score, bbox_pred = head(feats, nhwc=True)
+            for name, value in head.loss(cls_score, bbox_pred, *targets).items():
+                losses['s{}.{}'.format(i, name)] = value * lw if 'loss' in name else value
+            refined = None
+            if self.interleaved or i < self.num_stages - 1:
+                refined = self._refined_proposals(head, rois, targets[0], bbox_pred, img_meta, num)
+            mask_rois, mask_labels = rois, targets[0]
+            if self.interleaved:
+                # htc.py:264-283: the mask branch trains on RoIs re-assigned and re-sampled from
+                # the boxes this stage's box head just refined
+                with torch.no_grad():
+                    mask_rois, mt = self._sample_rois_fused(refined, gt_bboxes, gt_labels, generator,
+                                                            rc=rc, head=head)
+                    mask_labels = mt[0]
+            loss_mask = self._htc_mask_forward_train(i, x, mask_rois, mask_labels, gt_masks, rc,
+                                                     semantic_feat)
+            for name, value in loss_mask.items():
+                losses['s{}.{}'.format(i, name)] = value * lw if 'loss' in name else value
+            if refined is not None:
+                proposal_list = refined
+        return losses
+
+    # -- test time -----------------------------------------------------------------------------
+    def simple_test(self, img, img_meta, proposals=None, rescale=False):
+        """htc.py:313-432 with ``keep_all_stages=False``: the ensemble boxes (stage-averaged class
+        logits) and, per detection, the mean over stages of its class's mask probability
+        ``[k, 28, 28]`` (``merge_aug_masks`` without weights; pasting / RLE is evaluation tooling)."""
+        from .post_processing import bbox2result, multiclass_nms
+        if self.test_cfg.get('keep_all_stages', False):
+            raise NotImplementedError('keep_all_stages=True (per-stage results) is not built')
+        x = self.extract_feat(img)
+        proposal_list = (self.simple_test_rpn(x, img_meta, self.test_cfg.rpn)
+                         if proposals is None else proposals)
+        semantic_feat = self.semantic_head(x)[1] if self.with_semantic else None
+        props, valid = proposal_list[0] if isinstance(proposal_list[0], tuple) \
+            else (proposal_list[0], None)
+        rois = torch.cat([props.new_zeros((props.size(0), 1)), props[:, :4]], dim=1)
+        ms_scores = []
+        for i in range(self.num_stages):
+            head, ext = self.bbox_head[i], self.bbox_roi_extractor[i]
+            cls_score, bbox_pred = head(self._fused_roi_feats(ext, x, rois, semantic_feat, 'bbox'),
+                                        nhwc=True)
+            ms_scores.append(cls_score)
+            if i < self.num_stages - 1:
+                rois = head.regress_by_class(rois, cls_score.argmax(dim=1), bbox_pred, img_meta[0])
+        cls_score = sum(ms_scores) / float(len(ms_scores))
+        scale_factor = img_meta[0]['scale_factor']
+        bboxes, scores = self.bbox_head[-1].get_det_bboxes(
+            rois, cls_score, bbox_pred, img_meta[0]['img_shape'], scale_factor, rescale=rescale,
+            cfg=None)
+        if valid is not None:
+            scores = torch.where(valid[:, None], scores, scores.new_full((), -1.0))
+        cfg = self.test_cfg.rcnn
+        det_bboxes, det_labels = multiclass_nms(bboxes, scores, cfg.score_thr, cfg.nms,
+                                                cfg.max_per_img)
+        bbox_result = bbox2result(det_bboxes, det_labels, self.bbox_head[-1].num_classes)
+        if det_bboxes.shape[0] == 0:
+            return bbox_result, det_bboxes.new_zeros((0, 28, 28))
+        boxes = det_bboxes[:, :4] * scale_factor if rescale else det_bboxes[:, :4]
+        mask_rois = torch.cat([boxes.new_zeros((boxes.size(0), 1)), boxes], dim=1)
+        mask_feats = self._fused_roi_feats(self.mask_roi_extractor[-1], x, mask_rois, semantic_feat,
+                                           'mask')
+        probs, last = [], None
+        for i in range(self.num_stages):
+            head = self.mask_head[i]
+            last = head.res_features(mask_feats, last) if self.mask_info_flow \
+                else head.conv_features(mask_feats)
+            probs.append(head.get_mask_probs(head.upsample_features(last), det_labels))
+        return bbox_result, sum(probs) / float(len(probs))
 
 
 @DETECTORS.register_module

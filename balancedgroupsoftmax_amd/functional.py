@@ -513,8 +513,10 @@ def maxpool3x3s2_nhwc(x):
 # RoIAlign (multi-level, NHWC) and batched NMS
 # ----------------------------------------------------------------------------------------
 def roi_align_nhwc(feats, rois, featmap_strides, out_size=7, sample_num=2, finest_scale=56,
-                   return_levels=False):
-    """feats: list of ``[N,H_l,W_l,C]`` maps; rois ``[K,5]`` -> ``[K, out, out, C]``."""
+                   return_levels=False, pool=1, out=None):
+    """feats: list of ``[N,H_l,W_l,C]`` maps; rois ``[K,5]`` -> ``[K, out, out, C]``.
+    ``pool``: RoIAlign on the ``(out*pool)^2`` grid averaged down to ``out^2`` in the kernel
+    (== ``F.adaptive_avg_pool2d`` of the finer result);  ``out``: accumulate INTO this tensor."""
     import ctypes
     _require_cuda(rois, *feats)
     lib = capi.load()
@@ -525,20 +527,26 @@ def roi_align_nhwc(feats, rois, featmap_strides, out_size=7, sample_num=2, fines
     rois = _f32c(rois)
     K = rois.shape[0]
     ph, pw = (out_size, out_size) if isinstance(out_size, int) else tuple(out_size)
-    out = torch.empty((K, ph, pw, C), dtype=torch.float32, device=rois.device)
+    accumulate = out is not None
+    if accumulate:
+        assert tuple(out.shape) == (K, ph, pw, C) and out.is_contiguous() and \
+            out.dtype == torch.float32, (out.shape, (K, ph, pw, C))
+    else:
+        out = torch.empty((K, ph, pw, C), dtype=torch.float32, device=rois.device)
     lv = torch.empty((K,), dtype=torch.int32, device=rois.device) if return_levels else None
     ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
     hs = (ctypes.c_int * L)(*[int(f.shape[1]) for f in feats])
     ws = (ctypes.c_int * L)(*[int(f.shape[2]) for f in feats])
     sc = (ctypes.c_float * L)(*[1.0 / s for s in featmap_strides])
-    rc = lib.bgs_roi_align_nhwc_fwd(ptrs, hs, ws, sc, L, N, float(finest_scale), capi.ptr(rois),
-                                    K, C, ph, pw, sample_num, capi.ptr(out), capi.ptr(lv),
-                                    capi.current_stream(rois.device))
-    capi.check('bgs_roi_align_nhwc_fwd', rc)
+    rc = lib.bgs_roi_align_nhwc_fwd_ex(ptrs, hs, ws, sc, L, N, float(finest_scale), capi.ptr(rois),
+                                       K, C, ph, pw, sample_num, int(pool), int(accumulate),
+                                       capi.ptr(out), capi.ptr(lv),
+                                       capi.current_stream(rois.device))
+    capi.check('bgs_roi_align_nhwc_fwd_ex', rc)
     return (out, lv) if return_levels else out
 
 
-def roi_align_nhwc_bwd(dout, rois, dfeats, featmap_strides, sample_num=2, finest_scale=56):
+def roi_align_nhwc_bwd(dout, rois, dfeats, featmap_strides, sample_num=2, finest_scale=56, pool=1):
     """Scatter ``dout [K,ph,pw,C]`` into the per-level gradient maps ``dfeats`` (accumulated
     into, in place, with fp32 atomics)."""
     import ctypes
@@ -556,40 +564,92 @@ def roi_align_nhwc_bwd(dout, rois, dfeats, featmap_strides, sample_num=2, finest
     hs = (ctypes.c_int * L)(*[int(f.shape[1]) for f in dfeats])
     ws = (ctypes.c_int * L)(*[int(f.shape[2]) for f in dfeats])
     sc = (ctypes.c_float * L)(*[1.0 / s for s in featmap_strides])
-    rc = lib.bgs_roi_align_nhwc_bwd(ptrs, hs, ws, sc, L, N, float(finest_scale), capi.ptr(rois),
-                                    K, C, ph, pw, sample_num, capi.ptr(dout),
-                                    capi.current_stream(rois.device))
-    capi.check('bgs_roi_align_nhwc_bwd', rc)
+    rc = lib.bgs_roi_align_nhwc_bwd_ex(ptrs, hs, ws, sc, L, N, float(finest_scale), capi.ptr(rois),
+                                       K, C, ph, pw, sample_num, int(pool), capi.ptr(dout),
+                                       capi.current_stream(rois.device))
+    capi.check('bgs_roi_align_nhwc_bwd_ex', rc)
     return dfeats
 
 
 class _RoIAlignFn(torch.autograd.Function):
     """Differentiable multi-level RoIAlign (w.r.t. the feature maps; RoIs carry no gradient, as
-    in the reference: roi_align.py:52)."""
+    in the reference: roi_align.py:52).  With ``base`` the pooled result is added into it in
+    place (HTC semantic fusion: ``bbox_feats += pooled_semantic``); its gradient is ``dout``."""
 
     @staticmethod
-    def forward(ctx, rois, strides, out_size, sample_num, finest_scale, *feats):
+    def forward(ctx, rois, strides, out_size, sample_num, finest_scale, pool, base, *feats):
         ctx.save_for_backward(rois)
-        ctx.cfg = (tuple(strides), sample_num, finest_scale, [tuple(f.shape) for f in feats])
+        ctx.cfg = (tuple(strides), sample_num, finest_scale, pool, [tuple(f.shape) for f in feats],
+                   base is not None)
+        if base is not None:
+            ctx.mark_dirty(base)
         return roi_align_nhwc([f.detach() for f in feats], rois, strides, out_size, sample_num,
-                              finest_scale)
+                              finest_scale, pool=pool, out=base)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
         rois, = ctx.saved_tensors
-        strides, sample_num, finest_scale, shapes = ctx.cfg
-        dfeats = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in shapes]
-        roi_align_nhwc_bwd(dout.contiguous(), rois, dfeats, strides, sample_num, finest_scale)
-        return (None, None, None, None, None) + tuple(dfeats)
+        strides, sample_num, finest_scale, pool, shapes, has_base = ctx.cfg
+        dout = dout.contiguous()
+        dfeats = [None] * len(shapes)
+        if any(ctx.needs_input_grad[7:]):
+            dfeats = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in shapes]
+            roi_align_nhwc_bwd(dout, rois, dfeats, strides, sample_num, finest_scale, pool=pool)
+        dbase = dout if has_base and ctx.needs_input_grad[6] else None
+        return (None, None, None, None, None, None, dbase) + tuple(dfeats)
 
 
 def roi_align_nhwc_autograd(feats, rois, featmap_strides, out_size=7, sample_num=2,
-                            finest_scale=56):
-    if torch.is_grad_enabled() and any(f.requires_grad for f in feats):
+                            finest_scale=56, pool=1, add_to=None):
+    """``add_to``: RoI features ``[K, out, out, C]`` that receive ``+= pooled`` in place."""
+    ts = list(feats) + ([add_to] if add_to is not None else [])
+    if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
         return _RoIAlignFn.apply(rois, tuple(featmap_strides), out_size, sample_num, finest_scale,
-                                 *feats)
-    return roi_align_nhwc(feats, rois, featmap_strides, out_size, sample_num, finest_scale)
+                                 pool, add_to, *feats)
+    return roi_align_nhwc(feats, rois, featmap_strides, out_size, sample_num, finest_scale,
+                          pool=pool, out=add_to)
+
+
+def resize_bilinear_nhwc(x, size):
+    """``F.interpolate(x, size, mode='bilinear', align_corners=True)`` on an NHWC map."""
+    _require_cuda(x)
+    lib = capi.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    N, H, W, C = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    y = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    rc = lib.bgs_resize_bilinear_nhwc_f32(capi.ptr(x), capi.ptr(y), N, H, W, C, Ho, Wo, 1,
+                                          capi.current_stream(x.device))
+    capi.check('bgs_resize_bilinear_nhwc_f32', rc)
+    return y
+
+
+class _ResizeBilinearFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.in_shape = tuple(x.shape)
+        return resize_bilinear_nhwc(x.detach(), size)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        lib = capi.load()
+        N, H, W, C = ctx.in_shape
+        dy = dy.contiguous()
+        dx = torch.zeros(ctx.in_shape, dtype=torch.float32, device=dy.device)
+        rc = lib.bgs_resize_bilinear_nhwc_bwd_f32(capi.ptr(dy), capi.ptr(dx), N, H, W, C,
+                                                  dy.shape[1], dy.shape[2], 1,
+                                                  capi.current_stream(dy.device))
+        capi.check('bgs_resize_bilinear_nhwc_bwd_f32', rc)
+        return dx, None
+
+
+def resize_bilinear_nhwc_autograd(x, size):
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _ResizeBilinearFn.apply(x, tuple(size))
+    return resize_bilinear_nhwc(x, size)
 
 
 def nms_batched(boxes, counts, iou_thr, iou_mode=0, max_keep=0):

@@ -68,17 +68,27 @@ class FCNMaskHead(nn.Module):
         b = self.upsample.bias.float().repeat(4)
         return w, b
 
-    def features(self, x, nhwc=True):
-        """RoI features ``[P, h, w, C]`` (or NCHW with ``nhwc=False``) -> ``[P, 2h, 2w, C']``:
-        convs + deconv + ReLU, i.e. ``forward`` up to (not including) ``conv_logits``."""
-        if not nhwc:
-            x = x.permute(0, 2, 3, 1).contiguous()
+    def conv_features(self, x):
+        """The ``convs`` stack on NHWC RoI features; the result is a ``relu='consumers'`` output
+        (every consumer gates its own data gradient: ``mask_input=True``) unless ``num_convs == 0``."""
         first = True
         for m in self.convs:
             w, b = _fold_conv_bn(m.conv, None)
             x = BF.conv2d_autograd(x, w, b, pad=m.padding, relu='consumers',
                                    mask_input=not first)
             first = False
+        return x
+
+    def features(self, x, nhwc=True):
+        """RoI features ``[P, h, w, C]`` (or NCHW with ``nhwc=False``) -> ``[P, 2h, 2w, C']``:
+        convs + deconv + ReLU, i.e. ``forward`` up to (not including) ``conv_logits``."""
+        if not nhwc:
+            x = x.permute(0, 2, 3, 1).contiguous()
+        return self.upsample_features(self.conv_features(x))
+
+    def upsample_features(self, x):
+        """deconv (as a 1x1 conv to 4C + pixel shuffle) + ReLU on the ``conv_features`` output."""
+        first = self.num_convs == 0
         w, b = self._deconv_as_conv()
         if not (torch.is_grad_enabled() and self.upsample.weight.requires_grad):
             w, b = w.detach(), b.detach()
@@ -145,3 +155,71 @@ class FCNMaskHead(nn.Module):
         z = BF.mask_gt_logits(feats.reshape(P, H * W, C), wl, self.conv_logits.bias,
                               self._channel(det_labels + (0 if self.class_agnostic else 1)))
         return torch.sigmoid(z).view(P, H, W)
+
+
+@HEADS.register_module
+class HTCMaskHead(FCNMaskHead):
+    """mmdet/models/mask_heads/htc_mask_head.py:6-38: ``FCNMaskHead`` + ``conv_res`` (1x1 conv +
+    ReLU) that injects the previous stage's mask feature (HTC's mask information flow).
+
+    ``forward`` keeps the reference signature.  The detector uses the split form — ``res_features``
+    (``conv_res`` + add + ``convs``: what ``return_logits=False`` computes) and
+    ``upsample_features`` + the fused single-channel logits / BCE of the base class — so the
+    ``[P, 1231, 28, 28]`` logit tensor is never produced."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.conv_res = ConvModule(self.conv_out_channels, self.conv_out_channels, 1)
+
+    def init_weights(self):
+        super().init_weights()
+        nn.init.kaiming_normal_(self.conv_res.conv.weight, mode='fan_out', nonlinearity='relu')
+        nn.init.constant_(self.conv_res.conv.bias, 0)
+
+    def res_features(self, x, res_feat=None):
+        """NHWC ``x [P,h,w,C]`` (+ previous stage's ``res_feat``) -> this stage's ``res_feat``
+        (htc_mask_head.py:23-28)."""
+        if res_feat is not None:
+            w, b = _fold_conv_bn(self.conv_res.conv, None)
+            x = x + BF.conv2d_autograd(res_feat, w, b, relu=True, mask_input=self.num_convs > 0)
+        return self.conv_features(x)
+
+    def forward(self, x, res_feat=None, return_logits=True, return_feat=True, labels=None,
+                nhwc=False):
+        """Reference signature (NCHW in / out).  ``labels``: only each RoI's own channel."""
+        if not x.is_cuda:
+            if nhwc:
+                x = x.permute(0, 3, 1, 2)
+                res_feat = None if res_feat is None else res_feat.permute(0, 3, 1, 2)
+            if res_feat is not None:
+                x = x + self.relu(self.conv_res.conv(res_feat))
+            for m in self.convs:
+                x = self.relu(m.conv(x))
+            res_out = x
+            outs = []
+            if return_logits:
+                pred = self.conv_logits(self.relu(self.upsample(x)))
+                if labels is not None:
+                    pred = pred[torch.arange(pred.size(0)), self._channel(labels)]
+                outs.append(pred)
+            if return_feat:
+                outs.append(res_out)
+            return outs if len(outs) > 1 else outs[0]
+        if not nhwc:
+            x = x.permute(0, 2, 3, 1).contiguous()
+            res_feat = None if res_feat is None else res_feat.permute(0, 2, 3, 1).contiguous()
+        res_out = self.res_features(x, res_feat)
+        outs = []
+        if return_logits:
+            f = self.upsample_features(res_out)
+            P, H, W, C = f.shape
+            wl = self.conv_logits.weight.view(-1, C)
+            if labels is not None:
+                outs.append(BF.mask_gt_logits(f.reshape(P, H * W, C), wl, self.conv_logits.bias,
+                                              self._channel(labels)).view(P, H, W))
+            else:
+                y = BF.conv2d_autograd(f, wl.view(-1, 1, 1, C).contiguous(), self.conv_logits.bias)
+                outs.append(y.permute(0, 3, 1, 2))
+        if return_feat:
+            outs.append(res_out if nhwc else res_out.permute(0, 3, 1, 2))
+        return outs if len(outs) > 1 else outs[0]

@@ -36,10 +36,13 @@ class SingleRoIExtractor(nn.Module):
     def init_weights(self):
         pass
 
-    def forward(self, feats, rois, roi_scale_factor=None):
+    def forward(self, feats, rois, roi_scale_factor=None, out_size=None, pool=1, add_to=None):
+        """``out_size`` / ``pool`` / ``add_to`` (HTC semantic fusion): pool the ``out_size * pool``
+        RoIAlign grid down to ``out_size`` inside the kernel and add the result INTO ``add_to``."""
         if roi_scale_factor is not None:
-            raise NotImplementedError('roi_scale_factor (HTC variants) is outside this round')
+            raise NotImplementedError('roi_scale_factor is not used by the BAGS configs')
         return BF.roi_align_nhwc_autograd(list(feats[:self.num_inputs]), rois,
-                                          self.featmap_strides, out_size=self.out_size,
+                                          self.featmap_strides,
+                                          out_size=self.out_size if out_size is None else out_size,
                                           sample_num=self.sample_num,
-                                          finest_scale=self.finest_scale)
+                                          finest_scale=self.finest_scale, pool=pool, add_to=add_to)

@@ -44,6 +44,9 @@ def parse():
     ap.add_argument('--rois', type=int, default=1024, help='RoIs per GPU per step (2 img x 512)')
     ap.add_argument('--cascade', action='store_true',
                     help='cfg[4]: Cascade R-CNN X101-64x4d-FPN + BAGS, 3 stages (fp32)')
+    ap.add_argument('--htc', action='store_true',
+                    help='Hybrid Task Cascade X101-64x4d-FPN + BAGS (gs_htc_x101_64x4d_fpn_20e_16gpu_'
+                         'lvis): cascade + 3 HTCMaskHeads + semantic branch (fp32)')
     ap.add_argument('--selectp', type=int, default=1, choices=[0, 1, 3],
                     help='1 (as shipped): train bbox_head.fc_cls only; 0: train everything '
                          '(tools/train.py:49-57)')
@@ -139,9 +142,11 @@ class GsHeadStep(object):
 # ---------------------------------------------------------------------------------------------
 # detector workload: BASELINE.json configs[1]
 # ---------------------------------------------------------------------------------------------
-def detector_cfg(table_dir):
+def detector_cfg(table_dir, mask=False, cascade=False, htc=False):
     """gs_faster_rcnn_r50_fpn_1x_lvis_with0_bg8 (reference configs/bags/...), with the three
-    absent data files replaced by synthetic tables built with the same rule."""
+    absent data files replaced by synthetic tables built with the same rule.  ``mask`` /
+    ``cascade`` / ``htc``: the gs_mask_rcnn_r50, gs_cascade_rcnn_x101_64x4d and
+    gs_htc_x101_64x4d_fpn_20e_16gpu configs of the same directory."""
     paths = gs_tables.save_group_tables(table_dir, *gs_tables.synthetic_group_tables())
     ce = dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)
     model = dict(
@@ -179,14 +184,59 @@ def detector_cfg(table_dir):
                   sampler=dict(type='RandomSampler', num=512, pos_fraction=0.25, neg_pos_ub=-1,
                                add_gt_as_proposals=True),
                   pos_weight=-1, debug=False))
-    return model, train_cfg
+    return _cfg_variant(model, train_cfg, mask, cascade, htc)
+
+
+def _cfg_variant(model_cfg, train_cfg, mask, cascade, htc):
+    mask_ext = dict(type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', out_size=14, sample_num=2),
+                    out_channels=256, featmap_strides=[4, 8, 16, 32])
+    mask_head = dict(type='FCNMaskHead', num_convs=4, in_channels=256, conv_out_channels=256,
+                     num_classes=NUM_CLASSES,
+                     loss_mask=dict(type='CrossEntropyLoss', use_mask=True, loss_weight=1.0))
+    if mask:        # cfg[3] = configs/bags/gs_mask_rcnn_r50_fpn_1x_lvis.py
+        model_cfg['type'] = 'MaskRCNN'
+        model_cfg['mask_roi_extractor'] = mask_ext
+        model_cfg['mask_head'] = mask_head
+        train_cfg['rcnn']['mask_size'] = 28
+    if cascade or htc:     # cfg[4] = configs/bags/gs_cascade_rcnn_x101_64x4d_fpn_1x_lvis.py (fp32 here)
+        model_cfg['type'] = 'CascadeRCNN'
+        model_cfg['num_stages'] = 3
+        model_cfg['backbone'] = dict(type='ResNeXt', depth=101, groups=64, base_width=4,
+                                     num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                                     style='pytorch')
+        base = model_cfg['bbox_head']
+        heads = []
+        for stds in ([0.1, 0.1, 0.2, 0.2], [0.05, 0.05, 0.1, 0.1], [0.033, 0.033, 0.067, 0.067]):
+            h = dict(base, reg_class_agnostic=True, target_stds=stds)
+            h['gs_config'] = dict(base['gs_config'])
+            heads.append(h)
+        model_cfg['bbox_head'] = heads
+        rc = train_cfg['rcnn']
+        train_cfg['rcnn'] = [dict(rc, assigner=dict(rc['assigner'], pos_iou_thr=t, neg_iou_thr=t,
+                                                    min_pos_iou=t)) for t in (0.5, 0.6, 0.7)]
+        train_cfg['stage_loss_weights'] = [1, 0.5, 0.25]
+    if htc:         # configs/bags/gs_htc_x101_64x4d_fpn_20e_16gpu_lvis.py (fp32 here)
+        model_cfg['type'] = 'HybridTaskCascade'
+        model_cfg['interleaved'] = True
+        model_cfg['mask_info_flow'] = True
+        model_cfg['mask_roi_extractor'] = mask_ext
+        model_cfg['mask_head'] = dict(mask_head, type='HTCMaskHead')
+        model_cfg['semantic_roi_extractor'] = dict(
+            type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', out_size=14, sample_num=2),
+            out_channels=256, featmap_strides=[8])
+        model_cfg['semantic_head'] = dict(
+            type='FusedSemanticHead', num_ins=5, fusion_level=1, num_convs=4, in_channels=256,
+            conv_out_channels=256, num_classes=183, ignore_label=255, loss_weight=0.2)
+        for rc in train_cfg['rcnn']:
+            rc['mask_size'] = 28
+    return model_cfg, train_cfg
 
 
 class DetectorStep(object):
     """One training iteration of cfg[1] as shipped (selectp=1: full forward, backward through
     fc_cls, gradient all-reduce, clip, SGD) on synthetic 800x1344 inputs, 512 RoIs/img."""
 
-    def __init__(self, dev, rank, world, imgs, selectp=1, mask=False, cascade=False):
+    def __init__(self, dev, rank, world, imgs, selectp=1, mask=False, cascade=False, htc=False):
         import tempfile
         import balancedgroupsoftmax_amd as bgs
         from balancedgroupsoftmax_amd import train
@@ -194,35 +244,8 @@ class DetectorStep(object):
         self.train = train
         torch.manual_seed(0)                      # identical weights on every rank
         tmp = tempfile.mkdtemp(prefix='bgs_tables_')
-        model_cfg, train_cfg = detector_cfg(tmp)
-        if mask:        # cfg[3] = configs/bags/gs_mask_rcnn_r50_fpn_1x_lvis.py
-            model_cfg['type'] = 'MaskRCNN'
-            model_cfg['mask_roi_extractor'] = dict(
-                type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', out_size=14, sample_num=2),
-                out_channels=256, featmap_strides=[4, 8, 16, 32])
-            model_cfg['mask_head'] = dict(
-                type='FCNMaskHead', num_convs=4, in_channels=256, conv_out_channels=256,
-                num_classes=NUM_CLASSES,
-                loss_mask=dict(type='CrossEntropyLoss', use_mask=True, loss_weight=1.0))
-            train_cfg['rcnn']['mask_size'] = 28
-        if cascade:     # cfg[4] = configs/bags/gs_cascade_rcnn_x101_64x4d_fpn_1x_lvis.py (fp32 here)
-            model_cfg['type'] = 'CascadeRCNN'
-            model_cfg['num_stages'] = 3
-            model_cfg['backbone'] = dict(type='ResNeXt', depth=101, groups=64, base_width=4,
-                                         num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
-                                         style='pytorch')
-            base = model_cfg['bbox_head']
-            heads = []
-            for stds in ([0.1, 0.1, 0.2, 0.2], [0.05, 0.05, 0.1, 0.1], [0.033, 0.033, 0.067, 0.067]):
-                h = dict(base, reg_class_agnostic=True, target_stds=stds)
-                h['gs_config'] = dict(base['gs_config'])
-                heads.append(h)
-            model_cfg['bbox_head'] = heads
-            rc = train_cfg['rcnn']
-            train_cfg['rcnn'] = [dict(rc, assigner=dict(rc['assigner'], pos_iou_thr=t, neg_iou_thr=t,
-                                                        min_pos_iou=t)) for t in (0.5, 0.6, 0.7)]
-            train_cfg['stage_loss_weights'] = [1, 0.5, 0.25]
-        self.mask = mask
+        model_cfg, train_cfg = detector_cfg(tmp, mask=mask, cascade=cascade, htc=htc)
+        self.mask = mask = mask or htc
         self.model = bgs.build_detector(to_config_dict(model_cfg),
                                         train_cfg=to_config_dict(train_cfg), test_cfg=None).to(dev)
         self.selectp = selectp
@@ -254,12 +277,17 @@ class DetectorStep(object):
                 ry = ((b[:, 3] - b[:, 1]) / 2).clamp(min=1).view(-1, 1, 1)
                 self.gt_masks.append(((((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2) <= 1.0)
                                      .to(torch.uint8).contiguous())
+        self.extra = {}
+        if htc:           # [N, 1, H/8, W/8] stuff-class map with 20 % ignored pixels
+            seg = torch.randint(0, 183, (imgs, 1, H // 8, W // 8), generator=g)
+            seg[torch.rand(seg.shape, generator=g) < 0.2] = 255
+            self.extra['gt_semantic_seg'] = seg.to(dev)
         self.last = None
 
     def compute(self):
         """forward + losses + backward: free of host synchronisation -> hipGraph-capturable."""
         losses = self.model(self.img, self.metas, return_loss=True, gt_bboxes=self.gt_bboxes,
-                            gt_labels=self.gt_labels, gt_masks=self.gt_masks)
+                            gt_labels=self.gt_labels, gt_masks=self.gt_masks, **self.extra)
         loss, log_vars = self.train.parse_losses(losses)
         self.step_fn.optimizer.zero_grad(set_to_none=False)
         loss.backward()
@@ -452,7 +480,8 @@ def extras(dev, args):
     runs = (('selectp0', ['--selectp', '0']),
             ('mask_rcnn_selectp1', ['--mask']),
             ('mask_rcnn_selectp0', ['--mask', '--selectp', '0']),
-            ('cascade_x101_64x4d_selectp3_fp32', ['--cascade', '--selectp', '3']))
+            ('cascade_x101_64x4d_selectp3_fp32', ['--cascade', '--selectp', '3']),
+            ('htc_x101_64x4d_selectp3_fp32', ['--htc', '--selectp', '3']))
     for key, flags in runs:
         cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'detector', '--steps', '10',
                '--warmup', '3', '--imgs', str(args.imgs), '--no-extras', '--no-cpu-baseline',
@@ -483,6 +512,7 @@ def run_graph_child(args):
            '--imgs', str(args.imgs), '--selectp', str(args.selectp), '--no-extras',
            '--no-cpu-baseline', '--no-roofline']
     cmd += (['--mask'] if args.mask else []) + (['--cascade'] if args.cascade else [])
+    cmd += ['--htc'] if args.htc else []
     try:
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')]
@@ -498,7 +528,7 @@ def run_graph_child(args):
 def finish_line(out, args, dev, world):
     """Secondary measurements + per-kernel rooflines + CPU baseline, then the ONE JSON line."""
     if world == 1 and not args.no_extras and args.selectp == 1 and not args.mask \
-            and not args.cascade:
+            and not args.cascade and not args.htc:
         out['also_measured'] = extras(dev, args)
     if not args.no_roofline:
         out['roofline'] = conv_roofline(dev)
@@ -523,7 +553,8 @@ def main_detector(args, rank, local, world, dev):
         args.no_graph = True
     if args.child and os.environ.get('BGS_BENCH_CHILD_FAIL'):     # test hook for the fallback path
         os._exit(134)
-    step = DetectorStep(dev, rank, world, args.imgs, args.selectp, args.mask, args.cascade)
+    step = DetectorStep(dev, rank, world, args.imgs, args.selectp, args.mask, args.cascade,
+                        args.htc)
     # Launch policy.  The iteration is free of host synchronisation, so on ONE GPU the whole
     # step (forward, losses, backward, clip, SGD: ~560 launches) is captured into a single
     # hipGraph and replayed.  The graph must own the ENTIRE step: on ROCm 7.2 a large graph whose
@@ -561,7 +592,7 @@ def main_detector(args, rank, local, world, dev):
                                        'layer1: full forward and full backward through heads, '
                                        'RoIAlign, RPN, FPN, ResNet layer2-4'), args.imgs),
                        'selectp': args.selectp, 'mask_branch': bool(args.mask),
-                       'cascade_x101': bool(args.cascade),
+                       'cascade_x101': bool(args.cascade), 'htc_x101': bool(args.htc),
                        'trainable_params': int(sum(p.numel() for p in step.params)),
                        'imgs_per_gpu': args.imgs, 'rois_per_img': 512,
                        'launch': ('hipGraph replay of the whole step (forward+losses+backward+'

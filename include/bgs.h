@@ -245,6 +245,35 @@ int bgs_roi_align_nhwc_bwd(float* const* host_dfeats, const int* host_heights,
                            int pooled_h, int pooled_w, int sample_num, const float* dout,
                            bgs_stream_t stream);
 
+/* RoIAlign with a fused average pool and accumulate (HTC semantic fusion,
+ *   mmdet/models/detectors/htc.py:57-64,88-96: `semantic_roi_extractor([semantic_feat], rois)`
+ *   at 14x14 -> `F.adaptive_avg_pool2d(., 7)` -> `bbox_feats += .`).  Same contract as
+ *   bgs_roi_align_nhwc_fwd / _bwd plus:
+ *   pool        1 or 2: every output bin is the mean of pool x pool bins of the
+ *               (pooled_h*pool) x (pooled_w*pool) RoIAlign grid (pool == 2 needs C <= 256);
+ *   accumulate  != 0: out += result (out holds the box / mask RoI features).
+ *   The backward scatters dout / (4 * pool^2) per sample, atomically, into host_dfeats. */
+int bgs_roi_align_nhwc_fwd_ex(const float* const* host_feats, const int* host_heights,
+                              const int* host_widths, const float* host_scales, int num_levels,
+                              int num_images, float finest_scale, const float* rois, int K, int C,
+                              int pooled_h, int pooled_w, int sample_num, int pool,
+                              int accumulate, float* out, int* levels_out, bgs_stream_t stream);
+int bgs_roi_align_nhwc_bwd_ex(float* const* host_dfeats, const int* host_heights,
+                              const int* host_widths, const float* host_scales, int num_levels,
+                              int num_images, float finest_scale, const float* rois, int K, int C,
+                              int pooled_h, int pooled_w, int sample_num, int pool,
+                              const float* dout, bgs_stream_t stream);
+
+/* Bilinear resize of NHWC maps, align_corners = 1 only (BGS_ERR_UNSUPPORTED otherwise).
+ *   Replaces F.interpolate(feat, size, mode='bilinear', align_corners=True) of the HTC semantic
+ *   head (mmdet/models/mask_heads/fused_semantic_head.py:88-93); arithmetic = torch's
+ *   upsample_bilinear2d.  x [N,H,W,C] -> y [N,Ho,Wo,C], C % 4 == 0.
+ *   _bwd: dy [N,Ho,Wo,C] is scattered with fp32 atomics INTO dx [N,H,W,C] (zero it first). */
+int bgs_resize_bilinear_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, int Ho,
+                                 int Wo, int align_corners, bgs_stream_t stream);
+int bgs_resize_bilinear_nhwc_bwd_f32(const float* dy, float* dx, int N, int H, int W, int C,
+                                     int Ho, int Wo, int align_corners, bgs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Batched greedy NMS, entirely on the device.  Replaces ops.nms / nms_cuda
  *   (mmdet/ops/nms/nms_wrapper.py:8-49, src/nms_kernel.cu:13-131; CPU variant nms_cpu.cpp:5-59)

@@ -74,7 +74,7 @@ def test_refine_bboxes_equals_reference_head():
 def test_every_non_htc_bags_config_builds_unmodified(tmp_path, name):
     """configs/bags/*.py load with Config.fromfile and build through the registries; only the
     three data-file paths are redirected to synthetic tables (the files are not in the repo).
-    The two HTC configs need HybridTaskCascade (mask information flow + semantic head): not built."""
+    The HTC configs are covered by tests/test_htc_cpu.py."""
     cfg = bgs.Config.fromfile(os.path.join(ref_import.REFERENCE_ROOT, 'configs/bags', name))
     paths = gs_tables.save_group_tables(str(tmp_path), *gs_tables.synthetic_group_tables())
     heads = cfg.model.bbox_head if isinstance(cfg.model.bbox_head, list) else [cfg.model.bbox_head]
