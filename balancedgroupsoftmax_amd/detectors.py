@@ -589,7 +589,13 @@ class HybridTaskCascade(CascadeRCNN):
         """htc.py:313-432 with ``keep_all_stages=False``: the ensemble boxes (stage-averaged class
         logits) and, per detection, the mean over stages of its class's mask probability
         ``[k, 28, 28]`` (``merge_aug_masks`` without weights; pasting / RLE is evaluation tooling)."""
-        from .post_processing import bbox2result, multiclass_nms
+        from .post_processing import bbox2result
+        det_bboxes, det_labels, masks = self.simple_test_dets(img, img_meta, proposals, rescale)
+        return bbox2result(det_bboxes, det_labels, self.bbox_head[-1].num_classes), masks
+
+    def simple_test_dets(self, img, img_meta, proposals=None, rescale=False):
+        """-> ``(det_bboxes [k,5], det_labels [k], mask_probs [k,28,28])`` device tensors."""
+        from .post_processing import multiclass_nms
         if self.test_cfg.get('keep_all_stages', False):
             raise NotImplementedError('keep_all_stages=True (per-stage results) is not built')
         x = self.extract_feat(img)
@@ -617,11 +623,15 @@ class HybridTaskCascade(CascadeRCNN):
         cfg = self.test_cfg.rcnn
         det_bboxes, det_labels = multiclass_nms(bboxes, scores, cfg.score_thr, cfg.nms,
                                                 cfg.max_per_img)
-        bbox_result = bbox2result(det_bboxes, det_labels, self.bbox_head[-1].num_classes)
         if det_bboxes.shape[0] == 0:
-            return bbox_result, det_bboxes.new_zeros((0, 28, 28))
+            return det_bboxes, det_labels, det_bboxes.new_zeros((0, 28, 28))
         boxes = det_bboxes[:, :4] * scale_factor if rescale else det_bboxes[:, :4]
         mask_rois = torch.cat([boxes.new_zeros((boxes.size(0), 1)), boxes], dim=1)
+        return det_bboxes, det_labels, self._ensemble_masks(x, mask_rois, det_labels, semantic_feat)
+
+    def _ensemble_masks(self, x, mask_rois, det_labels, semantic_feat):
+        """htc.py:379-405: every stage's mask head on the final boxes' features (mask information
+        flow through ``conv_res``), mean of the per-class probabilities."""
         mask_feats = self._fused_roi_feats(self.mask_roi_extractor[-1], x, mask_rois, semantic_feat,
                                            'mask')
         probs, last = [], None
@@ -630,7 +640,7 @@ class HybridTaskCascade(CascadeRCNN):
             last = head.res_features(mask_feats, last) if self.mask_info_flow \
                 else head.conv_features(mask_feats)
             probs.append(head.get_mask_probs(head.upsample_features(last), det_labels))
-        return bbox_result, sum(probs) / float(len(probs))
+        return sum(probs) / float(len(probs))
 
 
 @DETECTORS.register_module

@@ -256,3 +256,36 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, iou_thr, max_num=-1, m
         order = np.argsort(-bb[:, 4], kind='stable')[:max_num]
         bb, ll = bb[order], ll[order]
     return bb, ll
+
+
+def fill_detector(state_dict, seed):
+    """In-place seeded values for EVERY tensor of a detector state_dict (sorted name order), for
+    the end-to-end goldens (tests/golden/make_golden_e2e.py): He-scaled conv / fc weights, small
+    biases, BatchNorm statistics that keep an eval-mode trunk well conditioned (variance in
+    [0.5, 1.5], the residual branch's last BN scaled down so that 16 bottlenecks do not blow the
+    activations up).  Works on the reference's and on this package's modules alike (same names)."""
+    import torch
+    rs = np.random.RandomState(seed)
+    for name in sorted(state_dict.keys()):
+        t = state_dict[name]
+        shape = tuple(t.shape)
+        if name.endswith('num_batches_tracked'):
+            continue
+        if name.endswith('running_var'):
+            v = rs.uniform(0.5, 1.5, size=shape)
+        elif name.endswith('running_mean'):
+            v = rs.standard_normal(shape) * 0.1
+        elif t.dim() == 1 and name.endswith('weight'):            # BatchNorm gamma
+            lo, hi = (0.2, 0.4) if '.bn3.' in name else (0.8, 1.2)
+            v = rs.uniform(lo, hi, size=shape)
+        elif name.endswith('weight'):
+            fan_in = int(np.prod(shape[1:]))
+            v = rs.standard_normal(shape) * np.sqrt(2.0 / max(fan_in, 1))
+            if name.startswith('neck.lateral_convs'):
+                v = v * 0.04       # the eval-mode trunk leaves activations of std ~25: back to O(1)
+            elif 'rpn_reg' in name:
+                v = v * 0.2        # proposal deltas of std ~0.3 (target_stds = 1)
+        else:
+            v = rs.standard_normal(shape) * 0.05
+        t.copy_(torch.from_numpy(np.asarray(v, dtype=F32)))
+    return state_dict

@@ -134,3 +134,25 @@ def test_cascade_mask_rcnn_is_refused_loudly(tmp_path):
     with pytest.raises(NotImplementedError, match='HybridTaskCascade'):
         bgs.build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
                            test_cfg=None)
+
+
+def test_e2e_golden_fixture_and_seeded_weights_are_reproducible(tmp_path):
+    """tests/golden/e2e_inference_golden.npz (executed reference detectors) is present and the
+    seeded filler writes the same values into this package's modules on every call."""
+    from oracle import det_oracle
+    from tests.golden import make_golden_e2e as E
+    z = np.load(os.path.join(os.path.dirname(E.__file__), 'e2e_inference_golden.npz'))
+    assert z['frcnn/det_bboxes'].shape == (50, 5) and z['htc/mask_probs'].shape == (50, 28, 28)
+    assert z['frcnn/proposals'].shape[1] == 5 and z['htc/cls_score2'].shape[1] == 1236
+    from balancedgroupsoftmax_amd.config import to_config_dict
+    a = bgs.build_detector(to_config_dict(E.configs(str(tmp_path), 'frcnn')), train_cfg=None,
+                           test_cfg=to_config_dict(E.TEST_CFG))
+    b = bgs.build_detector(to_config_dict(E.configs(str(tmp_path), 'frcnn')), train_cfg=None,
+                           test_cfg=to_config_dict(E.TEST_CFG))
+    with torch.no_grad():
+        det_oracle.fill_detector(a.state_dict(), E.FRCNN_SEED)
+        det_oracle.fill_detector(b.state_dict(), E.FRCNN_SEED)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    assert float(sa['backbone.layer1.0.bn1.running_var'].min()) >= 0.5
+    assert E.image().shape == (1, 3, E.H, E.W)
