@@ -98,9 +98,14 @@ class BBoxHead(nn.Module):
                            rcnn_train_cfg, self.num_reg_classes,
                            target_means=self.target_means, target_stds=self.target_stds)
 
-    def _loss_bbox(self, bbox_pred, labels, bbox_targets, bbox_weights, reduction_override):
+    def _loss_bbox(self, bbox_pred, labels, bbox_targets, bbox_weights, reduction_override,
+                   label_weights=None):
         """Box branch shared by every head (bbox_head.py:117-129, gs_bbox_head_with0.py:173-185):
         HIP gather + SmoothL1 + dense-gradient kernel, no boolean-mask indexing, no sync.
+
+        The normaliser is the reference's ``bbox_targets.size(0)`` = the number of sampled RoIs.
+        In a fixed-shape batch that is the number of REAL rows: padding slots (``label_weights``
+        == 0; the reference's sampler returns fewer RoIs instead) do not count.
 
         Deviation kept on purpose: an all-background batch returns 0 instead of tripping the
         reference's ``target.numel() > 0`` assertion (smooth_l1_loss.py:11), which would need a
@@ -111,9 +116,13 @@ class BBoxHead(nn.Module):
         lb = self.loss_bbox
         if type(lb).__name__ != 'SmoothL1Loss':
             raise NotImplementedError('HIP box loss implements SmoothL1Loss only')
-        return BF.bbox_smooth_l1_loss(bbox_pred, labels, bbox_targets, bbox_weights,
-                                      self.num_reg_classes, beta=lb.beta,
-                                      avg_factor=bbox_targets.size(0), loss_weight=lb.loss_weight)
+        val = BF.bbox_smooth_l1_loss(bbox_pred, labels, bbox_targets, bbox_weights,
+                                     self.num_reg_classes, beta=lb.beta,
+                                     avg_factor=bbox_targets.size(0), loss_weight=lb.loss_weight)
+        if label_weights is not None and label_weights.is_cuda:
+            n_real = (label_weights > 0).sum().to(torch.float32).clamp(min=1.0)
+            val = val * (float(bbox_targets.size(0)) / n_real)
+        return val
 
     @force_fp32(apply_to=('cls_score', 'bbox_pred'))
     def loss(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights,
@@ -127,7 +136,7 @@ class BBoxHead(nn.Module):
             losses['acc'] = accuracy(cls_score, labels)
         if bbox_pred is not None:
             losses['loss_bbox'] = self._loss_bbox(bbox_pred, labels, bbox_targets, bbox_weights,
-                                                  reduction_override)
+                                                  reduction_override, label_weights)
         return losses
 
     def _scores(self, cls_score):
@@ -395,17 +404,21 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
             w = w * np.asarray(cls_weight, dtype=np.float64)[bin_label]
         return w
 
-    def _remap_labels(self, labels):
+    def _remap_labels(self, labels, label_weights=None):
         """gs_bbox_head_with0.py:91-112 returned Python lists + floats via .item(); here the
         three results are device tensors: bin labels ``[B, N]`` i32, sample weights ``[B, N]``
-        f32 and avg factors ``[B]`` f32."""
+        f32 and avg factors ``[B]`` f32.
+
+        ``label_weights``: rows with weight 0 are padding slots of a fixed-shape batch (the
+        reference's sampler returns fewer RoIs instead of padding, so its head never sees such
+        rows and ignores the argument): they are left out of every count, draw and loss."""
         if self.sampler == 'device':
             if self._seed is None:
                 self._seed = (torch.initial_seed() * 0x9E3779B1) & 0xFFFFFFFFFFFFFFFF
             self._draw += 1
             return BF.gs_prepare(labels, self.label2binlabel, self.others_sample_ratio,
                                  seed=self._seed, seed_offset=self._draw,
-                                 cls_weight=self.cls_weight_table)
+                                 cls_weight=self.cls_weight_table, row_weights=label_weights)
         if self.sampler != 'numpy':
             raise ValueError('gs_config.sampler must be "device" or "numpy"')
         l2b = self.label2binlabel_host
@@ -413,9 +426,17 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
         B = l2b.shape[0]
         bl = l2b[:, lab]
         w = np.ones((B, lab.shape[0]), dtype=np.float64)
+        real = None
+        if label_weights is not None:
+            real = label_weights.detach().cpu().numpy() > 0
         for i in range(1, B):
             cw = None if self.cls_weights is None else self.cls_weights[i - 1]
-            w[i] = self._sample_others_numpy(bl[i], cw)
+            if real is None or real.all():
+                w[i] = self._sample_others_numpy(bl[i], cw)
+            else:
+                w[i, real] = self._sample_others_numpy(bl[i][real], cw)
+        if real is not None:
+            w[:, ~real] = 0.0
         avg = np.maximum(w.sum(axis=1).astype(np.float32), np.float32(1.0))
         dev = labels.device
         return (torch.from_numpy(np.ascontiguousarray(bl, dtype=np.int32)).to(dev),
@@ -439,7 +460,7 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
                                       'kernel (no detector on the BAGS path requests it)')
         losses = dict()
         if cls_score is not None:
-            bin_labels, weights, avg = self._remap_labels(labels)
+            bin_labels, weights, avg = self._remap_labels(labels, label_weights)
             per_bin = BF.group_softmax_loss(cls_score, bin_labels, self.pred_slice_host,
                                             weights, avg)
             per_bin = per_bin * self.bin_loss_weight
@@ -447,7 +468,7 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
                 losses['loss_cls_bin{}'.format(i)] = per_bin[i]
         if bbox_pred is not None:
             losses['loss_bbox'] = self._loss_bbox(bbox_pred, labels, bbox_targets, bbox_weights,
-                                                  reduction_override)
+                                                  reduction_override, label_weights)
         return losses
 
     @force_fp32(apply_to=('cls_score', ))

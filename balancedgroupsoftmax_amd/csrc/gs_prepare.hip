@@ -13,6 +13,9 @@
 //   32-bit counter-based random keys of the non-fg rows)  == uniform sampling of exactly k
 //   rows without replacement (ties broken by row index), found by a 4-pass radix select.
 //   avg    = max(sum_r w[r], 1)
+// Fixed-shape batches: `row_weights` (the detector's label_weights) marks padding slots with a
+// value <= 0 — the reference's sampler returns FEWER RoIs instead (two_stage.py:200-210), so such
+// rows are excluded from everything: not counted in N, never sampled, weight 0 in every bin.
 #include "bgs_common.h"
 
 namespace {
@@ -51,7 +54,8 @@ __device__ __forceinline__ double block_sum_d(double v, double* sm) {
 
 __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
     const int64_t* __restrict__ labels, const int64_t* __restrict__ l2b,
-    const float* __restrict__ cls_weight, int cw_stride, int N, int C, int B, double ratio,
+    const float* __restrict__ cls_weight, int cw_stride, const float* __restrict__ row_weights,
+    int N, int C, int B, double ratio,
     uint64_t seed, const uint64_t* __restrict__ seed_offset, int32_t* __restrict__ bl_out,
     float* __restrict__ w_out, float* __restrict__ avg_out) {
   __shared__ PrepShared sh;
@@ -60,17 +64,19 @@ __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
   const int64_t* map = l2b + (size_t)b * C;
   if (seed_offset) seed += 0x2545F4914F6CDD1Dull * seed_offset[0];  // device-side draw counter
 
-  // pass 0: bin labels + foreground count
-  int nfg_local = 0;
+  // pass 0: bin labels + foreground count (+ number of real rows)
+  int nfg_local = 0, nreal_local = 0;
   for (int r = tid; r < N; r += kThreads) {
     int64_t y = labels[r];
     y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
     const int64_t bl = map[y];
     if (bl_out) bl_out[(size_t)b * N + r] = (int32_t)bl;
-    nfg_local += (bl > 0) ? 1 : 0;
+    const bool real = !row_weights || row_weights[r] > 0.f;
+    nfg_local += (real && bl > 0) ? 1 : 0;
+    nreal_local += real ? 1 : 0;
   }
   const int n_fg = block_sum_i(nfg_local, sh.wsum_i);
-  const int n_bg = N - n_fg;
+  const int n_bg = block_sum_i(nreal_local, sh.wsum_i) - n_fg;
 
   // mode: 0 = all zero, 1 = all one, 2 = sampled
   int mode;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
       for (int r = tid; r < N; r += kThreads) {
         int64_t y = labels[r];
         y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
-        if (map[y] > 0) continue;
+        if (map[y] > 0 || (row_weights && !(row_weights[r] > 0.f))) continue;
         const unsigned key = bgs::hash_u32(seed, (uint32_t)b, (uint32_t)r);
         if ((key & himask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 0xFFu], 1);
       }
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
         for (int r = 0; r < N; ++r) {
           int64_t y = labels[r];
           y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
-          if (map[y] > 0) continue;
+          if (map[y] > 0 || (row_weights && !(row_weights[r] > 0.f))) continue;
           if (bgs::hash_u32(seed, (uint32_t)b, (uint32_t)r) == T) {
             if (++got == need) { bound = r + 1; break; }
           }
@@ -160,8 +166,8 @@ __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
     y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
     const int64_t bl = map[y];
     float w;
-    if (mode == 0) {
-      w = 0.f;  // reference returns zeros BEFORE the class-weight multiply (reweight.py:65-66)
+    if (mode == 0 || (row_weights && !(row_weights[r] > 0.f))) {
+      w = 0.f;  // (padding slot, or) the reference returns zeros BEFORE the class-weight multiply (reweight.py:65-66)
     } else {
       bool sel = true;
       if (mode == 2) {
@@ -187,7 +193,8 @@ __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
 }  // namespace
 
 extern "C" int bgs_gs_prepare(const int64_t* labels, const int64_t* label2binlabel,
-                              const float* cls_weight, int cls_weight_stride, int N, int C, int B,
+                              const float* cls_weight, int cls_weight_stride,
+                              const float* row_weights, int N, int C, int B,
                               double others_sample_ratio, uint64_t seed,
                               const uint64_t* seed_offset, int32_t* bin_labels_out,
                               float* weights_out, float* avg_out, bgs_stream_t stream) {
@@ -197,7 +204,8 @@ extern "C" int bgs_gs_prepare(const int64_t* labels, const int64_t* label2binlab
     return BGS_ERR_INVALID_ARG;
   if (cls_weight && cls_weight_stride <= 0) return BGS_ERR_INVALID_ARG;
   hipLaunchKernelGGL(gs_prepare_kernel, dim3(B), dim3(kThreads), 0, (hipStream_t)stream, labels,
-                     label2binlabel, cls_weight, cls_weight_stride, N, C, B, others_sample_ratio,
+                     label2binlabel, cls_weight, cls_weight_stride, row_weights, N, C, B,
+                     others_sample_ratio,
                      seed, seed_offset, bin_labels_out, weights_out, avg_out);
   BGS_RETURN_LAUNCH_STATUS();
 }

@@ -50,7 +50,7 @@ _seed_counter = itertools.count(1)
 
 
 def gs_prepare(labels, label2binlabel, others_sample_ratio, seed=None, cls_weight=None,
-               seed_offset=None):
+               seed_offset=None, row_weights=None):
     """Device-side ``_remap_labels``: returns ``bin_labels [B,N] i32`` (the
     ``label2binlabel[b][labels]`` gather), ``weights [B,N] f32``, ``avg [B] f32``.  No host sync.
 
@@ -58,8 +58,10 @@ def gs_prepare(labels, label2binlabel, others_sample_ratio, seed=None, cls_weigh
     a process-wide counter mixed with ``torch.initial_seed()`` (reproducible runs).
     ``seed_offset``: optional device int64 ``[1]`` draw counter added to the seed on the
     device (bump it with a tensor op; needed under hipGraph replay where ``seed`` is frozen).
+    ``row_weights``: the detector's ``label_weights [N]``; rows <= 0 are padding slots of a
+    fixed-shape batch and are left out of every count, draw and loss.
     """
-    _require_cuda(labels, label2binlabel, cls_weight)
+    _require_cuda(labels, label2binlabel, cls_weight, row_weights)
     lib = capi.load()
     labels = labels.contiguous()
     assert labels.dtype == torch.int64 and label2binlabel.dtype == torch.int64
@@ -76,8 +78,12 @@ def gs_prepare(labels, label2binlabel, others_sample_ratio, seed=None, cls_weigh
         assert cls_weight.dtype == torch.float32 and cls_weight.dim() == 2
         assert cls_weight.shape[0] == B - 1 and cls_weight.is_contiguous()
         cw_stride = cls_weight.shape[1]
+    if row_weights is not None:
+        row_weights = _f32c(row_weights)
+        assert row_weights.numel() == N
     rc = lib.bgs_gs_prepare(capi.ptr(labels), capi.ptr(label2binlabel), capi.ptr(cls_weight),
-                            cw_stride, N, C, B, float(others_sample_ratio), int(seed),
+                            cw_stride, capi.ptr(row_weights), N, C, B, float(others_sample_ratio),
+                            int(seed),
                             capi.ptr(seed_offset), capi.ptr(bl), capi.ptr(weights), capi.ptr(avg),
                             capi.current_stream(dev))
     capi.check('bgs_gs_prepare', rc)

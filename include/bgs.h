@@ -55,6 +55,10 @@ int bgs_selftest_mfma_peak(int blocks, int iters, float* out, bgs_stream_t strea
  *   label2binlabel  [B,C]  int64 (label2binlabel.pt)
  *   cls_weight      [B-1, cls_weight_stride] float or NULL: per-bin class weights indexed
  *                   by bin label (bins_cls_weight.pkl), row i-1 for bin i
+ *   row_weights     [N] float or NULL: the detector's label_weights; rows with a value <= 0 are
+ *                   padding slots of a fixed-shape batch (the reference's sampler returns fewer
+ *                   RoIs instead, two_stage.py:200-210) and are excluded from everything: not
+ *                   counted, never drawn, weight 0 in every bin
  *   others_sample_ratio    keep all in-bin foreground rows + int(n_fg*ratio) others,
  *                   drawn uniformly WITHOUT replacement (counter-based RNG keyed by
  *                   (seed, bin, row); same (seed) => same draw; no host RNG, no sync)
@@ -66,7 +70,7 @@ int bgs_selftest_mfma_peak(int blocks, int iters, float* out, bgs_stream_t strea
  *   avg_out         [B]    float  = max(sum_r weights[b,r], 1)
  * ---------------------------------------------------------------------------------- */
 int bgs_gs_prepare(const int64_t* labels, const int64_t* label2binlabel,
-                   const float* cls_weight, int cls_weight_stride,
+                   const float* cls_weight, int cls_weight_stride, const float* row_weights,
                    int N, int C, int B, double others_sample_ratio, uint64_t seed,
                    const uint64_t* seed_offset, int32_t* bin_labels_out, float* weights_out, float* avg_out,
                    bgs_stream_t stream);

@@ -48,7 +48,7 @@ def test_argument_validation_without_gpu():
     assert lib.bgs_gs_loss_fwd_bwd(None, None, bad.ctypes.data_as(ctypes.c_void_p), None, None,
                                    0, 2, 13, None, None, ws, None) == 1
     assert lib.bgs_gs_merge_score(None, None, None, -1, 10, 3, 13, None, None) == 1
-    assert lib.bgs_gs_prepare(None, None, None, 0, 4, 10, 3, 8.0, 1, None, None, None, None, None) == 1
+    assert lib.bgs_gs_prepare(None, None, None, 0, None, 4, 10, 3, 8.0, 1, None, None, None, None, None) == 1
     assert lib.bgs_bbox_smooth_l1_fwd_bwd(None, None, None, None, 4, 10, 0.0, 4.0, 1.0, None,
                                           None, None, None) == 1
     assert lib.bgs_gs_loss_workspace_bytes(1024, 5) >= 1024 * 4

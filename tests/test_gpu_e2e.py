@@ -135,3 +135,57 @@ def test_htc_vs_executed_reference_detector():
                 worst = max(worst, float(np.abs(m[j[0]] - z['htc/mask_probs'][k]).max()))
         assert hit >= 48, hit
         assert worst < 2e-3, worst          # ensemble mask probability of the matched detections
+
+
+def grad_close(a, b, tol=2e-4, frac=0.8, worst=3e-2, l2tol=1e-2):
+    """Gradients travel through up to ~50 ReLU layers: a pre-activation within fp32 noise of zero
+    takes the other branch than in the torch-CPU run (a handful of entries move by up to ~1 % of
+    the largest one); a wrong kernel is off by O(1) everywhere."""
+    rel = np.abs(a - b) / max(np.abs(b).max(), 1e-20)
+    l2 = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-20))
+    ok = (rel < tol).mean() > frac and rel.max() < worst and l2 < l2tol
+    if not ok:
+        print('grad_close: %.4f within tol, worst %.3e, rel-L2 %.3e' % ((rel < tol).mean(), rel.max(), l2))
+    return ok
+
+
+def test_training_iteration_vs_executed_reference_detector():
+    """Full ``forward_train`` + ``backward`` of the BASELINE config against the executed reference
+    (tests/golden/make_golden_train.py): every loss term and gradients from the head down to
+    layer2 of the trunk.  The samplers are configured to take every candidate (no random draw on
+    either side); everything else is the shipped configuration."""
+    from balancedgroupsoftmax_amd import train
+    from tests.golden import make_golden_train as T
+    z = np.load(os.path.join(os.path.dirname(T.__file__), 'e2e_train_golden.npz'))
+    tmp = tempfile.mkdtemp(prefix='bgs_e2e_')
+    model_cfg, train_cfg = T.configs(tmp)
+    model = bgs.build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
+                               test_cfg=to_config_dict(G.TEST_CFG))
+    with torch.no_grad():
+        det_oracle.fill_detector(model.state_dict(), T.SEED)
+    model.to(DEV)
+    train.select_training_param(model, 0)
+    model.train()
+    boxes, labels = T.gt()
+    losses = model(torch.from_numpy(G.image()).to(DEV), G.img_meta(), return_loss=True,
+                   gt_bboxes=[torch.from_numpy(boxes).to(DEV)],
+                   gt_labels=[torch.from_numpy(labels).to(DEV)])
+    for k in ('loss_rpn_cls', 'loss_rpn_bbox'):
+        got = np.array([float(t.detach().sum()) for t in losses[k]], np.float32)
+        assert np.abs(got - z['loss/' + k]).max() < 1e-4 * max(1.0, np.abs(z['loss/' + k]).max()), \
+            (k, got, z['loss/' + k])
+    for k in ['loss_cls_bin%d' % i for i in range(5)] + ['loss_bbox']:
+        got, exp = float(losses[k].detach().sum()), float(z['loss/' + k][0])
+        assert abs(got - exp) < 1e-4 * max(1.0, abs(exp)), (k, got, exp)
+    loss, _ = train.parse_losses(losses)
+    assert abs(float(loss.detach()) - float(z['loss/total'][0])) < 1e-4 * float(z['loss/total'][0])
+    loss.backward()
+    params = dict(model.named_parameters())
+    assert params['backbone.layer1.0.conv1.weight'].grad is None
+    bad = []
+    for name, idx in T.GRADS:
+        g = params[name].grad
+        assert g is not None, name
+        if not grad_close(g[idx].cpu().numpy(), z['grad/' + name]):
+            bad.append(name)
+    assert not bad, bad

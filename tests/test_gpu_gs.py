@@ -254,6 +254,42 @@ def test_device_sampling_matches_reference_rule(name):
     np.testing.assert_array_equal(w2.cpu().numpy(), w)
 
 
+@pytest.mark.parametrize('ratio', [2.0, 8.0, 1e6])
+def test_padding_rows_are_excluded_like_a_shorter_batch(ratio):
+    """Fixed-shape batches: rows with ``row_weights == 0`` (padding slots; the reference's sampler
+    returns FEWER RoIs instead, two_stage.py:200-210) must not count — weights 0 in every bin and
+    exactly the reference rule (counts, k, avg) on the real rows."""
+    case, l2b, ps, _, _, batch = case_setup('n512_cfg1')
+    labels = batch['labels'].copy()
+    N = labels.shape[0]
+    rs = np.random.RandomState(7)
+    real = rs.rand(N) > 0.3
+    labels[~real] = 0                                    # padding slots carry label 0
+    rw = real.astype(np.float32) * rs.uniform(0.5, 2.0, size=N).astype(np.float32)
+    bl, w, avg = BF.gs_prepare(dev(labels), dev(l2b), ratio, seed=99, row_weights=dev(rw))
+    w, avg, bl = w.cpu().numpy(), avg.cpu().numpy(), bl.cpu().numpy()
+    assert (w[:, ~real] == 0).all()
+    assert (w[0][real] == 1).all() and avg[0] == real.sum()
+    for b in range(1, bl.shape[0]):
+        n_fg, k = _expected_counts(bl[b][real], ratio)
+        sel = w[b] != 0
+        if n_fg == 0:
+            assert not sel.any() and avg[b] == 1.0
+            continue
+        assert sel[real & (bl[b] > 0)].all()
+        n_others = int((real & (bl[b] == 0)).sum())
+        assert int(sel[real & (bl[b] == 0)].sum()) == min(k, n_others)
+        assert avg[b] == pytest.approx(max(float(w[b].sum()), 1.0), rel=1e-6)
+    # the loss of the padded batch == the loss of the compacted batch when nothing is drawn
+    if ratio >= 1e6:
+        z = dev(batch['logits'])
+        full = BF.group_softmax_loss(z, dev(bl.astype(np.int32)), ps, dev(w), dev(avg))
+        idx = np.nonzero(real)[0]
+        bl_c, w_c, avg_c = BF.gs_prepare(dev(labels[idx]), dev(l2b), ratio, seed=99)
+        comp = BF.group_softmax_loss(dev(batch['logits'][idx]), bl_c, ps, w_c, avg_c)
+        assert torch.allclose(full, comp, rtol=1e-5, atol=1e-6)
+
+
 def test_device_sampling_is_uniform():
     """Selection frequency of every non-fg row over many seeds ~ k / n_bg."""
     case, l2b, ps, _, _, batch = case_setup('n512_cfg1')
