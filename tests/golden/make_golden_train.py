@@ -55,6 +55,27 @@ GRADS = [
 ]
 
 
+GRADS_HTC = [
+    ('bbox_head.0.fc_cls.weight', (slice(None, None, 16), slice(None, None, 16))),
+    ('bbox_head.1.fc_cls.weight', (slice(None, None, 16), slice(None, None, 16))),
+    ('bbox_head.2.fc_cls.weight', (slice(None, None, 16), slice(None, None, 16))),
+    ('bbox_head.1.shared_fcs.0.weight', (slice(None, None, 16), slice(None, None, 256))),
+    ('bbox_head.2.fc_reg.bias', (slice(None),)),
+    ('mask_head.0.convs.0.conv.weight', (slice(None, None, 16), slice(None, None, 16))),
+    ('mask_head.1.conv_res.conv.weight', (slice(None, None, 4), slice(None, None, 4))),
+    ('mask_head.2.conv_logits.weight', (slice(None, None, 16),)),
+    ('mask_head.2.upsample.bias', (slice(None),)),
+    ('semantic_head.conv_logits.weight', (slice(None, None, 4), slice(None, None, 4))),
+    ('semantic_head.lateral_convs.3.conv.weight', (slice(None, None, 8), slice(None, None, 8))),
+    ('semantic_head.conv_embedding.conv.bias', (slice(None),)),
+    ('neck.fpn_convs.1.conv.weight', (slice(None, None, 16), slice(None, None, 16))),
+    ('rpn_head.rpn_conv.weight', (slice(None, None, 16), slice(None, None, 16))),
+    ('backbone.layer3.0.conv1.weight', (slice(None, None, 8), slice(None, None, 8))),
+    ('backbone.layer2.1.bn2.weight', (slice(None),)),
+]
+HTC_SEED = 921
+
+
 def gt():
     rs = np.random.RandomState(SEED)
     n = 6
@@ -65,10 +86,33 @@ def gt():
     return boxes, labels
 
 
-def configs(table_dir):
+def gt_masks(boxes):
+    """One bitmap per GT: an axis-aligned ellipse inscribed in its box, ``[G, H, W]`` uint8."""
+    yy = np.arange(E.H, dtype=np.float32)[:, None]
+    xx = np.arange(E.W, dtype=np.float32)[None, :]
+    out = []
+    for x1, y1, x2, y2 in boxes:
+        cx, cy, rx, ry = (x1 + x2) / 2, (y1 + y2) / 2, max((x2 - x1) / 2, 1), max((y2 - y1) / 2, 1)
+        out.append(((((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2) <= 1.0).astype(np.uint8))
+    return np.stack(out)
+
+
+def gt_semantic_seg():
+    rs = np.random.RandomState(SEED + 5)
+    seg = rs.randint(0, 183, size=(1, 1, E.H // 8, E.W // 8)).astype(np.int64)
+    seg[rs.rand(*seg.shape) < 0.2] = 255
+    return seg
+
+
+def configs(table_dir, htc=False):
     from bench import detector_cfg
-    model, train_cfg = detector_cfg(table_dir)
-    model['bbox_head']['gs_config']['others_sample_ratio'] = 1e6
+    model, train_cfg = detector_cfg(table_dir, htc=htc)
+    heads = model['bbox_head'] if htc else [model['bbox_head']]
+    for h in heads:
+        h['gs_config']['others_sample_ratio'] = 1e6
+    if htc:         # plain ResNet-50 trunk: full backward on both sides
+        model['backbone'] = dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3),
+                                 frozen_stages=1, style='pytorch')
     train_cfg['rpn']['sampler']['num'] = 16384
     train_cfg['rpn_proposal'].update(nms_post=300, max_num=300)
     return model, train_cfg
@@ -103,6 +147,11 @@ def _bind_reference_ops():
     from mmdet.core.bbox.samplers.random_sampler import RandomSampler
     RandomSampler.random_choice = staticmethod(no_draw)
     np.random.choice = no_draw
+    # mask_target.py:31 resizes the cropped bitmap with mmcv.imresize = cv2.resize(INTER_LINEAR);
+    # neither is installed here: oracle/mask_oracle.py restates OpenCV's fixed-point path
+    # ("parity unpinned" for that one step, see its header)
+    from oracle import mask_oracle
+    sys.modules['mmcv'].imresize = lambda img, size: mask_oracle.resize_linear_u8(img, size)
 
 
 def main():
@@ -132,8 +181,36 @@ def main():
     for name, idx in GRADS:
         out['grad/' + name] = params[name].grad[idx].contiguous().numpy()
     assert params['backbone.layer1.0.conv1.weight'].grad is None      # frozen_stages=1
+
+    # ------------------------------------------------------------ HTC (R50 trunk) training step
+    model_cfg, train_cfg = configs(tmp, htc=True)
+    model = build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
+                           test_cfg=to_config_dict(E.TEST_CFG))
+    with torch.no_grad():
+        det_oracle.fill_detector(model.state_dict(), HTC_SEED)
+    model.train()
+
+    class _ReluCopy(torch.nn.Module):       # see make_golden_htc.py: in-place += on a ReLU output
+        def forward(self, t):
+            return torch.relu(t) * 1.0
+    model.semantic_head.lateral_convs[model.semantic_head.fusion_level].activate = _ReluCopy()
+    losses = model.forward_train(torch.from_numpy(E.image()), E.img_meta(),
+                                 [torch.from_numpy(boxes)], [torch.from_numpy(labels)],
+                                 gt_masks=[gt_masks(boxes)],
+                                 gt_semantic_seg=torch.from_numpy(gt_semantic_seg()))
+    total = 0
+    for k, v in losses.items():
+        vals = v if isinstance(v, list) else [v]
+        out['htc/loss/' + k] = np.array([float(t.detach().sum()) for t in vals], np.float32)
+        if 'loss' in k:
+            total = total + sum(t.sum() for t in vals)
+    total.backward()
+    out['htc/loss/total'] = np.array([float(total.detach())], np.float32)
+    params = dict(model.named_parameters())
+    for name, idx in GRADS_HTC:
+        out['htc/grad/' + name] = params[name].grad[idx].contiguous().numpy()
     for k in sorted(out):
-        if k.startswith('loss/'):
+        if 'loss/' in k:
             print(k, out[k])
     np.savez_compressed(OUT, **out)
     print('wrote', OUT, os.path.getsize(OUT))
