@@ -74,6 +74,17 @@ GRADS_HTC = [
     ('backbone.layer2.1.bn2.weight', (slice(None),)),
 ]
 HTC_SEED = 921
+GRADS_MASK = [
+    ('bbox_head.fc_cls.weight', (slice(None, None, 16), slice(None, None, 16))),
+    ('mask_head.convs.0.conv.weight', (slice(None, None, 16), slice(None, None, 16))),
+    ('mask_head.convs.3.conv.bias', (slice(None),)),
+    ('mask_head.upsample.weight', (slice(None, None, 8), slice(None, None, 8))),
+    ('mask_head.conv_logits.weight', (slice(None, None, 16),)),
+    ('mask_head.conv_logits.bias', (slice(None),)),
+    ('neck.fpn_convs.0.conv.weight', (slice(None, None, 16), slice(None, None, 16))),
+    ('backbone.layer2.3.conv3.weight', (slice(None, None, 16), slice(None, None, 8))),
+]
+MASK_SEED = 931
 
 
 def gt():
@@ -104,9 +115,9 @@ def gt_semantic_seg():
     return seg
 
 
-def configs(table_dir, htc=False):
+def configs(table_dir, htc=False, mask=False):
     from bench import detector_cfg
-    model, train_cfg = detector_cfg(table_dir, htc=htc)
+    model, train_cfg = detector_cfg(table_dir, htc=htc, mask=mask)
     heads = model['bbox_head'] if htc else [model['bbox_head']]
     for h in heads:
         h['gs_config']['others_sample_ratio'] = 1e6
@@ -209,6 +220,28 @@ def main():
     params = dict(model.named_parameters())
     for name, idx in GRADS_HTC:
         out['htc/grad/' + name] = params[name].grad[idx].contiguous().numpy()
+
+    # ------------------------------------------------------------ Mask R-CNN R50 (cfg[3])
+    model_cfg, train_cfg = configs(tmp, mask=True)
+    model = build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
+                           test_cfg=to_config_dict(E.TEST_CFG))
+    with torch.no_grad():
+        det_oracle.fill_detector(model.state_dict(), MASK_SEED)
+    model.train()
+    losses = model.forward_train(torch.from_numpy(E.image()), E.img_meta(),
+                                 [torch.from_numpy(boxes)], [torch.from_numpy(labels)],
+                                 gt_masks=[gt_masks(boxes)])
+    total = 0
+    for k, v in losses.items():
+        vals = v if isinstance(v, list) else [v]
+        out['mask/loss/' + k] = np.array([float(t.detach().sum()) for t in vals], np.float32)
+        if 'loss' in k:
+            total = total + sum(t.sum() for t in vals)
+    total.backward()
+    out['mask/loss/total'] = np.array([float(total.detach())], np.float32)
+    params = dict(model.named_parameters())
+    for name, idx in GRADS_MASK:
+        out['mask/grad/' + name] = params[name].grad[idx].contiguous().numpy()
     for k in sorted(out):
         if 'loss/' in k:
             print(k, out[k])

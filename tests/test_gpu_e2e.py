@@ -236,3 +236,48 @@ def test_htc_training_iteration_vs_executed_reference_detector():
         if not grad_close(g[idx].cpu().numpy(), z['htc/grad/' + name]):
             bad.append(name)
     assert not bad, bad
+
+
+def test_mask_rcnn_training_iteration_vs_executed_reference_detector():
+    """cfg[3] (gs_mask_rcnn_r50_fpn_1x_lvis): ``MaskRCNN.forward_train`` + ``backward`` against the
+    executed reference — the 18 loss terms incl. ``loss_mask`` and gradients of the mask head
+    (the single-channel logits / BCE kernels vs the reference's 1231-channel conv + gather), box
+    head, FPN and trunk."""
+    from balancedgroupsoftmax_amd import train
+    from tests.golden import make_golden_train as T
+    z = np.load(os.path.join(os.path.dirname(T.__file__), 'e2e_train_golden.npz'))
+    tmp = tempfile.mkdtemp(prefix='bgs_e2e_')
+    model_cfg, train_cfg = T.configs(tmp, mask=True)
+    model = bgs.build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
+                               test_cfg=to_config_dict(G.TEST_CFG))
+    with torch.no_grad():
+        det_oracle.fill_detector(model.state_dict(), T.MASK_SEED)
+    model.to(DEV)
+    train.select_training_param(model, 0)
+    model.train()
+    boxes, labels = T.gt()
+    losses = model(torch.from_numpy(G.image()).to(DEV), G.img_meta(), return_loss=True,
+                   gt_bboxes=[torch.from_numpy(boxes).to(DEV)],
+                   gt_labels=[torch.from_numpy(labels).to(DEV)],
+                   gt_masks=[torch.from_numpy(T.gt_masks(boxes)).to(DEV)])
+    keys = [k[len('mask/loss/'):] for k in z.files
+            if k.startswith('mask/loss/') and not k.endswith('total')]
+    assert set(keys) == set(losses.keys())
+    bad = []
+    for k in keys:
+        v = losses[k]
+        got = np.array([float(t.detach().sum()) for t in (v if isinstance(v, list) else [v])], np.float32)
+        exp = z['mask/loss/' + k]
+        if np.abs(got - exp).max() > 2e-4 * max(1.0, np.abs(exp).max()):
+            bad.append((k, got.tolist(), exp.tolist()))
+    assert not bad, bad
+    loss, _ = train.parse_losses(losses)
+    loss.backward()
+    params = dict(model.named_parameters())
+    bad = []
+    for name, idx in T.GRADS_MASK:
+        g = params[name].grad
+        assert g is not None, name
+        if not grad_close(g[idx].cpu().numpy(), z['mask/grad/' + name]):
+            bad.append(name)
+    assert not bad, bad
