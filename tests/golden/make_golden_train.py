@@ -129,7 +129,9 @@ def configs(table_dir, htc=False, mask=False):
     return model, train_cfg
 
 
-def _bind_reference_ops():
+def _bind_reference_ops(forbid_draws=True):
+    """``forbid_draws=False``: leave the reference's numpy samplers as shipped (used by
+    tools/ref_cpu_detector_time.py, which times the real iteration)."""
     E._bind_reference_ops()
     ra = sys.modules['mmdet.ops.roi_align.roi_align']
 
@@ -155,9 +157,10 @@ def _bind_reference_ops():
 
     def no_draw(*a, **k):
         raise AssertionError('a random draw was requested: the golden must be deterministic')
-    from mmdet.core.bbox.samplers.random_sampler import RandomSampler
-    RandomSampler.random_choice = staticmethod(no_draw)
-    np.random.choice = no_draw
+    if forbid_draws:
+        from mmdet.core.bbox.samplers.random_sampler import RandomSampler
+        RandomSampler.random_choice = staticmethod(no_draw)
+        np.random.choice = no_draw
     # mask_target.py:31 resizes the cropped bitmap with mmcv.imresize = cv2.resize(INTER_LINEAR);
     # neither is installed here: oracle/mask_oracle.py restates OpenCV's fixed-point path
     # ("parity unpinned" for that one step, see its header)

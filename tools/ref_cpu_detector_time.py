@@ -31,21 +31,8 @@ def main():
     from balancedgroupsoftmax_amd.config import to_config_dict
     from bench import detector_cfg
     from tests.golden import make_golden_train as T
-    # the reference's own ops, with the samplers left RANDOM (numpy), as shipped
     from tests.golden import make_golden_e2e as E
-    E._bind_reference_ops()
-    T_bind = T._bind_reference_ops
-    import numpy.random as npr
-    keep_choice = npr.choice
-    T_bind()
-    npr.choice = np.random.choice = keep_choice          # undo the no-draw guard of the goldens
-    from mmdet.core.bbox.samplers import random_sampler as rsamp
-    import importlib
-    importlib.reload(rsamp)
-    from mmdet.core.bbox import samplers
-    samplers.RandomSampler = rsamp.RandomSampler
-    import mmdet.core.bbox.assign_sampling as asmp
-    asmp.samplers.RandomSampler = rsamp.RandomSampler
+    T._bind_reference_ops(forbid_draws=False)      # the reference's own ops; numpy samplers as shipped
     from mmdet.models import build_detector
     tmp = tempfile.mkdtemp(prefix='bgs_refcpu_')
     model_cfg, train_cfg = detector_cfg(tmp)
