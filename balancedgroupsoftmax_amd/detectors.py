@@ -171,26 +171,35 @@ class TwoStageDetector(nn.Module):
             bw.append(posf[:, None].expand(-1, 4).contiguous())
         return torch.cat(labels), torch.cat(lw), torch.cat(bt), torch.cat(bw)
 
+    # -- RPN part of a training iteration ------------------------------------------------------
+    def _rpn_forward_train(self, x, img_meta, gt_bboxes, proposals, generator, losses):
+        """RPN losses + the fixed-shape proposal list (two_stage.py:157-176).
+
+        (Measured and dropped: launching the loss branch — anchor assignment, sampler, BCE +
+        SmoothL1 sums, ~0.45 ms of small latency-bound kernels that only read the RPN outputs — on
+        a second HIP stream next to the proposal -> RoI-head chain.  Correct and stable over 400
+        graph replays, but 12.00 vs 12.05 ms: the replayed graph does not run the two branches
+        concurrently, and eager launches are host-bound.  profiles/r2w_*.)"""
+        if not self.with_rpn:
+            return [(p, torch.ones(p.size(0), dtype=torch.bool, device=p.device)) for p in proposals]
+        cls_scores, bbox_preds = self.rpn_head(x)
+        losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
+                                         self.train_cfg.rpn, generator=generator))
+        proposal_cfg = self.train_cfg.get('rpn_proposal', None)
+        if proposal_cfg is None:
+            proposal_cfg = self.test_cfg.rpn
+        proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_meta, proposal_cfg)
+        # the head's stash of its own outputs carries this iteration's autograd graph when the
+        # trunk trains (selectp=0): drop it, or the graph (and its AccumulateGrad nodes, bound to
+        # the stream they were created on) would outlive the iteration
+        self.rpn_head._fused = None
+        return proposal_list
+
     def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
                       gt_masks=None, proposals=None, generator=None):
         x = self.extract_feat(img)
         losses = dict()
-        if self.with_rpn:
-            cls_scores, bbox_preds = self.rpn_head(x)
-            losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
-                                             self.train_cfg.rpn, generator=generator))
-            proposal_cfg = self.train_cfg.get('rpn_proposal', None)
-            if proposal_cfg is None:
-                proposal_cfg = self.test_cfg.rpn
-            proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_meta, proposal_cfg)
-            # the head's stash of its own outputs carries this iteration's autograd graph when
-            # the trunk trains (selectp=0): drop it, or the graph (and its AccumulateGrad nodes,
-            # bound to the stream they were created on) would outlive the iteration
-            self.rpn_head._fused = None
-            del cls_scores, bbox_preds
-        else:
-            proposal_list = [(p, torch.ones(p.size(0), dtype=torch.bool, device=p.device))
-                             for p in proposals]
+        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, generator, losses)
         if self.with_bbox:
             if img.is_cuda and self.train_cfg.rcnn.assigner.get('gt_max_assign_all', True):
                 rois, targets = self._sample_rois_fused(proposal_list, gt_bboxes, gt_labels,
@@ -377,20 +386,6 @@ class CascadeRCNN(TwoStageDetector):
         if self.mask_head is not None:
             for head in self.mask_head:
                 head.init_weights()
-
-    def _rpn_forward_train(self, x, img_meta, gt_bboxes, proposals, generator, losses):
-        """RPN losses + the fixed-shape proposal list (two_stage.py:157-176)."""
-        if not self.with_rpn:
-            return [(p, torch.ones(p.size(0), dtype=torch.bool, device=p.device)) for p in proposals]
-        cls_scores, bbox_preds = self.rpn_head(x)
-        losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
-                                         self.train_cfg.rpn, generator=generator))
-        proposal_cfg = self.train_cfg.get('rpn_proposal', None)
-        if proposal_cfg is None:
-            proposal_cfg = self.test_cfg.rpn
-        proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_meta, proposal_cfg)
-        self.rpn_head._fused = None
-        return proposal_list
 
     def _refined_proposals(self, head, rois, labels, bbox_pred, img_meta, num):
         """``refine_bboxes`` (bbox_head.py:169-208) in fixed shape: every sampled RoI re-regressed

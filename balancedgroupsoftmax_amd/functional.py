@@ -813,17 +813,26 @@ def rpn_loss(level_outs, num_anchors, anchors, assigned, pos_mask, neg_mask, gt_
 _KEY_COUNTERS = {}
 
 
+def _draw_counter(device, name):
+    """Per (device, sampler) draw counter (device int64 ``[1]``), advanced with a tensor op per
+    call.  One counter per sampler: the RPN sampler may run on a second stream next to the RoI
+    sampler (detectors._rpn_forward_train), and a shared counter would be a cross-stream race."""
+    key = (device.index, name)
+    ctr = _KEY_COUNTERS.get(key)
+    if ctr is None:
+        ctr = torch.zeros(1, dtype=torch.int64, device=device)
+        _KEY_COUNTERS[key] = ctr
+    ctr.add_(1)
+    return ctr
+
+
 def random_keys(n, device):
     """``[n]`` int64 sampling keys in ``[0, 2^62)`` from the counter-based device RNG
     (``bgs_random_keys``).  A per-device draw counter is advanced with a tensor op per call, so
     the launch is hipGraph-replayable and still draws fresh keys every replay."""
     lib = capi.load()
     device = torch.device(device)
-    ctr = _KEY_COUNTERS.get(device.index)
-    if ctr is None:
-        ctr = torch.zeros(1, dtype=torch.int64, device=device)
-        _KEY_COUNTERS[device.index] = ctr
-    ctr.add_(1)
+    ctr = _draw_counter(device, 'keys')
     out = torch.empty((n,), dtype=torch.int64, device=device)
     seed = (torch.initial_seed() * 0x9E3779B1 + 0x5851F42D) & 0xFFFFFFFFFFFFFFFF
     rc = lib.bgs_random_keys(seed, capi.ptr(ctr), int(n), capi.ptr(out),
@@ -840,11 +849,7 @@ def sample_pos_neg(assigned, num, pos_fraction, neg_pos_ub=-1):
     assert assigned.dim() == 2 and assigned.dtype == torch.int32 and assigned.is_contiguous()
     N, A = assigned.shape
     dev = assigned.device
-    ctr = _KEY_COUNTERS.get(dev.index)
-    if ctr is None:
-        ctr = torch.zeros(1, dtype=torch.int64, device=dev)
-        _KEY_COUNTERS[dev.index] = ctr
-    ctr.add_(1)
+    ctr = _draw_counter(dev, 'pos_neg')
     pos = torch.empty((N, A), dtype=torch.uint8, device=dev)
     neg = torch.empty((N, A), dtype=torch.uint8, device=dev)
     seed = (torch.initial_seed() * 0x9E3779B1 + 0x2545F491) & 0xFFFFFFFFFFFFFFFF
@@ -865,11 +870,7 @@ def sample_rois(assigned_list, num, pos_fraction):
     dev = assigned_list[0].device
     for a in assigned_list:
         assert a.dtype == torch.int32 and a.is_contiguous() and a.dim() == 1
-    ctr = _KEY_COUNTERS.get(dev.index)
-    if ctr is None:
-        ctr = torch.zeros(1, dtype=torch.int64, device=dev)
-        _KEY_COUNTERS[dev.index] = ctr
-    ctr.add_(1)
+    ctr = _draw_counter(dev, 'rois')
     inds = torch.empty((N, num), dtype=torch.int64, device=dev)
     is_pos = torch.empty((N, num), dtype=torch.uint8, device=dev)
     valid = torch.empty((N, num), dtype=torch.uint8, device=dev)
