@@ -109,8 +109,10 @@ SIGNATURES = {
                                          c_ptr, c_ptr, c_ptr, c_f32p, c_ptr, ctypes.c_int, c_ptr,
                                          c_ptr, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                          ctypes.c_float, c_f32p, c_f32p, c_f32p, c_ptr]),
+    'bgs_sample_pos_neg_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int]),
     'bgs_sample_pos_neg': (ctypes.c_int, [c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
-                                          ctypes.c_float, ctypes.c_uint64, c_ptr, c_ptr, c_ptr, c_ptr]),
+                                          ctypes.c_float, ctypes.c_uint64, c_ptr, c_ptr, c_ptr, c_ptr,
+                                          c_ptr]),
     'bgs_sample_rois': (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                        ctypes.c_uint64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'bgs_random_keys': (ctypes.c_int, [ctypes.c_uint64, c_ptr, ctypes.c_int, c_ptr, c_ptr]),

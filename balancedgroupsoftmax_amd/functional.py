@@ -853,9 +853,10 @@ def sample_pos_neg(assigned, num, pos_fraction, neg_pos_ub=-1):
     pos = torch.empty((N, A), dtype=torch.uint8, device=dev)
     neg = torch.empty((N, A), dtype=torch.uint8, device=dev)
     seed = (torch.initial_seed() * 0x9E3779B1 + 0x2545F491) & 0xFFFFFFFFFFFFFFFF
+    ws = _workspace(lib.bgs_sample_pos_neg_workspace_bytes(N), dev)
     rc = lib.bgs_sample_pos_neg(capi.ptr(assigned), N, A, int(num), float(pos_fraction),
                                 float(neg_pos_ub), seed, capi.ptr(ctr), capi.ptr(pos), capi.ptr(neg),
-                                capi.current_stream(dev))
+                                capi.ptr(ws), capi.current_stream(dev))
     capi.check('bgs_sample_pos_neg', rc)
     return pos, neg
 

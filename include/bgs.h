@@ -343,10 +343,14 @@ int bgs_rpn_loss(const float* const* host_level_outs, const int* host_level_hw, 
  *   pos_mask, neg_mask [N, A] uint8 with EXACTLY min(int(num * pos_fraction), #pos) positives and
  *   min(num - #pos_sampled [, int(neg_pos_ub * max(#pos_sampled, 1)) when neg_pos_ub >= 0], #neg)
  *   negatives per image, uniformly without replacement (radix select over bijective 32-bit
- *   keys of (seed, *draw_counter, image, anchor)).  draw_counter: device int64 [1] or NULL. */
+ *   keys of (seed, *draw_counter, image, anchor)).  draw_counter: device int64 [1] or NULL.
+ *   workspace: bgs_sample_pos_neg_workspace_bytes(N) bytes (counters + per-image key lists; the
+ *   three launches scan -> select -> mark communicate through it). */
+size_t bgs_sample_pos_neg_workspace_bytes(int N);
 int bgs_sample_pos_neg(const int* assigned, int N, int A, int num, float pos_fraction,
                        float neg_pos_ub, uint64_t seed, const long long* draw_counter,
-                       uint8_t* pos_mask, uint8_t* neg_mask, bgs_stream_t stream);
+                       uint8_t* pos_mask, uint8_t* neg_mask, void* workspace,
+                       bgs_stream_t stream);
 
 /* RandomSampler of the RoI head (two_stage.py:192-210; add_gt_as_proposals candidates = GT boxes
  *   followed by the proposals): host_assigned [N] HOST array of device pointers to each image's

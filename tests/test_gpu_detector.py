@@ -592,6 +592,41 @@ def test_rpn_sampler_kernel_counts_uniformity_and_reproducibility():
     assert abs(float(freq.std()) - 0.01224) < 0.002              # binomial spread, not clumped
 
 
+def test_rpn_sampler_list_and_fallback_paths_agree():
+    """The threshold comes from a short list of pre-filtered keys, or — when that list would be
+    too long / too short — from a radix select over all anchors.  Both must give exact counts:
+    (a) num so large that every negative is a candidate and the list overflows (fallback),
+    (b) so few negatives that fewer than k fall below the pre-filter threshold (fallback),
+    (c) 900 positives of which 128 are wanted (positive list), (d) take-all."""
+    from balancedgroupsoftmax_amd import functional as BF
+    g = torch.Generator().manual_seed(3)
+    # (a) A = 20000, num = 6000: t0 = all, 19000 negatives > list capacity
+    a = torch.zeros(1, 20000, dtype=torch.int32)
+    a[0, torch.randperm(20000, generator=g)[:1000]] = 1
+    pos, neg = BF.sample_pos_neg(a.to(DEV), 6000, 0.25)
+    assert int(pos.sum()) == 1000 and int(neg.sum()) == 5000
+    assert not (neg.cpu().bool() & (a != 0)).any() and not (pos.cpu().bool() & (a <= 0)).any()
+    # (b) A = 268569 with only 300 negatives, 256 wanted: ~2 of them pass the pre-filter
+    b = torch.full((1, 268569), -1, dtype=torch.int32)
+    idx = torch.randperm(268569, generator=g)
+    b[0, idx[:300]] = 0
+    b[0, idx[300:310]] = 4
+    pos, neg = BF.sample_pos_neg(b.to(DEV), 256, 0.5)
+    assert int(pos.sum()) == 10 and int(neg.sum()) == 246
+    assert not (neg.cpu().bool() & (b != 0)).any()
+    # (c) + (d)
+    c = torch.zeros(2, 50000, dtype=torch.int32)
+    c[0, torch.randperm(50000, generator=g)[:900]] = 2
+    c[1, :] = -1
+    c[1, :100] = 0
+    c[1, 100:130] = 1
+    pos, neg = BF.sample_pos_neg(c.to(DEV), 256, 0.5)
+    assert pos.sum(1).tolist() == [128, 30] and neg.sum(1).tolist() == [128, 100]
+    # two draws of (c) pick different subsets of the 900 positives
+    pos2, _ = BF.sample_pos_neg(c.to(DEV), 256, 0.5)
+    assert not torch.equal(pos2[0], pos[0])
+
+
 def test_roi_sampler_kernel_order_counts_and_padding():
     """bgs_sample_rois: positives first (<= int(num * pos_fraction)), then negatives, padding
     flagged invalid; indices unique, of the right class, and a fresh draw every call."""
