@@ -9,12 +9,24 @@
 // the device:
 //   1. nms_mask_kernel   grid (cb, cb, P): same 64x64 bitmask tiles (upper triangle only),
 //      legacy "+1" IoU (nms_kernel.cu:13-21);
-//   2. nms_scan_kernel   grid P, one wave per problem: boxes are consumed in chunks of 64;
-//      inside a chunk the greedy decision is a 64-step bit recurrence on the diagonal mask
-//      word (registers only), then lane j ORs the kept rows' word j into its running
-//      "removed" word.  Kept indices are emitted in ascending (= score) order.
+//   2. the greedy scan, boxes consumed in chunks of 64, kept indices emitted in ascending
+//      (= score) order:
+//      nms_scan_wide_kernel (few large problems: the RPN's 10 x <= 2000 boxes): one 16-wave
+//      workgroup per problem.  Wave w owns the "removed" words w, w+16, ... (wave-uniform
+//      registers).  Per chunk c the wave owning word c runs the 64-step bit recurrence on the
+//      diagonal word with v_readlane (lane r holds row r's word: scalar code, no memory), publishes
+//      the 64 "kept" bits through LDS, and after ONE barrier every wave folds its own words:
+//      lane r contributes row r's word if r was kept, OR-reduced over the wave with DPP.  The
+//      mask words a wave needs (row = lane, word = owned) do not depend on any decision, so they
+//      are prefetched four chunks ahead into registers: the serial chain is ~0.4 us per chunk
+//      (recurrence + barrier + reduce) instead of 11 us (staging loads, then 2 x 64 dependent LDS
+//      reads, all exposed in a single wave).
+//      nms_scan_kernel (many small problems: the 1230 per-class problems at test time): one wave
+//      per problem, rows staged through LDS.
 // Boxes must already be sorted by descending score per problem (the callers' topk does that).
 // iou_mode 0: suppress when IoU >  thr (nms_kernel.cu:60);  1: IoU >= thr (nms_cpu.cpp:55).
+#include <stdlib.h>
+
 #include "bgs_common.h"
 
 namespace {
@@ -120,6 +132,107 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
   if (lane == 0) keep_count[p] = min(nkeep, max_keep);
 }
 
+#ifndef BGS_NO_DPP
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+  v |= dpp_u32<0xb1>(v);   // quad_perm:[1,0,3,2]
+  v |= dpp_u32<0x4e>(v);   // quad_perm:[2,3,0,1]
+  v |= dpp_u32<0x124>(v);  // row_ror:4
+  v |= dpp_u32<0x128>(v);  // row_ror:8
+  v |= dpp_u32<0x142>(v);  // row_bcast:15
+  v |= dpp_u32<0x143>(v);  // row_bcast:31
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+#else
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v |= (uint32_t)__shfl_xor((int)v, off, 64);
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+#endif
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+  const uint32_t lo = wave_or_u32((uint32_t)v), hi = wave_or_u32((uint32_t)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int lane) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// one 16-wave workgroup per problem; WPW = words owned per wave (cb <= 16 * WPW).
+template <int WPW>
+__global__ __launch_bounds__(1024) void nms_scan_wide_kernel(
+    const unsigned long long* __restrict__ mask, const int* __restrict__ counts, int nmax, int cb,
+    int max_keep, int* __restrict__ keep, int* __restrict__ keep_count) {
+  constexpr int NW = 16, PF = 4;
+  __shared__ unsigned long long s_kept[2];
+  const int p = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = bgs::uniform(threadIdx.x >> 6);
+  const int n = min(counts[p], nmax);
+  const unsigned long long* pm = mask + (size_t)p * nmax * cb;
+  int* pk = keep + (size_t)p * nmax;
+  const int nchunks = (n + kTile - 1) / kTile;
+  unsigned long long remv[WPW];
+#pragma unroll
+  for (int q = 0; q < WPW; ++q) remv[q] = 0ull;
+  // pre[d][q]: word w + 16q of row 64 * c + lane, for the chunk c that maps to slot d
+  unsigned long long pre[PF][WPW];
+  auto load_chunk = [&](int c, unsigned long long (&dst)[WPW]) {
+    const int i = c * kTile + lane;
+#pragma unroll
+    for (int q = 0; q < WPW; ++q) {
+      const int j = w + NW * q;
+      // (words < c of a row are never written by the mask kernel, and never needed)
+      dst[q] = (c < nchunks && i < n && j < cb && j >= c) ? pm[(size_t)i * cb + j] : 0ull;
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < PF; ++d) load_chunk(d, pre[d]);
+  int nkeep = 0;
+  for (int c0 = 0; c0 < nchunks && nkeep < max_keep; c0 += PF) {
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+      const int c = c0 + d;
+      if (c >= nchunks || nkeep >= max_keep) break;        // workgroup-uniform
+      unsigned long long cur[WPW];
+#pragma unroll
+      for (int q = 0; q < WPW; ++q) cur[q] = pre[d][q];
+      load_chunk(c + PF, pre[d]);
+      const int rows_here = min(n - c * kTile, kTile);
+#pragma unroll
+      for (int q = 0; q < WPW; ++q) {
+        if (w + NW * q != c) continue;                     // wave-uniform: the owner of word c
+        unsigned long long dead = remv[q], kept = 0ull;
+        for (int r = 0; r < rows_here; ++r) {
+          if (!((dead >> r) & 1ull)) {
+            kept |= 1ull << r;
+            dead |= readlane_u64(cur[q], r);
+          }
+        }
+        if (lane == 0) s_kept[c & 1] = kept;
+      }
+      __syncthreads();
+      const unsigned long long kept = s_kept[c & 1];
+      const unsigned long long mine = ((kept >> lane) & 1ull) ? ~0ull : 0ull;
+#pragma unroll
+      for (int q = 0; q < WPW; ++q) {
+        const int j = w + NW * q;
+        if (j > c && j < cb) remv[q] |= wave_or_u64(cur[q] & mine);
+      }
+      if (w == 0 && lane < rows_here && ((kept >> lane) & 1ull)) {
+        const int rank = __popcll(kept & ((1ull << lane) - 1ull));
+        if (nkeep + rank < max_keep) pk[nkeep + rank] = c * kTile + lane;
+      }
+      nkeep += __popcll(kept);
+    }
+  }
+  if (threadIdx.x == 0) keep_count[p] = min(nkeep, max_keep);
+}
+
 }  // namespace
 
 extern "C" size_t bgs_nms_workspace_bytes(int P, int nmax) {
@@ -141,7 +254,21 @@ extern "C" int bgs_nms_batched(const float* boxes, const int* counts, int P, int
   unsigned long long* mask = (unsigned long long*)workspace;
   hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, P), dim3(kTile), 0, st, boxes, counts, nmax, cb,
                      iou_thr, iou_mode, mask);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(P), dim3(64), 0, st, mask, counts, nmax, cb, max_keep,
-                     keep, keep_count);
+  // few large problems (RPN) -> 16-wave workgroups; many small ones (per-class NMS) -> one wave each
+  const char* env = getenv("BGS_NMS_SCAN");           // tests: 1 = narrow, 2 = wide
+  const int force = env ? atoi(env) : 0;
+  const bool wide = force ? force == 2 : (P <= 64 && cb > 4);
+  if (!wide)
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(P), dim3(64), 0, st, mask, counts, nmax, cb, max_keep,
+                       keep, keep_count);
+  else if (cb <= 16)
+    hipLaunchKernelGGL(nms_scan_wide_kernel<1>, dim3(P), dim3(1024), 0, st, mask, counts, nmax, cb,
+                       max_keep, keep, keep_count);
+  else if (cb <= 32)
+    hipLaunchKernelGGL(nms_scan_wide_kernel<2>, dim3(P), dim3(1024), 0, st, mask, counts, nmax, cb,
+                       max_keep, keep, keep_count);
+  else
+    hipLaunchKernelGGL(nms_scan_wide_kernel<4>, dim3(P), dim3(1024), 0, st, mask, counts, nmax, cb,
+                       max_keep, keep, keep_count);
   BGS_RETURN_LAUNCH_STATUS();
 }

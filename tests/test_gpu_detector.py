@@ -283,9 +283,15 @@ def test_rpn_fused_loss_and_proposals_equal_tensor_form(tmp_path):
         b = torch.stack([v.reshape(()) for v in plain[k]]).cpu()
         assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), (k, a, b)
     assert float(torch.stack(fused['loss_rpn_bbox']).sum()) > 0
+    def canon(t):
+        # rows as a set: the final top-k orders equal scores arbitrarily (several thousand fp32
+        # sigmoids in [0.2, 0.5] do collide, and torch's top-k does not order ties reproducibly),
+        # and the fused decode's sigmoid may differ from torch's by 1 ulp
+        a = t.cpu().numpy().astype(np.float64)
+        return a[np.lexsort(np.round(a[:, :4] * 50).T[::-1])]
     for (pf, vf), (pp, vp) in zip(props_f, props_p):
         assert torch.equal(vf, vp) and int(vf.sum()) > 500
-        assert torch.allclose(pf[vf], pp[vp], rtol=1e-5, atol=1e-3)
+        assert np.allclose(canon(pf[vf]), canon(pp[vp]), rtol=1e-5, atol=1e-3)
 
 
 def test_rcnn_fused_sampling_targets_equal_tensor_form(tmp_path):
