@@ -11,8 +11,8 @@
 //      legacy "+1" IoU (nms_kernel.cu:13-21);
 //   2. the greedy scan, boxes consumed in chunks of 64, kept indices emitted in ascending
 //      (= score) order:
-//      nms_scan_wide_kernel (few large problems: the RPN's 10 x <= 2000 boxes): one 16-wave
-//      workgroup per problem.  Wave w owns the "removed" words w, w+16, ... (wave-uniform
+//      nms_scan_wide_kernel (problems of more than 256 boxes: the RPN's 10 x <= 2000, the 1230
+//      per-class problems at test time): one 16-wave workgroup per problem.  Wave w owns the "removed" words w, w+16, ... (wave-uniform
 //      registers).  Per chunk c the wave owning word c runs the 64-step bit recurrence on the
 //      diagonal word with v_readlane (lane r holds row r's word: scalar code, no memory), publishes
 //      the 64 "kept" bits through LDS, and after ONE barrier every wave folds its own words:
@@ -21,8 +21,7 @@
 //      are prefetched four chunks ahead into registers: the serial chain is ~0.4 us per chunk
 //      (recurrence + barrier + reduce) instead of 11 us (staging loads, then 2 x 64 dependent LDS
 //      reads, all exposed in a single wave).
-//      nms_scan_kernel (many small problems: the 1230 per-class problems at test time): one wave
-//      per problem, rows staged through LDS.
+//      nms_scan_kernel (<= 256 boxes): one wave per problem, rows staged through LDS.
 // Boxes must already be sorted by descending score per problem (the callers' topk does that).
 // iou_mode 0: suppress when IoU >  thr (nms_kernel.cu:60);  1: IoU >= thr (nms_cpu.cpp:55).
 #include <stdlib.h>
@@ -254,10 +253,11 @@ extern "C" int bgs_nms_batched(const float* boxes, const int* counts, int P, int
   unsigned long long* mask = (unsigned long long*)workspace;
   hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, P), dim3(kTile), 0, st, boxes, counts, nmax, cb,
                      iou_thr, iou_mode, mask);
-  // few large problems (RPN) -> 16-wave workgroups; many small ones (per-class NMS) -> one wave each
+  // problems of more than 256 boxes -> 16-wave workgroups (RPN: 0.44 -> 0.16 ms per call; the 1230
+  // per-class problems of 1000 boxes at test time: 1.59 -> 1.35 ms); tiny ones -> one wave each
   const char* env = getenv("BGS_NMS_SCAN");           // tests: 1 = narrow, 2 = wide
   const int force = env ? atoi(env) : 0;
-  const bool wide = force ? force == 2 : (P <= 64 && cb > 4);
+  const bool wide = force ? force == 2 : cb > 4;
   if (!wide)
     hipLaunchKernelGGL(nms_scan_kernel, dim3(P), dim3(64), 0, st, mask, counts, nmax, cb, max_keep,
                        keep, keep_count);
