@@ -1,0 +1,232 @@
+// Batched sorted top-k of fp32 rows for gfx950 (MI355X): the RPN's proposal pre-selection.
+//
+// Replaces the `scores.topk(cfg.nms_pre)` per FPN level and the final `scores.topk(num)` of
+// RPNHead.get_bboxes_single (mmdet/models/anchor_heads/rpn_head.py:79-83,99-103).  A training
+// iteration needs the 2000 largest of 201,600 / 50,400 / 12,600 / 3,150 / 819 objectness logits
+// per image and level, then the 2000 best of the 10,000 NMS survivors per image.  The torch
+// library answers each of the six calls with its own multi-kernel radix select + sort (15-40
+// launches, 0.5 ms per iteration in total, profiles/r2v_detector_prof_summary.md); here ALL rows of
+// a call set (different lengths, different k) go through the same eight launches:
+//
+//   3 x { hist   (G x P workgroups)  LDS histogram of the next 11 / 11 / 10 key bits of the
+//                                    elements that match the prefix found so far -> global bins
+//         pick   (P workgroups)      walk the bins from the top until k is covered: next digit }
+//   collect (G x P workgroups)       keys above the exact 32-bit threshold (and exactly as many
+//                                    equal to it as are still missing) -> a k-entry list
+//   sort    (P workgroups)           bitonic sort of the <= 4096 (key, index) composites in LDS,
+//                                    descending; values / indices out, zero fill beyond k.
+//
+// Keys are the usual order-preserving uint32 image of the floats; composites (key << 32 | ~index)
+// sort larger values first and, among equal values, smaller indices first.  Which of several
+// elements EQUAL to the threshold value are taken is unspecified (as in torch.topk).
+// HBM-bound in principle (4 reads of the rows: 6.4 MB for the largest level of two images), in
+// practice latency-bound: ~8 short launches.
+#include "bgs_common.h"
+
+namespace {
+
+constexpr int kMaxProblems = 64;
+constexpr int kMaxK = 4096;
+constexpr int kBins = 2048;
+constexpr int kChunk = 4096;     // elements per workgroup of the streaming kernels
+constexpr int kState = 8;        // per problem: prefix, pmask, k_rem, n_gt, n_eq
+
+struct TopkProblems {
+  const float* row[kMaxProblems];
+  int len[kMaxProblems];
+  int k[kMaxProblems];
+};
+
+struct TopkWs {
+  int* hist;                    // [P, kBins]
+  unsigned* state;              // [P, kState]
+  unsigned long long* list;     // [P, kmax]
+};
+
+__device__ __forceinline__ unsigned key_of(float f) {
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float value_of(unsigned key) {
+  return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+}
+
+__device__ __forceinline__ int shift_of(int pass) { return pass == 0 ? 21 : (pass == 1 ? 10 : 0); }
+__device__ __forceinline__ int bins_of(int pass) { return pass == 2 ? 1024 : 2048; }
+
+__global__ __launch_bounds__(256) void topk_hist_kernel(TopkProblems pr, TopkWs ws, int pass) {
+  __shared__ int h[kBins];
+  const int p = blockIdx.y, tid = threadIdx.x;
+  const int len = pr.len[p];
+  const int lo = blockIdx.x * kChunk;
+  if (lo >= len) return;                                  // workgroup-uniform
+  const int hi = min(len, lo + kChunk);
+  const int nb = bins_of(pass), shift = shift_of(pass);
+  for (int b = tid; b < nb; b += 256) h[b] = 0;
+  __syncthreads();
+  const unsigned prefix = ws.state[p * kState + 0], pmask = ws.state[p * kState + 1];
+  const float* row = pr.row[p];
+  for (int i = lo + tid; i < hi; i += 256) {
+    const unsigned key = key_of(row[i]);
+    if ((key & pmask) == prefix) atomicAdd(&h[(key >> shift) & (nb - 1)], 1);
+  }
+  __syncthreads();
+  int* g = ws.hist + (size_t)p * kBins;
+  for (int b = tid; b < nb; b += 256)
+    if (h[b]) atomicAdd(&g[b], h[b]);
+}
+
+// one wave per problem: bins are walked from the TOP (largest keys) until k_rem is covered
+__global__ __launch_bounds__(64) void topk_pick_kernel(TopkProblems pr, TopkWs ws, int pass) {
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int nb = bins_of(pass), shift = shift_of(pass);
+  int* g = ws.hist + (size_t)p * kBins;
+  unsigned* st = ws.state + p * kState;
+  int k_rem = pass == 0 ? min(pr.k[p], pr.len[p]) : (int)st[2];
+  const int per = nb / 64;                                 // bins per lane, lane 0 = top bins
+  int mine = 0;
+  for (int j = 0; j < per; ++j) mine += g[nb - 1 - (lane * per + j)];
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  const int excl = incl - mine;
+  if (k_rem > 0 && excl < k_rem && k_rem <= incl) {        // exactly one lane
+    int c = excl, digit = 0;
+    for (int j = 0; j < per; ++j) {
+      const int b = nb - 1 - (lane * per + j);
+      const int cnt = g[b];
+      if (k_rem <= c + cnt) {
+        digit = b;
+        break;
+      }
+      c += cnt;
+    }
+    st[0] |= (unsigned)digit << shift;
+    st[1] |= (unsigned)(nb - 1) << shift;
+    st[2] = (unsigned)(k_rem - c);                         // still to take inside this digit (>= 1)
+  } else if (k_rem <= 0 && lane == 0) {
+    st[1] = 0xffffffffu;                                   // k == 0: nothing passes
+    st[0] = 0xffffffffu;
+    st[2] = 0u;
+  }
+  __syncthreads();
+  for (int b = lane; b < kBins; b += 64) g[b] = 0;         // ready for the next pass
+}
+
+__global__ __launch_bounds__(256) void topk_collect_kernel(TopkProblems pr, TopkWs ws, int kmax) {
+  const int p = blockIdx.y, tid = threadIdx.x;
+  const int len = pr.len[p];
+  const int lo = blockIdx.x * kChunk;
+  if (lo >= len) return;
+  const int hi = min(len, lo + kChunk);
+  const int k = min(pr.k[p], len);
+  unsigned* st = ws.state + p * kState;
+  const unsigned T = st[0];
+  const int need_eq = (int)st[2];
+  unsigned long long* list = ws.list + (size_t)p * kmax;
+  const float* row = pr.row[p];
+  if (k <= 0) return;
+  for (int i = lo + tid; i < hi; i += 256) {
+    const unsigned key = key_of(row[i]);
+    if (key < T) continue;
+    const unsigned long long comp = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)i);
+    if (key > T) {
+      const int slot = (int)atomicAdd(&st[3], 1u);         // fills [0, k - need_eq)
+      list[slot] = comp;
+    } else {
+      const int slot = (int)atomicAdd(&st[4], 1u);         // ties fill from the back
+      if (slot < need_eq) list[k - 1 - slot] = comp;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void topk_sort_kernel(TopkProblems pr, TopkWs ws, int kmax,
+                                                         float* __restrict__ out_val,
+                                                         long long* __restrict__ out_idx) {
+  __shared__ unsigned long long buf[kMaxK];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const int k = min(pr.k[p], pr.len[p]);
+  int m = 1;
+  while (m < k) m <<= 1;
+  const unsigned long long* list = ws.list + (size_t)p * kmax;
+  for (int i = tid; i < m; i += 1024) buf[i] = i < k ? list[i] : 0ull;
+  __syncthreads();
+  for (int size = 2; size <= m; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int j = tid; j < (m >> 1); j += 1024) {
+        const int lo = (j / stride) * (stride << 1) + (j % stride);
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);              // descending blocks first: final = desc
+        const unsigned long long a = buf[lo], b = buf[hi];
+        if ((a < b) == desc) {
+          buf[lo] = b;
+          buf[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  float* ov = out_val + (size_t)p * kmax;
+  long long* oi = out_idx + (size_t)p * kmax;
+  for (int i = tid; i < kmax; i += 1024) {
+    if (i < k) {
+      const unsigned long long c = buf[i];
+      ov[i] = value_of((unsigned)(c >> 32));
+      oi[i] = (long long)(0xffffffffu - (unsigned)(c & 0xffffffffu));
+    } else {
+      ov[i] = 0.f;
+      oi[i] = 0;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t bgs_topk_workspace_bytes(int P, int kmax) {
+  if (P <= 0 || kmax <= 0) return 0;
+  return (size_t)P * (kBins * sizeof(int) + kState * sizeof(unsigned) +
+                      (size_t)kmax * sizeof(unsigned long long));
+}
+
+extern "C" int bgs_topk_sorted_f32(const float* const* host_rows, const int* host_len,
+                                   const int* host_k, int P, int kmax, float* out_val,
+                                   long long* out_idx, void* workspace, bgs_stream_t stream) {
+  if (P < 0 || kmax <= 0) return BGS_ERR_INVALID_ARG;
+  if (P == 0) return BGS_OK;
+  if (!host_rows || !host_len || !host_k || !out_val || !out_idx || !workspace)
+    return BGS_ERR_INVALID_ARG;
+  if (P > kMaxProblems || kmax > kMaxK) return BGS_ERR_UNSUPPORTED;
+  TopkProblems pr;
+  int maxlen = 0;
+  for (int p = 0; p < kMaxProblems; ++p) {
+    pr.row[p] = nullptr;
+    pr.len[p] = pr.k[p] = 0;
+  }
+  for (int p = 0; p < P; ++p) {
+    if (host_len[p] < 0 || host_k[p] < 0 || host_k[p] > kmax) return BGS_ERR_INVALID_ARG;
+    if (host_len[p] > 0 && !host_rows[p]) return BGS_ERR_INVALID_ARG;
+    pr.row[p] = host_rows[p];
+    pr.len[p] = host_len[p];
+    pr.k[p] = host_k[p];
+    if (host_len[p] > maxlen) maxlen = host_len[p];
+  }
+  TopkWs ws;
+  ws.hist = reinterpret_cast<int*>(workspace);
+  ws.state = reinterpret_cast<unsigned*>(ws.hist + (size_t)P * kBins);
+  ws.list = reinterpret_cast<unsigned long long*>(ws.state + (size_t)P * kState);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, (size_t)P * (kBins * sizeof(int) + kState * sizeof(unsigned)),
+                     st) != hipSuccess)
+    return BGS_ERR_LAUNCH;
+  const int G = maxlen > 0 ? (maxlen + kChunk - 1) / kChunk : 1;
+  for (int pass = 0; pass < 3; ++pass) {
+    hipLaunchKernelGGL(topk_hist_kernel, dim3(G, P), dim3(256), 0, st, pr, ws, pass);
+    hipLaunchKernelGGL(topk_pick_kernel, dim3(P), dim3(64), 0, st, pr, ws, pass);
+  }
+  hipLaunchKernelGGL(topk_collect_kernel, dim3(G, P), dim3(256), 0, st, pr, ws, kmax);
+  hipLaunchKernelGGL(topk_sort_kernel, dim3(P), dim3(1024), 0, st, pr, ws, kmax, out_val, out_idx);
+  BGS_RETURN_LAUNCH_STATUS();
+}

@@ -658,6 +658,37 @@ def resize_bilinear_nhwc_autograd(x, size):
     return resize_bilinear_nhwc(x, size)
 
 
+def topk_sorted(rows, ks, kmax):
+    """Sorted top-k of several row sets in one launch set (``bgs_topk_sorted_f32``).
+
+    ``rows``: list of L contiguous float32 tensors ``[N, n_l]``; ``ks``: list of L ints
+    (``k_l <= kmax <= 4096``).  Returns ``(values, indices)`` of shape ``[N, L, kmax]``: per
+    (image, set) the ``min(k_l, n_l)`` largest entries in descending order and their positions,
+    zeros beyond.  ``N * L <= 64``."""
+    _require_cuda(*rows)
+    lib = capi.load()
+    N = rows[0].shape[0]
+    L = len(rows)
+    dev = rows[0].device
+    ptrs, lens, kk = [], [], []
+    for i in range(N):
+        for r, k in zip(rows, ks):
+            assert r.dim() == 2 and r.shape[0] == N and r.dtype == torch.float32 and r.is_contiguous()
+            ptrs.append(r.data_ptr() + i * r.shape[1] * 4)
+            lens.append(int(r.shape[1]))
+            kk.append(int(k))
+    P = N * L
+    vals = torch.empty((N, L, kmax), dtype=torch.float32, device=dev)
+    idx = torch.empty((N, L, kmax), dtype=torch.int64, device=dev)
+    ws = _workspace(lib.bgs_topk_workspace_bytes(P, int(kmax)), dev)
+    import ctypes
+    rc = lib.bgs_topk_sorted_f32((ctypes.c_void_p * P)(*ptrs), _c_int_array(lens), _c_int_array(kk),
+                                 P, int(kmax), capi.ptr(vals), capi.ptr(idx), capi.ptr(ws),
+                                 capi.current_stream(dev))
+    capi.check('bgs_topk_sorted_f32', rc)
+    return vals, idx
+
+
 def nms_batched(boxes, counts, iou_thr, iou_mode=0, max_keep=0):
     """boxes ``[P,nmax,5]`` sorted by descending score per problem, counts ``[P]`` i32 ->
     ``keep [P,nmax]`` i32 (ascending indices), ``keep_count [P]`` i32.  No host sync."""

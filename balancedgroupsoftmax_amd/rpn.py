@@ -311,15 +311,18 @@ class RPNHead(nn.Module):
         nmax = cfg.nms_pre
         counts = []
         if self._use_fused(cls_scores):
-            top_i = torch.zeros((N, L, nmax), dtype=torch.int64, device=dev)
-            top_l = torch.zeros((N, L, nmax), dtype=torch.float32, device=dev)
-            for lvl in range(L):
-                logits = cls_scores[lvl].reshape(N, -1)          # sigmoid is monotone: top-k on logits
-                k = min(logits.shape[1], nmax)
-                v, i = logits.topk(k, dim=1)
-                top_i[:, lvl, :k] = i
-                top_l[:, lvl, :k] = v
-                counts.append(k)
+            rows = [cls_scores[lvl].reshape(N, -1).float().contiguous() for lvl in range(L)]
+            counts = [min(r.shape[1], nmax) for r in rows]
+            if N * L <= 64 and nmax <= 4096:
+                # sigmoid is monotone: top-k on the logits; all levels in one launch set
+                top_l, top_i = BF.topk_sorted(rows, counts, nmax)
+            else:
+                top_i = torch.zeros((N, L, nmax), dtype=torch.int64, device=dev)
+                top_l = torch.zeros((N, L, nmax), dtype=torch.float32, device=dev)
+                for lvl in range(L):
+                    v, i = rows[lvl].topk(counts[lvl], dim=1)
+                    top_i[:, lvl, :counts[lvl]] = i
+                    top_l[:, lvl, :counts[lvl]] = v
             boxes = BF.decode_proposals(self._fused, counts, self.num_anchors,
                                         self._all_anchors(featmap_sizes, dev), top_i, top_l,
                                         [m['img_shape'][:2] for m in img_metas],
@@ -356,7 +359,11 @@ class RPNHead(nn.Module):
         flat = kept.view(N, L * nmax, 5)
         flat_s = kept_scores.view(N, L * nmax)
         num = min(cfg.max_num, L * nmax)
-        top_s, top_i = flat_s.topk(num, dim=1)
+        if flat_s.is_cuda and N <= 64 and num <= 4096:
+            top_s, top_i = BF.topk_sorted([flat_s.contiguous()], [num], num)
+            top_s, top_i = top_s[:, 0], top_i[:, 0]
+        else:
+            top_s, top_i = flat_s.topk(num, dim=1)
         props = torch.gather(flat, 1, top_i[..., None].expand(-1, -1, 5))
         valid = top_s >= 0
         return [(props[i], valid[i]) for i in range(N)]

@@ -278,6 +278,20 @@ int bgs_resize_bilinear_nhwc_f32(const float* x, float* y, int N, int H, int W, 
 int bgs_resize_bilinear_nhwc_bwd_f32(const float* dy, float* dx, int N, int H, int W, int C,
                                      int Ho, int Wo, int align_corners, bgs_stream_t stream);
 
+/* Batched sorted top-k of fp32 rows: the proposal pre-selection of RPNHead.get_bboxes_single
+ *   (mmdet/models/anchor_heads/rpn_head.py:79-83 `scores.topk(cfg.nms_pre)` per level, :99-103
+ *   `scores.topk(num)` over the NMS survivors).  P <= 64 rows of different lengths / k in one set
+ *   of launches.
+ *   host_rows [P] HOST array of device pointers to contiguous float rows; host_len / host_k [P]
+ *   HOST ints (k[p] <= kmax <= 4096; min(k, len) entries are produced);
+ *   out_val / out_idx [P, kmax]: the largest values in DESCENDING order and their positions in the
+ *   row, zero-filled beyond min(k, len).  Which of several elements equal to the k-th value are
+ *   returned is unspecified (as for torch.topk).  workspace: bgs_topk_workspace_bytes(P, kmax). */
+size_t bgs_topk_workspace_bytes(int P, int kmax);
+int bgs_topk_sorted_f32(const float* const* host_rows, const int* host_len, const int* host_k,
+                        int P, int kmax, float* out_val, long long* out_idx, void* workspace,
+                        bgs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Batched greedy NMS, entirely on the device.  Replaces ops.nms / nms_cuda
  *   (mmdet/ops/nms/nms_wrapper.py:8-49, src/nms_kernel.cu:13-131; CPU variant nms_cpu.cpp:5-59)

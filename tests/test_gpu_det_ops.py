@@ -404,3 +404,58 @@ def test_roi_align_hip_vs_compiled_reference_kernels(out_size):
     d = [torch.zeros(2, H, W, C, device=DEV)]
     BF.roi_align_nhwc_bwd(dev(g), dev(rois), d, [8], finest_scale=1e9)
     np.testing.assert_allclose(d[0].cpu().numpy().transpose(0, 3, 1, 2), eb, rtol=1e-3, atol=1e-4)
+
+
+# ---------------------------------------------------------------- batched sorted top-k (RPN pre-selection)
+def test_topk_sorted_vs_torch_all_rpn_levels():
+    """bgs_topk_sorted_f32 == torch.topk(sorted) per (image, level): values exactly, indices
+    exactly where the values are distinct (ties among EQUAL values are unordered in both)."""
+    g = torch.Generator().manual_seed(0)
+    N, nmax = 2, 2000
+    lens = [201600, 50400, 12600, 3150, 819]
+    rows = [(torch.randn(N, n, generator=g) * 0.7 - 1.0).to(DEV) for n in lens]
+    ks = [min(n, nmax) for n in lens]
+    vals, idx = BF.topk_sorted(rows, ks, nmax)
+    assert tuple(vals.shape) == (N, 5, nmax) and idx.dtype == torch.int64
+    for l, (r, k) in enumerate(zip(rows, ks)):
+        ev, ei = r.topk(k, dim=1)
+        assert torch.equal(vals[:, l, :k], ev), l
+        assert torch.equal(r.gather(1, idx[:, l, :k]), ev), l          # indices point at the values
+        distinct = torch.ones_like(ev, dtype=torch.bool)
+        distinct[:, 1:] &= ev[:, 1:] != ev[:, :-1]
+        distinct[:, :-1] &= ev[:, :-1] != ev[:, 1:]
+        assert torch.equal(idx[:, l, :k][distinct], ei[distinct]), l
+        assert not vals[:, l, k:].any() and not idx[:, l, k:].any()    # zero fill beyond k
+        for i in range(N):
+            assert idx[i, l, :k].unique().numel() == k
+
+
+@pytest.mark.parametrize('case', ['ties', 'negzero', 'final', 'tiny'])
+def test_topk_sorted_edge_cases(case):
+    g = torch.Generator().manual_seed(1)
+    if case == 'ties':        # heavily quantised values: thousands equal to the threshold
+        r = (torch.randint(0, 7, (3, 30000), generator=g).float() - 3.0).to(DEV)
+        k, kmax = 2000, 2048
+    elif case == 'negzero':   # sign handling of the key transform: -0.0 < +0.0 in key order only
+        r = torch.cat([torch.randn(2, 5000, generator=g), torch.zeros(2, 10), -torch.zeros(2, 10),
+                       torch.full((2, 3), float('-inf')), torch.full((2, 2), float('inf'))], 1).to(DEV)
+        k, kmax = 4096, 4096
+    elif case == 'final':     # the post-NMS selection: -1 marks invalid slots
+        r = torch.rand(2, 10000, generator=g)
+        r[:, ::3] = -1.0
+        r = r.to(DEV)
+        k, kmax = 2000, 2000
+    else:                     # fewer elements than k; k == 1; a single element
+        r = torch.randn(4, 5, generator=g).to(DEV)
+        k, kmax = 16, 16
+    vals, idx = BF.topk_sorted([r.contiguous()], [k], kmax)
+    kk = min(k, r.shape[1])
+    ev, _ = r.topk(kk, dim=1)
+    assert torch.equal(vals[:, 0, :kk], ev)
+    assert torch.equal(r.gather(1, idx[:, 0, :kk]), ev)
+    for i in range(r.shape[0]):
+        assert idx[i, 0, :kk].unique().numel() == kk
+    assert not vals[:, 0, kk:].any()
+    if case == 'tiny':
+        v1, i1 = BF.topk_sorted([r.contiguous()], [1], 4)
+        assert torch.equal(v1[:, 0, 0], r.max(dim=1).values) and torch.equal(i1[:, 0, 0], r.argmax(dim=1))
