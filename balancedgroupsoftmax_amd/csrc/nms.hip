@@ -70,8 +70,12 @@ __global__ __launch_bounds__(kTile) void nms_mask_kernel(const float* __restrict
     const float* s = pb + (size_t)i * 5;
     const float cur[4] = {s[0], s[1], s[2], s[3]};
     unsigned long long t = 0ull;
-    const int start = (row_start == col_start) ? threadIdx.x + 1 : 0;
-    for (int j = start; j < col_size; ++j) {
+    // diagonal tiles carry the full symmetric word (every j != i): bits j > i are "i suppresses
+    // j", bits j < i are "i is suppressed by j" (IoU is symmetric) — the scan's parallel
+    // fixed-point iteration reads the latter, the serial recurrence ignores them
+    const int self = (row_start == col_start) ? (int)threadIdx.x : -1;
+    for (int j = 0; j < col_size; ++j) {
+      if (j == self) continue;
       const float v = iou_legacy(cur, cbx + j * 4);
       const bool sup = iou_mode ? (v >= thr) : (v > thr);
       if (sup) t |= 1ull << j;
@@ -200,20 +204,31 @@ __global__ __launch_bounds__(1024) void nms_scan_wide_kernel(
       unsigned long long cur[WPW];
 #pragma unroll
       for (int q = 0; q < WPW; ++q) cur[q] = pre[d][q];
-      load_chunk(c + PF, pre[d]);
       const int rows_here = min(n - c * kTile, kTile);
 #pragma unroll
       for (int q = 0; q < WPW; ++q) {
         if (w + NW * q != c) continue;                     // wave-uniform: the owner of word c
-        unsigned long long dead = remv[q], kept = 0ull;
-        for (int r = 0; r < rows_here; ++r) {
-          if (!((dead >> r) & 1ull)) {
-            kept |= 1ull << r;
-            dead |= readlane_u64(cur[q], r);
-          }
+        // greedy decision inside the chunk as a fixed point instead of a 64-step recurrence
+        // (a lone wave issues ~1 scalar instruction per 5 cycles: the readlane loop cost 2.7 us
+        // per chunk): kept = alive & ~{r : some kept s < r suppresses r}.  Row r's word holds
+        // in its bits below r exactly those s.  After t rounds the first t rows are final, so
+        // the iteration reaches the (unique) greedy solution; suppression chains are short and it
+        // typically stops after 2-4 rounds of ~8 instructions.
+        const unsigned long long rows_mask = rows_here == 64 ? ~0ull : ((1ull << rows_here) - 1ull);
+        const unsigned long long alive = ~remv[q] & rows_mask;
+        const unsigned long long below = cur[q] & ((1ull << lane) - 1ull);
+        unsigned long long kept = alive;
+        for (int it = 0; it <= kTile; ++it) {
+          const unsigned long long sup = __ballot((below & kept) != 0ull);
+          const unsigned long long next = alive & ~sup;
+          if (next == kept) break;
+          kept = next;
         }
         if (lane == 0) s_kept[c & 1] = kept;
       }
+      // refill this slot for chunk c + PF only now: issued before the recurrence, its s_waitcnt
+      // would also wait for these brand-new loads (a full memory round trip per chunk)
+      load_chunk(c + PF, pre[d]);
       __syncthreads();
       const unsigned long long kept = s_kept[c & 1];
       const unsigned long long mine = ((kept >> lane) & 1ull) ? ~0ull : 0ull;
