@@ -140,15 +140,18 @@ class TwoStageDetector(nn.Module):
                 inds, _, valid = A.sample_fixed(a, sc.num, sc.pos_fraction, None)
                 inds_l.append(inds.contiguous())
                 valid_l.append(valid)
-        # gt index of every sampled RoI (pos_assigned_gt_inds for the mask targets), -1 = none
-        self._sampled_gt_inds = torch.stack(
-            [assigned_l[i].gather(0, inds_l[i]).to(torch.int32) - 1 for i in range(N)])
-        # which sampled RoIs are GT boxes added as proposals (SamplingResult.pos_is_gt), and
-        # which slots are real (fewer candidates than `num` leaves padding slots)
-        self._sampled_valid = torch.stack(valid_l)
-        self._sampled_is_gt = torch.stack(
-            [(inds_l[i] < gt_bboxes[i].size(0)) if add_gt else torch.zeros_like(valid_l[i])
-             for i in range(N)])
+        if self.with_mask or isinstance(self.bbox_head, nn.ModuleList):
+            # (only the mask branch and the cascade refinement read these: skipped for the plain
+            #  box detectors, ~10 small launches)
+            # gt index of every sampled RoI (pos_assigned_gt_inds for the mask targets), -1 = none
+            self._sampled_gt_inds = torch.stack(
+                [assigned_l[i].gather(0, inds_l[i]).to(torch.int32) - 1 for i in range(N)])
+            # which sampled RoIs are GT boxes added as proposals (SamplingResult.pos_is_gt), and
+            # which slots are real (fewer candidates than `num` leaves padding slots)
+            self._sampled_valid = torch.stack(valid_l)
+            self._sampled_is_gt = torch.stack(
+                [(inds_l[i] < gt_bboxes[i].size(0)) if add_gt else torch.zeros_like(valid_l[i])
+                 for i in range(N)])
         head = self.bbox_head if head is None else head
         rois, labels, lw, bt, bw = BF.rcnn_targets(
             boxes_l, assigned_l, inds_l, valid_l, [g.contiguous() for g in gt_labels], gt_cat, offs,

@@ -18,16 +18,32 @@ import torch
 import torch.distributed as dist
 
 
+def _scalar(v):
+    return v if v.dim() == 0 else v.mean()
+
+
+def _total(vals):
+    """Sum of 0-dim tensors as ONE stack + ONE reduction (``sum(...)`` is a chain of adds, each a
+    launch forward and a node backward; the detectors produce 16-27 loss scalars per iteration)."""
+    vals = [v.reshape(()) for v in vals]
+    if len(vals) == 1:
+        return vals[0]
+    return torch.stack(vals).sum()
+
+
 def parse_losses(losses):
+    """mmdet/apis/train.py:24-47 (``parse_losses``): per entry the mean (of each element of a
+    list, summed), the total over every key containing ``'loss'``.  Same values; already-scalar
+    entries are not reduced again and the sums are single reductions."""
     log_vars = OrderedDict()
     for name, value in losses.items():
         if isinstance(value, torch.Tensor):
-            log_vars[name] = value.mean()
+            log_vars[name] = _scalar(value)
         elif isinstance(value, (list, tuple)):
-            log_vars[name] = sum(v.mean() for v in value)
+            log_vars[name] = _total([_scalar(v) for v in value])
         else:
             raise TypeError('{} is not a tensor or list of tensors'.format(name))
-    loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+    loss = _total([v for k, v in log_vars.items() if 'loss' in k])
     log_vars['loss'] = loss
     return loss, log_vars
 
