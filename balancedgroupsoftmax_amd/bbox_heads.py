@@ -99,7 +99,7 @@ class BBoxHead(nn.Module):
                            target_means=self.target_means, target_stds=self.target_stds)
 
     def _loss_bbox(self, bbox_pred, labels, bbox_targets, bbox_weights, reduction_override,
-                   label_weights=None):
+                   label_weights=None, n_real=None):
         """Box branch shared by every head (bbox_head.py:117-129, gs_bbox_head_with0.py:173-185):
         HIP gather + SmoothL1 + dense-gradient kernel, no boolean-mask indexing, no sync.
 
@@ -120,7 +120,8 @@ class BBoxHead(nn.Module):
                                      self.num_reg_classes, beta=lb.beta,
                                      avg_factor=bbox_targets.size(0), loss_weight=lb.loss_weight)
         if label_weights is not None and label_weights.is_cuda:
-            n_real = (label_weights > 0).sum().to(torch.float32).clamp(min=1.0)
+            if n_real is None:      # (the GS heads pass bin 0's avg factor = max(#real rows, 1))
+                n_real = (label_weights > 0).sum().to(torch.float32).clamp(min=1.0)
             val = val * (float(bbox_targets.size(0)) / n_real)
         return val
 
@@ -459,8 +460,12 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
             raise NotImplementedError('reduction_override="none" is not produced by the fused '
                                       'kernel (no detector on the BAGS path requests it)')
         losses = dict()
+        n_real = None
         if cls_score is not None:
             bin_labels, weights, avg = self._remap_labels(labels, label_weights)
+            # bin 0 weighs every real row 1 (gs_bbox_head_with0.py:100-102; the reweight variant's
+            # tables start at bin 1): its avg factor is max(#real rows, 1)
+            n_real = avg[0]
             per_bin = BF.group_softmax_loss(cls_score, bin_labels, self.pred_slice_host,
                                             weights, avg)
             per_bin = per_bin * self.bin_loss_weight
@@ -468,7 +473,7 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
                 losses['loss_cls_bin{}'.format(i)] = per_bin[i]
         if bbox_pred is not None:
             losses['loss_bbox'] = self._loss_bbox(bbox_pred, labels, bbox_targets, bbox_weights,
-                                                  reduction_override, label_weights)
+                                                  reduction_override, label_weights, n_real)
         return losses
 
     @force_fp32(apply_to=('cls_score', ))

@@ -94,8 +94,8 @@ SIGNATURES = {
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
                                     c_f32p, c_f32p, c_f32p, c_ptr]),
     'bgs_topk_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
-    'bgs_topk_sorted_f32': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, c_f32p,
-                                           c_ptr, c_ptr, c_ptr]),
+    'bgs_topk_sorted_f32': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int,
+                                           ctypes.c_int, c_f32p, c_ptr, c_ptr, c_ptr]),
     'bgs_nms_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     'bgs_nms_batched': (ctypes.c_int, [c_f32p, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                        ctypes.c_int, ctypes.c_int, c_ptr, c_ptr, c_ptr, c_ptr]),

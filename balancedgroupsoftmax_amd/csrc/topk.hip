@@ -35,7 +35,18 @@ struct TopkProblems {
   const float* row[kMaxProblems];
   int len[kMaxProblems];
   int k[kMaxProblems];
+  // element i of a row lives at row[(i / inner) * pitch + (i % inner)]; inner == 0: row[i].
+  // (The RPN's objectness logits are the first A of 5A channels of the fused head output.)
+  int inner[kMaxProblems];
+  int pitch[kMaxProblems];
 };
+
+__device__ __forceinline__ float topk_elem(const TopkProblems& pr, int p, const float* row, int i) {
+  const int inner = pr.inner[p];
+  if (inner == 0) return row[i];
+  const int q = i / inner;
+  return row[(size_t)q * pr.pitch[p] + (i - q * inner)];
+}
 
 struct TopkWs {
   int* hist;                    // [P, kBins]
@@ -67,7 +78,7 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(TopkProblems pr, TopkWs 
   const unsigned prefix = ws.state[p * kState + 0], pmask = ws.state[p * kState + 1];
   const float* row = pr.row[p];
   for (int i = lo + tid; i < hi; i += 256) {
-    const unsigned key = key_of(row[i]);
+    const unsigned key = key_of(topk_elem(pr, p, row, i));
     if ((key & pmask) == prefix) atomicAdd(&h[(key >> shift) & (nb - 1)], 1);
   }
   __syncthreads();
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(256) void topk_collect_kernel(TopkProblems pr, Topk
   const float* row = pr.row[p];
   if (k <= 0) return;
   for (int i = lo + tid; i < hi; i += 256) {
-    const unsigned key = key_of(row[i]);
+    const unsigned key = key_of(topk_elem(pr, p, row, i));
     if (key < T) continue;
     const unsigned long long comp = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)i);
     if (key > T) {
@@ -192,7 +203,8 @@ extern "C" size_t bgs_topk_workspace_bytes(int P, int kmax) {
 }
 
 extern "C" int bgs_topk_sorted_f32(const float* const* host_rows, const int* host_len,
-                                   const int* host_k, int P, int kmax, float* out_val,
+                                   const int* host_k, const int* host_inner,
+                                   const int* host_pitch, int P, int kmax, float* out_val,
                                    long long* out_idx, void* workspace, bgs_stream_t stream) {
   if (P < 0 || kmax <= 0) return BGS_ERR_INVALID_ARG;
   if (P == 0) return BGS_OK;
@@ -203,14 +215,21 @@ extern "C" int bgs_topk_sorted_f32(const float* const* host_rows, const int* hos
   int maxlen = 0;
   for (int p = 0; p < kMaxProblems; ++p) {
     pr.row[p] = nullptr;
-    pr.len[p] = pr.k[p] = 0;
+    pr.len[p] = pr.k[p] = pr.inner[p] = pr.pitch[p] = 0;
   }
+  if ((host_inner == nullptr) != (host_pitch == nullptr)) return BGS_ERR_INVALID_ARG;
   for (int p = 0; p < P; ++p) {
     if (host_len[p] < 0 || host_k[p] < 0 || host_k[p] > kmax) return BGS_ERR_INVALID_ARG;
     if (host_len[p] > 0 && !host_rows[p]) return BGS_ERR_INVALID_ARG;
     pr.row[p] = host_rows[p];
     pr.len[p] = host_len[p];
     pr.k[p] = host_k[p];
+    if (host_inner) {
+      if (host_inner[p] < 0 || (host_inner[p] > 0 && host_pitch[p] < host_inner[p]))
+        return BGS_ERR_INVALID_ARG;
+      pr.inner[p] = host_inner[p];
+      pr.pitch[p] = host_pitch[p];
+    }
     if (host_len[p] > maxlen) maxlen = host_len[p];
   }
   TopkWs ws;

@@ -658,31 +658,45 @@ def resize_bilinear_nhwc_autograd(x, size):
     return resize_bilinear_nhwc(x, size)
 
 
-def topk_sorted(rows, ks, kmax):
+def topk_sorted(rows, ks, kmax, inner=None):
     """Sorted top-k of several row sets in one launch set (``bgs_topk_sorted_f32``).
 
-    ``rows``: list of L contiguous float32 tensors ``[N, n_l]``; ``ks``: list of L ints
-    (``k_l <= kmax <= 4096``).  Returns ``(values, indices)`` of shape ``[N, L, kmax]``: per
-    (image, set) the ``min(k_l, n_l)`` largest entries in descending order and their positions,
-    zeros beyond.  ``N * L <= 64``."""
+    ``rows``: list of L float32 tensors, one per set, ``[N, ...]`` with contiguous per-image
+    blocks; ``ks``: list of L ints (``k_l <= kmax <= 4096``).  ``inner=None``: each per-image
+    block is a flat row.  ``inner=A``: the block is ``[n_pix, C]`` and the row consists of the
+    FIRST ``A`` channels of every pixel (``n_pix * A`` elements, index ``pix * A + a``) — the
+    objectness logits inside the fused RPN head output, read in place.
+    Returns ``(values, indices)`` ``[N, L, kmax]``: per (image, set) the ``min(k_l, len)`` largest
+    entries in descending order and their row positions, zeros beyond.  ``N * L <= 64``."""
+    import ctypes
     _require_cuda(*rows)
     lib = capi.load()
     N = rows[0].shape[0]
     L = len(rows)
     dev = rows[0].device
-    ptrs, lens, kk = [], [], []
+    ptrs, lens, kk, inn, pit = [], [], [], [], []
     for i in range(N):
         for r, k in zip(rows, ks):
-            assert r.dim() == 2 and r.shape[0] == N and r.dtype == torch.float32 and r.is_contiguous()
-            ptrs.append(r.data_ptr() + i * r.shape[1] * 4)
-            lens.append(int(r.shape[1]))
+            assert r.shape[0] == N and r.dtype == torch.float32 and r.is_contiguous()
+            per = r[0].numel()
+            ptrs.append(r.data_ptr() + i * per * 4)
+            if inner is None:
+                lens.append(per)
+                inn.append(0)
+                pit.append(0)
+            else:
+                C = int(r.shape[-1])
+                lens.append(per // C * int(inner))
+                inn.append(int(inner))
+                pit.append(C)
             kk.append(int(k))
     P = N * L
     vals = torch.empty((N, L, kmax), dtype=torch.float32, device=dev)
     idx = torch.empty((N, L, kmax), dtype=torch.int64, device=dev)
     ws = _workspace(lib.bgs_topk_workspace_bytes(P, int(kmax)), dev)
-    import ctypes
     rc = lib.bgs_topk_sorted_f32((ctypes.c_void_p * P)(*ptrs), _c_int_array(lens), _c_int_array(kk),
+                                 _c_int_array(inn) if inner is not None else None,
+                                 _c_int_array(pit) if inner is not None else None,
                                  P, int(kmax), capi.ptr(vals), capi.ptr(idx), capi.ptr(ws),
                                  capi.current_stream(dev))
     capi.check('bgs_topk_sorted_f32', rc)

@@ -311,16 +311,17 @@ class RPNHead(nn.Module):
         nmax = cfg.nms_pre
         counts = []
         if self._use_fused(cls_scores):
-            rows = [cls_scores[lvl].reshape(N, -1).float().contiguous() for lvl in range(L)]
-            counts = [min(r.shape[1], nmax) for r in rows]
+            na = self.num_anchors * self.cls_out_channels
+            counts = [min(int(c[0].numel()), nmax) for c in cls_scores]
             if N * L <= 64 and nmax <= 4096:
-                # sigmoid is monotone: top-k on the logits; all levels in one launch set
-                top_l, top_i = BF.topk_sorted(rows, counts, nmax)
+                # sigmoid is monotone: top-k on the logits — all levels in one launch set, read in
+                # place from the fused head output (first `na` of the 5 * na channels per pixel)
+                top_l, top_i = BF.topk_sorted(self._fused, counts, nmax, inner=na)
             else:
                 top_i = torch.zeros((N, L, nmax), dtype=torch.int64, device=dev)
                 top_l = torch.zeros((N, L, nmax), dtype=torch.float32, device=dev)
                 for lvl in range(L):
-                    v, i = rows[lvl].topk(counts[lvl], dim=1)
+                    v, i = cls_scores[lvl].reshape(N, -1).float().topk(counts[lvl], dim=1)
                     top_i[:, lvl, :counts[lvl]] = i
                     top_l[:, lvl, :counts[lvl]] = v
             boxes = BF.decode_proposals(self._fused, counts, self.num_anchors,

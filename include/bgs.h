@@ -282,15 +282,18 @@ int bgs_resize_bilinear_nhwc_bwd_f32(const float* dy, float* dx, int N, int H, i
  *   (mmdet/models/anchor_heads/rpn_head.py:79-83 `scores.topk(cfg.nms_pre)` per level, :99-103
  *   `scores.topk(num)` over the NMS survivors).  P <= 64 rows of different lengths / k in one set
  *   of launches.
- *   host_rows [P] HOST array of device pointers to contiguous float rows; host_len / host_k [P]
- *   HOST ints (k[p] <= kmax <= 4096; min(k, len) entries are produced);
+ *   host_rows [P] HOST array of device pointers to float rows; host_len / host_k [P] HOST ints
+ *   (k[p] <= kmax <= 4096; min(k, len) entries are produced); host_inner / host_pitch [P] HOST
+ *   ints or both NULL: element i of row p is row[(i / inner) * pitch + i % inner] (inner == 0 or
+ *   NULL: contiguous) — the objectness logits are the first A of the 5A channels of the fused RPN
+ *   head output and are read in place;
  *   out_val / out_idx [P, kmax]: the largest values in DESCENDING order and their positions in the
  *   row, zero-filled beyond min(k, len).  Which of several elements equal to the k-th value are
  *   returned is unspecified (as for torch.topk).  workspace: bgs_topk_workspace_bytes(P, kmax). */
 size_t bgs_topk_workspace_bytes(int P, int kmax);
 int bgs_topk_sorted_f32(const float* const* host_rows, const int* host_len, const int* host_k,
-                        int P, int kmax, float* out_val, long long* out_idx, void* workspace,
-                        bgs_stream_t stream);
+                        const int* host_inner, const int* host_pitch, int P, int kmax,
+                        float* out_val, long long* out_idx, void* workspace, bgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Batched greedy NMS, entirely on the device.  Replaces ops.nms / nms_cuda

@@ -430,6 +430,22 @@ def test_topk_sorted_vs_torch_all_rpn_levels():
             assert idx[i, l, :k].unique().numel() == k
 
 
+def test_topk_sorted_reads_fused_head_layout_in_place():
+    """``inner=A``: the row is the first A of C channels per pixel (the objectness logits inside
+    the fused RPN output ``[N, H, W, 5A]``) — same result as top-k of the gathered copy."""
+    g = torch.Generator().manual_seed(4)
+    fused = [torch.randn(2, h, w, 15, generator=g).to(DEV) for h, w in [(50, 84), (13, 21), (4, 5)]]
+    ks = [2000, 2000, 2000]
+    vals, idx = BF.topk_sorted(fused, [min(k, f[0].numel() // 5) for k, f in zip(ks, fused)], 2000,
+                               inner=3)
+    for l, f in enumerate(fused):
+        r = f[..., :3].reshape(2, -1)
+        k = min(2000, r.shape[1])
+        ev, ei = r.topk(k, dim=1)
+        assert torch.equal(vals[:, l, :k], ev) and torch.equal(idx[:, l, :k], ei)
+        assert not vals[:, l, k:].any()
+
+
 @pytest.mark.parametrize('case', ['ties', 'negzero', 'final', 'tiny'])
 def test_topk_sorted_edge_cases(case):
     g = torch.Generator().manual_seed(1)
