@@ -388,7 +388,9 @@ static int launch_conv(ConvArgs& p, int up, hipStream_t st, void* workspace = nu
   int splits = 1;
   p.partial = nullptr;
   p.kt_per_split = 0;
-  if (tile == 11 && workspace) {
+  // (BGS_CONV_TILE + BGS_CONV_SPLITK together also split the larger tiles: tuning sweeps)
+  const bool force_split = force != 0 && getenv("BGS_CONV_SPLITK") != nullptr;
+  if ((tile == 11 || force_split) && workspace) {
     const long long wgs = ((M + 63) / 64) * ((p.Cout + 63) / 64);
     const int nk = (p.K + bk - 1) / bk;
     // measured on the cfg[1] shapes (profiles/r1z_splitk_sweep*.txt): < 600 workgroups: aim at
