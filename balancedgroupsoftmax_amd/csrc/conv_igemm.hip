@@ -448,6 +448,7 @@ extern "C" size_t bgs_conv2d_workspace_bytes(long long M, int Cout) {
   if (M <= 0 || Cout <= 0) return 0;
   const long long wgs = ((M + 63) / 64) * ((Cout + 63) / 64);
   if (wgs >= 1500) return 0;
+  if (getenv("BGS_CONV_SPLITK")) return (size_t)16 * (size_t)M * Cout * sizeof(float);   // sweeps
   return (size_t)(wgs < 600 ? 8 : 2) * (size_t)M * Cout * sizeof(float);
 }
 
