@@ -50,7 +50,7 @@ def main():
     pf = os.environ.get('SWEEP_PF', '2')
     os.environ['BGS_CONV_PF'] = pf
     print('register prefetch depth PF =', pf)
-    tiles = ['0', '22', '21', '11']
+    tiles = os.environ.get('SWEEP_TILES', '0,22,21,11').split(',')
     tot = {t: 0.0 for t in tiles}
     tot['best'] = 0.0
     gf_total = 0.0
