@@ -32,7 +32,7 @@ from oracle import build_ref, det_oracle, ref_import  # noqa: E402
 
 OUT = os.path.join(HERE, 'e2e_inference_golden.npz')
 H, W = 192, 256
-IMG_SEED, FRCNN_SEED, HTC_SEED = 901, 902, 903
+IMG_SEED, FRCNN_SEED, HTC_SEED, MASK_SEED = 901, 902, 903, 904
 TEST_CFG = dict(rpn=dict(nms_across_levels=False, nms_pre=1000, nms_post=1000, max_num=300,
                          nms_thr=0.7, min_bbox_size=0),
                 rcnn=dict(score_thr=0.0, nms=dict(type='nms', iou_thr=0.5), max_per_img=50,
@@ -54,7 +54,7 @@ def configs(table_dir, which):
     """The model dicts of bench.detector_cfg (same keys / values as the reference config files;
     the three table files are synthetic)."""
     from bench import detector_cfg
-    model, _ = detector_cfg(table_dir, htc=(which == 'htc'))
+    model, _ = detector_cfg(table_dir, htc=(which == 'htc'), mask=(which == 'mask'))
     if which == 'htc':
         model['backbone'] = dict(model['backbone'], depth=50)
     return model
@@ -107,6 +107,26 @@ def main():
     out['frcnn/det_labels'] = dl.numpy()
     print('frcnn: proposals', tuple(props[0].shape), 'dets', tuple(db.shape),
           'score range', float(db[:, 4].min()), float(db[:, 4].max()))
+
+    # ---------------------------------------------------------------- Mask R-CNN R50 + BAGS (cfg[3])
+    model = build_detector(to_config_dict(configs(tmp, 'mask')), train_cfg=None, test_cfg=tcfg)
+    with torch.no_grad():
+        det_oracle.fill_detector(model.state_dict(), MASK_SEED)
+        model.eval()
+        x = model.extract_feat(img)
+        props = model.simple_test_rpn(x, meta, tcfg.rpn)
+        db, dl, _ = model.simple_test_bboxes(x, meta, props, tcfg.rcnn, rescale=False)
+        # test_mixins.py:153-180 (simple_test_mask) up to the per-detection class channel
+        mask_rois = bbox2roi([db[:, :4]])
+        mask_feats = model.mask_roi_extractor(x[:len(model.mask_roi_extractor.featmap_strides)],
+                                              mask_rois)
+        mask_pred = model.mask_head(mask_feats)
+        probs = mask_pred[torch.arange(db.size(0)), dl + 1].sigmoid()
+    out['mask/proposals'] = props[0].numpy()
+    out['mask/det_bboxes'] = db.numpy()
+    out['mask/det_labels'] = dl.numpy()
+    out['mask/mask_probs'] = probs.numpy()
+    print('mask: dets', tuple(db.shape), 'mask', tuple(probs.shape))
 
     # ---------------------------------------------------------------- HTC X50-64x4d + BAGS
     model = build_detector(to_config_dict(configs(tmp, 'htc')), train_cfg=None, test_cfg=tcfg)

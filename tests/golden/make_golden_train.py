@@ -85,6 +85,15 @@ GRADS_MASK = [
     ('backbone.layer2.3.conv3.weight', (slice(None, None, 16), slice(None, None, 8))),
 ]
 MASK_SEED = 931
+GRADS_CASCADE = [
+    ('bbox_head.0.fc_cls.weight', (slice(None, None, 16), slice(None, None, 16))),
+    ('bbox_head.1.fc_cls.bias', (slice(None),)),
+    ('bbox_head.2.fc_reg.weight', (slice(None), slice(None, None, 16))),
+    ('bbox_head.2.shared_fcs.1.weight', (slice(None, None, 16), slice(None, None, 16))),
+    ('neck.lateral_convs.2.conv.weight', (slice(None, None, 8), slice(None, None, 16))),
+    ('backbone.layer4.0.conv2.weight', (slice(None, None, 16), slice(None, None, 16))),
+]
+CASCADE_SEED = 941
 
 
 def gt():
@@ -115,13 +124,13 @@ def gt_semantic_seg():
     return seg
 
 
-def configs(table_dir, htc=False, mask=False):
+def configs(table_dir, htc=False, mask=False, cascade=False):
     from bench import detector_cfg
-    model, train_cfg = detector_cfg(table_dir, htc=htc, mask=mask)
-    heads = model['bbox_head'] if htc else [model['bbox_head']]
+    model, train_cfg = detector_cfg(table_dir, htc=htc, mask=mask, cascade=cascade)
+    heads = model['bbox_head'] if (htc or cascade) else [model['bbox_head']]
     for h in heads:
         h['gs_config']['others_sample_ratio'] = 1e6
-    if htc:         # plain ResNet-50 trunk: full backward on both sides
+    if htc or cascade:         # plain ResNet-50 trunk: full backward on both sides
         model['backbone'] = dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3),
                                  frozen_stages=1, style='pytorch')
     train_cfg['rpn']['sampler']['num'] = 16384
@@ -245,6 +254,27 @@ def main():
     params = dict(model.named_parameters())
     for name, idx in GRADS_MASK:
         out['mask/grad/' + name] = params[name].grad[idx].contiguous().numpy()
+
+    # ------------------------------------------------------------ Cascade R-CNN (cfg[4], R50 trunk)
+    model_cfg, train_cfg = configs(tmp, cascade=True)
+    model = build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
+                           test_cfg=to_config_dict(E.TEST_CFG))
+    with torch.no_grad():
+        det_oracle.fill_detector(model.state_dict(), CASCADE_SEED)
+    model.train()
+    losses = model.forward_train(torch.from_numpy(E.image()), E.img_meta(),
+                                 [torch.from_numpy(boxes)], [torch.from_numpy(labels)])
+    total = 0
+    for k, v in losses.items():
+        vals = v if isinstance(v, list) else [v]
+        out['cascade/loss/' + k] = np.array([float(t.detach().sum()) for t in vals], np.float32)
+        if 'loss' in k:
+            total = total + sum(t.sum() for t in vals)
+    total.backward()
+    out['cascade/loss/total'] = np.array([float(total.detach())], np.float32)
+    params = dict(model.named_parameters())
+    for name, idx in GRADS_CASCADE:
+        out['cascade/grad/' + name] = params[name].grad[idx].contiguous().numpy()
     for k in sorted(out):
         if 'loss/' in k:
             print(k, out[k])

@@ -281,3 +281,68 @@ def test_mask_rcnn_training_iteration_vs_executed_reference_detector():
         if not grad_close(g[idx].cpu().numpy(), z['mask/grad/' + name]):
             bad.append(name)
     assert not bad, bad
+
+
+def test_cascade_rcnn_training_iteration_vs_executed_reference_detector():
+    """cfg[4] orchestration (cascade_rcnn.py:152-298: three box stages at IoU 0.5 / 0.6 / 0.7, each
+    re-sampling from the boxes the previous stage refined, stage loss weights 1 / 0.5 / 0.25) on
+    a ResNet-50 trunk against the executed reference: 28 loss terms + gradients."""
+    from balancedgroupsoftmax_amd import train
+    from tests.golden import make_golden_train as T
+    z = np.load(os.path.join(os.path.dirname(T.__file__), 'e2e_train_golden.npz'))
+    tmp = tempfile.mkdtemp(prefix='bgs_e2e_')
+    model_cfg, train_cfg = T.configs(tmp, cascade=True)
+    model = bgs.build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
+                               test_cfg=to_config_dict(G.TEST_CFG))
+    with torch.no_grad():
+        det_oracle.fill_detector(model.state_dict(), T.CASCADE_SEED)
+    model.to(DEV)
+    train.select_training_param(model, 0)
+    model.train()
+    boxes, labels = T.gt()
+    losses = model(torch.from_numpy(G.image()).to(DEV), G.img_meta(), return_loss=True,
+                   gt_bboxes=[torch.from_numpy(boxes).to(DEV)],
+                   gt_labels=[torch.from_numpy(labels).to(DEV)])
+    keys = [k[len('cascade/loss/'):] for k in z.files
+            if k.startswith('cascade/loss/') and not k.endswith('total')]
+    assert set(keys) == set(losses.keys())
+    bad = []
+    for k in keys:
+        v = losses[k]
+        got = np.array([float(t.detach().sum()) for t in (v if isinstance(v, list) else [v])], np.float32)
+        exp = z['cascade/loss/' + k]
+        if np.abs(got - exp).max() > 2e-4 * max(1.0, np.abs(exp).max()):
+            bad.append((k, got.tolist(), exp.tolist()))
+    assert not bad, bad
+    loss, _ = train.parse_losses(losses)
+    loss.backward()
+    params = dict(model.named_parameters())
+    bad = [name for name, idx in T.GRADS_CASCADE
+           if not grad_close(params[name].grad[idx].cpu().numpy(), z['cascade/grad/' + name])]
+    assert not bad, bad
+
+
+def test_mask_rcnn_test_pass_vs_executed_reference_detector():
+    """cfg[3] at test time: detections and each detection's class mask probability
+    (test_mixins.py:153-180 up to the sigmoid of the predicted class' channel)."""
+    z = np.load(GOLD)
+    model = _build('mask', G.MASK_SEED)
+    img = torch.from_numpy(G.image()).to(DEV)
+    meta = G.img_meta()
+    with torch.no_grad():
+        x = model.extract_feat(img)
+        rp = torch.from_numpy(z['mask/proposals']).to(DEV)
+        db, dl, _ = model.simple_test_bboxes(x, meta, [rp], model.test_cfg.rcnn)
+        masks = model.simple_test_mask(x, meta, db, dl).cpu().numpy()
+    got = np.concatenate([db.cpu().numpy(), dl.cpu().numpy()[:, None].astype(np.float32)], 1)
+    exp = np.concatenate([z['mask/det_bboxes'], z['mask/det_labels'][:, None].astype(np.float32)], 1)
+    assert got.shape == exp.shape == (50, 6) and masks.shape == (50, 28, 28)
+    hit, worst = 0, 0.0
+    for k, e in enumerate(exp):
+        j = np.nonzero((got[:, 5] == e[5]) & (np.abs(got[:, :4] - e[:4]).max(axis=1) < 0.05)
+                       & (np.abs(got[:, 4] - e[4]) < 2e-5))[0]
+        if len(j):
+            hit += 1
+            worst = max(worst, float(np.abs(masks[j[0]] - z['mask/mask_probs'][k]).max()))
+    assert hit >= 48, hit
+    assert worst < 2e-3, worst
