@@ -196,3 +196,41 @@ def test_full_detector_builds_from_reference_config(tmp_path):
     loss, log_vars = train.parse_losses(dict(loss_a=torch.tensor(1.0), acc=torch.tensor(50.0),
                                              loss_b=[torch.tensor(2.0), torch.tensor(3.0)]))
     assert float(loss) == 6.0 and float(log_vars['loss_b']) == 5.0
+
+
+def test_parse_losses_equals_the_reference_formula_with_gradients():
+    """``train.parse_losses`` (single stack + sum reductions) == mmdet/apis/train.py:15-27 (means,
+    chained ``sum``) in value and in the gradient every loss tensor receives — on the loss dict
+    shapes the detectors produce (per-level lists, 0-dim scalars, a non-scalar entry, an ``acc``)."""
+    from collections import OrderedDict
+    from balancedgroupsoftmax_amd import train
+    g = torch.Generator().manual_seed(0)
+
+    def make():
+        d = OrderedDict()
+        d['loss_rpn_cls'] = [torch.rand((), generator=g).requires_grad_(True) for _ in range(5)]
+        d['loss_rpn_bbox'] = [torch.rand((), generator=g).requires_grad_(True) for _ in range(5)]
+        for i in range(5):
+            d['s0.loss_cls_bin%d' % i] = torch.rand((), generator=g).requires_grad_(True)
+        d['loss_elementwise'] = torch.rand(7, generator=g).requires_grad_(True)     # mean() applies
+        d['acc'] = torch.tensor(50.0)                                               # not a loss
+        return d
+
+    d = make()
+    loss, log_vars = train.parse_losses(d)
+    # the reference's arithmetic (its .item() conversion of log_vars aside)
+    ref_vars = OrderedDict()
+    for k, v in d.items():
+        ref_vars[k] = v.mean() if isinstance(v, torch.Tensor) else sum(t.mean() for t in v)
+    ref = sum(v for k, v in ref_vars.items() if 'loss' in k)
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-6
+    for k in ref_vars:
+        assert abs(float(log_vars[k].detach()) - float(ref_vars[k].detach())) < 1e-6
+    assert 'loss' in log_vars and 'acc' in log_vars
+    leaves = [t for v in d.values() for t in (v if isinstance(v, list) else [v]) if t.requires_grad]
+    got = torch.autograd.grad(loss, leaves)
+    exp = torch.autograd.grad(ref, leaves)
+    for a, b in zip(got, exp):
+        assert torch.allclose(a, b)
+    with pytest.raises(TypeError):
+        train.parse_losses(dict(loss_x=3.0))
