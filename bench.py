@@ -563,7 +563,7 @@ def main_detector(args, rank, local, world, dev):
     # replays (tools/debug/two_graphs.py reproduces it: "variants plain" vs "variants whole";
     # DESIGN.md §5).  With N > 1 the gradient all-reduce (RCCL) sits between backward and the
     # optimizer, so multi-GPU runs launch eagerly — the step is GPU-bound and eager launches
-    # cost < 1 % (14.08 vs 13.98 ms).
+    # cost nothing measurable (10.99 vs 10.96 ms).
     graph = None
     if world == 1 and not args.no_graph:
         graph = try_graph(step)
@@ -571,6 +571,13 @@ def main_detector(args, rank, local, world, dev):
     dt = timed_loop(fn, args.steps, args.warmup, world)
     ms_per_step = dt * 1e3 / args.steps
     imgs_per_s = args.imgs * world * args.steps / dt
+    cfg_name = 'gs_faster_rcnn_r50_fpn_1x_lvis_with0_bg8 (cfg[1])'
+    if args.htc:
+        cfg_name = 'gs_htc_x101_64x4d_fpn_20e_16gpu_lvis (cfg[4], HTC, fp32)'
+    elif args.cascade:
+        cfg_name = 'gs_cascade_rcnn_x101_64x4d_fpn_1x_lvis (cfg[4], fp32)'
+    elif args.mask:
+        cfg_name = 'gs_mask_rcnn_r50_fpn_1x_lvis (cfg[3])'
     if rank == 0:
         lv = {k: round(float(v), 5) for k, v in step.last.items()}
         out = {
@@ -580,7 +587,7 @@ def main_detector(args, rank, local, world, dev):
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': 'gs_faster_rcnn_r50_fpn_1x_lvis_with0_bg8 (cfg[1]) training '
+            'config': {'workload': cfg_name + ' training '
                                    'iteration %s, grad all-reduce, clip 35, SGD): '
                                    '%d img/GPU, 3x800x1344 (1333x800 padded /32), 20 GT/img, '
                                    '512 RoI/img, 1231 classes, 5 bins; random-init weights'
