@@ -144,20 +144,32 @@ __global__ __launch_bounds__(256) void sample_scan_kernel(const int* __restrict_
   if (tid < 2) s_cnt[tid] = 0;
   __syncthreads();
   int c_pos = 0, c_neg = 0;
-  for (int i = lo + tid; i < hi; i += 256) {
-    const int a = assigned[i];
-    if (a < 0) continue;
+  const int lane = tid & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // wave-uniform trip count (the ballots below need converged lanes); one atomic per wave and
+  // list instead of one per candidate: ~2000 appends to ONE counter serialised to 40 us
+  for (int i0 = lo; i0 < hi; i0 += 256) {
+    const int i = i0 + tid;
+    const int a = i < hi ? assigned[i] : -1;
     const uint32_t key = mix32((uint32_t)i + offset);
-    if (a > 0) {
-      ++c_pos;
-      const int slot = atomicAdd(&ctr[2], 1);
-      if (slot < kCand) lp[slot] = key;
-    } else {
-      ++c_neg;
-      if (key <= t0_neg) {
-        const int slot = atomicAdd(&ctr[3], 1);
-        if (slot < kCand) ln[slot] = key;
-      }
+    const bool is_pos = a > 0, is_neg = a == 0;
+    c_pos += is_pos;
+    c_neg += is_neg;
+    const bool cand_neg = is_neg && key <= t0_neg;
+    const unsigned long long mp = __ballot(is_pos), mn = __ballot(cand_neg);
+    if (mp) {
+      int base = 0;
+      if (lane == __ffsll((long long)mp) - 1) base = atomicAdd(&ctr[2], __popcll(mp));
+      base = __shfl(base, __ffsll((long long)mp) - 1, 64);
+      const int slot = base + __popcll(mp & below);
+      if (is_pos && slot < kCand) lp[slot] = key;
+    }
+    if (mn) {
+      int base = 0;
+      if (lane == __ffsll((long long)mn) - 1) base = atomicAdd(&ctr[3], __popcll(mn));
+      base = __shfl(base, __ffsll((long long)mn) - 1, 64);
+      const int slot = base + __popcll(mn & below);
+      if (cand_neg && slot < kCand) ln[slot] = key;
     }
   }
   c_pos = bgs::wave_sum_i(c_pos);

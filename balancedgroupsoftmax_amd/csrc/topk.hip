@@ -140,16 +140,30 @@ __global__ __launch_bounds__(256) void topk_collect_kernel(TopkProblems pr, Topk
   unsigned long long* list = ws.list + (size_t)p * kmax;
   const float* row = pr.row[p];
   if (k <= 0) return;
-  for (int i = lo + tid; i < hi; i += 256) {
-    const unsigned key = key_of(topk_elem(pr, p, row, i));
-    if (key < T) continue;
+  const int lane = tid & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // (wave-uniform trip count; one atomic per wave and list, not one per selected element)
+  for (int i0 = lo; i0 < hi; i0 += 256) {
+    const int i = i0 + tid;
+    const bool in = i < hi;
+    const unsigned key = in ? key_of(topk_elem(pr, p, row, i)) : 0u;
     const unsigned long long comp = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)i);
-    if (key > T) {
-      const int slot = (int)atomicAdd(&st[3], 1u);         // fills [0, k - need_eq)
-      list[slot] = comp;
-    } else {
-      const int slot = (int)atomicAdd(&st[4], 1u);         // ties fill from the back
-      if (slot < need_eq) list[k - 1 - slot] = comp;
+    const bool gt = in && key > T, eq = in && key == T;
+    const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+    if (mg) {
+      const int leader = __ffsll((long long)mg) - 1;
+      int base = 0;
+      if (lane == leader) base = (int)atomicAdd(&st[3], (unsigned)__popcll(mg));
+      base = __shfl(base, leader, 64);
+      if (gt) list[base + __popcll(mg & below)] = comp;    // fills [0, k - need_eq)
+    }
+    if (me) {
+      const int leader = __ffsll((long long)me) - 1;
+      int base = 0;
+      if (lane == leader) base = (int)atomicAdd(&st[4], (unsigned)__popcll(me));
+      base = __shfl(base, leader, 64);
+      const int slot = base + __popcll(me & below);
+      if (eq && slot < need_eq) list[k - 1 - slot] = comp;  // ties fill from the back
     }
   }
 }
