@@ -61,6 +61,8 @@ SIGNATURES = {
     'bgs_conv2d_wgrad_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 9),
     'bgs_conv2d_wgrad_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p]
                                   + [ctypes.c_int] * 10 + [c_ptr, c_ptr]),
+    'bgs_conv3x3_halo_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 6
+                                  + [c_ptr]),
     'bgs_grouped_conv3x3_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 7
                                      + [c_ptr]),
     'bgs_maxpool3x3s2_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p] + [ctypes.c_int] * 4 + [c_ptr]),

@@ -6,6 +6,7 @@ Every wrapper requires CUDA(ROCm) tensors and raises otherwise — there is no C
 path in the product.
 """
 import itertools
+import os
 
 import torch
 
@@ -246,6 +247,19 @@ def bbox_smooth_l1_loss(bbox_pred, labels, bbox_targets, bbox_weights, num_reg_c
 # ----------------------------------------------------------------------------------------
 # conv / linear on the fp32 matrix cores (NHWC activations, [Cout,R,S,Cin] weights)
 # ----------------------------------------------------------------------------------------
+def _use_halo_kernel(M, Cout):
+    """``BGS_CONV_HALO`` = 1: every eligible 3x3 layer, 0: never; unset: where it was measured
+    faster than the general kernel (tools/conv_halo_check.py, profiles/r3m_conv_halo.txt): the
+    large-M, Cout % 128 == 0 layers (FPN output conv and RPN conv on P2: 114 vs 98 TFLOP/s); its
+    fixed 128 x 128 tile without split-K loses on the smaller ones."""
+    env = os.environ.get('BGS_CONV_HALO')
+    if env == '1':
+        return True
+    if env == '0':
+        return False
+    return M >= 100000 and Cout % 128 == 0
+
+
 def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None,
                 residual_mode=0, out=None):
     """``y = act(conv(x, w) + bias + residual)``; x ``[N,H,W,Cin]``, w ``[Cout,R,S,Cin]``.
@@ -266,6 +280,15 @@ def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None
         assert tuple(residual.shape) == exp and residual.is_contiguous(), (residual.shape, exp)
     if out is None:
         out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    if R == 3 and S == 3 and stride == 1 and pad == 1 and residual is None and Cin % 16 == 0 \
+            and _use_halo_kernel(N * Ho * Wo, Cout):
+        # halo-resident 3x3 kernel (csrc/conv_halo.hip): the input patch is staged in LDS once per
+        # channel chunk and shared by the nine taps
+        rc = lib.bgs_conv3x3_halo_nhwc_f32(capi.ptr(x), capi.ptr(w_krsc), capi.ptr(bias),
+                                           capi.ptr(out), N, H, W, Cin, Cout, int(bool(relu)),
+                                           capi.current_stream(x.device))
+        capi.check('bgs_conv3x3_halo_nhwc_f32', rc)
+        return out
     wsb = lib.bgs_conv2d_workspace_bytes(N * Ho * Wo, Cout)      # split-K scratch (small-M layers)
     ws = _workspace(wsb, x.device) if wsb else None
     rc = lib.bgs_conv2d_nhwc_f32_ws(capi.ptr(x), capi.ptr(w_krsc), capi.ptr(bias),

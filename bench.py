@@ -325,17 +325,20 @@ def conv_roofline(dev, iters=20):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * 2 * 200 * 336 * 256 * 256 * 9
     tf = flops / (ms * 1e-3) / 1e12
+    halo = BF._use_halo_kernel(2 * 200 * 336, 256)
+    kname = 'conv3x3_halo_f32_kernel' if halo else 'conv_igemm_f32_kernel<2,2,16,1>'
     traffic = None
-    try:      # HBM-side bytes per launch from the committed PMC passes (profiles/r2d_pmc_conv.md)
+    try:      # HBM-side bytes per launch from the committed PMC passes (profiles/r3l_pmc_conv.md)
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
                                'pmc_traffic.json')) as f:
-            traffic = json.load(f)['conv_igemm_f32_kernel<2,2,16,1>'][
-                'fpn_p2_out_2x200x336_3x3_256_256']['traffic_bytes_per_launch']
+            traffic = json.load(f)[kname]['fpn_p2_out_2x200x336_3x3_256_256'][
+                'traffic_bytes_per_launch']
     except Exception:
         pass
     return dict(bound='mfma', achieved=round(tf, 2), peak=157.3, unit='TFLOP/s',
                 frac=round(tf / 157.3, 4), traffic=traffic,
-                kernel='conv_igemm_f32_kernel<2,2> (v_mfma_f32_32x32x2_f32)',
+                kernel=('conv3x3_halo_f32_kernel (halo-resident A operand, v_mfma_f32_32x32x2_f32)'
+                        if halo else 'conv_igemm_f32_kernel<2,2> (v_mfma_f32_32x32x2_f32)'),
                 ms_per_launch=round(ms, 4), flops_per_launch=flops,
                 layer='FPN output conv P2: N=2, 200x336, 3x3, 256->256 (M=134400, K=2304)',
                 timing='hipEvent over %d back-to-back launches' % iters)

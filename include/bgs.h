@@ -206,6 +206,14 @@ int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, float*
                               int W, int Cin, int Cout, int R, int S, int stride, int pad,
                               int accumulate, void* workspace, bgs_stream_t stream);
 
+/* EXPERIMENTAL (the host mirror uses it only with BGS_CONV_HALO=1): the 3x3 / stride 1 / pad 1
+ * case of bgs_conv2d_nhwc_f32 (same call sites: fpn.py:131-134 output convs, rpn_head.py:31 rpn_conv,
+ * resnet.py:244 conv2) with the workgroup's 8 x 16 output pixels + halo staged in LDS once per
+ * 16-channel chunk and reused by the nine taps.  y = act(conv(x, w) + bias);
+ * Cin % 16 == 0; no residual. */
+int bgs_conv3x3_halo_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int N,
+                              int H, int W, int Cin, int Cout, int relu, bgs_stream_t stream);
+
 /* Grouped 3x3 convolution (pad 1, stride 1 or 2) + bias + ReLU, NHWC: conv2 of the ResNeXt
  * bottleneck (mmdet/models/backbones/resnext.py:47-57, cfg 5 = X101-64x4d).  x [N,H,W,C],
  * w [C,3,3,C/groups] (output channel, tap, input channel within the group), bias [C] or NULL,

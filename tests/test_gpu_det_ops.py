@@ -4,6 +4,7 @@ linear, max pooling, multi-level RoIAlign, batched NMS — against the CPU oracl
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from balancedgroupsoftmax_amd import functional as BF
 from oracle import build_ref, det_oracle
@@ -346,6 +347,38 @@ def test_roi_align_autograd_accumulates_into_feature_grads():
         idx = np.nonzero(lv == i)[0]
         exp = det_oracle.roi_align_backward(ones[idx], rois[idx], 1.0 / s, feats[i].shape, 2)
         assert np.abs(ft[i].grad.cpu().numpy() - exp).max() <= 1e-4 * max(1.0, np.abs(exp).max())
+
+
+@pytest.mark.parametrize('shape', [(1, 8, 16, 16, 128, False), (2, 13, 21, 64, 256, True),
+                                   (1, 25, 42, 256, 200, True), (2, 50, 84, 32, 64, False),
+                                   (1, 3, 5, 48, 15, True), (1, 200, 513, 16, 128, True)])
+def test_conv3x3_halo_kernel_vs_torch_cpu(monkeypatch, shape):
+    """csrc/conv_halo.hip (input patch + halo staged in LDS once per channel chunk, shared by the
+    nine taps) == torch-CPU F.conv2d and == the general implicit-GEMM kernel: tiles that hang over
+    the image, Cout that is not a multiple of the 128-wide tile, one pixel tile only, and a
+    shape large enough (M >= 100000, Cout % 128 == 0) for the DEFAULT dispatch to choose it."""
+    N, H, W, Cin, Cout, relu = shape
+    rs = np.random.RandomState(H * 7 + Cin)
+    x = rs.randn(N, H, W, Cin).astype(np.float32)
+    w = (rs.randn(Cout, 3, 3, Cin) * 0.05).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32)
+    exp = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w).permute(0, 3, 1, 2),
+                   torch.from_numpy(b), padding=1)
+    if relu:
+        exp = exp.relu()
+    exp = exp.permute(0, 2, 3, 1)
+    tol = 2e-5 * float(exp.abs().max())
+    monkeypatch.setenv('BGS_CONV_HALO', '1')
+    got = BF.conv2d_nhwc(dev(x), dev(w), dev(b), pad=1, relu=relu)
+    assert float((got.cpu() - exp).abs().max()) <= tol
+    monkeypatch.setenv('BGS_CONV_HALO', '0')
+    gen = BF.conv2d_nhwc(dev(x), dev(w), dev(b), pad=1, relu=relu)
+    assert float((gen.cpu() - exp).abs().max()) <= tol
+    monkeypatch.delenv('BGS_CONV_HALO')
+    dflt = BF.conv2d_nhwc(dev(x), dev(w), dev(b), pad=1, relu=relu)
+    use_halo = BF._use_halo_kernel(N * H * W, Cout)
+    assert use_halo == (N * H * W >= 100000 and Cout % 128 == 0)
+    assert torch.equal(dflt, got if use_halo else gen)
 
 
 def test_conv_split_k_matches_single_pass(monkeypatch):

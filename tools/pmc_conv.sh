@@ -19,7 +19,7 @@ for C in ['FETCH_SIZE','WRITE_SIZE']:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(files[0])):
         name = r.get('Kernel_Name','')[:48]
-        if 'conv_igemm' in name:
+        if 'conv_igemm' in name or 'conv3x3_halo' in name:
             agg[(name, r.get('Grid_Size'), r.get('Counter_Name'))].append(float(r.get('Counter_Value', 0)))
     for k, v in agg.items():
         print(C, k, 'n=%d' % len(v), 'avg=%.1f' % (sum(v)/len(v)), 'min=%.1f' % min(v))
