@@ -1,5 +1,6 @@
-// EXPERIMENTAL (opt-in: BGS_CONV_HALO=1) — 3x3 / stride 1 / pad 1 implicit-GEMM convolution with
-// a halo-resident A operand, fp32 MFMA, NHWC, gfx950.  Design: DESIGN.md appendix A.
+// 3x3 / stride 1 / pad 1 implicit-GEMM convolution with a halo-resident A operand, fp32 MFMA,
+// NHWC, gfx950.  Design: DESIGN.md appendix A.  First version: used for the large-M layers
+// (functional._use_halo_kernel); BGS_CONV_HALO=0|1 overrides.
 //
 // The general kernel (conv_igemm.hip) fetches every input pixel once per filter tap: nine global
 // loads of a [pixels x BK] tile per channel chunk, 9x the input over the fabric

@@ -206,11 +206,12 @@ int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, float*
                               int W, int Cin, int Cout, int R, int S, int stride, int pad,
                               int accumulate, void* workspace, bgs_stream_t stream);
 
-/* EXPERIMENTAL (the host mirror uses it only with BGS_CONV_HALO=1): the 3x3 / stride 1 / pad 1
- * case of bgs_conv2d_nhwc_f32 (same call sites: fpn.py:131-134 output convs, rpn_head.py:31 rpn_conv,
- * resnet.py:244 conv2) with the workgroup's 8 x 16 output pixels + halo staged in LDS once per
- * 16-channel chunk and reused by the nine taps.  y = act(conv(x, w) + bias);
- * Cin % 16 == 0; no residual. */
+/* The 3x3 / stride 1 / pad 1 case of bgs_conv2d_nhwc_f32 (same call sites: fpn.py:131-134 output
+ * convs, rpn_head.py:31 rpn_conv, resnet.py:244 conv2) with the workgroup's 8 x 16 output pixels
+ * + halo staged in LDS once per 16-channel chunk and reused by the nine taps (DESIGN.md appendix
+ * A): 9x less input traffic.  y = act(conv(x, w) + bias); Cin % 16 == 0; no residual.  First
+ * version (fixed 128 x 128 tile, no split-K): the host mirror uses it where it is faster than the
+ * general kernel — M >= 100000 output pixels and Cout % 128 == 0 (BGS_CONV_HALO=0|1 overrides). */
 int bgs_conv3x3_halo_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int N,
                               int H, int W, int Cin, int Cout, int relu, bgs_stream_t stream);
 
