@@ -133,3 +133,17 @@ def test_reference_module_checkpoint_loads_into_the_detector(tmp_path):
     assert [m[0] for m in rep['mismatched']] == ['bbox_head.fc_cls.weight', 'bbox_head.fc_cls.bias']
     assert all(k.startswith('bbox_head.') for k in rep['missing'])
     assert torch.equal(model.backbone.layer3[2].conv2.weight, sd['backbone.layer3.2.conv2.weight'])
+
+
+def test_halo_kernel_dispatch_policy(monkeypatch):
+    """``functional._use_halo_kernel``: the halo-resident 3x3 kernel is chosen for the large-M
+    layers whose Cout fills its 128-wide tile; BGS_CONV_HALO=0|1 overrides (tuning / A-B runs)."""
+    from balancedgroupsoftmax_amd import functional as BF
+    monkeypatch.delenv('BGS_CONV_HALO', raising=False)
+    assert BF._use_halo_kernel(2 * 200 * 336, 256)          # FPN output conv / RPN conv on P2
+    assert not BF._use_halo_kernel(2 * 100 * 168, 256)      # P3: the general kernel is faster
+    assert not BF._use_halo_kernel(2 * 200 * 336, 64)       # layer1 conv2: half the tile would idle
+    monkeypatch.setenv('BGS_CONV_HALO', '0')
+    assert not BF._use_halo_kernel(2 * 200 * 336, 256)
+    monkeypatch.setenv('BGS_CONV_HALO', '1')
+    assert BF._use_halo_kernel(10, 15)
