@@ -1,0 +1,116 @@
+// Shared by the implicit-GEMM convolution kernels (conv_igemm.hip: fp32 MFMA; conv_bfx.hip: bf16
+// MFMA on split operands): the argument block and the fused epilogue.
+#pragma once
+
+#include "bgs_common.h"
+
+namespace bgs_conv {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+// LDS row = [k even: 8 floats][k odd: 8 floats][4 pad] = 20 floats.  The A/B fragment of
+// v_mfma_f32_32x32x2_f32 wants, in lane l, k = 2*kk + (l >> 5) for kk = 0..7: lanes 0-31 need
+// the even k of their row and lanes 32-63 the odd k — 8 contiguous floats each, fetched with two
+// ds_read_b128 per K tile (instead of 8 ds_read_b32: the 64x64 tile was LDS-bandwidth bound).
+// Stride 20 floats makes the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots.
+// (BK = 16: stride 20 floats; BK = 32: stride 36 floats — both spread 16 consecutive rows over
+// 16 distinct 16-byte slots of the 256-byte bank row.)
+
+struct ConvArgs {
+  const float* x;     // [N, H, W, Cin]
+  const float* w;     // [Cout, R, S, Cin]
+  const float* bias;  // [Cout] or null
+  const float* res;   // residual or null: [N, Ho, Wo, Cout] (mode 1) / [N, Ho/2, Wo/2, Cout] (mode 2:
+                      // nearest-2x upsampled) / [N, 2Ho, 2Wo, Cout] (mode 3: 2x2 sum-pooled)
+  const float* mask;  // null, or [N, Ho, Wo, Cout]: y = mask > 0 ? y : 0 (ReLU backward)
+  float* y;           // [N, Ho, Wo, Cout]
+  int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
+  int M, K;           // M = N*Ho*Wo, K = R*S*Cin
+  int relu, res_mode;
+  // split-K (small-M layers expose too few workgroups to fill 256 CUs): gridDim.z slices of
+  // `kt_per_split` K tiles each write raw partial sums to partial[z][M][Cout]; the epilogue
+  // (bias / residual / ReLU / mask) then runs in conv_splitk_epilogue_kernel.
+  float* partial;
+  int kt_per_split;
+  // XCD-aware tile order: the launch is 1-D; workgroup b runs on XCD b % 8 (round-robin dispatch),
+  // and is given tile (b % 8) * chunk + b / 8 — every XCD walks its own contiguous band of the
+  // image, with the Cout tiles of one pixel tile back to back, so the 3x3 halo rows and the
+  // re-read of the same pixels for the next Cout tile hit that XCD's L2 (PMC: 2.46 GB fetched per
+  // 158-GFLOP layer before, profiles/r2d_pmc_conv.md).
+  int tiles_m, tiles_n, chunk;
+};
+
+// Fused epilogue of a (64*MB) x (64*NB) workgroup tile held as MB x NB accumulators of the 32x32
+// MFMA per wave (2 x 2 waves).  C/D layout of every 32x32 MFMA on gfx950 (dtype-independent):
+// col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int MB, int NB>
+__device__ __forceinline__ void conv_store_tile(const ConvArgs& p, const f32x16 (&acc)[MB][NB],
+                                                int m0, int n0, int wm, int wn, int lane) {
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (p.partial) {
+    float* part = p.partial + (size_t)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m0 + wm * 32 * MB + a * 32 + i;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int j = n0 + wn * 32 * NB + b * 32 + (lane & 31);
+          if (j < p.Cout) part[(size_t)m * p.Cout + j] = acc[a][b][r];
+        }
+      }
+    return;
+  }
+  const int hw = p.Ho * p.Wo;
+#pragma unroll
+  for (int a = 0; a < MB; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int m = m0 + wm * 32 * MB + a * 32 + i;
+      if (m >= p.M) continue;
+      size_t res_row = 0;
+      if (p.res_mode == 1) {
+        res_row = (size_t)m * p.Cout;
+      } else if (p.res_mode == 2) {
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        const int ho = rem / p.Wo, wo = rem - (rem / p.Wo) * p.Wo;
+        res_row = (((size_t)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout;
+      } else if (p.res_mode == 3) {
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        const int ho = rem / p.Wo, wo = rem - (rem / p.Wo) * p.Wo;
+        res_row = (((size_t)n * (p.Ho * 2) + ho * 2) * (p.Wo * 2) + wo * 2) * p.Cout;
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int j = n0 + wn * 32 * NB + b * 32 + (lane & 31);
+        if (j >= p.Cout) continue;
+        float v = acc[a][b][r];
+        if (p.bias) v += p.bias[j];
+        if (p.res_mode == 3) {
+          const size_t down = (size_t)p.Wo * 2 * p.Cout;
+          v += (p.res[res_row + j] + p.res[res_row + p.Cout + j]) +
+               (p.res[res_row + down + j] + p.res[res_row + down + p.Cout + j]);
+        } else if (p.res_mode) {
+          v += p.res[res_row + j];
+        }
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.mask) v = p.mask[(size_t)m * p.Cout + j] > 0.f ? v : 0.f;
+        p.y[(size_t)m * p.Cout + j] = v;
+      }
+    }
+  }
+}
+
+}  // namespace bgs_conv
+
+// split-K reduction + epilogue launch (defined in conv_igemm.hip)
+int bgs_internal_conv_splitk_epilogue(bgs_conv::ConvArgs& p, int splits, hipStream_t st);

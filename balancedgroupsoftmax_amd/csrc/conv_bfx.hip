@@ -1,0 +1,750 @@
+// Implicit-GEMM convolution / linear layer on the bf16 matrix cores of gfx950 (MI355X) with
+// fp32-faithful results: "bf16x6" operand splitting.
+//
+// Same contract as conv_igemm.hip (the layers the reference delegates to cuDNN / cuBLAS:
+// mmdet/models/backbones/resnet.py:220-266, necks/fpn.py:101-141, anchor_heads/rpn_head.py:30-35,
+// bbox_heads/convfc_bbox_head.py:132-168): fp32 NHWC activations in, fp32 out, fp32 accumulate.
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate (157 vs 2500 TFLOP/s).  An fp32
+// value x is EXACTLY  hi + mid + lo + e,  hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)
+// (round-to-nearest-even; the subtractions are exact in fp32), |e| <= 2^-27 |x|.  The product
+// a*b is then the sum of nine bf16 x bf16 products, each EXACT in the fp32 accumulator of
+// v_mfma_f32_32x32x16_bf16; the six with i + j <= 2 are kept, the three dropped ones are
+// <= 2^-25 |a b| — below fp32 rounding (2^-24).  Six bf16 MFMAs replace eight fp32 MFMA steps of
+// 1/8 the K depth: 6/16 of the matrix-pipe time, the same (or smaller) error against an fp64
+// reference as the fp32 MFMA kernel (tests/test_gpu_det_ops.py::test_bfx_error_not_above_f32_mfma).
+//
+//   * weights are split ONCE on the device (bgs_conv_bfx_split_weights) into three bf16 planes laid
+//     out [plane][K/16][Cout][16]: the B slice of a K step is one contiguous, fully coalesced run;
+//   * activations stay fp32 in HBM (nothing else in the detector changes); the A tile is split
+//     in registers on its way to LDS (5.5 VALU ops per element, hidden under the 24 MFMAs of a
+//     K step);
+//   * workgroup = 4 waves (2 x 2), wave tile MB x NB blocks of 32 x 32, BK = 16 (one bf16 MFMA K
+//     step); LDS rows are 32 B of data + 16 B pad (stride 3 x 16 B: the four 16-lane groups of
+//     ds_read_b128 hit 16 distinct slots); double-buffered, one barrier per K step;
+//   * epilogue, split-K and the XCD-banded tile order are those of conv_igemm.hip (conv_args.h).
+#include <stdlib.h>
+
+#include "conv_args.h"
+
+using namespace bgs_conv;
+
+namespace {
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct BfxArgs {
+  ConvArgs c;
+  const __bf16* ws;      // split weights [NS][KC][Cout][16]
+  int KC;                // ceil(K / 16)
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);   // v_cvt_pk_bf16_f32 (RNE)
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) {
+  return __builtin_bit_cast(float, u & 0xffff0000u);
+}
+
+// x (4 consecutive k) -> three planes of 4 packed bf16 each
+__device__ __forceinline__ void split3(const f32x4 v, u32x2& hi, u32x2& mid, u32x2& lo) {
+  hi = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+  const f32x4 r = {v[0] - bf16_lo(hi[0]), v[1] - bf16_hi(hi[0]), v[2] - bf16_lo(hi[1]),
+                   v[3] - bf16_hi(hi[1])};
+  mid = u32x2{pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3])};
+  const f32x4 r2 = {r[0] - bf16_lo(mid[0]), r[1] - bf16_hi(mid[0]), r[2] - bf16_lo(mid[1]),
+                    r[3] - bf16_hi(mid[1])};
+  lo = u32x2{pack_bf16(r2[0], r2[1]), pack_bf16(r2[2], r2[3])};
+}
+
+
+// NS = 3: fp32-faithful (six products).  NS = 2: hi/mid only, three products (error ~2^-17: a
+// tuning / ablation arm, not used by the detector).  UP as in conv_igemm.hip.
+// BK = 16 or 32 (k depth staged per barrier).
+template <int MB, int NB, int BK, int NS, int UP>
+__global__ __launch_bounds__(kThreads, 2) void conv_igemm_bfx_kernel(BfxArgs q) {
+  const ConvArgs& p = q.c;
+  constexpr int BM = 64 * MB, BN = 64 * NB;
+  constexpr int KS = BK / 16;            // bf16 MFMA K steps per staged tile
+  constexpr int LDR = BK * 2 + 16;       // LDS row stride in bytes: 48 / 80 (odd multiples of 16)
+  constexpr int KQ = BK / 4;             // fp32 quads per A row per K step
+  constexpr int RP = kThreads / KQ;      // A rows staged per pass
+  constexpr int PA = BM / RP;
+  constexpr int NPIECE = NS * KS * BN * 2;   // 16-byte pieces of the B tile (all planes)
+  constexpr int PB = (NPIECE + kThreads - 1) / kThreads;
+  constexpr int A_PLANE = BM * LDR, B_PLANE = BN * LDR;
+  constexpr int BUF = NS * (A_PLANE + B_PLANE);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int vtile = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if (vtile >= p.tiles_m * p.tiles_n) return;          // workgroup-uniform
+  const int m0 = (vtile / p.tiles_n) * BM, n0 = (vtile % p.tiles_n) * BN;
+
+  // ---- A staging role: 4 consecutive k (one 16-byte load) of rows srow + RP*pass
+  const int kq = tid % KQ;
+  const int srow = tid / KQ;
+  int a_hi0[PA], a_wi0[PA];
+  const float* a_base[PA];
+  bool a_ok[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int m = m0 + srow + RP * i;
+    a_ok[i] = m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    const int hw = p.Ho * p.Wo;
+    const int n = mm / hw;
+    const int rem = mm - n * hw;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    a_hi0[i] = ho * p.stride - p.pad;
+    a_wi0[i] = wo * p.stride - p.pad;
+    a_base[i] = p.x + (size_t)n * p.H * p.W * p.Cin;
+  }
+  // ---- B staging role: piece id = tid + 256*i -> (plane, row, half)
+  const __bf16* b_src[PB];
+  int b_dst[PB];
+  bool b_use[PB], b_ok[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int id = tid + kThreads * i;
+    b_use[i] = id < NPIECE;
+    const int idc = b_use[i] ? id : 0;
+    const int plane = idc / (KS * BN * 2);
+    const int rem0 = idc - plane * (KS * BN * 2);
+    const int ch = rem0 / (BN * 2);
+    const int rem = rem0 - ch * (BN * 2);
+    const int row = rem >> 1, half = rem & 1;
+    b_ok[i] = b_use[i] && (n0 + row < p.Cout);
+    b_src[i] = q.ws + (((size_t)plane * q.KC + ch) * p.Cout + (b_ok[i] ? n0 + row : 0)) * 16 + half * 8;
+    b_dst[i] = NS * A_PLANE + plane * B_PLANE + row * LDR + ch * 32 + half * 16;
+  }
+
+  const int nk_all = q.KC / KS;          // KC is a multiple of 2 (zero-padded planes); KS = 1 here
+  const int kt_begin = p.partial ? blockIdx.z * p.kt_per_split : 0;
+  const int kt_end = p.partial ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
+  int kt_load = kt_begin;
+  int kg = kt_begin * BK + kq * 4;
+  int kc, kr, ks;
+  {
+    const int rs = kg / p.Cin;
+    kc = kg - rs * p.Cin;
+    kr = rs / p.S;
+    ks = rs - kr * p.S;
+  }
+
+  f32x4 ra[PA];
+  u32x4 rb[PB];
+  auto load_tile = [&]() {
+    const bool kok = kg < p.K;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      int hi = a_hi0[i] + kr, wi = a_wi0[i] + ks;
+      bool ok = a_ok[i] && kok && hi >= 0 && wi >= 0;
+      if (UP == 2) {
+        ok = ok && !((hi | wi) & 1);
+        hi >>= 1;
+        wi >>= 1;
+      }
+      ok = ok && hi < p.H && wi < p.W;
+      ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok)
+        ra[i] = *reinterpret_cast<const f32x4*>(a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + kc);
+    }
+    const size_t koff = (size_t)kt_load * KS * p.Cout * 16;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      rb[i] = u32x4{0u, 0u, 0u, 0u};
+      if (b_ok[i]) rb[i] = *reinterpret_cast<const u32x4*>(b_src[i] + koff);
+    }
+    ++kt_load;
+    kg += BK;
+    kc += BK;
+    while (kc >= p.Cin) {
+      kc -= p.Cin;
+      if (++ks == p.S) {
+        ks = 0;
+        ++kr;
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* base = lds + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      u32x2 h, m, l;
+      split3(ra[i], h, m, l);
+      unsigned char* d = base + (srow + RP * i) * LDR + kq * 8;
+      *reinterpret_cast<u32x2*>(d) = h;
+      if (NS >= 2) *reinterpret_cast<u32x2*>(d + A_PLANE) = m;
+      if (NS >= 3) *reinterpret_cast<u32x2*>(d + 2 * A_PLANE) = l;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      if (b_use[i]) *reinterpret_cast<u32x4*>(base + b_dst[i]) = rb[i];
+  };
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int frow = lane & 31, fk = lane >> 5;
+  const int a_frag = (wm * 32 * MB + frow) * LDR + fk * 16;
+  const int b_frag = NS * A_PLANE + (wn * 32 * NB + frow) * LDR + fk * 16;
+
+  const int nk = kt_end - kt_begin;
+  load_tile();
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) load_tile();            // global loads of tile kt+1 in flight under the MFMAs
+    const unsigned char* base = lds + buf * BUF;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      bf16x8 fa[NS][MB], fb[NS][NB];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int a = 0; a < MB; ++a)
+          fa[s][a] = *reinterpret_cast<const bf16x8*>(base + a_frag + s * A_PLANE + a * 32 * LDR + s2 * 32);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          fb[s][b] = *reinterpret_cast<const bf16x8*>(base + b_frag + s * B_PLANE + b * 32 * LDR + s2 * 32);
+      }
+      // products (i, j) with i + j <= NS - 1, smallest terms first; the MB x NB accumulators
+      // interleave, so consecutive MFMAs are independent
+#pragma unroll
+      for (int t = NS - 1; t >= 0; --t)
+#pragma unroll
+        for (int i = 0; i <= t; ++i)
+#pragma unroll
+          for (int a = 0; a < MB; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[t - i][b], acc[a][b],
+                                                                  0, 0, 0);
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  conv_store_tile<MB, NB>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// w [rows][K] fp32 -> out [NS][KC][rows][16] bf16 planes (zero-padded K tail)
+__global__ __launch_bounds__(256) void bfx_split_weights_kernel(const float* __restrict__ w,
+                                                                __bf16* __restrict__ out, int rows,
+                                                                int K, int KC, int NS) {
+  const size_t total = (size_t)KC * rows * 8;          // bf16 pairs per plane
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * 256) {
+    const int kk = (int)(e & 7) * 2;
+    const size_t t = e >> 3;
+    const int row = (int)(t % rows);
+    const int kc = (int)(t / rows);
+    const int k = kc * 16 + kk;
+    const float v0 = k < K ? w[(size_t)row * K + k] : 0.f;
+    const float v1 = k + 1 < K ? w[(size_t)row * K + k + 1] : 0.f;
+    const unsigned h = pack_bf16(v0, v1);
+    const float r0 = v0 - bf16_lo(h), r1 = v1 - bf16_hi(h);
+    const unsigned m = pack_bf16(r0, r1);
+    const unsigned l = pack_bf16(r0 - bf16_lo(m), r1 - bf16_hi(m));
+    unsigned* o = reinterpret_cast<unsigned*>(out) + e;
+    o[0] = h;
+    if (NS >= 2) o[total] = m;
+    if (NS >= 3) o[2 * total] = l;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 with a halo-resident A operand (the structure of conv_halo.hip, DESIGN.md
+// appendix A) on split operands: the workgroup's 8 x 16 output pixels plus halo (10 x 18 pixels x
+// 16 channels) are split ONCE per channel chunk into three bf16 planes in LDS and shared by the
+// nine taps — the split cost and the A traffic drop 9x; only the pre-split filter slice streams
+// per tap (contiguous 4 KB runs per plane).  A is single-buffered (one extra barrier per chunk),
+// B double-buffered: 62.8 KB of LDS -> two workgroups per CU.  gridDim.z slices the channel chunks
+// (split-K for the small maps); partial slabs go through the shared split-K epilogue.
+constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, PROWS = PH * PW;   // 180 patch pixels
+constexpr int HLDR = 48;                                                    // LDS row stride, bytes
+constexpr int AQ = PROWS * 4;                                               // fp32 quads per patch
+constexpr int AQT = (AQ + kThreads - 1) / kThreads;                         // 3 per thread
+
+struct HaloBfxArgs {
+  ConvArgs c;            // x, bias, y, N, H, W, Cin, Cout, relu, M, partial, tiles_m/n, chunk
+  const __bf16* ws;      // split weights [3][KC][Cout][16], K = 9 * Cin
+  int KC;
+  int tiles_y, tiles_x;
+  int chunks_per_split;  // channel chunks per gridDim.z slice
+};
+
+template <int NB>
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx_kernel(HaloBfxArgs q) {
+  const ConvArgs& p = q.c;
+  constexpr int BN = 64 * NB;
+  constexpr int A_PLANE = PROWS * HLDR, B_PLANE = BN * HLDR;
+  constexpr int A_BYTES = 3 * A_PLANE, B_BUF = 3 * B_PLANE;
+  constexpr int NPIECE = 3 * BN * 2;
+  constexpr int PB = (NPIECE + kThreads - 1) / kThreads;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[A_BYTES + 2 * B_BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int vtile = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if (vtile >= p.tiles_m * p.tiles_n) return;                  // workgroup-uniform
+  const int tm = vtile / p.tiles_n, tn = vtile - tm * p.tiles_n;
+  const int n = tm / (q.tiles_y * q.tiles_x);
+  const int trem = tm - n * (q.tiles_y * q.tiles_x);
+  const int ty = trem / q.tiles_x, tx = trem - ty * q.tiles_x;
+  const int h0 = ty * TH - 1, w0 = tx * TW - 1;                // input coords of patch (0, 0)
+  const int n0 = tn * BN;
+  const int cchunks = p.Cin / 16;
+  const int c_begin = p.partial ? blockIdx.z * q.chunks_per_split : 0;
+  const int c_end = p.partial ? min(cchunks, c_begin + q.chunks_per_split) : cchunks;
+
+  // ---- staging roles.  A: patch quads idx = tid + 256 i; prow = idx / 4, kq = idx % 4
+  const float* a_src[AQT];
+  int a_dst[AQT];
+  bool a_use[AQT], a_in[AQT];
+#pragma unroll
+  for (int i = 0; i < AQT; ++i) {
+    const int idx = tid + kThreads * i;
+    a_use[i] = idx < AQ;
+    const int prow = a_use[i] ? idx >> 2 : 0, kq = idx & 3;
+    const int pr = prow / PW, pc = prow - pr * PW;
+    const int hi = h0 + pr, wi = w0 + pc;
+    a_in[i] = a_use[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+    a_src[i] = p.x + (((size_t)n * p.H + (a_in[i] ? hi : 0)) * p.W + (a_in[i] ? wi : 0)) * p.Cin + kq * 4;
+    a_dst[i] = prow * HLDR + kq * 8;
+  }
+  // B: piece id = tid + 256 i -> (plane, row, half)
+  const __bf16* b_src[PB];
+  int b_dst[PB];
+  bool b_use[PB], b_ok[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int id = tid + kThreads * i;
+    b_use[i] = id < NPIECE;
+    const int idc = b_use[i] ? id : 0;
+    const int plane = idc / (BN * 2);
+    const int rem = idc - plane * (BN * 2);
+    const int row = rem >> 1, half = rem & 1;
+    b_ok[i] = b_use[i] && (n0 + row < p.Cout);
+    b_src[i] = q.ws + ((size_t)plane * q.KC * p.Cout + (b_ok[i] ? n0 + row : 0)) * 16 + half * 8;
+    b_dst[i] = A_BYTES + plane * B_PLANE + row * HLDR + half * 16;
+  }
+
+  f32x4 ra[AQT];
+  u32x4 rb[PB];
+  auto load_a = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < AQT; ++i) {
+      ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a_in[i]) ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + chunk * 16);
+    }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < AQT; ++i) {
+      if (!a_use[i]) continue;
+      u32x2 h, m, l;
+      split3(ra[i], h, m, l);
+      unsigned char* d = lds + a_dst[i];
+      *reinterpret_cast<u32x2*>(d) = h;
+      *reinterpret_cast<u32x2*>(d + A_PLANE) = m;
+      *reinterpret_cast<u32x2*>(d + 2 * A_PLANE) = l;
+    }
+  };
+  auto load_b = [&](int chunk, int tap) {
+    const size_t koff = (size_t)(tap * cchunks + chunk) * p.Cout * 16;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      rb[i] = u32x4{0u, 0u, 0u, 0u};
+      if (b_ok[i]) rb[i] = *reinterpret_cast<const u32x4*>(b_src[i] + koff);
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      if (b_use[i]) *reinterpret_cast<u32x4*>(lds + buf * B_BUF + b_dst[i]) = rb[i];
+  };
+
+  // ---- fragment roles: lane frow of sub-tile a owns pixel m = 64 wm + 32 a + frow
+  const int frow = lane & 31, fk = lane >> 5;
+  int a_frag[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int m = wm * 64 + a * 32 + frow;
+    a_frag[a] = ((m >> 4) * PW + (m & 15)) * HLDR + fk * 16;      // patch row of tap (0, 0)
+  }
+  const int b_frag = A_BYTES + (wn * 32 * NB + frow) * HLDR + fk * 16;
+
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nsteps = (c_end - c_begin) * 9;
+  load_a(c_begin);
+  load_b(c_begin, 0);
+  store_a();
+  store_b(0);
+  __syncthreads();
+  int chunk = c_begin, tap = 0;
+  for (int t = 0; t < nsteps; ++t) {
+    const int bbuf = t & 1;
+    const bool more = t + 1 < nsteps;
+    int nchunk = chunk, ntap = tap + 1;
+    if (ntap == 9) {
+      ntap = 0;
+      ++nchunk;
+    }
+    if (more) load_b(nchunk, ntap);                             // next filter slice in flight
+    const bool next_a = tap == 0 && chunk + 1 < c_end;
+    if (next_a) load_a(chunk + 1);                              // next patch: held in registers
+
+    const int tap_off = ((tap / 3) * PW + (tap % 3)) * HLDR;
+    bf16x8 fa[3][2], fb[3][NB];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a] + tap_off + s * A_PLANE);
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        fb[s][b] = *reinterpret_cast<const bf16x8*>(lds + bbuf * B_BUF + b_frag + s * B_PLANE + b * 32 * HLDR);
+    }
+#pragma unroll
+    for (int tt = 2; tt >= 0; --tt)
+#pragma unroll
+      for (int i = 0; i <= tt; ++i)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[tt - i][b], acc[a][b],
+                                                                0, 0, 0);
+    if (more) store_b(bbuf ^ 1);
+    __syncthreads();
+    if (tap == 8 && chunk + 1 < c_end) {                        // every wave is done with patch `chunk`
+      store_a();
+      __syncthreads();
+    }
+    tap = ntap;
+    chunk = nchunk;
+  }
+
+  // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  float* part = p.partial ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : nullptr;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int m = wm * 64 + a * 32 + i;
+      const int ho = ty * TH + (m >> 4), wo = tx * TW + (m & 15);
+      if (ho >= p.H || wo >= p.W) continue;
+      const size_t row = (((size_t)n * p.H + ho) * p.W + wo) * p.Cout;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int j = n0 + wn * 32 * NB + b * 32 + (lane & 31);
+        if (j >= p.Cout) continue;
+        float v = acc[a][b][r];
+        if (part) {
+          part[row + j] = v;
+        } else {
+          if (p.bias) v += p.bias[j];
+          if (p.relu) v = fmaxf(v, 0.f);
+          p.y[row + j] = v;
+        }
+      }
+    }
+  }
+}
+
+int g_halo_last_nb = 0, g_halo_last_splits = 0;
+int g_halo_force_splits = -1;
+
+int halo_bfx_plan(long long M, int tiles_m, int Cin, int Cout, int& nb) {
+  nb = Cout <= 64 ? 1 : 2;
+  const int tiles_n = (Cout + 64 * nb - 1) / (64 * nb);
+  const long long wgs = (long long)tiles_m * tiles_n;
+  const int cchunks = Cin / 16;
+  // measured (profiles/r2a_bfx_sweep.txt): 263 workgroups -> 4 slices, 526 -> 4, 2100 -> 1
+  int want = 1;
+  if (wgs < 1500) want = (int)((2047 + wgs) / wgs);
+  if (want > cchunks / 2) want = cchunks / 2;
+  if (want > 8) want = 8;
+  if (g_halo_force_splits >= 1) want = g_halo_force_splits < cchunks ? g_halo_force_splits : cchunks;
+  if (want < 1) want = 1;
+  return want;
+}
+
+struct BfxKnobs {
+  int tile = 0, splitk = -1;
+  BfxKnobs() {
+    if (const char* e = getenv("BGS_BFX_TILE")) tile = atoi(e);
+    if (const char* e = getenv("BGS_BFX_SPLITK")) splitk = atoi(e);
+  }
+};
+BfxKnobs& bfx_knobs() {
+  static BfxKnobs k;
+  return k;
+}
+int g_last_tile = 0, g_last_splits = 0;
+
+// tile (MB*10 + NB), K depth per barrier and split-K factor for a layer
+void bfx_plan(long long M, int Cout, int KC, int& tile, int& bk, int& want) {
+  const BfxKnobs& knobs = bfx_knobs();
+  // measured on the cfg[1] shapes (profiles/r2a_bfx_sweep.txt): the 64x64 tile wins or ties on
+  // every conv layer (these K steps are short: 6 MFMAs per wave per barrier, the grid matters more
+  // than the tile); 128x128 only for the very deep reductions (fc1: K = 12544, 0.183 vs 0.253 ms)
+  tile = (KC >= 512 && Cout >= 256) ? 22 : 11;
+  if (knobs.tile == 22 || knobs.tile == 21 || knobs.tile == 12 || knobs.tile == 11) tile = knobs.tile;
+  bk = 16;
+  const int bm = tile / 10 * 64, bn = tile % 10 * 64;
+  const long long wgs = ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn);
+  const int nk = KC;
+  want = 1;
+  if (wgs < 600) want = (int)((1100 + wgs - 1) / wgs);
+  else if (wgs < 1500) want = 2;
+  if (want > nk / 8) want = nk / 8;
+  if (want > 8) want = 8;
+  if (knobs.splitk >= 1 && knobs.splitk <= 16) want = knobs.splitk < nk ? knobs.splitk : nk;
+  if (want < 1) want = 1;
+}
+
+int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t workspace_bytes) {
+  ConvArgs& p = q.c;
+  const BfxKnobs& knobs = bfx_knobs();
+  const long long M = p.M;
+  int tile, bk, want;
+  bfx_plan(M, p.Cout, q.KC, tile, bk, want);
+  const int bm = tile / 10 * 64, bn = tile % 10 * 64;
+  int splits = 1;
+  p.partial = nullptr;
+  p.kt_per_split = 0;
+  if (!workspace) want = 1;
+  while (want > 1 && (size_t)want * (size_t)M * p.Cout * sizeof(float) > workspace_bytes) --want;
+  if (want > 1) {
+    const int nk = q.KC;
+    p.kt_per_split = (nk + want - 1) / want;
+    splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
+    p.partial = reinterpret_cast<float*>(workspace);
+  }
+  p.tiles_m = (int)((M + bm - 1) / bm);
+  p.tiles_n = (p.Cout + bn - 1) / bn;
+  p.chunk = (p.tiles_m * p.tiles_n + 7) / 8;
+  dim3 grid((unsigned)(8 * p.chunk), 1u, (unsigned)splits);
+  g_last_tile = tile;
+  g_last_splits = splits;
+#define BFX_L(MB_, NB_, UP_) \
+  hipLaunchKernelGGL((conv_igemm_bfx_kernel<MB_, NB_, 16, 3, UP_>), grid, dim3(kThreads), 0, st, q)
+#define BFX_T(MB_, NB_) \
+  do { if (up == 2) BFX_L(MB_, NB_, 2); else BFX_L(MB_, NB_, 1); } while (0)
+  if (tile == 22) BFX_T(2, 2);
+  else if (tile == 21) BFX_T(2, 1);
+  else if (tile == 12) BFX_T(1, 2);
+  else BFX_T(1, 1);
+#undef BFX_T
+#undef BFX_L
+  if (splits > 1) {
+    if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
+    return bgs_internal_conv_splitk_epilogue(p, splits, st);
+  }
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+inline int bfx_kc(int K) { return 2 * ((K + 31) / 32); }
+
+}  // namespace
+
+extern "C" size_t bgs_conv_bfx_weight_bytes(int rows, int K) {
+  if (rows <= 0 || K <= 0) return 0;
+  return (size_t)3 * bfx_kc(K) * rows * 16 * sizeof(__bf16);
+}
+
+extern "C" int bgs_conv_bfx_split_weights(const float* w, void* out, int rows, int K,
+                                          bgs_stream_t stream) {
+  if (!w || !out || rows <= 0 || K <= 0) return BGS_ERR_INVALID_ARG;
+  if ((uintptr_t)out % 16 != 0) return BGS_ERR_INVALID_ARG;
+  const int KC = bfx_kc(K);
+  const size_t total = (size_t)KC * rows * 8;
+  size_t g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(bfx_split_weights_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                     w, reinterpret_cast<__bf16*>(out), rows, K, KC, 3);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" size_t bgs_conv_bfx_workspace_bytes(long long M, int Cout, int K) {
+  if (M <= 0 || Cout <= 0 || K <= 0) return 0;
+  int tile, bk, want;
+  bfx_plan(M, Cout, bfx_kc(K), tile, bk, want);
+  return want > 1 ? (size_t)want * (size_t)M * Cout * sizeof(float) : 0;
+}
+
+// tuning / test hook: tile 0 = auto | 11 | 12 | 21 | 22; splitk -1 = auto | 1..16.
+// Process-wide; not for concurrent use.
+extern "C" void bgs_conv_bfx_tuning(int tile, int splitk) {
+  BfxKnobs& k = bfx_knobs();
+  k.tile = tile;
+  k.splitk = splitk;
+}
+
+extern "C" int bgs_conv_bfx_last_launch(int* tile, int* splits) {
+  if (tile) *tile = g_last_tile;
+  if (splits) *splits = g_last_splits;
+  return BGS_OK;
+}
+
+extern "C" int bgs_conv2d_nhwc_f32_bfx_ws(const float* x, const void* wsplit, const float* bias,
+                                          const float* residual, float* y, int N, int H, int W,
+                                          int Cin, int Cout, int R, int S, int stride, int pad,
+                                          int relu, int residual_mode, void* workspace,
+                                          size_t workspace_bytes, bgs_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
+      pad < 0)
+    return BGS_ERR_INVALID_ARG;
+  if (!x || !wsplit || !y) return BGS_ERR_INVALID_ARG;
+  if (Cin % 4 != 0) return BGS_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)wsplit) % 16 != 0) return BGS_ERR_INVALID_ARG;
+  if (residual_mode < 0 || residual_mode > 2 || (residual_mode != 0 && !residual))
+    return BGS_ERR_INVALID_ARG;
+  BfxArgs q;
+  ConvArgs& p = q.c;
+  p.x = x; p.w = nullptr; p.bias = bias; p.res = residual; p.mask = nullptr; p.y = y;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S;
+  p.stride = stride; p.pad = pad;
+  p.Ho = (H + 2 * pad - R) / stride + 1;
+  p.Wo = (W + 2 * pad - S) / stride + 1;
+  if (p.Ho <= 0 || p.Wo <= 0) return BGS_ERR_INVALID_ARG;
+  if (residual_mode == 2 && ((p.Ho & 1) || (p.Wo & 1))) return BGS_ERR_INVALID_ARG;
+  const long long M = (long long)N * p.Ho * p.Wo;
+  if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  p.M = (int)M;
+  p.K = R * S * Cin;
+  p.relu = relu;
+  p.res_mode = residual_mode;
+  q.ws = reinterpret_cast<const __bf16*>(wsplit);
+  q.KC = bfx_kc(p.K);
+  return launch_conv_bfx(q, 1, (hipStream_t)stream, workspace, workspace_bytes);
+}
+
+// Data gradient (see bgs_conv2d_dgrad_nhwc_f32_ws): wt_split = split of the flipped, transposed
+// filter [Cin][R][S][Cout] (rows = Cin, K = R*S*Cout).
+extern "C" int bgs_conv2d_dgrad_nhwc_f32_bfx_ws(const float* dy, const void* wt_split,
+                                                const float* residual, const float* mask, float* dx,
+                                                int N, int H, int W, int Cin, int Cout, int R, int S,
+                                                int stride, int pad, int residual_mode,
+                                                void* workspace, size_t workspace_bytes,
+                                                bgs_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || pad < 0)
+    return BGS_ERR_INVALID_ARG;
+  if (!dy || !wt_split || !dx) return BGS_ERR_INVALID_ARG;
+  if (stride != 1 && stride != 2) return BGS_ERR_UNSUPPORTED;
+  if (Cout % 4 != 0) return BGS_ERR_UNSUPPORTED;
+  if (((uintptr_t)dy | (uintptr_t)wt_split) % 16 != 0) return BGS_ERR_INVALID_ARG;
+  if (!(residual_mode == 0 || residual_mode == 1 || residual_mode == 3) ||
+      (residual_mode != 0 && !residual))
+    return BGS_ERR_INVALID_ARG;
+  if (R != S || R - 1 - pad < 0) return BGS_ERR_UNSUPPORTED;
+  const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return BGS_ERR_INVALID_ARG;
+  BfxArgs q;
+  ConvArgs& p = q.c;
+  p.x = dy; p.w = nullptr; p.bias = nullptr; p.res = residual; p.mask = mask; p.y = dx;
+  p.N = N; p.H = Ho; p.W = Wo; p.Cin = Cout; p.Cout = Cin; p.R = R; p.S = S;
+  p.stride = 1; p.pad = R - 1 - pad;
+  p.Ho = H; p.Wo = W;
+  const long long M = (long long)N * H * W;
+  if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  p.M = (int)M;
+  p.K = R * S * Cout;
+  p.relu = 0;
+  p.res_mode = residual_mode;
+  q.ws = reinterpret_cast<const __bf16*>(wt_split);
+  q.KC = bfx_kc(p.K);
+  return launch_conv_bfx(q, stride, (hipStream_t)stream, workspace, workspace_bytes);
+}
+
+extern "C" size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const int tiles_m = N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  int nb;
+  const int want = halo_bfx_plan((long long)N * H * W, tiles_m, Cin, Cout, nb);
+  return want > 1 ? (size_t)want * (size_t)N * H * W * Cout * sizeof(float) : 0;
+}
+
+extern "C" void bgs_conv3x3_halo_bfx_tuning(int splits) { g_halo_force_splits = splits; }
+
+extern "C" int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits) {
+  if (nb) *nb = g_halo_last_nb;
+  if (splits) *splits = g_halo_last_splits;
+  return BGS_OK;
+}
+
+// 3x3 / stride 1 / pad 1, Cin % 16 == 0; wsplit = bgs_conv_bfx_split_weights of [Cout][3][3][Cin].
+extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias,
+                                             float* y, int N, int H, int W, int Cin, int Cout,
+                                             int relu, void* workspace, size_t workspace_bytes,
+                                             bgs_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BGS_ERR_INVALID_ARG;
+  if (!x || !wsplit || !y) return BGS_ERR_INVALID_ARG;
+  if (Cin % 16 != 0) return BGS_ERR_UNSUPPORTED;
+  if ((uintptr_t)x % 16 != 0 || (uintptr_t)wsplit % 16 != 0) return BGS_ERR_UNSUPPORTED;
+  const long long M = (long long)N * H * W;
+  if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  HaloBfxArgs q;
+  ConvArgs& p = q.c;
+  p.x = x; p.w = nullptr; p.bias = bias; p.res = nullptr; p.mask = nullptr; p.y = y;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = 3; p.S = 3; p.stride = 1; p.pad = 1;
+  p.Ho = H; p.Wo = W; p.M = (int)M; p.K = 9 * Cin; p.relu = relu; p.res_mode = 0;
+  p.partial = nullptr; p.kt_per_split = 0;
+  q.ws = reinterpret_cast<const __bf16*>(wsplit);
+  q.KC = bfx_kc(p.K);
+  q.tiles_y = (H + TH - 1) / TH;
+  q.tiles_x = (W + TW - 1) / TW;
+  p.tiles_m = N * q.tiles_y * q.tiles_x;
+  int nb;
+  int want = halo_bfx_plan(M, p.tiles_m, Cin, Cout, nb);
+  if (!workspace) want = 1;
+  while (want > 1 && (size_t)want * (size_t)M * Cout * sizeof(float) > workspace_bytes) --want;
+  const int cchunks = Cin / 16;
+  int splits = 1;
+  q.chunks_per_split = cchunks;
+  if (want > 1) {
+    q.chunks_per_split = (cchunks + want - 1) / want;
+    splits = (cchunks + q.chunks_per_split - 1) / q.chunks_per_split;
+    p.partial = reinterpret_cast<float*>(workspace);
+  }
+  p.tiles_n = (Cout + 64 * nb - 1) / (64 * nb);
+  p.chunk = (p.tiles_m * p.tiles_n + 7) / 8;
+  g_halo_last_nb = nb;
+  g_halo_last_splits = splits;
+  dim3 grid((unsigned)(8 * p.chunk), 1u, (unsigned)splits);
+  if (nb == 1)
+    hipLaunchKernelGGL(conv3x3_halo_bfx_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+  else
+    hipLaunchKernelGGL(conv3x3_halo_bfx_kernel<2>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+  if (splits > 1) {
+    if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
+    return bgs_internal_conv_splitk_epilogue(p, splits, (hipStream_t)stream);
+  }
+  BGS_RETURN_LAUNCH_STATUS();
+}

@@ -21,46 +21,11 @@
 //     nearest-2x-upsampled for the FPN top-down path) and ReLU, and writes NHWC directly.
 #include <stdlib.h>
 
-#include "bgs_common.h"
+#include "conv_args.h"
+
+using namespace bgs_conv;
 
 namespace {
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kThreads = 256;
-// LDS row = [k even: 8 floats][k odd: 8 floats][4 pad] = 20 floats.  The A/B fragment of
-// v_mfma_f32_32x32x2_f32 wants, in lane l, k = 2*kk + (l >> 5) for kk = 0..7: lanes 0-31 need
-// the even k of their row and lanes 32-63 the odd k — 8 contiguous floats each, fetched with two
-// ds_read_b128 per K tile (instead of 8 ds_read_b32: the 64x64 tile was LDS-bandwidth bound).
-// Stride 20 floats makes the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots.
-// (BK = 16: stride 20 floats; BK = 32: stride 36 floats — both spread 16 consecutive rows over
-// 16 distinct 16-byte slots of the 256-byte bank row.)
-
-struct ConvArgs {
-  const float* x;     // [N, H, W, Cin]
-  const float* w;     // [Cout, R, S, Cin]
-  const float* bias;  // [Cout] or null
-  const float* res;   // residual or null: [N, Ho, Wo, Cout] (mode 1) / [N, Ho/2, Wo/2, Cout] (mode 2:
-                      // nearest-2x upsampled) / [N, 2Ho, 2Wo, Cout] (mode 3: 2x2 sum-pooled)
-  const float* mask;  // null, or [N, Ho, Wo, Cout]: y = mask > 0 ? y : 0 (ReLU backward)
-  float* y;           // [N, Ho, Wo, Cout]
-  int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
-  int M, K;           // M = N*Ho*Wo, K = R*S*Cin
-  int relu, res_mode;
-  // split-K (small-M layers expose too few workgroups to fill 256 CUs): gridDim.z slices of
-  // `kt_per_split` K tiles each write raw partial sums to partial[z][M][Cout]; the epilogue
-  // (bias / residual / ReLU / mask) then runs in conv_splitk_epilogue_kernel.
-  float* partial;
-  int kt_per_split;
-  // XCD-aware tile order: the launch is 1-D; workgroup b runs on XCD b % 8 (round-robin dispatch),
-  // and is given tile (b % 8) * chunk + b / 8 — every XCD walks its own contiguous band of the
-  // image, with the Cout tiles of one pixel tile back to back, so the 3x3 halo rows and the
-  // re-read of the same pixels for the next Cout tile hit that XCD's L2 (PMC: 2.46 GB fetched per
-  // 158-GFLOP layer before, profiles/r2d_pmc_conv.md).
-  int tiles_m, tiles_n, chunk;
-};
 
 // UP = 1: plain convolution.  UP = 2: the input is read as if it had been zero-upsampled by 2
 // (x_virtual[2h, 2w] = x[h, w], zeros elsewhere) — the data gradient of a stride-2 convolution.
@@ -237,65 +202,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_f32_kernel(ConvArgs p) {
     mfma_half(1);
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  if (p.partial) {
-    float* part = p.partial + (size_t)blockIdx.z * p.M * p.Cout;
-#pragma unroll
-    for (int a = 0; a < MB; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int m = m0 + wm * 32 * MB + a * 32 + i;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const int j = n0 + wn * 32 * NB + b * 32 + (lane & 31);
-          if (j < p.Cout) part[(size_t)m * p.Cout + j] = acc[a][b][r];
-        }
-      }
-    return;
-  }
-  const int hw = p.Ho * p.Wo;
-#pragma unroll
-  for (int a = 0; a < MB; ++a) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int m = m0 + wm * 32 * MB + a * 32 + i;
-      if (m >= p.M) continue;
-      size_t res_row = 0;
-      if (p.res_mode == 1) {
-        res_row = (size_t)m * p.Cout;
-      } else if (p.res_mode == 2) {
-        const int n = m / hw;
-        const int rem = m - n * hw;
-        const int ho = rem / p.Wo, wo = rem - (rem / p.Wo) * p.Wo;
-        res_row = (((size_t)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout;
-      } else if (p.res_mode == 3) {
-        const int n = m / hw;
-        const int rem = m - n * hw;
-        const int ho = rem / p.Wo, wo = rem - (rem / p.Wo) * p.Wo;
-        res_row = (((size_t)n * (p.Ho * 2) + ho * 2) * (p.Wo * 2) + wo * 2) * p.Cout;
-      }
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int j = n0 + wn * 32 * NB + b * 32 + (lane & 31);
-        if (j >= p.Cout) continue;
-        float v = acc[a][b][r];
-        if (p.bias) v += p.bias[j];
-        if (p.res_mode == 3) {
-          const size_t down = (size_t)p.Wo * 2 * p.Cout;
-          v += (p.res[res_row + j] + p.res[res_row + p.Cout + j]) +
-               (p.res[res_row + down + j] + p.res[res_row + down + p.Cout + j]);
-        } else if (p.res_mode) {
-          v += p.res[res_row + j];
-        }
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.mask) v = p.mask[(size_t)m * p.Cout + j] > 0.f ? v : 0.f;
-        p.y[(size_t)m * p.Cout + j] = v;
-      }
-    }
-  }
+  conv_store_tile<MB, NB>(p, acc, m0, n0, wm, wn, lane);
 }
 
 // y[m][j] = epilogue( sum_z partial[z][m][j] ): fixed summation order (bitwise reproducible).
@@ -416,6 +323,42 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const float* __r
 
 }  // namespace
 
+// y = epilogue(sum of the split-K partial slabs): shared with conv_bfx.hip.
+int bgs_internal_conv_splitk_epilogue(ConvArgs& p, int splits, hipStream_t st) {
+  const size_t total = (size_t)p.M * p.Cout;
+  auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
+  if (p.Cout % 4 == 0 && al16(p.partial) && al16(p.y) && al16(p.bias) && al16(p.res) &&
+      al16(p.mask)) {
+    size_t g = (total / 4 + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(conv_splitk_epilogue4_kernel, dim3((unsigned)g), dim3(256), 0, st, p,
+                       splits);
+  } else {
+    size_t g = (total + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)g), dim3(256), 0, st, p,
+                       splits);
+  }
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+// Tuning knobs are read from the environment ONCE (first launch), not per launch.
+struct ConvKnobs {
+  int tile = 0, bk = 0, splitk = 0, noswizzle = 0;
+  bool has_splitk = false;
+  ConvKnobs() {
+    if (const char* e = getenv("BGS_CONV_TILE")) tile = atoi(e);
+    if (const char* e = getenv("BGS_CONV_BK")) bk = atoi(e);
+    if (const char* e = getenv("BGS_CONV_SPLITK")) { splitk = atoi(e); has_splitk = true; }
+    noswizzle = getenv("BGS_CONV_NOSWIZZLE") != nullptr;
+  }
+};
+static ConvKnobs& conv_knobs() {
+  static ConvKnobs k;
+  return k;
+}
+static int g_last_tile = 0, g_last_bk = 0, g_last_up = 0, g_last_splits = 0;
+
 // Shared launcher: tile / K-tile choice from the per-layer sweeps of the R50-FPN shapes
 // (tools/conv_sweep.py, profiles/r1i_conv_sweep.txt, r1q_conv_sweep_bk*.txt): the 128x128 tile
 // only pays for the two huge-M, deep-K 3x3 convs on the stride-4 maps; everywhere else the 64x64
@@ -424,21 +367,21 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const float* __r
 static int launch_conv(ConvArgs& p, int up, hipStream_t st, void* workspace = nullptr,
                        size_t workspace_bytes = 0) {
   const long long M = p.M;
-  int force = 0;  // tuning hook: BGS_CONV_TILE=22|21|11 forces a tile configuration
-  if (const char* e = getenv("BGS_CONV_TILE")) force = atoi(e);
+  const ConvKnobs& knobs = conv_knobs();
+  const int force = knobs.tile;  // tuning hook: BGS_CONV_TILE=22|21|11 forces a tile configuration
   int tile = 11;
   if (p.Cout > 64 && p.K >= 1152 && M >= 100000) tile = 22;
   else if (p.Cout <= 64 && M >= 400000) tile = 21;
   if (force == 22 || force == 21 || force == 11) tile = force;
   int bk = (p.K >= 512 && tile == 11) ? 32 : 16;
-  if (const char* e = getenv("BGS_CONV_BK")) bk = atoi(e) == 32 ? 32 : (atoi(e) == 16 ? 16 : bk);
+  if (knobs.bk == 32 || knobs.bk == 16) bk = knobs.bk;
   // split-K: only for the 64x64 tile when the grid cannot fill the chip (< ~2 workgroups per CU)
   // and the reduction is deep enough to share out (>= 8 K tiles per slice)
   int splits = 1;
   p.partial = nullptr;
   p.kt_per_split = 0;
   // (BGS_CONV_TILE + BGS_CONV_SPLITK together also split the larger tiles: tuning sweeps)
-  const bool force_split = force != 0 && getenv("BGS_CONV_SPLITK") != nullptr;
+  const bool force_split = force != 0 && knobs.has_splitk;
   if ((tile == 11 || force_split) && workspace) {
     const long long wgs = ((M + 63) / 64) * ((p.Cout + 63) / 64);
     const int nk = (p.K + bk - 1) / bk;
@@ -449,8 +392,8 @@ static int launch_conv(ConvArgs& p, int up, hipStream_t st, void* workspace = nu
     else if (wgs < 1500) want = 2;
     if (want > nk / 8) want = nk / 8;
     if (want > 8) want = 8;
-    if (const char* e = getenv("BGS_CONV_SPLITK")) {
-      const int f = atoi(e);
+    if (knobs.has_splitk) {
+      const int f = knobs.splitk;
       if (f >= 1 && f <= 16) want = f < nk ? f : nk;
     }
     while (want > 1 && (size_t)want * (size_t)M * p.Cout * sizeof(float) > workspace_bytes) --want;
@@ -460,6 +403,7 @@ static int launch_conv(ConvArgs& p, int up, hipStream_t st, void* workspace = nu
       p.partial = reinterpret_cast<float*>(workspace);
     }
   }
+  g_last_tile = tile; g_last_bk = bk; g_last_up = up; g_last_splits = splits;
 #define BGS_CONV_LAUNCH2(MB_, NB_, BK_, UP_)                                                     \
   hipLaunchKernelGGL((conv_igemm_f32_kernel<MB_, NB_, BK_, UP_>), grid, dim3(kThreads), 0, st, p)
 #define BGS_CONV_LAUNCH(MB_, NB_, BM_, BN_)                                                      \
@@ -467,7 +411,7 @@ static int launch_conv(ConvArgs& p, int up, hipStream_t st, void* workspace = nu
     p.tiles_m = (int)((M + BM_ - 1) / BM_);                                                      \
     p.tiles_n = (p.Cout + BN_ - 1) / BN_;                                                        \
     p.chunk = (p.tiles_m * p.tiles_n + 7) / 8;                                                   \
-    if (getenv("BGS_CONV_NOSWIZZLE")) p.chunk = 0;                                               \
+    if (knobs.noswizzle) p.chunk = 0;                                                            \
     dim3 grid((unsigned)(p.chunk ? 8 * p.chunk : p.tiles_m * p.tiles_n), 1u, (unsigned)splits);   \
     if (up == 2) {                                                                               \
       if (bk == 32) BGS_CONV_LAUNCH2(MB_, NB_, 32, 2);                                           \
@@ -484,22 +428,28 @@ static int launch_conv(ConvArgs& p, int up, hipStream_t st, void* workspace = nu
 #undef BGS_CONV_LAUNCH2
   if (splits > 1) {
     if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
-    const size_t total = (size_t)p.M * p.Cout;
-    auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
-    if (p.Cout % 4 == 0 && al16(p.partial) && al16(p.y) && al16(p.bias) && al16(p.res) &&
-        al16(p.mask)) {
-      size_t g = (total / 4 + 255) / 256;
-      if (g > 8192) g = 8192;
-      hipLaunchKernelGGL(conv_splitk_epilogue4_kernel, dim3((unsigned)g), dim3(256), 0, st, p,
-                         splits);
-    } else {
-      size_t g = (total + 255) / 256;
-      if (g > 8192) g = 8192;
-      hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)g), dim3(256), 0, st, p,
-                         splits);
-    }
+    return bgs_internal_conv_splitk_epilogue(p, splits, st);
   }
   BGS_RETURN_LAUNCH_STATUS();
+}
+
+// Tuning / test hooks (process-wide; not for concurrent use).  tile 0 = auto | 11 | 21 | 22;
+// bk 0 = auto | 16 | 32; splitk 0 = auto | 1..16 (with a forced tile also splits the larger tiles).
+extern "C" void bgs_conv_tuning(int tile, int bk, int splitk, int noswizzle) {
+  ConvKnobs& k = conv_knobs();
+  k.tile = tile;
+  k.bk = bk;
+  k.splitk = splitk;
+  k.has_splitk = splitk >= 1;
+  k.noswizzle = noswizzle;
+}
+
+extern "C" int bgs_conv_last_launch(int* tile, int* bk, int* up, int* splits) {
+  if (tile) *tile = g_last_tile;
+  if (bk) *bk = g_last_bk;
+  if (up) *up = g_last_up;
+  if (splits) *splits = g_last_splits;
+  return BGS_OK;
 }
 
 // Scratch for the split-K path of the two entry points below (0 is always legal: no split).
@@ -507,7 +457,7 @@ extern "C" size_t bgs_conv2d_workspace_bytes(long long M, int Cout) {
   if (M <= 0 || Cout <= 0) return 0;
   const long long wgs = ((M + 63) / 64) * ((Cout + 63) / 64);
   if (wgs >= 1500) return 0;
-  if (getenv("BGS_CONV_SPLITK")) return (size_t)16 * (size_t)M * Cout * sizeof(float);   // sweeps
+  if (conv_knobs().has_splitk) return (size_t)16 * (size_t)M * Cout * sizeof(float);   // sweeps
   return (size_t)(wgs < 600 ? 8 : 2) * (size_t)M * Cout * sizeof(float);
 }
 

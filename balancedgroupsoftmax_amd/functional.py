@@ -245,8 +245,97 @@ def bbox_smooth_l1_loss(bbox_pred, labels, bbox_targets, bbox_weights, num_reg_c
 
 
 # ----------------------------------------------------------------------------------------
-# conv / linear on the fp32 matrix cores (NHWC activations, [Cout,R,S,Cin] weights)
+# conv / linear on the matrix cores (NHWC fp32 activations, [Cout,R,S,Cin] fp32 weights)
+#   math 'bf16x6' (default): bf16 MFMA on exactly split operands, fp32-faithful (csrc/conv_bfx.hip)
+#   math 'f32':              v_mfma_f32_32x32x2_f32 (csrc/conv_igemm.hip, csrc/conv_halo.hip)
 # ----------------------------------------------------------------------------------------
+_CONV_MATH = [os.environ.get('BGS_CONV_MATH', 'bf16x6')]
+
+
+def set_conv_math(mode):
+    """'bf16x6' | 'f32'; returns the previous mode.  Both give fp32-accurate results (the split
+    kernel's error against fp64 is not above the fp32 MFMA kernel's); 'f32' keeps the bit-exact
+    fp32 fma chain."""
+    assert mode in ('bf16x6', 'f32'), mode
+    prev = _CONV_MATH[0]
+    _CONV_MATH[0] = mode
+    return prev
+
+
+def conv_math():
+    return _CONV_MATH[0]
+
+
+_SPLIT_CACHE = {}
+
+
+def bfx_split_weights(w2d, cache=True):
+    """``w2d [rows, K]`` fp32 -> the three bf16 planes ``bgs_conv2d_nhwc_f32_bfx_ws`` streams.
+    Frozen tensors (``requires_grad == False``) are split once and cached per (storage, version);
+    trained ones are split on every call (inside a captured step the split launch is part of the
+    graph, so replays see the updated weights)."""
+    _require_cuda(w2d)
+    lib = capi.load()
+    assert w2d.dtype == torch.float32 and w2d.dim() == 2 and w2d.is_contiguous()
+    rows, K = w2d.shape
+    cacheable = cache and not w2d.requires_grad
+    key = (w2d.data_ptr(), w2d._version, rows, K)
+    if cacheable:
+        hit = _SPLIT_CACHE.get(key)
+        if hit is not None:
+            return hit[1]
+    out = torch.empty(lib.bgs_conv_bfx_weight_bytes(rows, K), dtype=torch.uint8, device=w2d.device)
+    rc = lib.bgs_conv_bfx_split_weights(capi.ptr(w2d), capi.ptr(out), rows, K,
+                                        capi.current_stream(w2d.device))
+    capi.check('bgs_conv_bfx_split_weights', rc)
+    if cacheable:
+        if len(_SPLIT_CACHE) > 4096:
+            _SPLIT_CACHE.clear()
+        _SPLIT_CACHE[key] = (w2d, out)      # the source is kept alive: its address cannot be reused
+    return out
+
+
+def conv_bfx_tuning(tile=0, splitk=-1, halo_splits=-1):
+    """Process-wide tuning / test hook of the bf16x6 kernels (see include/bgs.h)."""
+    lib = capi.load()
+    lib.bgs_conv_bfx_tuning(int(tile), int(splitk))
+    lib.bgs_conv3x3_halo_bfx_tuning(int(halo_splits))
+
+
+def conv_bfx_last_launch():
+    """-> dict(tile, splits, halo_nb, halo_splits) of the last bf16x6 launches."""
+    import ctypes
+    lib = capi.load()
+    a, c, d, e = (ctypes.c_int() for _ in range(4))
+    lib.bgs_conv_bfx_last_launch(ctypes.byref(a), ctypes.byref(c))
+    lib.bgs_conv3x3_halo_bfx_last_launch(ctypes.byref(d), ctypes.byref(e))
+    return dict(tile=a.value, splits=c.value, halo_nb=d.value, halo_splits=e.value)
+
+
+def conv_tuning(tile=0, bk=0, splitk=0, noswizzle=0):
+    """Process-wide tuning / test hook of the fp32 MFMA conv kernel (see include/bgs.h)."""
+    capi.load().bgs_conv_tuning(int(tile), int(bk), int(splitk), int(noswizzle))
+
+
+def conv_last_launch():
+    """-> dict(tile, bk, up, splits) of the last fp32 MFMA conv launch."""
+    import ctypes
+    a, b, c, d = (ctypes.c_int() for _ in range(4))
+    capi.load().bgs_conv_last_launch(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d))
+    return dict(tile=a.value, bk=b.value, up=c.value, splits=d.value)
+
+
+def _use_halo_bfx(M, Cout):
+    """bf16x6 path: the halo kernel wins on the large maps (profiles/r2a_bfx_sweep.txt: P2 0.86 vs
+    1.07 ms, P3 0.25 vs 0.30, layer1/2 conv2), ties at M = 8400 and below."""
+    env = os.environ.get('BGS_CONV_HALO')
+    if env == '1':
+        return True
+    if env == '0':
+        return False
+    return M >= 30000
+
+
 def _use_halo_kernel(M, Cout):
     """``BGS_CONV_HALO`` = 1: every eligible 3x3 layer, 0: never; unset: where it was measured
     faster than the general kernel (tools/conv_halo_check.py, profiles/r3m_conv_halo.txt): the
@@ -280,8 +369,27 @@ def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None
         assert tuple(residual.shape) == exp and residual.is_contiguous(), (residual.shape, exp)
     if out is None:
         out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-    if R == 3 and S == 3 and stride == 1 and pad == 1 and residual is None and Cin % 16 == 0 \
-            and _use_halo_kernel(N * Ho * Wo, Cout):
+    halo_ok = R == 3 and S == 3 and stride == 1 and pad == 1 and residual is None and Cin % 16 == 0
+    if _CONV_MATH[0] == 'bf16x6':
+        wsplit = bfx_split_weights(w_krsc.view(Cout, R * S * Cin))
+        st = capi.current_stream(x.device)
+        if halo_ok and _use_halo_bfx(N * Ho * Wo, Cout):
+            wsb = lib.bgs_conv3x3_halo_bfx_workspace_bytes(N, H, W, Cin, Cout)
+            ws = _workspace(wsb, x.device) if wsb else None
+            rc = lib.bgs_conv3x3_halo_nhwc_f32_bfx(capi.ptr(x), capi.ptr(wsplit), capi.ptr(bias),
+                                                   capi.ptr(out), N, H, W, Cin, Cout,
+                                                   int(bool(relu)), capi.ptr(ws), wsb, st)
+            capi.check('bgs_conv3x3_halo_nhwc_f32_bfx', rc)
+            return out
+        wsb = lib.bgs_conv_bfx_workspace_bytes(N * Ho * Wo, Cout, R * S * Cin)
+        ws = _workspace(wsb, x.device) if wsb else None
+        rc = lib.bgs_conv2d_nhwc_f32_bfx_ws(capi.ptr(x), capi.ptr(wsplit), capi.ptr(bias),
+                                            capi.ptr(residual), capi.ptr(out), N, H, W, Cin, Cout,
+                                            R, S, stride, pad, int(bool(relu)), residual_mode,
+                                            capi.ptr(ws), wsb, st)
+        capi.check('bgs_conv2d_nhwc_f32_bfx_ws', rc)
+        return out
+    if halo_ok and _use_halo_kernel(N * Ho * Wo, Cout):
         # halo-resident 3x3 kernel (csrc/conv_halo.hip): the input patch is staged in LDS once per
         # channel chunk and shared by the nine taps
         rc = lib.bgs_conv3x3_halo_nhwc_f32(capi.ptr(x), capi.ptr(w_krsc), capi.ptr(bias),
@@ -324,6 +432,7 @@ def conv2d_dgrad_nhwc(dy, w_krsc, in_hw, stride=1, pad=0, residual=None, residua
         w_krsc = torch.nn.functional.pad(w_krsc.detach(), (0, 0, 0, 0, 0, 0, 0, padc))
         Cout += padc
         wt = None
+    wt_is_temp = wt is None
     if wt is None:
         wt = dgrad_filter(w_krsc)
     if residual is not None and residual_mode == 0:
@@ -334,6 +443,17 @@ def conv2d_dgrad_nhwc(dy, w_krsc, in_hw, stride=1, pad=0, residual=None, residua
     if mask is not None:
         assert tuple(mask.shape) == (N, H, W, Cin) and mask.is_contiguous()
     dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dy.device)
+    if _CONV_MATH[0] == 'bf16x6':
+        wt_split = bfx_split_weights(wt.view(Cin, R * S * Cout), cache=not wt_is_temp)
+        wsb = lib.bgs_conv_bfx_workspace_bytes(N * H * W, Cin, R * S * Cout)
+        ws = _workspace(wsb, dy.device) if wsb else None
+        rc = lib.bgs_conv2d_dgrad_nhwc_f32_bfx_ws(capi.ptr(dy), capi.ptr(wt_split),
+                                                  capi.ptr(residual), capi.ptr(mask), capi.ptr(dx),
+                                                  N, H, W, Cin, Cout, R, S, stride, pad,
+                                                  residual_mode, capi.ptr(ws), wsb,
+                                                  capi.current_stream(dy.device))
+        capi.check('bgs_conv2d_dgrad_nhwc_f32_bfx_ws', rc)
+        return dx
     wsb = lib.bgs_conv2d_workspace_bytes(N * H * W, Cin)
     ws = _workspace(wsb, dy.device) if wsb else None
     rc = lib.bgs_conv2d_dgrad_nhwc_f32_ws(capi.ptr(dy), capi.ptr(wt), capi.ptr(residual),

@@ -206,6 +206,12 @@ int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, float*
                               int W, int Cin, int Cout, int R, int S, int stride, int pad,
                               int accumulate, void* workspace, bgs_stream_t stream);
 
+/* Tuning / test hooks of the fp32 MFMA conv kernel (process-wide): tile 0 = auto | 11 | 21 | 22
+ * (MB*10+NB blocks of 64), bk 0 = auto | 16 | 32, splitk 0 = auto | 1..16, noswizzle 1 = plain tile
+ * order; bgs_conv_last_launch reports the instantiation the last launch used. */
+void bgs_conv_tuning(int tile, int bk, int splitk, int noswizzle);
+int bgs_conv_last_launch(int* tile, int* bk, int* up, int* splits);
+
 /* The 3x3 / stride 1 / pad 1 case of bgs_conv2d_nhwc_f32 (same call sites: fpn.py:131-134 output
  * convs, rpn_head.py:31 rpn_conv, resnet.py:244 conv2) with the workgroup's 8 x 16 output pixels
  * + halo staged in LDS once per 16-channel chunk and reused by the nine taps (DESIGN.md appendix
@@ -214,6 +220,46 @@ int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, float*
  * general kernel — M >= 100000 output pixels and Cout % 128 == 0 (BGS_CONV_HALO=0|1 overrides). */
 int bgs_conv3x3_halo_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int N,
                               int H, int W, int Cin, int Cout, int relu, bgs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * The same convolutions on the bf16 matrix cores with fp32-faithful results ("bf16x6",
+ * csrc/conv_bfx.hip): every fp32 operand is split exactly into three bf16 terms
+ * (hi + mid + lo, round-to-nearest-even) and the six products with i + j <= 2 are accumulated
+ * in fp32 by v_mfma_f32_32x32x16_bf16 — 6/16 of the matrix-pipe time of the fp32 MFMA kernel at
+ * the same error against an fp64 reference (dropped terms <= 2^-25 |a b|).  Same call sites and
+ * epilogues as bgs_conv2d_nhwc_f32_ws / bgs_conv2d_dgrad_nhwc_f32_ws / bgs_conv3x3_halo_nhwc_f32;
+ * activations stay fp32 NHWC.  The filter is split once by the caller:
+ *   bgs_conv_bfx_split_weights(w [rows][K] fp32 -> out, bgs_conv_bfx_weight_bytes(rows, K) bytes,
+ *   16-byte aligned), layout [3][2*ceil(K/32)][rows][16] bf16 (zero-padded K tail); rows = Cout
+ *   (forward; K = R*S*Cin) or Cin (data gradient: the flipped / transposed filter, K = R*S*Cout).
+ * workspace: bgs_conv_bfx_workspace_bytes(M, Cout, K) / bgs_conv3x3_halo_bfx_workspace_bytes(...)
+ * bytes of split-K scratch (0 / NULL is always legal).
+ * bgs_conv_bfx_tuning / bgs_conv3x3_halo_bfx_tuning: process-wide tuning and test hooks
+ * (tile 0 = auto | 11 | 12 | 21 | 22 as MB*10+NB blocks of 64; splitk -1 = auto | 1..16);
+ * *_last_launch report what the last launch used (tests assert the instantiation they meant
+ * to cover).
+ * ---------------------------------------------------------------------------------- */
+size_t bgs_conv_bfx_weight_bytes(int rows, int K);
+int bgs_conv_bfx_split_weights(const float* w, void* out, int rows, int K, bgs_stream_t stream);
+size_t bgs_conv_bfx_workspace_bytes(long long M, int Cout, int K);
+int bgs_conv2d_nhwc_f32_bfx_ws(const float* x, const void* wsplit, const float* bias,
+                               const float* residual, float* y, int N, int H, int W, int Cin,
+                               int Cout, int R, int S, int stride, int pad, int relu,
+                               int residual_mode, void* workspace, size_t workspace_bytes,
+                               bgs_stream_t stream);
+int bgs_conv2d_dgrad_nhwc_f32_bfx_ws(const float* dy, const void* wt_split, const float* residual,
+                                     const float* mask, float* dx, int N, int H, int W, int Cin,
+                                     int Cout, int R, int S, int stride, int pad,
+                                     int residual_mode, void* workspace, size_t workspace_bytes,
+                                     bgs_stream_t stream);
+size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias, float* y,
+                                  int N, int H, int W, int Cin, int Cout, int relu,
+                                  void* workspace, size_t workspace_bytes, bgs_stream_t stream);
+void bgs_conv_bfx_tuning(int tile, int splitk);
+int bgs_conv_bfx_last_launch(int* tile, int* splits);
+void bgs_conv3x3_halo_bfx_tuning(int splits);
+int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits);
 
 /* Grouped 3x3 convolution (pad 1, stride 1 or 2) + bias + ReLU, NHWC: conv2 of the ResNeXt
  * bottleneck (mmdet/models/backbones/resnext.py:47-57, cfg 5 = X101-64x4d).  x [N,H,W,C],

@@ -1,6 +1,8 @@
 """GPU parity tests of the detector ops behind the C ABI: fp32-MFMA implicit-GEMM conv /
 linear, max pooling, multi-level RoIAlign, batched NMS — against the CPU oracles
 (oracle/det_oracle.py; torch-CPU conv; the compiled reference nms_cpu.cpp)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -35,8 +37,23 @@ CONV_CASES = [
 ]
 
 
+MATHS = ['bf16x6', 'f32']
+
+
+@pytest.fixture
+def conv_math(request):
+    """Runs the test body under one of the two conv arithmetic modes and restores every
+    process-wide tuning hook afterwards."""
+    prev = BF.set_conv_math(request.param)
+    yield request.param
+    BF.set_conv_math(prev)
+    BF.conv_tuning()
+    BF.conv_bfx_tuning()
+
+
+@pytest.mark.parametrize('conv_math', MATHS, indirect=True)
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv2d_vs_torch_cpu(case):
+def test_conv2d_vs_torch_cpu(case, conv_math):
     name, N, H, W, Cin, Cout, R, stride, pad, use_bias, relu, res_mode = case
     import zlib
     rs = np.random.RandomState(zlib.crc32(name.encode()))
@@ -60,6 +77,110 @@ def test_conv2d_vs_torch_cpu(case):
     assert err < 2e-5 * max(1.0, np.abs(exp).max()), err
     exp32 = det_oracle.conv2d_nhwc(x, w, b, stride, pad, relu, res_full)
     assert np.abs(y - exp32).max() < 1e-4 * max(1.0, np.abs(exp32).max())
+
+
+def _conv_ref64(x, w, b, stride, pad, relu):
+    y = F.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2),
+                 torch.from_numpy(w).double().permute(0, 3, 1, 2),
+                 torch.from_numpy(b).double(), stride=stride, padding=pad)
+    return (y.relu() if relu else y).permute(0, 2, 3, 1).numpy()
+
+
+# Every template instantiation the two launchers can choose (csrc/conv_igemm.hip launch_conv:
+# tile {22, 21, 11} x BK {16, 32} x UP {1, 2}; csrc/conv_bfx.hip: tile {22, 21, 12, 11} x UP {1, 2}),
+# forced through the tuning hooks and CONFIRMED through the last-launch queries — the size-based
+# defaults only reach the larger tiles at M >= 100,000.
+F32_INST = [(t, bk, up) for t in (22, 21, 11) for bk in (16, 32) for up in (1, 2)]
+BFX_INST = [(t, up) for t in (22, 21, 12, 11) for up in (1, 2)]
+
+
+def _inst_problem(up, seed):
+    """up = 1: a forward 3x3 conv with bias + ReLU; up = 2: the data gradient of a stride-2 3x3
+    conv (the zero-upsampled read path).  Sizes ragged against every tile (M = 2*37*45 = 3330 /
+    dgrad 2*37*45 input pixels, Cout 200 / Cin 72)."""
+    rs = np.random.RandomState(seed)
+    if up == 1:
+        N, H, W, Cin, Cout = 2, 37, 45, 40, 200
+        x = rs.standard_normal((N, H, W, Cin)).astype(np.float32)
+        w = (rs.standard_normal((Cout, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(np.float32)
+        b = rs.standard_normal(Cout).astype(np.float32)
+        exp = _conv_ref64(x, w, b, 1, 1, True)
+        return (lambda: BF.conv2d_nhwc(dev(x), dev(w), dev(b), pad=1, relu=True)), exp
+    N, H, W, Cin, Cout = 2, 37, 45, 72, 136
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    dy = rs.standard_normal((N, Ho, Wo, Cout)).astype(np.float32)
+    w = (rs.standard_normal((Cout, 3, 3, Cin)) / np.sqrt(9 * Cout)).astype(np.float32)
+    xr = torch.zeros(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    yr = F.conv2d(xr, torch.from_numpy(w).double().permute(0, 3, 1, 2), stride=2, padding=1)
+    (gx,) = torch.autograd.grad(yr, xr, torch.from_numpy(dy).double().permute(0, 3, 1, 2))
+    return (lambda: BF.conv2d_dgrad_nhwc(dev(dy), dev(w), (H, W), stride=2, pad=1)), \
+        gx.permute(0, 2, 3, 1).numpy()
+
+
+@pytest.mark.parametrize('inst', F32_INST, ids=['t%d_bk%d_up%d' % i for i in F32_INST])
+def test_conv_f32_every_instantiation(inst):
+    tile, bk, up = inst
+    prev = BF.set_conv_math('f32')
+    try:
+        run, exp = _inst_problem(up, tile * 100 + bk + up)
+        BF.conv_tuning(tile=tile, bk=bk, splitk=1)
+        got = run().cpu().numpy()
+        used = BF.conv_last_launch()
+        assert (used['tile'], used['bk'], used['up'], used['splits']) == (tile, bk, up, 1), used
+        assert np.abs(got - exp).max() < 2e-5 * np.abs(exp).max()
+        BF.conv_tuning(tile=tile, bk=bk, splitk=3)           # the same tile with split-K
+        got = run().cpu().numpy()
+        assert BF.conv_last_launch()['splits'] == 3
+        assert np.abs(got - exp).max() < 2e-5 * np.abs(exp).max()
+    finally:
+        BF.conv_tuning()
+        BF.set_conv_math(prev)
+
+
+@pytest.mark.parametrize('inst', BFX_INST, ids=['t%d_up%d' % i for i in BFX_INST])
+def test_conv_bfx_every_instantiation(inst):
+    tile, up = inst
+    prev = BF.set_conv_math('bf16x6')
+    os.environ['BGS_CONV_HALO'] = '0'
+    try:
+        run, exp = _inst_problem(up, tile * 100 + up)
+        for splitk in (1, 3):
+            BF.conv_bfx_tuning(tile=tile, splitk=splitk)
+            got = run().cpu().numpy()
+            used = BF.conv_bfx_last_launch()
+            assert (used['tile'], used['splits']) == (tile, splitk), used
+            assert np.abs(got - exp).max() < 2e-5 * np.abs(exp).max()
+    finally:
+        os.environ.pop('BGS_CONV_HALO', None)
+        BF.conv_bfx_tuning()
+        BF.set_conv_math(prev)
+
+
+def test_bfx_error_not_above_f32_mfma():
+    """The bf16x6 kernels are not a reduced-precision mode: against an fp64 reference their error
+    (normalised by sum |a||b|, the fp32 rounding scale of the reduction) is at the level of the
+    fp32 MFMA kernel's — for a deep reduction (K = 4608), wide-dynamic-range operands (so that the
+    mid / lo planes matter) and the halo kernel."""
+    rs = np.random.RandomState(77)
+    N, H, W, Cin, Cout = 1, 24, 40, 512, 128
+    x = (rs.standard_normal((N, H, W, Cin)) * np.exp(rs.uniform(-4, 4, (N, H, W, Cin)))).astype(np.float32)
+    w = (rs.standard_normal((Cout, 3, 3, Cin)) * np.exp(rs.uniform(-4, 4, (Cout, 3, 3, Cin))) / 70).astype(np.float32)
+    b = np.zeros(Cout, np.float32)
+    exp = _conv_ref64(x, w, b, 1, 1, False)
+    den = _conv_ref64(np.abs(x), np.abs(w), b, 1, 1, False).max()
+    errs = {}
+    for math, halo in (('f32', '0'), ('bf16x6', '0'), ('bf16x6', '1')):
+        prev = BF.set_conv_math(math)
+        os.environ['BGS_CONV_HALO'] = halo
+        try:
+            y = BF.conv2d_nhwc(dev(x), dev(w), dev(b), pad=1).cpu().numpy().astype(np.float64)
+        finally:
+            os.environ.pop('BGS_CONV_HALO', None)
+            BF.set_conv_math(prev)
+        errs[(math, halo)] = np.abs(y - exp).max() / den
+    assert errs[('f32', '0')] < 5e-7, errs
+    for k in (('bf16x6', '0'), ('bf16x6', '1')):
+        assert errs[k] < max(1.5 * errs[('f32', '0')], 1.5e-7), errs
 
 
 def test_linear_matches_fc_shapes():
@@ -349,14 +470,16 @@ def test_roi_align_autograd_accumulates_into_feature_grads():
         assert np.abs(ft[i].grad.cpu().numpy() - exp).max() <= 1e-4 * max(1.0, np.abs(exp).max())
 
 
+@pytest.mark.parametrize('conv_math', MATHS, indirect=True)
 @pytest.mark.parametrize('shape', [(1, 8, 16, 16, 128, False), (2, 13, 21, 64, 256, True),
                                    (1, 25, 42, 256, 200, True), (2, 50, 84, 32, 64, False),
                                    (1, 3, 5, 48, 15, True), (1, 200, 513, 16, 128, True)])
-def test_conv3x3_halo_kernel_vs_torch_cpu(monkeypatch, shape):
-    """csrc/conv_halo.hip (input patch + halo staged in LDS once per channel chunk, shared by the
-    nine taps) == torch-CPU F.conv2d and == the general implicit-GEMM kernel: tiles that hang over
-    the image, Cout that is not a multiple of the 128-wide tile, one pixel tile only, and a
-    shape large enough (M >= 100000, Cout % 128 == 0) for the DEFAULT dispatch to choose it."""
+def test_conv3x3_halo_kernel_vs_torch_cpu(monkeypatch, shape, conv_math):
+    """csrc/conv_halo.hip / the halo kernel of csrc/conv_bfx.hip (input patch + halo staged in LDS
+    once per channel chunk, shared by the nine taps) == torch-CPU F.conv2d and == the general
+    implicit-GEMM kernel: tiles that hang over the image, Cout that is not a multiple of the
+    128-wide tile, one pixel tile only, and a shape large enough for the DEFAULT dispatch to
+    choose it."""
     N, H, W, Cin, Cout, relu = shape
     rs = np.random.RandomState(H * 7 + Cin)
     x = rs.randn(N, H, W, Cin).astype(np.float32)
@@ -371,17 +494,29 @@ def test_conv3x3_halo_kernel_vs_torch_cpu(monkeypatch, shape):
     monkeypatch.setenv('BGS_CONV_HALO', '1')
     got = BF.conv2d_nhwc(dev(x), dev(w), dev(b), pad=1, relu=relu)
     assert float((got.cpu() - exp).abs().max()) <= tol
+    if conv_math == 'bf16x6':
+        for hs in (1, 2):                                      # channel-chunk split-K of the halo kernel
+            BF.conv_bfx_tuning(halo_splits=hs)
+            g2 = BF.conv2d_nhwc(dev(x), dev(w), dev(b), pad=1, relu=relu)
+            assert BF.conv_bfx_last_launch()['halo_splits'] == min(hs, Cin // 16)
+            assert float((g2.cpu() - exp).abs().max()) <= tol
+        BF.conv_bfx_tuning()
     monkeypatch.setenv('BGS_CONV_HALO', '0')
     gen = BF.conv2d_nhwc(dev(x), dev(w), dev(b), pad=1, relu=relu)
     assert float((gen.cpu() - exp).abs().max()) <= tol
     monkeypatch.delenv('BGS_CONV_HALO')
     dflt = BF.conv2d_nhwc(dev(x), dev(w), dev(b), pad=1, relu=relu)
-    use_halo = BF._use_halo_kernel(N * H * W, Cout)
-    assert use_halo == (N * H * W >= 100000 and Cout % 128 == 0)
+    if conv_math == 'f32':
+        use_halo = BF._use_halo_kernel(N * H * W, Cout)
+        assert use_halo == (N * H * W >= 100000 and Cout % 128 == 0)
+    else:
+        use_halo = BF._use_halo_bfx(N * H * W, Cout)
+        assert use_halo == (N * H * W >= 30000)
     assert torch.equal(dflt, got if use_halo else gen)
 
 
-def test_conv_split_k_matches_single_pass(monkeypatch):
+@pytest.mark.parametrize('conv_math', MATHS, indirect=True)
+def test_conv_split_k_matches_single_pass(conv_math):
     """Split-K (small-M layers) == the single-pass kernel for every epilogue: bias+ReLU, same-shape
     and upsampled residuals (forward), sum-pooled residual + ReLU mask (data gradient)."""
     rs = np.random.RandomState(9)
@@ -401,13 +536,18 @@ def test_conv_split_k_matches_single_pass(monkeypatch):
                 BF.conv2d_nhwc(x, w, None, pad=1, residual=res2, residual_mode=2),
                 BF.conv2d_dgrad_nhwc(dy, w, (H, W), 1, 1, residual=res3, residual_mode=3, mask=mask),
                 BF.conv2d_dgrad_nhwc(dy, w, (H, W), 1, 1, residual=mask, mask=mask)]
-    monkeypatch.setenv('BGS_CONV_SPLITK', '1')
+    def force(k):
+        if conv_math == 'f32':
+            BF.conv_tuning(splitk=k)
+        else:
+            BF.conv_bfx_tuning(splitk=k if k else -1)
+    force(1)
     ref = run()
-    for f in ('2', '5', '8'):
-        monkeypatch.setenv('BGS_CONV_SPLITK', f)
+    for f in (2, 5, 8):
+        force(f)
         for a, e in zip(run(), ref):
             assert float((a - e).abs().max()) <= 2e-5 * float(e.abs().max())
-    monkeypatch.delenv('BGS_CONV_SPLITK')
+    force(0)
     for a, e in zip(run(), ref):                              # the library's own choice
         assert float((a - e).abs().max()) <= 2e-5 * float(e.abs().max())
 

@@ -191,6 +191,61 @@ def test_training_iteration_vs_executed_reference_detector():
     assert not bad, bad
 
 
+@pytest.mark.parametrize('mode', ['bf16x6', 'bf16x6-nohalo', 'f32', 'f32-nohalo'])
+def test_fullsize_training_iteration_vs_executed_reference(mode, monkeypatch):
+    """BASELINE cfg[1] AT ITS REAL SIZE (2 x 3x800x1344, 20 GT/img) against the executed reference
+    (tests/golden/make_golden_fullsize.py): the kernels and tile instantiations the size-based
+    dispatch only reaches here (128x128 / 128x64 tiles, halo kernels, > 2000-workgroup XCD-banded
+    grids, 268,569 anchors per image) produce the reference's 8 loss terms to 1e-4 and its
+    gradients from ``fc_cls`` down to ResNet layer2 — under both conv arithmetic modes, with and
+    without the halo kernels.  Samplers take every candidate on both sides (no random draw)."""
+    from balancedgroupsoftmax_amd import functional as BF
+    from balancedgroupsoftmax_amd import train
+    from tests.golden import make_golden_fullsize as T
+    z = np.load(os.path.join(os.path.dirname(T.__file__), 'e2e_train_fullsize_golden.npz'))
+    math, _, nohalo = mode.partition('-')
+    if nohalo:
+        monkeypatch.setenv('BGS_CONV_HALO', '0')
+    prev = BF.set_conv_math(math)
+    try:
+        tmp = tempfile.mkdtemp(prefix='bgs_full_')
+        model_cfg, train_cfg = T.configs(tmp)
+        model = bgs.build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
+                                   test_cfg=to_config_dict(G.TEST_CFG))
+        with torch.no_grad():
+            det_oracle.fill_detector(model.state_dict(), T.SEED)
+        model.to(DEV)
+        train.select_training_param(model, 0)
+        model.train()
+        boxes, labels = T.gt()
+        losses = model(T.image().to(DEV), T.img_meta(), return_loss=True,
+                       gt_bboxes=[torch.from_numpy(b).to(DEV) for b in boxes],
+                       gt_labels=[torch.from_numpy(l).to(DEV) for l in labels])
+        bad = []
+        for k in ['loss_rpn_cls', 'loss_rpn_bbox'] + ['loss_cls_bin%d' % i for i in range(5)] + ['loss_bbox']:
+            v = losses[k]
+            got = np.array([float(t.detach().sum()) for t in (v if isinstance(v, list) else [v])], np.float32)
+            exp = z['loss/' + k]
+            if np.abs(got - exp).max() > 1e-4 * np.abs(exp).max() + 1e-7:
+                bad.append((k, got.tolist(), exp.tolist()))
+        assert not bad, bad
+        loss, _ = train.parse_losses(losses)
+        assert abs(float(loss.detach()) - float(z['loss/total'][0])) < 1e-4 * float(z['loss/total'][0])
+        loss.backward()
+        params = dict(model.named_parameters())
+        bad = []
+        for name, idx in T.GRADS:
+            g = params[name].grad
+            assert g is not None, name
+            if not grad_close(g[idx].cpu().numpy(), z['grad/' + name]):
+                bad.append(name)
+        assert not bad, bad
+    finally:
+        BF.set_conv_math(prev)
+        del model
+        torch.cuda.empty_cache()
+
+
 def test_htc_training_iteration_vs_executed_reference_detector():
     """``HybridTaskCascade.forward_train`` + ``backward`` (htc.py:196-311: three box stages with
     semantic fusion, interleaved re-sampling from the refined boxes, mask information flow, semantic
