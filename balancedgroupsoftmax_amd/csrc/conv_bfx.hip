@@ -36,6 +36,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// Out-of-range operands (image border, K tail, rows past Cout) are LOADED from this zero page: the
+// address is selected before the load, so the loaded registers need no select after it and stay
+// in flight until they are staged — a branch around the load or a select behind it makes hipcc
+// wait for the load right where it is issued (in front of the MFMAs instead of behind them).
+__device__ __attribute__((aligned(16))) unsigned g_zero_page[16];
+
 struct BfxArgs {
   ConvArgs c;
   const __bf16* ws;      // split weights [NS][KC][Cout][16]
@@ -66,6 +72,8 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2& hi, u32x2& mid, u32
 // NS = 3: fp32-faithful (six products).  NS = 2: hi/mid only, three products (error ~2^-17: a
 // tuning / ablation arm, not used by the detector).  UP as in conv_igemm.hip.
 // BK = 16 or 32 (k depth staged per barrier).
+// (Tried: a register prefetch depth of two K steps — hipcc re-uses the destination registers of the
+// loads in flight for address arithmetic and waits for them at the top of the next step: slower.)
 template <int MB, int NB, int BK, int NS, int UP>
 __global__ __launch_bounds__(kThreads, 2) void conv_igemm_bfx_kernel(BfxArgs q) {
   const ConvArgs& p = q.c;
@@ -141,9 +149,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_bfx_kernel(BfxArgs q) 
     ks = rs - kr * p.S;
   }
 
-  f32x4 ra[PA];
-  u32x4 rb[PB];
-  auto load_tile = [&]() {
+  f32x4 ra0[PA];
+  u32x4 rb0[PB];
+  auto load_tile = [&](f32x4 (&ra)[PA], u32x4 (&rb)[PB]) {
     const bool kok = kg < p.K;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
@@ -155,15 +163,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_bfx_kernel(BfxArgs q) 
         wi >>= 1;
       }
       ok = ok && hi < p.H && wi < p.W;
-      ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ok)
-        ra[i] = *reinterpret_cast<const f32x4*>(a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + kc);
+      const float* src = ok ? a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + kc
+                            : reinterpret_cast<const float*>(g_zero_page);
+      ra[i] = *reinterpret_cast<const f32x4*>(src);
     }
     const size_t koff = (size_t)kt_load * KS * p.Cout * 16;
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      rb[i] = u32x4{0u, 0u, 0u, 0u};
-      if (b_ok[i]) rb[i] = *reinterpret_cast<const u32x4*>(b_src[i] + koff);
+      const __bf16* src = b_ok[i] ? b_src[i] + koff : reinterpret_cast<const __bf16*>(g_zero_page);
+      rb[i] = *reinterpret_cast<const u32x4*>(src);
     }
     ++kt_load;
     kg += BK;
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_bfx_kernel(BfxArgs q) 
       }
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const f32x4 (&ra)[PA], const u32x4 (&rb)[PB]) {
     unsigned char* base = lds + buf * BUF;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
@@ -205,13 +213,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_bfx_kernel(BfxArgs q) 
   const int b_frag = NS * A_PLANE + (wn * 32 * NB + frow) * LDR + fk * 16;
 
   const int nk = kt_end - kt_begin;
-  load_tile();
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more) load_tile();            // global loads of tile kt+1 in flight under the MFMAs
+  auto compute = [&](int buf) {
     const unsigned char* base = lds + buf * BUF;
 #pragma unroll
     for (int s2 = 0; s2 < KS; ++s2) {
@@ -238,7 +240,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_bfx_kernel(BfxArgs q) 
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[t - i][b], acc[a][b],
                                                                   0, 0, 0);
     }
-    if (more) store_tile(buf ^ 1);
+  };
+  load_tile(ra0, rb0);
+  store_tile(0, ra0, rb0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) load_tile(ra0, rb0);      // global loads of tile kt+1 in flight under the MFMAs
+    compute(buf);
+    if (more) store_tile(buf ^ 1, ra0, rb0);
     __syncthreads();
   }
   conv_store_tile<MB, NB>(p, acc, m0, n0, wm, wn, lane);
@@ -351,8 +362,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx_kernel(HaloBfxAr
   auto load_a = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < AQT; ++i) {
-      ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a_in[i]) ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + chunk * 16);
+      const float* src = a_in[i] ? a_src[i] + chunk * 16 : reinterpret_cast<const float*>(g_zero_page);
+      ra[i] = *reinterpret_cast<const f32x4*>(src);
     }
   };
   auto store_a = [&]() {
@@ -371,8 +382,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx_kernel(HaloBfxAr
     const size_t koff = (size_t)(tap * cchunks + chunk) * p.Cout * 16;
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      rb[i] = u32x4{0u, 0u, 0u, 0u};
-      if (b_ok[i]) rb[i] = *reinterpret_cast<const u32x4*>(b_src[i] + koff);
+      const __bf16* src = b_ok[i] ? b_src[i] + koff : reinterpret_cast<const __bf16*>(g_zero_page);
+      rb[i] = *reinterpret_cast<const u32x4*>(src);
     }
   };
   auto store_b = [&](int buf) {
@@ -477,17 +488,218 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx_kernel(HaloBfxAr
   }
 }
 
+// Variant 2 (default): the same data flow with (i) the nine taps of a chunk fully unrolled — the
+// tap's patch offset is an immediate of the ds_read, no per-step integer division — and (ii) the
+// filter slices stored UNPADDED (32-byte rows) with the two 16-byte halves of a row swapped on odd
+// 8-row groups (conflict-free ds_read_b128 without padding): 50.5 KB of LDS and <= 168 VGPRs ->
+// THREE workgroups per CU.  Measured on the P2 layer (profiles/r2f_pmc_bfx_halo.md): with two
+// workgroups per CU the matrix pipe is busy 49 % of the time — the four waves of a workgroup sit
+// on four SIMDs, each shared with ONE wave of another workgroup, and every barrier couples them;
+// a third resident workgroup fills the gaps.  (A mid-step barrier / fragment read-ahead pipeline
+// inside the wave, as in conv_igemm.hip, measured +0 % here and cost 44 VGPRs: dropped.)
+template <int NB>
+__global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxArgs q) {
+  const ConvArgs& p = q.c;
+  constexpr int BN = 64 * NB;
+  constexpr int A_PLANE = PROWS * HLDR, A_BYTES = 3 * A_PLANE;
+  constexpr int B_PLANE = BN * 32, B_BUF = 3 * B_PLANE;
+  constexpr int NPIECE = 3 * BN * 2;
+  constexpr int PB = (NPIECE + kThreads - 1) / kThreads;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[A_BYTES + 2 * B_BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int vtile = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if (vtile >= p.tiles_m * p.tiles_n) return;                  // workgroup-uniform
+  const int tm = vtile / p.tiles_n, tn = vtile - tm * p.tiles_n;
+  const int n = tm / (q.tiles_y * q.tiles_x);
+  const int trem = tm - n * (q.tiles_y * q.tiles_x);
+  const int ty = trem / q.tiles_x, tx = trem - ty * q.tiles_x;
+  const int h0 = ty * TH - 1, w0 = tx * TW - 1;                // input coords of patch (0, 0)
+  const int n0 = tn * BN;
+  const int cchunks = p.Cin / 16;
+  const int c_begin = p.partial ? blockIdx.z * q.chunks_per_split : 0;
+  const int c_end = p.partial ? min(cchunks, c_begin + q.chunks_per_split) : cchunks;
+
+  // ---- staging roles.  A: patch quads idx = tid + 256 i; prow = idx / 4, kq = idx % 4
+  const float* a_src[AQT];
+  int a_dst[AQT];
+  bool a_use[AQT];
+#pragma unroll
+  for (int i = 0; i < AQT; ++i) {
+    const int idx = tid + kThreads * i;
+    a_use[i] = idx < AQ;
+    const int prow = a_use[i] ? idx >> 2 : 0, kq = idx & 3;
+    const int pr = prow / PW, pc = prow - pr * PW;
+    const int hi = h0 + pr, wi = w0 + pc;
+    const bool in = a_use[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+    // outside the image: the zero page, with a zero channel stride (a_cs)
+    a_src[i] = in ? p.x + (((size_t)n * p.H + hi) * p.W + wi) * p.Cin + kq * 4
+                  : reinterpret_cast<const float*>(g_zero_page);
+    a_dst[i] = (in ? 1 : 0) | ((prow * HLDR + kq * 8) << 1);   // bit 0: advances with the chunk
+  }
+  // B: piece id = tid + 256 i -> (plane, row, half); halves swapped on odd 8-row groups
+  const __bf16* b_src[PB];
+  int b_dst[PB];
+  bool b_use[PB], b_ok[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int id = tid + kThreads * i;
+    b_use[i] = id < NPIECE;
+    const int idc = b_use[i] ? id : 0;
+    const int plane = idc / (BN * 2);
+    const int rem = idc - plane * (BN * 2);
+    const int row = rem >> 1, half = rem & 1;
+    b_ok[i] = b_use[i] && (n0 + row < p.Cout);
+    b_src[i] = b_ok[i] ? q.ws + ((size_t)plane * q.KC * p.Cout + n0 + row) * 16 + half * 8
+                       : reinterpret_cast<const __bf16*>(g_zero_page);
+    b_dst[i] = A_BYTES + plane * B_PLANE + row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
+  }
+
+  f32x4 ra[AQT];
+  u32x4 rb[PB];
+  auto load_a = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < AQT; ++i)
+      ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + ((a_dst[i] & 1) ? chunk * 16 : 0));
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < AQT; ++i) {
+      if (!a_use[i]) continue;
+      u32x2 h, m, l;
+      split3(ra[i], h, m, l);
+      unsigned char* d = lds + (a_dst[i] >> 1);
+      *reinterpret_cast<u32x2*>(d) = h;
+      *reinterpret_cast<u32x2*>(d + A_PLANE) = m;
+      *reinterpret_cast<u32x2*>(d + 2 * A_PLANE) = l;
+    }
+  };
+  auto load_b = [&](int chunk, int tap) {
+    const size_t koff = (size_t)(tap * cchunks + chunk) * p.Cout * 16;
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      rb[i] = *reinterpret_cast<const u32x4*>(b_src[i] + (b_ok[i] ? koff : 0));
+  };
+  auto store_b = [&](int buf_off) {
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      if (b_use[i]) *reinterpret_cast<u32x4*>(lds + buf_off + b_dst[i]) = rb[i];
+  };
+
+  // ---- fragment roles: lane frow of sub-tile a owns pixel m = 64 wm + 32 a + frow
+  const int frow = lane & 31, fk = lane >> 5;
+  int a_frag[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int m = wm * 64 + a * 32 + frow;
+    a_frag[a] = ((m >> 4) * PW + (m & 15)) * HLDR + fk * 16;      // patch row of tap (0, 0)
+  }
+  const int brow = wn * 32 * NB + frow;                           // + 32 b: same 8-row-group parity
+  const int b_frag = A_BYTES + brow * 32 + ((fk ^ ((brow >> 3) & 1)) << 4);
+
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  load_a(c_begin);
+  load_b(c_begin, 0);
+  store_a();
+  store_b(0);
+  __syncthreads();
+  int cur = 0, nxt = B_BUF;                                      // byte offsets of the two B buffers
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const bool last_chunk = chunk + 1 >= c_end;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int rd = (tap & 1) ? nxt : cur;                       // buffer of this step
+      const int wr = (tap & 1) ? cur : nxt;                       // buffer of the next step
+      const bool more = tap < 8 || !last_chunk;
+      if (tap < 8) load_b(chunk, tap + 1);                        // next filter slice in flight
+      else if (more) load_b(chunk + 1, 0);
+      if (tap == 0 && !last_chunk) load_a(chunk + 1);             // next patch: held in registers
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int tap_off = ((tap / 3) * PW + (tap % 3)) * HLDR;    // compile-time constant
+      bf16x8 fa[3][2], fb[3][NB];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+          fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a] + tap_off + s * A_PLANE);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          fb[s][b] = *reinterpret_cast<const bf16x8*>(lds + rd + b_frag + s * B_PLANE + b * 32 * 32);
+      }
+#pragma unroll
+      for (int tt = 2; tt >= 0; --tt)
+#pragma unroll
+        for (int i = 0; i <= tt; ++i)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[tt - i][b], acc[a][b],
+                                                                  0, 0, 0);
+      if (more) store_b(wr);
+      __syncthreads();
+      if (tap == 8 && !last_chunk) {                              // every wave is done with this patch
+        store_a();
+        __syncthreads();
+      }
+    }
+    // nine steps per chunk: the buffer roles swap from chunk to chunk
+    const int t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+
+  // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  float* part = p.partial ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : nullptr;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int m = wm * 64 + a * 32 + i;
+      const int ho = ty * TH + (m >> 4), wo = tx * TW + (m & 15);
+      if (ho >= p.H || wo >= p.W) continue;
+      const size_t row = (((size_t)n * p.H + ho) * p.W + wo) * p.Cout;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int j = n0 + wn * 32 * NB + b * 32 + (lane & 31);
+        if (j >= p.Cout) continue;
+        float v = acc[a][b][r];
+        if (part) {
+          part[row + j] = v;
+        } else {
+          if (p.bias) v += p.bias[j];
+          if (p.relu) v = fmaxf(v, 0.f);
+          p.y[row + j] = v;
+        }
+      }
+    }
+  }
+}
+
 int g_halo_last_nb = 0, g_halo_last_splits = 0;
-int g_halo_force_splits = -1;
+int g_halo_force_splits = -1, g_halo_variant = 2;
 
 int halo_bfx_plan(long long M, int tiles_m, int Cin, int Cout, int& nb) {
   nb = Cout <= 64 ? 1 : 2;
   const int tiles_n = (Cout + 64 * nb - 1) / (64 * nb);
   const long long wgs = (long long)tiles_m * tiles_n;
   const int cchunks = Cin / 16;
-  // measured (profiles/r2a_bfx_sweep.txt): 263 workgroups -> 4 slices, 526 -> 4, 2100 -> 1
+  // measured (profiles/r2g_bfx_sweep.txt; 768 resident workgroups): 68 workgroups -> 8 slices,
+  // 132 -> 4, 263 -> 2, 526 -> 2, 1050 / 2100 -> 1
   int want = 1;
-  if (wgs < 1500) want = (int)((2047 + wgs) / wgs);
+  if (wgs < 100) want = 8;
+  else if (wgs < 200) want = 4;
+  else if (wgs < 700) want = 2;
   if (want > cchunks / 2) want = cchunks / 2;
   if (want > 8) want = 8;
   if (g_halo_force_splits >= 1) want = g_halo_force_splits < cchunks ? g_halo_force_splits : cchunks;
@@ -691,7 +903,10 @@ extern "C" size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int 
   return want > 1 ? (size_t)want * (size_t)N * H * W * Cout * sizeof(float) : 0;
 }
 
-extern "C" void bgs_conv3x3_halo_bfx_tuning(int splits) { g_halo_force_splits = splits; }
+extern "C" void bgs_conv3x3_halo_bfx_tuning(int splits, int variant) {
+  g_halo_force_splits = splits;
+  g_halo_variant = variant == 1 ? 1 : 2;     // 1 = first version (2 workgroups / CU), 2 = unrolled, 3 / CU (default)
+}
 
 extern "C" int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits) {
   if (nb) *nb = g_halo_last_nb;
@@ -738,10 +953,17 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit,
   g_halo_last_nb = nb;
   g_halo_last_splits = splits;
   dim3 grid((unsigned)(8 * p.chunk), 1u, (unsigned)splits);
-  if (nb == 1)
-    hipLaunchKernelGGL(conv3x3_halo_bfx_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
-  else
-    hipLaunchKernelGGL(conv3x3_halo_bfx_kernel<2>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+  if (g_halo_variant == 1) {
+    if (nb == 1)
+      hipLaunchKernelGGL(conv3x3_halo_bfx_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    else
+      hipLaunchKernelGGL(conv3x3_halo_bfx_kernel<2>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+  } else {
+    if (nb == 1)
+      hipLaunchKernelGGL(conv3x3_halo_bfx3_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    else
+      hipLaunchKernelGGL(conv3x3_halo_bfx3_kernel<2>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+  }
   if (splits > 1) {
     if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
     return bgs_internal_conv_splitk_epilogue(p, splits, (hipStream_t)stream);

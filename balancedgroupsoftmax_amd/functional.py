@@ -295,11 +295,11 @@ def bfx_split_weights(w2d, cache=True):
     return out
 
 
-def conv_bfx_tuning(tile=0, splitk=-1, halo_splits=-1):
+def conv_bfx_tuning(tile=0, splitk=-1, halo_splits=-1, halo_variant=2):
     """Process-wide tuning / test hook of the bf16x6 kernels (see include/bgs.h)."""
     lib = capi.load()
     lib.bgs_conv_bfx_tuning(int(tile), int(splitk))
-    lib.bgs_conv3x3_halo_bfx_tuning(int(halo_splits))
+    lib.bgs_conv3x3_halo_bfx_tuning(int(halo_splits), int(halo_variant))
 
 
 def conv_bfx_last_launch():
@@ -326,14 +326,15 @@ def conv_last_launch():
 
 
 def _use_halo_bfx(M, Cout):
-    """bf16x6 path: the halo kernel wins on the large maps (profiles/r2a_bfx_sweep.txt: P2 0.86 vs
-    1.07 ms, P3 0.25 vs 0.30, layer1/2 conv2), ties at M = 8400 and below."""
+    """bf16x6 path: the halo kernel wins on every 3x3 stride-1 layer of cfg[1] down to the 25x42
+    maps (profiles/r2g_bfx_sweep.txt: P2 0.74 vs 1.01 ms, P3 0.22 vs 0.28, M = 8400: 0.078 vs
+    0.089, M = 2100: 0.035 vs 0.039); the 13x21 level (M = 546) stays on the general kernel."""
     env = os.environ.get('BGS_CONV_HALO')
     if env == '1':
         return True
     if env == '0':
         return False
-    return M >= 30000
+    return M >= 2000
 
 
 def _use_halo_kernel(M, Cout):

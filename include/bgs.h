@@ -258,7 +258,7 @@ int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const floa
                                   void* workspace, size_t workspace_bytes, bgs_stream_t stream);
 void bgs_conv_bfx_tuning(int tile, int splitk);
 int bgs_conv_bfx_last_launch(int* tile, int* splits);
-void bgs_conv3x3_halo_bfx_tuning(int splits);
+void bgs_conv3x3_halo_bfx_tuning(int splits, int variant);
 int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits);
 
 /* Grouped 3x3 convolution (pad 1, stride 1 or 2) + bias + ReLU, NHWC: conv2 of the ResNeXt

@@ -511,7 +511,7 @@ def test_conv3x3_halo_kernel_vs_torch_cpu(monkeypatch, shape, conv_math):
         assert use_halo == (N * H * W >= 100000 and Cout % 128 == 0)
     else:
         use_halo = BF._use_halo_bfx(N * H * W, Cout)
-        assert use_halo == (N * H * W >= 30000)
+        assert use_halo == (N * H * W >= 2000)
     assert torch.equal(dflt, got if use_halo else gen)
 
 

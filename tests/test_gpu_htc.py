@@ -154,7 +154,11 @@ def test_htc_mask_head_chain_vs_executed_reference_golden():
     # of dx within 2e-4, worst 0.96 % of the largest entry
     assert close(x.grad.permute(0, 3, 1, 2)[:, :, ::5, ::3].cpu().numpy(), z['msk/dx'], frac=0.75,
                  worst=3e-2)
-    assert close(h1.conv_res.conv.weight.grad[::2, ::2].cpu().numpy(), z['msk/dres_w'])
+    # (which pre-activations flip depends on the summation order of the kernel that ran: measured
+    # 0.91 of the entries within tol under the fp32 MFMA kernels, 0.78 under bf16x6 — while dx and
+    # the deepest gradient below come out CLOSER under bf16x6: 0.88 / 0.16 vs 0.84 / 0.11,
+    # tools/debug/htc_chain_metrics.py)
+    assert close(h1.conv_res.conv.weight.grad[::2, ::2].cpu().numpy(), z['msk/dres_w'], frac=0.7)
     # the deepest weight gradient sums every position's (flip-perturbed) contribution: uniform
     # noise instead of a few outliers (measured: worst 0.58 % of the largest entry, rel-L2 4.8e-3)
     assert close(h0.convs[0].conv.weight.grad[::16, ::16].cpu().numpy(), z['msk/dh0_conv0_w'],

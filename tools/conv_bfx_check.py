@@ -171,19 +171,21 @@ def sweep(quick):
         t32 = run('f32', lambda: bench(lambda: BF.conv2d_nhwc(x, w, b, stride=stride, pad=pad, relu=True)))
         res = {}
         os.environ['BGS_CONV_HALO'] = '0'
-        cfgs = [0] if quick else [0, 22, 21, 12, 11]
-        for tile in cfgs:
+        cfgs = [(0, -1)] if quick else [(0, -1), (11, -1), (12, -1), (22, -1)]
+        for tile, sk in cfgs:
             if tile == 22 and M * Cout < 128 * 128 * 64:
                 continue
-            BF.conv_bfx_tuning(tile, -1)
-            res['t%d' % tile] = run('bf16x6', lambda: bench(
+            if sk > 1 and R * R * Cin // 16 < 2 * sk:
+                continue
+            BF.conv_bfx_tuning(tile, sk)
+            res['t%d/%d' % (tile, sk)] = run('bf16x6', lambda: bench(
                 lambda: BF.conv2d_nhwc(x, w, b, stride=stride, pad=pad, relu=True)))
         BF.conv_bfx_tuning()
         if R == 3 and stride == 1 and Cin % 16 == 0:
             os.environ['BGS_CONV_HALO'] = '1'
-            for hs in ([-1] if quick else [-1, 1, 2, 4]):
-                BF.conv_bfx_tuning(halo_splits=hs)
-                res['halo/%d' % hs] = run('bf16x6', lambda: bench(
+            for hv, hs in ([(2, -1)] if quick else [(1, -1), (2, -1), (2, 1), (2, 2), (2, 4), (2, 8)]):
+                BF.conv_bfx_tuning(halo_splits=hs, halo_variant=hv)
+                res['halo%d/%d' % (hv, hs)] = run('bf16x6', lambda: bench(
                     lambda: BF.conv2d_nhwc(x, w, b, stride=1, pad=1, relu=True)))
             BF.conv_bfx_tuning()
         os.environ.pop('BGS_CONV_HALO', None)

@@ -1,0 +1,9 @@
+mkdir -p gpurun_out/r2g
+timeout 900 python tools/conv_bfx_check.py --out gpurun_out/r2g/bfx_sweep.txt > gpurun_out/r2g/bfx_check.log 2>&1
+echo "bfx_check rc=$?"; grep -c " ok" gpurun_out/r2g/bfx_check.log; grep "BAD\|CORRECT\|MISMATCH\|Error\|error" gpurun_out/r2g/bfx_check.log | head
+timeout 300 python bench.py --steps 20 --warmup 5 > gpurun_out/r2g/bench.json 2> gpurun_out/r2g/bench.err
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r2g/bench.json'))
+print({k:d[k] for k in ('value','ms_per_step','ms_per_step_eager')}, d['roofline']['ms_per_launch'], {k:v['ms_per_step'] for k,v in d['also_measured'].items()})
+PY
