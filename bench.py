@@ -59,9 +59,15 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true',
                     help='skip the per-kernel roofline timings (used by the extras sub-runs)')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches, not hipGraph replay')
+    ap.add_argument('--conv-math', default=None, choices=['bf16x6', 'f32'],
+                    help="conv / linear arithmetic: 'bf16x6' (default; bf16 MFMA on exactly split fp32 "
+                         "operands, fp32-faithful) or 'f32' (v_mfma_f32_32x32x2_f32)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     a = ap.parse_args()
+    if a.conv_math is not None:
+        BF.set_conv_math(a.conv_math)
+    a.conv_math = BF.conv_math()
     if a.steps is None:
         a.steps = 30 if a.workload == 'detector' else 200
     if a.warmup is None:
@@ -305,43 +311,74 @@ class DetectorStep(object):
         self.apply()
 
 
-def conv_roofline(dev, iters=20):
-    """Dominant kernel of the detector step: the fp32-MFMA implicit-GEMM conv.  Timed on the
-    largest single layer (FPN output conv on P2: 2x200x336 pixels, 3x3, 256->256 = 158.6 GFLOP)
-    with HIP events on the launch stream.  Peak: 157.3 TFLOP/s fp32 matrix (MI355X_MICROARCH.md)."""
-    x = torch.randn(2, 200, 336, 256, device=dev)
-    w = torch.randn(256, 3, 3, 256, device=dev) * 0.02
-    b = torch.randn(256, device=dev)
-    out = torch.empty(2, 200, 336, 256, device=dev)
-    for _ in range(3):
-        BF.conv2d_nhwc(x, w, b, pad=1, out=out)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        BF.conv2d_nhwc(x, w, b, pad=1, out=out)
-    e1.record()
-    torch.cuda.synchronize()
+CONV_MATH_NOTE = {
+    'bf16x6': 'fp32 tensors in HBM, fp32 accumulate, fp32 results; each fp32 product is formed on the '
+              'bf16 matrix cores from the exact three-way bf16 split of both operands (six partial '
+              'products, dropped terms <= 2^-25 |ab|): error vs fp64 not above the fp32 MFMA kernel\'s '
+              '(tests/test_gpu_det_ops.py::test_bfx_error_not_above_f32_mfma)',
+    'f32': 'v_mfma_f32_32x32x2_f32: fp32 in / fp32 accumulate, bit-exact fma chain',
+}
+
+
+def conv_roofline(dev, math, iters=20):
+    """Dominant kernel of the detector step: the 3x3 halo convolution.  Timed on the largest single
+    layer (FPN output conv on P2: 2x200x336 pixels, 3x3, 256->256 = 158.5 algorithmic GFLOP) with
+    HIP events on the launch stream.  `achieved` = ALGORITHMIC flops / time.  Peaks
+    (MI355X_MICROARCH.md): fp32 matrix 157.3 TFLOP/s; bf16 matrix 2500 TFLOP/s dense — the bf16x6
+    kernel spends SIX bf16 MFMA passes per algorithmic fp32 multiply-add, so its matrix-pipe
+    ceiling in algorithmic flops is 2500 / 6 = 416.7 TFLOP/s (frac = matrix-pipe busy fraction)."""
+    prev = BF.set_conv_math(math)
+    try:
+        x = torch.randn(2, 200, 336, 256, device=dev)
+        w = torch.randn(256, 3, 3, 256, device=dev) * 0.02
+        b = torch.randn(256, device=dev)
+        out = torch.empty(2, 200, 336, 256, device=dev)
+        for _ in range(3):
+            BF.conv2d_nhwc(x, w, b, pad=1, out=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            BF.conv2d_nhwc(x, w, b, pad=1, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+    finally:
+        BF.set_conv_math(prev)
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * 2 * 200 * 336 * 256 * 256 * 9
     tf = flops / (ms * 1e-3) / 1e12
-    halo = BF._use_halo_kernel(2 * 200 * 336, 256)
-    kname = 'conv3x3_halo_f32_kernel' if halo else 'conv_igemm_f32_kernel<2,2,16,1>'
-    traffic = None
-    try:      # HBM-side bytes per launch from the committed PMC passes (profiles/r3l_pmc_conv.md)
+    if math == 'bf16x6':
+        kname = 'conv3x3_halo_bfx3_kernel<2>'
+        kdesc = kname + ' (halo-resident A operand split to 3 bf16 planes in LDS, v_mfma_f32_32x32x16_bf16 x 6)'
+        peak, passes = 2500.0 / 6.0, 6
+    else:
+        halo = BF._use_halo_kernel(2 * 200 * 336, 256)
+        kname = 'conv3x3_halo_f32_kernel' if halo else 'conv_igemm_f32_kernel<2,2,16,1>'
+        kdesc = kname + ' (v_mfma_f32_32x32x2_f32)'
+        peak, passes = 157.3, 1
+    traffic = src = None
+    try:      # HBM-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs)
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
                                'pmc_traffic.json')) as f:
-            traffic = json.load(f)[kname]['fpn_p2_out_2x200x336_3x3_256_256'][
-                'traffic_bytes_per_launch']
+            ent = json.load(f)[kname]['fpn_p2_out_2x200x336_3x3_256_256']
+        traffic, src = ent['traffic_bytes_per_launch'], ent['source']
     except Exception:
         pass
-    return dict(bound='mfma', achieved=round(tf, 2), peak=157.3, unit='TFLOP/s',
-                frac=round(tf / 157.3, 4), traffic=traffic,
-                kernel=('conv3x3_halo_f32_kernel (halo-resident A operand, v_mfma_f32_32x32x2_f32)'
-                        if halo else 'conv_igemm_f32_kernel<2,2> (v_mfma_f32_32x32x2_f32)'),
-                ms_per_launch=round(ms, 4), flops_per_launch=flops,
-                layer='FPN output conv P2: N=2, 200x336, 3x3, 256->256 (M=134400, K=2304)',
-                timing='hipEvent over %d back-to-back launches' % iters)
+    r = dict(bound='mfma', achieved=round(tf, 2), peak=round(peak, 1), unit='TFLOP/s',
+             frac=round(tf / peak, 4), traffic=traffic,
+             traffic_source=('committed PMC measurement of this kernel on this layer, not collected '
+                             'in this run: %s' % src) if src else None,
+             algorithmic_bytes=277610496, kernel=kdesc, ms_per_launch=round(ms, 4),
+             flops_per_launch=flops,
+             layer='FPN output conv P2: N=2, 200x336, 3x3, 256->256 (M=134400, K=2304)',
+             timing='hipEvent over %d back-to-back launches' % iters)
+    if passes > 1:
+        r.update(mfma_dtype='bf16', mfma_passes_per_flop=passes,
+                 matrix_pipe_tflops=round(tf * passes, 1), peak_bf16_dense=2500.0,
+                 peak_note='algorithmic-flop ceiling of the bf16x6 kernel = 2500 (bf16 dense MFMA) / 6 '
+                           'passes; against the fp32-MFMA peak (157.3) the same launch is %.2fx'
+                           % (tf / 157.3))
+    return r
 
 
 def timed_loop(fn, steps, warmup, world):
@@ -447,6 +484,7 @@ def cpu_baseline(n, seconds):
     l2b_t, ps_t = torch.from_numpy(l2b), torch.from_numpy(ps)
     cores = os.cpu_count() or 1
     best = None
+    tried = {}
     # torch-CPU oversubscribes badly on many-core hosts: report the best thread count tried
     for nt in sorted(set([1, 8, 32, min(cores, 64)])):
         if nt > cores:
@@ -462,15 +500,36 @@ def cpu_baseline(n, seconds):
             gs_torch_port.gs_loss_fwd_bwd(z, lab, l2b_t, ps_t, 8.0)
             times.append(time.perf_counter() - t0)
         med = float(np.median(times))
+        tried[str(nt)] = round(med * 1e6 / n, 4)
         if best is None or med < best[0]:
             best = (med, nt, len(times))
     med, nt, cnt = best
     return dict(value=round(med * 1e6 / n, 4), unit='us/RoI', cores=nt, kind='port',
-                host_cores=cores,
+                host_cores=cores, threads_tried=tried,
                 sample='%d x (loss+backward) of the torch-CPU port of GSBBoxHeadWith0.loss '
                        '(oracle/gs_torch_port.py) on N=%d RoIs x 1236 logits (cls branch, numpy '
                        'sampling incl.), median; best of 1/8/32/64 threads = %d; torch %s'
-                       % (cnt, n, nt, torch.__version__))
+                       % (cnt, n, nt, torch.__version__),
+                port_vs_reference_class='the port is ~3x FASTER than the executed reference class '
+                                        'it stands in for (BASELINE.md section 2: GSBBoxHeadWith0.'
+                                        'loss()+backward() itself, N=1024: 3.11 us/RoI at 8 threads, '
+                                        '12.04 us/RoI at 1 thread, authoring container) — it fuses '
+                                        'the per-bin python loop; the reference class cannot be '
+                                        'timed on the GPU box (/root/reference does not travel)')
+
+
+def cpu_baseline_detector():
+    """The EXECUTED reference detector's whole training iteration on CPU (cfg[1], same inputs as
+    this bench): measured in the authoring container (tools/ref_cpu_detector_time.py), quoted from
+    the committed record — /root/reference does not exist on the GPU box."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                        'r2v_reference_detector_cpu_time.jsonl')
+    try:
+        recs = [json.loads(ln) for ln in open(path) if ln.strip().startswith('{')]
+        return dict(kind='reference', where='authoring container (not this host)', records=recs,
+                    source='profiles/r2v_reference_detector_cpu_time.jsonl')
+    except Exception:
+        return None
 
 
 def extras(dev, args):
@@ -480,7 +539,8 @@ def extras(dev, args):
     (this script with --no-extras), so a failure there can never take the headline line down."""
     import subprocess
     res = {}
-    runs = (('selectp0', ['--selectp', '0']),
+    runs = (('f32_mfma_math_selectp1', ['--conv-math', 'f32']),
+            ('selectp0', ['--selectp', '0']),
             ('mask_rcnn_selectp1', ['--mask']),
             ('mask_rcnn_selectp0', ['--mask', '--selectp', '0']),
             ('cascade_x101_64x4d_selectp3_fp32', ['--cascade', '--selectp', '3']),
@@ -488,7 +548,8 @@ def extras(dev, args):
     for key, flags in runs:
         cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'detector', '--steps', '10',
                '--warmup', '3', '--imgs', str(args.imgs), '--no-extras', '--no-cpu-baseline',
-               '--no-roofline'] + flags + (['--no-graph'] if args.no_graph else [])
+               '--no-roofline'] + (['--conv-math', args.conv_math] if '--conv-math' not in flags else []) \
+            + flags + (['--no-graph'] if args.no_graph else [])
         try:
             out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
             line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')]
@@ -497,6 +558,7 @@ def extras(dev, args):
                 continue
             d = json.loads(line[-1])
             res[key] = {'img_per_s': d['value'], 'ms_per_step': d['ms_per_step'],
+                        'conv_math': d['config'].get('conv_math_mode'),
                         'trainable_params': d['config']['trainable_params'],
                         'loss': d['last_losses']['loss'], 'launch': d['config']['launch']}
         except Exception as e:  # pragma: no cover
@@ -513,7 +575,7 @@ def run_graph_child(args):
     cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'detector', '--child',
            '--gpus', '1', '--steps', str(args.steps), '--warmup', str(args.warmup),
            '--imgs', str(args.imgs), '--selectp', str(args.selectp), '--no-extras',
-           '--no-cpu-baseline', '--no-roofline']
+           '--no-cpu-baseline', '--no-roofline', '--conv-math', args.conv_math]
     cmd += (['--mask'] if args.mask else []) + (['--cascade'] if args.cascade else [])
     cmd += ['--htc'] if args.htc else []
     try:
@@ -534,14 +596,22 @@ def finish_line(out, args, dev, world):
             and not args.cascade and not args.htc:
         out['also_measured'] = extras(dev, args)
     if not args.no_roofline:
-        out['roofline'] = conv_roofline(dev)
+        out['roofline'] = conv_roofline(dev, args.conv_math)
+        if args.conv_math != 'f32':
+            out['roofline_f32_mfma_kernel'] = conv_roofline(dev, 'f32')
         gs_inp = make_inputs(1024, seed=1000, dev=dev)
         out['roofline_gs_loss'] = kernel_roofline(gs_inp, 1024)
     if world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(1024, args.cpu_seconds)
         cb['note'] = ('GroupSoftmax loss()+backward() only: the reference cannot run the whole '
-                      'detector on CPU (its RoIAlign has no CPU path, roi_align.py:27-28)')
+                      'detector on CPU as shipped (its RoIAlign has no CPU path, roi_align.py:27-28); '
+                      'see cpu_baseline_detector for the whole iteration with its ops built for the host')
         out['cpu_baseline'] = cb
+        out['cpu_baseline_1thread'] = {'value': cb['threads_tried'].get('1'), 'unit': 'us/RoI',
+                                       'cores': 1, 'kind': 'port'}
+        cbd = cpu_baseline_detector()
+        if cbd:
+            out['cpu_baseline_detector'] = cbd
     print(json.dumps(out), flush=True)
 
 
@@ -588,9 +658,12 @@ def main_detector(args, rank, local, world, dev):
                       'fwd+bwd R50-FPN+BAGS 1333x800, 512 RoI; GroupSoftmax us/RoI)',
             'value': round(imgs_per_s, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.conv_math == 'f32' else 'f32 (conv/linear products on the bf16 MFMA '
+                     'from exact 3-way bf16 splits, fp32 accumulate: fp32-faithful)',
             'data': 'synthetic',
-            'config': {'workload': cfg_name + ' training '
+            'config': {'conv_math_mode': args.conv_math, 'conv_math': CONV_MATH_NOTE[args.conv_math],
+                       'workload': cfg_name + ' training '
                                    'iteration %s, grad all-reduce, clip 35, SGD): '
                                    '%d img/GPU, 3x800x1344 (1333x800 padded /32), 20 GT/img, '
                                    '512 RoI/img, 1231 classes, 5 bins; random-init weights'
@@ -609,7 +682,10 @@ def main_detector(args, rank, local, world, dev):
                                   'clip+SGD)') if graph else 'eager launches',
                        'parallelism': 'dp%d (one process per GPU; flat fp32 all-reduce of the '
                                       '%d trainable grads over RCCL)'
-                                      % (world, sum(p.numel() for p in step.params))},
+                                      % (world, sum(p.numel() for p in step.params)),
+                       'ranks': world,
+                       'collective_backend': (__import__('torch.distributed').distributed.get_backend()
+                                              if world > 1 else None)},
             'img_per_s_per_gpu': round(imgs_per_s / world, 3),
             'last_losses': lv,
         }
@@ -622,14 +698,35 @@ def main_detector(args, rank, local, world, dev):
     barrier(world)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run (one
+    process per GPU, the reference's tools/dist_train.sh:8-9 layout) and relay its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
+           str(args.gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product has no CPU path)')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     rank, local, world = init_dist(args)
     if world != args.gpus:
-        sys.stderr.write('note: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)\n'
-                         % (args.gpus, world))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d: the line would report the wrong '
+                         'n_gpus' % (args.gpus, world))
+    if world > 1:
+        import torch.distributed as dist
+        assert dist.get_world_size() == args.gpus
     dev = torch.device('cuda', local)
     if args.workload == 'detector':
         return main_detector(args, rank, local, world, dev)
