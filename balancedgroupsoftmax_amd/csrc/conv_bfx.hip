@@ -43,6 +43,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[16];
 
 struct BfxArgs {
+  int ns;                // operand planes used: 3 = fp32-faithful (six products), 1 = bf16 operands
   ConvArgs c;
   const __bf16* ws;      // split weights [NS][KC][Cout][16]
   int KC;                // ceil(K / 16)
@@ -294,6 +295,7 @@ constexpr int AQ = PROWS * 4;                                               // f
 constexpr int AQT = (AQ + kThreads - 1) / kThreads;                         // 3 per thread
 
 struct HaloBfxArgs {
+  int ns;
   ConvArgs c;            // x, bias, y, N, H, W, Cin, Cout, relu, M, partial, tiles_m/n, chunk
   const __bf16* ws;      // split weights [3][KC][Cout][16], K = 9 * Cin
   int KC;
@@ -497,13 +499,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx_kernel(HaloBfxAr
 // on four SIMDs, each shared with ONE wave of another workgroup, and every barrier couples them;
 // a third resident workgroup fills the gaps.  (A mid-step barrier / fragment read-ahead pipeline
 // inside the wave, as in conv_igemm.hip, measured +0 % here and cost 44 VGPRs: dropped.)
-template <int NB>
+template <int NB, int NS>
 __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxArgs q) {
   const ConvArgs& p = q.c;
   constexpr int BN = 64 * NB;
-  constexpr int A_PLANE = PROWS * HLDR, A_BYTES = 3 * A_PLANE;
-  constexpr int B_PLANE = BN * 32, B_BUF = 3 * B_PLANE;
-  constexpr int NPIECE = 3 * BN * 2;
+  constexpr int A_PLANE = PROWS * HLDR, A_BYTES = NS * A_PLANE;
+  constexpr int B_PLANE = BN * 32, B_BUF = NS * B_PLANE;
+  constexpr int NPIECE = NS * BN * 2;
   constexpr int PB = (NPIECE + kThreads - 1) / kThreads;
   __shared__ __attribute__((aligned(16))) unsigned char lds[A_BYTES + 2 * B_BUF];
 
@@ -571,8 +573,8 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxA
       split3(ra[i], h, m, l);
       unsigned char* d = lds + (a_dst[i] >> 1);
       *reinterpret_cast<u32x2*>(d) = h;
-      *reinterpret_cast<u32x2*>(d + A_PLANE) = m;
-      *reinterpret_cast<u32x2*>(d + 2 * A_PLANE) = l;
+      if (NS >= 2) *reinterpret_cast<u32x2*>(d + A_PLANE) = m;
+      if (NS >= 3) *reinterpret_cast<u32x2*>(d + 2 * A_PLANE) = l;
     }
   };
   auto load_b = [&](int chunk, int tap) {
@@ -625,9 +627,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxA
       constexpr int dummy = 0;
       (void)dummy;
       const int tap_off = ((tap / 3) * PW + (tap % 3)) * HLDR;    // compile-time constant
-      bf16x8 fa[3][2], fb[3][NB];
+      bf16x8 fa[NS][2], fb[NS][NB];
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
+      for (int s = 0; s < NS; ++s) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
           fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a] + tap_off + s * A_PLANE);
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxA
           fb[s][b] = *reinterpret_cast<const bf16x8*>(lds + rd + b_frag + s * B_PLANE + b * 32 * 32);
       }
 #pragma unroll
-      for (int tt = 2; tt >= 0; --tt)
+      for (int tt = NS - 1; tt >= 0; --tt)
 #pragma unroll
         for (int i = 0; i <= tt; ++i)
 #pragma unroll
@@ -765,10 +767,13 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   dim3 grid((unsigned)(8 * p.chunk), 1u, (unsigned)splits);
   g_last_tile = tile;
   g_last_splits = splits;
-#define BFX_L(MB_, NB_, UP_) \
-  hipLaunchKernelGGL((conv_igemm_bfx_kernel<MB_, NB_, 16, 3, UP_>), grid, dim3(kThreads), 0, st, q)
-#define BFX_T(MB_, NB_) \
-  do { if (up == 2) BFX_L(MB_, NB_, 2); else BFX_L(MB_, NB_, 1); } while (0)
+#define BFX_L(MB_, NB_, NS_, UP_) \
+  hipLaunchKernelGGL((conv_igemm_bfx_kernel<MB_, NB_, 16, NS_, UP_>), grid, dim3(kThreads), 0, st, q)
+#define BFX_T(MB_, NB_)                                                                  \
+  do {                                                                                   \
+    if (q.ns == 1) { if (up == 2) BFX_L(MB_, NB_, 1, 2); else BFX_L(MB_, NB_, 1, 1); }   \
+    else { if (up == 2) BFX_L(MB_, NB_, 3, 2); else BFX_L(MB_, NB_, 3, 1); }             \
+  } while (0)
   if (tile == 22) BFX_T(2, 2);
   else if (tile == 21) BFX_T(2, 1);
   else if (tile == 12) BFX_T(1, 2);
@@ -828,17 +833,19 @@ extern "C" int bgs_conv_bfx_last_launch(int* tile, int* splits) {
 extern "C" int bgs_conv2d_nhwc_f32_bfx_ws(const float* x, const void* wsplit, const float* bias,
                                           const float* residual, float* y, int N, int H, int W,
                                           int Cin, int Cout, int R, int S, int stride, int pad,
-                                          int relu, int residual_mode, void* workspace,
+                                          int relu, int residual_mode, int planes, void* workspace,
                                           size_t workspace_bytes, bgs_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
       pad < 0)
     return BGS_ERR_INVALID_ARG;
   if (!x || !wsplit || !y) return BGS_ERR_INVALID_ARG;
+  if (planes != 1 && planes != 3) return BGS_ERR_INVALID_ARG;
   if (Cin % 4 != 0) return BGS_ERR_UNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)wsplit) % 16 != 0) return BGS_ERR_INVALID_ARG;
   if (residual_mode < 0 || residual_mode > 2 || (residual_mode != 0 && !residual))
     return BGS_ERR_INVALID_ARG;
   BfxArgs q;
+  q.ns = planes;
   ConvArgs& p = q.c;
   p.x = x; p.w = nullptr; p.bias = bias; p.res = residual; p.mask = nullptr; p.y = y;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S;
@@ -863,12 +870,13 @@ extern "C" int bgs_conv2d_nhwc_f32_bfx_ws(const float* x, const void* wsplit, co
 extern "C" int bgs_conv2d_dgrad_nhwc_f32_bfx_ws(const float* dy, const void* wt_split,
                                                 const float* residual, const float* mask, float* dx,
                                                 int N, int H, int W, int Cin, int Cout, int R, int S,
-                                                int stride, int pad, int residual_mode,
+                                                int stride, int pad, int residual_mode, int planes,
                                                 void* workspace, size_t workspace_bytes,
                                                 bgs_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || pad < 0)
     return BGS_ERR_INVALID_ARG;
   if (!dy || !wt_split || !dx) return BGS_ERR_INVALID_ARG;
+  if (planes != 1 && planes != 3) return BGS_ERR_INVALID_ARG;
   if (stride != 1 && stride != 2) return BGS_ERR_UNSUPPORTED;
   if (Cout % 4 != 0) return BGS_ERR_UNSUPPORTED;
   if (((uintptr_t)dy | (uintptr_t)wt_split) % 16 != 0) return BGS_ERR_INVALID_ARG;
@@ -879,6 +887,7 @@ extern "C" int bgs_conv2d_dgrad_nhwc_f32_bfx_ws(const float* dy, const void* wt_
   const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return BGS_ERR_INVALID_ARG;
   BfxArgs q;
+  q.ns = planes;
   ConvArgs& p = q.c;
   p.x = dy; p.w = nullptr; p.bias = nullptr; p.res = residual; p.mask = mask; p.y = dx;
   p.N = N; p.H = Ho; p.W = Wo; p.Cin = Cout; p.Cout = Cin; p.R = R; p.S = S;
@@ -917,15 +926,17 @@ extern "C" int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits) {
 // 3x3 / stride 1 / pad 1, Cin % 16 == 0; wsplit = bgs_conv_bfx_split_weights of [Cout][3][3][Cin].
 extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias,
                                              float* y, int N, int H, int W, int Cin, int Cout,
-                                             int relu, void* workspace, size_t workspace_bytes,
-                                             bgs_stream_t stream) {
+                                             int relu, int planes, void* workspace,
+                                             size_t workspace_bytes, bgs_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BGS_ERR_INVALID_ARG;
   if (!x || !wsplit || !y) return BGS_ERR_INVALID_ARG;
+  if (planes != 1 && planes != 3) return BGS_ERR_INVALID_ARG;
   if (Cin % 16 != 0) return BGS_ERR_UNSUPPORTED;
   if ((uintptr_t)x % 16 != 0 || (uintptr_t)wsplit % 16 != 0) return BGS_ERR_UNSUPPORTED;
   const long long M = (long long)N * H * W;
   if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
   HaloBfxArgs q;
+  q.ns = planes;
   ConvArgs& p = q.c;
   p.x = x; p.w = nullptr; p.bias = bias; p.res = nullptr; p.mask = nullptr; p.y = y;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = 3; p.S = 3; p.stride = 1; p.pad = 1;
@@ -953,16 +964,22 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit,
   g_halo_last_nb = nb;
   g_halo_last_splits = splits;
   dim3 grid((unsigned)(8 * p.chunk), 1u, (unsigned)splits);
-  if (g_halo_variant == 1) {
+  if (g_halo_variant == 1 && q.ns == 3) {
     if (nb == 1)
       hipLaunchKernelGGL(conv3x3_halo_bfx_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
     else
       hipLaunchKernelGGL(conv3x3_halo_bfx_kernel<2>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
   } else {
-    if (nb == 1)
-      hipLaunchKernelGGL(conv3x3_halo_bfx3_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
-    else
-      hipLaunchKernelGGL(conv3x3_halo_bfx3_kernel<2>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    if (q.ns == 1) {
+      if (nb == 1)
+        hipLaunchKernelGGL((conv3x3_halo_bfx3_kernel<1, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+      else
+        hipLaunchKernelGGL((conv3x3_halo_bfx3_kernel<2, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    } else if (nb == 1) {
+      hipLaunchKernelGGL((conv3x3_halo_bfx3_kernel<1, 3>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    } else {
+      hipLaunchKernelGGL((conv3x3_halo_bfx3_kernel<2, 3>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    }
   }
   if (splits > 1) {
     if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;

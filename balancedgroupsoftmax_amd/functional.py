@@ -248,15 +248,17 @@ def bbox_smooth_l1_loss(bbox_pred, labels, bbox_targets, bbox_weights, num_reg_c
 # conv / linear on the matrix cores (NHWC fp32 activations, [Cout,R,S,Cin] fp32 weights)
 #   math 'bf16x6' (default): bf16 MFMA on exactly split operands, fp32-faithful (csrc/conv_bfx.hip)
 #   math 'f32':              v_mfma_f32_32x32x2_f32 (csrc/conv_igemm.hip, csrc/conv_halo.hip)
+#   math 'bf16':             operands rounded to bf16 for the MFMA, fp32 accumulate / storage: the
+#                            arithmetic of the reference's fp16 autocast (mmdet/core/fp16/) — cfg[4]
 # ----------------------------------------------------------------------------------------
 _CONV_MATH = [os.environ.get('BGS_CONV_MATH', 'bf16x6')]
 
 
 def set_conv_math(mode):
-    """'bf16x6' | 'f32'; returns the previous mode.  Both give fp32-accurate results (the split
-    kernel's error against fp64 is not above the fp32 MFMA kernel's); 'f32' keeps the bit-exact
-    fp32 fma chain."""
-    assert mode in ('bf16x6', 'f32'), mode
+    """'bf16x6' | 'f32' | 'bf16'; returns the previous mode.  The first two give fp32-accurate
+    results (the split kernel's error against fp64 is not above the fp32 MFMA kernel's; 'f32'
+    keeps the bit-exact fp32 fma chain); 'bf16' is the reduced-precision mode of cfg[4]."""
+    assert mode in ('bf16x6', 'f32', 'bf16'), mode
     prev = _CONV_MATH[0]
     _CONV_MATH[0] = mode
     return prev
@@ -371,7 +373,8 @@ def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None
     if out is None:
         out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
     halo_ok = R == 3 and S == 3 and stride == 1 and pad == 1 and residual is None and Cin % 16 == 0
-    if _CONV_MATH[0] == 'bf16x6':
+    if _CONV_MATH[0] != 'f32':
+        planes = 3 if _CONV_MATH[0] == 'bf16x6' else 1
         wsplit = bfx_split_weights(w_krsc.view(Cout, R * S * Cin))
         st = capi.current_stream(x.device)
         if halo_ok and _use_halo_bfx(N * Ho * Wo, Cout):
@@ -379,7 +382,7 @@ def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None
             ws = _workspace(wsb, x.device) if wsb else None
             rc = lib.bgs_conv3x3_halo_nhwc_f32_bfx(capi.ptr(x), capi.ptr(wsplit), capi.ptr(bias),
                                                    capi.ptr(out), N, H, W, Cin, Cout,
-                                                   int(bool(relu)), capi.ptr(ws), wsb, st)
+                                                   int(bool(relu)), planes, capi.ptr(ws), wsb, st)
             capi.check('bgs_conv3x3_halo_nhwc_f32_bfx', rc)
             return out
         wsb = lib.bgs_conv_bfx_workspace_bytes(N * Ho * Wo, Cout, R * S * Cin)
@@ -387,7 +390,7 @@ def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None
         rc = lib.bgs_conv2d_nhwc_f32_bfx_ws(capi.ptr(x), capi.ptr(wsplit), capi.ptr(bias),
                                             capi.ptr(residual), capi.ptr(out), N, H, W, Cin, Cout,
                                             R, S, stride, pad, int(bool(relu)), residual_mode,
-                                            capi.ptr(ws), wsb, st)
+                                            planes, capi.ptr(ws), wsb, st)
         capi.check('bgs_conv2d_nhwc_f32_bfx_ws', rc)
         return out
     if halo_ok and _use_halo_kernel(N * Ho * Wo, Cout):
@@ -444,14 +447,16 @@ def conv2d_dgrad_nhwc(dy, w_krsc, in_hw, stride=1, pad=0, residual=None, residua
     if mask is not None:
         assert tuple(mask.shape) == (N, H, W, Cin) and mask.is_contiguous()
     dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dy.device)
-    if _CONV_MATH[0] == 'bf16x6':
+    if _CONV_MATH[0] != 'f32':
         wt_split = bfx_split_weights(wt.view(Cin, R * S * Cout), cache=not wt_is_temp)
         wsb = lib.bgs_conv_bfx_workspace_bytes(N * H * W, Cin, R * S * Cout)
         ws = _workspace(wsb, dy.device) if wsb else None
         rc = lib.bgs_conv2d_dgrad_nhwc_f32_bfx_ws(capi.ptr(dy), capi.ptr(wt_split),
                                                   capi.ptr(residual), capi.ptr(mask), capi.ptr(dx),
                                                   N, H, W, Cin, Cout, R, S, stride, pad,
-                                                  residual_mode, capi.ptr(ws), wsb,
+                                                  residual_mode,
+                                                  3 if _CONV_MATH[0] == 'bf16x6' else 1,
+                                                  capi.ptr(ws), wsb,
                                                   capi.current_stream(dy.device))
         capi.check('bgs_conv2d_dgrad_nhwc_f32_bfx_ws', rc)
         return dx

@@ -11,6 +11,9 @@ reference tree).
   backward on the communication stream; with ``selectp=1`` the payload is 5.07 MB.
 * ``DistOptimizerStep``       dist_utils.py:51-58 — zero_grad, backward, all-reduce, clip
   (max_norm=35, L2), SGD step.
+* ``wrap_fp16_model`` / ``Fp16OptimizerStep``  mmdet/core/fp16/hooks.py:11-127 — the reduced-
+  precision mode of BASELINE cfg[4] ("bf16"): conv / linear operands rounded to bf16 for the MFMA,
+  fp32 accumulate; fp32 master weights, loss scaling.
 """
 from collections import OrderedDict
 
@@ -212,4 +215,51 @@ class DistOptimizerStep(object):
     def __call__(self, loss):
         self.optimizer.zero_grad(set_to_none=False)
         loss.backward()
+        self.exchange_and_update()
+
+
+def wrap_fp16_model(model, math='bf16'):
+    """The reference converts the model with ``model.half()`` and keeps an fp32 copy of the weights
+    in the optimizer (hooks.py:40-44,86-94); normalisation layers and every ``@force_fp32`` loss
+    (the GroupSoftmax / box / mask losses, gs_bbox_head_with0.py:147) stay in fp32.
+
+    Here the SAME arithmetic comes from the kernels instead of from tensor dtypes: under
+    ``conv_math = 'bf16'`` every conv / linear rounds both operands to bf16 on their way into the
+    matrix cores (``planes = 1`` of csrc/conv_bfx.hip) and accumulates in fp32.  Parameters and
+    activations stay fp32 in HBM, so the parameters ARE the fp32 master weights (no copy, no
+    copy-back), eval-mode BatchNorm is folded in fp32, and the losses see fp32 logits — what
+    ``patch_norm_fp32`` / ``force_fp32`` arrange in the reference.  Returns the previous mode."""
+    from . import functional as BF
+    assert math in ('bf16',), math
+    prev = BF.set_conv_math(math)
+    model._conv_math = math
+    return prev
+
+
+class Fp16OptimizerStep(DistOptimizerStep):
+    """``Fp16OptimizerHook.after_train_iter`` (hooks.py:58-83): scale the loss, backward, all-reduce
+    the gradients of the fp32 weights, scale them back, clip, step.  (bf16 has the exponent range
+    of fp32, so the scale is not needed for range; it is kept for the hook's contract and is exact
+    for powers of two.)"""
+
+    def __init__(self, params, optimizer, grad_clip=None, world_size=1, loss_scale=512.0, **kw):
+        super().__init__(params, optimizer, grad_clip=grad_clip, world_size=world_size, **kw)
+        self.loss_scale = float(loss_scale)
+
+    def exchange_and_update(self):
+        if self.overlap is not None:
+            self.overlap.finish()
+        else:
+            allreduce_grads(self.params, self.world_size)
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if grads and self.loss_scale != 1.0:
+            torch._foreach_div_(grads, self.loss_scale)
+        if self.grad_clip is not None:
+            torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip['max_norm'],
+                                           self.grad_clip.get('norm_type', 2))
+        self.optimizer.step()
+
+    def __call__(self, loss):
+        self.optimizer.zero_grad(set_to_none=False)
+        (loss * self.loss_scale).backward()
         self.exchange_and_update()

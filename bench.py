@@ -59,9 +59,10 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true',
                     help='skip the per-kernel roofline timings (used by the extras sub-runs)')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches, not hipGraph replay')
-    ap.add_argument('--conv-math', default=None, choices=['bf16x6', 'f32'],
+    ap.add_argument('--conv-math', default=None, choices=['bf16x6', 'f32', 'bf16'],
                     help="conv / linear arithmetic: 'bf16x6' (default; bf16 MFMA on exactly split fp32 "
-                         "operands, fp32-faithful) or 'f32' (v_mfma_f32_32x32x2_f32)")
+                         "operands, fp32-faithful), 'f32' (v_mfma_f32_32x32x2_f32) or 'bf16' (operands "
+                         "rounded to bf16, fp32 accumulate: the reduced-precision mode of cfg[4])")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     a = ap.parse_args()
@@ -242,7 +243,8 @@ class DetectorStep(object):
     """One training iteration of cfg[1] as shipped (selectp=1: full forward, backward through
     fc_cls, gradient all-reduce, clip, SGD) on synthetic 800x1344 inputs, 512 RoIs/img."""
 
-    def __init__(self, dev, rank, world, imgs, selectp=1, mask=False, cascade=False, htc=False):
+    def __init__(self, dev, rank, world, imgs, selectp=1, mask=False, cascade=False, htc=False,
+                 conv_math='bf16x6'):
         import tempfile
         import balancedgroupsoftmax_amd as bgs
         from balancedgroupsoftmax_amd import train
@@ -259,8 +261,14 @@ class DetectorStep(object):
         self.model.train()
         opt = train.build_optimizer(self.params, dict(type='SGD', lr=0.01, momentum=0.9,
                                                       weight_decay=0.0001))
-        self.step_fn = train.DistOptimizerStep(self.params, opt, dict(max_norm=35, norm_type=2),
-                                               world_size=world)
+        if conv_math == 'bf16':     # mmdet/core/fp16/hooks.py: wrap_fp16_model + Fp16OptimizerHook
+            train.wrap_fp16_model(self.model, 'bf16')
+            self.step_fn = train.Fp16OptimizerStep(self.params, opt, dict(max_norm=35, norm_type=2),
+                                                   world_size=world, loss_scale=512.0)
+        else:
+            self.step_fn = train.DistOptimizerStep(self.params, opt, dict(max_norm=35, norm_type=2),
+                                                   world_size=world)
+        self.loss_scale = getattr(self.step_fn, 'loss_scale', 1.0)
         g = torch.Generator().manual_seed(1000 + rank)          # different data per rank
         H, W = 800, 1344                                        # 1333 padded to /32 (Pad(size_divisor=32))
         self.img = torch.randn(imgs, 3, H, W, generator=g).to(dev)
@@ -296,7 +304,7 @@ class DetectorStep(object):
                             gt_labels=self.gt_labels, gt_masks=self.gt_masks, **self.extra)
         loss, log_vars = self.train.parse_losses(losses)
         self.step_fn.optimizer.zero_grad(set_to_none=False)
-        loss.backward()
+        (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
         # detached copies only: holding the loss would keep the autograd graph (and its
         # AccumulateGrad nodes) alive across iterations
         self.last = {k: v.detach() for k, v in log_vars.items()}
@@ -317,6 +325,9 @@ CONV_MATH_NOTE = {
               'products, dropped terms <= 2^-25 |ab|): error vs fp64 not above the fp32 MFMA kernel\'s '
               '(tests/test_gpu_det_ops.py::test_bfx_error_not_above_f32_mfma)',
     'f32': 'v_mfma_f32_32x32x2_f32: fp32 in / fp32 accumulate, bit-exact fma chain',
+    'bf16': 'REDUCED PRECISION (cfg[4] only): conv / linear operands rounded to bf16 for '
+            'v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 storage and master weights, fp32 '
+            'GroupSoftmax / box / mask losses (force_fp32), loss scale 512 (Fp16OptimizerHook)',
 }
 
 
@@ -351,6 +362,10 @@ def conv_roofline(dev, math, iters=20):
         kname = 'conv3x3_halo_bfx3_kernel<2>'
         kdesc = kname + ' (halo-resident A operand split to 3 bf16 planes in LDS, v_mfma_f32_32x32x16_bf16 x 6)'
         peak, passes = 2500.0 / 6.0, 6
+    elif math == 'bf16':
+        kname = 'conv3x3_halo_bfx3_kernel<2,1>'
+        kdesc = kname + ' (operands rounded to bf16, v_mfma_f32_32x32x16_bf16 x 1)'
+        peak, passes = 2500.0, 1
     else:
         halo = BF._use_halo_kernel(2 * 200 * 336, 256)
         kname = 'conv3x3_halo_f32_kernel' if halo else 'conv_igemm_f32_kernel<2,2,16,1>'
@@ -544,7 +559,9 @@ def extras(dev, args):
             ('mask_rcnn_selectp1', ['--mask']),
             ('mask_rcnn_selectp0', ['--mask', '--selectp', '0']),
             ('cascade_x101_64x4d_selectp3_fp32', ['--cascade', '--selectp', '3']),
-            ('htc_x101_64x4d_selectp3_fp32', ['--htc', '--selectp', '3']))
+            ('cascade_x101_64x4d_selectp3_bf16', ['--cascade', '--selectp', '3', '--conv-math', 'bf16']),
+            ('htc_x101_64x4d_selectp3_fp32', ['--htc', '--selectp', '3']),
+            ('htc_x101_64x4d_selectp3_bf16', ['--htc', '--selectp', '3', '--conv-math', 'bf16']))
     for key, flags in runs:
         cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'detector', '--steps', '10',
                '--warmup', '3', '--imgs', str(args.imgs), '--no-extras', '--no-cpu-baseline',
@@ -627,7 +644,7 @@ def main_detector(args, rank, local, world, dev):
     if args.child and os.environ.get('BGS_BENCH_CHILD_FAIL'):     # test hook for the fallback path
         os._exit(134)
     step = DetectorStep(dev, rank, world, args.imgs, args.selectp, args.mask, args.cascade,
-                        args.htc)
+                        args.htc, conv_math=args.conv_math)
     # Launch policy.  The iteration is free of host synchronisation, so on ONE GPU the whole
     # step (forward, losses, backward, clip, SGD: ~560 launches) is captured into a single
     # hipGraph and replayed.  The graph must own the ENTIRE step: on ROCm 7.2 a large graph whose
@@ -646,9 +663,9 @@ def main_detector(args, rank, local, world, dev):
     imgs_per_s = args.imgs * world * args.steps / dt
     cfg_name = 'gs_faster_rcnn_r50_fpn_1x_lvis_with0_bg8 (cfg[1])'
     if args.htc:
-        cfg_name = 'gs_htc_x101_64x4d_fpn_20e_16gpu_lvis (cfg[4], HTC, fp32)'
+        cfg_name = 'gs_htc_x101_64x4d_fpn_20e_16gpu_lvis (cfg[4], HTC)'
     elif args.cascade:
-        cfg_name = 'gs_cascade_rcnn_x101_64x4d_fpn_1x_lvis (cfg[4], fp32)'
+        cfg_name = 'gs_cascade_rcnn_x101_64x4d_fpn_1x_lvis (cfg[4])'
     elif args.mask:
         cfg_name = 'gs_mask_rcnn_r50_fpn_1x_lvis (cfg[3])'
     if rank == 0:
@@ -659,8 +676,10 @@ def main_detector(args, rank, local, world, dev):
             'value': round(imgs_per_s, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.conv_math == 'f32' else 'f32 (conv/linear products on the bf16 MFMA '
-                     'from exact 3-way bf16 splits, fp32 accumulate: fp32-faithful)',
+            'dtype': {'f32': 'f32', 'bf16': 'bf16 (conv/linear operands rounded to bf16, fp32 '
+                                                   'accumulate; fp32 storage, master weights and losses)',
+                      'bf16x6': 'f32 (conv/linear products on the bf16 MFMA from exact 3-way bf16 '
+                                'splits, fp32 accumulate: fp32-faithful)'}[args.conv_math],
             'data': 'synthetic',
             'config': {'conv_math_mode': args.conv_math, 'conv_math': CONV_MATH_NOTE[args.conv_math],
                        'workload': cfg_name + ' training '

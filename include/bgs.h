@@ -232,6 +232,10 @@ int bgs_conv3x3_halo_nhwc_f32(const float* x, const float* w, const float* bias,
  *   bgs_conv_bfx_split_weights(w [rows][K] fp32 -> out, bgs_conv_bfx_weight_bytes(rows, K) bytes,
  *   16-byte aligned), layout [3][2*ceil(K/32)][rows][16] bf16 (zero-padded K tail); rows = Cout
  *   (forward; K = R*S*Cin) or Cin (data gradient: the flipped / transposed filter, K = R*S*Cout).
+ * planes = 3: the fp32-faithful mode above.  planes = 1: only the `hi` plane of both operands is
+ *   used — operands rounded to bf16 (RNE), fp32 accumulate, fp32 results: the arithmetic of the
+ *   reference's fp16/bf16 autocast (mmdet/core/fp16/decorators.py:9-160) with fp32 storage, 1/6 of
+ *   the matrix-pipe work (BASELINE cfg[4] "bf16"); the split buffer is the same (plane 0 = bf16(w)).
  * workspace: bgs_conv_bfx_workspace_bytes(M, Cout, K) / bgs_conv3x3_halo_bfx_workspace_bytes(...)
  * bytes of split-K scratch (0 / NULL is always legal).
  * bgs_conv_bfx_tuning / bgs_conv3x3_halo_bfx_tuning: process-wide tuning and test hooks
@@ -245,16 +249,16 @@ size_t bgs_conv_bfx_workspace_bytes(long long M, int Cout, int K);
 int bgs_conv2d_nhwc_f32_bfx_ws(const float* x, const void* wsplit, const float* bias,
                                const float* residual, float* y, int N, int H, int W, int Cin,
                                int Cout, int R, int S, int stride, int pad, int relu,
-                               int residual_mode, void* workspace, size_t workspace_bytes,
-                               bgs_stream_t stream);
+                               int residual_mode, int planes, void* workspace,
+                               size_t workspace_bytes, bgs_stream_t stream);
 int bgs_conv2d_dgrad_nhwc_f32_bfx_ws(const float* dy, const void* wt_split, const float* residual,
                                      const float* mask, float* dx, int N, int H, int W, int Cin,
                                      int Cout, int R, int S, int stride, int pad,
-                                     int residual_mode, void* workspace, size_t workspace_bytes,
-                                     bgs_stream_t stream);
+                                     int residual_mode, int planes, void* workspace,
+                                     size_t workspace_bytes, bgs_stream_t stream);
 size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias, float* y,
-                                  int N, int H, int W, int Cin, int Cout, int relu,
+                                  int N, int H, int W, int Cin, int Cout, int relu, int planes,
                                   void* workspace, size_t workspace_bytes, bgs_stream_t stream);
 void bgs_conv_bfx_tuning(int tile, int splitk);
 int bgs_conv_bfx_last_launch(int* tile, int* splits);

@@ -246,6 +246,73 @@ def test_fullsize_training_iteration_vs_executed_reference(mode, monkeypatch):
         torch.cuda.empty_cache()
 
 
+def test_cascade_bf16_mode_vs_fp32_golden_and_fp16_optimizer_step():
+    """BASELINE cfg[4] "bf16": ``train.wrap_fp16_model`` (conv / linear operands rounded to bf16 in
+    the MFMA kernels, fp32 accumulate and storage) on the 3-stage Cascade R-CNN against the
+    EXECUTED fp32 reference iteration (the golden of the fp32 test above): every loss term within
+    the bf16 budget (2 % of the total; discrete NMS / assignment decisions may move), and
+    ``Fp16OptimizerStep`` (loss scale 512, mmdet/core/fp16/hooks.py:58-83) produces the same update
+    as the unscaled step."""
+    from balancedgroupsoftmax_amd import functional as BF
+    from balancedgroupsoftmax_amd import train
+    from tests.golden import make_golden_train as T
+    z = np.load(os.path.join(os.path.dirname(T.__file__), 'e2e_train_golden.npz'))
+    tmp = tempfile.mkdtemp(prefix='bgs_e2e_')
+    model_cfg, train_cfg = T.configs(tmp, cascade=True)
+
+    def build():
+        m = bgs.build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
+                               test_cfg=to_config_dict(G.TEST_CFG))
+        with torch.no_grad():
+            det_oracle.fill_detector(m.state_dict(), T.CASCADE_SEED)
+        m.to(DEV)
+        m.train()
+        return m
+
+    boxes, labels = T.gt()
+
+    def run(m):
+        return m(torch.from_numpy(G.image()).to(DEV), G.img_meta(), return_loss=True,
+                 gt_bboxes=[torch.from_numpy(boxes).to(DEV)],
+                 gt_labels=[torch.from_numpy(labels).to(DEV)])
+
+    model = build()
+    params = train.select_training_param(model, 3)
+    prev = train.wrap_fp16_model(model, 'bf16')
+    try:
+        assert BF.conv_math() == 'bf16'
+        losses = run(model)
+        total_exp = float(z['cascade/loss/total'][0])
+        worst = 0.0
+        for k, v in losses.items():
+            got = np.array([float(t.detach().sum()) for t in (v if isinstance(v, list) else [v])])
+            exp = z['cascade/loss/' + k]
+            worst = max(worst, float(np.abs(got - exp).max()))
+        loss, _ = train.parse_losses(losses)
+        print('bf16 cascade: total %.5f vs fp32 reference %.5f, worst term diff %.2e'
+              % (float(loss.detach()), total_exp, worst))
+        assert abs(float(loss.detach()) - total_exp) < 2e-2 * total_exp
+        assert worst < 2e-2 * total_exp
+        # scaled vs unscaled optimizer step from the same state: identical update (512 = 2^9)
+        opt_a = torch.optim.SGD(params, lr=0.01, momentum=0.9, weight_decay=1e-4)
+        w0 = [p.detach().clone() for p in params]
+        train.Fp16OptimizerStep(params, opt_a, grad_clip=dict(max_norm=35, norm_type=2),
+                                loss_scale=512.0)(loss)
+        wa = [p.detach().clone() for p in params]
+        with torch.no_grad():
+            for p, w in zip(params, w0):
+                p.copy_(w)
+        opt_b = torch.optim.SGD(params, lr=0.01, momentum=0.9, weight_decay=1e-4)
+        loss_b, _ = train.parse_losses(run(model))
+        train.DistOptimizerStep(params, opt_b, grad_clip=dict(max_norm=35, norm_type=2))(loss_b)
+        for a, p, w in zip(wa, params, w0):
+            step = (p.detach() - w).abs().max()
+            assert float(step) > 0
+            assert float((a - p.detach()).abs().max()) <= 1e-5 * float(step) + 1e-9
+    finally:
+        BF.set_conv_math(prev)
+
+
 def test_htc_training_iteration_vs_executed_reference_detector():
     """``HybridTaskCascade.forward_train`` + ``backward`` (htc.py:196-311: three box stages with
     semantic fusion, interleaved re-sampling from the refined boxes, mask information flow, semantic

@@ -8,8 +8,42 @@ import csv
 import sys
 
 
-def main(path):
+CATS = [('conv: halo 3x3', ('conv3x3_halo',)), ('conv: implicit GEMM', ('conv_igemm',)),
+        ('conv: split-K epilogue', ('conv_splitk',)), ('conv: weight split / wgrad / grouped / pool',
+                                                       ('bfx_split', 'conv_wgrad', 'grouped_conv', 'maxpool')),
+        ('torch glue (elementwise / copy / cat / reduce / index)', ('at::native', 'rocclr', 'at::cuda', 'cub::', 'rocprim', 'hipcub')),
+        ('GroupSoftmax + box loss', ('gs_', 'bbox_sl1', 'reduce_partials')),
+        ('targets / sampling / RPN loss', ('iou_', 'rpn_loss', 'sample_', 'rcnn_targets', 'random_keys', 'decode_proposals')),
+        ('top-k / NMS', ('topk_', 'nms_')), ('RoIAlign', ('roi_align',)), ('mask / resize', ('mask_', 'resize_'))]
+
+
+def categories(rows, steps):
+    """Per-step GPU time by kernel family (the trace holds `steps` eager steps incl. warm-up)."""
+    tot = collections.OrderedDict((c, [0, 0]) for c, _ in CATS)
+    tot['other'] = [0, 0]
+    for r in rows:
+        d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+        name = r['Kernel_Name']
+        for c, keys in CATS:
+            if any(k in name for k in keys):
+                break
+        else:
+            c = 'other'
+        tot[c][0] += d
+        tot[c][1] += 1
+    alln = sum(v[0] for v in tot.values())
+    print('| kernel family | ms / step | launches / step | % |')
+    print('|---|---|---|---|')
+    for c, (ns, n) in tot.items():
+        print('| %s | %.3f | %.1f | %.1f |' % (c, ns / steps / 1e6, n / steps, 100.0 * ns / alln))
+    print('| **all kernels** | %.3f | %.1f | 100 |' % (alln / steps / 1e6, sum(v[1] for v in tot.values()) / steps))
+    print()
+
+
+def main(path, steps=None):
     rows = list(csv.DictReader(open(path)))
+    if steps:
+        categories(rows, steps)
     agg = collections.defaultdict(list)
     for r in rows:
         d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
@@ -30,4 +64,4 @@ def main(path):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else None)
