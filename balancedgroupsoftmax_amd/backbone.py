@@ -196,9 +196,21 @@ class ResNet(nn.Module):
 
     def init_weights(self, pretrained=None):
         """resnet.py:496-520 (kaiming for convs, BN = 1/0, zero-init of the last BN)."""
-        if pretrained is not None:
-            raise NotImplementedError('no network / model zoo in this environment: load a '
-                                      'state_dict explicitly')
+        if isinstance(pretrained, str):
+            # resnet.py:496-499: load_checkpoint(self, pretrained, strict=False)
+            if '://' in pretrained:      # torchvision:// / open-mmlab:// / http(s):// model-zoo URLs
+                import warnings
+                warnings.warn('pretrained=%r is a model-zoo URL and there is no network here: the '
+                              'backbone keeps its RANDOM initialisation (frozen stages included). '
+                              'Pass a local checkpoint path, or load a state_dict explicitly '
+                              '(checkpoint.load_checkpoint / load_from).' % (pretrained,),
+                              RuntimeWarning, stacklevel=2)
+            else:
+                from .checkpoint import load_checkpoint
+                load_checkpoint(self, pretrained, strict=False)     # raises if the file is missing
+                return
+        elif pretrained is not None:
+            raise TypeError('pretrained must be a str or None')
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')

@@ -54,10 +54,8 @@ class TwoStageDetector(nn.Module):
     with_shared_head = property(lambda self: False)
 
     def init_weights(self, pretrained=None):
-        if isinstance(pretrained, str):
-            # 'torchvision://resnet50' etc.: there is no network here; weights stay at their
-            # random init until a state_dict is loaded explicitly.
-            pretrained = None
+        # local checkpoint paths are loaded into the backbone, model-zoo URLs warn loudly
+        # (backbone.ResNet.init_weights; reference: two_stage.py:66-68 -> resnet.py:496-499)
         self.backbone.init_weights(pretrained=pretrained)
         if self.with_neck:
             self.neck.init_weights()
@@ -376,8 +374,6 @@ class CascadeRCNN(TwoStageDetector):
                                       'cascade mask branch is built as HybridTaskCascade')
 
     def init_weights(self, pretrained=None):
-        if isinstance(pretrained, str):
-            pretrained = None
         self.backbone.init_weights(pretrained=pretrained)
         if self.with_neck:
             self.neck.init_weights()

@@ -131,15 +131,19 @@ class _GroupSoftmaxLoss(torch.autograd.Function):
         dl = ctx.dlogits
         if dl is None:
             return None, None, None, None, None
+        if ctx.prev_g is not None:
+            # The kernel's dlogits buffer is scaled IN PLACE and handed to autograd (no second
+            # [N, W] tensor per step); a second backward through a retained graph would rescale a
+            # tensor the first one already gave away (and could not recover bins whose first
+            # upstream grad was 0).  Refuse instead of returning wrong gradients.
+            raise RuntimeError('group_softmax_loss: the fused dlogits buffer was consumed by the '
+                               'first backward; a second backward through a retained graph is not '
+                               'supported — call the loss again')
         lib = capi.load()
         g = grad_loss.detach().to(torch.float32).contiguous()
-        if ctx.prev_g is not None:  # a second backward through a retained graph
-            g_eff = torch.where(ctx.prev_g == 0, torch.zeros_like(g), g / ctx.prev_g)
-        else:
-            g_eff = g
         N, W = dl.shape
         ps_keep, ps_ptr = capi.host_i64(ctx.pred_slice_host)
-        rc = lib.bgs_gs_scale_grad(capi.ptr(dl), ps_ptr, capi.ptr(g_eff), N, ps_keep.shape[0], W,
+        rc = lib.bgs_gs_scale_grad(capi.ptr(dl), ps_ptr, capi.ptr(g), N, ps_keep.shape[0], W,
                                    capi.current_stream(dl.device))
         capi.check('bgs_gs_scale_grad', rc)
         ctx.prev_g = g
@@ -553,17 +557,49 @@ class _ConvFn(torch.autograd.Function):
         return dx, dw, db, dres, None, None, None, None, None
 
 
+class _ReluGateFn(torch.autograd.Function):
+    """Identity whose backward applies the ReLU gate of its (post-ReLU) input: turns a
+    ``relu='consumers'`` conv output into an ordinary tensor that ANY consumer may use."""
+
+    @staticmethod
+    def forward(ctx, y):
+        ctx.save_for_backward(y)
+        return y.view_as(y)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return torch.ops.aten.threshold_backward(g.contiguous(), y, 0.0)
+
+
+def relu_gate(y):
+    """Public-boundary adapter for ``relu='consumers'`` outputs (see :class:`_ConvFn`): the
+    returned tensor carries the ReLU backward itself.  No-op when nothing is being recorded."""
+    if torch.is_grad_enabled() and y.requires_grad and getattr(y, '_bgs_consumers_mask', False):
+        return _ReluGateFn.apply(y)
+    return y
+
+
 def conv2d_autograd(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None,
                     residual_mode=0, mask_input=False):
     """:func:`conv2d_nhwc` that records an autograd node when any input requires grad.
     ``relu``: False / True / ``'consumers'`` (see :class:`_ConvFn`); ``mask_input``: ``x`` is the
-    output of a ``relu='consumers'`` conv."""
+    output of a ``relu='consumers'`` conv.  The contract is checked where it can be: outputs of
+    ``relu='consumers'`` convs are tagged, and feeding a tagged tensor to a conv WITHOUT
+    ``mask_input=True`` raises (its gradient would skip the ReLU gate)."""
     ts = [t for t in (x, w_krsc, bias, residual) if t is not None]
     if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
+        if getattr(x, '_bgs_consumers_mask', False) and not mask_input:
+            raise RuntimeError("conv2d_autograd: x is the output of a relu='consumers' conv (its ReLU "
+                               "backward is delegated to its consumers) but mask_input is False")
         if residual is not None and residual_mode == 0:
             residual_mode = 1
-        return _ConvFn.apply(x, w_krsc, bias, residual, stride, pad, relu, residual_mode,
-                             bool(mask_input))
+        y = _ConvFn.apply(x, w_krsc, bias, residual, stride, pad, relu, residual_mode,
+                          bool(mask_input))
+        if relu == 'consumers':
+            y._bgs_consumers_mask = True
+        return y
     return conv2d_nhwc(x, w_krsc, bias, stride=stride, pad=pad, relu=bool(relu),
                        residual=residual, residual_mode=residual_mode)
 
@@ -900,6 +936,11 @@ def iou_assign(boxes, gt_cat, gt_offsets, pos_iou_thr, neg_iou_thr, min_pos_iou=
     boxes = boxes if boxes.dtype == torch.float32 and boxes.is_contiguous() else _f32c(boxes)
     gt_cat = _f32c(gt_cat)
     N = len(gt_offsets) - 1
+    for i in range(N):
+        # max_iou_assigner.py:76-77: an image without GT boxes is an error in the reference; the
+        # fused kernel would silently mark every box of that image "ignore" (-1)
+        if gt_offsets[i + 1] - gt_offsets[i] <= 0:
+            raise ValueError('No gt or proposals (image %d of the batch has no GT box)' % i)
     if shared_boxes:
         A, bs = boxes.shape[0], boxes.shape[1]
         img_stride = 0

@@ -70,7 +70,9 @@ class FCNMaskHead(nn.Module):
 
     def conv_features(self, x):
         """The ``convs`` stack on NHWC RoI features; the result is a ``relu='consumers'`` output
-        (every consumer gates its own data gradient: ``mask_input=True``) unless ``num_convs == 0``."""
+        (every consumer gates its own data gradient: ``mask_input=True``) unless ``num_convs == 0``.
+        INTERNAL contract (the output is tagged; ``BF.conv2d_autograd`` refuses it without
+        ``mask_input=True``); hand it to foreign code through ``BF.relu_gate`` only."""
         first = True
         for m in self.convs:
             w, b = _fold_conv_bn(m.conv, None)
@@ -221,5 +223,8 @@ class HTCMaskHead(FCNMaskHead):
                 y = BF.conv2d_autograd(f, wl.view(-1, 1, 1, C).contiguous(), self.conv_logits.bias)
                 outs.append(y.permute(0, 3, 1, 2))
         if return_feat:
-            outs.append(res_out if nhwc else res_out.permute(0, 3, 1, 2))
+            # public boundary: the caller may be anything, so the returned feature carries its own
+            # ReLU backward (inside this module the consumers gate it: relu='consumers')
+            pub = BF.relu_gate(res_out)
+            outs.append(pub if nhwc else pub.permute(0, 3, 1, 2))
         return outs if len(outs) > 1 else outs[0]

@@ -104,6 +104,10 @@ def test_default_weights_and_upstream_scale():
                                           grad_scale=gs)
     np.testing.assert_allclose(losses.detach().cpu().numpy(), ol, rtol=1e-5)
     np.testing.assert_allclose(z.grad.cpu().numpy(), od, rtol=1e-5, atol=1e-8)
+    # the fused gradient buffer is consumed by the first backward: a second one through the
+    # retained graph fails loudly instead of rescaling a tensor that was already handed out
+    with pytest.raises(RuntimeError, match='second backward'):
+        (losses * dev(gs)).sum().backward()
 
 
 def test_half_and_bf16_logits_are_computed_in_fp32():
