@@ -23,7 +23,8 @@ folded weights.  With trainable trunk parameters (``selectp=0``) the fold is rec
 as differentiable tensor code (so autograd unfolds ``dW', db'`` into the conv weight and the BN
 affine parameters) and every conv records ``functional._ConvFn`` (dgrad / wgrad kernels,
 csrc/conv_igemm.hip + csrc/conv_wgrad.hip).  The stem + max-pool have no backward here: they are
-frozen in every BAGS config (``frozen_stages=1``).
+frozen in every BAGS config (``frozen_stages=1``); with ``frozen_stages=-1`` the stem trains too
+(weight / BN gradients of the 7x7 conv, max-pool backward).
 """
 import contextlib
 
@@ -78,16 +79,6 @@ class _FoldCache(object):
         return self.data
 
 
-def _check_frozen(module, what):
-    if torch.is_grad_enabled():
-        for n, p in module.named_parameters():
-            if p.requires_grad:
-                raise NotImplementedError(
-                    '%s.%s requires grad: no backward for the stem conv + max-pool (frozen in '
-                    'every BAGS config: frozen_stages=1). Freeze it or run under torch.no_grad().'
-                    % (what, n))
-
-
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -126,7 +117,7 @@ class Bottleneck(nn.Module):
             identity = BF.conv2d_autograd(x, f['ds'][0], f['ds'][1], stride=self.stride)
         # conv1 -> conv2 -> conv3 is a chain of single consumers: the ReLU backward of o1 / o2
         # rides in the epilogue of the next conv's dgrad (relu='consumers' + mask_input)
-        if self.groups > 1:      # ResNeXt: grouped 3x3 (csrc/grouped_conv.hip), forward only
+        if self.groups > 1:      # ResNeXt: grouped 3x3 (csrc/grouped_conv.hip)
             out = BF.conv2d_autograd(x, f['c1'][0], f['c1'][1], relu=True)
             out = BF.grouped_conv3x3_nhwc(out, f['c2'][0], f['c2'][1], self.groups,
                                           stride=self.stride, relu=True)
@@ -232,10 +223,12 @@ class ResNet(nn.Module):
 
     def forward(self, img):
         """img ``[N,3,H,W]`` (as the reference) -> tuple of NHWC feature maps."""
-        _check_frozen(nn.ModuleList([self.conv1, self.bn1]), 'backbone stem')
+        # frozen_stages >= 1 (every BAGS config): a plain forward launch on the cached fold;
+        # frozen_stages < 1: the fold is on the tape (resnet.py:483-494), the conv records its
+        # weight / bias gradient (the image needs none) and the max-pool its routing
         stem = self._cache.get(nn.ModuleList([self.conv1, self.bn1]), self._build_stem)
         x = self.to_nhwc4(img)
-        x = BF.conv2d_nhwc(x, stem[0], stem[1], stride=2, pad=3, relu=True)
+        x = BF.conv2d_autograd(x, stem[0], stem[1], stride=2, pad=3, relu=True)
         x = BF.maxpool3x3s2_nhwc(x)
         outs = []
         for i, name in enumerate(self.res_layers):
@@ -259,7 +252,7 @@ class ResNet(nn.Module):
 class ResNeXt(ResNet):
     """mmdet/models/backbones/resnext.py:95-222: the ResNet layout with grouped 3x3 convs
     (``groups=64, base_width=4`` = X101-64x4d in configs/bags/gs_cascade_rcnn_x101_64x4d_*.py).
-    Parameter names / shapes are the reference's; forward only on the grouped convs."""
+    Parameter names / shapes are the reference's."""
 
     def __init__(self, groups=1, base_width=4, **kwargs):
         super().__init__(groups=groups, base_width=base_width, **kwargs)

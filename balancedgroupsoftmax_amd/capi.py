@@ -81,6 +81,12 @@ SIGNATURES = {
     'bgs_conv3x3_halo_bfx_last_launch': (ctypes.c_int, [c_ptr, c_ptr]),
     'bgs_grouped_conv3x3_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 7
                                      + [c_ptr]),
+    'bgs_grouped_conv3x3_dgrad_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 6
+                                           + [c_ptr]),
+    'bgs_grouped_conv3x3_wgrad_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 6),
+    'bgs_grouped_conv3x3_wgrad_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p]
+                                           + [ctypes.c_int] * 7 + [c_ptr, c_ptr]),
+    'bgs_maxpool3x3s2_bwd_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 4 + [c_ptr]),
     'bgs_maxpool3x3s2_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p] + [ctypes.c_int] * 4 + [c_ptr]),
     'bgs_roi_align_nhwc_fwd': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_int,

@@ -321,6 +321,60 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const float* __r
   }
 }
 
+// Backward of maxpool3x3s2_nhwc_kernel: one thread per INPUT (pixel, channel quad) gathers from the
+// <= 4 output windows that contain it; an input element receives a window's gradient iff it is that
+// window's FIRST maximum in (row, column) scan order — the element torch's max_pool2d backward
+// (the op the reference calls, resnet.py:452) routes to.  No atomics: deterministic.
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_nhwc_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ dy,
+                                                                    float* __restrict__ dx, int N,
+                                                                    int H, int W, int C, int Ho,
+                                                                    int Wo) {
+  const int c4n = C >> 2;
+  const size_t total = (size_t)N * H * W * c4n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    size_t t = i / c4n;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    const f32x4 mine = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    // windows (ho, wo) with ho*2-1 <= h <= ho*2+1
+    for (int ho = (h >> 1); ho <= ((h + 1) >> 1); ++ho) {
+      if (ho < 0 || ho >= Ho) continue;
+      for (int wo = (w >> 1); wo <= ((w + 1) >> 1); ++wo) {
+        if (wo < 0 || wo >= Wo) continue;
+        const f32x4 gy = *reinterpret_cast<const f32x4*>(dy + ((((size_t)n * Ho + ho) * Wo + wo) * C + c4 * 4));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          // is (h, w) the first maximum of this window for channel u?
+          bool first = true;
+          for (int dyy = 0; dyy < 3 && first; ++dyy) {
+            const int hi = ho * 2 - 1 + dyy;
+            if (hi < 0 || hi >= H) continue;
+            for (int dxx = 0; dxx < 3; ++dxx) {
+              const int wi = wo * 2 - 1 + dxx;
+              if (wi < 0 || wi >= W) continue;
+              if (hi == h && wi == w) continue;
+              const float v = x[(((size_t)n * H + hi) * W + wi) * C + c4 * 4 + u];
+              const bool before = hi < h || (hi == h && wi < w);
+              if (v > mine[u] || (before && v == mine[u]) || v != v) {   // NaN propagates like torch
+                first = false;
+                break;
+              }
+            }
+          }
+          if (first) g[u] += gy[u];
+        }
+      }
+    }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = g;
+  }
+}
+
 }  // namespace
 
 // y = epilogue(sum of the split-K partial slabs): shared with conv_bfx.hip.
@@ -568,5 +622,20 @@ extern "C" int bgs_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H,
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel, dim3((unsigned)grid), dim3(256), 0,
                      (hipStream_t)stream, x, y, N, H, W, C, Ho, Wo);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+// Backward of bgs_maxpool3x3s2_nhwc_f32 (ResNet stem when `frozen_stages < 1`): x [N,H,W,C] (the
+// pool's input), dy [N,Ho,Wo,C] -> dx [N,H,W,C] (overwritten).
+extern "C" int bgs_maxpool3x3s2_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int N, int H,
+                                             int W, int C, bgs_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || !x || !dy || !dx) return BGS_ERR_INVALID_ARG;
+  if (C % 4 != 0 || ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16 != 0) return BGS_ERR_UNSUPPORTED;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)N * H * W * (C / 4);
+  size_t grid = (total + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_nhwc_kernel, dim3((unsigned)grid), dim3(256), 0,
+                     (hipStream_t)stream, x, dy, dx, N, H, W, C, Ho, Wo);
   BGS_RETURN_LAUNCH_STATUS();
 }

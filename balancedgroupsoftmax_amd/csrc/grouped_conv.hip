@@ -11,6 +11,9 @@
 // floats are the A / B operands of four consecutive MFMAs (k index = lane group j):
 //     acc[a] += x[pix(a,i)+tap][16*slab + 4j + u] * w[n][tap][.. 4j + u ..],  u = 0..3
 // A workgroup = 4 waves = the same 64 pixels x 4 neighbouring channel tiles (input reuse in L1).
+// Backward (`selectp = 0` on the X101 configs): the data gradient is the SAME kernel on dy with
+// the per-group transposed, flipped filter (`up = 2` reads dy as if zero-upsampled for the
+// stride-2 blocks); the weight gradient is grouped_wgrad3x3_kernel below.
 // (First version: one thread per pixel x 4 channels on the vector ALUs re-read its 4 x 9 x cg
 //  weights per pixel: 0.69 ms per layer3 conv = 3.6 TFLOP/s, 47 % of the X101 step.)
 #include "bgs_common.h"
@@ -22,7 +25,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int CG>
 __global__ __launch_bounds__(256) void grouped_conv3x3_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, int stride, int relu) {
+    float* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, int stride, int relu,
+    int up) {
   constexpr int KH = CG >= 16 ? CG / 16 : 1;       // 16-channel K slabs per tap
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, j = lane >> 4;
@@ -73,9 +77,15 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_mfma_kernel(
         f32x4 av[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          const int hi = hi0[a] + r, wi = wi0[a] + s;
+          int hi = hi0[a] + r, wi = wi0[a] + s;
+          bool in = ok[a] && hi >= 0 && wi >= 0;
+          if (up == 2) {          // input read as if zero-upsampled by 2 (stride-2 data gradient)
+            in = in && !((hi | wi) & 1);
+            hi >>= 1;
+            wi >>= 1;
+          }
           av[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (ok[a] && hi >= 0 && hi < H && wi >= 0 && wi < W)
+          if (in && hi < H && wi < W)
             av[a] = *reinterpret_cast<const f32x4*>(xb[a] + ((size_t)hi * W + wi) * C + in0 +
                                                     kh * 16 + 4 * j);
         }
@@ -120,12 +130,155 @@ extern "C" int bgs_grouped_conv3x3_nhwc_f32(const float* x, const float* w, cons
   hipStream_t st = (hipStream_t)stream;
 #define BGS_GC_LAUNCH(CG_)                                                                        \
   hipLaunchKernelGGL((grouped_conv3x3_mfma_kernel<CG_>), grid, dim3(256), 0, st, x, w, bias, y, N, \
-                     H, W, C, Ho, Wo, stride, relu)
+                     H, W, C, Ho, Wo, stride, relu, 1)
   if (cg == 4) BGS_GC_LAUNCH(4);
   else if (cg == 8) BGS_GC_LAUNCH(8);
   else if (cg == 16) BGS_GC_LAUNCH(16);
   else if (cg == 32) BGS_GC_LAUNCH(32);
   else return BGS_ERR_UNSUPPORTED;   // ResNeXt 32x4d / 64x4d use 4..32 channels per group
 #undef BGS_GC_LAUNCH
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+
+namespace {
+
+// Weight gradient of the grouped 3x3 conv: dw[co][r][s][cl] = sum_m dy[m][co] * x[pix(m)+tap][g*cg+cl].
+// Thread = one (co, cl) pair with nine accumulators; a workgroup covers 256 / CG output channels
+// and one chunk of `chunk` output pixels; partial sums per chunk go to `part[chunk][C*9*CG]` and
+// are added in a fixed order by grouped_wgrad_reduce_kernel (bitwise reproducible, like
+// conv_wgrad.hip).  This layer family is < 1 % of the X101 flops: a plain VALU kernel.
+template <int CG>
+__global__ __launch_bounds__(256) void grouped_wgrad3x3_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int N,
+    int H, int W, int C, int Ho, int Wo, int stride, int chunk) {
+  const int pair = blockIdx.y * 256 + threadIdx.x;         // (co, cl)
+  const int co = pair / CG, cl = pair - co * CG;
+  if (co >= C) return;
+  const int ci = (co / CG) * CG + cl;
+  const int M = N * Ho * Wo;
+  const int m_begin = blockIdx.x * chunk, m_end = min(M, m_begin + chunk);
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  const int hw = Ho * Wo;
+  for (int m = m_begin; m < m_end; ++m) {
+    const float g = dy[(size_t)m * C + co];
+    const int n = m / hw, rem = m - n * hw;
+    const int ho = rem / Wo, wo = rem - ho * Wo;
+    const float* xb = x + (size_t)n * H * W * C + ci;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hi = ho * stride - 1 + r;
+      if (hi < 0 || hi >= H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int wi = wo * stride - 1 + s;
+        if (wi < 0 || wi >= W) continue;
+        acc[r * 3 + s] = fmaf(g, xb[((size_t)hi * W + wi) * C], acc[r * 3 + s]);
+      }
+    }
+  }
+  float* o = part + (size_t)blockIdx.x * C * 9 * CG + (size_t)co * 9 * CG + cl;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) o[t * CG] = acc[t];
+}
+
+__global__ __launch_bounds__(256) void grouped_wgrad_reduce_kernel(const float* __restrict__ part,
+                                                                   float* __restrict__ dw,
+                                                                   float* __restrict__ db,
+                                                                   const float* __restrict__ dy,
+                                                                   int total, int chunks, int C,
+                                                                   long long M, int accumulate) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < total) {
+    float v = 0.f;
+    for (int c = 0; c < chunks; ++c) v += part[(size_t)c * total + e];
+    dw[e] = accumulate ? dw[e] + v : v;
+  }
+  if (db && e < C) {                     // bias gradient: column sums of dy (fixed order)
+    float v = 0.f;
+    for (long long m = 0; m < M; ++m) v += dy[m * C + e];
+    db[e] = accumulate ? db[e] + v : v;
+  }
+}
+
+}  // namespace
+
+// Data gradient of bgs_grouped_conv3x3_nhwc_f32: dy [N,Ho,Wo,C] -> dx [N,H,W,C].  wt = the filter
+// transposed inside each group and flipped: wt[g*cg+cl][2-r][2-s][co_local] = w[g*cg+co_local][r][s][cl].
+extern "C" int bgs_grouped_conv3x3_dgrad_nhwc_f32(const float* dy, const float* wt, float* dx, int N,
+                                                  int H, int W, int C, int groups, int stride,
+                                                  bgs_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || groups <= 0 || (stride != 1 && stride != 2))
+    return BGS_ERR_INVALID_ARG;
+  if (!dy || !wt || !dx) return BGS_ERR_INVALID_ARG;
+  if (C % groups != 0 || C % 16 != 0) return BGS_ERR_UNSUPPORTED;
+  const int cg = C / groups;
+  if (((uintptr_t)dy | (uintptr_t)wt | (uintptr_t)dx) % 16 != 0) return BGS_ERR_INVALID_ARG;
+  const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;   // dy dims
+  const long long M = (long long)N * H * W;
+  if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)((M + 63) / 64), (unsigned)((C / 16 + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  const float* nobias = nullptr;
+  // "input" = dy (Ho x Wo, zero-upsampled when stride 2), "output" = dx (H x W), unit stride, pad 1
+#define BGS_GD_LAUNCH(CG_)                                                                         \
+  hipLaunchKernelGGL((grouped_conv3x3_mfma_kernel<CG_>), grid, dim3(256), 0, st, dy, wt, nobias, dx, \
+                     N, Ho, Wo, C, H, W, 1, 0, stride)
+  if (cg == 4) BGS_GD_LAUNCH(4);
+  else if (cg == 8) BGS_GD_LAUNCH(8);
+  else if (cg == 16) BGS_GD_LAUNCH(16);
+  else if (cg == 32) BGS_GD_LAUNCH(32);
+  else return BGS_ERR_UNSUPPORTED;
+#undef BGS_GD_LAUNCH
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+static int grouped_wgrad_chunks(long long M, int* chunk) {
+  *chunk = 1024;
+  return (int)((M + *chunk - 1) / *chunk);
+}
+
+extern "C" size_t bgs_grouped_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int C, int groups,
+                                                            int stride) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || groups <= 0 || C % groups) return 0;
+  const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  int chunk;
+  const int chunks = grouped_wgrad_chunks((long long)N * Ho * Wo, &chunk);
+  return (size_t)chunks * C * 9 * (C / groups) * sizeof(float);
+}
+
+// dw [C,3,3,C/groups] (+)= ..., db [C] (+)= column sums of dy when db != NULL.
+extern "C" int bgs_grouped_conv3x3_wgrad_nhwc_f32(const float* x, const float* dy, float* dw,
+                                                  float* db, int N, int H, int W, int C, int groups,
+                                                  int stride, int accumulate, void* workspace,
+                                                  bgs_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || groups <= 0 || (stride != 1 && stride != 2))
+    return BGS_ERR_INVALID_ARG;
+  if (!x || !dy || !dw || !workspace) return BGS_ERR_INVALID_ARG;
+  if (C % groups != 0) return BGS_ERR_UNSUPPORTED;
+  const int cg = C / groups;
+  const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  const long long M = (long long)N * Ho * Wo;
+  if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  int chunk;
+  const int chunks = grouped_wgrad_chunks(M, &chunk);
+  float* part = reinterpret_cast<float*>(workspace);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)chunks, (unsigned)((C * cg + 255) / 256));
+#define BGS_GW_LAUNCH(CG_)                                                                       \
+  hipLaunchKernelGGL((grouped_wgrad3x3_kernel<CG_>), grid, dim3(256), 0, st, x, dy, part, N, H, W, \
+                     C, Ho, Wo, stride, chunk)
+  if (cg == 4) BGS_GW_LAUNCH(4);
+  else if (cg == 8) BGS_GW_LAUNCH(8);
+  else if (cg == 16) BGS_GW_LAUNCH(16);
+  else if (cg == 32) BGS_GW_LAUNCH(32);
+  else return BGS_ERR_UNSUPPORTED;
+#undef BGS_GW_LAUNCH
+  if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
+  const int total = C * 9 * cg;
+  hipLaunchKernelGGL(grouped_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     st, part, dw, db, dy, total, chunks, C, M, accumulate);
   BGS_RETURN_LAUNCH_STATUS();
 }

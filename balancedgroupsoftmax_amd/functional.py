@@ -667,17 +667,9 @@ def linear_autograd(x, weight, bias=None, relu=False, mask_input=False):
     return y.view(M, Nout)
 
 
-def grouped_conv3x3_nhwc(x, w, bias, groups, stride=1, relu=False):
-    """Grouped 3x3 / pad 1 conv (ResNeXt conv2): x ``[N,H,W,C]``, w ``[C,3,3,C/groups]``.
-    Forward only (selectp 1 / 3 freeze the trunk)."""
-    _require_cuda(x, w, bias)
+def _grouped_conv3x3_launch(x, w, bias, groups, stride, relu):
     lib = capi.load()
-    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and w.is_contiguous()
-    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
-        raise NotImplementedError('no backward for the grouped conv (ResNeXt trunks train with '
-                                  'selectp = 1 / 3 only)')
     N, H, W, C = x.shape
-    assert tuple(w.shape) == (C, 3, 3, C // groups), (w.shape, C, groups)
     out = torch.empty((N, (H - 1) // stride + 1, (W - 1) // stride + 1, C), dtype=torch.float32,
                       device=x.device)
     rc = lib.bgs_grouped_conv3x3_nhwc_f32(capi.ptr(x), capi.ptr(w), capi.ptr(bias), capi.ptr(out),
@@ -687,10 +679,73 @@ def grouped_conv3x3_nhwc(x, w, bias, groups, stride=1, relu=False):
     return out
 
 
-def maxpool3x3s2_nhwc(x):
-    _require_cuda(x)
+def grouped_dgrad_filter(w, groups):
+    """``w [C,3,3,cg]`` -> ``wt[g*cg+cl][2-r][2-s][co_local] = w[g*cg+co_local][r][s][cl]``: the
+    filter of the data gradient (transposed inside each group, both spatial axes flipped)."""
+    C, _, _, cg = w.shape
+    return w.detach().view(groups, cg, 3, 3, cg).flip(2, 3).permute(0, 4, 2, 3, 1) \
+        .reshape(C, 3, 3, cg).contiguous()
+
+
+class _GroupedConvFn(torch.autograd.Function):
+    """Differentiable grouped 3x3 conv (+ bias + ReLU): ResNeXt conv2 under ``selectp = 0``
+    (resnext.py:47-57).  dx = the MFMA forward kernel on dy with the per-group transposed filter,
+    dw / db = ``bgs_grouped_conv3x3_wgrad_nhwc_f32``."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, groups, stride, relu):
+        y = _grouped_conv3x3_launch(x.detach(), w.detach(), None if bias is None else bias.detach(),
+                                    groups, stride, relu)
+        ctx.cfg = (groups, stride, bool(relu), bias is not None)
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        groups, stride, relu, has_bias = ctx.cfg
+        lib = capi.load()
+        dz = dy.contiguous()
+        if relu:
+            dz = torch.ops.aten.threshold_backward(dz, y, 0.0)
+        N, H, W, C = x.shape
+        st = capi.current_stream(x.device)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = grouped_dgrad_filter(w, groups)
+            dx = torch.empty_like(x)
+            rc = lib.bgs_grouped_conv3x3_dgrad_nhwc_f32(capi.ptr(dz), capi.ptr(wt), capi.ptr(dx), N,
+                                                        H, W, C, groups, stride, st)
+            capi.check('bgs_grouped_conv3x3_dgrad_nhwc_f32', rc)
+        want_b = has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            dw = torch.empty_like(w)
+            db = torch.empty((C,), dtype=torch.float32, device=x.device) if want_b else None
+            ws = _workspace(lib.bgs_grouped_conv3x3_wgrad_workspace_bytes(N, H, W, C, groups, stride),
+                            x.device)
+            rc = lib.bgs_grouped_conv3x3_wgrad_nhwc_f32(capi.ptr(x), capi.ptr(dz), capi.ptr(dw),
+                                                        capi.ptr(db), N, H, W, C, groups, stride, 0,
+                                                        capi.ptr(ws), st)
+            capi.check('bgs_grouped_conv3x3_wgrad_nhwc_f32', rc)
+        return dx, dw, db, None, None, None
+
+
+def grouped_conv3x3_nhwc(x, w, bias, groups, stride=1, relu=False):
+    """Grouped 3x3 / pad 1 conv (ResNeXt conv2): x ``[N,H,W,C]``, w ``[C,3,3,C/groups]``; records
+    an autograd node when an input requires grad."""
+    _require_cuda(x, w, bias)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and w.is_contiguous()
+    N, H, W, C = x.shape
+    assert tuple(w.shape) == (C, 3, 3, C // groups), (w.shape, C, groups)
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or
+                                    (bias is not None and bias.requires_grad)):
+        return _GroupedConvFn.apply(x, w, bias, int(groups), int(stride), bool(relu))
+    return _grouped_conv3x3_launch(x, w, bias, groups, stride, relu)
+
+
+def _maxpool_launch(x):
     lib = capi.load()
-    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
     N, H, W, C = x.shape
     out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float32,
                       device=x.device)
@@ -698,6 +753,35 @@ def maxpool3x3s2_nhwc(x):
                                        capi.current_stream(x.device))
     capi.check('bgs_maxpool3x3s2_nhwc_f32', rc)
     return out
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return _maxpool_launch(x.detach())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        lib = capi.load()
+        N, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        rc = lib.bgs_maxpool3x3s2_bwd_nhwc_f32(capi.ptr(x), capi.ptr(dy.contiguous()), capi.ptr(dx),
+                                               N, H, W, C, capi.current_stream(x.device))
+        capi.check('bgs_maxpool3x3s2_bwd_nhwc_f32', rc)
+        return dx
+
+
+def maxpool3x3s2_nhwc(x):
+    """3x3 / stride 2 / pad 1 max pooling (ResNet stem); differentiable when ``x`` requires grad
+    (``frozen_stages < 1``)."""
+    _require_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _MaxPoolFn.apply(x)
+    return _maxpool_launch(x)
 
 
 # ----------------------------------------------------------------------------------------

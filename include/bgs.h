@@ -268,15 +268,35 @@ int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits);
 /* Grouped 3x3 convolution (pad 1, stride 1 or 2) + bias + ReLU, NHWC: conv2 of the ResNeXt
  * bottleneck (mmdet/models/backbones/resnext.py:47-57, cfg 5 = X101-64x4d).  x [N,H,W,C],
  * w [C,3,3,C/groups] (output channel, tap, input channel within the group), bias [C] or NULL,
- * y [N,Ho,Wo,C].  C/groups in {4, 8, 16, 32}.  Forward only. */
+ * y [N,Ho,Wo,C].  C/groups in {4, 8, 16, 32}. */
 int bgs_grouped_conv3x3_nhwc_f32(const float* x, const float* w, const float* bias, float* y,
                                  int N, int H, int W, int C, int groups, int stride, int relu,
                                  bgs_stream_t stream);
+
+/* Backward of bgs_grouped_conv3x3_nhwc_f32 (`selectp = 0` on the ResNeXt configs; the reference
+ * gets it from cuDNN through autograd of nn.Conv2d(groups=...), resnext.py:47-57).
+ * dgrad: dy [N,Ho,Wo,C] -> dx [N,H,W,C] with the caller's re-laid-out filter
+ *   wt[g*cg+cl][2-r][2-s][co_local] = w[g*cg+co_local][r][s][cl] (transposed inside each group,
+ *   flipped); stride 1 or 2 (the MFMA forward kernel on dy, zero-upsampled for stride 2).
+ * wgrad: dw [C,3,3,C/groups] (+)= sum_m dy[m,co] x[..]; db [C] (+)= column sums of dy (db may be
+ *   NULL); partial sums per 1024-pixel chunk are added in a fixed order (bitwise reproducible);
+ *   workspace >= bgs_grouped_conv3x3_wgrad_workspace_bytes(...). */
+int bgs_grouped_conv3x3_dgrad_nhwc_f32(const float* dy, const float* wt, float* dx, int N, int H,
+                                       int W, int C, int groups, int stride, bgs_stream_t stream);
+size_t bgs_grouped_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int C, int groups, int stride);
+int bgs_grouped_conv3x3_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, float* db, int N,
+                                       int H, int W, int C, int groups, int stride, int accumulate,
+                                       void* workspace, bgs_stream_t stream);
 
 /* 3x3 / stride 2 / pad 1 max pooling, NHWC (ResNet stem, resnet.py:452). C % 4 == 0.
  * y [N, (H-1)/2+1, (W-1)/2+1, C]. */
 int bgs_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C,
                               bgs_stream_t stream);
+/* Its backward (`frozen_stages < 1`): x = the pool's input, dy [N,Ho,Wo,C] -> dx [N,H,W,C]
+ * (overwritten).  The gradient of a window goes to its FIRST maximum in scan order, as in torch's
+ * max_pool2d backward; gather formulation, no atomics. */
+int bgs_maxpool3x3s2_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int N, int H, int W,
+                                  int C, bgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Multi-level RoIAlign forward (NHWC).  Replaces SingleRoIExtractor.forward

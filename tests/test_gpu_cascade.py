@@ -30,6 +30,102 @@ def test_grouped_conv3x3_vs_torch_cpu(cg, stride):
     assert float((got.permute(0, 3, 1, 2).cpu() - exp).abs().max()) < 1e-4 * float(exp.abs().max())
 
 
+@pytest.mark.parametrize('cg,stride,hw', [(4, 1, (13, 18)), (8, 2, (13, 18)), (16, 1, (12, 17)),
+                                          (32, 2, (14, 20)), (32, 1, (9, 11)), (4, 2, (16, 16))])
+def test_grouped_conv3x3_backward_vs_torch_autograd(cg, stride, hw):
+    """dx / dw / db of the grouped 3x3 conv + ReLU (ResNeXt conv2 under selectp = 0,
+    resnext.py:47-57) against torch-CPU fp64 autograd of ``F.conv2d(groups=...)``."""
+    rs = np.random.RandomState(cg * 10 + stride)
+    groups = 8
+    C = cg * groups
+    H, W = hw
+    x = rs.randn(2, H, W, C).astype(np.float32)
+    w = (rs.randn(C, cg, 3, 3) * 0.2).astype(np.float32)
+    b = rs.randn(C).astype(np.float32)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).double().requires_grad_(True)
+    wt = torch.from_numpy(w).double().requires_grad_(True)
+    bt = torch.from_numpy(b).double().requires_grad_(True)
+    yt = F.relu(F.conv2d(xt, wt, bt, stride=stride, padding=1, groups=groups))
+    gy = rs.randn(*yt.shape).astype(np.float32)
+    yt.backward(torch.from_numpy(gy).double())
+    xd = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    wd = torch.from_numpy(np.ascontiguousarray(w.transpose(0, 2, 3, 1))).to(DEV).requires_grad_(True)
+    bd = torch.from_numpy(b).to(DEV).requires_grad_(True)
+    yd = BF.grouped_conv3x3_nhwc(xd, wd, bd, groups, stride=stride, relu=True)
+    assert float((yd.permute(0, 3, 1, 2).detach().cpu().double() - yt.detach()).abs().max()) < 1e-4
+    yd.backward(torch.from_numpy(np.ascontiguousarray(gy.transpose(0, 2, 3, 1))).to(DEV))
+    for got, exp in ((xd.grad.permute(0, 3, 1, 2), xt.grad), (wd.grad.permute(0, 3, 1, 2), wt.grad),
+                     (bd.grad, bt.grad)):
+        assert float((got.cpu().double() - exp).abs().max()) < 2e-5 * float(exp.abs().max())
+    # weight gradient is bitwise reproducible (fixed-order chunk reduction)
+    xd2 = torch.from_numpy(x).to(DEV)
+    wd2 = wd.detach().clone().requires_grad_(True)
+    BF.grouped_conv3x3_nhwc(xd2, wd2, None, groups, stride=stride, relu=False).sum().backward()
+    wd3 = wd.detach().clone().requires_grad_(True)
+    BF.grouped_conv3x3_nhwc(xd2, wd3, None, groups, stride=stride, relu=False).sum().backward()
+    assert torch.equal(wd2.grad, wd3.grad)
+
+
+def test_maxpool_backward_and_trainable_stem_vs_torch():
+    """``frozen_stages = 0`` (resnet.py:483-494): max-pool backward (first maximum of a window, the
+    element torch routes to — ties included) and the stem conv's weight / BN gradients."""
+    rs = np.random.RandomState(4)
+    x = rs.randn(2, 17, 23, 8).astype(np.float32)
+    x[0, 3:6, 4:9] = 1.5                                   # plateaus: ties inside windows
+    x = np.round(x * 4) / 4                                # many exact ties
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).double().requires_grad_(True)
+    yt = F.max_pool2d(xt, 3, 2, 1)
+    gy = rs.randn(*yt.shape).astype(np.float32)
+    yt.backward(torch.from_numpy(gy).double())
+    xd = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    yd = BF.maxpool3x3s2_nhwc(xd)
+    np.testing.assert_array_equal(yd.detach().permute(0, 3, 1, 2).cpu().numpy(), yt.detach().float().numpy())
+    yd.backward(torch.from_numpy(np.ascontiguousarray(gy.transpose(0, 2, 3, 1))).to(DEV))
+    np.testing.assert_allclose(xd.grad.permute(0, 3, 1, 2).cpu().numpy(), xt.grad.float().numpy(),
+                               rtol=0, atol=1e-6)
+    # whole stem + layer1 with frozen_stages = 0 vs torch-CPU autograd of the reference arithmetic
+    torch.manual_seed(1)
+    m = bgs.build_backbone(dict(type='ResNet', depth=50, num_stages=4, out_indices=(0,),
+                                frozen_stages=-1, style='pytorch'))
+    m.init_weights()
+    from tests.test_gpu_detector import randomize_bn
+    randomize_bn(m)
+    for blk in m.layer1:
+        torch.nn.init.constant_(blk.bn3.weight, 0.5)
+    m.train()
+    img = torch.randn(1, 3, 64, 96)
+    ref = {k: v.detach().clone().double().requires_grad_(True) for k, v in m.named_parameters()}
+    bufs = {k: v.detach().clone().double() for k, v in m.named_buffers()}
+
+    def cbn(t, pre, bnp, stride, pad, relu):
+        t = F.conv2d(t, ref[pre + '.weight'], None, stride, pad)
+        t = F.batch_norm(t, bufs[bnp + '.running_mean'], bufs[bnp + '.running_var'],
+                         ref[bnp + '.weight'], ref[bnp + '.bias'], False, 0., 1e-5)
+        return F.relu(t) if relu else t
+    t = cbn(img.double(), 'conv1', 'bn1', 2, 3, True)
+    t = F.max_pool2d(t, 3, 2, 1)
+    for i in range(3):
+        p = 'layer1.%d.' % i
+        idt = t if i else cbn(t, p + 'downsample.0', p + 'downsample.1', 1, 0, False)
+        o = cbn(t, p + 'conv1', p + 'bn1', 1, 0, True)
+        o = cbn(o, p + 'conv2', p + 'bn2', 1, 1, True)
+        o = cbn(o, p + 'conv3', p + 'bn3', 1, 0, False)
+        t = F.relu(o + idt)
+    g = torch.randn(t.shape, dtype=torch.float64)
+    t.backward(g)
+    m.to(DEV)
+    (out,) = m(img.to(DEV))
+    assert float((out.permute(0, 3, 1, 2).detach().cpu().double() - t.detach()).abs().max()) < \
+        1e-4 * float(t.detach().abs().max())
+    out.backward(g.permute(0, 2, 3, 1).contiguous().float().to(DEV))
+    params = dict(m.named_parameters())
+    for k in ('conv1.weight', 'bn1.weight', 'bn1.bias', 'layer1.0.conv2.weight', 'layer1.2.bn3.bias'):
+        got, exp = params[k].grad.cpu().double(), ref[k].grad
+        assert got is not None
+        rel = float((got - exp).abs().max() / exp.abs().max().clamp(min=1e-12))
+        assert rel < 2e-3, (k, rel)      # a ReLU flip at fp32 noise moves single entries
+
+
 def test_resnext_stage_forward_vs_torch_cpu():
     from tests.test_gpu_detector import randomize_bn, ref_bottleneck, nchw, rel_err
     torch.manual_seed(0)
