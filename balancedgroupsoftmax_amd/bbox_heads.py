@@ -280,9 +280,9 @@ class ConvFCBBoxHead(BBoxHead):
 
     def forward(self, x, nhwc=False):
         """``x``: RoI features ``[K, C, h, w]`` (reference layout) or, with ``nhwc=True``,
-        ``[K, h, w, C]`` as produced by our RoIAlign.  On the GPU every FC runs in the fp32-MFMA
-        GEMM kernel (bias + ReLU fused); on the CPU (shape checks only) plain nn.Linear."""
-        hip = x.is_cuda
+        ``[K, h, w, C]`` as produced by our RoIAlign.  Every FC runs in the MFMA GEMM kernel (bias +
+        ReLU fused).  (torch restatement for the CPU checks: oracle/tensor_forms.convfc_bbox_forward.)"""
+        BF._require_cuda(x)
         if self.with_avg_pool:
             if nhwc:
                 raise NotImplementedError('with_avg_pool on NHWC RoI features')
@@ -290,9 +290,6 @@ class ConvFCBBoxHead(BBoxHead):
         x = x.reshape(x.size(0), -1)
 
         def fc_apply(fc, t, relu, first=False, t_is_relu=False):
-            if not hip:
-                y = fc(t)
-                return self.relu(y) if relu else y
             w = self._fc1_weight(fc, nhwc) if first else fc.weight
             # every consumer of a hidden FC output is another FC of this head: the ReLU backward
             # rides in the consumers' dgrad epilogue

@@ -7,15 +7,15 @@
 ``forward_train`` returns the reference's loss dict (``loss_rpn_cls``/``loss_rpn_bbox``: lists
 over the 5 levels, ``loss_cls_bin0..B-1``, ``loss_bbox``).  The orchestration differs where the
 reference synchronises with the host: proposals, RoI assignment and sampling are fixed-shape
-device tensors here (assign.py), so one training iteration issues no ``.item()`` /
-``nonzero()`` / D2H copy at all.
+device tensors produced by fused kernels (csrc/det_targets.hip, csrc/sampler.hip), so one
+training iteration issues no ``.item()`` / ``nonzero()`` / D2H copy at all.  There is ONE path:
+CPU tensors raise (the tensor-op restatements used to pin the kernels are test infrastructure,
+oracle/tensor_forms.py).
 """
 import torch
 import torch.nn as nn
 
-from . import assign as A
 from . import builder
-from .box_ops import bbox2delta
 from .registry import DETECTORS
 
 
@@ -74,34 +74,13 @@ class TwoStageDetector(nn.Module):
         return self.neck(x) if self.with_neck else x
 
     # -- RoI assignment + sampling (two_stage.py:192-210), fixed shape ---------------------
-    def _assign_and_sample(self, proposals, prop_valid, gt_bboxes, gt_labels, generator=None):
-        """One image.  Returns dict of fixed-size tensors for ``num`` sampled RoIs:
-        ``bboxes [num,4]``, ``is_pos``, ``valid``, ``labels``, ``gt_bboxes`` (of positives)."""
-        rc = self.train_cfg.rcnn
-        ac, sc = rc.assigner, rc.sampler
-        boxes = proposals[:, :4]
-        overlaps = A.bbox_overlaps(gt_bboxes, boxes)
-        assigned, _ = A.max_iou_assign(overlaps, ac.pos_iou_thr, ac.neg_iou_thr,
-                                       ac.get('min_pos_iou', 0.0),
-                                       ac.get('gt_max_assign_all', True), valid=prop_valid)
-        G = gt_bboxes.size(0)
-        if sc.get('add_gt_as_proposals', True):
-            # base_sampler.py:49-53 + AssignResult.add_gt_: GTs are prepended and own themselves
-            boxes = torch.cat([gt_bboxes, boxes], 0)
-            assigned = torch.cat([torch.arange(1, G + 1, device=boxes.device), assigned])
-        inds, is_pos, valid = A.sample_fixed(assigned, sc.num, sc.pos_fraction, generator)
-        a = assigned[inds]
-        gi = (a - 1).clamp(min=0)
-        labels = torch.where(is_pos, gt_labels[gi], torch.zeros_like(gt_labels[gi]))
-        return dict(bboxes=boxes[inds], is_pos=is_pos, valid=valid, labels=labels,
-                    gt_bboxes=gt_bboxes[gi])
-
-    def _sample_rois_fused(self, proposal_list, gt_bboxes, gt_labels, generator=None, rc=None,
+    def _sample_rois_fused(self, proposal_list, gt_bboxes, gt_labels, samplers=None, rc=None,
                            head=None):
-        """GPU path of two_stage.py:192-222: one batched assignment launch pair, the fixed-shape
-        sampler, and one kernel that emits rois / labels / box targets for all images.
+        """two_stage.py:192-222: one batched assignment launch pair, the fixed-shape sampler, and
+        one kernel that emits rois / labels / box targets for all images.
         ``rc`` / ``head``: the stage's rcnn config and bbox head (cascade); defaults: the
-        detector's own."""
+        detector's own.  ``samplers``: test hook (``dict(rcnn=fn)``: a caller-supplied draw
+        instead of the device RandomSampler; oracle/tensor_forms.sampler_hooks)."""
         from . import functional as BF
         rc = self.train_cfg.rcnn if rc is None else rc
         ac, sc = rc.assigner, rc.sampler
@@ -124,20 +103,18 @@ class TwoStageDetector(nn.Module):
                 a = torch.cat([torch.arange(1, G + 1, device=a.device, dtype=torch.int32), a])
             boxes_l.append(b.contiguous())
             assigned_l.append(a.contiguous())
-            if generator is not None:      # reproducible tests: the tensor-op sampler
-                inds, _, valid = A.sample_fixed(a, sc.num, sc.pos_fraction, generator)
+            if samplers is not None:       # test hook: caller-supplied draw
+                inds, _, valid = samplers['rcnn'](a, sc.num, sc.pos_fraction)
                 inds_l.append(inds.contiguous())
                 valid_l.append(valid)
-        if generator is None and all(a.numel() <= 4096 for a in assigned_l):
+        if samplers is None:
+            if any(a.numel() > 4096 for a in assigned_l):
+                raise NotImplementedError('bgs_sample_rois sorts <= 4096 candidates per image in LDS '
+                                          '(rpn_proposal.max_num + GT boxes)')
             # one launch for the batch (csrc/sampler.hip: sort of (class, random key) composites)
             inds_all, _, valid_all = BF.sample_rois(assigned_l, sc.num, sc.pos_fraction)
             inds_l = [inds_all[i] for i in range(N)]
             valid_l = [valid_all[i].bool() for i in range(N)]
-        elif generator is None:
-            for a in assigned_l:
-                inds, _, valid = A.sample_fixed(a, sc.num, sc.pos_fraction, None)
-                inds_l.append(inds.contiguous())
-                valid_l.append(valid)
         if self.with_mask or isinstance(self.bbox_head, nn.ModuleList):
             # (only the mask branch and the cascade refinement read these: skipped for the plain
             #  box detectors, ~10 small launches)
@@ -156,24 +133,8 @@ class TwoStageDetector(nn.Module):
             sc.num, head.target_means, head.target_stds, rc.pos_weight)
         return rois, (labels, lw, bt, bw)
 
-    def _bbox_targets(self, samples):
-        """``bbox_target`` (mmdet/core/bbox/bbox_target.py:7-61) on the fixed-size samples."""
-        rc = self.train_cfg.rcnn
-        head = self.bbox_head
-        labels, lw, bt, bw = [], [], [], []
-        for s in samples:
-            pos = s['is_pos'] & s['valid']
-            posf = pos.float()
-            d = bbox2delta(s['bboxes'], s['gt_bboxes'], head.target_means, head.target_stds)
-            labels.append(torch.where(pos, s['labels'], torch.zeros_like(s['labels'])))
-            pw = 1.0 if rc.pos_weight <= 0 else rc.pos_weight
-            lw.append(posf * pw + (s['valid'] & ~s['is_pos']).float())
-            bt.append(torch.where(pos[:, None], d, torch.zeros_like(d)))   # (not d*0: NaN-safe)
-            bw.append(posf[:, None].expand(-1, 4).contiguous())
-        return torch.cat(labels), torch.cat(lw), torch.cat(bt), torch.cat(bw)
-
     # -- RPN part of a training iteration ------------------------------------------------------
-    def _rpn_forward_train(self, x, img_meta, gt_bboxes, proposals, generator, losses):
+    def _rpn_forward_train(self, x, img_meta, gt_bboxes, proposals, samplers, losses):
         """RPN losses + the fixed-shape proposal list (two_stage.py:157-176).
 
         (Measured and dropped: launching the loss branch — anchor assignment, sampler, BCE +
@@ -185,7 +146,7 @@ class TwoStageDetector(nn.Module):
             return [(p, torch.ones(p.size(0), dtype=torch.bool, device=p.device)) for p in proposals]
         cls_scores, bbox_preds = self.rpn_head(x)
         losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
-                                         self.train_cfg.rpn, generator=generator))
+                                         self.train_cfg.rpn, samplers=samplers))
         proposal_cfg = self.train_cfg.get('rpn_proposal', None)
         if proposal_cfg is None:
             proposal_cfg = self.test_cfg.rpn
@@ -197,21 +158,14 @@ class TwoStageDetector(nn.Module):
         return proposal_list
 
     def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
-                      gt_masks=None, proposals=None, generator=None):
+                      gt_masks=None, proposals=None, samplers=None):
         x = self.extract_feat(img)
         losses = dict()
-        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, generator, losses)
+        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, samplers, losses)
         if self.with_bbox:
-            if img.is_cuda and self.train_cfg.rcnn.assigner.get('gt_max_assign_all', True):
-                rois, targets = self._sample_rois_fused(proposal_list, gt_bboxes, gt_labels,
-                                                        generator)
-            else:   # tensor-op form (device-agnostic; what the CPU tests check vs the reference)
-                samples = [self._assign_and_sample(proposal_list[i][0], proposal_list[i][1],
-                                                   gt_bboxes[i], gt_labels[i], generator)
-                           for i in range(img.size(0))]
-                rois = torch.cat([torch.cat([s['bboxes'].new_full((s['bboxes'].size(0), 1), i),
-                                             s['bboxes']], 1) for i, s in enumerate(samples)], 0)
-                targets = self._bbox_targets(samples)
+            if not self.train_cfg.rcnn.assigner.get('gt_max_assign_all', True):
+                raise NotImplementedError('gt_max_assign_all=False')
+            rois, targets = self._sample_rois_fused(proposal_list, gt_bboxes, gt_labels, samplers)
             bbox_feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
             cls_score, bbox_pred = self.bbox_head(bbox_feats, nhwc=True)
             losses.update(self.bbox_head.loss(cls_score, bbox_pred, *targets))
@@ -399,17 +353,17 @@ class CascadeRCNN(TwoStageDetector):
             return [(boxes[j * num:(j + 1) * num], keep[j]) for j in range(n_img)]
 
     def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
-                      gt_masks=None, proposals=None, generator=None):
+                      gt_masks=None, proposals=None, samplers=None):
         if not img.is_cuda:
             raise NotImplementedError('CascadeRCNN.forward_train runs on the GPU path only')
         x = self.extract_feat(img)
         losses = dict()
-        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, generator, losses)
+        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, samplers, losses)
         for i in range(self.num_stages):
             rc = self.train_cfg.rcnn[i]
             lw = self.train_cfg.stage_loss_weights[i]
             head, ext = self.bbox_head[i], self.bbox_roi_extractor[i]
-            rois, targets = self._sample_rois_fused(proposal_list, gt_bboxes, gt_labels, generator,
+            rois, targets = self._sample_rois_fused(proposal_list, gt_bboxes, gt_labels, samplers,
                                                     rc=rc, head=head)
             feats = ext(x[:ext.num_inputs], rois)
             cls_score, bbox_pred = head(feats, nhwc=True)
@@ -534,14 +488,14 @@ class HybridTaskCascade(CascadeRCNN):
         return head.loss_from_features(feats, mask_targets, pos_labels, valid)
 
     def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
-                      gt_masks=None, gt_semantic_seg=None, proposals=None, generator=None):
+                      gt_masks=None, gt_semantic_seg=None, proposals=None, samplers=None):
         if not img.is_cuda:
             raise NotImplementedError('HybridTaskCascade.forward_train runs on the GPU path only')
         if gt_masks is None:
             raise ValueError('HTC needs gt_masks (per image a uint8 [G, H, W] tensor)')
         x = self.extract_feat(img)
         losses = dict()
-        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, generator, losses)
+        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, samplers, losses)
         semantic_feat = None
         if self.with_semantic:
             if gt_semantic_seg is None:
@@ -553,7 +507,7 @@ class HybridTaskCascade(CascadeRCNN):
             lw = self.train_cfg.stage_loss_weights[i]
             head, ext = self.bbox_head[i], self.bbox_roi_extractor[i]
             num = rc.sampler.num
-            rois, targets = self._sample_rois_fused(proposal_list, gt_bboxes, gt_labels, generator,
+            rois, targets = self._sample_rois_fused(proposal_list, gt_bboxes, gt_labels, samplers,
                                                     rc=rc, head=head)
             feats = self._fused_roi_feats(ext, x, rois, semantic_feat, 'bbox')
             cls_score, bbox_pred = head(feats, nhwc=True)
@@ -567,7 +521,7 @@ class HybridTaskCascade(CascadeRCNN):
                 # htc.py:264-283: the mask branch trains on RoIs re-assigned and re-sampled from
                 # the boxes this stage's box head just refined
                 with torch.no_grad():
-                    mask_rois, mt = self._sample_rois_fused(refined, gt_bboxes, gt_labels, generator,
+                    mask_rois, mt = self._sample_rois_fused(refined, gt_bboxes, gt_labels, samplers,
                                                             rc=rc, head=head)
                     mask_labels = mt[0]
             loss_mask = self._htc_mask_forward_train(i, x, mask_rois, mask_labels, gt_masks, rc,

@@ -11,13 +11,12 @@ reference's ``weight_reduce_loss`` (mmdet/models/losses/utils.py:26-52):
     avg_factor None :  plain none / mean / sum
 
 Inside ``GSBBoxHeadWith0.loss`` these modules are *configuration carriers* (loss_weight,
-beta): the arithmetic runs in the fused HIP kernels (functional.py).  Called directly
-(e.g. a plain ``BBoxHead`` or the RPN's sigmoid mode) they evaluate the same formulas
-with tensor ops.
+beta): the arithmetic runs in the fused HIP kernels (functional.py).  Called directly (a plain
+``BBoxHead``) they run HIP kernels as well — there is no tensor-op / CPU evaluation in the
+product; the torch formulas that pin the kernels live in oracle/tensor_forms.py.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .registry import LOSSES
 
@@ -47,36 +46,37 @@ def reduce_weighted(elementwise, weight=None, reduction='mean', avg_factor=None)
     raise ValueError('unknown reduction %r' % (reduction,))
 
 
-def softmax_ce(pred, label, weight=None, reduction='mean', avg_factor=None):
-    per_row = F.cross_entropy(pred, label, reduction='none')
-    w = None if weight is None else weight.float()
-    return reduce_weighted(per_row, w, reduction, avg_factor)
-
-
-def sigmoid_bce(pred, label, weight=None, reduction='mean', avg_factor=None):
-    """RPN objectness mode.  Integer class labels are expanded to one-hot over
-    ``pred.size(-1)`` channels with label c>=1 -> channel c-1 (cross_entropy_loss.py:22-32)."""
-    if pred.dim() != label.dim():
-        # label c >= 1 -> channel c-1 (no nonzero(): that would be a host sync)
-        chan = torch.arange(1, pred.size(-1) + 1, device=label.device, dtype=label.dtype)
-        label = (label.view(-1, 1) == chan.view(1, -1)).to(label.dtype)
-        if weight is not None:
-            weight = weight.view(-1, 1).expand(weight.size(0), pred.size(-1))
-    w = None if weight is None else weight.float()
-    el = F.binary_cross_entropy_with_logits(pred, label.float(), w, reduction='none')
-    return reduce_weighted(el, None, reduction, avg_factor)
-
-
-def mask_bce(pred, target, label, reduction='mean', avg_factor=None):
-    """Mask head mode: BCE on the GT-class channel only (cross_entropy_loss.py:54-61)."""
-    assert reduction == 'mean' and avg_factor is None
-    rows = torch.arange(pred.size(0), dtype=torch.long, device=pred.device)
-    chosen = pred[rows, label].squeeze(1)
-    return F.binary_cross_entropy_with_logits(chosen, target, reduction='mean')[None]
+def _avg_and_scale(n_rows, reduction, avg_factor):
+    """(avg passed to the kernel, scalar to divide the kernel's result by) for the
+    ``weight_reduce_loss`` rules above; 'none' has no fused form."""
+    if reduction == 'none':
+        raise NotImplementedError("reduction='none': the fused HIP losses return reduced scalars")
+    if avg_factor is not None:
+        if reduction != 'mean':
+            raise ValueError('avg_factor can not be used with reduction="sum"')
+        if isinstance(avg_factor, torch.Tensor):
+            return 1.0, avg_factor.to(torch.float32)
+        return float(avg_factor), None
+    if reduction == 'mean':
+        return float(n_rows), None
+    if reduction == 'sum':
+        return 1.0, None
+    raise ValueError('unknown reduction %r' % (reduction,))
 
 
 @LOSSES.register_module
 class CrossEntropyLoss(nn.Module):
+    """Registry key + ctor kwargs of the reference (cross_entropy_loss.py:64-103).  Inside the BAGS
+    heads / RPN / mask heads the module is a configuration carrier (``loss_weight``,
+    ``use_sigmoid``): the arithmetic runs in the fused kernels (``bgs_gs_loss_fwd_bwd``,
+    ``bgs_rpn_loss``, ``bgs_mask_bce``).  Called directly it runs on the GPU too:
+
+    * softmax mode (plain ``BBoxHead``): ONE bin of the GroupSoftmax row kernel spanning all
+      ``K`` columns — ``sum_r w_r (lse_r - z_r[label_r]) / avg``;
+    * sigmoid / mask mode: fused with their producers (``RPNHead.loss``,
+      ``FCNMaskHead.loss_from_features``) — a direct call raises, pointing there.
+
+    There is no CPU / tensor-op path (the torch formulas are in oracle/tensor_forms.py)."""
 
     def __init__(self, use_sigmoid=False, use_mask=False, reduction='mean', loss_weight=1.0):
         super().__init__()
@@ -84,28 +84,38 @@ class CrossEntropyLoss(nn.Module):
             raise AssertionError('use_sigmoid and use_mask are mutually exclusive')
         self.use_sigmoid, self.use_mask = use_sigmoid, use_mask
         self.reduction, self.loss_weight = reduction, loss_weight
-        self.cls_criterion = (sigmoid_bce if use_sigmoid else
-                              mask_bce if use_mask else softmax_ce)
 
     def forward(self, cls_score, label, weight=None, avg_factor=None, reduction_override=None,
                 **kwargs):
+        from . import functional as BF
         assert reduction_override in _REDUCTIONS
         red = reduction_override or self.reduction
-        return self.loss_weight * self.cls_criterion(cls_score, label, weight, reduction=red,
-                                                     avg_factor=avg_factor, **kwargs)
-
-
-def smooth_l1(pred, target, weight=None, beta=1.0, reduction='mean', avg_factor=None):
-    """0.5 d^2 / beta for |d| < beta else |d| - beta/2 (smooth_l1_loss.py:9-15)."""
-    assert beta > 0
-    assert pred.size() == target.size() and target.numel() > 0
-    d = (pred - target).abs()
-    el = torch.where(d < beta, d * d * (0.5 / beta), d - 0.5 * beta)
-    return reduce_weighted(el, weight, reduction, avg_factor)
+        if self.use_sigmoid:
+            raise NotImplementedError('CrossEntropyLoss(use_sigmoid=True) is evaluated inside '
+                                      'RPNHead.loss (bgs_rpn_loss: targets + BCE + SmoothL1 fused)')
+        if self.use_mask:
+            raise NotImplementedError('CrossEntropyLoss(use_mask=True) is evaluated inside '
+                                      'FCNMaskHead.loss_from_features (bgs_mask_bce: GT-channel '
+                                      'logits + BCE fused)')
+        BF._require_cuda(cls_score, label, weight)
+        n, k = cls_score.shape
+        avg, div = _avg_and_scale(n, red, avg_factor)
+        wts = (torch.ones((1, n), dtype=torch.float32, device=cls_score.device) if weight is None
+               else weight.to(torch.float32).reshape(1, n).contiguous())
+        bl = label.to(torch.int32).reshape(1, n).contiguous()
+        avg_t = torch.full((1,), avg, dtype=torch.float32, device=cls_score.device)
+        val = BF.group_softmax_loss(cls_score, bl, [[0, k]], wts, avg_t)[0]
+        if div is not None:
+            val = val / div
+        return self.loss_weight * val
 
 
 @LOSSES.register_module
 class SmoothL1Loss(nn.Module):
+    """Registry key + ctor kwargs of the reference (smooth_l1_loss.py:18-45): ``0.5 d^2 / beta`` for
+    ``|d| < beta`` else ``|d| - beta / 2``.  The box heads read ``beta`` / ``loss_weight`` and run
+    ``bgs_bbox_smooth_l1_fwd_bwd`` on the class-indexed ``[N, 4C]`` predictions; a direct call on
+    ``pred / target / weight [P, 4]`` runs the same kernel in its class-agnostic form."""
 
     def __init__(self, beta=1.0, reduction='mean', loss_weight=1.0):
         super().__init__()
@@ -113,10 +123,18 @@ class SmoothL1Loss(nn.Module):
 
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None,
                 **kwargs):
+        from . import functional as BF
         assert reduction_override in _REDUCTIONS
         red = reduction_override or self.reduction
-        return self.loss_weight * smooth_l1(pred, target, weight, beta=self.beta, reduction=red,
-                                            avg_factor=avg_factor, **kwargs)
+        BF._require_cuda(pred, target, weight)
+        assert pred.dim() == 2 and pred.shape[1] == 4 and pred.size() == target.size() and \
+            target.numel() > 0, (tuple(pred.shape), tuple(target.shape))
+        avg, div = _avg_and_scale(pred.numel(), red, avg_factor)
+        w = torch.ones_like(pred, dtype=torch.float32) if weight is None else weight
+        rows = torch.ones((pred.shape[0],), dtype=torch.int64, device=pred.device)
+        val = BF.bbox_smooth_l1_loss(pred, rows, target, w, 1, beta=self.beta, avg_factor=avg,
+                                     loss_weight=self.loss_weight)
+        return val if div is None else val / div
 
 
 def accuracy(pred, target, topk=1):

@@ -103,15 +103,7 @@ class FCNMaskHead(nn.Module):
         """Reference signature (``labels=None``): ``[P, num_classes, 2h, 2w]`` logits (NCHW).  With
         ``labels [P]``: only ``mask_pred[i, labels[i]]`` -> ``[P, 2h, 2w]`` (what the loss and
         ``get_seg_masks`` read)."""
-        if not x.is_cuda:            # CPU: shape / state-dict checks only (plain torch modules)
-            t = x if not nhwc else x.permute(0, 3, 1, 2)
-            for m in self.convs:
-                t = self.relu(m.conv(t))
-            t = self.relu(self.upsample(t))
-            pred = self.conv_logits(t)
-            if labels is None:
-                return pred
-            return pred[torch.arange(pred.size(0)), self._channel(labels)]
+        BF._require_cuda(x)          # (torch restatement: oracle/tensor_forms.fcn_mask_forward)
         f = self.features(x, nhwc=nhwc)
         P, H, W, C = f.shape
         wl = self.conv_logits.weight.view(-1, C)
@@ -136,8 +128,12 @@ class FCNMaskHead(nn.Module):
 
     # -- loss ---------------------------------------------------------------------------------
     def loss(self, mask_pred, mask_targets, labels):
-        """Reference signature on full ``[P, K, S, S]`` logits (fcn_mask_head.py:113-123)."""
-        return dict(loss_mask=self.loss_mask(mask_pred, mask_targets, self._channel(labels)))
+        """Reference signature on full ``[P, K, S, S]`` logits (fcn_mask_head.py:113-123).  Not
+        evaluated here: the product never materialises the K-channel logits (988 MB at P = 256);
+        use ``loss_from_features`` (GT-channel ``conv_logits`` + BCE fused, ``bgs_mask_bce``)."""
+        raise NotImplementedError('FCNMaskHead.loss on full [P, K, S, S] logits: call '
+                                  'loss_from_features(features(x), mask_targets, labels) — the '
+                                  'GT-channel logits and the BCE run fused (bgs_mask_bce)')
 
     def loss_from_features(self, feats, mask_targets, labels, valid=None):
         """Same value from the ``features()`` output ``[P, S, S, C]``: the single-channel
@@ -189,24 +185,7 @@ class HTCMaskHead(FCNMaskHead):
     def forward(self, x, res_feat=None, return_logits=True, return_feat=True, labels=None,
                 nhwc=False):
         """Reference signature (NCHW in / out).  ``labels``: only each RoI's own channel."""
-        if not x.is_cuda:
-            if nhwc:
-                x = x.permute(0, 3, 1, 2)
-                res_feat = None if res_feat is None else res_feat.permute(0, 3, 1, 2)
-            if res_feat is not None:
-                x = x + self.relu(self.conv_res.conv(res_feat))
-            for m in self.convs:
-                x = self.relu(m.conv(x))
-            res_out = x
-            outs = []
-            if return_logits:
-                pred = self.conv_logits(self.relu(self.upsample(x)))
-                if labels is not None:
-                    pred = pred[torch.arange(pred.size(0)), self._channel(labels)]
-                outs.append(pred)
-            if return_feat:
-                outs.append(res_out)
-            return outs if len(outs) > 1 else outs[0]
+        BF._require_cuda(x)          # (torch restatement: oracle/tensor_forms.htc_mask_forward)
         if not nhwc:
             x = x.permute(0, 2, 3, 1).contiguous()
             res_feat = None if res_feat is None else res_feat.permute(0, 2, 3, 1).contiguous()

@@ -10,8 +10,10 @@ Differences in *how*, not *what*:
   1x1 ``rpn_cls`` / ``rpn_reg`` are evaluated as ONE conv with concatenated output channels;
 * outputs stay NHWC ``[N,H,W,A]`` / ``[N,H,W,4A]`` — exactly the ``permute(0,2,3,1)`` order the
   reference flattens to (anchor_head.py:150-158, rpn_head.py:69-77);
-* targets: all anchors of an image are assigned in one vectorised pass on the device
-  (assign.py), no CPU fallback for >50 GTs, no numpy shuffles, no ``nonzero``;
+* targets: all anchors of a batch are assigned, sampled and turned into losses by fused kernels
+  (csrc/det_targets.hip, csrc/sampler.hip): no CPU fallback for >50 GTs, no numpy shuffles, no
+  ``nonzero``; ONE path — the tensor-op restatement that pins the kernels to the reference
+  classes is test infrastructure (oracle/tensor_forms.py);
 * proposals: the 5 levels x N images go through ONE batched on-device NMS launch pair
   (csrc/nms.hip) instead of 10 ``nms_cuda`` calls with a D2H copy each (rpn_head.py:92).
 """
@@ -19,10 +21,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import assign as A
 from . import functional as BF
 from .backbone import _fold_conv_bn, _FoldCache
-from .box_ops import bbox2delta, delta2bbox
 from .builder import build_loss
 from .registry import HEADS
 
@@ -163,70 +163,21 @@ class RPNHead(nn.Module):
         return anchor_list, valid_flag_list
 
     # -- loss ---------------------------------------------------------------------------
-    def anchor_targets(self, anchors, valid, gt_bboxes, img_shape, cfg, generator=None):
-        """``anchor_target_single`` (anchor_target.py:94-159) for one image, dense outputs over
-        ALL anchors: labels, label_weights ``[A]``, bbox_targets, bbox_weights ``[A,4]`` and the
-        device scalars n_pos, n_neg."""
-        ab = cfg.allowed_border
-        inside = valid
-        if ab >= 0:
-            img_h, img_w = img_shape[:2]
-            inside = valid & (anchors[:, 0] >= -ab) & (anchors[:, 1] >= -ab) & \
-                (anchors[:, 2] < img_w + ab) & (anchors[:, 3] < img_h + ab)
-        ac = cfg.assigner
-        overlaps = A.bbox_overlaps(gt_bboxes, anchors)
-        assigned, _ = A.max_iou_assign(overlaps, ac.pos_iou_thr, ac.neg_iou_thr,
-                                       ac.get('min_pos_iou', 0.0),
-                                       ac.get('gt_max_assign_all', True), valid=inside)
-        sc = cfg.sampler
-        pos, neg = A.sample_pos_neg_masks(assigned, sc.num, sc.pos_fraction,
-                                          sc.get('neg_pos_ub', -1), generator)
-        gt_of = gt_bboxes[(assigned - 1).clamp(min=0)]
-        deltas = bbox2delta(anchors, gt_of, self.target_means, self.target_stds)
-        posf = pos.to(anchors.dtype)
-        bbox_targets = torch.where(pos[:, None], deltas, torch.zeros_like(deltas))
-        bbox_weights = posf[:, None].expand(-1, 4)
-        labels = pos.long()
-        pw = 1.0 if cfg.pos_weight <= 0 else cfg.pos_weight
-        label_weights = posf * pw + neg.to(anchors.dtype)
-        return labels, label_weights, bbox_targets, bbox_weights, pos.sum(), neg.sum()
-
     def loss(self, cls_scores, bbox_preds, gt_bboxes, img_metas, cfg, gt_bboxes_ignore=None,
-             generator=None):
+             samplers=None):
         """Keys ``loss_rpn_cls`` / ``loss_rpn_bbox``: lists with one scalar per level
-        (rpn_head.py:37-53, anchor_head.py:163-207)."""
+        (rpn_head.py:37-53, anchor_head.py:163-207).  ONE path: the fused kernels
+        (``anchor_target`` + BCE + SmoothL1 in csrc/det_targets.hip / csrc/sampler.hip), which read
+        this head's own output buffers.  (The tensor-op restatement that pins them to the
+        reference classes lives in oracle/tensor_forms.py: test infrastructure.)
+        ``samplers``: test hook, ``dict(rpn=fn)`` replaces the device RandomSampler by a
+        caller-supplied draw so that two paths can be compared sample for sample."""
+        if not self._use_fused(cls_scores):
+            raise RuntimeError("RPNHead.loss reads the head's own GPU outputs: call forward() on "
+                               "CUDA tensors first and pass its results unchanged (there is no "
+                               "CPU / tensor-op path in the product)")
         featmap_sizes = [tuple(c.shape[1:3]) for c in cls_scores]
-        dev = cls_scores[0].device
-        if self._use_fused(cls_scores):
-            return self._loss_fused(featmap_sizes, gt_bboxes, img_metas, cfg, generator)
-        anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, dev)
-        n_lvl = [a.size(0) for a in anchor_list[0]]
-        per_img = []
-        n_pos_tot = n_neg_tot = 0
-        for i, meta in enumerate(img_metas):
-            anchors = torch.cat(anchor_list[i])
-            valid = torch.cat(valid_flag_list[i])
-            t = self.anchor_targets(anchors, valid, gt_bboxes[i], meta['img_shape'], cfg,
-                                    generator)
-            per_img.append(t[:4])
-            n_pos_tot = n_pos_tot + t[4].clamp(min=1)      # max(inds.numel(), 1) per image
-            n_neg_tot = n_neg_tot + t[5].clamp(min=1)
-        num_total_samples = (n_pos_tot + n_neg_tot).to(torch.float32)
-        stacked = [torch.stack([p[k] for p in per_img]) for k in range(4)]   # [N, A(,4)]
-        losses_cls, losses_bbox = [], []
-        start = 0
-        for lvl, n in enumerate(n_lvl):
-            sl = slice(start, start + n)
-            start += n
-            cs = cls_scores[lvl].reshape(-1, self.cls_out_channels).float()
-            bp = bbox_preds[lvl].reshape(-1, 4).float()
-            labels = stacked[0][:, sl].reshape(-1)
-            lw = stacked[1][:, sl].reshape(-1)
-            bt = stacked[2][:, sl].reshape(-1, 4)
-            bw = stacked[3][:, sl].reshape(-1, 4)
-            losses_cls.append(self.loss_cls(cs, labels, lw, avg_factor=num_total_samples))
-            losses_bbox.append(self.loss_bbox(bp, bt, bw, avg_factor=num_total_samples))
-        return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox)
+        return self._loss_fused(featmap_sizes, gt_bboxes, img_metas, cfg, samplers)
 
     # -- fused HIP path (csrc/det_targets.hip) -------------------------------------------------
     def _use_fused(self, cls_scores):
@@ -264,7 +215,7 @@ class RPNHead(nn.Module):
             self._anchor_cache[key] = torch.stack(rows).to(torch.uint8).contiguous()
         return self._anchor_cache[key]
 
-    def _loss_fused(self, featmap_sizes, gt_bboxes, img_metas, cfg, generator=None):
+    def _loss_fused(self, featmap_sizes, gt_bboxes, img_metas, cfg, samplers=None):
         dev = self._fused[0].device
         anchors = self._all_anchors(featmap_sizes, dev)
         inside = self._inside_flags(featmap_sizes, img_metas, cfg.allowed_border, dev)
@@ -277,14 +228,13 @@ class RPNHead(nn.Module):
             raise NotImplementedError('gt_max_assign_all=False')
         assigned = BF.iou_assign(anchors, gt_cat, offs, ac.pos_iou_thr, ac.neg_iou_thr,
                                  ac.get('min_pos_iou', 0.0), valid=inside, shared_boxes=True)
-        if generator is None:     # one launch for the batch (csrc/sampler.hip)
+        if samplers is None:      # one launch for the batch (csrc/sampler.hip)
             pos_m, neg_m = BF.sample_pos_neg(assigned, sc.num, sc.pos_fraction,
                                              sc.get('neg_pos_ub', -1))
-        else:                     # explicit generator (reproducible tests): tensor-op sampler
+        else:                     # test hook: caller-supplied draw (oracle/tensor_forms.sampler_hooks)
             pos, neg = [], []
             for i in range(len(img_metas)):
-                p, n = A.sample_pos_neg_masks(assigned[i], sc.num, sc.pos_fraction,
-                                              sc.get('neg_pos_ub', -1), generator)
+                p, n = samplers['rpn'](assigned[i], sc.num, sc.pos_fraction, sc.get('neg_pos_ub', -1))
                 pos.append(p)
                 neg.append(n)
             pos_m, neg_m = torch.stack(pos).to(torch.uint8), torch.stack(neg).to(torch.uint8)
@@ -305,44 +255,24 @@ class RPNHead(nn.Module):
                                       'BAGS configs')
         featmap_sizes = [tuple(c.shape[1:3]) for c in cls_scores]
         dev = cls_scores[0].device
-        mlvl_anchors = self._level_anchors(featmap_sizes, dev)
         N = cls_scores[0].shape[0]
         L = len(cls_scores)
         nmax = cfg.nms_pre
-        counts = []
-        if self._use_fused(cls_scores):
-            na = self.num_anchors * self.cls_out_channels
-            counts = [min(int(c[0].numel()), nmax) for c in cls_scores]
-            if N * L <= 64 and nmax <= 4096:
-                # sigmoid is monotone: top-k on the logits — all levels in one launch set, read in
-                # place from the fused head output (first `na` of the 5 * na channels per pixel)
-                top_l, top_i = BF.topk_sorted(self._fused, counts, nmax, inner=na)
-            else:
-                top_i = torch.zeros((N, L, nmax), dtype=torch.int64, device=dev)
-                top_l = torch.zeros((N, L, nmax), dtype=torch.float32, device=dev)
-                for lvl in range(L):
-                    v, i = cls_scores[lvl].reshape(N, -1).float().topk(counts[lvl], dim=1)
-                    top_i[:, lvl, :counts[lvl]] = i
-                    top_l[:, lvl, :counts[lvl]] = v
-            boxes = BF.decode_proposals(self._fused, counts, self.num_anchors,
-                                        self._all_anchors(featmap_sizes, dev), top_i, top_l,
-                                        [m['img_shape'][:2] for m in img_metas],
-                                        self.target_means, self.target_stds)
-            return self._nms_and_select(boxes, counts, cfg, N, L, nmax, dev)
-        boxes = torch.zeros((N, L, nmax, 5), dtype=torch.float32, device=dev)
-        for lvl in range(L):
-            scores = cls_scores[lvl].reshape(N, -1).float().sigmoid()
-            deltas = bbox_preds[lvl].reshape(N, -1, 4).float()
-            n = scores.shape[1]
-            k = min(n, nmax)
-            top_s, top_i = scores.topk(k, dim=1)                    # sorted, descending
-            anchors = mlvl_anchors[lvl][top_i]                      # [N,k,4]
-            d = torch.gather(deltas, 1, top_i[..., None].expand(-1, -1, 4))
-            for i in range(N):
-                boxes[i, lvl, :k, :4] = delta2bbox(anchors[i], d[i], self.target_means,
-                                                   self.target_stds, img_metas[i]['img_shape'])
-            boxes[:, lvl, :k, 4] = top_s
-            counts.append(k)
+        if not self._use_fused(cls_scores):
+            raise RuntimeError("RPNHead.get_bboxes reads the head's own GPU outputs: call forward() "
+                               "on CUDA tensors first (no CPU / tensor-op path in the product)")
+        if N * L > 64 or nmax > 4096:
+            raise NotImplementedError('bgs_topk_sorted handles <= 64 (image, level) rows of <= 4096 '
+                                      'selected entries (got %d rows, nms_pre=%d)' % (N * L, nmax))
+        na = self.num_anchors * self.cls_out_channels
+        counts = [min(int(c[0].numel()), nmax) for c in cls_scores]
+        # sigmoid is monotone: top-k on the logits — all levels in one launch set, read in place from
+        # the fused head output (first `na` of the 5 * na channels per pixel)
+        top_l, top_i = BF.topk_sorted(self._fused, counts, nmax, inner=na)
+        boxes = BF.decode_proposals(self._fused, counts, self.num_anchors,
+                                    self._all_anchors(featmap_sizes, dev), top_i, top_l,
+                                    [m['img_shape'][:2] for m in img_metas],
+                                    self.target_means, self.target_stds)
         return self._nms_and_select(boxes, counts, cfg, N, L, nmax, dev)
 
     def _nms_and_select(self, boxes, counts, cfg, N, L, nmax, dev):
@@ -360,11 +290,11 @@ class RPNHead(nn.Module):
         flat = kept.view(N, L * nmax, 5)
         flat_s = kept_scores.view(N, L * nmax)
         num = min(cfg.max_num, L * nmax)
-        if flat_s.is_cuda and N <= 64 and num <= 4096:
-            top_s, top_i = BF.topk_sorted([flat_s.contiguous()], [num], num)
-            top_s, top_i = top_s[:, 0], top_i[:, 0]
-        else:
-            top_s, top_i = flat_s.topk(num, dim=1)
+        if N > 64 or num > 4096:
+            raise NotImplementedError('bgs_topk_sorted: <= 64 rows / <= 4096 selected (got %d, %d)'
+                                      % (N, num))
+        top_s, top_i = BF.topk_sorted([flat_s.contiguous()], [num], num)
+        top_s, top_i = top_s[:, 0], top_i[:, 0]
         props = torch.gather(flat, 1, top_i[..., None].expand(-1, -1, 5))
         valid = top_s >= 0
         return [(props[i], valid[i]) for i in range(N)]

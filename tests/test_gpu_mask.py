@@ -77,16 +77,19 @@ def test_full_logits_path_agrees_with_gt_channel_path():
         one = head(x, labels=lab, nhwc=True)
     assert tuple(full.shape) == (5, 21, 28, 28)
     assert torch.allclose(full[torch.arange(5), lab], one, rtol=1e-4, atol=1e-5)
-    # loss through the reference-signature entry point (full logits) == fused path
+    # mask_cross_entropy on the full logits (cross_entropy_loss.py:54-61, torch restatement) == fused
+    from oracle import tensor_forms as TF
     tgt = (torch.rand(5, 28, 28, device=DEV) > 0.5).float()
-    a = head.loss(full, tgt, lab)['loss_mask']
+    a = TF.mask_bce(full, tgt, lab)
     b = head.loss_from_features(head.features(x), tgt, lab)['loss_mask']
     assert torch.allclose(a.reshape(()), b.reshape(()), rtol=1e-5)
     # padding slots are excluded from the mean
     valid = torch.tensor([1, 1, 0, 1, 0], device=DEV, dtype=torch.bool)
     c = head.loss_from_features(head.features(x), tgt, lab, valid)['loss_mask']
-    d = head.loss(full[valid], tgt[valid], lab[valid])['loss_mask']
+    d = TF.mask_bce(full[valid], tgt[valid], lab[valid])
     assert torch.allclose(c.reshape(()), d.reshape(()), rtol=1e-5)
+    with pytest.raises(NotImplementedError, match='loss_from_features'):
+        head.loss(full, tgt, lab)          # the K-channel entry point is refused, not emulated
 
 
 def test_mask_target_kernel_bit_exact_vs_oracle():

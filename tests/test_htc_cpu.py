@@ -9,7 +9,7 @@ import torch
 
 import balancedgroupsoftmax_amd as bgs
 from balancedgroupsoftmax_amd import gs_tables, train
-from oracle import mask_oracle, ref_import
+from oracle import mask_oracle, ref_import, tensor_forms
 from tests.golden import make_golden_htc as G
 
 needs_ref = pytest.mark.skipif(not ref_import.reference_available(), reason='reference tree absent')
@@ -25,17 +25,20 @@ def _mask_head():
 
 
 def test_fused_semantic_head_torch_path_vs_executed_reference_golden():
-    """The CPU (plain torch containers) forward + loss of the mirror == the executed reference."""
+    """The torch restatement (oracle/tensor_forms.py) over the mirror's parameter containers == the
+    executed reference: pins the state-dict layout and the oracle the GPU test compares with."""
     z = np.load(GOLD)
     head = _semantic_head()
     with torch.no_grad():
         mask_oracle.fill_mask_head(head.state_dict(), G.SEM['seed'] + 1000)
     feats, labels = G.semantic_inputs()
-    pred, emb = head([torch.from_numpy(f) for f in feats])
+    pred, emb = tensor_forms.semantic_forward(head, [torch.from_numpy(f) for f in feats])
     assert np.abs(pred.detach().numpy() - z['sem/pred']).max() < 1e-4
     assert np.abs(emb.detach().numpy()[:, ::2] - z['sem/feat']).max() < 1e-4
-    loss = head.loss(pred, torch.from_numpy(labels))
-    assert abs(float(loss) - float(z['sem/loss'][0])) < 1e-5
+    loss = tensor_forms.semantic_loss(head, pred, torch.from_numpy(labels))
+    assert abs(float(loss.detach()) - float(z['sem/loss'][0])) < 1e-5
+    with pytest.raises(RuntimeError, match='no CPU fallback'):     # the product has ONE path
+        head([torch.from_numpy(f) for f in feats])
 
 
 def test_htc_mask_head_torch_path_vs_executed_reference_golden():
@@ -47,13 +50,14 @@ def test_htc_mask_head_torch_path_vs_executed_reference_golden():
     feats, labels, targets = G.mask_inputs()
     x, lab = torch.from_numpy(feats), torch.from_numpy(labels)
     with torch.no_grad():
-        last = h0(x, None, return_logits=False)
+        fwd = tensor_forms.htc_mask_forward
+        last = fwd(h0, x, None, return_logits=False)
         assert np.abs(last.numpy()[:, ::4] - z['msk/res_feat0']).max() < 1e-4
-        pred0, feat0 = h0(x, None)
+        pred0, feat0 = fwd(h0, x, None)
         assert torch.equal(feat0, last) and pred0.shape == (G.MSK['P'], G.MSK['C'], 28, 28)
-        z0 = h0(x, None, return_feat=False, labels=lab)
+        z0 = fwd(h0, x, None, return_feat=False, labels=lab)
         assert np.abs(z0.numpy() - z['msk/gt_logits0']).max() < 1e-4
-        z1 = h1(x, last, return_feat=False, labels=lab)
+        z1 = fwd(h1, x, last, return_feat=False, labels=lab)
         assert np.abs(z1.numpy() - z['msk/gt_logits1']).max() < 1e-4
         got = mask_oracle.mask_cross_entropy(z1.numpy(), targets)
         assert abs(got - float(z['msk/loss'][0])) < 2e-6

