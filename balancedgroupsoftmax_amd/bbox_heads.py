@@ -459,12 +459,23 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
         losses = dict()
         n_real = None
         if cls_score is not None:
-            bin_labels, weights, avg = self._remap_labels(labels, label_weights)
+            if self.sampler == 'device' and self.cls_weight_table is None and \
+                    0 < cls_score.shape[0] <= BF.GS_FUSED_MAX_ROWS and self.num_bins <= 15:
+                # ONE streaming launch: label remap + "others" sampling inside the loss kernel
+                if self._seed is None:
+                    self._seed = (torch.initial_seed() * 0x9E3779B1) & 0xFFFFFFFFFFFFFFFF
+                self._draw += 1
+                per_bin, avg = BF.gs_head_loss_fused(
+                    cls_score, labels, self.label2binlabel, self.pred_slice_host,
+                    self.others_sample_ratio, self._seed, seed_offset=self._draw,
+                    row_weights=label_weights)
+            else:
+                bin_labels, weights, avg = self._remap_labels(labels, label_weights)
+                per_bin = BF.group_softmax_loss(cls_score, bin_labels, self.pred_slice_host,
+                                                weights, avg)
             # bin 0 weighs every real row 1 (gs_bbox_head_with0.py:100-102; the reweight variant's
             # tables start at bin 1): its avg factor is max(#real rows, 1)
             n_real = avg[0]
-            per_bin = BF.group_softmax_loss(cls_score, bin_labels, self.pred_slice_host,
-                                            weights, avg)
             per_bin = per_bin * self.bin_loss_weight
             for i in range(self.num_bins):
                 losses['loss_cls_bin{}'.format(i)] = per_bin[i]

@@ -40,6 +40,10 @@ SIGNATURES = {
     'bgs_gs_loss_fwd_bwd': (ctypes.c_int, [c_f32p, c_ptr, c_i64p, c_f32p, c_f32p,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            c_f32p, c_f32p, c_ptr, c_ptr]),
+    'bgs_gs_head_loss_fused': (ctypes.c_int, [c_f32p, c_i64p, c_i64p, c_f32p, c_ptr, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_double, ctypes.c_uint64, c_ptr, c_f32p,
+                                              c_f32p, c_f32p, c_ptr, c_f32p, c_ptr, c_ptr]),
     'bgs_gs_loss_reduce': (ctypes.c_int, [c_ptr, ctypes.c_int, ctypes.c_int, c_f32p, c_ptr]),
     'bgs_gs_scale_grad': (ctypes.c_int, [c_f32p, c_i64p, c_f32p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, c_ptr]),

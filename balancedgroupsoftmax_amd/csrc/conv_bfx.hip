@@ -256,6 +256,176 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_bfx_kernel(BfxArgs q) 
   conv_store_tile<MB, NB>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 64 x 64 tile with an LDS-DMA operand ring (the small-grid layers: ResNet layer3/4, the upper FPN /
+// RPN levels, the 1x1 convs, the FC heads — 50-100 us launches whose K loops are LATENCY-bound: one
+// register-staged step costs an L2 round trip + split + ds_write + barrier ~ 1.2 us for 0.08 us of
+// MFMA work, and a register prefetch deeper than one step is undone by hipcc, see above).
+//   * both operands travel global -> LDS by `global_load_lds_dwordx4` (no VGPR staging, no
+//     ds_write): a ring of NST = 4 stages of 10 KB (A: 64 rows x 16 fp32 raw = 4 KB, B: 3 planes x
+//     64 rows x 16 bf16 = 6 KB), THREE K steps in flight; one counted `s_waitcnt vmcnt` + one raw
+//     `s_barrier` per step (a plain __syncthreads() would drain the DMA queue);
+//   * the DMA writes LDS lane-linearly, so the bank-conflict-free layouts are produced by permuting
+//     the per-lane SOURCE addresses: A rows (64 B) keep their four 16-byte quads XOR-swizzled by
+//     (row >> 2) & 3, B rows (32 B) swap halves on odd 8-row groups;
+//   * A stays fp32 in LDS and is split into the three bf16 planes when a wave reads its fragment
+//     (8 values per lane per K step: 44 VALU ops beside 6 MFMAs, on the other issue port);
+//   * out-of-range operands (borders, K tail, rows >= Cout, steps past the end of the K loop) are
+//     fetched from the zero page, so every wave issues the same number of DMAs per step and the
+//     vmcnt arithmetic stays uniform.
+constexpr int DMA_NST = 4;
+constexpr int DMA_A_BYTES = 64 * 64, DMA_B_PLANE = 64 * 32, DMA_STAGE = DMA_A_BYTES + 3 * DMA_B_PLANE;
+
+__device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int UP>
+__global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs q) {
+  const ConvArgs& p = q.c;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[DMA_NST * DMA_STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = bgs::uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int vtile = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if (vtile >= p.tiles_m * p.tiles_n) return;          // workgroup-uniform
+  const int m0 = (vtile / p.tiles_n) * 64, n0 = (vtile % p.tiles_n) * 64;
+
+  // ---- A DMA role: wave w fills rows 16w .. 16w+15 of a stage; lane -> (row, physical quad)
+  const int arow = wave * 16 + (lane >> 2);
+  const int aq = (lane & 3) ^ ((arow >> 2) & 3);       // logical quad (4 consecutive k) fetched
+  int a_hi0, a_wi0;
+  const float* a_base;
+  bool a_ok;
+  {
+    const int m = m0 + arow;
+    a_ok = m < p.M;
+    const int mm = a_ok ? m : 0;
+    const int hw = p.Ho * p.Wo;
+    const int n = mm / hw;
+    const int rem = mm - n * hw;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    a_hi0 = ho * p.stride - p.pad;
+    a_wi0 = wo * p.stride - p.pad;
+    a_base = p.x + (size_t)n * p.H * p.W * p.Cin;
+  }
+  // ---- B DMA role: six 1 KB blocks per stage (plane j/2, rows 32 (j%2) ..); wave w takes block w
+  //      and, for w < 2, block w + 4
+  const __bf16* b_src[2];
+  bool b_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = wave + 4 * i;
+    const int plane = j >> 1;
+    const int row = (j & 1) * 32 + (lane >> 1);
+    const int half = (lane & 1) ^ ((row >> 3) & 1);
+    b_ok[i] = j < 6 && (n0 + row < p.Cout);
+    b_src[i] = q.ws + ((size_t)plane * q.KC * p.Cout + (b_ok[i] ? n0 + row : 0)) * 16 + half * 8;
+  }
+  const bool two_b = wave < 2;                          // wave-uniform
+
+  const int nk_all = q.KC;
+  const int kt_begin = p.partial ? blockIdx.z * p.kt_per_split : 0;
+  const int kt_end = p.partial ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
+  const int nk = kt_end - kt_begin;
+  int kg = kt_begin * 16 + aq * 4;
+  int kc, kr, ks;
+  {
+    const int rs = kg / p.Cin;
+    kc = kg - rs * p.Cin;
+    kr = rs / p.S;
+    ks = rs - kr * p.S;
+  }
+  int kt_issue = 0;                                    // K steps issued so far (relative)
+  auto issue = [&]() {
+    unsigned char* st = lds + (kt_issue & (DMA_NST - 1)) * DMA_STAGE;
+    const bool live = kt_issue < nk;
+    // A
+    int hi = a_hi0 + kr, wi = a_wi0 + ks;
+    bool ok = live && a_ok && kg < p.K && hi >= 0 && wi >= 0;
+    if (UP == 2) {
+      ok = ok && !((hi | wi) & 1);
+      hi >>= 1;
+      wi >>= 1;
+    }
+    ok = ok && hi < p.H && wi < p.W;
+    const float* asrc = ok ? a_base + ((size_t)hi * p.W + wi) * p.Cin + kc
+                           : reinterpret_cast<const float*>(g_zero_page);
+    glds16(asrc, st + wave * 1024);
+    // B
+    const size_t koff = (size_t)(kt_begin + kt_issue) * p.Cout * 16;
+    {
+      const __bf16* bsrc = (live && b_ok[0]) ? b_src[0] + koff
+                                             : reinterpret_cast<const __bf16*>(g_zero_page);
+      glds16(bsrc, st + DMA_A_BYTES + wave * 1024);
+    }
+    if (two_b) {
+      const __bf16* bsrc = (live && b_ok[1]) ? b_src[1] + koff
+                                             : reinterpret_cast<const __bf16*>(g_zero_page);
+      glds16(bsrc, st + DMA_A_BYTES + (wave + 4) * 1024);
+    }
+    ++kt_issue;
+    kg += 16;
+    kc += 16;
+    while (kc >= p.Cin) {
+      kc -= p.Cin;
+      if (++ks == p.S) {
+        ks = 0;
+        ++kr;
+      }
+    }
+  };
+
+  // ---- fragment roles
+  const int frow = lane & 31, fk = lane >> 5;
+  const int ar = wm * 32 + frow;
+  const int ac = (ar >> 2) & 3;
+  const int a_off0 = ar * 64 + (((2 * fk) ^ ac) << 4);
+  const int a_off1 = ar * 64 + (((2 * fk + 1) ^ ac) << 4);
+  const int br = wn * 32 + frow;
+  const int b_off = DMA_A_BYTES + br * 32 + ((fk ^ ((br >> 3) & 1)) << 4);
+
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+
+  issue();
+  issue();
+  issue();
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt has landed once at most two younger stages (2 or 3 DMAs each) are still in flight
+    if (two_b) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // every wave's part of stage kt is visible; every wave is
+    asm volatile("" ::: "memory");         // done reading stage kt-1 (= the slot refilled next)
+    issue();
+    const unsigned char* st = lds + (kt & (DMA_NST - 1)) * DMA_STAGE;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(st + a_off0);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(st + a_off1);
+    bf16x8 fb[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      fb[s] = *reinterpret_cast<const bf16x8*>(st + b_off + s * DMA_B_PLANE);
+    u32x2 h0, m0_, l0, h1, m1, l1;
+    split3(a0, h0, m0_, l0);
+    split3(a1, h1, m1, l1);
+    bf16x8 fa[3];
+    fa[0] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+    fa[1] = __builtin_bit_cast(bf16x8, u32x4{m0_[0], m0_[1], m1[0], m1[1]});
+    fa[2] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+#pragma unroll
+    for (int t = 2; t >= 0; --t)
+#pragma unroll
+      for (int i = 0; i <= t; ++i)
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[t - i], acc[0][0], 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the (zero-page) tail DMAs
+  conv_store_tile<1, 1>(p, acc, m0, n0, wm, wn, lane);
+}
+
 // w [rows][K] fp32 -> out [NS][KC][rows][16] bf16 planes (zero-padded K tail)
 __global__ __launch_bounds__(256) void bfx_split_weights_kernel(const float* __restrict__ w,
                                                                 __bf16* __restrict__ out, int rows,
@@ -710,7 +880,7 @@ int halo_bfx_plan(long long M, int tiles_m, int Cin, int Cout, int& nb) {
 }
 
 struct BfxKnobs {
-  int tile = 0, splitk = -1;
+  int tile = 0, splitk = -1, dma = 1;
   BfxKnobs() {
     if (const char* e = getenv("BGS_BFX_TILE")) tile = atoi(e);
     if (const char* e = getenv("BGS_BFX_SPLITK")) splitk = atoi(e);
@@ -720,7 +890,7 @@ BfxKnobs& bfx_knobs() {
   static BfxKnobs k;
   return k;
 }
-int g_last_tile = 0, g_last_splits = 0;
+int g_last_tile = 0, g_last_splits = 0, g_last_dma = 0;
 
 // tile (MB*10 + NB), K depth per barrier and split-K factor for a layer
 void bfx_plan(long long M, int Cout, int KC, int& tile, int& bk, int& want) {
@@ -774,10 +944,15 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
     if (q.ns == 1) { if (up == 2) BFX_L(MB_, NB_, 1, 2); else BFX_L(MB_, NB_, 1, 1); }   \
     else { if (up == 2) BFX_L(MB_, NB_, 3, 2); else BFX_L(MB_, NB_, 3, 1); }             \
   } while (0)
+  g_last_dma = 0;
   if (tile == 22) BFX_T(2, 2);
   else if (tile == 21) BFX_T(2, 1);
   else if (tile == 12) BFX_T(1, 2);
-  else BFX_T(1, 1);
+  else if (knobs.dma && q.ns == 3) {
+    g_last_dma = 1;
+    if (up == 2) hipLaunchKernelGGL(conv_igemm_bfx_dma_kernel<2>, grid, dim3(kThreads), 0, st, q);
+    else hipLaunchKernelGGL(conv_igemm_bfx_dma_kernel<1>, grid, dim3(kThreads), 0, st, q);
+  } else BFX_T(1, 1);
 #undef BFX_T
 #undef BFX_L
   if (splits > 1) {
@@ -820,12 +995,13 @@ extern "C" size_t bgs_conv_bfx_workspace_bytes(long long M, int Cout, int K) {
 // Process-wide; not for concurrent use.
 extern "C" void bgs_conv_bfx_tuning(int tile, int splitk) {
   BfxKnobs& k = bfx_knobs();
-  k.tile = tile;
+  k.tile = tile & 0xff;               // bit 8 set: the register-staged 64x64 kernel instead of the
+  k.dma = (tile & 0x100) ? 0 : 1;     // LDS-DMA ring (A/B runs and tests of both)
   k.splitk = splitk;
 }
 
 extern "C" int bgs_conv_bfx_last_launch(int* tile, int* splits) {
-  if (tile) *tile = g_last_tile;
+  if (tile) *tile = g_last_tile | (g_last_dma ? 0x200 : 0);   // bit 9: the LDS-DMA kernel ran
   if (splits) *splits = g_last_splits;
   return BGS_OK;
 }

@@ -217,6 +217,156 @@ __global__ __launch_bounds__(kBlock) void gs_scale_grad_kernel(float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused head kernel: _remap_labels + _sample_others (gs_prepare.hip) INSIDE the loss kernel, for
+// N <= 4096 rows and no per-class reweighting — one launch instead of prepare -> boundary -> loss.
+// Every workgroup derives what it needs itself:
+//   prologue (all rows, 8 B per row from L2): per row a 16-bit flag word {real, foreground in bin
+//   b} in LDS and the per-bin foreground counts -> k_b = int(n_fg * ratio), mode_b and, in closed
+//   form, avg_b = max(sum_r w_b[r], 1) = n_real (all-ones modes) | n_fg + k_b (sampled) | 1;
+//   per own row: w_b[r] = foreground, or "rank of (key(b, r), r) among the bin's background rows
+//   < k_b" — the same exact-k, ties-by-row-index selection over the same counter-based keys as
+//   gs_prepare_kernel's radix select, evaluated for ONE row by counting (N / 256 hashes per lane).
+// Results are bitwise those of bgs_gs_prepare + bgs_gs_loss_fwd_bwd (tests/test_gpu_gs.py).
+constexpr int kFusedMaxN = 4096;
+
+template <int VEC, bool WRITE_GRAD>
+__global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(
+    const float* __restrict__ logits, const int64_t* __restrict__ labels,
+    const int64_t* __restrict__ l2b, const float* __restrict__ row_weights, bgs::BinGeom geom,
+    int N, int C, int B, int W, int wpad, double ratio, uint64_t seed,
+    const uint64_t* __restrict__ seed_offset, float* __restrict__ partial,
+    float* __restrict__ dlogits, float* __restrict__ avg_out, int32_t* __restrict__ bl_out,
+    float* __restrict__ w_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][wpad] rows (+ slack)
+  __shared__ unsigned short sh_flags[kFusedMaxN];               // bit 15: real row, bit b: fg in bin b
+  __shared__ int sh_cnt[BGS_MAX_BINS + 1];                      // n_fg per bin, [B] = n_real
+  __shared__ int sh_rank[kWaves][BGS_MAX_BINS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = bgs::uniform(tid >> 6);
+  if (seed_offset) seed += 0x2545F4914F6CDD1Dull * seed_offset[0];   // device-side draw counter
+
+  // ---- prologue: flags of every row + per-bin foreground counts
+  if (tid <= BGS_MAX_BINS) sh_cnt[tid] = 0;
+  __syncthreads();
+  for (int r = tid; r < N; r += kBlock) {
+    int64_t y = labels[r];
+    y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
+    const bool real = !row_weights || row_weights[r] > 0.f;
+    unsigned bits = 0u;
+    for (int b = 0; b < B; ++b)
+      if (l2b[(size_t)b * C + y] > 0) bits |= 1u << b;
+    if (real) {
+      atomicAdd(&sh_cnt[B], 1);
+      for (unsigned m = bits; m; m &= m - 1) atomicAdd(&sh_cnt[__builtin_ctz(m)], 1);
+    }
+    sh_flags[r] = (unsigned short)(real ? (bits | 0x8000u) : 0u);
+  }
+  __syncthreads();
+  // lane b < B of every wave: constants of bin b (gs_prepare_kernel's mode / k / avg)
+  int my_mode = 0, my_k = 0;          // 0 = all zero, 1 = all one, 2 = sampled
+  float my_inv_avg = 0.f;
+  if (lane < B) {
+    const int n_real = sh_cnt[B], n_fg = sh_cnt[lane], n_bg = n_real - n_fg;
+    float total;
+    if (lane == 0) {
+      my_mode = 1;
+      total = (float)n_real;
+    } else if (n_fg == 0) {
+      my_mode = 0;
+      total = 0.f;
+    } else {
+      my_k = (int)((double)n_fg * ratio);
+      my_mode = (my_k >= n_bg) ? 1 : 2;
+      total = my_mode == 1 ? (float)n_real : (float)(n_fg + my_k);
+    }
+    const float a = fmaxf(total, 1.f);
+    my_inv_avg = 1.f / a;
+    if (blockIdx.x == 0 && wave == 0 && avg_out) avg_out[lane] = a;
+  }
+  float lacc = 0.f;
+
+  int par = 0;
+  for (int r = blockIdx.x; r < N; r += gridDim.x, par ^= 1) {
+    float* row = smem + (size_t)par * wpad;
+    bgs::stage_row<VEC>(logits + (size_t)r * W, row, W, tid, kBlock);
+    const unsigned fr = sh_flags[r];
+    // ---- sampling decision of this row in the sampled bins: rank among the bin's background rows
+    for (int b = 1; b < B; ++b) {
+      const int mode_b = __builtin_amdgcn_readlane(my_mode, b);
+      const bool need = mode_b == 2 && (fr & 0x8000u) && !((fr >> b) & 1u);   // block-uniform
+      int cnt = 0;
+      if (need) {
+        const unsigned mine = bgs::hash_u32(seed, (uint32_t)b, (uint32_t)r);
+        for (int q = tid; q < N; q += kBlock) {
+          const unsigned f = sh_flags[q];
+          if ((f & 0x8000u) && !((f >> b) & 1u)) {
+            const unsigned key = bgs::hash_u32(seed, (uint32_t)b, (uint32_t)q);
+            cnt += (key < mine || (key == mine && q < r)) ? 1 : 0;
+          }
+        }
+        cnt = bgs::wave_sum_i(cnt);
+      }
+      if (lane == 0) sh_rank[wave][b] = cnt;
+    }
+    int64_t yr = labels[r];
+    yr = yr < 0 ? 0 : (yr >= C ? (int64_t)C - 1 : yr);
+    int my_bl = 0;
+    if (lane < B) my_bl = (int)l2b[(size_t)lane * C + yr];
+    __syncthreads();                      // row staged + ranks published
+    float my_coef = 0.f;
+    if (lane < B) {
+      float w = 0.f;
+      if (fr & 0x8000u) {
+        if (my_mode == 1) {
+          w = 1.f;
+        } else if (my_mode == 2) {
+          if (my_bl > 0) {
+            w = 1.f;
+          } else {
+            int rank = 0;
+#pragma unroll
+            for (int v = 0; v < kWaves; ++v) rank += sh_rank[v][lane];
+            w = rank < my_k ? 1.f : 0.f;
+          }
+        }
+      }
+      my_coef = w * my_inv_avg;
+      if (wave == 0) {
+        if (bl_out) bl_out[(size_t)lane * N + r] = my_bl;
+        if (w_out) w_out[(size_t)lane * N + r] = w;
+      }
+    }
+    for (int b = wave; b < B; b += kWaves) {  // bins are independent: one wave each
+      const int s = geom.start[b], n = geom.len[b];
+      const float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_coef), b));
+      const int tgt = min(max(__builtin_amdgcn_readlane(my_bl, b), 0), n - 1);
+      float* seg = row + s;
+      if (coef == 0.f) {
+        if (WRITE_GRAD)
+          for (int j = lane; j < n; j += BGS_WAVE) seg[j] = 0.f;
+        continue;
+      }
+      float term;
+      if (n <= BGS_WAVE * bgs::kSweep) {
+        term = bgs::bin_loss_registers<WRITE_GRAD>(seg, n, lane, coef, tgt);
+      } else {
+        const float zt = seg[tgt];
+        float m, S;
+        bgs::bin_softmax_inplace(seg, n, lane, m, S);
+        term = coef * ((m + logf(S)) - zt);
+        if (WRITE_GRAD) bgs::bin_grad_inplace(seg, n, lane, coef / S, coef, tgt);
+      }
+      if (lane == b) lacc += term;
+    }
+    __syncthreads();                      // gradient row complete; sh_rank free for the next row
+    if (WRITE_GRAD) bgs::unstage_row<VEC>(row, dlogits + (size_t)r * W, W, tid, kBlock);
+  }
+  if (lane < B && (lane % kWaves) == wave)
+    partial[(size_t)lane * gridDim.x + blockIdx.x] = lacc;
+}
+
 template <int VEC>
 void launch_rowwave(bool grad, int grid, hipStream_t st, const float* logits, const int32_t* bl,
                     const float* w, const float* avg, const bgs::BinGeom& geom, int N, int B,
@@ -292,6 +442,48 @@ extern "C" int bgs_gs_loss_fwd_bwd(const float* logits, const int32_t* bin_label
   if (loss_out)
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, st, partial, grid, B,
                        loss_out, 1.0f);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+// _remap_labels + _sample_others + loss forward + backward in ONE launch (+ the partial reduce):
+// see gs_head_fused_kernel.  N <= 4096, bins must tile [0, W), no per-class reweighting (those
+// cases use bgs_gs_prepare + bgs_gs_loss_fwd_bwd).  avg_out [B] is always written (the box loss
+// normaliser reads bin 0's); bin_labels_out / weights_out [B, N] are optional (tests).
+extern "C" int bgs_gs_head_loss_fused(const float* logits, const int64_t* labels,
+                                      const int64_t* label2binlabel, const float* row_weights,
+                                      const int64_t* host_pred_slice, int N, int C, int B, int W,
+                                      double others_sample_ratio, uint64_t seed,
+                                      const uint64_t* seed_offset, float* loss_out, float* dlogits,
+                                      float* avg_out, int32_t* bin_labels_out, float* weights_out,
+                                      void* workspace, bgs_stream_t stream) {
+  if (N <= 0 || C <= 0 || B <= 0 || W <= 0) return BGS_ERR_INVALID_ARG;
+  if (B > BGS_MAX_BINS - 1 || N > kFusedMaxN) return BGS_ERR_UNSUPPORTED;
+  if (!logits || !labels || !label2binlabel || !host_pred_slice || !loss_out || !avg_out || !workspace)
+    return BGS_ERR_INVALID_ARG;
+  bgs::BinGeom geom;
+  int tiles = 0;
+  const int rc = bgs::make_bin_geom(host_pred_slice, B, W, &geom, &tiles);
+  if (rc != BGS_OK) return rc;
+  if (!tiles || W > 7936) return BGS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  const int grid = loss_grid(N);
+  const uintptr_t al = (uintptr_t)logits | (uintptr_t)(dlogits ? dlogits : logits);
+  const int wpad = (W + 3) & ~3;
+  const size_t lds = sizeof(float) * (2 * (size_t)wpad + BGS_WAVE * bgs::kSweep);
+#define BGS_FUSED_LAUNCH(VEC_, GRAD_)                                                             \
+  hipLaunchKernelGGL((gs_head_fused_kernel<VEC_, GRAD_>), dim3(grid), dim3(kBlock), lds, st, logits, \
+                     labels, label2binlabel, row_weights, geom, N, C, B, W, wpad,                  \
+                     others_sample_ratio, seed, seed_offset, partial, dlogits, avg_out,            \
+                     bin_labels_out, weights_out)
+  const bool grad = dlogits != nullptr;
+  if (W % 4 == 0 && al % 16 == 0) { if (grad) BGS_FUSED_LAUNCH(4, true); else BGS_FUSED_LAUNCH(4, false); }
+  else if (W % 2 == 0 && al % 8 == 0) { if (grad) BGS_FUSED_LAUNCH(2, true); else BGS_FUSED_LAUNCH(2, false); }
+  else { if (grad) BGS_FUSED_LAUNCH(1, true); else BGS_FUSED_LAUNCH(1, false); }
+#undef BGS_FUSED_LAUNCH
+  if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, st, partial, grid, B, loss_out,
+                     1.0f);
   BGS_RETURN_LAUNCH_STATUS();
 }
 

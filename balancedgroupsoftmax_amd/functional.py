@@ -151,6 +151,67 @@ class _GroupSoftmaxLoss(torch.autograd.Function):
         return out, None, None, None, None
 
 
+class _GsHeadFusedLoss(torch.autograd.Function):
+    """``_remap_labels`` + ``_sample_others`` + loss + gradient in one streaming launch
+    (``bgs_gs_head_loss_fused``); backward as :class:`_GroupSoftmaxLoss`."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, l2b, pred_slice_host, ratio, seed, seed_offset, row_weights,
+                debug):
+        lib = capi.load()
+        z = _f32c(logits)
+        N, W = z.shape
+        B, C = l2b.shape
+        dev = z.device
+        want_grad = logits.requires_grad
+        loss = torch.empty((B,), dtype=torch.float32, device=dev)
+        avg = torch.empty((B,), dtype=torch.float32, device=dev)
+        dlogits = torch.empty_like(z) if want_grad else None
+        bl = torch.empty((B, N), dtype=torch.int32, device=dev) if debug else None
+        w = torch.empty((B, N), dtype=torch.float32, device=dev) if debug else None
+        ws = _workspace(lib.bgs_gs_loss_workspace_bytes(N, B), dev)
+        ps_keep, ps_ptr = capi.host_i64(pred_slice_host)
+        rw = None if row_weights is None else _f32c(row_weights)
+        rc = lib.bgs_gs_head_loss_fused(capi.ptr(z), capi.ptr(labels), capi.ptr(l2b), capi.ptr(rw),
+                                        ps_ptr, N, C, B, W, float(ratio), int(seed),
+                                        capi.ptr(seed_offset), capi.ptr(loss), capi.ptr(dlogits),
+                                        capi.ptr(avg), capi.ptr(bl), capi.ptr(w), capi.ptr(ws),
+                                        capi.current_stream(dev))
+        capi.check('bgs_gs_head_loss_fused', rc)
+        ctx.dlogits = dlogits
+        ctx.pred_slice_host = pred_slice_host
+        ctx.in_dtype = logits.dtype
+        ctx.prev_g = None
+        ctx.mark_non_differentiable(avg)
+        if debug:
+            ctx.mark_non_differentiable(bl, w)
+            return loss, avg, bl, w
+        return loss, avg
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_loss, *_unused):
+        out = _GroupSoftmaxLoss.backward(ctx, grad_loss)[0]
+        return (out,) + (None,) * 8
+
+
+GS_FUSED_MAX_ROWS = 4096
+
+
+def gs_head_loss_fused(cls_score, labels, label2binlabel, pred_slice, others_sample_ratio,
+                       seed, seed_offset=None, row_weights=None, debug=False):
+    """The BAGS head's classification loss straight from ``labels``: ``(losses [B], avg [B])``
+    (``debug=True`` adds the bin labels and sample weights ``[B, N]`` the kernel used).
+    Requires ``N <= 4096`` rows, ``B <= 15`` and no per-class reweighting; same values, bit for
+    bit, as :func:`gs_prepare` + :func:`group_softmax_loss` with the same seed."""
+    _require_cuda(cls_score, labels, label2binlabel, row_weights)
+    assert labels.dtype == torch.int64 and label2binlabel.dtype == torch.int64
+    assert cls_score.dim() == 2 and 0 < cls_score.shape[0] <= GS_FUSED_MAX_ROWS
+    return _GsHeadFusedLoss.apply(cls_score, labels.contiguous(), label2binlabel.contiguous(),
+                                  _host_pred_slice(pred_slice), float(others_sample_ratio), int(seed),
+                                  seed_offset, row_weights, bool(debug))
+
+
 def group_softmax_loss(cls_score, bin_labels, pred_slice, weights=None, avg=None):
     """Per-bin weighted CE of the ``[N, W]`` logits -> ``[B]`` losses (differentiable
     w.r.t. ``cls_score``).

@@ -136,8 +136,8 @@ class GsHeadStep(object):
         i = self.inp
         self.logits.grad = None
         self.draw += 1            # device-side draw counter: a new sample every step, also under graph replay
-        bl, w, avg = BF.gs_prepare(i['labels'], i['l2b'], 8.0, seed=12345, seed_offset=self.draw)
-        per_bin = BF.group_softmax_loss(self.logits, bl, i['ps_np'], w, avg)
+        per_bin, _avg = BF.gs_head_loss_fused(self.logits, i['labels'], i['l2b'], i['ps_np'], 8.0,
+                                              seed=12345, seed_offset=self.draw)
         lbox = BF.bbox_smooth_l1_loss(i['bbox_pred'], i['labels'], i['bbox_targets'],
                                       i['bbox_weights'], NUM_CLASSES, beta=1.0,
                                       avg_factor=i['labels'].numel())

@@ -103,6 +103,22 @@ int bgs_gs_loss_fwd_bwd(const float* logits, const int32_t* bin_labels,
                         float* loss_out, float* dlogits, void* workspace,
                         bgs_stream_t stream);
 
+/* The head's classification loss in ONE streaming launch (+ the partial reduce): _remap_labels
+ * (gs_bbox_head_with0.py:91-112) and _sample_others (:63-89) are evaluated inside the loss kernel —
+ * every workgroup derives the per-bin counts from the 8-byte labels itself and decides its own row's
+ * sample weights by ranking the row's counter-based key among the bin's background rows (the same
+ * exact-k, ties-by-row selection as bgs_gs_prepare; bitwise-equal results).  N <= 4096, B <= 15,
+ * bins tiling [0, W), no per-class reweighting (otherwise BGS_ERR_UNSUPPORTED: use bgs_gs_prepare +
+ * bgs_gs_loss_fwd_bwd).  labels [N] i64, label2binlabel [B,C] i64, row_weights [N] or NULL (<= 0:
+ * padding slot), host_pred_slice [B,2] HOST; loss_out [B], dlogits [N,W] or NULL, avg_out [B]
+ * (written: max(sum_r w_b[r], 1)), bin_labels_out / weights_out [B,N] or NULL; workspace >=
+ * bgs_gs_loss_workspace_bytes(N, B). */
+int bgs_gs_head_loss_fused(const float* logits, const int64_t* labels, const int64_t* label2binlabel,
+                           const float* row_weights, const int64_t* host_pred_slice, int N, int C,
+                           int B, int W, double others_sample_ratio, uint64_t seed,
+                           const uint64_t* seed_offset, float* loss_out, float* dlogits,
+                           float* avg_out, int32_t* bin_labels_out, float* weights_out,
+                           void* workspace, bgs_stream_t stream);
 /* Second phase of bgs_gs_loss_fwd_bwd(loss_out = NULL): loss_out[b] = sum of the partials. */
 int bgs_gs_loss_reduce(const void* workspace, int N, int B, float* loss_out, bgs_stream_t stream);
 

@@ -91,7 +91,7 @@ def _conv_ref64(x, w, b, stride, pad, relu):
 # forced through the tuning hooks and CONFIRMED through the last-launch queries — the size-based
 # defaults only reach the larger tiles at M >= 100,000.
 F32_INST = [(t, bk, up) for t in (22, 21, 11) for bk in (16, 32) for up in (1, 2)]
-BFX_INST = [(t, up) for t in (22, 21, 12, 11) for up in (1, 2)]
+BFX_INST = [(t, up) for t in (22, 21, 12, 11, 11 | 0x100) for up in (1, 2)]   # 0x100: register-staged 64x64
 
 
 def _inst_problem(up, seed):
@@ -148,7 +148,10 @@ def test_conv_bfx_every_instantiation(inst):
             BF.conv_bfx_tuning(tile=tile, splitk=splitk)
             got = run().cpu().numpy()
             used = BF.conv_bfx_last_launch()
-            assert (used['tile'], used['splits']) == (tile, splitk), used
+            # tile 11 runs the LDS-DMA ring kernel (reported with bit 9), 11 | 0x100 the register-
+            # staged one
+            expect = {11: 11 | 0x200, 11 | 0x100: 11}.get(tile, tile)
+            assert (used['tile'], used['splits']) == (expect, splitk), used
             assert np.abs(got - exp).max() < 2e-5 * np.abs(exp).max()
     finally:
         os.environ.pop('BGS_CONV_HALO', None)

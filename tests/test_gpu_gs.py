@@ -442,3 +442,54 @@ def test_head_forward_loss_backward_device_sampler(tmp_path):
     assert head.fc_reg.weight.grad is None
     scores = head._merge_score(cls_score.detach())
     assert scores.shape == (64, C) and torch.isfinite(scores).all()
+
+
+@pytest.mark.parametrize('name', ['n1', 'n7', 'n512_cfg1', 'n1024_cfg2', 'n64_allbg', 'n40_allfg',
+                                  'n96_onebin', 'n256_ratio2', 'n96_3bins', 'n96_9bins'])
+def test_fused_head_kernel_equals_prepare_plus_loss(name):
+    """``bgs_gs_head_loss_fused`` (remap + sampling inside the loss kernel) == ``bgs_gs_prepare`` +
+    ``bgs_gs_loss_fwd_bwd`` with the same seed: the same rows sampled (exact-k, ties by row), the
+    same avg factors, bitwise-equal losses and gradients — incl. padding rows (``row_weights``)."""
+    case, l2b, ps, _, _, batch = case_setup(name)
+    n = case['n']
+    ratio = float(case.get('ratio', 8.0))
+    labels = dev(batch['labels'])
+    l2b_t = dev(l2b)
+    draw = torch.full((1,), 7, dtype=torch.int64, device=DEV)
+    for rw in (None, (np.arange(n) % 5 != 3).astype(np.float32)):
+        rw_t = None if rw is None else dev(rw)
+        bl, w, avg = BF.gs_prepare(labels, l2b_t, ratio, seed=4242, seed_offset=draw,
+                                   row_weights=rw_t)
+        z0 = dev(batch['logits']).requires_grad_(True)
+        ref = BF.group_softmax_loss(z0, bl, ps, w, avg)
+        ref.sum().backward()
+        z1 = dev(batch['logits']).requires_grad_(True)
+        got, avg1, bl1, w1 = BF.gs_head_loss_fused(z1, labels, l2b_t, ps, ratio, 4242,
+                                                   seed_offset=draw, row_weights=rw_t, debug=True)
+        got.sum().backward()
+        np.testing.assert_array_equal(bl1.cpu().numpy(), bl.cpu().numpy())
+        np.testing.assert_array_equal(w1.cpu().numpy(), w.cpu().numpy())
+        np.testing.assert_array_equal(avg1.detach().cpu().numpy(), avg.cpu().numpy())
+        np.testing.assert_array_equal(got.detach().cpu().numpy(), ref.detach().cpu().numpy())
+        np.testing.assert_array_equal(z1.grad.cpu().numpy(), z0.grad.cpu().numpy())
+
+
+def test_fused_head_kernel_large_batch_and_forward_only():
+    """N = 4096 (the fused kernel's limit; each workgroup owns two rows) and the forward-only
+    launch; exact sample counts per bin."""
+    counts = gs_tables.synthetic_instance_counts(C, seed=0)
+    l2b, ps, _ = gs_tables.build_group_tables(counts)
+    batch = gs_oracle.make_roi_batch(4096, int(ps[:, 1].sum()), C, seed=3)
+    labels, l2b_t = dev(batch['labels']), dev(l2b)
+    bl, w, avg = BF.gs_prepare(labels, l2b_t, 8.0, seed=99)
+    with torch.no_grad():
+        ref = BF.group_softmax_loss(dev(batch['logits']), bl, ps, w, avg)
+        got, avg1, bl1, w1 = BF.gs_head_loss_fused(dev(batch['logits']), labels, l2b_t, ps, 8.0, 99,
+                                                   debug=True)
+    np.testing.assert_array_equal(w1.cpu().numpy(), w.cpu().numpy())
+    np.testing.assert_array_equal(got.cpu().numpy(), ref.cpu().numpy())
+    blh = gs_oracle.remap_labels(batch['labels'], l2b)
+    for b in range(1, l2b.shape[0]):
+        n_fg = int((blh[b] > 0).sum())
+        if n_fg:
+            assert int(w1[b].sum()) == n_fg + min(int(n_fg * 8.0), 4096 - n_fg)

@@ -101,7 +101,7 @@ def errors():
         e6 = (y6.cpu().double() - ref).abs().max().item() / den
         good = e6 < max(2 * e32, 2e-7)
         ok &= good
-        say('%-20s tile %d splits %d | err/sum|ab|: f32 %.2e  bf16x6 %.2e  %s'
+        say('%-20s tile %#x splits %d | err/sum|ab|: f32 %.2e  bf16x6 %.2e  %s'
             % (name, used['tile'], used['splits'], e32, e6, 'ok' if good else 'BAD'))
     # halo kernel
     os.environ['BGS_CONV_HALO'] = '1'
@@ -171,7 +171,7 @@ def sweep(quick):
         t32 = run('f32', lambda: bench(lambda: BF.conv2d_nhwc(x, w, b, stride=stride, pad=pad, relu=True)))
         res = {}
         os.environ['BGS_CONV_HALO'] = '0'
-        cfgs = [(0, -1)] if quick else [(0, -1), (11, -1), (12, -1), (22, -1)]
+        cfgs = [(0, -1)] if quick else [(0, -1), (11, -1), (11, 1), (11, 2), (11, 4), (11, 8), (11 | 0x100, -1), (12, -1), (22, -1)]
         for tile, sk in cfgs:
             if tile == 22 and M * Cout < 128 * 128 * 64:
                 continue
