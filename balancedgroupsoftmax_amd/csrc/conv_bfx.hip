@@ -43,6 +43,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[16];
 
 struct BfxArgs {
+  const unsigned* zero;  // device address of g_zero_page (read through SGPRs by the DMA kernel)
   int ns;                // operand planes used: 3 = fp32-faithful (six products), 1 = bf16 operands
   ConvArgs c;
   const __bf16* ws;      // split weights [NS][KC][Cout][16]
@@ -281,9 +282,14 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int UP>
+//   * the loop is instruction-issue bound (four waves per SIMD share ~190 instructions per step for
+//     6 MFMAs each): P1X1 (1x1 filter, no padding — the bulk of these launches) replaces the tap /
+//     border arithmetic by one pointer increment per operand, and the zero page arrives as a
+//     kernel argument (SGPRs) instead of a GOT load per step.
+template <int UP, bool P1X1>
 __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs q) {
   const ConvArgs& p = q.c;
+  const unsigned* __restrict__ zero_page = q.zero;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[DMA_NST * DMA_STAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -340,43 +346,56 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
     ks = rs - kr * p.S;
   }
   int kt_issue = 0;                                    // K steps issued so far (relative)
+  // P1X1: the tap never changes -> fixed per-lane source pointers, advanced by one K step per issue
+  const float* a_ptr = nullptr;
+  if (P1X1) {
+    const int hi = a_hi0, wi = a_wi0;                   // pad == 0: always inside the image
+    a_ptr = a_base + ((size_t)hi * p.W + wi) * p.Cin + kg;
+  }
+  const size_t b_step = (size_t)p.Cout * 16;
+  const __bf16* b_ptr0 = b_src[0] + (size_t)kt_begin * b_step;
+  const __bf16* b_ptr1 = b_src[1] + (size_t)kt_begin * b_step;
   auto issue = [&]() {
     unsigned char* st = lds + (kt_issue & (DMA_NST - 1)) * DMA_STAGE;
     const bool live = kt_issue < nk;
-    // A
-    int hi = a_hi0 + kr, wi = a_wi0 + ks;
-    bool ok = live && a_ok && kg < p.K && hi >= 0 && wi >= 0;
-    if (UP == 2) {
-      ok = ok && !((hi | wi) & 1);
-      hi >>= 1;
-      wi >>= 1;
+    const float* asrc;
+    if (P1X1) {
+      asrc = (live && a_ok && kg < p.K) ? a_ptr : reinterpret_cast<const float*>(zero_page);
+      a_ptr += 16;
+      kg += 16;
+    } else {
+      int hi = a_hi0 + kr, wi = a_wi0 + ks;
+      bool ok = live && a_ok && kg < p.K && hi >= 0 && wi >= 0;
+      if (UP == 2) {
+        ok = ok && !((hi | wi) & 1);
+        hi >>= 1;
+        wi >>= 1;
+      }
+      ok = ok && hi < p.H && wi < p.W;
+      asrc = ok ? a_base + ((size_t)hi * p.W + wi) * p.Cin + kc
+                : reinterpret_cast<const float*>(zero_page);
+      kg += 16;
+      kc += 16;
+      while (kc >= p.Cin) {
+        kc -= p.Cin;
+        if (++ks == p.S) {
+          ks = 0;
+          ++kr;
+        }
+      }
     }
-    ok = ok && hi < p.H && wi < p.W;
-    const float* asrc = ok ? a_base + ((size_t)hi * p.W + wi) * p.Cin + kc
-                           : reinterpret_cast<const float*>(g_zero_page);
     glds16(asrc, st + wave * 1024);
-    // B
-    const size_t koff = (size_t)(kt_begin + kt_issue) * p.Cout * 16;
     {
-      const __bf16* bsrc = (live && b_ok[0]) ? b_src[0] + koff
-                                             : reinterpret_cast<const __bf16*>(g_zero_page);
+      const __bf16* bsrc = (live && b_ok[0]) ? b_ptr0 : reinterpret_cast<const __bf16*>(zero_page);
       glds16(bsrc, st + DMA_A_BYTES + wave * 1024);
     }
     if (two_b) {
-      const __bf16* bsrc = (live && b_ok[1]) ? b_src[1] + koff
-                                             : reinterpret_cast<const __bf16*>(g_zero_page);
+      const __bf16* bsrc = (live && b_ok[1]) ? b_ptr1 : reinterpret_cast<const __bf16*>(zero_page);
       glds16(bsrc, st + DMA_A_BYTES + (wave + 4) * 1024);
     }
+    b_ptr0 += b_step;
+    b_ptr1 += b_step;
     ++kt_issue;
-    kg += 16;
-    kc += 16;
-    while (kc >= p.Cin) {
-      kc -= p.Cin;
-      if (++ks == p.S) {
-        ks = 0;
-        ++kr;
-      }
-    }
   };
 
   // ---- fragment roles
@@ -425,6 +444,12 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the (zero-page) tail DMAs
   conv_store_tile<1, 1>(p, acc, m0, n0, wm, wn, lane);
 }
+
+// (Tried: the same tile and ring with TWO waves per workgroup — each wave 32 rows x all 64 columns,
+//  so that a row block's A fragment is split by one wave instead of two and the fixed per-step
+//  instructions are shared by 12 MFMAs instead of 6.  Equal on the small grids, 15-30 % SLOWER on the
+//  large ones (stem 0.216 vs 0.169 ms, FPN lateral P2 0.190 vs 0.159): at 40 KB of LDS per workgroup
+//  only two waves per SIMD are resident.  profiles/r2s_bfx_sweep_dma2.txt.  Removed.)
 
 // w [rows][K] fp32 -> out [NS][KC][rows][16] bf16 planes (zero-padded K tail)
 __global__ __launch_bounds__(256) void bfx_split_weights_kernel(const float* __restrict__ w,
@@ -913,8 +938,19 @@ void bfx_plan(long long M, int Cout, int KC, int& tile, int& bk, int& want) {
   if (want < 1) want = 1;
 }
 
+const unsigned* zero_page_device() {
+  static const unsigned* ptr = nullptr;
+  if (!ptr) {
+    void* a = nullptr;
+    if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_zero_page)) == hipSuccess) ptr = (const unsigned*)a;
+  }
+  return ptr;
+}
+
 int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t workspace_bytes) {
   ConvArgs& p = q.c;
+  q.zero = zero_page_device();
+  if (!q.zero) return BGS_ERR_LAUNCH;
   const BfxKnobs& knobs = bfx_knobs();
   const long long M = p.M;
   int tile, bk, want;
@@ -950,8 +986,10 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   else if (tile == 12) BFX_T(1, 2);
   else if (knobs.dma && q.ns == 3) {
     g_last_dma = 1;
-    if (up == 2) hipLaunchKernelGGL(conv_igemm_bfx_dma_kernel<2>, grid, dim3(kThreads), 0, st, q);
-    else hipLaunchKernelGGL(conv_igemm_bfx_dma_kernel<1>, grid, dim3(kThreads), 0, st, q);
+    const bool p1x1 = up == 1 && p.R == 1 && p.S == 1 && p.pad == 0;
+    if (up == 2) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<2, false>), grid, dim3(kThreads), 0, st, q);
+    else if (p1x1) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, true>), grid, dim3(kThreads), 0, st, q);
+    else hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, false>), grid, dim3(kThreads), 0, st, q);
   } else BFX_T(1, 1);
 #undef BFX_T
 #undef BFX_L

@@ -91,7 +91,8 @@ def _conv_ref64(x, w, b, stride, pad, relu):
 # forced through the tuning hooks and CONFIRMED through the last-launch queries — the size-based
 # defaults only reach the larger tiles at M >= 100,000.
 F32_INST = [(t, bk, up) for t in (22, 21, 11) for bk in (16, 32) for up in (1, 2)]
-BFX_INST = [(t, up) for t in (22, 21, 12, 11, 11 | 0x100) for up in (1, 2)]   # 0x100: register-staged 64x64
+BFX_INST = [(t, up) for t in (22, 21, 12, 11, 11 | 0x100) for up in (1, 2)]
+# 64x64 tile: default = the LDS-DMA ring kernel, 0x100 = register-staged
 
 
 def _inst_problem(up, seed):
@@ -144,6 +145,15 @@ def test_conv_bfx_every_instantiation(inst):
     os.environ['BGS_CONV_HALO'] = '0'
     try:
         run, exp = _inst_problem(up, tile * 100 + up)
+        if up == 1:      # + the 1x1 / no-padding specialisation of the DMA kernels (stride 2, ragged)
+            rs = np.random.RandomState(tile)
+            x1 = rs.standard_normal((2, 27, 35, 48)).astype(np.float32)
+            w1 = (rs.standard_normal((72, 1, 1, 48)) / 7).astype(np.float32)
+            b1 = rs.standard_normal(72).astype(np.float32)
+            exp1 = _conv_ref64(x1, w1, b1, 2, 0, False)
+            BF.conv_bfx_tuning(tile=tile, splitk=1)
+            got1 = BF.conv2d_nhwc(dev(x1), dev(w1), dev(b1), stride=2).cpu().numpy()
+            assert np.abs(got1 - exp1).max() < 2e-5 * np.abs(exp1).max()
         for splitk in (1, 3):
             BF.conv_bfx_tuning(tile=tile, splitk=splitk)
             got = run().cpu().numpy()

@@ -171,14 +171,14 @@ def sweep(quick):
         t32 = run('f32', lambda: bench(lambda: BF.conv2d_nhwc(x, w, b, stride=stride, pad=pad, relu=True)))
         res = {}
         os.environ['BGS_CONV_HALO'] = '0'
-        cfgs = [(0, -1)] if quick else [(0, -1), (11, -1), (11, 1), (11, 2), (11, 4), (11, 8), (11 | 0x100, -1), (12, -1), (22, -1)]
+        cfgs = [(0, -1)] if quick else [(0, -1), (11, -1), (11 | 0x100, -1), (12, -1), (22, -1)]
         for tile, sk in cfgs:
             if tile == 22 and M * Cout < 128 * 128 * 64:
                 continue
             if sk > 1 and R * R * Cin // 16 < 2 * sk:
                 continue
             BF.conv_bfx_tuning(tile, sk)
-            res['t%d/%d' % (tile, sk)] = run('bf16x6', lambda: bench(
+            res['t%x/%d' % (tile, sk)] = run('bf16x6', lambda: bench(
                 lambda: BF.conv2d_nhwc(x, w, b, stride=stride, pad=pad, relu=True)))
         BF.conv_bfx_tuning()
         if R == 3 and stride == 1 and Cin % 16 == 0:
