@@ -21,6 +21,11 @@ VARIANTS = {
     '': dict(name='libbgs.so', flags=[]),
     'nodpp': dict(name='libbgs_nodpp.so', flags=['-DBGS_NO_DPP']),
 }
+# built on request only (python -m ...build --variant ablate): timing-only instantiations of the
+# conv loops with one component removed (tools/ablate.py); never loaded by the product
+EXTRA_VARIANTS = {
+    'ablate': dict(name='libbgs_ablate.so', flags=['-DBGS_ABLATE']),
+}
 
 
 def _hipcc():
@@ -46,11 +51,11 @@ def _digest(flags):
 
 
 def lib_path(variant=''):
-    return os.path.join(PKG, VARIANTS[variant]['name'])
+    return os.path.join(PKG, {**VARIANTS, **EXTRA_VARIANTS}[variant]['name'])
 
 
 def build(variant='', force=False, verbose=True):
-    v = VARIANTS[variant]
+    v = {**VARIANTS, **EXTRA_VARIANTS}[variant]
     out = lib_path(variant)
     stamp = out + '.stamp'
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
@@ -85,7 +90,7 @@ def build(variant='', force=False, verbose=True):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('--variant', default='', choices=sorted(VARIANTS))
+    ap.add_argument('--variant', default='', choices=sorted({**VARIANTS, **EXTRA_VARIANTS}))
     ap.add_argument('--all', action='store_true')
     ap.add_argument('--force', action='store_true')
     a = ap.parse_args()

@@ -48,6 +48,10 @@ struct BfxArgs {
   ConvArgs c;
   const __bf16* ws;      // split weights [NS][KC][Cout][16]
   int KC;                // ceil(K / 16)
+  // split-form activations in (conv_igemm_bfx_pl_kernel): three planes of [N][H][W][Cin] bf16,
+  // `xp_plane` elements apart; null = the fp32 tensor c.x is the input
+  const __bf16* xp = nullptr;
+  long long xp_plane = 0;
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -286,7 +290,9 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_
 //     6 MFMAs each): P1X1 (1x1 filter, no padding — the bulk of these launches) replaces the tap /
 //     border arithmetic by one pointer increment per operand, and the zero page arrives as a
 //     kernel argument (SGPRs) instead of a GOT load per step.
-template <int UP, bool P1X1>
+// ABL (only instantiated != 0 under -DBGS_ABLATE, tools/ablate.py): timing-only variants that drop
+// one component of the loop — 1: MFMAs, 2: DMA issue, 4: fragment ds_reads, 8: the A split.
+template <int UP, bool P1X1, int ABL = 0>
 __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs q) {
   const ConvArgs& p = q.c;
   const unsigned* __restrict__ zero_page = q.zero;
@@ -384,12 +390,12 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
         }
       }
     }
-    glds16(asrc, st + wave * 1024);
-    {
+    if (!(ABL & 2)) glds16(asrc, st + wave * 1024);
+    if (!(ABL & 2)) {
       const __bf16* bsrc = (live && b_ok[0]) ? b_ptr0 : reinterpret_cast<const __bf16*>(zero_page);
       glds16(bsrc, st + DMA_A_BYTES + wave * 1024);
     }
-    if (two_b) {
+    if (two_b && !(ABL & 2)) {
       const __bf16* bsrc = (live && b_ok[1]) ? b_ptr1 : reinterpret_cast<const __bf16*>(zero_page);
       glds16(bsrc, st + DMA_A_BYTES + (wave + 4) * 1024);
     }
@@ -414,6 +420,8 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
   issue();
   issue();
   issue();
+  f32x4 a0, a1;
+  bf16x8 fb[3];
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt has landed once at most two younger stages (2 or 3 DMAs each) are still in flight
     if (two_b) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -421,25 +429,37 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
     __builtin_amdgcn_s_barrier();          // every wave's part of stage kt is visible; every wave is
     asm volatile("" ::: "memory");         // done reading stage kt-1 (= the slot refilled next)
     issue();
-    const unsigned char* st = lds + (kt & (DMA_NST - 1)) * DMA_STAGE;
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(st + a_off0);
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(st + a_off1);
-    bf16x8 fb[3];
+    const unsigned char* st = lds + (((ABL & 4) ? 0 : kt) & (DMA_NST - 1)) * DMA_STAGE;
+    if (!(ABL & 4) || kt == 0) {
+      a0 = *reinterpret_cast<const f32x4*>(st + a_off0);
+      a1 = *reinterpret_cast<const f32x4*>(st + a_off1);
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
-      fb[s] = *reinterpret_cast<const bf16x8*>(st + b_off + s * DMA_B_PLANE);
-    u32x2 h0, m0_, l0, h1, m1, l1;
-    split3(a0, h0, m0_, l0);
-    split3(a1, h1, m1, l1);
+      for (int s = 0; s < 3; ++s)
+        fb[s] = *reinterpret_cast<const bf16x8*>(st + b_off + s * DMA_B_PLANE);
+    }
     bf16x8 fa[3];
-    fa[0] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
-    fa[1] = __builtin_bit_cast(bf16x8, u32x4{m0_[0], m0_[1], m1[0], m1[1]});
-    fa[2] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+    if (ABL & 8) {
+      fa[0] = __builtin_bit_cast(bf16x8, a0);
+      fa[1] = __builtin_bit_cast(bf16x8, a1);
+      fa[2] = __builtin_bit_cast(bf16x8, a0 + a1);
+    } else {
+      u32x2 h0, m0_, l0, h1, m1, l1;
+      split3(a0, h0, m0_, l0);
+      split3(a1, h1, m1, l1);
+      fa[0] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+      fa[1] = __builtin_bit_cast(bf16x8, u32x4{m0_[0], m0_[1], m1[0], m1[1]});
+      fa[2] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+    }
+    if (ABL & 1) {
 #pragma unroll
-    for (int t = 2; t >= 0; --t)
+      for (int s = 0; s < 3; ++s) asm volatile("" ::"v"(fa[s]), "v"(fb[s]));
+    } else {
 #pragma unroll
-      for (int i = 0; i <= t; ++i)
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[t - i], acc[0][0], 0, 0, 0);
+      for (int t = 2; t >= 0; --t)
+#pragma unroll
+        for (int i = 0; i <= t; ++i)
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[t - i], acc[0][0], 0, 0, 0);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the (zero-page) tail DMAs
   conv_store_tile<1, 1>(p, acc, m0, n0, wm, wn, lane);
@@ -450,6 +470,165 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
 //  instructions are shared by 12 MFMAs instead of 6.  Equal on the small grids, 15-30 % SLOWER on the
 //  large ones (stem 0.216 vs 0.169 ms, FPN lateral P2 0.190 vs 0.159): at 40 KB of LDS per workgroup
 //  only two waves per SIMD are resident.  profiles/r2s_bfx_sweep_dma2.txt.  Removed.)
+
+// ---------------------------------------------------------------------------------------------
+// The 64 x 64 ring kernel on SPLIT-FORM activations: the producing layer's epilogue has already
+// written the exact hi / mid / lo bf16 planes of its output (ConvArgs::yp), so BOTH operands reach
+// LDS by `global_load_lds_dwordx4` in the format the matrix cores take and the K loop carries no
+// VALU work at all: per wave and K step 3 DMAs, 6 ds_read_b128, 6 MFMAs, one counted vmcnt, one
+// barrier (the fp32-input kernel above spends ~44 VALU instructions per step re-splitting A — per
+// reading wave, i.e. 2 x tiles_n times per element; that loop is issue-bound, this one is not).
+// HBM pays 6 instead of 4 bytes per activation element — the cheap side of the trade on this chip.
+//   * stage = 12 KB: A planes 0..2 then B planes 0..2, each 64 rows x 32 B, halves of a row
+//     swapped on odd 8-row groups (conflict-free ds_read_b128 without padding);
+//   * 12 DMA pieces of 1 KB per stage, three per wave (wave w: pieces w, w + 4, w + 8), so the
+//     vmcnt arithmetic is uniform; NST - 1 stages in flight;
+//   * Cin % 16 == 0 (a K step never straddles a filter tap), so tap / channel bookkeeping is
+//     wave-uniform (SALU).
+template <bool P1X1, int NST>
+__global__ __launch_bounds__(kThreads, NST == 3 ? 4 : 3) void conv_igemm_bfx_pl_kernel(BfxArgs q) {
+  const ConvArgs& p = q.c;
+  const unsigned* __restrict__ zero_page = q.zero;
+  constexpr int PLANE = 64 * 32, STAGE = 6 * PLANE;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = bgs::uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int vtile = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if (vtile >= p.tiles_m * p.tiles_n) return;          // workgroup-uniform
+  const int m0 = (vtile / p.tiles_n) * 64, n0 = (vtile % p.tiles_n) * 64;
+
+  // ---- DMA roles.  Every piece of wave w covers rows 32 (w & 1) + (lane >> 1) of its operand;
+  //      waves 0/1 carry A0, A2, B1 and waves 2/3 carry A1, B0, B2.
+  const int drow = (wave & 1) * 32 + (lane >> 1);
+  const int dhalf = (lane & 1) ^ ((drow >> 3) & 1);    // logical half (8 consecutive k) fetched
+  const bool hi_pair = wave >= 2;                      // wave-uniform
+  int a_hi0, a_wi0;
+  const __bf16* a_img;
+  bool a_ok;
+  {
+    const int m = m0 + drow;
+    a_ok = m < p.M;
+    const int mm = a_ok ? m : 0;
+    const int hw = p.Ho * p.Wo;
+    const int n = mm / hw;
+    const int rem = mm - n * hw;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    a_hi0 = ho * p.stride - p.pad;
+    a_wi0 = wo * p.stride - p.pad;
+    a_img = q.xp + (size_t)n * p.H * p.W * p.Cin + dhalf * 8;
+  }
+  const bool b_ok = n0 + drow < p.Cout;
+  const __bf16* b_row = q.ws + (size_t)(b_ok ? n0 + drow : 0) * 16 + dhalf * 8;
+  const size_t b_plane = (size_t)q.KC * p.Cout * 16;
+  const size_t b_step = (size_t)p.Cout * 16;
+
+  const int nk_all = q.KC;
+  const int kt_begin = p.partial ? blockIdx.z * p.kt_per_split : 0;
+  const int kt_end = p.partial ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
+  const int nk = kt_end - kt_begin;
+  int kg = kt_begin * 16;                               // wave-uniform K position of the next issue
+  int kc, kr, ks;
+  {
+    const int rs = kg / p.Cin;
+    kc = kg - rs * p.Cin;
+    kr = rs / p.S;
+    ks = rs - kr * p.S;
+  }
+  int kt_issue = 0;
+  const __bf16* a_ptr = nullptr;                        // P1X1: fixed pixel, advancing channel
+  if (P1X1) a_ptr = a_img + ((size_t)a_hi0 * p.W + a_wi0) * p.Cin + kg;
+  const __bf16* b_ptr = b_row + (size_t)kt_begin * b_step;
+  // plane / LDS slot of this wave's three pieces
+  const int a_pl0 = hi_pair ? 1 : 0;                    // first A piece
+  const int b_pl0 = hi_pair ? 0 : 1;                    // first B piece
+  const int slot = (wave & 1) * 1024;
+  auto issue = [&]() {
+    unsigned char* st = lds + (kt_issue % NST) * STAGE + slot;
+    const bool live = kt_issue < nk;
+    const __bf16* asrc;
+    bool aok;
+    if (P1X1) {
+      aok = live && a_ok && kg < p.K;
+      asrc = a_ptr;
+      a_ptr += 16;
+    } else {
+      const int hi = a_hi0 + kr, wi = a_wi0 + ks;
+      aok = live && a_ok && kg < p.K && hi >= 0 && wi >= 0 && hi < p.H && wi < p.W;
+      asrc = a_img + ((size_t)hi * p.W + wi) * p.Cin + kc;
+      kc += 16;
+      if (kc >= p.Cin) {
+        kc = 0;
+        if (++ks == p.S) {
+          ks = 0;
+          ++kr;
+        }
+      }
+    }
+    kg += 16;
+    const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page);
+    const bool bok = live && b_ok;
+    glds16(aok ? asrc + (size_t)a_pl0 * q.xp_plane : zp, st + a_pl0 * 2 * 1024);
+    if (!hi_pair) glds16(aok ? asrc + 2 * (size_t)q.xp_plane : zp, st + 4 * 1024);
+    glds16(bok ? b_ptr + b_pl0 * b_plane : zp, st + 3 * PLANE + b_pl0 * 2 * 1024);
+    if (hi_pair) glds16(bok ? b_ptr + 2 * b_plane : zp, st + 3 * PLANE + 4 * 1024);
+    b_ptr += b_step;
+    ++kt_issue;
+  };
+
+  // ---- fragment roles
+  const int frow = lane & 31, fk = lane >> 5;
+  const int ar = wm * 32 + frow;
+  const int a_off = ar * 32 + ((fk ^ ((ar >> 3) & 1)) << 4);
+  const int br = wn * 32 + frow;
+  const int b_off = 3 * PLANE + br * 32 + ((fk ^ ((br >> 3) & 1)) << 4);
+
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i) issue();
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt has landed once at most NST - 2 younger stages (3 DMAs each) are still in flight
+    if (NST == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue();
+    const unsigned char* st = lds + (kt % NST) * STAGE;
+    bf16x8 fa[3], fb[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      fa[s] = *reinterpret_cast<const bf16x8*>(st + a_off + s * PLANE);
+      fb[s] = *reinterpret_cast<const bf16x8*>(st + b_off + s * PLANE);
+    }
+#pragma unroll
+    for (int t = 2; t >= 0; --t)
+#pragma unroll
+      for (int i = 0; i <= t; ++i)
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[t - i], acc[0][0], 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the (zero-page) tail DMAs
+  conv_store_tile<1, 1>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// x [rows][C] fp32 -> split-form planes [3][rows][C] bf16 (for tensors no conv epilogue produced:
+// RoI features, test inputs); four consecutive channels per thread.
+__global__ __launch_bounds__(256) void bfx_split_act_kernel(const float* __restrict__ x,
+                                                            unsigned short* __restrict__ out,
+                                                            size_t quads, size_t plane) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < quads; e += (size_t)gridDim.x * 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * e);
+    u32x2 h, m, l;
+    split3(v, h, m, l);
+    *reinterpret_cast<u32x2*>(out + 4 * e) = h;
+    *reinterpret_cast<u32x2*>(out + plane + 4 * e) = m;
+    *reinterpret_cast<u32x2*>(out + 2 * plane + 4 * e) = l;
+  }
+}
 
 // w [rows][K] fp32 -> out [NS][KC][rows][16] bf16 planes (zero-padded K tail)
 __global__ __launch_bounds__(256) void bfx_split_weights_kernel(const float* __restrict__ w,
@@ -694,7 +873,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx_kernel(HaloBfxAr
 // on four SIMDs, each shared with ONE wave of another workgroup, and every barrier couples them;
 // a third resident workgroup fills the gaps.  (A mid-step barrier / fragment read-ahead pipeline
 // inside the wave, as in conv_igemm.hip, measured +0 % here and cost 44 VGPRs: dropped.)
-template <int NB, int NS>
+// ABL as above — 1: MFMAs, 2: filter-slice loads + stores, 4: fragment ds_reads (first step only),
+// 8: barriers, 16: patch reload (load_a / store_a).
+template <int NB, int NS, int ABL = 0>
 __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxArgs q) {
   const ConvArgs& p = q.c;
   constexpr int BN = 64 * NB;
@@ -809,6 +990,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxA
   store_b(0);
   __syncthreads();
   int cur = 0, nxt = B_BUF;                                      // byte offsets of the two B buffers
+  bf16x8 fa[NS][2], fb[NS][NB];
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     const bool last_chunk = chunk + 1 >= c_end;
 #pragma unroll
@@ -816,37 +998,48 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxA
       const int rd = (tap & 1) ? nxt : cur;                       // buffer of this step
       const int wr = (tap & 1) ? cur : nxt;                       // buffer of the next step
       const bool more = tap < 8 || !last_chunk;
-      if (tap < 8) load_b(chunk, tap + 1);                        // next filter slice in flight
-      else if (more) load_b(chunk + 1, 0);
-      if (tap == 0 && !last_chunk) load_a(chunk + 1);             // next patch: held in registers
-      constexpr int dummy = 0;
-      (void)dummy;
-      const int tap_off = ((tap / 3) * PW + (tap % 3)) * HLDR;    // compile-time constant
-      bf16x8 fa[NS][2], fb[NS][NB];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-          fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a] + tap_off + s * A_PLANE);
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-          fb[s][b] = *reinterpret_cast<const bf16x8*>(lds + rd + b_frag + s * B_PLANE + b * 32 * 32);
+      if (!(ABL & 2)) {
+        if (tap < 8) load_b(chunk, tap + 1);                      // next filter slice in flight
+        else if (more) load_b(chunk + 1, 0);
       }
+      if (tap == 0 && !last_chunk && !(ABL & 16)) load_a(chunk + 1);   // next patch: held in registers
+      const int tap_off = ((tap / 3) * PW + (tap % 3)) * HLDR;    // compile-time constant
+      if (!(ABL & 4) || (chunk == c_begin && tap == 0)) {
 #pragma unroll
-      for (int tt = NS - 1; tt >= 0; --tt)
-#pragma unroll
-        for (int i = 0; i <= tt; ++i)
+        for (int s = 0; s < NS; ++s) {
 #pragma unroll
           for (int a = 0; a < 2; ++a)
+            fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a] + tap_off + s * A_PLANE);
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[tt - i][b], acc[a][b],
-                                                                  0, 0, 0);
-      if (more) store_b(wr);
-      __syncthreads();
-      if (tap == 8 && !last_chunk) {                              // every wave is done with this patch
+          for (int b = 0; b < NB; ++b)
+            fb[s][b] = *reinterpret_cast<const bf16x8*>(lds + rd + b_frag + s * B_PLANE + b * 32 * 32);
+        }
+      }
+      if (ABL & 1) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+          for (int a = 0; a < 2; ++a) asm volatile("" ::"v"(fa[s][a]));
+#pragma unroll
+          for (int b = 0; b < NB; ++b) asm volatile("" ::"v"(fb[s][b]));
+        }
+      } else {
+#pragma unroll
+        for (int tt = NS - 1; tt >= 0; --tt)
+#pragma unroll
+          for (int i = 0; i <= tt; ++i)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < NB; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[tt - i][b], acc[a][b],
+                                                                    0, 0, 0);
+      }
+      if (more && !(ABL & 2)) store_b(wr);
+      if (!(ABL & 8)) __syncthreads();
+      if (tap == 8 && !last_chunk && !(ABL & 16)) {               // every wave is done with this patch
         store_a();
-        __syncthreads();
+        if (!(ABL & 8)) __syncthreads();
       }
     }
     // nine steps per chunk: the buffer roles swap from chunk to chunk
@@ -905,7 +1098,7 @@ int halo_bfx_plan(long long M, int tiles_m, int Cin, int Cout, int& nb) {
 }
 
 struct BfxKnobs {
-  int tile = 0, splitk = -1, dma = 1;
+  int tile = 0, splitk = -1, dma = 1, pl_nst = 4;
   BfxKnobs() {
     if (const char* e = getenv("BGS_BFX_TILE")) tile = atoi(e);
     if (const char* e = getenv("BGS_BFX_SPLITK")) splitk = atoi(e);
@@ -916,14 +1109,16 @@ BfxKnobs& bfx_knobs() {
   return k;
 }
 int g_last_tile = 0, g_last_splits = 0, g_last_dma = 0;
+int g_ablate = 0;          // -DBGS_ABLATE builds only (tools/ablate.py): component-ablation timing
 
 // tile (MB*10 + NB), K depth per barrier and split-K factor for a layer
-void bfx_plan(long long M, int Cout, int KC, int& tile, int& bk, int& want) {
+void bfx_plan(long long M, int Cout, int KC, int& tile, int& bk, int& want, bool split_in = false) {
   const BfxKnobs& knobs = bfx_knobs();
   // measured on the cfg[1] shapes (profiles/r2a_bfx_sweep.txt): the 64x64 tile wins or ties on
   // every conv layer (these K steps are short: 6 MFMAs per wave per barrier, the grid matters more
   // than the tile); 128x128 only for the very deep reductions (fc1: K = 12544, 0.183 vs 0.253 ms)
   tile = (KC >= 512 && Cout >= 256) ? 22 : 11;
+  if (split_in) tile = 11;
   if (knobs.tile == 22 || knobs.tile == 21 || knobs.tile == 12 || knobs.tile == 11) tile = knobs.tile;
   bk = 16;
   const int bm = tile / 10 * 64, bn = tile % 10 * 64;
@@ -954,7 +1149,8 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   const BfxKnobs& knobs = bfx_knobs();
   const long long M = p.M;
   int tile, bk, want;
-  bfx_plan(M, p.Cout, q.KC, tile, bk, want);
+  bfx_plan(M, p.Cout, q.KC, tile, bk, want, q.xp != nullptr);
+  if (q.xp) tile = 11;
   const int bm = tile / 10 * 64, bn = tile % 10 * 64;
   int splits = 1;
   p.partial = nullptr;
@@ -981,13 +1177,31 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
     else { if (up == 2) BFX_L(MB_, NB_, 3, 2); else BFX_L(MB_, NB_, 3, 1); }             \
   } while (0)
   g_last_dma = 0;
-  if (tile == 22) BFX_T(2, 2);
+  if (q.xp) {                                   // split-form input: the 64 x 64 ring kernel only
+    if (tile != 11 || q.ns != 3 || up != 1) return BGS_ERR_UNSUPPORTED;
+    g_last_dma = 2;
+    const bool p1x1 = p.R == 1 && p.S == 1 && p.pad == 0;
+    if (knobs.pl_nst == 3) {
+      if (p1x1) hipLaunchKernelGGL((conv_igemm_bfx_pl_kernel<true, 3>), grid, dim3(kThreads), 0, st, q);
+      else hipLaunchKernelGGL((conv_igemm_bfx_pl_kernel<false, 3>), grid, dim3(kThreads), 0, st, q);
+    } else {
+      if (p1x1) hipLaunchKernelGGL((conv_igemm_bfx_pl_kernel<true, 4>), grid, dim3(kThreads), 0, st, q);
+      else hipLaunchKernelGGL((conv_igemm_bfx_pl_kernel<false, 4>), grid, dim3(kThreads), 0, st, q);
+    }
+  } else if (tile == 22) BFX_T(2, 2);
   else if (tile == 21) BFX_T(2, 1);
   else if (tile == 12) BFX_T(1, 2);
   else if (knobs.dma && q.ns == 3) {
     g_last_dma = 1;
     const bool p1x1 = up == 1 && p.R == 1 && p.S == 1 && p.pad == 0;
     if (up == 2) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<2, false>), grid, dim3(kThreads), 0, st, q);
+#ifdef BGS_ABLATE
+    else if (p1x1 && g_ablate) {
+#define ABL_D(A_) case A_: hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, true, A_>), grid, dim3(kThreads), 0, st, q); break;
+      switch (g_ablate) { ABL_D(1) ABL_D(2) ABL_D(3) ABL_D(4) ABL_D(8) ABL_D(9) ABL_D(12) ABL_D(6) default: return BGS_ERR_UNSUPPORTED; }
+#undef ABL_D
+    }
+#endif
     else if (p1x1) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, true>), grid, dim3(kThreads), 0, st, q);
     else hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, false>), grid, dim3(kThreads), 0, st, q);
   } else BFX_T(1, 1);
@@ -1035,11 +1249,12 @@ extern "C" void bgs_conv_bfx_tuning(int tile, int splitk) {
   BfxKnobs& k = bfx_knobs();
   k.tile = tile & 0xff;               // bit 8 set: the register-staged 64x64 kernel instead of the
   k.dma = (tile & 0x100) ? 0 : 1;     // LDS-DMA ring (A/B runs and tests of both)
+  k.pl_nst = (tile & 0x400) ? 3 : 4;  // bit 10: 3-stage ring (4 workgroups / CU) of the split-form kernel
   k.splitk = splitk;
 }
 
 extern "C" int bgs_conv_bfx_last_launch(int* tile, int* splits) {
-  if (tile) *tile = g_last_tile | (g_last_dma ? 0x200 : 0);   // bit 9: the LDS-DMA kernel ran
+  if (tile) *tile = g_last_tile | (g_last_dma == 1 ? 0x200 : 0) | (g_last_dma == 2 ? 0x800 : 0);   // bit 9: the LDS-DMA kernel ran; bit 11: the split-form-input kernel
   if (splits) *splits = g_last_splits;
   return BGS_OK;
 }
@@ -1076,6 +1291,65 @@ extern "C" int bgs_conv2d_nhwc_f32_bfx_ws(const float* x, const void* wsplit, co
   p.res_mode = residual_mode;
   q.ws = reinterpret_cast<const __bf16*>(wsplit);
   q.KC = bfx_kc(p.K);
+  return launch_conv_bfx(q, 1, (hipStream_t)stream, workspace, workspace_bytes);
+}
+
+extern "C" int bgs_conv_bfx_split_act(const float* x, void* planes, long long rows, int C,
+                                      bgs_stream_t stream) {
+  if (!x || !planes || rows <= 0 || C <= 0) return BGS_ERR_INVALID_ARG;
+  if (C % 4 != 0) return BGS_ERR_UNSUPPORTED;
+  if ((uintptr_t)x % 16 != 0 || (uintptr_t)planes % 16 != 0) return BGS_ERR_INVALID_ARG;
+  const size_t quads = (size_t)rows * C / 4;
+  size_t g = (quads + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(bfx_split_act_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x,
+                     reinterpret_cast<unsigned short*>(planes), quads, (size_t)rows * C);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" size_t bgs_conv_bfx_ex_workspace_bytes(long long M, int Cout, int K, int split_in) {
+  if (M <= 0 || Cout <= 0 || K <= 0) return 0;
+  int tile, bk, want;
+  bfx_plan(M, Cout, bfx_kc(K), tile, bk, want, split_in != 0);
+  return want > 1 ? (size_t)want * (size_t)M * Cout * sizeof(float) : 0;
+}
+
+extern "C" int bgs_conv2d_nhwc_bfx_ex(const float* x, const void* xplanes, const void* wsplit,
+                                      const float* bias, const float* residual, float* y,
+                                      void* yplanes, int N, int H, int W, int Cin, int Cout, int R,
+                                      int S, int stride, int pad, int relu, int residual_mode,
+                                      void* workspace, size_t workspace_bytes, bgs_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
+      pad < 0)
+    return BGS_ERR_INVALID_ARG;
+  if ((!x && !xplanes) || !wsplit || (!y && !yplanes)) return BGS_ERR_INVALID_ARG;
+  if (xplanes ? Cin % 16 != 0 : Cin % 4 != 0) return BGS_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)xplanes | (uintptr_t)wsplit | (uintptr_t)yplanes) % 16 != 0)
+    return BGS_ERR_INVALID_ARG;
+  if (residual_mode < 0 || residual_mode > 2 || (residual_mode != 0 && !residual))
+    return BGS_ERR_INVALID_ARG;
+  BfxArgs q;
+  q.ns = 3;
+  ConvArgs& p = q.c;
+  p.x = x; p.w = nullptr; p.bias = bias; p.res = residual; p.mask = nullptr; p.y = y;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S;
+  p.stride = stride; p.pad = pad;
+  p.Ho = (H + 2 * pad - R) / stride + 1;
+  p.Wo = (W + 2 * pad - S) / stride + 1;
+  if (p.Ho <= 0 || p.Wo <= 0) return BGS_ERR_INVALID_ARG;
+  if (residual_mode == 2 && ((p.Ho & 1) || (p.Wo & 1))) return BGS_ERR_INVALID_ARG;
+  const long long M = (long long)N * p.Ho * p.Wo;
+  if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  p.M = (int)M;
+  p.K = R * S * Cin;
+  p.relu = relu;
+  p.res_mode = residual_mode;
+  p.yp = reinterpret_cast<unsigned short*>(yplanes);
+  p.yp_plane = M * Cout;
+  q.ws = reinterpret_cast<const __bf16*>(wsplit);
+  q.KC = bfx_kc(p.K);
+  q.xp = reinterpret_cast<const __bf16*>(xplanes);
+  q.xp_plane = (long long)N * H * W * Cin;
   return launch_conv_bfx(q, 1, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
@@ -1127,6 +1401,8 @@ extern "C" size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int 
 }
 
 extern "C" void bgs_conv3x3_halo_bfx_tuning(int splits, int variant) {
+  g_ablate = (variant >> 8) & 0xff;          // timing-only ablation modes (-DBGS_ABLATE builds)
+  variant &= 0xff;
   g_halo_force_splits = splits;
   g_halo_variant = variant == 1 ? 1 : 2;     // 1 = first version (2 workgroups / CU), 2 = unrolled, 3 / CU (default)
 }
@@ -1191,6 +1467,12 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit,
         hipLaunchKernelGGL((conv3x3_halo_bfx3_kernel<2, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
     } else if (nb == 1) {
       hipLaunchKernelGGL((conv3x3_halo_bfx3_kernel<1, 3>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+#ifdef BGS_ABLATE
+    } else if (g_ablate) {
+#define ABL_H(A_) case A_: hipLaunchKernelGGL((conv3x3_halo_bfx3_kernel<2, 3, A_>), grid, dim3(kThreads), 0, (hipStream_t)stream, q); break;
+      switch (g_ablate) { ABL_H(1) ABL_H(2) ABL_H(3) ABL_H(4) ABL_H(5) ABL_H(6) ABL_H(8) ABL_H(16) ABL_H(18) ABL_H(26) ABL_H(30) ABL_H(14) default: return BGS_ERR_UNSUPPORTED; }
+#undef ABL_H
+#endif
     } else {
       hipLaunchKernelGGL((conv3x3_halo_bfx3_kernel<2, 3>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
     }

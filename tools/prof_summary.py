@@ -40,10 +40,27 @@ def categories(rows, steps):
     print()
 
 
+def steady_steps(rows, marker='maxpool3x3s2'):
+    """The kernels of the LAST complete steps of the trace (between occurrences of a kernel that
+    runs once per step): warm-up work (BN folding, filter splits, allocator fills) is excluded."""
+    rows = sorted(rows, key=lambda r: int(r['Start_Timestamp']))
+    marks = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
+    if len(marks) < 3:
+        return rows, 0
+    n = min(4, len(marks) - 1)
+    return rows[marks[-1 - n]:marks[-1]], n
+
+
 def main(path, steps=None):
     rows = list(csv.DictReader(open(path)))
     if steps:
-        categories(rows, steps)
+        srows, n = steady_steps(rows)
+        if n:
+            print('steady state: the last %d complete steps of the trace (per step)\n' % n)
+            categories(srows, n)
+            rows = srows
+        else:
+            categories(rows, steps)
     agg = collections.defaultdict(list)
     for r in rows:
         d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
