@@ -465,6 +465,199 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
   conv_store_tile<1, 1>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The operand ring with larger workgroup tiles: (64 MB) x (64 NB), 2 x 2 waves of (32 MB) x (32 NB).
+// Ablation of the 64 x 64 kernel (tools/ablate.py, profiles/r2w_ablate_conv_loops.txt): with the DMA
+// issue removed a layer runs in 0.069 instead of 0.158 ms, with the MFMAs removed in 0.136 — the
+// loop is bound by global -> LDS traffic (10 KB per 24 MFMAs), not by the matrix pipe and not by
+// the A split (removing it changes nothing).  A 128 x 128 tile moves 20 KB per 96 MFMAs.
+//   * stage = A (64 MB rows x 64 B fp32, quads XOR-swizzled) + B (3 planes x 64 NB rows x 32 B,
+//     halves swapped on odd 8-row groups); NST = 3 stages;
+//   * 4 MB + 6 NB DMA pieces of 1 KB per stage, dealt round-robin to the four waves (piece w, w + 4,
+//     ..; ids past the end are dummy pieces into a scratch block: uniform DMA count per wave).
+template <int MB, int NB, bool P1X1>
+__global__ __launch_bounds__(kThreads, 2) void conv_igemm_bfx_ring_kernel(BfxArgs q) {
+  const ConvArgs& p = q.c;
+  const unsigned* __restrict__ zero_page = q.zero;
+  constexpr int NST = 3;
+  constexpr int A_BYTES = 64 * MB * 64, B_PLANE = 64 * NB * 32, STAGE = A_BYTES + 3 * B_PLANE;
+  constexpr int NA = 4 * MB, NBP = 6 * NB, NP = NA + NBP, PWV = (NP + 3) / 4;
+  constexpr int SCR = NST * STAGE;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[SCR + (4 * PWV > NP ? 1024 : 0)];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = bgs::uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int vtile = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if (vtile >= p.tiles_m * p.tiles_n) return;          // workgroup-uniform
+  const int m0 = (vtile / p.tiles_n) * (64 * MB), n0 = (vtile % p.tiles_n) * (64 * NB);
+
+  const int nk_all = q.KC;
+  const int kt_begin = p.partial ? blockIdx.z * p.kt_per_split : 0;
+  const int kt_end = p.partial ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
+  const int nk = kt_end - kt_begin;
+
+  // ---- DMA roles: piece i of this wave has id = wave + 4 i (kind is wave-uniform)
+  const float* a_base[PWV];        // A pieces: image base (+ fixed pixel offset when P1X1)
+  int a_hi0[PWV], a_wi0[PWV], a_q[PWV];
+  bool a_ok[PWV];
+  const __bf16* b_ptr[PWV];        // B pieces: advancing source pointer
+  bool b_ok[PWV];
+#pragma unroll
+  for (int i = 0; i < PWV; ++i) {
+    const int id = wave + 4 * i;
+    a_ok[i] = false;
+    b_ok[i] = false;
+    a_base[i] = nullptr;
+    b_ptr[i] = nullptr;
+    a_hi0[i] = a_wi0[i] = a_q[i] = 0;
+    if (id < NA) {
+      const int row = id * 16 + (lane >> 2);
+      a_q[i] = (lane & 3) ^ ((row >> 2) & 3);
+      const int m = m0 + row;
+      a_ok[i] = m < p.M;
+      const int mm = a_ok[i] ? m : 0;
+      const int hw = p.Ho * p.Wo;
+      const int n = mm / hw;
+      const int rem = mm - n * hw;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      a_hi0[i] = ho * p.stride - p.pad;
+      a_wi0[i] = wo * p.stride - p.pad;
+      a_base[i] = p.x + (size_t)n * p.H * p.W * p.Cin;
+      if (P1X1) a_base[i] += ((size_t)a_hi0[i] * p.W + a_wi0[i]) * p.Cin + kt_begin * 16 + a_q[i] * 4;
+    } else if (id < NP) {
+      const int j = id - NA;
+      const int plane = j / (2 * NB), rb = j - plane * (2 * NB);
+      const int row = rb * 32 + (lane >> 1);
+      const int half = (lane & 1) ^ ((row >> 3) & 1);
+      b_ok[i] = n0 + row < p.Cout;
+      b_ptr[i] = q.ws + ((size_t)plane * q.KC * p.Cout + (b_ok[i] ? n0 + row : 0)) * 16 + half * 8 +
+                 (size_t)kt_begin * p.Cout * 16;
+    }
+  }
+  int kg = kt_begin * 16;           // + 4 a_q per lane
+  int kc0, kr, ks;                  // tap position of k = kg (lane-independent part)
+  {
+    const int rs = kg / p.Cin;
+    kc0 = kg - rs * p.Cin;
+    kr = rs / p.S;
+    ks = rs - kr * p.S;
+  }
+  const size_t b_step = (size_t)p.Cout * 16;
+  int kt_issue = 0;
+  auto issue = [&]() {
+    unsigned char* st = lds + (kt_issue % NST) * STAGE;
+    const bool live = kt_issue < nk;
+#pragma unroll
+    for (int i = 0; i < PWV; ++i) {
+      const int id = wave + 4 * i;                      // wave-uniform
+      if (id < NA) {
+        const float* src;
+        if (P1X1) {
+          src = (live && a_ok[i] && kg + a_q[i] * 4 < p.K) ? a_base[i]
+                                                            : reinterpret_cast<const float*>(zero_page);
+          a_base[i] += 16;
+        } else {
+          // Cin % 4 == 0: a quad never straddles a tap, but a 16-k step may (Cin = 4: the stem)
+          int kc = kc0 + a_q[i] * 4, r2 = kr, s2 = ks;
+          while (kc >= p.Cin) {
+            kc -= p.Cin;
+            if (++s2 == p.S) {
+              s2 = 0;
+              ++r2;
+            }
+          }
+          const int hi = a_hi0[i] + r2, wi = a_wi0[i] + s2;
+          const bool ok = live && a_ok[i] && kg + a_q[i] * 4 < p.K && hi >= 0 && wi >= 0 && hi < p.H &&
+                          wi < p.W;
+          src = ok ? a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + kc
+                   : reinterpret_cast<const float*>(zero_page);
+        }
+        glds16(src, st + id * 1024);
+      } else if (id < NP) {
+        const __bf16* src = (live && b_ok[i]) ? b_ptr[i] : reinterpret_cast<const __bf16*>(zero_page);
+        b_ptr[i] += b_step;
+        glds16(src, st + A_BYTES + (id - NA) * 1024);
+      } else {
+        glds16(zero_page, lds + SCR);
+      }
+    }
+    kg += 16;
+    if (!P1X1) {
+      kc0 += 16;
+      while (kc0 >= p.Cin) {
+        kc0 -= p.Cin;
+        if (++ks == p.S) {
+          ks = 0;
+          ++kr;
+        }
+      }
+    }
+    ++kt_issue;
+  };
+
+  // ---- fragment roles
+  const int frow = lane & 31, fk = lane >> 5;
+  int a_off0[MB], a_off1[MB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a) {
+    const int ar = wm * 32 * MB + a * 32 + frow;
+    const int ac = (ar >> 2) & 3;
+    a_off0[a] = ar * 64 + (((2 * fk) ^ ac) << 4);
+    a_off1[a] = ar * 64 + (((2 * fk + 1) ^ ac) << 4);
+  }
+  const int br = wn * 32 * NB + frow;                   // + 32 b keeps the 8-row-group parity
+  const int b_off = A_BYTES + br * 32 + ((fk ^ ((br >> 3) & 1)) << 4);
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  issue();
+  issue();
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt has landed once at most one younger stage (PWV DMAs) is still in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PWV) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue();
+    const unsigned char* st = lds + (kt % NST) * STAGE;
+    bf16x8 fa[3][MB], fb[3][NB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(st + a_off0[a]);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(st + a_off1[a]);
+      u32x2 h0, m0_, l0, h1, m1, l1;
+      split3(a0, h0, m0_, l0);
+      split3(a1, h1, m1, l1);
+      fa[0][a] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+      fa[1][a] = __builtin_bit_cast(bf16x8, u32x4{m0_[0], m0_[1], m1[0], m1[1]});
+      fa[2][a] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        fb[s][b] = *reinterpret_cast<const bf16x8*>(st + b_off + s * B_PLANE + b * 32 * 32);
+#pragma unroll
+    for (int t = 2; t >= 0; --t)
+#pragma unroll
+      for (int i = 0; i <= t; ++i)
+#pragma unroll
+        for (int a = 0; a < MB; ++a)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[t - i][b], acc[a][b], 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the (zero-page) tail DMAs
+  conv_store_tile<MB, NB>(p, acc, m0, n0, wm, wn, lane);
+}
+
 // (Tried: the same tile and ring with TWO waves per workgroup — each wave 32 rows x all 64 columns,
 //  so that a row block's A fragment is split by one wave instead of two and the fixed per-step
 //  instructions are shared by 12 MFMAs instead of 6.  Equal on the small grids, 15-30 % SLOWER on the
@@ -675,6 +868,9 @@ struct HaloBfxArgs {
   int KC;
   int tiles_y, tiles_x;
   int chunks_per_split;  // channel chunks per gridDim.z slice
+  const unsigned* zero = nullptr;   // device zero page (DMA source of out-of-range operands)
+  const __bf16* xp = nullptr;       // split-form input [3][N][H][W][Cin] bf16 (v4 kernel), or null
+  long long xp_plane = 0;
 };
 
 template <int NB>
@@ -1076,8 +1272,252 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxA
   }
 }
 
-int g_halo_last_nb = 0, g_halo_last_splits = 0;
-int g_halo_force_splits = -1, g_halo_variant = 2;
+// Variant 4: the operands reach LDS by DMA (`global_load_lds_dwordx4`).  Component ablation of
+// variant 3 on the P2 layer (tools/ablate.py, profiles/r2w_ablate_conv_loops.txt): 0.89 ms =
+// 0.61 ms of MFMA issue + 0.36 ms of staging that does NOT hide behind it — the filter slice's
+// round trip through VGPRs (3 global loads + 3 ds_write_b128 per thread and tap: 0.20 ms) and the
+// patch reload (global load, 66 VALU of splitting, 9 ds_write_b64 per thread and chunk, a second
+// barrier: 0.13 ms) sit in every wave's own instruction stream, and the three co-resident waves of
+// a SIMD fall into step (fair MFMA arbitration makes them finish — and stall — together).
+//   * filter slices: 12 (NB = 2) / 6 (NB = 1) DMA pieces of 1 KB per tap, issued right after the
+//     step's barrier into the other buffer; no VGPRs, no ds_write, one vmcnt(0) before the barrier;
+//   * APL: the input arrives in SPLIT FORM (the producing conv's epilogue wrote the hi / mid / lo
+//     planes, ConvArgs::yp) and the 10 x 18 pixel patch of a chunk is 27 DMA pieces (48-byte rows:
+//     two data lanes + one pad lane per pixel) issued at tap 8 — once every wave has read its
+//     last fragment of the old patch — and landing under that tap's MFMAs: no splitting, no
+//     ds_write, no register staging; !APL keeps variant 3's register path for fp32 inputs.
+// LDS: 24 KB filter double buffer + 1 KB scratch (dummy pieces) + 27 KB patch = 52 KB -> three
+// workgroups per CU.
+template <int NB, bool APL>
+__global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxArgs q) {
+  const ConvArgs& p = q.c;
+  constexpr int BN = 64 * NB;
+  constexpr int B_PLANE = BN * 32, B_BUF = 3 * B_PLANE;
+  constexpr int SCR = 2 * B_BUF;                         // 1 KB scratch: target of dummy pieces
+  constexpr int A_OFF = SCR + 1024;
+  constexpr int A_PLANE = APL ? 9 * 1024 : PROWS * HLDR;   // 9 DMA pieces >= 180 rows x 48 B
+  constexpr int A_PIECES = 27, A_PER_WAVE = 7;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[A_OFF + 3 * A_PLANE];
+  const unsigned* __restrict__ zero_page = q.zero;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = bgs::uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int vtile = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if (vtile >= p.tiles_m * p.tiles_n) return;                  // workgroup-uniform
+  const int tm = vtile / p.tiles_n, tn = vtile - tm * p.tiles_n;
+  const int n = tm / (q.tiles_y * q.tiles_x);
+  const int trem = tm - n * (q.tiles_y * q.tiles_x);
+  const int ty = trem / q.tiles_x, tx = trem - ty * q.tiles_x;
+  const int h0 = ty * TH - 1, w0 = tx * TW - 1;                // input coords of patch (0, 0)
+  const int n0 = tn * BN;
+  const int cchunks = p.Cin / 16;
+  const int c_begin = p.partial ? blockIdx.z * q.chunks_per_split : 0;
+  const int c_end = p.partial ? min(cchunks, c_begin + q.chunks_per_split) : cchunks;
+
+  // ---- filter DMA roles.  NB = 2: wave w carries rows 32 w .. 32 w + 31 of the three planes.
+  //      NB = 1: six pieces (plane, row half): wave w takes piece w and, w < 2, piece w + 4 (a
+  //      dummy piece into the scratch block otherwise: every wave issues the same DMA count).
+  const int brow_d = (NB == 2 ? wave * 32 : (wave & 1) * 32) + (lane >> 1);
+  const int bhalf_d = (lane & 1) ^ ((brow_d >> 3) & 1);
+  const bool b_okd = n0 + brow_d < p.Cout;
+  const __bf16* b_lane = q.ws + (size_t)(b_okd ? n0 + brow_d : 0) * 16 + bhalf_d * 8;
+  const size_t b_plane = (size_t)q.KC * p.Cout * 16;
+  auto issue_b = [&](int chunk, int tap, int buf_off) {
+    const size_t koff = (size_t)(tap * cchunks + chunk) * p.Cout * 16;
+    const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page);
+    if (NB == 2) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        glds16(b_okd ? b_lane + s * b_plane + koff : zp, lds + buf_off + s * B_PLANE + wave * 1024);
+    } else {
+      const int s0 = wave >> 1;                                  // piece w: plane w / 2, half w % 2
+      glds16(b_okd ? b_lane + s0 * b_plane + koff : zp, lds + buf_off + s0 * B_PLANE + (wave & 1) * 1024);
+      if (wave < 2) glds16(b_okd ? b_lane + 2 * b_plane + koff : zp, lds + buf_off + 2 * B_PLANE + wave * 1024);
+      else glds16(zp, lds + SCR);
+    }
+  };
+
+  // ---- patch roles
+  // APL: piece i (0..26) = plane i / 9, lanes 64 (i % 9) .. : L -> patch pixel L / 3, part L % 3
+  //      (0 / 1: the two 16-byte halves of the pixel's 16 channels, 2: pad).  Wave w issues pieces
+  //      w, w + 4, ..: seven each (the 28th is a dummy).
+  int a_off[A_PER_WAVE];                                        // element offset in a plane, -1 = zero page
+  // !APL: variant 3's register staging
+  const float* a_src[AQT];
+  int a_dst[AQT];
+  bool a_use[AQT];
+  f32x4 ra[AQT];
+  if (APL) {
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+      const int piece = wave + 4 * i;
+      const int L = (piece % 9) * 64 + lane;
+      const int prow = L / 3, part = L - prow * 3;
+      const int pr = prow / PW, pc = prow - pr * PW;
+      const int hi = h0 + pr, wi = w0 + pc;
+      const bool in = piece < A_PIECES && prow < PROWS && part < 2 && hi >= 0 && hi < p.H && wi >= 0 &&
+                      wi < p.W;
+      a_off[i] = in ? (int)((((size_t)n * p.H + hi) * p.W + wi) * p.Cin) + part * 8 : -1;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < AQT; ++i) {
+      const int idx = tid + kThreads * i;
+      a_use[i] = idx < AQ;
+      const int prow = a_use[i] ? idx >> 2 : 0, kq = idx & 3;
+      const int pr = prow / PW, pc = prow - pr * PW;
+      const int hi = h0 + pr, wi = w0 + pc;
+      const bool in = a_use[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+      a_src[i] = in ? p.x + (((size_t)n * p.H + hi) * p.W + wi) * p.Cin + kq * 4
+                    : reinterpret_cast<const float*>(g_zero_page);
+      a_dst[i] = (in ? 1 : 0) | ((prow * HLDR + kq * 8) << 1);   // bit 0: advances with the chunk
+    }
+  }
+  auto issue_a = [&](int chunk) {                               // APL
+    const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page);
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+      const int piece = wave + 4 * i;                            // wave-uniform
+      const int plane = piece / 9;
+      const __bf16* src = a_off[i] >= 0 ? q.xp + (size_t)plane * q.xp_plane + a_off[i] + chunk * 16 : zp;
+      unsigned char* dst = piece < A_PIECES ? lds + A_OFF + plane * A_PLANE + (piece % 9) * 1024
+                                            : lds + SCR;
+      glds16(src, dst);
+    }
+  };
+  auto load_a = [&](int chunk) {                                // !APL
+#pragma unroll
+    for (int i = 0; i < AQT; ++i)
+      ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + ((a_dst[i] & 1) ? chunk * 16 : 0));
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < AQT; ++i) {
+      if (!a_use[i]) continue;
+      u32x2 h, m, l;
+      split3(ra[i], h, m, l);
+      unsigned char* d = lds + A_OFF + (a_dst[i] >> 1);
+      *reinterpret_cast<u32x2*>(d) = h;
+      *reinterpret_cast<u32x2*>(d + A_PLANE) = m;
+      *reinterpret_cast<u32x2*>(d + 2 * A_PLANE) = l;
+    }
+  };
+
+  // ---- fragment roles: lane frow of sub-tile a owns pixel m = 64 wm + 32 a + frow
+  const int frow = lane & 31, fk = lane >> 5;
+  int a_frag[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int m = wm * 64 + a * 32 + frow;
+    a_frag[a] = A_OFF + ((m >> 4) * PW + (m & 15)) * HLDR + fk * 16;      // patch row of tap (0, 0)
+  }
+  const int brow = wn * 32 * NB + frow;                           // + 32 b: same 8-row-group parity
+  const int b_frag = brow * 32 + ((fk ^ ((brow >> 3) & 1)) << 4);
+
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if (APL) issue_a(c_begin);
+  else load_a(c_begin);
+  issue_b(c_begin, 0, 0);
+  if (!APL) store_a();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0, nxt = B_BUF;                                      // byte offsets of the two B buffers
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const bool last_chunk = chunk + 1 >= c_end;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int rd = (tap & 1) ? nxt : cur;                       // buffer of this step
+      const int wr = (tap & 1) ? cur : nxt;                       // buffer of the next step
+      if (tap < 8) issue_b(chunk, tap + 1, wr);                   // next filter slice: DMA in flight
+      else if (!last_chunk) issue_b(chunk + 1, 0, wr);
+      if (!APL && tap == 0 && !last_chunk) load_a(chunk + 1);     // next patch: held in registers
+      const int tap_off = ((tap / 3) * PW + (tap % 3)) * HLDR;    // compile-time constant
+      bf16x8 fa[3][2], fb[3][NB];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+          fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a] + tap_off + s * A_PLANE);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          fb[s][b] = *reinterpret_cast<const bf16x8*>(lds + rd + b_frag + s * B_PLANE + b * 32 * 32);
+      }
+      if (APL && tap == 8 && !last_chunk) {
+        // every wave holds its last fragments of this patch in registers: refill it under the MFMAs
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_a(chunk + 1);
+      }
+#pragma unroll
+      for (int tt = 2; tt >= 0; --tt)
+#pragma unroll
+        for (int i = 0; i <= tt; ++i)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[tt - i][b], acc[a][b],
+                                                                  0, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // next slice (and patch) landed
+      __syncthreads();
+      if (!APL && tap == 8 && !last_chunk) {                      // every wave is done with this patch
+        store_a();
+        __syncthreads();
+      }
+    }
+    // nine steps per chunk: the buffer roles swap from chunk to chunk
+    const int t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+
+  // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  float* part = p.partial ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : nullptr;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int m = wm * 64 + a * 32 + i;
+      const int ho = ty * TH + (m >> 4), wo = tx * TW + (m & 15);
+      if (ho >= p.H || wo >= p.W) continue;
+      const size_t row = (((size_t)n * p.H + ho) * p.W + wo) * p.Cout;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int j = n0 + wn * 32 * NB + b * 32 + (lane & 31);
+        if (j >= p.Cout) continue;
+        float v = acc[a][b][r];
+        if (part) {
+          part[row + j] = v;
+        } else {
+          if (p.bias) v += p.bias[j];
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (p.y) p.y[row + j] = v;
+          if (p.yp) {
+            unsigned short h, md, l;
+            split3_scalar(v, h, md, l);
+            unsigned short* o = p.yp + row + j;
+            o[0] = h;
+            o[p.yp_plane] = md;
+            o[2 * p.yp_plane] = l;
+          }
+        }
+      }
+    }
+  }
+}
+
+int g_halo_last_nb = 0, g_halo_last_splits = 0, g_halo_last_variant = 0;
+int g_halo_force_splits = -1, g_halo_variant = 4;
 
 int halo_bfx_plan(long long M, int tiles_m, int Cin, int Cout, int& nb) {
   nb = Cout <= 64 ? 1 : 2;
@@ -1098,7 +1538,7 @@ int halo_bfx_plan(long long M, int tiles_m, int Cin, int Cout, int& nb) {
 }
 
 struct BfxKnobs {
-  int tile = 0, splitk = -1, dma = 1, pl_nst = 4;
+  int tile = 0, splitk = -1, dma = 1, pl_nst = 4, ring = 0;
   BfxKnobs() {
     if (const char* e = getenv("BGS_BFX_TILE")) tile = atoi(e);
     if (const char* e = getenv("BGS_BFX_SPLITK")) splitk = atoi(e);
@@ -1188,6 +1628,18 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
       if (p1x1) hipLaunchKernelGGL((conv_igemm_bfx_pl_kernel<true, 4>), grid, dim3(kThreads), 0, st, q);
       else hipLaunchKernelGGL((conv_igemm_bfx_pl_kernel<false, 4>), grid, dim3(kThreads), 0, st, q);
     }
+  } else if (knobs.ring && q.ns == 3 && up == 1 && tile != 11) {
+    g_last_dma = 3;
+    const bool p1x1 = p.R == 1 && p.S == 1 && p.pad == 0;
+#define BFX_R(MB_, NB_)                                                                                       \
+  do {                                                                                                        \
+    if (p1x1) hipLaunchKernelGGL((conv_igemm_bfx_ring_kernel<MB_, NB_, true>), grid, dim3(kThreads), 0, st, q); \
+    else hipLaunchKernelGGL((conv_igemm_bfx_ring_kernel<MB_, NB_, false>), grid, dim3(kThreads), 0, st, q);     \
+  } while (0)
+    if (tile == 22) BFX_R(2, 2);
+    else if (tile == 21) BFX_R(2, 1);
+    else BFX_R(1, 2);
+#undef BFX_R
   } else if (tile == 22) BFX_T(2, 2);
   else if (tile == 21) BFX_T(2, 1);
   else if (tile == 12) BFX_T(1, 2);
@@ -1250,11 +1702,12 @@ extern "C" void bgs_conv_bfx_tuning(int tile, int splitk) {
   k.tile = tile & 0xff;               // bit 8 set: the register-staged 64x64 kernel instead of the
   k.dma = (tile & 0x100) ? 0 : 1;     // LDS-DMA ring (A/B runs and tests of both)
   k.pl_nst = (tile & 0x400) ? 3 : 4;  // bit 10: 3-stage ring (4 workgroups / CU) of the split-form kernel
+  k.ring = (tile & 0x1000) ? 1 : 0;   // bit 12: the DMA-ring kernel for the 128 x 128 / 128 x 64 / 64 x 128 tiles
   k.splitk = splitk;
 }
 
 extern "C" int bgs_conv_bfx_last_launch(int* tile, int* splits) {
-  if (tile) *tile = g_last_tile | (g_last_dma == 1 ? 0x200 : 0) | (g_last_dma == 2 ? 0x800 : 0);   // bit 9: the LDS-DMA kernel ran; bit 11: the split-form-input kernel
+  if (tile) *tile = g_last_tile | (g_last_dma == 1 ? 0x200 : 0) | (g_last_dma == 2 ? 0x800 : 0) | (g_last_dma == 3 ? 0x1000 : 0);   // bit 9: the LDS-DMA kernel ran; bit 11: the split-form-input kernel
   if (splits) *splits = g_last_splits;
   return BGS_OK;
 }
@@ -1404,30 +1857,37 @@ extern "C" void bgs_conv3x3_halo_bfx_tuning(int splits, int variant) {
   g_ablate = (variant >> 8) & 0xff;          // timing-only ablation modes (-DBGS_ABLATE builds)
   variant &= 0xff;
   g_halo_force_splits = splits;
-  g_halo_variant = variant == 1 ? 1 : 2;     // 1 = first version (2 workgroups / CU), 2 = unrolled, 3 / CU (default)
+  g_halo_variant = variant == 1 ? 1 : (variant == 2 ? 2 : 4);   /* 0 = the default */   // 1 = first version (2 workgroups / CU), 2 = taps unrolled + 3 / CU (register-staged), 4 = DMA operands (default)
 }
 
 extern "C" int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits) {
-  if (nb) *nb = g_halo_last_nb;
+  if (nb) *nb = g_halo_last_nb | (g_halo_last_variant << 8);   // bits 8..: the kernel variant that ran
   if (splits) *splits = g_halo_last_splits;
   return BGS_OK;
 }
 
-// 3x3 / stride 1 / pad 1, Cin % 16 == 0; wsplit = bgs_conv_bfx_split_weights of [Cout][3][3][Cin].
-extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias,
-                                             float* y, int N, int H, int W, int Cin, int Cout,
-                                             int relu, int planes, void* workspace,
-                                             size_t workspace_bytes, bgs_stream_t stream) {
+namespace {
+int halo_bfx_launch(const float* x, const void* xplanes, const void* wsplit, const float* bias,
+                    float* y, void* yplanes, int N, int H, int W, int Cin, int Cout, int relu,
+                    int planes, void* workspace, size_t workspace_bytes, bgs_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BGS_ERR_INVALID_ARG;
-  if (!x || !wsplit || !y) return BGS_ERR_INVALID_ARG;
+  if ((!x && !xplanes) || !wsplit || (!y && !yplanes)) return BGS_ERR_INVALID_ARG;
   if (planes != 1 && planes != 3) return BGS_ERR_INVALID_ARG;
+  if ((xplanes || yplanes) && planes != 3) return BGS_ERR_UNSUPPORTED;
   if (Cin % 16 != 0) return BGS_ERR_UNSUPPORTED;
-  if ((uintptr_t)x % 16 != 0 || (uintptr_t)wsplit % 16 != 0) return BGS_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)xplanes | (uintptr_t)wsplit | (uintptr_t)yplanes) % 16 != 0)
+    return BGS_ERR_UNSUPPORTED;
   const long long M = (long long)N * H * W;
-  if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  if (M > 0x7fffffffLL || M * Cin > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
   HaloBfxArgs q;
   q.ns = planes;
+  q.zero = zero_page_device();
+  if (!q.zero) return BGS_ERR_LAUNCH;
+  q.xp = reinterpret_cast<const __bf16*>(xplanes);
+  q.xp_plane = M * Cin;
   ConvArgs& p = q.c;
+  p.yp = reinterpret_cast<unsigned short*>(yplanes);
+  p.yp_plane = M * Cout;
   p.x = x; p.w = nullptr; p.bias = bias; p.res = nullptr; p.mask = nullptr; p.y = y;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = 3; p.S = 3; p.stride = 1; p.pad = 1;
   p.Ho = H; p.Wo = W; p.M = (int)M; p.K = 9 * Cin; p.relu = relu; p.res_mode = 0;
@@ -1454,7 +1914,17 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit,
   g_halo_last_nb = nb;
   g_halo_last_splits = splits;
   dim3 grid((unsigned)(8 * p.chunk), 1u, (unsigned)splits);
-  if (g_halo_variant == 1 && q.ns == 3) {
+  const bool v4 = q.ns == 3 && (g_halo_variant == 4 || q.xp || p.yp || !p.y);
+  g_halo_last_variant = v4 ? 4 : g_halo_variant;
+  if (v4) {
+    if (nb == 1) {
+      if (q.xp) hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+      else hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, false>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    } else {
+      if (q.xp) hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+      else hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, false>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    }
+  } else if (g_halo_variant == 1 && q.ns == 3) {
     if (nb == 1)
       hipLaunchKernelGGL(conv3x3_halo_bfx_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
     else
@@ -1482,4 +1952,24 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit,
     return bgs_internal_conv_splitk_epilogue(p, splits, (hipStream_t)stream);
   }
   BGS_RETURN_LAUNCH_STATUS();
+}
+}  // namespace
+
+// 3x3 / stride 1 / pad 1, Cin % 16 == 0; wsplit = bgs_conv_bfx_split_weights of [Cout][3][3][Cin].
+extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias,
+                                             float* y, int N, int H, int W, int Cin, int Cout,
+                                             int relu, int planes, void* workspace,
+                                             size_t workspace_bytes, bgs_stream_t stream) {
+  if (!x || !y) return BGS_ERR_INVALID_ARG;
+  return halo_bfx_launch(x, nullptr, wsplit, bias, y, nullptr, N, H, W, Cin, Cout, relu, planes,
+                         workspace, workspace_bytes, stream);
+}
+
+// The same layer with split-form activations on either side (see bgs_conv2d_nhwc_bfx_ex).
+extern "C" int bgs_conv3x3_halo_nhwc_bfx_ex(const float* x, const void* xplanes, const void* wsplit,
+                                            const float* bias, float* y, void* yplanes, int N, int H,
+                                            int W, int Cin, int Cout, int relu, void* workspace,
+                                            size_t workspace_bytes, bgs_stream_t stream) {
+  return halo_bfx_launch(xplanes ? nullptr : x, xplanes, wsplit, bias, y, yplanes, N, H, W, Cin, Cout,
+                         relu, 3, workspace, workspace_bytes, stream);
 }

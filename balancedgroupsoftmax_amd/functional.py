@@ -362,7 +362,7 @@ def bfx_split_weights(w2d, cache=True):
     return out
 
 
-def conv_bfx_tuning(tile=0, splitk=-1, halo_splits=-1, halo_variant=2):
+def conv_bfx_tuning(tile=0, splitk=-1, halo_splits=-1, halo_variant=0):
     """Process-wide tuning / test hook of the bf16x6 kernels (see include/bgs.h)."""
     lib = capi.load()
     lib.bgs_conv_bfx_tuning(int(tile), int(splitk))
@@ -376,7 +376,8 @@ def conv_bfx_last_launch():
     a, c, d, e = (ctypes.c_int() for _ in range(4))
     lib.bgs_conv_bfx_last_launch(ctypes.byref(a), ctypes.byref(c))
     lib.bgs_conv3x3_halo_bfx_last_launch(ctypes.byref(d), ctypes.byref(e))
-    return dict(tile=a.value, splits=c.value, halo_nb=d.value, halo_splits=e.value)
+    return dict(tile=a.value, splits=c.value, halo_nb=d.value & 0xff, halo_variant=d.value >> 8,
+                halo_splits=e.value)
 
 
 def conv_tuning(tile=0, bk=0, splitk=0, noswizzle=0):
@@ -460,6 +461,17 @@ def conv2d_nhwc_split(x, x_planes, w_krsc, bias=None, stride=1, pad=0, relu=Fals
     y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=dev) if want_f32 else None
     yp = torch.empty((3, N, Ho, Wo, Cout), dtype=torch.bfloat16, device=dev) if want_planes else None
     wsplit = bfx_split_weights(w_krsc.view(Cout, R * S * Cin))
+    if (R == 3 and S == 3 and stride == 1 and pad == 1 and residual is None and Cin % 16 == 0
+            and _use_halo_bfx(N * Ho * Wo, Cout)):
+        wsb = lib.bgs_conv3x3_halo_bfx_workspace_bytes(N, H, W, Cin, Cout)
+        ws = _workspace(wsb, dev) if wsb else None
+        rc = lib.bgs_conv3x3_halo_nhwc_bfx_ex(capi.ptr(x) if x_planes is None else None,
+                                              capi.ptr(x_planes), capi.ptr(wsplit), capi.ptr(bias),
+                                              capi.ptr(y), capi.ptr(yp), N, H, W, Cin, Cout,
+                                              int(bool(relu)), capi.ptr(ws), wsb,
+                                              capi.current_stream(dev))
+        capi.check('bgs_conv3x3_halo_nhwc_bfx_ex', rc)
+        return y, yp
     wsb = lib.bgs_conv_bfx_ex_workspace_bytes(N * Ho * Wo, Cout, R * S * Cin,
                                               int(x_planes is not None))
     ws = _workspace(wsb, dev) if wsb else None

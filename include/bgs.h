@@ -288,6 +288,10 @@ int bgs_conv2d_nhwc_bfx_ex(const float* x, const void* xplanes, const void* wspl
                            int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                            int relu, int residual_mode, void* workspace, size_t workspace_bytes,
                            bgs_stream_t stream);
+int bgs_conv3x3_halo_nhwc_bfx_ex(const float* x, const void* xplanes, const void* wsplit,
+                                 const float* bias, float* y, void* yplanes, int N, int H, int W,
+                                 int Cin, int Cout, int relu, void* workspace,
+                                 size_t workspace_bytes, bgs_stream_t stream);
 size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias, float* y,
                                   int N, int H, int W, int Cin, int Cout, int relu, int planes,
