@@ -72,18 +72,11 @@ SIGNATURES = {
     'bgs_conv_bfx_workspace_bytes': (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int]),
     'bgs_conv2d_nhwc_f32_bfx_ws': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, c_f32p, c_f32p]
                                    + [ctypes.c_int] * 12 + [c_ptr, ctypes.c_size_t, c_ptr]),
-    'bgs_conv_bfx_split_act': (ctypes.c_int, [c_f32p, c_ptr, ctypes.c_longlong, ctypes.c_int, c_ptr]),
-    'bgs_conv_bfx_ex_workspace_bytes': (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
-                                                          ctypes.c_int]),
-    'bgs_conv2d_nhwc_bfx_ex': (ctypes.c_int, [c_f32p, c_ptr, c_ptr, c_f32p, c_f32p, c_f32p, c_ptr]
-                               + [ctypes.c_int] * 11 + [c_ptr, ctypes.c_size_t, c_ptr]),
     'bgs_conv2d_dgrad_nhwc_f32_bfx_ws': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, c_f32p, c_f32p]
                                          + [ctypes.c_int] * 11 + [c_ptr, ctypes.c_size_t, c_ptr]),
     'bgs_conv3x3_halo_bfx_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 5),
     'bgs_conv3x3_halo_nhwc_f32_bfx': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, c_f32p]
                                       + [ctypes.c_int] * 7 + [c_ptr, ctypes.c_size_t, c_ptr]),
-    'bgs_conv3x3_halo_nhwc_bfx_ex': (ctypes.c_int, [c_f32p, c_ptr, c_ptr, c_f32p, c_f32p, c_ptr]
-                                     + [ctypes.c_int] * 6 + [c_ptr, ctypes.c_size_t, c_ptr]),
     'bgs_conv_bfx_tuning': (None, [ctypes.c_int] * 2),
     'bgs_conv_bfx_last_launch': (ctypes.c_int, [c_ptr, c_ptr]),
     'bgs_conv_tuning': (None, [ctypes.c_int] * 4),

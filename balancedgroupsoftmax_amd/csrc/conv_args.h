@@ -41,30 +41,7 @@ struct ConvArgs {
   // re-read of the same pixels for the next Cout tile hit that XCD's L2 (PMC: 2.46 GB fetched per
   // 158-GFLOP layer before, profiles/r2d_pmc_conv.md).
   int tiles_m, tiles_n, chunk;
-  // Split-form output (conv_bfx.hip): besides (or instead of, y == nullptr) the fp32 tensor the
-  // epilogue writes the EXACT three-way bf16 split of every result, hi / mid / lo planes of
-  // [M][Cout] bf16 each, `yp_plane` elements apart — the operand format the bf16x6 kernels feed
-  // to the matrix cores, so that the consuming layer does not split the same values again.
-  unsigned short* yp = nullptr;
-  long long yp_plane = 0;
 };
-
-// v -> (hi, mid, lo) bf16 bit patterns, round-to-nearest-even at every step (v_cvt_pk_bf16_f32);
-// hi + mid + lo == v exactly for every finite fp32 v whose low-order terms do not underflow.
-__device__ __forceinline__ void split3_scalar(float v, unsigned short& h, unsigned short& m,
-                                              unsigned short& l) {
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-  const bf16x2_t a = __builtin_convertvector(f32x2{v, 0.f}, bf16x2_t);
-  const unsigned ua = __builtin_bit_cast(unsigned, a);
-  const float r1 = v - __builtin_bit_cast(float, ua << 16);
-  const bf16x2_t b = __builtin_convertvector(f32x2{r1, 0.f}, bf16x2_t);
-  const unsigned ub = __builtin_bit_cast(unsigned, b);
-  const float r2 = r1 - __builtin_bit_cast(float, ub << 16);
-  const bf16x2_t c = __builtin_convertvector(f32x2{r2, 0.f}, bf16x2_t);
-  h = (unsigned short)(ua & 0xffffu);
-  m = (unsigned short)(ub & 0xffffu);
-  l = (unsigned short)(__builtin_bit_cast(unsigned, c) & 0xffffu);
-}
 
 // Fused epilogue of a (64*MB) x (64*NB) workgroup tile held as MB x NB accumulators of the 32x32
 // MFMA per wave (2 x 2 waves).  C/D layout of every 32x32 MFMA on gfx950 (dtype-independent):
@@ -127,15 +104,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& p, const f32x16 
         }
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.mask) v = p.mask[(size_t)m * p.Cout + j] > 0.f ? v : 0.f;
-        if (p.y) p.y[(size_t)m * p.Cout + j] = v;
-        if (p.yp) {
-          unsigned short h, md, l;
-          split3_scalar(v, h, md, l);
-          unsigned short* o = p.yp + (size_t)m * p.Cout + j;
-          o[0] = h;
-          o[p.yp_plane] = md;
-          o[2 * p.yp_plane] = l;
-        }
+        p.y[(size_t)m * p.Cout + j] = v;
       }
     }
   }

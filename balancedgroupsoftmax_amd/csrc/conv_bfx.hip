@@ -48,10 +48,6 @@ struct BfxArgs {
   ConvArgs c;
   const __bf16* ws;      // split weights [NS][KC][Cout][16]
   int KC;                // ceil(K / 16)
-  // split-form activations in (conv_igemm_bfx_pl_kernel): three planes of [N][H][W][Cin] bf16,
-  // `xp_plane` elements apart; null = the fp32 tensor c.x is the input
-  const __bf16* xp = nullptr;
-  long long xp_plane = 0;
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -465,363 +461,11 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
   conv_store_tile<1, 1>(p, acc, m0, n0, wm, wn, lane);
 }
 
-// ---------------------------------------------------------------------------------------------
-// The operand ring with larger workgroup tiles: (64 MB) x (64 NB), 2 x 2 waves of (32 MB) x (32 NB).
-// Ablation of the 64 x 64 kernel (tools/ablate.py, profiles/r2w_ablate_conv_loops.txt): with the DMA
-// issue removed a layer runs in 0.069 instead of 0.158 ms, with the MFMAs removed in 0.136 — the
-// loop is bound by global -> LDS traffic (10 KB per 24 MFMAs), not by the matrix pipe and not by
-// the A split (removing it changes nothing).  A 128 x 128 tile moves 20 KB per 96 MFMAs.
-//   * stage = A (64 MB rows x 64 B fp32, quads XOR-swizzled) + B (3 planes x 64 NB rows x 32 B,
-//     halves swapped on odd 8-row groups); NST = 3 stages;
-//   * 4 MB + 6 NB DMA pieces of 1 KB per stage, dealt round-robin to the four waves (piece w, w + 4,
-//     ..; ids past the end are dummy pieces into a scratch block: uniform DMA count per wave).
-template <int MB, int NB, bool P1X1>
-__global__ __launch_bounds__(kThreads, 2) void conv_igemm_bfx_ring_kernel(BfxArgs q) {
-  const ConvArgs& p = q.c;
-  const unsigned* __restrict__ zero_page = q.zero;
-  constexpr int NST = 3;
-  constexpr int A_BYTES = 64 * MB * 64, B_PLANE = 64 * NB * 32, STAGE = A_BYTES + 3 * B_PLANE;
-  constexpr int NA = 4 * MB, NBP = 6 * NB, NP = NA + NBP, PWV = (NP + 3) / 4;
-  constexpr int SCR = NST * STAGE;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[SCR + (4 * PWV > NP ? 1024 : 0)];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = bgs::uniform(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int vtile = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
-  if (vtile >= p.tiles_m * p.tiles_n) return;          // workgroup-uniform
-  const int m0 = (vtile / p.tiles_n) * (64 * MB), n0 = (vtile % p.tiles_n) * (64 * NB);
-
-  const int nk_all = q.KC;
-  const int kt_begin = p.partial ? blockIdx.z * p.kt_per_split : 0;
-  const int kt_end = p.partial ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
-  const int nk = kt_end - kt_begin;
-
-  // ---- DMA roles: piece i of this wave has id = wave + 4 i (kind is wave-uniform)
-  const float* a_base[PWV];        // A pieces: image base (+ fixed pixel offset when P1X1)
-  int a_hi0[PWV], a_wi0[PWV], a_q[PWV];
-  bool a_ok[PWV];
-  const __bf16* b_ptr[PWV];        // B pieces: advancing source pointer
-  bool b_ok[PWV];
-#pragma unroll
-  for (int i = 0; i < PWV; ++i) {
-    const int id = wave + 4 * i;
-    a_ok[i] = false;
-    b_ok[i] = false;
-    a_base[i] = nullptr;
-    b_ptr[i] = nullptr;
-    a_hi0[i] = a_wi0[i] = a_q[i] = 0;
-    if (id < NA) {
-      const int row = id * 16 + (lane >> 2);
-      a_q[i] = (lane & 3) ^ ((row >> 2) & 3);
-      const int m = m0 + row;
-      a_ok[i] = m < p.M;
-      const int mm = a_ok[i] ? m : 0;
-      const int hw = p.Ho * p.Wo;
-      const int n = mm / hw;
-      const int rem = mm - n * hw;
-      const int ho = rem / p.Wo;
-      const int wo = rem - ho * p.Wo;
-      a_hi0[i] = ho * p.stride - p.pad;
-      a_wi0[i] = wo * p.stride - p.pad;
-      a_base[i] = p.x + (size_t)n * p.H * p.W * p.Cin;
-      if (P1X1) a_base[i] += ((size_t)a_hi0[i] * p.W + a_wi0[i]) * p.Cin + kt_begin * 16 + a_q[i] * 4;
-    } else if (id < NP) {
-      const int j = id - NA;
-      const int plane = j / (2 * NB), rb = j - plane * (2 * NB);
-      const int row = rb * 32 + (lane >> 1);
-      const int half = (lane & 1) ^ ((row >> 3) & 1);
-      b_ok[i] = n0 + row < p.Cout;
-      b_ptr[i] = q.ws + ((size_t)plane * q.KC * p.Cout + (b_ok[i] ? n0 + row : 0)) * 16 + half * 8 +
-                 (size_t)kt_begin * p.Cout * 16;
-    }
-  }
-  int kg = kt_begin * 16;           // + 4 a_q per lane
-  int kc0, kr, ks;                  // tap position of k = kg (lane-independent part)
-  {
-    const int rs = kg / p.Cin;
-    kc0 = kg - rs * p.Cin;
-    kr = rs / p.S;
-    ks = rs - kr * p.S;
-  }
-  const size_t b_step = (size_t)p.Cout * 16;
-  int kt_issue = 0;
-  auto issue = [&]() {
-    unsigned char* st = lds + (kt_issue % NST) * STAGE;
-    const bool live = kt_issue < nk;
-#pragma unroll
-    for (int i = 0; i < PWV; ++i) {
-      const int id = wave + 4 * i;                      // wave-uniform
-      if (id < NA) {
-        const float* src;
-        if (P1X1) {
-          src = (live && a_ok[i] && kg + a_q[i] * 4 < p.K) ? a_base[i]
-                                                            : reinterpret_cast<const float*>(zero_page);
-          a_base[i] += 16;
-        } else {
-          // Cin % 4 == 0: a quad never straddles a tap, but a 16-k step may (Cin = 4: the stem)
-          int kc = kc0 + a_q[i] * 4, r2 = kr, s2 = ks;
-          while (kc >= p.Cin) {
-            kc -= p.Cin;
-            if (++s2 == p.S) {
-              s2 = 0;
-              ++r2;
-            }
-          }
-          const int hi = a_hi0[i] + r2, wi = a_wi0[i] + s2;
-          const bool ok = live && a_ok[i] && kg + a_q[i] * 4 < p.K && hi >= 0 && wi >= 0 && hi < p.H &&
-                          wi < p.W;
-          src = ok ? a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + kc
-                   : reinterpret_cast<const float*>(zero_page);
-        }
-        glds16(src, st + id * 1024);
-      } else if (id < NP) {
-        const __bf16* src = (live && b_ok[i]) ? b_ptr[i] : reinterpret_cast<const __bf16*>(zero_page);
-        b_ptr[i] += b_step;
-        glds16(src, st + A_BYTES + (id - NA) * 1024);
-      } else {
-        glds16(zero_page, lds + SCR);
-      }
-    }
-    kg += 16;
-    if (!P1X1) {
-      kc0 += 16;
-      while (kc0 >= p.Cin) {
-        kc0 -= p.Cin;
-        if (++ks == p.S) {
-          ks = 0;
-          ++kr;
-        }
-      }
-    }
-    ++kt_issue;
-  };
-
-  // ---- fragment roles
-  const int frow = lane & 31, fk = lane >> 5;
-  int a_off0[MB], a_off1[MB];
-#pragma unroll
-  for (int a = 0; a < MB; ++a) {
-    const int ar = wm * 32 * MB + a * 32 + frow;
-    const int ac = (ar >> 2) & 3;
-    a_off0[a] = ar * 64 + (((2 * fk) ^ ac) << 4);
-    a_off1[a] = ar * 64 + (((2 * fk + 1) ^ ac) << 4);
-  }
-  const int br = wn * 32 * NB + frow;                   // + 32 b keeps the 8-row-group parity
-  const int b_off = A_BYTES + br * 32 + ((fk ^ ((br >> 3) & 1)) << 4);
-
-  f32x16 acc[MB][NB];
-#pragma unroll
-  for (int a = 0; a < MB; ++a)
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  issue();
-  issue();
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed once at most one younger stage (PWV DMAs) is still in flight
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PWV) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    issue();
-    const unsigned char* st = lds + (kt % NST) * STAGE;
-    bf16x8 fa[3][MB], fb[3][NB];
-#pragma unroll
-    for (int a = 0; a < MB; ++a) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(st + a_off0[a]);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(st + a_off1[a]);
-      u32x2 h0, m0_, l0, h1, m1, l1;
-      split3(a0, h0, m0_, l0);
-      split3(a1, h1, m1, l1);
-      fa[0][a] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
-      fa[1][a] = __builtin_bit_cast(bf16x8, u32x4{m0_[0], m0_[1], m1[0], m1[1]});
-      fa[2][a] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
-    }
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-        fb[s][b] = *reinterpret_cast<const bf16x8*>(st + b_off + s * B_PLANE + b * 32 * 32);
-#pragma unroll
-    for (int t = 2; t >= 0; --t)
-#pragma unroll
-      for (int i = 0; i <= t; ++i)
-#pragma unroll
-        for (int a = 0; a < MB; ++a)
-#pragma unroll
-          for (int b = 0; b < NB; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[t - i][b], acc[a][b], 0, 0, 0);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the (zero-page) tail DMAs
-  conv_store_tile<MB, NB>(p, acc, m0, n0, wm, wn, lane);
-}
-
 // (Tried: the same tile and ring with TWO waves per workgroup — each wave 32 rows x all 64 columns,
 //  so that a row block's A fragment is split by one wave instead of two and the fixed per-step
 //  instructions are shared by 12 MFMAs instead of 6.  Equal on the small grids, 15-30 % SLOWER on the
 //  large ones (stem 0.216 vs 0.169 ms, FPN lateral P2 0.190 vs 0.159): at 40 KB of LDS per workgroup
 //  only two waves per SIMD are resident.  profiles/r2s_bfx_sweep_dma2.txt.  Removed.)
-
-// ---------------------------------------------------------------------------------------------
-// The 64 x 64 ring kernel on SPLIT-FORM activations: the producing layer's epilogue has already
-// written the exact hi / mid / lo bf16 planes of its output (ConvArgs::yp), so BOTH operands reach
-// LDS by `global_load_lds_dwordx4` in the format the matrix cores take and the K loop carries no
-// VALU work at all: per wave and K step 3 DMAs, 6 ds_read_b128, 6 MFMAs, one counted vmcnt, one
-// barrier (the fp32-input kernel above spends ~44 VALU instructions per step re-splitting A — per
-// reading wave, i.e. 2 x tiles_n times per element; that loop is issue-bound, this one is not).
-// HBM pays 6 instead of 4 bytes per activation element — the cheap side of the trade on this chip.
-//   * stage = 12 KB: A planes 0..2 then B planes 0..2, each 64 rows x 32 B, halves of a row
-//     swapped on odd 8-row groups (conflict-free ds_read_b128 without padding);
-//   * 12 DMA pieces of 1 KB per stage, three per wave (wave w: pieces w, w + 4, w + 8), so the
-//     vmcnt arithmetic is uniform; NST - 1 stages in flight;
-//   * Cin % 16 == 0 (a K step never straddles a filter tap), so tap / channel bookkeeping is
-//     wave-uniform (SALU).
-template <bool P1X1, int NST>
-__global__ __launch_bounds__(kThreads, NST == 3 ? 4 : 3) void conv_igemm_bfx_pl_kernel(BfxArgs q) {
-  const ConvArgs& p = q.c;
-  const unsigned* __restrict__ zero_page = q.zero;
-  constexpr int PLANE = 64 * 32, STAGE = 6 * PLANE;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = bgs::uniform(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int vtile = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
-  if (vtile >= p.tiles_m * p.tiles_n) return;          // workgroup-uniform
-  const int m0 = (vtile / p.tiles_n) * 64, n0 = (vtile % p.tiles_n) * 64;
-
-  // ---- DMA roles.  Every piece of wave w covers rows 32 (w & 1) + (lane >> 1) of its operand;
-  //      waves 0/1 carry A0, A2, B1 and waves 2/3 carry A1, B0, B2.
-  const int drow = (wave & 1) * 32 + (lane >> 1);
-  const int dhalf = (lane & 1) ^ ((drow >> 3) & 1);    // logical half (8 consecutive k) fetched
-  const bool hi_pair = wave >= 2;                      // wave-uniform
-  int a_hi0, a_wi0;
-  const __bf16* a_img;
-  bool a_ok;
-  {
-    const int m = m0 + drow;
-    a_ok = m < p.M;
-    const int mm = a_ok ? m : 0;
-    const int hw = p.Ho * p.Wo;
-    const int n = mm / hw;
-    const int rem = mm - n * hw;
-    const int ho = rem / p.Wo;
-    const int wo = rem - ho * p.Wo;
-    a_hi0 = ho * p.stride - p.pad;
-    a_wi0 = wo * p.stride - p.pad;
-    a_img = q.xp + (size_t)n * p.H * p.W * p.Cin + dhalf * 8;
-  }
-  const bool b_ok = n0 + drow < p.Cout;
-  const __bf16* b_row = q.ws + (size_t)(b_ok ? n0 + drow : 0) * 16 + dhalf * 8;
-  const size_t b_plane = (size_t)q.KC * p.Cout * 16;
-  const size_t b_step = (size_t)p.Cout * 16;
-
-  const int nk_all = q.KC;
-  const int kt_begin = p.partial ? blockIdx.z * p.kt_per_split : 0;
-  const int kt_end = p.partial ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
-  const int nk = kt_end - kt_begin;
-  int kg = kt_begin * 16;                               // wave-uniform K position of the next issue
-  int kc, kr, ks;
-  {
-    const int rs = kg / p.Cin;
-    kc = kg - rs * p.Cin;
-    kr = rs / p.S;
-    ks = rs - kr * p.S;
-  }
-  int kt_issue = 0;
-  const __bf16* a_ptr = nullptr;                        // P1X1: fixed pixel, advancing channel
-  if (P1X1) a_ptr = a_img + ((size_t)a_hi0 * p.W + a_wi0) * p.Cin + kg;
-  const __bf16* b_ptr = b_row + (size_t)kt_begin * b_step;
-  // plane / LDS slot of this wave's three pieces
-  const int a_pl0 = hi_pair ? 1 : 0;                    // first A piece
-  const int b_pl0 = hi_pair ? 0 : 1;                    // first B piece
-  const int slot = (wave & 1) * 1024;
-  auto issue = [&]() {
-    unsigned char* st = lds + (kt_issue % NST) * STAGE + slot;
-    const bool live = kt_issue < nk;
-    const __bf16* asrc;
-    bool aok;
-    if (P1X1) {
-      aok = live && a_ok && kg < p.K;
-      asrc = a_ptr;
-      a_ptr += 16;
-    } else {
-      const int hi = a_hi0 + kr, wi = a_wi0 + ks;
-      aok = live && a_ok && kg < p.K && hi >= 0 && wi >= 0 && hi < p.H && wi < p.W;
-      asrc = a_img + ((size_t)hi * p.W + wi) * p.Cin + kc;
-      kc += 16;
-      if (kc >= p.Cin) {
-        kc = 0;
-        if (++ks == p.S) {
-          ks = 0;
-          ++kr;
-        }
-      }
-    }
-    kg += 16;
-    const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page);
-    const bool bok = live && b_ok;
-    glds16(aok ? asrc + (size_t)a_pl0 * q.xp_plane : zp, st + a_pl0 * 2 * 1024);
-    if (!hi_pair) glds16(aok ? asrc + 2 * (size_t)q.xp_plane : zp, st + 4 * 1024);
-    glds16(bok ? b_ptr + b_pl0 * b_plane : zp, st + 3 * PLANE + b_pl0 * 2 * 1024);
-    if (hi_pair) glds16(bok ? b_ptr + 2 * b_plane : zp, st + 3 * PLANE + 4 * 1024);
-    b_ptr += b_step;
-    ++kt_issue;
-  };
-
-  // ---- fragment roles
-  const int frow = lane & 31, fk = lane >> 5;
-  const int ar = wm * 32 + frow;
-  const int a_off = ar * 32 + ((fk ^ ((ar >> 3) & 1)) << 4);
-  const int br = wn * 32 + frow;
-  const int b_off = 3 * PLANE + br * 32 + ((fk ^ ((br >> 3) & 1)) << 4);
-
-  f32x16 acc[1][1];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-
-#pragma unroll
-  for (int i = 0; i < NST - 1; ++i) issue();
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed once at most NST - 2 younger stages (3 DMAs each) are still in flight
-    if (NST == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    issue();
-    const unsigned char* st = lds + (kt % NST) * STAGE;
-    bf16x8 fa[3], fb[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      fa[s] = *reinterpret_cast<const bf16x8*>(st + a_off + s * PLANE);
-      fb[s] = *reinterpret_cast<const bf16x8*>(st + b_off + s * PLANE);
-    }
-#pragma unroll
-    for (int t = 2; t >= 0; --t)
-#pragma unroll
-      for (int i = 0; i <= t; ++i)
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[t - i], acc[0][0], 0, 0, 0);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the (zero-page) tail DMAs
-  conv_store_tile<1, 1>(p, acc, m0, n0, wm, wn, lane);
-}
-
-// x [rows][C] fp32 -> split-form planes [3][rows][C] bf16 (for tensors no conv epilogue produced:
-// RoI features, test inputs); four consecutive channels per thread.
-__global__ __launch_bounds__(256) void bfx_split_act_kernel(const float* __restrict__ x,
-                                                            unsigned short* __restrict__ out,
-                                                            size_t quads, size_t plane) {
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < quads; e += (size_t)gridDim.x * 256) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * e);
-    u32x2 h, m, l;
-    split3(v, h, m, l);
-    *reinterpret_cast<u32x2*>(out + 4 * e) = h;
-    *reinterpret_cast<u32x2*>(out + plane + 4 * e) = m;
-    *reinterpret_cast<u32x2*>(out + 2 * plane + 4 * e) = l;
-  }
-}
 
 // w [rows][K] fp32 -> out [NS][KC][rows][16] bf16 planes (zero-padded K tail)
 __global__ __launch_bounds__(256) void bfx_split_weights_kernel(const float* __restrict__ w,
@@ -868,9 +512,7 @@ struct HaloBfxArgs {
   int KC;
   int tiles_y, tiles_x;
   int chunks_per_split;  // channel chunks per gridDim.z slice
-  const unsigned* zero = nullptr;   // device zero page (DMA source of out-of-range operands)
-  const __bf16* xp = nullptr;       // split-form input [3][N][H][W][Cin] bf16 (v4 kernel), or null
-  long long xp_plane = 0;
+  const unsigned* zero = nullptr;   // device zero page (DMA source of out-of-range rows, variant 4)
 };
 
 template <int NB>
@@ -1272,31 +914,25 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxA
   }
 }
 
-// Variant 4: the operands reach LDS by DMA (`global_load_lds_dwordx4`).  Component ablation of
-// variant 3 on the P2 layer (tools/ablate.py, profiles/r2w_ablate_conv_loops.txt): 0.89 ms =
-// 0.61 ms of MFMA issue + 0.36 ms of staging that does NOT hide behind it — the filter slice's
-// round trip through VGPRs (3 global loads + 3 ds_write_b128 per thread and tap: 0.20 ms) and the
-// patch reload (global load, 66 VALU of splitting, 9 ds_write_b64 per thread and chunk, a second
-// barrier: 0.13 ms) sit in every wave's own instruction stream, and the three co-resident waves of
-// a SIMD fall into step (fair MFMA arbitration makes them finish — and stall — together).
-//   * filter slices: 12 (NB = 2) / 6 (NB = 1) DMA pieces of 1 KB per tap, issued right after the
-//     step's barrier into the other buffer; no VGPRs, no ds_write, one vmcnt(0) before the barrier;
-//   * APL: the input arrives in SPLIT FORM (the producing conv's epilogue wrote the hi / mid / lo
-//     planes, ConvArgs::yp) and the 10 x 18 pixel patch of a chunk is 27 DMA pieces (48-byte rows:
-//     two data lanes + one pad lane per pixel) issued at tap 8 — once every wave has read its
-//     last fragment of the old patch — and landing under that tap's MFMAs: no splitting, no
-//     ds_write, no register staging; !APL keeps variant 3's register path for fp32 inputs.
-// LDS: 24 KB filter double buffer + 1 KB scratch (dummy pieces) + 27 KB patch = 52 KB -> three
-// workgroups per CU.
-template <int NB, bool APL>
+// Variant 4 (default): the filter slices reach LDS by DMA (`global_load_lds_dwordx4`) instead of a
+// round trip through VGPRs.  Component ablation of variant 2 on the P2 layer (tools/ablate.py,
+// profiles/r2w_ablate_conv_loops.txt): 0.89 ms = 0.61 ms of MFMA issue + 0.36 ms of staging that
+// does not hide behind it; the filter slice (3 global loads + 3 ds_write_b128 per thread and tap)
+// is the largest part.  Here every tap's slice is 12 (NB = 2) / 6 (NB = 1) DMA pieces of 1 KB
+// issued right after the step's barrier into the other buffer: no VGPRs, no ds_write, one
+// vmcnt(0) before the barrier.  Bit-identical to variant 2; 3.49 -> 3.33 ms over the 3x3 layers of
+// a cfg[1] forward (profiles/r2x_halo4_sweep.txt).  The patch keeps the register path (global
+// load, split, ds_write_b64): a DMA of a pre-split ("split-form") patch written by the producing
+// layer's epilogue was built and measured too — no faster, 1.5x the activation bytes: removed.
+// LDS: 24 KB filter double buffer + 1 KB scratch (dummy pieces) + 25.3 KB patch.
+template <int NB>
 __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxArgs q) {
   const ConvArgs& p = q.c;
   constexpr int BN = 64 * NB;
   constexpr int B_PLANE = BN * 32, B_BUF = 3 * B_PLANE;
   constexpr int SCR = 2 * B_BUF;                         // 1 KB scratch: target of dummy pieces
   constexpr int A_OFF = SCR + 1024;
-  constexpr int A_PLANE = APL ? 9 * 1024 : PROWS * HLDR;   // 9 DMA pieces >= 180 rows x 48 B
-  constexpr int A_PIECES = 27, A_PER_WAVE = 7;
+  constexpr int A_PLANE = PROWS * HLDR;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[A_OFF + 3 * A_PLANE];
   const unsigned* __restrict__ zero_page = q.zero;
 
@@ -1338,55 +974,24 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
     }
   };
 
-  // ---- patch roles
-  // APL: piece i (0..26) = plane i / 9, lanes 64 (i % 9) .. : L -> patch pixel L / 3, part L % 3
-  //      (0 / 1: the two 16-byte halves of the pixel's 16 channels, 2: pad).  Wave w issues pieces
-  //      w, w + 4, ..: seven each (the 28th is a dummy).
-  int a_off[A_PER_WAVE];                                        // element offset in a plane, -1 = zero page
-  // !APL: variant 3's register staging
+  // ---- patch staging roles (variant 2's): patch quads idx = tid + 256 i; prow = idx / 4, kq = idx % 4
   const float* a_src[AQT];
   int a_dst[AQT];
   bool a_use[AQT];
   f32x4 ra[AQT];
-  if (APL) {
 #pragma unroll
-    for (int i = 0; i < A_PER_WAVE; ++i) {
-      const int piece = wave + 4 * i;
-      const int L = (piece % 9) * 64 + lane;
-      const int prow = L / 3, part = L - prow * 3;
-      const int pr = prow / PW, pc = prow - pr * PW;
-      const int hi = h0 + pr, wi = w0 + pc;
-      const bool in = piece < A_PIECES && prow < PROWS && part < 2 && hi >= 0 && hi < p.H && wi >= 0 &&
-                      wi < p.W;
-      a_off[i] = in ? (int)((((size_t)n * p.H + hi) * p.W + wi) * p.Cin) + part * 8 : -1;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < AQT; ++i) {
-      const int idx = tid + kThreads * i;
-      a_use[i] = idx < AQ;
-      const int prow = a_use[i] ? idx >> 2 : 0, kq = idx & 3;
-      const int pr = prow / PW, pc = prow - pr * PW;
-      const int hi = h0 + pr, wi = w0 + pc;
-      const bool in = a_use[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-      a_src[i] = in ? p.x + (((size_t)n * p.H + hi) * p.W + wi) * p.Cin + kq * 4
-                    : reinterpret_cast<const float*>(g_zero_page);
-      a_dst[i] = (in ? 1 : 0) | ((prow * HLDR + kq * 8) << 1);   // bit 0: advances with the chunk
-    }
+  for (int i = 0; i < AQT; ++i) {
+    const int idx = tid + kThreads * i;
+    a_use[i] = idx < AQ;
+    const int prow = a_use[i] ? idx >> 2 : 0, kq = idx & 3;
+    const int pr = prow / PW, pc = prow - pr * PW;
+    const int hi = h0 + pr, wi = w0 + pc;
+    const bool in = a_use[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+    a_src[i] = in ? p.x + (((size_t)n * p.H + hi) * p.W + wi) * p.Cin + kq * 4
+                  : reinterpret_cast<const float*>(g_zero_page);
+    a_dst[i] = (in ? 1 : 0) | ((prow * HLDR + kq * 8) << 1);   // bit 0: advances with the chunk
   }
-  auto issue_a = [&](int chunk) {                               // APL
-    const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page);
-#pragma unroll
-    for (int i = 0; i < A_PER_WAVE; ++i) {
-      const int piece = wave + 4 * i;                            // wave-uniform
-      const int plane = piece / 9;
-      const __bf16* src = a_off[i] >= 0 ? q.xp + (size_t)plane * q.xp_plane + a_off[i] + chunk * 16 : zp;
-      unsigned char* dst = piece < A_PIECES ? lds + A_OFF + plane * A_PLANE + (piece % 9) * 1024
-                                            : lds + SCR;
-      glds16(src, dst);
-    }
-  };
-  auto load_a = [&](int chunk) {                                // !APL
+  auto load_a = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < AQT; ++i)
       ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + ((a_dst[i] & 1) ? chunk * 16 : 0));
@@ -1423,10 +1028,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  if (APL) issue_a(c_begin);
-  else load_a(c_begin);
+  load_a(c_begin);
   issue_b(c_begin, 0, 0);
-  if (!APL) store_a();
+  store_a();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0, nxt = B_BUF;                                      // byte offsets of the two B buffers
@@ -1438,7 +1042,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
       const int wr = (tap & 1) ? cur : nxt;                       // buffer of the next step
       if (tap < 8) issue_b(chunk, tap + 1, wr);                   // next filter slice: DMA in flight
       else if (!last_chunk) issue_b(chunk + 1, 0, wr);
-      if (!APL && tap == 0 && !last_chunk) load_a(chunk + 1);     // next patch: held in registers
+      if (tap == 0 && !last_chunk) load_a(chunk + 1);             // next patch: held in registers
       const int tap_off = ((tap / 3) * PW + (tap % 3)) * HLDR;    // compile-time constant
       bf16x8 fa[3][2], fb[3][NB];
 #pragma unroll
@@ -1449,13 +1053,6 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
 #pragma unroll
         for (int b = 0; b < NB; ++b)
           fb[s][b] = *reinterpret_cast<const bf16x8*>(lds + rd + b_frag + s * B_PLANE + b * 32 * 32);
-      }
-      if (APL && tap == 8 && !last_chunk) {
-        // every wave holds its last fragments of this patch in registers: refill it under the MFMAs
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue_a(chunk + 1);
       }
 #pragma unroll
       for (int tt = 2; tt >= 0; --tt)
@@ -1469,7 +1066,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
                                                                   0, 0, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // next slice (and patch) landed
       __syncthreads();
-      if (!APL && tap == 8 && !last_chunk) {                      // every wave is done with this patch
+      if (tap == 8 && !last_chunk) {                              // every wave is done with this patch
         store_a();
         __syncthreads();
       }
@@ -1501,15 +1098,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
         } else {
           if (p.bias) v += p.bias[j];
           if (p.relu) v = fmaxf(v, 0.f);
-          if (p.y) p.y[row + j] = v;
-          if (p.yp) {
-            unsigned short h, md, l;
-            split3_scalar(v, h, md, l);
-            unsigned short* o = p.yp + row + j;
-            o[0] = h;
-            o[p.yp_plane] = md;
-            o[2 * p.yp_plane] = l;
-          }
+          p.y[row + j] = v;
         }
       }
     }
@@ -1538,7 +1127,7 @@ int halo_bfx_plan(long long M, int tiles_m, int Cin, int Cout, int& nb) {
 }
 
 struct BfxKnobs {
-  int tile = 0, splitk = -1, dma = 1, pl_nst = 4, ring = 0;
+  int tile = 0, splitk = -1, dma = 1;
   BfxKnobs() {
     if (const char* e = getenv("BGS_BFX_TILE")) tile = atoi(e);
     if (const char* e = getenv("BGS_BFX_SPLITK")) splitk = atoi(e);
@@ -1552,13 +1141,12 @@ int g_last_tile = 0, g_last_splits = 0, g_last_dma = 0;
 int g_ablate = 0;          // -DBGS_ABLATE builds only (tools/ablate.py): component-ablation timing
 
 // tile (MB*10 + NB), K depth per barrier and split-K factor for a layer
-void bfx_plan(long long M, int Cout, int KC, int& tile, int& bk, int& want, bool split_in = false) {
+void bfx_plan(long long M, int Cout, int KC, int& tile, int& bk, int& want) {
   const BfxKnobs& knobs = bfx_knobs();
   // measured on the cfg[1] shapes (profiles/r2a_bfx_sweep.txt): the 64x64 tile wins or ties on
   // every conv layer (these K steps are short: 6 MFMAs per wave per barrier, the grid matters more
   // than the tile); 128x128 only for the very deep reductions (fc1: K = 12544, 0.183 vs 0.253 ms)
   tile = (KC >= 512 && Cout >= 256) ? 22 : 11;
-  if (split_in) tile = 11;
   if (knobs.tile == 22 || knobs.tile == 21 || knobs.tile == 12 || knobs.tile == 11) tile = knobs.tile;
   bk = 16;
   const int bm = tile / 10 * 64, bn = tile % 10 * 64;
@@ -1589,8 +1177,7 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   const BfxKnobs& knobs = bfx_knobs();
   const long long M = p.M;
   int tile, bk, want;
-  bfx_plan(M, p.Cout, q.KC, tile, bk, want, q.xp != nullptr);
-  if (q.xp) tile = 11;
+  bfx_plan(M, p.Cout, q.KC, tile, bk, want);
   const int bm = tile / 10 * 64, bn = tile % 10 * 64;
   int splits = 1;
   p.partial = nullptr;
@@ -1617,30 +1204,7 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
     else { if (up == 2) BFX_L(MB_, NB_, 3, 2); else BFX_L(MB_, NB_, 3, 1); }             \
   } while (0)
   g_last_dma = 0;
-  if (q.xp) {                                   // split-form input: the 64 x 64 ring kernel only
-    if (tile != 11 || q.ns != 3 || up != 1) return BGS_ERR_UNSUPPORTED;
-    g_last_dma = 2;
-    const bool p1x1 = p.R == 1 && p.S == 1 && p.pad == 0;
-    if (knobs.pl_nst == 3) {
-      if (p1x1) hipLaunchKernelGGL((conv_igemm_bfx_pl_kernel<true, 3>), grid, dim3(kThreads), 0, st, q);
-      else hipLaunchKernelGGL((conv_igemm_bfx_pl_kernel<false, 3>), grid, dim3(kThreads), 0, st, q);
-    } else {
-      if (p1x1) hipLaunchKernelGGL((conv_igemm_bfx_pl_kernel<true, 4>), grid, dim3(kThreads), 0, st, q);
-      else hipLaunchKernelGGL((conv_igemm_bfx_pl_kernel<false, 4>), grid, dim3(kThreads), 0, st, q);
-    }
-  } else if (knobs.ring && q.ns == 3 && up == 1 && tile != 11) {
-    g_last_dma = 3;
-    const bool p1x1 = p.R == 1 && p.S == 1 && p.pad == 0;
-#define BFX_R(MB_, NB_)                                                                                       \
-  do {                                                                                                        \
-    if (p1x1) hipLaunchKernelGGL((conv_igemm_bfx_ring_kernel<MB_, NB_, true>), grid, dim3(kThreads), 0, st, q); \
-    else hipLaunchKernelGGL((conv_igemm_bfx_ring_kernel<MB_, NB_, false>), grid, dim3(kThreads), 0, st, q);     \
-  } while (0)
-    if (tile == 22) BFX_R(2, 2);
-    else if (tile == 21) BFX_R(2, 1);
-    else BFX_R(1, 2);
-#undef BFX_R
-  } else if (tile == 22) BFX_T(2, 2);
+  if (tile == 22) BFX_T(2, 2);
   else if (tile == 21) BFX_T(2, 1);
   else if (tile == 12) BFX_T(1, 2);
   else if (knobs.dma && q.ns == 3) {
@@ -1701,13 +1265,11 @@ extern "C" void bgs_conv_bfx_tuning(int tile, int splitk) {
   BfxKnobs& k = bfx_knobs();
   k.tile = tile & 0xff;               // bit 8 set: the register-staged 64x64 kernel instead of the
   k.dma = (tile & 0x100) ? 0 : 1;     // LDS-DMA ring (A/B runs and tests of both)
-  k.pl_nst = (tile & 0x400) ? 3 : 4;  // bit 10: 3-stage ring (4 workgroups / CU) of the split-form kernel
-  k.ring = (tile & 0x1000) ? 1 : 0;   // bit 12: the DMA-ring kernel for the 128 x 128 / 128 x 64 / 64 x 128 tiles
   k.splitk = splitk;
 }
 
 extern "C" int bgs_conv_bfx_last_launch(int* tile, int* splits) {
-  if (tile) *tile = g_last_tile | (g_last_dma == 1 ? 0x200 : 0) | (g_last_dma == 2 ? 0x800 : 0) | (g_last_dma == 3 ? 0x1000 : 0);   // bit 9: the LDS-DMA kernel ran; bit 11: the split-form-input kernel
+  if (tile) *tile = g_last_tile | (g_last_dma ? 0x200 : 0);   // bit 9: the LDS-DMA kernel ran
   if (splits) *splits = g_last_splits;
   return BGS_OK;
 }
@@ -1744,65 +1306,6 @@ extern "C" int bgs_conv2d_nhwc_f32_bfx_ws(const float* x, const void* wsplit, co
   p.res_mode = residual_mode;
   q.ws = reinterpret_cast<const __bf16*>(wsplit);
   q.KC = bfx_kc(p.K);
-  return launch_conv_bfx(q, 1, (hipStream_t)stream, workspace, workspace_bytes);
-}
-
-extern "C" int bgs_conv_bfx_split_act(const float* x, void* planes, long long rows, int C,
-                                      bgs_stream_t stream) {
-  if (!x || !planes || rows <= 0 || C <= 0) return BGS_ERR_INVALID_ARG;
-  if (C % 4 != 0) return BGS_ERR_UNSUPPORTED;
-  if ((uintptr_t)x % 16 != 0 || (uintptr_t)planes % 16 != 0) return BGS_ERR_INVALID_ARG;
-  const size_t quads = (size_t)rows * C / 4;
-  size_t g = (quads + 255) / 256;
-  if (g > 16384) g = 16384;
-  hipLaunchKernelGGL(bfx_split_act_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x,
-                     reinterpret_cast<unsigned short*>(planes), quads, (size_t)rows * C);
-  BGS_RETURN_LAUNCH_STATUS();
-}
-
-extern "C" size_t bgs_conv_bfx_ex_workspace_bytes(long long M, int Cout, int K, int split_in) {
-  if (M <= 0 || Cout <= 0 || K <= 0) return 0;
-  int tile, bk, want;
-  bfx_plan(M, Cout, bfx_kc(K), tile, bk, want, split_in != 0);
-  return want > 1 ? (size_t)want * (size_t)M * Cout * sizeof(float) : 0;
-}
-
-extern "C" int bgs_conv2d_nhwc_bfx_ex(const float* x, const void* xplanes, const void* wsplit,
-                                      const float* bias, const float* residual, float* y,
-                                      void* yplanes, int N, int H, int W, int Cin, int Cout, int R,
-                                      int S, int stride, int pad, int relu, int residual_mode,
-                                      void* workspace, size_t workspace_bytes, bgs_stream_t stream) {
-  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
-      pad < 0)
-    return BGS_ERR_INVALID_ARG;
-  if ((!x && !xplanes) || !wsplit || (!y && !yplanes)) return BGS_ERR_INVALID_ARG;
-  if (xplanes ? Cin % 16 != 0 : Cin % 4 != 0) return BGS_ERR_UNSUPPORTED;
-  if (((uintptr_t)x | (uintptr_t)xplanes | (uintptr_t)wsplit | (uintptr_t)yplanes) % 16 != 0)
-    return BGS_ERR_INVALID_ARG;
-  if (residual_mode < 0 || residual_mode > 2 || (residual_mode != 0 && !residual))
-    return BGS_ERR_INVALID_ARG;
-  BfxArgs q;
-  q.ns = 3;
-  ConvArgs& p = q.c;
-  p.x = x; p.w = nullptr; p.bias = bias; p.res = residual; p.mask = nullptr; p.y = y;
-  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S;
-  p.stride = stride; p.pad = pad;
-  p.Ho = (H + 2 * pad - R) / stride + 1;
-  p.Wo = (W + 2 * pad - S) / stride + 1;
-  if (p.Ho <= 0 || p.Wo <= 0) return BGS_ERR_INVALID_ARG;
-  if (residual_mode == 2 && ((p.Ho & 1) || (p.Wo & 1))) return BGS_ERR_INVALID_ARG;
-  const long long M = (long long)N * p.Ho * p.Wo;
-  if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
-  p.M = (int)M;
-  p.K = R * S * Cin;
-  p.relu = relu;
-  p.res_mode = residual_mode;
-  p.yp = reinterpret_cast<unsigned short*>(yplanes);
-  p.yp_plane = M * Cout;
-  q.ws = reinterpret_cast<const __bf16*>(wsplit);
-  q.KC = bfx_kc(p.K);
-  q.xp = reinterpret_cast<const __bf16*>(xplanes);
-  q.xp_plane = (long long)N * H * W * Cin;
   return launch_conv_bfx(q, 1, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
@@ -1857,7 +1360,9 @@ extern "C" void bgs_conv3x3_halo_bfx_tuning(int splits, int variant) {
   g_ablate = (variant >> 8) & 0xff;          // timing-only ablation modes (-DBGS_ABLATE builds)
   variant &= 0xff;
   g_halo_force_splits = splits;
-  g_halo_variant = variant == 1 ? 1 : (variant == 2 ? 2 : 4);   /* 0 = the default */   // 1 = first version (2 workgroups / CU), 2 = taps unrolled + 3 / CU (register-staged), 4 = DMA operands (default)
+  // 1 = first version (2 workgroups / CU), 2 = taps unrolled + 3 workgroups / CU (register-staged
+  // filter slices), 4 (and 0 = the default) = filter slices by LDS-DMA
+  g_halo_variant = variant == 1 ? 1 : (variant == 2 ? 2 : 4);
 }
 
 extern "C" int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits) {
@@ -1866,28 +1371,21 @@ extern "C" int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits) {
   return BGS_OK;
 }
 
-namespace {
-int halo_bfx_launch(const float* x, const void* xplanes, const void* wsplit, const float* bias,
-                    float* y, void* yplanes, int N, int H, int W, int Cin, int Cout, int relu,
-                    int planes, void* workspace, size_t workspace_bytes, bgs_stream_t stream) {
+// 3x3 / stride 1 / pad 1, Cin % 16 == 0; wsplit = bgs_conv_bfx_split_weights of [Cout][3][3][Cin].
+extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias,
+                                             float* y, int N, int H, int W, int Cin, int Cout,
+                                             int relu, int planes, void* workspace,
+                                             size_t workspace_bytes, bgs_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BGS_ERR_INVALID_ARG;
-  if ((!x && !xplanes) || !wsplit || (!y && !yplanes)) return BGS_ERR_INVALID_ARG;
+  if (!x || !wsplit || !y) return BGS_ERR_INVALID_ARG;
   if (planes != 1 && planes != 3) return BGS_ERR_INVALID_ARG;
-  if ((xplanes || yplanes) && planes != 3) return BGS_ERR_UNSUPPORTED;
   if (Cin % 16 != 0) return BGS_ERR_UNSUPPORTED;
-  if (((uintptr_t)x | (uintptr_t)xplanes | (uintptr_t)wsplit | (uintptr_t)yplanes) % 16 != 0)
-    return BGS_ERR_UNSUPPORTED;
+  if ((uintptr_t)x % 16 != 0 || (uintptr_t)wsplit % 16 != 0) return BGS_ERR_UNSUPPORTED;
   const long long M = (long long)N * H * W;
-  if (M > 0x7fffffffLL || M * Cin > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
   HaloBfxArgs q;
   q.ns = planes;
-  q.zero = zero_page_device();
-  if (!q.zero) return BGS_ERR_LAUNCH;
-  q.xp = reinterpret_cast<const __bf16*>(xplanes);
-  q.xp_plane = M * Cin;
   ConvArgs& p = q.c;
-  p.yp = reinterpret_cast<unsigned short*>(yplanes);
-  p.yp_plane = M * Cout;
   p.x = x; p.w = nullptr; p.bias = bias; p.res = nullptr; p.mask = nullptr; p.y = y;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = 3; p.S = 3; p.stride = 1; p.pad = 1;
   p.Ho = H; p.Wo = W; p.M = (int)M; p.K = 9 * Cin; p.relu = relu; p.res_mode = 0;
@@ -1914,16 +1412,13 @@ int halo_bfx_launch(const float* x, const void* xplanes, const void* wsplit, con
   g_halo_last_nb = nb;
   g_halo_last_splits = splits;
   dim3 grid((unsigned)(8 * p.chunk), 1u, (unsigned)splits);
-  const bool v4 = q.ns == 3 && (g_halo_variant == 4 || q.xp || p.yp || !p.y);
-  g_halo_last_variant = v4 ? 4 : g_halo_variant;
+  const bool v4 = q.ns == 3 && g_halo_variant == 4;
+  g_halo_last_variant = v4 ? 4 : (g_halo_variant == 1 && q.ns == 3 ? 1 : 2);
   if (v4) {
-    if (nb == 1) {
-      if (q.xp) hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
-      else hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, false>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
-    } else {
-      if (q.xp) hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
-      else hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, false>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
-    }
+    q.zero = zero_page_device();
+    if (!q.zero) return BGS_ERR_LAUNCH;
+    if (nb == 1) hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    else hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
   } else if (g_halo_variant == 1 && q.ns == 3) {
     if (nb == 1)
       hipLaunchKernelGGL(conv3x3_halo_bfx_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
@@ -1952,24 +1447,4 @@ int halo_bfx_launch(const float* x, const void* xplanes, const void* wsplit, con
     return bgs_internal_conv_splitk_epilogue(p, splits, (hipStream_t)stream);
   }
   BGS_RETURN_LAUNCH_STATUS();
-}
-}  // namespace
-
-// 3x3 / stride 1 / pad 1, Cin % 16 == 0; wsplit = bgs_conv_bfx_split_weights of [Cout][3][3][Cin].
-extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias,
-                                             float* y, int N, int H, int W, int Cin, int Cout,
-                                             int relu, int planes, void* workspace,
-                                             size_t workspace_bytes, bgs_stream_t stream) {
-  if (!x || !y) return BGS_ERR_INVALID_ARG;
-  return halo_bfx_launch(x, nullptr, wsplit, bias, y, nullptr, N, H, W, Cin, Cout, relu, planes,
-                         workspace, workspace_bytes, stream);
-}
-
-// The same layer with split-form activations on either side (see bgs_conv2d_nhwc_bfx_ex).
-extern "C" int bgs_conv3x3_halo_nhwc_bfx_ex(const float* x, const void* xplanes, const void* wsplit,
-                                            const float* bias, float* y, void* yplanes, int N, int H,
-                                            int W, int Cin, int Cout, int relu, void* workspace,
-                                            size_t workspace_bytes, bgs_stream_t stream) {
-  return halo_bfx_launch(xplanes ? nullptr : x, xplanes, wsplit, bias, y, yplanes, N, H, W, Cin, Cout,
-                         relu, 3, workspace, workspace_bytes, stream);
 }

@@ -232,14 +232,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs p, i
     }
     if (p.relu) v = fmaxf(v, 0.f);
     if (p.mask) v = p.mask[e] > 0.f ? v : 0.f;
-    if (p.y) p.y[e] = v;
-    if (p.yp) {
-      unsigned short h, md, l;
-      split3_scalar(v, h, md, l);
-      p.yp[e] = h;
-      p.yp[p.yp_plane + e] = md;
-      p.yp[2 * p.yp_plane + e] = l;
-    }
+    p.y[e] = v;
   }
 }
 
@@ -288,16 +281,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue4_kernel(ConvArgs p, 
 #pragma unroll
       for (int t = 0; t < 4; ++t) v[t] = mk[t] > 0.f ? v[t] : 0.f;
     }
-    if (p.y) *reinterpret_cast<f32x4*>(p.y + e) = v;
-    if (p.yp) {                        // split-form output: three 8-byte stores (4 bf16 each)
-      unsigned short h[4], md[4], l[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) split3_scalar(v[t], h[t], md[t], l[t]);
-      typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-      *reinterpret_cast<u16x4*>(p.yp + e) = u16x4{h[0], h[1], h[2], h[3]};
-      *reinterpret_cast<u16x4*>(p.yp + p.yp_plane + e) = u16x4{md[0], md[1], md[2], md[3]};
-      *reinterpret_cast<u16x4*>(p.yp + 2 * p.yp_plane + e) = u16x4{l[0], l[1], l[2], l[3]};
-    }
+    *reinterpret_cast<f32x4*>(p.y + e) = v;
   }
 }
 
@@ -397,7 +381,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_nhwc_kernel(const float*
 int bgs_internal_conv_splitk_epilogue(ConvArgs& p, int splits, hipStream_t st) {
   const size_t total = (size_t)p.M * p.Cout;
   auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
-  if (p.Cout % 4 == 0 && al16(p.partial) && al16(p.y) && (!p.yp || (((uintptr_t)p.yp & 7) == 0 && p.yp_plane % 4 == 0)) && al16(p.bias) && al16(p.res) &&
+  if (p.Cout % 4 == 0 && al16(p.partial) && al16(p.y) && al16(p.bias) && al16(p.res) &&
       al16(p.mask)) {
     size_t g = (total / 4 + 255) / 256;
     if (g > 8192) g = 8192;

@@ -418,72 +418,6 @@ def _use_halo_kernel(M, Cout):
     return M >= 100000 and Cout % 128 == 0
 
 
-def split_act(x):
-    """fp32 ``[..., C]`` -> split-form planes ``[3, ..., C]`` bf16 (hi / mid / lo, exact: the three
-    planes sum to ``x``): the operand format of the bf16x6 kernels.  Conv epilogues produce it
-    directly (``conv2d_nhwc(..., want_planes=True)``); this standalone kernel is for tensors no conv
-    produced (RoI features, test inputs)."""
-    _require_cuda(x)
-    lib = capi.load()
-    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 4 == 0
-    out = torch.empty((3,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)
-    rc = lib.bgs_conv_bfx_split_act(capi.ptr(x), capi.ptr(out), x.numel() // x.shape[-1],
-                                    x.shape[-1], capi.current_stream(x.device))
-    capi.check('bgs_conv_bfx_split_act', rc)
-    return out
-
-
-def conv2d_nhwc_split(x, x_planes, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None,
-                      residual_mode=0, want_f32=True, want_planes=False):
-    """bf16x6 convolution with split-form activations on either side: ``x_planes`` (``[3,N,H,W,Cin]``
-    bf16, from ``split_act`` or a producing conv's ``want_planes``) replaces the fp32 input when
-    given (Cin % 16 == 0; the K loop then carries no operand splitting), ``want_planes`` makes the
-    epilogue write the split form of the result.  Bit-identical to ``conv2d_nhwc`` on the same
-    values.  -> (y fp32 or None, y_planes or None)."""
-    _require_cuda(x, x_planes, w_krsc, bias, residual)
-    lib = capi.load()
-    assert _CONV_MATH[0] == 'bf16x6'
-    src = x if x is not None else x_planes[0]
-    N, H, W, Cin = src.shape
-    Cout, R, S, Cin2 = w_krsc.shape
-    assert Cin == Cin2 and (want_f32 or want_planes)
-    if x_planes is not None:
-        assert x_planes.dtype == torch.bfloat16 and x_planes.is_contiguous()
-        assert tuple(x_planes.shape) == (3, N, H, W, Cin) and Cin % 16 == 0
-    Ho = (H + 2 * pad - R) // stride + 1
-    Wo = (W + 2 * pad - S) // stride + 1
-    if residual is not None and residual_mode == 0:
-        residual_mode = 1
-    if residual is not None:
-        exp = (N, Ho, Wo, Cout) if residual_mode == 1 else (N, Ho // 2, Wo // 2, Cout)
-        assert tuple(residual.shape) == exp and residual.is_contiguous(), (residual.shape, exp)
-    dev = w_krsc.device
-    y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=dev) if want_f32 else None
-    yp = torch.empty((3, N, Ho, Wo, Cout), dtype=torch.bfloat16, device=dev) if want_planes else None
-    wsplit = bfx_split_weights(w_krsc.view(Cout, R * S * Cin))
-    if (R == 3 and S == 3 and stride == 1 and pad == 1 and residual is None and Cin % 16 == 0
-            and _use_halo_bfx(N * Ho * Wo, Cout)):
-        wsb = lib.bgs_conv3x3_halo_bfx_workspace_bytes(N, H, W, Cin, Cout)
-        ws = _workspace(wsb, dev) if wsb else None
-        rc = lib.bgs_conv3x3_halo_nhwc_bfx_ex(capi.ptr(x) if x_planes is None else None,
-                                              capi.ptr(x_planes), capi.ptr(wsplit), capi.ptr(bias),
-                                              capi.ptr(y), capi.ptr(yp), N, H, W, Cin, Cout,
-                                              int(bool(relu)), capi.ptr(ws), wsb,
-                                              capi.current_stream(dev))
-        capi.check('bgs_conv3x3_halo_nhwc_bfx_ex', rc)
-        return y, yp
-    wsb = lib.bgs_conv_bfx_ex_workspace_bytes(N * Ho * Wo, Cout, R * S * Cin,
-                                              int(x_planes is not None))
-    ws = _workspace(wsb, dev) if wsb else None
-    rc = lib.bgs_conv2d_nhwc_bfx_ex(capi.ptr(x) if x_planes is None else None, capi.ptr(x_planes),
-                                    capi.ptr(wsplit), capi.ptr(bias), capi.ptr(residual),
-                                    capi.ptr(y), capi.ptr(yp), N, H, W, Cin, Cout, R, S, stride,
-                                    pad, int(bool(relu)), residual_mode, capi.ptr(ws), wsb,
-                                    capi.current_stream(dev))
-    capi.check('bgs_conv2d_nhwc_bfx_ex', rc)
-    return y, yp
-
-
 def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None,
                 residual_mode=0, out=None):
     """``y = act(conv(x, w) + bias + residual)``; x ``[N,H,W,Cin]``, w ``[Cout,R,S,Cin]``.

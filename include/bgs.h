@@ -255,6 +255,8 @@ int bgs_conv3x3_halo_nhwc_f32(const float* x, const float* w, const float* bias,
  * workspace: bgs_conv_bfx_workspace_bytes(M, Cout, K) / bgs_conv3x3_halo_bfx_workspace_bytes(...)
  * bytes of split-K scratch (0 / NULL is always legal).
  * bgs_conv_bfx_tuning / bgs_conv3x3_halo_bfx_tuning: process-wide tuning and test hooks
+ * (halo variant: 0 = default = 4: filter slices by LDS-DMA; 2: register-staged slices; 1: first
+ * version; bgs_conv3x3_halo_bfx_last_launch reports the variant in bits 8.. of *nb).
  * (tile 0 = auto | 11 | 12 | 21 | 22 as MB*10+NB blocks of 64; splitk -1 = auto | 1..16);
  * *_last_launch report what the last launch used (tests assert the instantiation they meant
  * to cover).
@@ -272,26 +274,6 @@ int bgs_conv2d_dgrad_nhwc_f32_bfx_ws(const float* dy, const void* wt_split, cons
                                      int Cout, int R, int S, int stride, int pad,
                                      int residual_mode, int planes, void* workspace,
                                      size_t workspace_bytes, bgs_stream_t stream);
-/* Split-form activations: [3][N][H][W][C] bf16 = the exact hi / mid / lo split of an fp32 NHWC
- * tensor (the three planes sum to it), i.e. the operand format the bf16x6 kernels feed to the
- * matrix cores.  bgs_conv2d_nhwc_bfx_ex is bgs_conv2d_nhwc_f32_bfx_ws (planes = 3) with
- *   - an optional split-form INPUT `xplanes` (then x may be NULL; Cin % 16 == 0): both operands
- *     stream global -> LDS by DMA and the K loop carries no operand splitting;
- *   - an optional split-form OUTPUT `yplanes` written by the epilogue beside (or instead of, y ==
- *     NULL) the fp32 result — what the next layer consumes.
- * Results are bit-identical to the fp32-input entry point.  bgs_conv_bfx_split_act produces the
- * split form of a tensor no conv epilogue wrote (C % 4 == 0). */
-int bgs_conv_bfx_split_act(const float* x, void* planes, long long rows, int C, bgs_stream_t stream);
-size_t bgs_conv_bfx_ex_workspace_bytes(long long M, int Cout, int K, int split_in);
-int bgs_conv2d_nhwc_bfx_ex(const float* x, const void* xplanes, const void* wsplit,
-                           const float* bias, const float* residual, float* y, void* yplanes, int N,
-                           int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                           int relu, int residual_mode, void* workspace, size_t workspace_bytes,
-                           bgs_stream_t stream);
-int bgs_conv3x3_halo_nhwc_bfx_ex(const float* x, const void* xplanes, const void* wsplit,
-                                 const float* bias, float* y, void* yplanes, int N, int H, int W,
-                                 int Cin, int Cout, int relu, void* workspace,
-                                 size_t workspace_bytes, bgs_stream_t stream);
 size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias, float* y,
                                   int N, int H, int W, int Cin, int Cout, int relu, int planes,

@@ -483,6 +483,36 @@ def test_roi_align_autograd_accumulates_into_feature_grads():
         assert np.abs(ft[i].grad.cpu().numpy() - exp).max() <= 1e-4 * max(1.0, np.abs(exp).max())
 
 
+@pytest.mark.parametrize('shape', [(1, 8, 16, 16, 128, False, -1), (2, 13, 21, 64, 256, True, -1),
+                                   (1, 25, 42, 256, 200, True, 1), (2, 50, 84, 32, 64, False, 1),
+                                   (1, 3, 5, 48, 15, True, 3), (1, 19, 37, 128, 64, True, 4),
+                                   (2, 40, 56, 64, 128, True, 2)])
+def test_halo_bfx_variants_bit_identical(monkeypatch, shape):
+    """The bf16x6 halo kernel's default variant (4: filter slices by LDS-DMA, both Cout tile
+    widths, dummy DMA pieces, channel-chunk split-K) == variant 2 (register-staged slices) bit for
+    bit: same operand values, same MFMA order — only the way the slices reach LDS differs."""
+    N, H, W, Cin, Cout, relu, hs = shape
+    rs = np.random.RandomState(H * 11 + Cout)
+    x = (rs.standard_normal((N, H, W, Cin)) * np.exp(rs.standard_normal((N, H, W, Cin)))).astype(np.float32)
+    w = (rs.standard_normal((Cout, 3, 3, Cin)) / (9 * Cin) ** 0.5).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32)
+    prev = BF.set_conv_math('bf16x6')
+    monkeypatch.setenv('BGS_CONV_HALO', '1')
+    try:
+        BF.conv_bfx_tuning(halo_splits=hs, halo_variant=2)
+        y2 = BF.conv2d_nhwc(dev(x), dev(w), dev(b), pad=1, relu=relu)
+        u2 = BF.conv_bfx_last_launch()
+        BF.conv_bfx_tuning(halo_splits=hs)
+        y4 = BF.conv2d_nhwc(dev(x), dev(w), dev(b), pad=1, relu=relu)
+        u4 = BF.conv_bfx_last_launch()
+        assert (u2['halo_variant'], u4['halo_variant']) == (2, 4)
+        assert u2['halo_nb'] == u4['halo_nb'] and u2['halo_splits'] == u4['halo_splits']
+        assert torch.equal(y2, y4)
+    finally:
+        BF.conv_bfx_tuning()
+        BF.set_conv_math(prev)
+
+
 @pytest.mark.parametrize('conv_math', MATHS, indirect=True)
 @pytest.mark.parametrize('shape', [(1, 8, 16, 16, 128, False), (2, 13, 21, 64, 256, True),
                                    (1, 25, 42, 256, 200, True), (2, 50, 84, 32, 64, False),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Halo kernel variant 4 (DMA operands, optional split-form input / output) against variant 2 on the
+"""Halo kernel variant 4 (filter slices by LDS-DMA) against variant 2 (register-staged slices) on the
 GPU box: bit-identity and per-layer timing of cfg[1]'s 3x3 stride-1 layers.
 
     python tools/conv_halo4_check.py [--out gpurun_out/halo4.txt]
@@ -42,23 +42,11 @@ def identity():
         BF.conv_bfx_tuning(halo_splits=hs, halo_variant=4)
         y4 = BF.conv2d_nhwc(x, w, b, stride=1, pad=1, relu=relu)
         u4 = BF.conv_bfx_last_launch()
-        xp = BF.split_act(x)
-        y5, yp5 = BF.conv2d_nhwc_split(None, xp, w, b, stride=1, pad=1, relu=relu, want_f32=True,
-                                       want_planes=True)
-        u5 = BF.conv_bfx_last_launch()
-        _, yp6 = BF.conv2d_nhwc_split(x, None, w, b, stride=1, pad=1, relu=relu, want_f32=False,
-                                      want_planes=True)
         BF.conv_bfx_tuning()
-        s3 = (yp5[0].float() + yp5[1].float()) + yp5[2].float()
-        good = (torch.equal(y2, y4) and torch.equal(y2, y5) and torch.equal(s3, y2) and
-                torch.equal(yp5.view(torch.int16), yp6.view(torch.int16)) and u2['halo_variant'] == 2 and
-                u4['halo_variant'] == 4 and u5['halo_variant'] == 4)
-        if Cout % 4 == 0:
-            good = good and torch.equal(BF.split_act(y2).view(torch.int16), yp5.view(torch.int16))
+        good = torch.equal(y2, y4) and u2['halo_variant'] == 2 and u4['halo_variant'] == 4
         ok &= bool(good)
-        say('halo N%d %dx%d %d->%d nb %d splits %d | v4 == v2 %s  split-in == v2 %s  planes sum == y %s  %s'
-            % (N, H, W, Cin, Cout, u4['halo_nb'], u4['halo_splits'], torch.equal(y2, y4), torch.equal(y2, y5),
-               torch.equal(s3, y2), 'ok' if good else 'BAD'))
+        say('halo N%d %dx%d %d->%d nb %d splits %d | v4 == v2 %s  %s'
+            % (N, H, W, Cin, Cout, u4['halo_nb'], u4['halo_splits'], torch.equal(y2, y4), 'ok' if good else 'BAD'))
     os.environ.pop('BGS_CONV_HALO', None)
     say('IDENTICAL' if ok else 'MISMATCH')
     return ok
@@ -67,9 +55,8 @@ def identity():
 def sweep():
     dev = 'cuda:0'
     os.environ['BGS_CONV_HALO'] = '1'
-    tot = dict(v2=0.0, v4=0.0, v4p=0.0, v4pp=0.0)
-    say('%-12s %8s %6s %5s | v2 (register-staged) | v4 DMA filter | v4 + split-form in | + split-form out only | + both outputs'
-        % ('layer', 'M', 'K', 'Cout'))
+    tot = dict(v2=0.0, v4=0.0)
+    say('%-12s %8s %6s %5s | v2 (register-staged) | v4 DMA filter' % ('layer', 'M', 'K', 'Cout'))
     for name, H, W, Cin, Cout, R, stride, cnt in LAYERS:
         if not (R == 3 and stride == 1 and Cin % 16 == 0 and NIMG * H * W >= 2000):
             continue
@@ -78,26 +65,17 @@ def sweep():
         b = torch.randn(Cout, device=dev)
         M = NIMG * H * W
         gf = 2.0 * M * 9 * Cin * Cout / 1e9
-        xp = BF.split_act(x)
         BF.conv_bfx_tuning(halo_variant=2)
         t2 = bench(lambda: BF.conv2d_nhwc(x, w, b, pad=1, relu=True), iters=20)
         BF.conv_bfx_tuning(halo_variant=4)
         t4 = bench(lambda: BF.conv2d_nhwc(x, w, b, pad=1, relu=True), iters=20)
-        t4p = bench(lambda: BF.conv2d_nhwc_split(None, xp, w, b, pad=1, relu=True), iters=20)
-        t4pp = bench(lambda: BF.conv2d_nhwc_split(None, xp, w, b, pad=1, relu=True, want_f32=False,
-                                                  want_planes=True), iters=20)
-        t4pb = bench(lambda: BF.conv2d_nhwc_split(None, xp, w, b, pad=1, relu=True, want_f32=True,
-                                                  want_planes=True), iters=20)
         BF.conv_bfx_tuning()
         tot['v2'] += t2 * cnt
         tot['v4'] += t4 * cnt
-        tot['v4p'] += t4p * cnt
-        tot['v4pp'] += t4pp * cnt
-        say('%-12s %8d %6d %5d | %6.3f (%5.1f) | %6.3f (%5.1f) | %6.3f (%5.1f) | %6.3f | %6.3f   x%d'
-            % (name, M, 9 * Cin, Cout, t2, gf / t2, t4, gf / t4, t4p, gf / t4p, t4pp, t4pb, cnt))
+        say('%-12s %8d %6d %5d | %6.3f (%5.1f) | %6.3f (%5.1f)   x%d'
+            % (name, M, 9 * Cin, Cout, t2, gf / t2, t4, gf / t4, cnt))
     os.environ.pop('BGS_CONV_HALO', None)
-    say('3x3 stride-1 layers per forward: v2 %.3f ms | v4 %.3f | v4 split-form in %.3f | split-form in and out %.3f'
-        % (tot['v2'], tot['v4'], tot['v4p'], tot['v4pp']))
+    say('3x3 stride-1 layers per forward: v2 %.3f ms | v4 %.3f' % (tot['v2'], tot['v4']))
 
 
 def main():
