@@ -359,8 +359,9 @@ def conv_roofline(dev, math, iters=20):
     flops = 2.0 * 2 * 200 * 336 * 256 * 256 * 9
     tf = flops / (ms * 1e-3) / 1e12
     if math == 'bf16x6':
-        kname = 'conv3x3_halo_bfx3_kernel<2>'
-        kdesc = kname + ' (halo-resident A operand split to 3 bf16 planes in LDS, v_mfma_f32_32x32x16_bf16 x 6)'
+        kname = 'conv3x3_halo_bfx4_kernel<2>'
+        kdesc = kname + (' (halo-resident A operand split to 3 bf16 planes in LDS, filter slices by '
+                         'LDS-DMA, v_mfma_f32_32x32x16_bf16 x 6)')
         peak, passes = 2500.0 / 6.0, 6
     elif math == 'bf16':
         kname = 'conv3x3_halo_bfx3_kernel<2,1>'

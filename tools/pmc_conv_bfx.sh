@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o conv -- python $R/tools/conv_p2_once.py > $OUT/$name.log 2> $OUT/$name.err
+  timeout -k 3 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o conv -- python $R/tools/conv_p2_once.py > $OUT/$name.log 2> $OUT/$name.err
   echo "$name rc=$?"
 }
 run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
