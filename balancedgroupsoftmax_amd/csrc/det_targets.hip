@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void rpn_loss_kernel(LevelTable Lv, ImgTable T
 }
 
 // loss_cls[l], loss_bbox[l] = weight * sum over images / (sum_n max(n_pos,1) + max(n_neg,1))
-__global__ __launch_bounds__(256) void rpn_loss_finalize_kernel(const float* __restrict__ partial,
+__global__ __launch_bounds__(1024) void rpn_loss_finalize_kernel(const float* __restrict__ partial,
                                                                 int N, int blocks, int L,
                                                                 float w_cls, float w_bbox,
                                                                 float* __restrict__ loss_cls,
@@ -259,9 +259,10 @@ __global__ __launch_bounds__(256) void rpn_loss_finalize_kernel(const float* __r
                                                                 float* __restrict__ num_total_out) {
   __shared__ float tot[kMaxImgs][kMaxLevels][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // one wave per (image, level, quantity) triple, fixed summation order
+  // one wave per (image, level, quantity) triple, fixed summation order; 16 waves (the 40 triples
+  // of cfg[1] on 4 waves were 33 us of dependent strided loads)
   const int jobs = N * L * 4;
-  for (int j = wave; j < jobs; j += 4) {
+  for (int j = wave; j < jobs; j += 16) {
     const int q = j & 3, l = (j >> 2) % L, n = (j >> 2) / L;
     float s = 0.f;
     for (int b = lane; b < blocks; b += 64) s += partial[(((size_t)n * blocks + b) * L + l) * 4 + q];
@@ -541,7 +542,7 @@ extern "C" int bgs_rpn_loss(const float* const* host_level_outs, const int* host
   hipLaunchKernelGGL(rpn_loss_kernel, dim3(blocks, N), dim3(256), 0, st, Lv, T, anchors, assigned,
                      pos_mask, neg_mask, gt, cod, beta, pos_weight <= 0.f ? 1.f : pos_weight, A,
                      (float*)workspace);
-  hipLaunchKernelGGL(rpn_loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace,
+  hipLaunchKernelGGL(rpn_loss_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)workspace,
                      N, blocks, L, loss_weight_cls, loss_weight_bbox, loss_cls_out, loss_bbox_out,
                      num_total_out);
   BGS_RETURN_LAUNCH_STATUS();
