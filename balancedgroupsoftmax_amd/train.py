@@ -81,10 +81,21 @@ def build_optimizer(params, cfg):
     return getattr(torch.optim, typ)(params, **cfg)
 
 
+_EXCHANGE_AT_ONE = [False]
+
+
+def exchange_at_world_size_one(flag):
+    """Test hook: run the gradient all-reduce even in a 1-rank process group, so that the collective's
+    place in the step (and in a captured hipGraph of it) can be exercised on a single GPU."""
+    prev = _EXCHANGE_AT_ONE[0]
+    _EXCHANGE_AT_ONE[0] = bool(flag)
+    return prev
+
+
 def allreduce_grads(params, world_size, async_op=False):
     """Flatten -> one SUM all-reduce -> /world_size -> unflatten (dist_utils.py:9-41)."""
     grads = [p.grad for p in params if p.requires_grad and p.grad is not None]
-    if world_size == 1 or not grads:
+    if (world_size == 1 and not _EXCHANGE_AT_ONE[0]) or not grads:
         return None
     flat = torch.cat([g.reshape(-1) for g in grads])
     work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)

@@ -59,6 +59,9 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true',
                     help='skip the per-kernel roofline timings (used by the extras sub-runs)')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches, not hipGraph replay')
+    ap.add_argument('--dist-graph', action='store_true',
+                    help='N > 1 over RCCL: capture the WHOLE step, gradient all-reduce included, into '
+                         'one hipGraph per rank (default for N > 1: eager launches)')
     ap.add_argument('--conv-math', default=None, choices=['bf16x6', 'f32', 'bf16'],
                     help="conv / linear arithmetic: 'bf16x6' (default; bf16 MFMA on exactly split fp32 "
                          "operands, fp32-faithful), 'f32' (v_mfma_f32_32x32x2_f32) or 'bf16' (operands "
@@ -91,6 +94,18 @@ def init_dist(args):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('BGS_DIST_BACKEND', 'nccl')                   # nccl = RCCL on ROCm
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif os.environ.get('BGS_BENCH_SELF_GROUP'):
+        # test hook: a 1-rank RCCL group whose all-reduce really runs, so that the N > 1 launch
+        # policies (eager exchange, --dist-graph) can be exercised on a single-GPU box
+        import socket
+        import torch.distributed as dist
+        from balancedgroupsoftmax_amd import train as BT
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group(backend='nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0,
+                                world_size=1)
+        BT.exchange_at_world_size_one(True)
     return rank, local, world
 
 
@@ -596,6 +611,7 @@ def run_graph_child(args):
            '--no-cpu-baseline', '--no-roofline', '--conv-math', args.conv_math]
     cmd += (['--mask'] if args.mask else []) + (['--cascade'] if args.cascade else [])
     cmd += ['--htc'] if args.htc else []
+    cmd += ['--dist-graph'] if args.dist_graph else []
     try:
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')]
@@ -656,12 +672,20 @@ def main_detector(args, rank, local, world, dev):
     # optimizer, so multi-GPU runs launch eagerly — the step is GPU-bound and eager launches
     # cost nothing measurable (10.99 vs 10.96 ms).
     graph = None
-    if world == 1 and not args.no_graph:
+    self_group = bool(os.environ.get('BGS_BENCH_SELF_GROUP'))
+    rccl = world > 1 and __import__('torch.distributed').distributed.get_backend() == 'nccl'
+    if not args.no_graph and ((world == 1 and not self_group) or
+                              (args.dist_graph and (rccl or self_group))):
+        # --dist-graph: the RCCL all-reduce is captured with the rest of the step (the communicator
+        # is set up by the eager warm-up iterations inside try_graph)
         graph = try_graph(step)
     fn = graph.replay if graph is not None else step
     dt = timed_loop(fn, args.steps, args.warmup, world)
     ms_per_step = dt * 1e3 / args.steps
     imgs_per_s = args.imgs * world * args.steps / dt
+    ms_eager = None
+    if graph is not None:       # every rank: the same step launched eagerly, for the graph-vs-eager figure
+        ms_eager = round(timed_loop(step, 5, 2, world) * 1e3 / 5, 3)
     cfg_name = 'gs_faster_rcnn_r50_fpn_1x_lvis_with0_bg8 (cfg[1])'
     if args.htc:
         cfg_name = 'gs_htc_x101_64x4d_fpn_20e_16gpu_lvis (cfg[4], HTC)'
@@ -699,6 +723,7 @@ def main_detector(args, rank, local, world, dev):
                        'trainable_params': int(sum(p.numel() for p in step.params)),
                        'imgs_per_gpu': args.imgs, 'rois_per_img': 512,
                        'launch': ('hipGraph replay of the whole step (forward+losses+backward+'
+                                  + ('RCCL all-reduce+' if (world > 1 or self_group) else '') +
                                   'clip+SGD)') if graph else 'eager launches',
                        'parallelism': 'dp%d (one process per GPU; flat fp32 all-reduce of the '
                                       '%d trainable grads over RCCL)'
@@ -709,9 +734,10 @@ def main_detector(args, rank, local, world, dev):
             'img_per_s_per_gpu': round(imgs_per_s / world, 3),
             'last_losses': lv,
         }
-        if graph is not None and world == 1:
-            dte = timed_loop(step, 5, 2, 1)
-            out['ms_per_step_eager'] = round(dte * 1e3 / 5, 3)
+        if ms_eager is not None:
+            out['ms_per_step_eager'] = ms_eager
+        if self_group:
+            out['config']['collective_backend'] = 'nccl (1-rank group: test hook BGS_BENCH_SELF_GROUP)'
         if fallback_note:
             out['config']['launch_note'] = fallback_note
         finish_line(out, args, dev, world)
