@@ -110,6 +110,85 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& p, const f32x16 
   }
 }
 
+// The same epilogue through an LDS transpose: the accumulators are written to a row-major tile
+// in LDS (the operand buffers are free after the K loop) and every thread then handles four
+// consecutive channels of a row — ONE 16-byte residual load and ONE 16-byte store where the C/D
+// layout path issues four 4-byte ones.  The short-K layers (K = 64: four K steps) spend most of their
+// vector-memory instructions in the epilogue; the CU's vector-memory path is what bounds these
+// kernels (profiles/r2z_pmc_ring_kernel.md).  Identical arithmetic, identical results.
+// Preconditions (checked by conv_epilogue_vec_ok): Cout % 4 == 0, 16-byte aligned y / residual /
+// mask / bias / slab, residual mode 0 / 1 / 2.  `scratch`: (64 MB) x (64 NB + 4) floats of LDS that
+// no wave reads any more (callers barrier first).
+__device__ __forceinline__ bool conv_epilogue_vec_ok(const ConvArgs& p) {
+  const uintptr_t a = (uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.mask | (uintptr_t)p.bias |
+                      (uintptr_t)p.partial;
+  return (p.Cout & 3) == 0 && (a & 15) == 0 && p.res_mode != 3;
+}
+
+template <int MB, int NB>
+__device__ __forceinline__ void conv_store_tile_lds(const ConvArgs& p, const f32x16 (&acc)[MB][NB],
+                                                    int m0, int n0, int wm, int wn, int lane,
+                                                    float* scratch) {
+  constexpr int BM = 64 * MB, BN = 64 * NB, LD = BN + 4;
+  constexpr int TPR = BN / 4, RPP = kThreads / TPR;     // threads per row, rows per pass
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = wm * 32 * MB + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        scratch[i * LD + wn * 32 * NB + b * 32 + (lane & 31)] = acc[a][b][r];
+      }
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const int c4 = (tid % TPR) * 4, r0 = tid / TPR;
+  const int j = n0 + c4;
+  if (j >= p.Cout) return;
+  if (p.partial) {
+    float* part = p.partial + (size_t)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+    for (int ps = 0; ps < BM / RPP; ++ps) {
+      const int i = r0 + ps * RPP;
+      const int m = m0 + i;
+      if (m >= p.M) break;
+      *reinterpret_cast<f32x4*>(part + (size_t)m * p.Cout + j) =
+          *reinterpret_cast<const f32x4*>(scratch + i * LD + c4);
+    }
+    return;
+  }
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + j);
+  const int hw = p.Ho * p.Wo;
+#pragma unroll
+  for (int ps = 0; ps < BM / RPP; ++ps) {
+    const int i = r0 + ps * RPP;
+    const int m = m0 + i;
+    if (m >= p.M) break;
+    f32x4 v = *reinterpret_cast<const f32x4*>(scratch + i * LD + c4);
+    v += bias;
+    if (p.res_mode == 1) {
+      v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + j);
+    } else if (p.res_mode == 2) {
+      const int n = m / hw;
+      const int rem = m - n * hw;
+      const int ho = rem / p.Wo, wo = rem - (rem / p.Wo) * p.Wo;
+      v += *reinterpret_cast<const f32x4*>(
+          p.res + (((size_t)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + j);
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+    }
+    if (p.mask) {
+      const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m * p.Cout + j);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = mk[t] > 0.f ? v[t] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + j) = v;
+  }
+}
+
 }  // namespace bgs_conv
 
 // split-K reduction + epilogue launch (defined in conv_igemm.hip)

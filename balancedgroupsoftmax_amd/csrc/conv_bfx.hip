@@ -254,6 +254,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_bfx_kernel(BfxArgs q) 
     if (more) store_tile(buf ^ 1, ra0, rb0);
     __syncthreads();
   }
+  // (the loop's last __syncthreads() is behind every wave's last fragment read)
+  if (sizeof(lds) >= (size_t)BM * (BN + 4) * 4 && conv_epilogue_vec_ok(p)) {
+    conv_store_tile_lds<MB, NB>(p, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(lds));
+    return;
+  }
   conv_store_tile<MB, NB>(p, acc, m0, n0, wm, wn, lane);
 }
 
@@ -458,6 +463,11 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the (zero-page) tail DMAs
+  if (conv_epilogue_vec_ok(p)) {                       // workgroup-uniform
+    __syncthreads();                                   // every wave is done with the ring
+    conv_store_tile_lds<1, 1>(p, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(lds));
+    return;
+  }
   conv_store_tile<1, 1>(p, acc, m0, n0, wm, wn, lane);
 }
 
@@ -514,6 +524,57 @@ struct HaloBfxArgs {
   int chunks_per_split;  // channel chunks per gridDim.z slice
   const unsigned* zero = nullptr;   // device zero page (DMA source of out-of-range rows, variant 4)
 };
+
+// The halo kernels' epilogue through an LDS transpose (see conv_store_tile_lds): the 8 x 16 pixel x
+// (64 NB) channel tile leaves in two halves of 64 pixels (the accumulators of the waves wm = 0, then
+// wm = 1), every thread storing four consecutive channels of a pixel with one 16-byte access.
+// `scratch`: 64 x (64 NB + 4) floats of LDS no wave reads any more.
+template <int NB>
+__device__ __forceinline__ void halo_store_tile_lds(const ConvArgs& p, const f32x16 (&acc)[2][NB], int n,
+                                                    int ty, int tx, int n0, int wm, int wn, int lane,
+                                                    float* scratch) {
+  constexpr int BN = 64 * NB, LD = BN + 4, TPR = BN / 4, RPP = kThreads / TPR;
+  const int tid = threadIdx.x;
+  const int c4 = (tid % TPR) * 4, r0 = tid / TPR;
+  const int j = n0 + c4;
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && !p.partial && j < p.Cout) bias = *reinterpret_cast<const f32x4*>(p.bias + j);
+  float* dst = p.partial ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : p.y;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (wm == h) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            scratch[i * LD + wn * 32 * NB + b * 32 + (lane & 31)] = acc[a][b][r];
+          }
+    }
+    __syncthreads();
+    if (j < p.Cout) {
+#pragma unroll
+      for (int ps = 0; ps < 64 / RPP; ++ps) {
+        const int i = r0 + ps * RPP;
+        const int m = h * 64 + i;
+        const int ho = ty * TH + (m >> 4), wo = tx * TW + (m & 15);
+        if (ho >= p.H || wo >= p.W) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + i * LD + c4);
+        if (!p.partial) {
+          v += bias;
+          if (p.relu) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+          }
+        }
+        *reinterpret_cast<f32x4*>(dst + (((size_t)n * p.H + ho) * p.W + wo) * p.Cout + j) = v;
+      }
+    }
+    if (h == 0) __syncthreads();
+  }
+}
 
 template <int NB>
 __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx_kernel(HaloBfxArgs q) {
@@ -886,6 +947,11 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxA
     nxt = t;
   }
 
+  // (the loop's last barrier is behind every wave's last fragment read)
+  if (sizeof(lds) >= (size_t)64 * (BN + 4) * 4 && conv_epilogue_vec_ok(p)) {
+    halo_store_tile_lds<NB>(p, acc, n, ty, tx, n0, wm, wn, lane, reinterpret_cast<float*>(lds));
+    return;
+  }
   // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   float* part = p.partial ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : nullptr;
 #pragma unroll
@@ -1077,6 +1143,11 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
     nxt = t;
   }
 
+  // (the loop's last barrier is behind every wave's last fragment read)
+  if (sizeof(lds) >= (size_t)64 * (BN + 4) * 4 && conv_epilogue_vec_ok(p)) {
+    halo_store_tile_lds<NB>(p, acc, n, ty, tx, n0, wm, wn, lane, reinterpret_cast<float*>(lds));
+    return;
+  }
   // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   float* part = p.partial ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : nullptr;
 #pragma unroll
