@@ -1223,9 +1223,15 @@ void bfx_plan(long long M, int Cout, int KC, int& tile, int& bk, int& want) {
   const int bm = tile / 10 * 64, bn = tile % 10 * 64;
   const long long wgs = ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn);
   const int nk = KC;
+  // re-measured with the LDS-transpose epilogue (profiles/r3l_splitk_resweep.txt): a slice must be
+  // worth its slab traffic and the second launch — grids below 400 workgroups aim at ~1100, 400-600
+  // split three ways only for K >= 2048, 600-1500 two ways only for K >= 1152; K < 512 never splits
+  // (l2.c1 0.049 -> 0.042, l4.c3 0.056 -> 0.042, the RPN heads 0.018 -> 0.013 ms)
   want = 1;
-  if (wgs < 600) want = (int)((1100 + wgs - 1) / wgs);
-  else if (wgs < 1500) want = 2;
+  if (wgs < 400) want = (int)((1100 + wgs - 1) / wgs);
+  else if (wgs < 600) want = nk >= 128 ? 3 : 1;
+  else if (wgs < 1500) want = nk >= 72 ? 2 : 1;
+  if (nk < 32) want = 1;
   if (want > nk / 8) want = nk / 8;
   if (want > 8) want = 8;
   if (knobs.splitk >= 1 && knobs.splitk <= 16) want = knobs.splitk < nk ? knobs.splitk : nk;
