@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_bfx_kernel(BfxArgs q) 
 //     fetched from the zero page, so every wave issues the same number of DMAs per step and the
 //     vmcnt arithmetic stays uniform.
 constexpr int DMA_NST = 4;
-constexpr int DMA_A_BYTES = 64 * 64, DMA_B_PLANE = 64 * 32, DMA_STAGE = DMA_A_BYTES + 3 * DMA_B_PLANE;
+constexpr int DMA_A_BYTES = 64 * 64, DMA_B_PLANE = 64 * 32;
 
 __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -293,10 +293,15 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_
 //     kernel argument (SGPRs) instead of a GOT load per step.
 // ABL (only instantiated != 0 under -DBGS_ABLATE, tools/ablate.py): timing-only variants that drop
 // one component of the loop — 1: MFMAs, 2: DMA issue, 4: fragment ds_reads, 8: the A split.
-template <int UP, bool P1X1, int ABL = 0>
+// NS = 3: fp32-faithful (six products).  NS = 1: the bf16 mode of cfg[4] — hi planes only: the B
+// stage is one plane (two DMA pieces), A is rounded to bf16 when a wave reads its fragment, one MFMA
+// per step.
+template <int UP, bool P1X1, int ABL = 0, int NS = 3>
 __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs q) {
   const ConvArgs& p = q.c;
   const unsigned* __restrict__ zero_page = q.zero;
+  constexpr int DMA_STAGE = DMA_A_BYTES + NS * DMA_B_PLANE;
+  constexpr int NBP = 2 * NS;                          // B pieces of 1 KB per stage
   __shared__ __attribute__((aligned(1024))) unsigned char lds[DMA_NST * DMA_STAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -335,10 +340,11 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
     const int plane = j >> 1;
     const int row = (j & 1) * 32 + (lane >> 1);
     const int half = (lane & 1) ^ ((row >> 3) & 1);
-    b_ok[i] = j < 6 && (n0 + row < p.Cout);
+    b_ok[i] = j < NBP && (n0 + row < p.Cout);
     b_src[i] = q.ws + ((size_t)plane * q.KC * p.Cout + (b_ok[i] ? n0 + row : 0)) * 16 + half * 8;
   }
-  const bool two_b = wave < 2;                          // wave-uniform
+  const bool one_b = wave < NBP;                        // wave-uniform: this wave carries B piece `wave`
+  const bool two_b = wave + 4 < NBP;                    // .. and B piece `wave + 4`
 
   const int nk_all = q.KC;
   const int kt_begin = p.partial ? blockIdx.z * p.kt_per_split : 0;
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
       }
     }
     if (!(ABL & 2)) glds16(asrc, st + wave * 1024);
-    if (!(ABL & 2)) {
+    if (one_b && !(ABL & 2)) {
       const __bf16* bsrc = (live && b_ok[0]) ? b_ptr0 : reinterpret_cast<const __bf16*>(zero_page);
       glds16(bsrc, st + DMA_A_BYTES + wave * 1024);
     }
@@ -424,9 +430,10 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
   f32x4 a0, a1;
   bf16x8 fb[3];
   for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed once at most two younger stages (2 or 3 DMAs each) are still in flight
+    // stage kt has landed once at most two younger stages (1, 2 or 3 DMAs each) are still in flight
     if (two_b) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (one_b) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // every wave's part of stage kt is visible; every wave is
     asm volatile("" ::: "memory");         // done reading stage kt-1 (= the slot refilled next)
     issue();
@@ -435,11 +442,14 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
       a0 = *reinterpret_cast<const f32x4*>(st + a_off0);
       a1 = *reinterpret_cast<const f32x4*>(st + a_off1);
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int s = 0; s < NS; ++s)
         fb[s] = *reinterpret_cast<const bf16x8*>(st + b_off + s * DMA_B_PLANE);
     }
     bf16x8 fa[3];
-    if (ABL & 8) {
+    if (NS == 1) {
+      fa[0] = __builtin_bit_cast(bf16x8, u32x4{pack_bf16(a0[0], a0[1]), pack_bf16(a0[2], a0[3]),
+                                               pack_bf16(a1[0], a1[1]), pack_bf16(a1[2], a1[3])});
+    } else if (ABL & 8) {
       fa[0] = __builtin_bit_cast(bf16x8, a0);
       fa[1] = __builtin_bit_cast(bf16x8, a1);
       fa[2] = __builtin_bit_cast(bf16x8, a0 + a1);
@@ -453,10 +463,10 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
     }
     if (ABL & 1) {
 #pragma unroll
-      for (int s = 0; s < 3; ++s) asm volatile("" ::"v"(fa[s]), "v"(fb[s]));
+      for (int s = 0; s < NS; ++s) asm volatile("" ::"v"(fa[s]), "v"(fb[s]));
     } else {
 #pragma unroll
-      for (int t = 2; t >= 0; --t)
+      for (int t = NS - 1; t >= 0; --t)
 #pragma unroll
         for (int i = 0; i <= t; ++i)
           acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[t - i], acc[0][0], 0, 0, 0);
@@ -991,15 +1001,17 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxA
 // load, split, ds_write_b64): a DMA of a pre-split ("split-form") patch written by the producing
 // layer's epilogue was built and measured too — no faster, 1.5x the activation bytes: removed.
 // LDS: 24 KB filter double buffer + 1 KB scratch (dummy pieces) + 25.3 KB patch.
-template <int NB>
+// (NS = 1: the bf16 mode — hi planes only, one MFMA per product.)
+template <int NB, int NS = 3>
 __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxArgs q) {
   const ConvArgs& p = q.c;
   constexpr int BN = 64 * NB;
-  constexpr int B_PLANE = BN * 32, B_BUF = 3 * B_PLANE;
+  constexpr int B_PLANE = BN * 32, B_BUF = NS * B_PLANE;
   constexpr int SCR = 2 * B_BUF;                         // 1 KB scratch: target of dummy pieces
   constexpr int A_OFF = SCR + 1024;
   constexpr int A_PLANE = PROWS * HLDR;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[A_OFF + 3 * A_PLANE];
+  constexpr int OPER_BYTES = A_OFF + NS * A_PLANE, EPI_BYTES = 64 * (BN + 4) * 4;   // operands | epilogue tile
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[OPER_BYTES > EPI_BYTES ? OPER_BYTES : EPI_BYTES];
   const unsigned* __restrict__ zero_page = q.zero;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1030,12 +1042,15 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
     const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page);
     if (NB == 2) {
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int s = 0; s < NS; ++s)
         glds16(b_okd ? b_lane + s * b_plane + koff : zp, lds + buf_off + s * B_PLANE + wave * 1024);
-    } else {
+    } else if (NS == 3) {
       const int s0 = wave >> 1;                                  // piece w: plane w / 2, half w % 2
       glds16(b_okd ? b_lane + s0 * b_plane + koff : zp, lds + buf_off + s0 * B_PLANE + (wave & 1) * 1024);
       if (wave < 2) glds16(b_okd ? b_lane + 2 * b_plane + koff : zp, lds + buf_off + 2 * B_PLANE + wave * 1024);
+      else glds16(zp, lds + SCR);
+    } else {                                                     // one plane: two pieces
+      if (wave < 2) glds16(b_okd ? b_lane + koff : zp, lds + buf_off + wave * 1024);
       else glds16(zp, lds + SCR);
     }
   };
@@ -1070,8 +1085,8 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
       split3(ra[i], h, m, l);
       unsigned char* d = lds + A_OFF + (a_dst[i] >> 1);
       *reinterpret_cast<u32x2*>(d) = h;
-      *reinterpret_cast<u32x2*>(d + A_PLANE) = m;
-      *reinterpret_cast<u32x2*>(d + 2 * A_PLANE) = l;
+      if (NS >= 2) *reinterpret_cast<u32x2*>(d + A_PLANE) = m;
+      if (NS >= 3) *reinterpret_cast<u32x2*>(d + 2 * A_PLANE) = l;
     }
   };
 
@@ -1110,9 +1125,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
       else if (!last_chunk) issue_b(chunk + 1, 0, wr);
       if (tap == 0 && !last_chunk) load_a(chunk + 1);             // next patch: held in registers
       const int tap_off = ((tap / 3) * PW + (tap % 3)) * HLDR;    // compile-time constant
-      bf16x8 fa[3][2], fb[3][NB];
+      bf16x8 fa[NS][2], fb[NS][NB];
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
+      for (int s = 0; s < NS; ++s) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
           fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a] + tap_off + s * A_PLANE);
@@ -1121,7 +1136,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
           fb[s][b] = *reinterpret_cast<const bf16x8*>(lds + rd + b_frag + s * B_PLANE + b * 32 * 32);
       }
 #pragma unroll
-      for (int tt = 2; tt >= 0; --tt)
+      for (int tt = NS - 1; tt >= 0; --tt)
 #pragma unroll
         for (int i = 0; i <= tt; ++i)
 #pragma unroll
@@ -1284,7 +1299,13 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   if (tile == 22) BFX_T(2, 2);
   else if (tile == 21) BFX_T(2, 1);
   else if (tile == 12) BFX_T(1, 2);
-  else if (knobs.dma && q.ns == 3) {
+  else if (knobs.dma && q.ns == 1) {
+    g_last_dma = 1;
+    const bool p1x1 = up == 1 && p.R == 1 && p.S == 1 && p.pad == 0;
+    if (up == 2) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<2, false, 0, 1>), grid, dim3(kThreads), 0, st, q);
+    else if (p1x1) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, true, 0, 1>), grid, dim3(kThreads), 0, st, q);
+    else hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, false, 0, 1>), grid, dim3(kThreads), 0, st, q);
+  } else if (knobs.dma && q.ns == 3) {
     g_last_dma = 1;
     const bool p1x1 = up == 1 && p.R == 1 && p.S == 1 && p.pad == 0;
     if (up == 2) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<2, false>), grid, dim3(kThreads), 0, st, q);
@@ -1489,13 +1510,19 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit,
   g_halo_last_nb = nb;
   g_halo_last_splits = splits;
   dim3 grid((unsigned)(8 * p.chunk), 1u, (unsigned)splits);
-  const bool v4 = q.ns == 3 && g_halo_variant == 4;
+  const bool v4 = g_halo_variant == 4;
   g_halo_last_variant = v4 ? 4 : (g_halo_variant == 1 && q.ns == 3 ? 1 : 2);
   if (v4) {
     q.zero = zero_page_device();
     if (!q.zero) return BGS_ERR_LAUNCH;
-    if (nb == 1) hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
-    else hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    if (q.ns == 1) {
+      if (nb == 1) hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+      else hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    } else if (nb == 1) {
+      hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, 3>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    } else {
+      hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, 3>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    }
   } else if (g_halo_variant == 1 && q.ns == 3) {
     if (nb == 1)
       hipLaunchKernelGGL(conv3x3_halo_bfx_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);

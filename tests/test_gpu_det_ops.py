@@ -691,3 +691,62 @@ def test_topk_sorted_edge_cases(case):
     if case == 'tiny':
         v1, i1 = BF.topk_sorted([r.contiguous()], [1], 4)
         assert torch.equal(v1[:, 0, 0], r.max(dim=1).values) and torch.equal(i1[:, 0, 0], r.argmax(dim=1))
+
+
+@pytest.mark.parametrize('case', [
+    # N, H, W, Cin, Cout, R, stride, pad, relu, res, halo
+    (2, 20, 24, 64, 96, 1, 1, 0, True, False, False),
+    (1, 17, 23, 128, 200, 1, 1, 0, True, True, False),
+    (2, 31, 45, 32, 64, 3, 2, 1, True, False, False),
+    (1, 64, 96, 4, 64, 7, 2, 3, True, False, False),
+    (2, 13, 21, 512, 128, 1, 1, 0, False, True, False),
+    (2, 13, 21, 64, 256, 3, 1, 1, True, False, True),
+    (1, 19, 37, 128, 64, 3, 1, 1, False, False, True),
+    (2, 50, 84, 32, 64, 3, 1, 1, True, False, True),
+], ids=lambda c: 'x'.join(str(v) for v in c[:8]))
+def test_conv_bf16_mode_is_bf16_rounded_operands_with_fp32_accumulate(monkeypatch, case):
+    """conv_math = 'bf16' (cfg[4], planes = 1 of the bf16x6 kernels: the 64x64 DMA ring, the halo
+    kernel, split-K): the result is the convolution of the bf16-ROUNDED operands accumulated in fp32 —
+    checked against an fp64 convolution of the rounded operands (so the only difference left is fp32
+    summation order), and the ring kernel == the register-staged kernel bit for bit."""
+    N, H, W, Cin, Cout, R, stride, pad, relu, with_res, halo = case
+    rs = np.random.RandomState(H * 13 + Cout)
+    x = rs.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rs.standard_normal((Cout, R, R, Cin)) / (R * R * Cin) ** 0.5).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32)
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    res = rs.standard_normal((N, Ho, Wo, Cout)).astype(np.float32) if with_res else None
+    xr = torch.from_numpy(x).bfloat16().double()
+    wr = torch.from_numpy(w).bfloat16().double()
+    exp = F.conv2d(xr.permute(0, 3, 1, 2), wr.permute(0, 3, 1, 2), torch.from_numpy(b).double(),
+                   stride=stride, padding=pad).permute(0, 2, 3, 1)
+    if res is not None:
+        exp = exp + torch.from_numpy(res).double()
+    if relu:
+        exp = exp.clamp(min=0)
+    scale = float(F.conv2d(xr.abs().permute(0, 3, 1, 2), wr.abs().permute(0, 3, 1, 2), stride=stride,
+                           padding=pad).max())
+    prev = BF.set_conv_math('bf16')
+    monkeypatch.setenv('BGS_CONV_HALO', '1' if halo else '0')
+    try:
+        for sk in (1, 2):
+            if halo:
+                BF.conv_bfx_tuning(halo_splits=sk)
+            else:
+                BF.conv_bfx_tuning(11, sk)
+            got = BF.conv2d_nhwc(dev(x), dev(w), dev(b), stride=stride, pad=pad, relu=relu,
+                                 residual=None if res is None else dev(res))
+            used = BF.conv_bfx_last_launch()
+            assert float((got.cpu().double() - exp).abs().max()) <= 2e-6 * scale, used
+            if halo:
+                assert used['halo_variant'] == 4 and used['halo_splits'] == sk
+                BF.conv_bfx_tuning(halo_splits=sk, halo_variant=2)
+            else:
+                assert used['tile'] == 11 | 0x200 and used['splits'] == sk, used     # the DMA ring ran
+                BF.conv_bfx_tuning(11 | 0x100, sk)
+            old = BF.conv2d_nhwc(dev(x), dev(w), dev(b), stride=stride, pad=pad, relu=relu,
+                                 residual=None if res is None else dev(res))
+            assert torch.equal(old, got)
+    finally:
+        BF.conv_bfx_tuning()
+        BF.set_conv_math(prev)
