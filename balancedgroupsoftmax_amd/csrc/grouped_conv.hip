@@ -93,22 +93,27 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_mfma_kernel(
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int a = 0; a < 4; ++a)
-            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][u], bv[u], acc[a], 0, 0, 0);
+            // the TRANSPOSED product (filter rows x pixel columns: the two operand registers
+            // swapped): in the D layout — column = lane & 15, rows 4 (lane >> 4) + t — a lane then
+            // owns four CONSECUTIVE output channels of one pixel: one 16-byte store per sub-tile
+            // instead of four 4-byte ones (the vector-memory instruction count bounds these kernels)
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[u], av[a][u], acc[a], 0, 0, 0);
       }
     }
   }
-  // D layout of the 16x16 MFMA: column = lane & 15 (output channel), rows 4*(lane>>4) + t
-  const float bsv = bias ? bias[n_out] : 0.f;
+  const int c_out = ct * 16 + 4 * j;               // first of this lane's four output channels
+  f32x4 bsv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bsv = *reinterpret_cast<const f32x4*>(bias + c_out);
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
+    const int m = m0 + a * 16 + i;
+    if (m >= M) continue;
+    f32x4 v = acc[a] + bsv;
+    if (relu) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int m = m0 + a * 16 + 4 * j + t;
-      if (m >= M) continue;
-      float v = acc[a][t] + bsv;
-      if (relu) v = fmaxf(v, 0.f);
-      y[(size_t)m * C + n_out] = v;
+      for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
     }
+    *reinterpret_cast<f32x4*>(y + (size_t)m * C + c_out) = v;
   }
 }
 
@@ -122,7 +127,7 @@ extern "C" int bgs_grouped_conv3x3_nhwc_f32(const float* x, const float* w, cons
   if (!x || !w || !y) return BGS_ERR_INVALID_ARG;
   if (C % groups != 0 || C % 16 != 0) return BGS_ERR_UNSUPPORTED;
   const int cg = C / groups;
-  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) % 16 != 0) return BGS_ERR_INVALID_ARG;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias) % 16 != 0) return BGS_ERR_INVALID_ARG;
   const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   const long long M = (long long)N * Ho * Wo;
   if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
