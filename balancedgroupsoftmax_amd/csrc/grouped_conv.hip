@@ -16,6 +16,8 @@
 // stride-2 blocks); the weight gradient is grouped_wgrad3x3_kernel below.
 // (First version: one thread per pixel x 4 channels on the vector ALUs re-read its 4 x 9 x cg
 //  weights per pixel: 0.69 ms per layer3 conv = 3.6 TFLOP/s, 47 % of the X101 step.)
+#include <stdlib.h>
+
 #include "bgs_common.h"
 
 namespace {
@@ -117,6 +119,148 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_mfma_kernel(
   }
 }
 
+// Stride-1 layers (30 of the 33 grouped convs of an X101 forward, and their data gradients) with an
+// LDS-RESIDENT input patch.  A workgroup owns an 8 x 16 pixel tile x 64 channels (whole groups); the
+// 10 x 18 pixel patch of those 64 channels (45 KB) reaches LDS ONCE by `global_load_lds_dwordx4` —
+// for a grouped conv the 64-channel slab is the ENTIRE reduction of its groups, there is no K loop —
+// and the nine taps read shifted rows (the kernel above re-fetches every tap from L1 / L2: 45
+// global loads per wave; 62 us per layer3 conv against 13 us of HBM traffic).  Wave w computes the
+// 128 pixels x 16 output channels 16 w .. 16 w + 15 of the slab as eight 16-pixel sub-tiles (tile
+// rows); its 9 (x 2 for cg = 32) filter fragments live in registers for the whole kernel.
+//   * LDS layout: pixel P at 256 P bytes; the 16-byte channel quad q sits in slot q ^ (P & 15): the
+//     DMA writes lane-linearly, so the swizzle is applied to the SOURCE quad each lane fetches, and a
+//     fragment read (16 consecutive pixels of a tile row, same quad) hits 16 distinct slots;
+//   * transposed product as above: a lane owns four consecutive output channels of one pixel.
+constexpr int GTH = 8, GTW = 16, GPH = GTH + 2, GPW = GTW + 2, GPIX = GPH * GPW;   // 180 patch pixels
+constexpr int GDMA = (GPIX * 16 + 63) / 64;                                       // 45 DMA pieces
+
+__device__ __forceinline__ void gc_glds16(const void* src, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __attribute__((aligned(16))) unsigned g_gc_zero_page[4];
+
+template <int CG>
+__global__ __launch_bounds__(256, CG == 32 ? 2 : 3) void grouped_conv3x3_lds_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ y, int N, int H, int W, int C, int tiles_y, int tiles_x, int relu) {
+  constexpr int KH = CG >= 16 ? CG / 16 : 1;       // 16-channel K slabs per tap
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[GDMA * 1024];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, j = lane >> 4;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y, n = t / tiles_y;
+  const int c0 = blockIdx.y * 64;                  // first channel of the slab
+  const int h0 = ty * GTH - 1, w0 = tx * GTW - 1;  // input coords of patch (0, 0)
+
+  // ---- patch DMA: piece d (1 KB) = patch pixels 4 d .. 4 d + 3; lane -> (pixel, slot); wave w issues
+  //      pieces w, w + 4, ..
+  const float* xn = x + (size_t)n * H * W * C + c0;
+  for (int d = wave; d < GDMA; d += 4) {
+    const int P = 4 * d + (lane >> 4);
+    const int q = (lane & 15) ^ (P & 15);          // source quad of this slot
+    const int pr = P / GPW, pc = P - pr * GPW;
+    const int hi = h0 + pr, wi = w0 + pc;
+    const bool in = P < GPIX && hi >= 0 && hi < H && wi >= 0 && wi < W;
+    const float* src = in ? xn + ((size_t)hi * W + wi) * C + 4 * q
+                          : reinterpret_cast<const float*>(g_gc_zero_page);
+    gc_glds16(src, lds + d * 1024);
+  }
+
+  // ---- this wave's filter fragments (registers) while the patch is in flight
+  const int ct16 = c0 + wave * 16;                 // first output channel of this wave
+  const int n_out = ct16 + i;                      // B' row of this lane (output channel)
+  const int grp_first = ct16 / CG;
+  const int in0 = (CG >= 16) ? grp_first * CG : ct16;      // first input channel of the K slab(s)
+  bool w_live = true;
+  int w_off = 4 * j;
+  if (CG < 16) {
+    const int g_in = (in0 + 4 * j) / CG, g_out = n_out / CG;
+    w_live = g_in == g_out;
+    w_off = (in0 + 4 * j) - g_in * CG;
+  }
+  f32x4 bv[9][KH];
+  const float* wrow = w + (size_t)n_out * 9 * CG;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) {
+      bv[tap][kh] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (w_live) bv[tap][kh] = *reinterpret_cast<const f32x4*>(wrow + tap * CG + kh * 16 + w_off);
+    }
+  f32x4 acc[GTH];
+#pragma unroll
+  for (int a = 0; a < GTH; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int qbase = (in0 - c0) / 4 + j;            // quad (within the slab) this lane feeds per K slab
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+#pragma unroll
+      for (int a = 0; a < GTH; ++a) {
+        const int P = (a + r) * GPW + i + s2;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+          const int q = qbase + kh * 4;
+          const f32x4 av = *reinterpret_cast<const f32x4*>(lds + P * 256 + ((q ^ (P & 15)) << 4));
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[r * 3 + s2][kh][u], av[u], acc[a], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int c_out = ct16 + 4 * j;
+  f32x4 bsv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bsv = *reinterpret_cast<const f32x4*>(bias + c_out);
+  const int wo = tx * GTW + i;
+#pragma unroll
+  for (int a = 0; a < GTH; ++a) {
+    const int ho = ty * GTH + a;
+    if (ho >= H || wo >= W) continue;
+    f32x4 v = acc[a] + bsv;
+    if (relu) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) v[tt] = fmaxf(v[tt], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(y + (((size_t)n * H + ho) * W + wo) * C + c_out) = v;
+  }
+}
+
+// stride-1 launch (forward, or the data gradient with the per-group transposed filter)
+int launch_grouped_s1(const float* x, const float* w, const float* bias, float* y, int N, int H, int W,
+                      int C, int cg, int relu, hipStream_t st) {
+  const int tiles_y = (H + GTH - 1) / GTH, tiles_x = (W + GTW - 1) / GTW;
+  dim3 grid((unsigned)(N * tiles_y * tiles_x), (unsigned)(C / 64));
+#define BGS_GL_LAUNCH(CG_)                                                                          \
+  hipLaunchKernelGGL((grouped_conv3x3_lds_kernel<CG_>), grid, dim3(256), 0, st, x, w, bias, y, N, H, W, \
+                     C, tiles_y, tiles_x, relu)
+  if (cg == 4) BGS_GL_LAUNCH(4);
+  else if (cg == 8) BGS_GL_LAUNCH(8);
+  else if (cg == 16) BGS_GL_LAUNCH(16);
+  else if (cg == 32) BGS_GL_LAUNCH(32);
+  else return BGS_ERR_UNSUPPORTED;
+#undef BGS_GL_LAUNCH
+  return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
+}
+
+int g_grouped_lds = -1;      // BGS_GROUPED_LDS=0: the direct-load kernel everywhere (A/B, tests)
+bool grouped_lds_enabled() {
+  if (g_grouped_lds < 0) {
+    const char* e = getenv("BGS_GROUPED_LDS");
+    g_grouped_lds = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return g_grouped_lds != 0;
+}
+
 }  // namespace
 
 extern "C" int bgs_grouped_conv3x3_nhwc_f32(const float* x, const float* w, const float* bias,
@@ -133,6 +277,8 @@ extern "C" int bgs_grouped_conv3x3_nhwc_f32(const float* x, const float* w, cons
   if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
   dim3 grid((unsigned)((M + 63) / 64), (unsigned)((C / 16 + 3) / 4));
   hipStream_t st = (hipStream_t)stream;
+  if (stride == 1 && C % 64 == 0 && grouped_lds_enabled())
+    return launch_grouped_s1(x, w, bias, y, N, H, W, C, cg, relu, st);
 #define BGS_GC_LAUNCH(CG_)                                                                        \
   hipLaunchKernelGGL((grouped_conv3x3_mfma_kernel<CG_>), grid, dim3(256), 0, st, x, w, bias, y, N, \
                      H, W, C, Ho, Wo, stride, relu, 1)
@@ -227,6 +373,8 @@ extern "C" int bgs_grouped_conv3x3_dgrad_nhwc_f32(const float* dy, const float* 
   dim3 grid((unsigned)((M + 63) / 64), (unsigned)((C / 16 + 3) / 4));
   hipStream_t st = (hipStream_t)stream;
   const float* nobias = nullptr;
+  if (stride == 1 && C % 64 == 0 && grouped_lds_enabled())      // dy and dx have the same size
+    return launch_grouped_s1(dy, wt, nobias, dx, N, H, W, C, cg, 0, st);
   // "input" = dy (Ho x Wo, zero-upsampled when stride 2), "output" = dx (H x W), unit stride, pad 1
 #define BGS_GD_LAUNCH(CG_)                                                                         \
   hipLaunchKernelGGL((grouped_conv3x3_mfma_kernel<CG_>), grid, dim3(256), 0, st, dy, wt, nobias, dx, \

@@ -30,6 +30,26 @@ def test_grouped_conv3x3_vs_torch_cpu(cg, stride):
     assert float((got.permute(0, 3, 1, 2).cpu() - exp).abs().max()) < 1e-4 * float(exp.abs().max())
 
 
+@pytest.mark.parametrize('cg,hw', [(4, (13, 18)), (8, (21, 37)), (16, (8, 16)), (32, (25, 42)), (16, (50, 84))])
+def test_grouped_conv3x3_lds_resident_kernel_vs_torch_cpu(cg, hw):
+    """Stride-1 grouped conv with C % 64 == 0 (every stride-1 conv2 of ResNeXt-101 64x4d): the
+    LDS-resident-patch kernel — ragged tiles on both axes, one exact tile, two images, every
+    channels-per-group instantiation — against torch-CPU ``F.conv2d(groups=...)``."""
+    rs = np.random.RandomState(cg * 7 + hw[0])
+    groups = 16
+    C = cg * groups
+    x = rs.randn(2, hw[0], hw[1], C).astype(np.float32)
+    w = (rs.randn(C, cg, 3, 3) * 0.2).astype(np.float32)
+    b = rs.randn(C).astype(np.float32)
+    exp = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w), torch.from_numpy(b),
+                   padding=1, groups=groups)
+    wk = torch.from_numpy(np.ascontiguousarray(w.transpose(0, 2, 3, 1))).to(DEV)
+    got = BF.grouped_conv3x3_nhwc(torch.from_numpy(x).to(DEV), wk, torch.from_numpy(b).to(DEV), groups,
+                                  stride=1, relu=False)
+    assert tuple(got.shape) == (2, hw[0], hw[1], C)
+    assert float((got.permute(0, 3, 1, 2).cpu() - exp).abs().max()) < 1e-4 * float(exp.abs().max())
+
+
 @pytest.mark.parametrize('cg,stride,hw', [(4, 1, (13, 18)), (8, 2, (13, 18)), (16, 1, (12, 17)),
                                           (32, 2, (14, 20)), (32, 1, (9, 11)), (4, 2, (16, 16))])
 def test_grouped_conv3x3_backward_vs_torch_autograd(cg, stride, hw):
