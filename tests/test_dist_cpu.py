@@ -133,3 +133,41 @@ def test_overlapped_bucketed_exchange_equals_flat_allreduce(tmp_path):
         assert torch.allclose(a, b, atol=1e-7)
     for a, b in zip(ov[0]['w'][:n], fl[0]['w']):
         assert torch.allclose(a, b, atol=1e-6)
+
+
+def _one_rank_worker(rank, world, port):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        fc = torch.nn.Linear(4, 3)
+        params = list(fc.parameters())
+        for p in params:
+            p.grad = torch.full_like(p, 2.0)
+        calls = []
+        real = dist.all_reduce
+
+        def spy(t, *a, **k):
+            calls.append(t.numel())
+            return real(t, *a, **k)
+
+        dist.all_reduce = spy
+        try:
+            assert train.allreduce_grads(params, 1) is None and calls == []       # default: no collective
+            prev = train.exchange_at_world_size_one(True)
+            assert prev is False
+            train.allreduce_grads(params, 1)
+            assert calls == [sum(p.numel() for p in params)]                      # ONE flat all-reduce
+            assert all(torch.equal(p.grad, torch.full_like(p, 2.0)) for p in params)   # sum / 1
+        finally:
+            dist.all_reduce = real
+            train.exchange_at_world_size_one(False)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_at_world_size_one_hook_runs_the_collective():
+    """The test hook behind ``BGS_BENCH_SELF_GROUP`` (bench.py --dist-graph on a single-GPU box): with it
+    the gradient exchange issues its flat all-reduce even in a 1-rank group, without it it does not."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_one_rank_worker, args=(1, port), nprocs=1, join=True)
