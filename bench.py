@@ -388,6 +388,7 @@ def conv_roofline(dev, math, iters=20):
         kdesc = kname + ' (v_mfma_f32_32x32x2_f32)'
         peak, passes = 157.3, 1
     traffic = src = None
+    ent = {}
     try:      # HBM-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs)
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
                                'pmc_traffic.json')) as f:
@@ -403,6 +404,14 @@ def conv_roofline(dev, math, iters=20):
              flops_per_launch=flops,
              layer='FPN output conv P2: N=2, 200x336, 3x3, 256->256 (M=134400, K=2304)',
              timing='hipEvent over %d back-to-back launches' % iters)
+    if ent.get('matrix_pipe_busy'):
+        # committed PMC pass of the same kernel on the same layer (not collected in this run): the
+        # fraction of cycles the matrix pipe was busy, and the clock the chip sustained under it —
+        # `frac` is priced against the 2.4 GHz data-sheet peak
+        r.update(matrix_pipe_busy_pmc=ent['matrix_pipe_busy'],
+                 effective_clock_ghz_pmc=ent['effective_clock_ghz'],
+                 pmc_note='frac x 2.4 / %.1f ~ matrix_pipe_busy_pmc (%s)'
+                          % (ent['effective_clock_ghz'], ent.get('counters', '')))
     if passes > 1:
         r.update(mfma_dtype='bf16', mfma_passes_per_flop=passes,
                  matrix_pipe_tflops=round(tf * passes, 1), peak_bf16_dense=2500.0,
