@@ -279,7 +279,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_bfx_kernel(BfxArgs q) 
 //   * out-of-range operands (borders, K tail, rows >= Cout, steps past the end of the K loop) are
 //     fetched from the zero page, so every wave issues the same number of DMAs per step and the
 //     vmcnt arithmetic stays uniform.
-constexpr int DMA_NST = 4;
 constexpr int DMA_A_BYTES = 64 * 64, DMA_B_PLANE = 64 * 32;
 
 __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
@@ -296,8 +295,13 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_
 // NS = 3: fp32-faithful (six products).  NS = 1: the bf16 mode of cfg[4] — hi planes only: the B
 // stage is one plane (two DMA pieces), A is rounded to bf16 when a wave reads its fragment, one MFMA
 // per step.
-template <int UP, bool P1X1, int ABL = 0, int NS = 3>
-__global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs q) {
+// DMA_NST = 3 (default: 30 KB, FIVE workgroups per CU) | 4 (40 KB, four per CU).  Many layers of
+// cfg[1] have a grid just above a multiple of the 1024 slots four workgroups per CU give (2100,
+// 1050, 2112, 1056, 1232 workgroups: a last round of 2-5 % of the chip that costs a full workgroup
+// duration); with five per CU those grids need one round less, and two stages in flight are enough
+// to cover the L2 latency (188 cycles): -4 % over the igemm layers, never worse.
+template <int UP, bool P1X1, int ABL = 0, int NS = 3, int DMA_NST = 4>
+__global__ __launch_bounds__(kThreads, DMA_NST == 3 ? 5 : 4) void conv_igemm_bfx_dma_kernel(BfxArgs q) {
   const ConvArgs& p = q.c;
   const unsigned* __restrict__ zero_page = q.zero;
   constexpr int DMA_STAGE = DMA_A_BYTES + NS * DMA_B_PLANE;
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
   const __bf16* b_ptr0 = b_src[0] + (size_t)kt_begin * b_step;
   const __bf16* b_ptr1 = b_src[1] + (size_t)kt_begin * b_step;
   auto issue = [&]() {
-    unsigned char* st = lds + (kt_issue & (DMA_NST - 1)) * DMA_STAGE;
+    unsigned char* st = lds + (kt_issue % DMA_NST) * DMA_STAGE;
     const bool live = kt_issue < nk;
     const float* asrc;
     if (P1X1) {
@@ -424,20 +428,25 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_bfx_dma_kernel(BfxArgs
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
 
-  issue();
-  issue();
-  issue();
+#pragma unroll
+  for (int i = 0; i < DMA_NST - 1; ++i) issue();
   f32x4 a0, a1;
   bf16x8 fb[3];
   for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed once at most two younger stages (1, 2 or 3 DMAs each) are still in flight
-    if (two_b) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (one_b) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    // stage kt has landed once at most DMA_NST - 2 younger stages (1, 2 or 3 DMAs each) are still in flight
+    if (DMA_NST == 4) {
+      if (two_b) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (one_b) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      if (two_b) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (one_b) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();          // every wave's part of stage kt is visible; every wave is
     asm volatile("" ::: "memory");         // done reading stage kt-1 (= the slot refilled next)
     issue();
-    const unsigned char* st = lds + (((ABL & 4) ? 0 : kt) & (DMA_NST - 1)) * DMA_STAGE;
+    const unsigned char* st = lds + (((ABL & 4) ? 0 : kt) % DMA_NST) * DMA_STAGE;
     if (!(ABL & 4) || kt == 0) {
       a0 = *reinterpret_cast<const f32x4*>(st + a_off0);
       a1 = *reinterpret_cast<const f32x4*>(st + a_off1);
@@ -1213,7 +1222,7 @@ int halo_bfx_plan(long long M, int tiles_m, int Cin, int Cout, int& nb) {
 }
 
 struct BfxKnobs {
-  int tile = 0, splitk = -1, dma = 1;
+  int tile = 0, splitk = -1, dma = 1, nst = 0;
   BfxKnobs() {
     if (const char* e = getenv("BGS_BFX_TILE")) tile = atoi(e);
     if (const char* e = getenv("BGS_BFX_SPLITK")) splitk = atoi(e);
@@ -1223,7 +1232,18 @@ BfxKnobs& bfx_knobs() {
   static BfxKnobs k;
   return k;
 }
-int g_last_tile = 0, g_last_splits = 0, g_last_dma = 0;
+int g_last_tile = 0, g_last_splits = 0, g_last_dma = 0, g_last_nst = 4;
+
+// ring depth of the 64 x 64 DMA kernel: 3 stages (30 KB: five workgroups per CU) unless the tuning
+// hook asks for the 4-stage ring (40 KB, four per CU).
+int bfx_ring_stages(const BfxKnobs& knobs, long long wgs) {
+  // measured (profiles/r3u_ring_stages_ab.txt): the 3-stage ring wins or ties on every layer of
+  // cfg[1] — most where the grid sits just above a multiple of 1024 (fpn.lat1 0.078 -> 0.068,
+  // l2.c1 0.044 -> 0.040, l4.b0.c1 0.076 -> 0.072), never behind by more than 1 %
+  (void)wgs;
+  return knobs.nst == 4 ? 4 : 3;
+}
+
 int g_ablate = 0;          // -DBGS_ABLATE builds only (tools/ablate.py): component-ablation timing
 
 // tile (MB*10 + NB), K depth per barrier and split-K factor for a layer
@@ -1296,6 +1316,7 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
     else { if (up == 2) BFX_L(MB_, NB_, 3, 2); else BFX_L(MB_, NB_, 3, 1); }             \
   } while (0)
   g_last_dma = 0;
+  g_last_nst = 4;
   if (tile == 22) BFX_T(2, 2);
   else if (tile == 21) BFX_T(2, 1);
   else if (tile == 12) BFX_T(1, 2);
@@ -1305,6 +1326,15 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
     if (up == 2) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<2, false, 0, 1>), grid, dim3(kThreads), 0, st, q);
     else if (p1x1) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, true, 0, 1>), grid, dim3(kThreads), 0, st, q);
     else hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, false, 0, 1>), grid, dim3(kThreads), 0, st, q);
+  } else if (knobs.dma && q.ns == 3 && bfx_ring_stages(knobs, (long long)p.tiles_m * p.tiles_n * splits) == 3) {
+    g_last_dma = 1;
+    g_last_nst = 3;
+    if (up == 2)
+      hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<2, false, 0, 3, 3>), grid, dim3(kThreads), 0, st, q);
+    else if (p.R == 1 && p.S == 1 && p.pad == 0)
+      hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, true, 0, 3, 3>), grid, dim3(kThreads), 0, st, q);
+    else
+      hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, false, 0, 3, 3>), grid, dim3(kThreads), 0, st, q);
   } else if (knobs.dma && q.ns == 3) {
     g_last_dma = 1;
     const bool p1x1 = up == 1 && p.R == 1 && p.S == 1 && p.pad == 0;
@@ -1363,11 +1393,12 @@ extern "C" void bgs_conv_bfx_tuning(int tile, int splitk) {
   BfxKnobs& k = bfx_knobs();
   k.tile = tile & 0xff;               // bit 8 set: the register-staged 64x64 kernel instead of the
   k.dma = (tile & 0x100) ? 0 : 1;     // LDS-DMA ring (A/B runs and tests of both)
+  k.nst = (tile & 0x400) ? 3 : ((tile & 0x800) ? 4 : 0);   // bit 10 / 11: force the 3- / 4-stage ring
   k.splitk = splitk;
 }
 
 extern "C" int bgs_conv_bfx_last_launch(int* tile, int* splits) {
-  if (tile) *tile = g_last_tile | (g_last_dma ? 0x200 : 0);   // bit 9: the LDS-DMA kernel ran
+  if (tile) *tile = g_last_tile | (g_last_dma ? 0x200 : 0) | (g_last_nst == 3 ? 0x400 : 0);   // bit 9: the LDS-DMA kernel ran; bit 10: its 3-stage (five workgroups / CU) instantiation
   if (splits) *splits = g_last_splits;
   return BGS_OK;
 }

@@ -376,8 +376,8 @@ def conv_bfx_last_launch():
     a, c, d, e = (ctypes.c_int() for _ in range(4))
     lib.bgs_conv_bfx_last_launch(ctypes.byref(a), ctypes.byref(c))
     lib.bgs_conv3x3_halo_bfx_last_launch(ctypes.byref(d), ctypes.byref(e))
-    return dict(tile=a.value, splits=c.value, halo_nb=d.value & 0xff, halo_variant=d.value >> 8,
-                halo_splits=e.value)
+    return dict(tile=a.value & ~0x400, ring_stages=3 if a.value & 0x400 else 4, splits=c.value,
+                halo_nb=d.value & 0xff, halo_variant=d.value >> 8, halo_splits=e.value)
 
 
 def conv_tuning(tile=0, bk=0, splitk=0, noswizzle=0):

@@ -91,8 +91,9 @@ def _conv_ref64(x, w, b, stride, pad, relu):
 # forced through the tuning hooks and CONFIRMED through the last-launch queries — the size-based
 # defaults only reach the larger tiles at M >= 100,000.
 F32_INST = [(t, bk, up) for t in (22, 21, 11) for bk in (16, 32) for up in (1, 2)]
-BFX_INST = [(t, up) for t in (22, 21, 12, 11, 11 | 0x100) for up in (1, 2)]
-# 64x64 tile: default = the LDS-DMA ring kernel, 0x100 = register-staged
+BFX_INST = [(t, up) for t in (22, 21, 12, 11, 11 | 0x800, 11 | 0x100) for up in (1, 2)]
+# 64x64 tile: default = the LDS-DMA ring kernel with 3 stages (five workgroups / CU), 0x800 = its 4-stage
+# instantiation, 0x100 = register-staged
 
 
 def _inst_problem(up, seed):
@@ -160,8 +161,10 @@ def test_conv_bfx_every_instantiation(inst):
             used = BF.conv_bfx_last_launch()
             # tile 11 runs the LDS-DMA ring kernel (reported with bit 9), 11 | 0x100 the register-
             # staged one
-            expect = {11: 11 | 0x200, 11 | 0x100: 11}.get(tile, tile)
+            expect = {11: 11 | 0x200, 11 | 0x800: 11 | 0x200, 11 | 0x100: 11}.get(tile, tile)
             assert (used['tile'], used['splits']) == (expect, splitk), used
+            if tile & 0xff == 11 and not tile & 0x100:
+                assert used['ring_stages'] == (4 if tile & 0x800 else 3), used
             assert np.abs(got - exp).max() < 2e-5 * np.abs(exp).max()
     finally:
         os.environ.pop('BGS_CONV_HALO', None)
