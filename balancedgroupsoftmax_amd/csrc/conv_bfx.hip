@@ -301,7 +301,7 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_
 // duration); with five per CU those grids need one round less, and two stages in flight are enough
 // to cover the L2 latency (188 cycles): -4 % over the igemm layers, never worse.
 template <int UP, bool P1X1, int ABL = 0, int NS = 3, int DMA_NST = 4>
-__global__ __launch_bounds__(kThreads, DMA_NST == 3 ? 5 : 4) void conv_igemm_bfx_dma_kernel(BfxArgs q) {
+__global__ __launch_bounds__(kThreads, NS == 1 ? (DMA_NST == 3 ? 8 : 6) : (DMA_NST == 3 ? 5 : 4)) void conv_igemm_bfx_dma_kernel(BfxArgs q) {
   const ConvArgs& p = q.c;
   const unsigned* __restrict__ zero_page = q.zero;
   constexpr int DMA_STAGE = DMA_A_BYTES + NS * DMA_B_PLANE;
@@ -1226,6 +1226,7 @@ struct BfxKnobs {
   BfxKnobs() {
     if (const char* e = getenv("BGS_BFX_TILE")) tile = atoi(e);
     if (const char* e = getenv("BGS_BFX_SPLITK")) splitk = atoi(e);
+    if (const char* e = getenv("BGS_BFX_NST")) nst = atoi(e);      // 3 | 4: ring depth of the 64 x 64 kernel
   }
 };
 BfxKnobs& bfx_knobs() {
@@ -1323,9 +1324,16 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   else if (knobs.dma && q.ns == 1) {
     g_last_dma = 1;
     const bool p1x1 = up == 1 && p.R == 1 && p.S == 1 && p.pad == 0;
-    if (up == 2) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<2, false, 0, 1>), grid, dim3(kThreads), 0, st, q);
-    else if (p1x1) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, true, 0, 1>), grid, dim3(kThreads), 0, st, q);
-    else hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, false, 0, 1>), grid, dim3(kThreads), 0, st, q);
+    if (knobs.nst != 3) {         // default: 4 x 6 KB, six workgroups per CU (cascade X101 bf16: 10.06 vs 10.15 ms)
+      if (up == 2) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<2, false, 0, 1, 4>), grid, dim3(kThreads), 0, st, q);
+      else if (p1x1) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, true, 0, 1, 4>), grid, dim3(kThreads), 0, st, q);
+      else hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, false, 0, 1, 4>), grid, dim3(kThreads), 0, st, q);
+    } else {                      // 3 x 6 KB: eight per CU
+      g_last_nst = 3;
+      if (up == 2) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<2, false, 0, 1, 3>), grid, dim3(kThreads), 0, st, q);
+      else if (p1x1) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, true, 0, 1, 3>), grid, dim3(kThreads), 0, st, q);
+      else hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, false, 0, 1, 3>), grid, dim3(kThreads), 0, st, q);
+    }
   } else if (knobs.dma && q.ns == 3 && bfx_ring_stages(knobs, (long long)p.tiles_m * p.tiles_n * splits) == 3) {
     g_last_dma = 1;
     g_last_nst = 3;
