@@ -359,7 +359,10 @@ def conv_roofline(dev, math, iters=20):
         w = torch.randn(256, 3, 3, 256, device=dev) * 0.02
         b = torch.randn(256, device=dev)
         out = torch.empty(2, 200, 336, 256, device=dev)
-        for _ in range(3):
+        # warm-up: the first ~10 launches after an idle period run 8-10 % slower (clock ramp: 0.81 vs
+        # 0.74 ms on the P2 layer); inside the step the kernel runs warm (rocprofv3 average 0.743 ms,
+        # profiles/r3k_detector_prof_summary.md), and that is the state a roofline should describe
+        for _ in range(25):
             BF.conv2d_nhwc(x, w, b, pad=1, out=out)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -403,7 +406,7 @@ def conv_roofline(dev, math, iters=20):
              algorithmic_bytes=277610496, kernel=kdesc, ms_per_launch=round(ms, 4),
              flops_per_launch=flops,
              layer='FPN output conv P2: N=2, 200x336, 3x3, 256->256 (M=134400, K=2304)',
-             timing='hipEvent over %d back-to-back launches' % iters)
+             timing='hipEvent over %d back-to-back launches after 25 warm-up launches' % iters)
     if ent.get('matrix_pipe_busy'):
         # committed PMC pass of the same kernel on the same layer (not collected in this run): the
         # fraction of cycles the matrix pipe was busy, and the clock the chip sustained under it —
