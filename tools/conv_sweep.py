@@ -33,7 +33,9 @@ FC = [('fc1', 1024, 12544, 1024), ('fc2', 1024, 1024, 1024), ('fc_cls', 1024, 10
 
 
 def bench(fn, iters=10):
-    for _ in range(2):
+    # (the first launches after an idle period run up to 8 % slower — clock ramp; with 2 warm-up calls
+    #  the FIRST configuration timed for a layer was measurably penalised: warm up properly)
+    for _ in range(8):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
