@@ -85,6 +85,8 @@ SIGNATURES = {
     'bgs_conv3x3_halo_bfx_last_launch': (ctypes.c_int, [c_ptr, c_ptr]),
     'bgs_grouped_conv3x3_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 7
                                      + [c_ptr]),
+    'bgs_grouped_conv3x3_nhwc_bf16ops': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 7
+                                         + [c_ptr]),
     'bgs_grouped_conv3x3_dgrad_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 6
                                            + [c_ptr]),
     'bgs_grouped_conv3x3_wgrad_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 6),

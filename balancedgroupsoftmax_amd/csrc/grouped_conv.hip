@@ -141,7 +141,19 @@ __device__ __forceinline__ void gc_glds16(const void* src, unsigned char* lds_wa
 
 __device__ __attribute__((aligned(16))) unsigned g_gc_zero_page[4];
 
-template <int CG>
+// BF: the bf16 mode of cfg[4] — both operands rounded to bf16 (RNE) on their way into
+// v_mfma_f32_16x16x16_bf16 (one MFMA per tap and sub-tile instead of four fp32 ones), fp32 accumulate.
+typedef short bf16x4_bits __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4_bits gc_pack_bf16(const f32x4 v) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t lo = __builtin_convertvector(f32x2_t{v[0], v[1]}, bf16x2_t);
+  const bf16x2_t hi = __builtin_convertvector(f32x2_t{v[2], v[3]}, bf16x2_t);
+  return __builtin_bit_cast(bf16x4_bits, u32x2_t{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)});
+}
+
+template <int CG, bool BF = false>
 __global__ __launch_bounds__(256, CG == 32 ? 2 : 3) void grouped_conv3x3_lds_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ y, int N, int H, int W, int C, int tiles_y, int tiles_x, int relu) {
@@ -211,9 +223,14 @@ __global__ __launch_bounds__(256, CG == 32 ? 2 : 3) void grouped_conv3x3_lds_ker
         for (int kh = 0; kh < KH; ++kh) {
           const int q = qbase + kh * 4;
           const f32x4 av = *reinterpret_cast<const f32x4*>(lds + P * 256 + ((q ^ (P & 15)) << 4));
+          if (BF) {
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gc_pack_bf16(bv[r * 3 + s2][kh]),
+                                                               gc_pack_bf16(av), acc[a], 0, 0, 0);
+          } else {
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[r * 3 + s2][kh][u], av[u], acc[a], 0, 0, 0);
+            for (int u = 0; u < 4; ++u)
+              acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[r * 3 + s2][kh][u], av[u], acc[a], 0, 0, 0);
+          }
         }
       }
     }
@@ -237,12 +254,18 @@ __global__ __launch_bounds__(256, CG == 32 ? 2 : 3) void grouped_conv3x3_lds_ker
 
 // stride-1 launch (forward, or the data gradient with the per-group transposed filter)
 int launch_grouped_s1(const float* x, const float* w, const float* bias, float* y, int N, int H, int W,
-                      int C, int cg, int relu, hipStream_t st) {
+                      int C, int cg, int relu, hipStream_t st, bool bf = false) {
   const int tiles_y = (H + GTH - 1) / GTH, tiles_x = (W + GTW - 1) / GTW;
   dim3 grid((unsigned)(N * tiles_y * tiles_x), (unsigned)(C / 64));
-#define BGS_GL_LAUNCH(CG_)                                                                          \
-  hipLaunchKernelGGL((grouped_conv3x3_lds_kernel<CG_>), grid, dim3(256), 0, st, x, w, bias, y, N, H, W, \
-                     C, tiles_y, tiles_x, relu)
+#define BGS_GL_LAUNCH(CG_)                                                                              \
+  do {                                                                                                  \
+    if (bf)                                                                                             \
+      hipLaunchKernelGGL((grouped_conv3x3_lds_kernel<CG_, true>), grid, dim3(256), 0, st, x, w, bias, y, \
+                         N, H, W, C, tiles_y, tiles_x, relu);                                           \
+    else                                                                                                \
+      hipLaunchKernelGGL((grouped_conv3x3_lds_kernel<CG_, false>), grid, dim3(256), 0, st, x, w, bias, y, \
+                         N, H, W, C, tiles_y, tiles_x, relu);                                           \
+  } while (0)
   if (cg == 4) BGS_GL_LAUNCH(4);
   else if (cg == 8) BGS_GL_LAUNCH(8);
   else if (cg == 16) BGS_GL_LAUNCH(16);
@@ -355,6 +378,21 @@ __global__ __launch_bounds__(256) void grouped_wgrad_reduce_kernel(const float* 
 }
 
 }  // namespace
+
+// bgs_grouped_conv3x3_nhwc_f32 with both operands rounded to bf16 (fp32 tensors, fp32 accumulate):
+// the bf16 mode of cfg[4] (the reference's fp16 autocast, mmdet/core/fp16/decorators.py:9-160).
+// Stride 1 and C % 64 == 0 only (the LDS-resident kernel); BGS_ERR_UNSUPPORTED otherwise — the caller
+// then uses the fp32 entry point.
+extern "C" int bgs_grouped_conv3x3_nhwc_bf16ops(const float* x, const float* w, const float* bias,
+                                                float* y, int N, int H, int W, int C, int groups,
+                                                int stride, int relu, bgs_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || groups <= 0) return BGS_ERR_INVALID_ARG;
+  if (!x || !w || !y) return BGS_ERR_INVALID_ARG;
+  if (stride != 1 || C % groups != 0 || C % 64 != 0) return BGS_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias) % 16 != 0) return BGS_ERR_INVALID_ARG;
+  if ((long long)N * H * W > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  return launch_grouped_s1(x, w, bias, y, N, H, W, C, C / groups, relu, (hipStream_t)stream, true);
+}
 
 // Data gradient of bgs_grouped_conv3x3_nhwc_f32: dy [N,Ho,Wo,C] -> dx [N,H,W,C].  wt = the filter
 // transposed inside each group and flipped: wt[g*cg+cl][2-r][2-s][co_local] = w[g*cg+co_local][r][s][cl].

@@ -734,6 +734,14 @@ def _grouped_conv3x3_launch(x, w, bias, groups, stride, relu):
     N, H, W, C = x.shape
     out = torch.empty((N, (H - 1) // stride + 1, (W - 1) // stride + 1, C), dtype=torch.float32,
                       device=x.device)
+    if _CONV_MATH[0] == 'bf16' and stride == 1 and C % 64 == 0:
+        # cfg[4] bf16 mode: operands rounded to bf16 in the kernel, fp32 accumulate (the other
+        # layouts keep the fp32 kernel: more precise than the mode asks for)
+        rc = lib.bgs_grouped_conv3x3_nhwc_bf16ops(capi.ptr(x), capi.ptr(w), capi.ptr(bias),
+                                                  capi.ptr(out), N, H, W, C, int(groups), 1,
+                                                  int(bool(relu)), capi.current_stream(x.device))
+        capi.check('bgs_grouped_conv3x3_nhwc_bf16ops', rc)
+        return out
     rc = lib.bgs_grouped_conv3x3_nhwc_f32(capi.ptr(x), capi.ptr(w), capi.ptr(bias), capi.ptr(out),
                                           N, H, W, C, int(groups), int(stride), int(bool(relu)),
                                           capi.current_stream(x.device))

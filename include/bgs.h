@@ -291,6 +291,13 @@ int bgs_grouped_conv3x3_nhwc_f32(const float* x, const float* w, const float* bi
                                  int N, int H, int W, int C, int groups, int stride, int relu,
                                  bgs_stream_t stream);
 
+/* The same layer with both operands rounded to bf16 (RNE) for v_mfma_f32_16x16x16_bf16, fp32 tensors and
+ * fp32 accumulate: the bf16 mode of BASELINE cfg[4].  Stride 1 and C % 64 == 0 only (BGS_ERR_UNSUPPORTED
+ * otherwise: use the fp32 entry point). */
+int bgs_grouped_conv3x3_nhwc_bf16ops(const float* x, const float* w, const float* bias, float* y,
+                                     int N, int H, int W, int C, int groups, int stride, int relu,
+                                     bgs_stream_t stream);
+
 /* Backward of bgs_grouped_conv3x3_nhwc_f32 (`selectp = 0` on the ResNeXt configs; the reference
  * gets it from cuDNN through autograd of nn.Conv2d(groups=...), resnext.py:47-57).
  * dgrad: dy [N,Ho,Wo,C] -> dx [N,H,W,C] with the caller's re-laid-out filter

@@ -50,6 +50,35 @@ def test_grouped_conv3x3_lds_resident_kernel_vs_torch_cpu(cg, hw):
     assert float((got.permute(0, 3, 1, 2).cpu() - exp).abs().max()) < 1e-4 * float(exp.abs().max())
 
 
+@pytest.mark.parametrize('cg,hw', [(4, (13, 18)), (8, (21, 37)), (16, (50, 84)), (32, (25, 42))])
+def test_grouped_conv3x3_bf16_mode_is_bf16_rounded_operands(cg, hw):
+    """conv_math = 'bf16' (cfg[4]): the stride-1 grouped conv rounds both operands to bf16 and
+    accumulates in fp32 — checked against an fp64 grouped convolution of the ROUNDED operands."""
+    rs = np.random.RandomState(cg * 3 + hw[1])
+    groups = 16
+    C = cg * groups
+    x = rs.randn(2, hw[0], hw[1], C).astype(np.float32)
+    w = (rs.randn(C, cg, 3, 3) * 0.2).astype(np.float32)
+    b = rs.randn(C).astype(np.float32)
+    xr = torch.from_numpy(x).bfloat16().double()
+    wr = torch.from_numpy(w).bfloat16().double()
+    exp = F.relu(F.conv2d(xr.permute(0, 3, 1, 2), wr, torch.from_numpy(b).double(), padding=1,
+                          groups=groups))
+    scale = float(F.conv2d(xr.abs().permute(0, 3, 1, 2), wr.abs(), padding=1, groups=groups).max())
+    wk = torch.from_numpy(np.ascontiguousarray(w.transpose(0, 2, 3, 1))).to(DEV)
+    prev = BF.set_conv_math('bf16')
+    try:
+        got = BF.grouped_conv3x3_nhwc(torch.from_numpy(x).to(DEV), wk, torch.from_numpy(b).to(DEV),
+                                      groups, stride=1, relu=True)
+    finally:
+        BF.set_conv_math(prev)
+    assert float((got.permute(0, 3, 1, 2).cpu().double() - exp).abs().max()) <= 2e-6 * scale
+    # and it IS the rounded arithmetic: the fp32 kernel's result differs by the bf16 rounding error
+    ref32 = BF.grouped_conv3x3_nhwc(torch.from_numpy(x).to(DEV), wk, torch.from_numpy(b).to(DEV), groups,
+                                    stride=1, relu=True)
+    assert float((got - ref32).abs().max()) > 1e-4 * scale
+
+
 @pytest.mark.parametrize('cg,stride,hw', [(4, 1, (13, 18)), (8, 2, (13, 18)), (16, 1, (12, 17)),
                                           (32, 2, (14, 20)), (32, 1, (9, 11)), (4, 2, (16, 16))])
 def test_grouped_conv3x3_backward_vs_torch_autograd(cg, stride, hw):
