@@ -152,6 +152,8 @@ SIGNATURES = {
     'bgs_decode_proposals': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, c_f32p,
                                             c_ptr, c_f32p, ctypes.c_int, c_ptr, c_ptr, c_ptr,
                                             ctypes.c_float, ctypes.c_int, c_f32p, c_ptr]),
+    'bgs_refine_boxes': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, ctypes.c_int, ctypes.c_int, c_ptr,
+                                        ctypes.c_int, c_f32p, c_f32p, ctypes.c_float, c_f32p, c_ptr]),
     'bgs_rcnn_targets': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32p, c_ptr,
                                         ctypes.c_int, ctypes.c_int, c_ptr, c_ptr, ctypes.c_float,
                                         c_f32p, c_ptr, c_f32p, c_f32p, c_f32p, c_ptr]),

@@ -388,6 +388,49 @@ __global__ __launch_bounds__(256) void decode_proposals_kernel(
   o[4] = 1.f / (1.f + expf(-top_logit[tj]));
 }
 
+// Cascade stage hand-over in ONE launch (BBoxHead.refine_bboxes -> regress_by_class -> delta2bbox,
+// mmdet/models/bbox_heads/bbox_head.py:169-239, mmdet/core/bbox/transforms.py:34-111): every RoI is
+// re-regressed with the deltas of its own class (or the class-agnostic four) and clipped to its
+// image.  The tensor-op form is ~35 element-wise launches per image and stage.  Same operation order
+// as box_ops.delta2bbox with every product and sum rounded separately (fp contract off), so the
+// boxes are those of the tensor form bit for bit wherever expf agrees.
+__global__ __launch_bounds__(256) void refine_boxes_kernel(const float* __restrict__ rois,
+                                                           const long long* __restrict__ labels,
+                                                           const float* __restrict__ bbox_pred,
+                                                           int K, int pred_cols, Coding cod,
+                                                           ImgTable T, int n_img, float max_ratio,
+                                                           float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const float* r = rois + (size_t)k * 5;
+  int img = (int)r[0];
+  img = img < 0 ? 0 : (img >= n_img ? n_img - 1 : img);
+  long long c = 0;
+  if (pred_cols > 4 && labels) {
+    c = labels[k];
+    const long long nc = pred_cols / 4;
+    c = c < 0 ? 0 : (c >= nc ? nc - 1 : c);
+  }
+  const float* d = bbox_pred + (size_t)k * pred_cols + c * 4;
+  const float dx = d[0] * cod.stdv[0] + cod.mean[0];
+  const float dy = d[1] * cod.stdv[1] + cod.mean[1];
+  float dw = d[2] * cod.stdv[2] + cod.mean[2];
+  float dh = d[3] * cod.stdv[3] + cod.mean[3];
+  dw = fminf(fmaxf(dw, -max_ratio), max_ratio);
+  dh = fminf(fmaxf(dh, -max_ratio), max_ratio);
+  const float pw = r[3] - r[1] + 1.0f, ph = r[4] - r[2] + 1.0f;
+  const float px = (r[1] + r[3]) * 0.5f, py = (r[2] + r[4]) * 0.5f;
+  const float gw = pw * expf(dw), gh = ph * expf(dh);
+  const float gx = px + pw * dx, gy = py + ph * dy;
+  const float wmax = (float)(T.img_w[img] - 1), hmax = (float)(T.img_h[img] - 1);
+  float* o = out + (size_t)k * 4;
+  o[0] = fminf(fmaxf(gx - gw * 0.5f + 0.5f, 0.f), wmax);
+  o[1] = fminf(fmaxf(gy - gh * 0.5f + 0.5f, 0.f), hmax);
+  o[2] = fminf(fmaxf(gx + gw * 0.5f - 0.5f, 0.f), wmax);
+  o[3] = fminf(fmaxf(gy + gh * 0.5f - 0.5f, 0.f), hmax);
+}
+
 // ---------------------------------------------------------------------------------------------
 struct PtrTable {
   const float* boxes[kMaxImgs];      // candidate boxes of the image [cand_n, >=4] (row stride below)
@@ -640,6 +683,35 @@ extern "C" int bgs_decode_proposals(const float* const* host_level_outs, const i
   hipLaunchKernelGGL(decode_proposals_kernel, dim3((nmax + 255) / 256, L, N), dim3(256), 0,
                      (hipStream_t)stream, Lv, T, Ct, anchors, top_idx, top_logit, cod,
                      fabsf(logf(wh_ratio_clip)), nmax, boxes_out);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+// rois [K,5] (image index, x1, y1, x2, y2), labels [K] int64 or NULL (class-agnostic), bbox_pred
+// [K, pred_cols] (pred_cols = 4 or 4 * classes) -> out [K,4].  host_img_hw = {h0, w0, h1, w1, ..}.
+extern "C" int bgs_refine_boxes(const float* rois, const long long* labels, const float* bbox_pred,
+                                int K, int pred_cols, const int* host_img_hw, int N,
+                                const float* host_means, const float* host_stds, float wh_ratio_clip,
+                                float* out, bgs_stream_t stream) {
+  if (K < 0 || N <= 0 || N > kMaxImgs || pred_cols < 4 || pred_cols % 4 != 0) return BGS_ERR_INVALID_ARG;
+  if (K == 0) return BGS_OK;
+  if (!rois || !bbox_pred || !out || !host_img_hw || !host_means || !host_stds || wh_ratio_clip <= 0.f)
+    return BGS_ERR_INVALID_ARG;
+  if (pred_cols > 4 && !labels) return BGS_ERR_INVALID_ARG;
+  ImgTable T;
+  for (int i = 0; i < kMaxImgs; ++i) {
+    const int s = i < N ? i : 0;
+    T.gt_off[i] = 0;
+    T.img_h[i] = host_img_hw[2 * s];
+    T.img_w[i] = host_img_hw[2 * s + 1];
+  }
+  T.gt_off[kMaxImgs] = 0;
+  Coding cod;
+  for (int i = 0; i < 4; ++i) {
+    cod.mean[i] = host_means[i];
+    cod.stdv[i] = host_stds[i];
+  }
+  hipLaunchKernelGGL(refine_boxes_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, rois,
+                     labels, bbox_pred, K, pred_cols, cod, T, N, fabsf(logf(wh_ratio_clip)), out);
   BGS_RETURN_LAUNCH_STATUS();
 }
 

@@ -343,12 +343,14 @@ class CascadeRCNN(TwoStageDetector):
     def _refined_proposals(self, head, rois, labels, bbox_pred, img_meta, num):
         """``refine_bboxes`` (bbox_head.py:169-208) in fixed shape: every sampled RoI re-regressed
         with its target class; GT rows and padding slots are masked instead of removed."""
+        from . import functional as BF
         n_img = len(img_meta)
         with torch.no_grad():
-            bp = bbox_pred.detach()
-            boxes = torch.cat([head.regress_by_class(
-                rois[j * num:(j + 1) * num, 1:], labels[j * num:(j + 1) * num],
-                bp[j * num:(j + 1) * num], img_meta[j]) for j in range(n_img)])
+            # regress_by_class + delta2bbox for every image in ONE launch (csrc/det_targets.hip:
+            # refine_boxes_kernel; the tensor form is ~35 element-wise launches per image and stage)
+            boxes = BF.refine_boxes(rois.contiguous(), labels.contiguous(), bbox_pred.detach().contiguous(),
+                                    [m['img_shape'] for m in img_meta], head.target_means,
+                                    head.target_stds)
             keep = self._sampled_valid & ~self._sampled_is_gt
             return [(boxes[j * num:(j + 1) * num], keep[j]) for j in range(n_img)]
 

@@ -1297,6 +1297,30 @@ def decode_proposals(level_outs, level_counts, num_anchors, anchors, top_idx, to
     return out
 
 
+def refine_boxes(rois, labels, bbox_pred, img_shapes, means, stds, wh_ratio_clip=16 / 1000):
+    """Cascade stage hand-over (``regress_by_class`` + ``delta2bbox`` for all images) in one launch:
+    ``rois [K,5]`` (image index, box), ``labels [K]`` int64 (ignored when ``bbox_pred`` has 4 columns:
+    class-agnostic), ``bbox_pred [K, 4 or 4*classes]``, ``img_shapes`` = per-image ``(h, w)`` clip bounds
+    -> ``[K,4]`` boxes."""
+    _require_cuda(rois, labels, bbox_pred)
+    lib = capi.load()
+    K, cols = bbox_pred.shape
+    assert rois.dtype == torch.float32 and bbox_pred.dtype == torch.float32
+    assert rois.is_contiguous() and bbox_pred.is_contiguous() and tuple(rois.shape) == (K, 5)
+    lab = None
+    if cols > 4:
+        assert labels.dtype == torch.int64 and labels.is_contiguous() and labels.numel() == K
+        lab = labels
+    out = torch.empty((K, 4), dtype=torch.float32, device=rois.device)
+    hw = [int(v) for s_ in img_shapes for v in s_[:2]]
+    rc = lib.bgs_refine_boxes(capi.ptr(rois), capi.ptr(lab), capi.ptr(bbox_pred), K, cols,
+                              _c_int_array(hw), len(img_shapes), _c_float_array(means),
+                              _c_float_array(stds), float(wh_ratio_clip), capi.ptr(out),
+                              capi.current_stream(rois.device))
+    capi.check('bgs_refine_boxes', rc)
+    return out
+
+
 def rcnn_targets(boxes_list, assigned_list, inds_list, valid_list, gt_labels_list, gt_cat,
                  gt_offsets, num, means, stds, pos_weight=-1):
     """Sampled RoIs -> ``rois [N*num,5]``, ``labels`` i64, ``label_weights``, ``bbox_targets``,

@@ -516,6 +516,15 @@ int bgs_decode_proposals(const float* const* host_level_outs, const int* host_le
                          const float* host_stds, float wh_ratio_clip, int nmax, float* boxes_out,
                          bgs_stream_t stream);
 
+/* Cascade stage hand-over in one launch: BBoxHead.refine_bboxes -> regress_by_class -> delta2bbox
+ * (mmdet/models/bbox_heads/bbox_head.py:169-239, mmdet/core/bbox/transforms.py:34-111).  rois [K,5]
+ * (image index, x1, y1, x2, y2), labels [K] int64 (NULL when pred_cols == 4: class-agnostic),
+ * bbox_pred [K, pred_cols], host_img_hw = {h0, w0, h1, w1, ...} (N images: the clip bounds), wh_ratio_clip
+ * as delta2bbox's (16 / 1000) -> out [K,4].  GT rows / padding slots are the caller's business (masks). */
+int bgs_refine_boxes(const float* rois, const long long* labels, const float* bbox_pred, int K,
+                     int pred_cols, const int* host_img_hw, int N, const float* host_means,
+                     const float* host_stds, float wh_ratio_clip, float* out, bgs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * RoI-head targets of the sampled RoIs.  Replaces bbox2roi (transforms.py:149-168) +
  *   bbox_target_single (mmdet/core/bbox/bbox_target.py:35-61).  Per image n (HOST pointer

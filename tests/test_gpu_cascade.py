@@ -281,3 +281,31 @@ def test_cascade_rcnn_training_iteration_and_test(tmp_path):
             h.fc_cls.weight.mul_(30.0)
     res = model(img[:1], metas[:1], return_loss=False, rescale=False)
     assert len(res) == 1230 and sum(r.shape[0] for r in res) == 300
+
+
+@pytest.mark.parametrize('agnostic', [True, False])
+def test_refine_boxes_kernel_equals_regress_by_class(agnostic):
+    """bgs_refine_boxes (one launch for all images) == BBoxHead.regress_by_class -> delta2bbox per image
+    (bbox_head.py:210-239, transforms.py:34-111): class gather, decode, clip to each image's own shape —
+    bit for bit (same operation order, separately rounded)."""
+    from balancedgroupsoftmax_amd.box_ops import delta2bbox
+    rs = np.random.RandomState(5 + agnostic)
+    K, C = 300, 7
+    shapes = [(97, 143, 3), (120, 101, 3)]
+    img = rs.randint(0, 2, size=K).astype(np.float32)
+    x1 = rs.uniform(-5, 120, K); y1 = rs.uniform(-5, 100, K)
+    boxes = np.stack([x1, y1, x1 + rs.uniform(0, 60, K), y1 + rs.uniform(0, 60, K)], 1).astype(np.float32)
+    rois = torch.from_numpy(np.concatenate([img[:, None], boxes], 1)).to(DEV)
+    labels = torch.from_numpy(rs.randint(0, C, size=K).astype(np.int64)).to(DEV)
+    pred = torch.from_numpy((rs.standard_normal((K, 4 if agnostic else 4 * C)) * 2).astype(np.float32)).to(DEV)
+    means, stds = (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2)
+    got = BF.refine_boxes(rois, labels, pred, shapes, means, stds)
+    exp = torch.empty_like(got)
+    for j, shp in enumerate(shapes):
+        m = rois[:, 0] == j
+        d = pred[m]
+        if not agnostic:
+            cols = (labels[m] * 4).view(-1, 1) + torch.arange(4, device=DEV).view(1, 4)
+            d = torch.gather(d, 1, cols)
+        exp[m] = delta2bbox(rois[m, 1:], d, means, stds, shp)
+    assert torch.equal(got, exp)
