@@ -490,6 +490,199 @@ __global__ __launch_bounds__(kThreads, NS == 1 ? (DMA_NST == 3 ? 8 : 6) : (DMA_N
   conv_store_tile<1, 1>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 mode (NS = 1), large layers: 128 x 128 tile on the operand ring with EIGHT waves (4 x 2, each
+// 32 x 64).  With one MFMA per product the 64 x 64 ring moves 6 KB per 4 MFMAs — the bf16 mode is
+// bound by the memory path outright (cascade X101: 46 launches of M = 8400, K = 1024, Cout = 1024 at
+// 61 us = 290 TFLOP/s of a 2500 peak); this tile moves 12 KB per 16 MFMAs and keeps 32 waves per CU
+// (four workgroups of 37 KB).  (For the fp32-faithful mode the same tile was within 2 % of the 64 x 64
+// ring and is not instantiated: profiles/r3h_ring8_sweep.txt.)
+//   * stage = A 128 rows x 64 B fp32 (quads XOR-swizzled) + B 128 rows x 32 B (hi plane, halves
+//     swapped on odd 8-row groups) = 12 KB, three stages; 12 DMA pieces, two slots per wave (wave w:
+//     A rows 16 w.., B piece w for w < 4, a dummy piece into the scratch block otherwise);
+//   * epilogue: the LDS transpose in two halves of 64 rows (512 threads, 16 rows per pass).
+template <bool P1X1>
+__global__ __launch_bounds__(512, 2) void conv_igemm_bf16_ring8_kernel(BfxArgs q) {
+  const ConvArgs& p = q.c;
+  const unsigned* __restrict__ zero_page = q.zero;
+  constexpr int NST = 3, A_BYTES = 128 * 64, B_PLANE = 128 * 32, STAGE = A_BYTES + B_PLANE;
+  constexpr int SCR = NST * STAGE;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[SCR + 1024];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = bgs::uniform(tid >> 6);               // 0..7
+  const int wm = wave >> 1, wn = wave & 1;
+  const int vtile = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if (vtile >= p.tiles_m * p.tiles_n) return;          // workgroup-uniform
+  const int m0 = (vtile / p.tiles_n) * 128, n0 = (vtile % p.tiles_n) * 128;
+
+  const int nk_all = q.KC;
+  const int kt_begin = p.partial ? blockIdx.z * p.kt_per_split : 0;
+  const int kt_end = p.partial ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
+  const int nk = kt_end - kt_begin;
+
+  // ---- A DMA role: rows 16 wave + (lane >> 2); lane -> physical quad, logical = physical ^ ((row >> 2) & 3)
+  const int arow = wave * 16 + (lane >> 2);
+  const int aq = (lane & 3) ^ ((arow >> 2) & 3);
+  int a_hi0, a_wi0;
+  const float* a_base;
+  bool a_ok;
+  {
+    const int m = m0 + arow;
+    a_ok = m < p.M;
+    const int mm = a_ok ? m : 0;
+    const int hw = p.Ho * p.Wo;
+    const int n = mm / hw;
+    const int rem = mm - n * hw;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    a_hi0 = ho * p.stride - p.pad;
+    a_wi0 = wo * p.stride - p.pad;
+    a_base = p.x + (size_t)n * p.H * p.W * p.Cin;
+  }
+  // ---- B DMA role (waves 0..3): rows 32 wave + (lane >> 1) of the hi plane
+  const int brow_d = (wave & 3) * 32 + (lane >> 1);
+  const int bhalf_d = (lane & 1) ^ ((brow_d >> 3) & 1);
+  const bool has_b = wave < 4;                          // wave-uniform
+  const bool b_ok = has_b && (n0 + brow_d < p.Cout);
+  const __bf16* b_ptr = q.ws + (size_t)(b_ok ? n0 + brow_d : 0) * 16 + bhalf_d * 8 +
+                        (size_t)kt_begin * p.Cout * 16;
+  int kg = kt_begin * 16 + aq * 4;
+  int kc, kr, ks;
+  {
+    const int rs = kg / p.Cin;
+    kc = kg - rs * p.Cin;
+    kr = rs / p.S;
+    ks = rs - kr * p.S;
+  }
+  const float* a_ptr = nullptr;
+  if (P1X1) a_ptr = a_base + ((size_t)a_hi0 * p.W + a_wi0) * p.Cin + kg;
+  const size_t b_step = (size_t)p.Cout * 16;
+  int kt_issue = 0;
+  auto issue = [&]() {
+    unsigned char* st = lds + (kt_issue % NST) * STAGE;
+    const bool live = kt_issue < nk;
+    const float* asrc;
+    if (P1X1) {
+      asrc = (live && a_ok && kg < p.K) ? a_ptr : reinterpret_cast<const float*>(zero_page);
+      a_ptr += 16;
+      kg += 16;
+    } else {
+      const int hi = a_hi0 + kr, wi = a_wi0 + ks;
+      const bool ok = live && a_ok && kg < p.K && hi >= 0 && wi >= 0 && hi < p.H && wi < p.W;
+      asrc = ok ? a_base + ((size_t)hi * p.W + wi) * p.Cin + kc
+                : reinterpret_cast<const float*>(zero_page);
+      kg += 16;
+      kc += 16;
+      while (kc >= p.Cin) {
+        kc -= p.Cin;
+        if (++ks == p.S) {
+          ks = 0;
+          ++kr;
+        }
+      }
+    }
+    const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page);
+    glds16(asrc, st + wave * 1024);
+    if (has_b) glds16((live && b_ok) ? b_ptr : zp, st + A_BYTES + wave * 1024);
+    else glds16(zp, lds + SCR);
+    b_ptr += b_step;
+    ++kt_issue;
+  };
+
+  // ---- fragment roles: wave tile = rows 32 wm .., columns 64 wn .. (two 32-wide sub-tiles)
+  const int frow = lane & 31, fk = lane >> 5;
+  const int ar = wm * 32 + frow;
+  const int ac = (ar >> 2) & 3;
+  const int a_off0 = ar * 64 + (((2 * fk) ^ ac) << 4);
+  const int a_off1 = ar * 64 + (((2 * fk + 1) ^ ac) << 4);
+  const int br = wn * 64 + frow;                        // + 32 b keeps the 8-row-group parity
+  const int b_off = A_BYTES + br * 32 + ((fk ^ ((br >> 3) & 1)) << 4);
+
+  f32x16 acc[1][2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][b][r] = 0.f;
+
+  issue();
+  issue();
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // one younger stage (2 DMAs) may be in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue();
+    const unsigned char* st = lds + (kt % NST) * STAGE;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(st + a_off0);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(st + a_off1);
+    const bf16x8 fa = __builtin_bit_cast(bf16x8, u32x4{pack_bf16(a0[0], a0[1]), pack_bf16(a0[2], a0[3]),
+                                                       pack_bf16(a1[0], a1[1]), pack_bf16(a1[2], a1[3])});
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const bf16x8 fb = *reinterpret_cast<const bf16x8*>(st + b_off + b * 32 * 32);
+      acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[0][b], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the (zero-page) tail DMAs
+  if (!conv_epilogue_vec_ok(p)) {
+    conv_store_tile<1, 2>(p, acc, m0, n0, wm, wn, lane);
+    return;
+  }
+  // ---- epilogue through LDS, two halves of 64 rows: scratch 64 x 132 floats
+  float* scratch = reinterpret_cast<float*>(lds);
+  constexpr int LD = 132;
+  const int c4 = (tid & 31) * 4, r0 = tid >> 5;         // 32 threads per row, 16 rows per pass
+  const int j = n0 + c4;
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && !p.partial && j < p.Cout) bias = *reinterpret_cast<const f32x4*>(p.bias + j);
+  float* dst = p.partial ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : p.y;
+  const int hw = p.Ho * p.Wo;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();                                   // ring (h = 0) / previous half (h = 1) no longer read
+    if ((wm >> 1) == h) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (wm & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          scratch[i * LD + wn * 64 + b * 32 + (lane & 31)] = acc[0][b][r];
+        }
+    }
+    __syncthreads();
+    if (j >= p.Cout) continue;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int i = r0 + ps * 16;
+      const int m = m0 + h * 64 + i;
+      if (m >= p.M) break;
+      f32x4 v = *reinterpret_cast<const f32x4*>(scratch + i * LD + c4);
+      if (!p.partial) {
+        v += bias;
+        if (p.res_mode == 1) {
+          v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + j);
+        } else if (p.res_mode == 2) {
+          const int n = m / hw;
+          const int rem = m - n * hw;
+          const int ho = rem / p.Wo, wo = rem - (rem / p.Wo) * p.Wo;
+          v += *reinterpret_cast<const f32x4*>(
+              p.res + (((size_t)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout + j);
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+        }
+        if (p.mask) {
+          const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m * p.Cout + j);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = mk[t] > 0.f ? v[t] : 0.f;
+        }
+      }
+      *reinterpret_cast<f32x4*>(dst + (size_t)m * p.Cout + j) = v;
+    }
+  }
+}
+
 // (Tried: the same tile and ring with TWO waves per workgroup — each wave 32 rows x all 64 columns,
 //  so that a row block's A fragment is split by one wave instead of two and the fixed per-step
 //  instructions are shared by 12 MFMAs instead of 6.  Equal on the small grids, 15-30 % SLOWER on the
@@ -1222,11 +1415,12 @@ int halo_bfx_plan(long long M, int tiles_m, int Cin, int Cout, int& nb) {
 }
 
 struct BfxKnobs {
-  int tile = 0, splitk = -1, dma = 1, nst = 0;
+  int tile = 0, splitk = -1, dma = 1, nst = 0, ring8 = 1;
   BfxKnobs() {
     if (const char* e = getenv("BGS_BFX_TILE")) tile = atoi(e);
     if (const char* e = getenv("BGS_BFX_SPLITK")) splitk = atoi(e);
     if (const char* e = getenv("BGS_BFX_NST")) nst = atoi(e);      // 3 | 4: ring depth of the 64 x 64 kernel
+    if (const char* e = getenv("BGS_BF16_RING8")) ring8 = atoi(e);  // 0: bf16 mode on the 64 x 64 ring only
   }
 };
 BfxKnobs& bfx_knobs() {
@@ -1291,6 +1485,20 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   const long long M = p.M;
   int tile, bk, want;
   bfx_plan(M, p.Cout, q.KC, tile, bk, want);
+  // bf16 mode: the 8-wave 128 x 128 ring for the large layers (memory-path bound: half the bytes per MFMA)
+  const bool ring8 = q.ns == 1 && up == 1 && knobs.tile == 0 && knobs.ring8 && M >= 2048 &&
+                     p.Cout >= 256 && q.KC >= 16;
+  if (ring8) {
+    tile = 22;
+    const long long wgs = ((M + 127) / 128) * ((p.Cout + 127) / 128);
+    want = 1;
+    if (wgs < 400) want = (int)((1100 + wgs - 1) / wgs);
+    else if (wgs < 600 && q.KC >= 128) want = 2;
+    if (want > q.KC / 8) want = q.KC / 8;
+    if (want > 8) want = 8;
+    if (knobs.splitk >= 1 && knobs.splitk <= 16) want = knobs.splitk < q.KC ? knobs.splitk : q.KC;
+    if (want < 1) want = 1;
+  }
   const int bm = tile / 10 * 64, bn = tile % 10 * 64;
   int splits = 1;
   p.partial = nullptr;
@@ -1318,7 +1526,14 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   } while (0)
   g_last_dma = 0;
   g_last_nst = 4;
-  if (tile == 22) BFX_T(2, 2);
+  if (ring8) {
+    g_last_dma = 1;
+    g_last_nst = 3;
+    if (p.R == 1 && p.S == 1 && p.pad == 0)
+      hipLaunchKernelGGL((conv_igemm_bf16_ring8_kernel<true>), grid, dim3(512), 0, st, q);
+    else
+      hipLaunchKernelGGL((conv_igemm_bf16_ring8_kernel<false>), grid, dim3(512), 0, st, q);
+  } else if (tile == 22) BFX_T(2, 2);
   else if (tile == 21) BFX_T(2, 1);
   else if (tile == 12) BFX_T(1, 2);
   else if (knobs.dma && q.ns == 1) {

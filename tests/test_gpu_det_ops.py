@@ -753,3 +753,46 @@ def test_conv_bf16_mode_is_bf16_rounded_operands_with_fp32_accumulate(monkeypatc
     finally:
         BF.conv_bfx_tuning()
         BF.set_conv_math(prev)
+
+
+@pytest.mark.parametrize('case', [
+    # N, H, W, Cin, Cout, R, stride, pad, relu, res_mode, splitk
+    (2, 40, 56, 256, 320, 1, 1, 0, True, 1, -1),
+    (2, 67, 95, 256, 256, 1, 2, 0, False, 0, -1),
+    (2, 91, 123, 128, 272, 3, 2, 1, True, 0, -1),
+    (2, 40, 56, 512, 256, 1, 1, 0, True, 2, 3),
+    (1, 46, 50, 256, 1236, 1, 1, 0, False, 0, -1),
+], ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv_bf16_mode_large_layers_run_the_8_wave_128x128_ring(monkeypatch, case):
+    """bf16 mode, M >= 2048 / Cout >= 256 / K >= 256: the 8-wave 128 x 128 ring kernel (ragged M and Cout
+    tiles, stride 2, 3x3 with padding, residual modes, split-K, its two-half LDS epilogue) == the 64 x 64
+    ring bit for bit (same products, same K order)."""
+    N, H, W, Cin, Cout, R, stride, pad, relu, rm, sk = case
+    rs = np.random.RandomState(H + Cout)
+    x = rs.standard_normal((N, H, W, Cin)).astype(np.float32)
+    w = (rs.standard_normal((Cout, R, R, Cin)) / (R * R * Cin) ** 0.5).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32)
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    res = None
+    if rm == 1:
+        res = rs.standard_normal((N, Ho, Wo, Cout)).astype(np.float32)
+    elif rm == 2:
+        res = rs.standard_normal((N, Ho // 2, Wo // 2, Cout)).astype(np.float32)
+    prev = BF.set_conv_math('bf16')
+    monkeypatch.setenv('BGS_CONV_HALO', '0')
+    try:
+        BF.conv_bfx_tuning(0, sk)
+        got = BF.conv2d_nhwc(dev(x), dev(w), dev(b), stride=stride, pad=pad, relu=relu,
+                             residual=None if res is None else dev(res), residual_mode=rm)
+        used = BF.conv_bfx_last_launch()
+        assert used['tile'] == 22 | 0x200, used                     # 128 x 128, DMA ring
+        if sk > 0:
+            assert used['splits'] == sk
+        BF.conv_bfx_tuning(11, sk)
+        ref = BF.conv2d_nhwc(dev(x), dev(w), dev(b), stride=stride, pad=pad, relu=relu,
+                             residual=None if res is None else dev(res), residual_mode=rm)
+        assert BF.conv_bfx_last_launch()['tile'] == 11 | 0x200
+        assert torch.equal(got, ref)
+    finally:
+        BF.conv_bfx_tuning()
+        BF.set_conv_math(prev)
