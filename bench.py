@@ -636,6 +636,23 @@ def run_graph_child(args):
     return None
 
 
+def gs_head_metric(inp, n, steps=300, warmup=20):
+    """The BASELINE metric's second half, 'GroupSoftmax us/RoI', as the whole head-loss step
+    (GSBBoxHeadWith0.loss() + backward(): label remap, 'others' sampling, per-bin loss forward and
+    backward, box loss, the sums) on a 1024-RoI batch resident in HBM — what `--workload gs_head`
+    reports as its `value`, here as a field of the default line."""
+    step = GsHeadStep(inp)
+    graph = try_graph(step)
+    fn = graph.replay if graph is not None else step
+    dt = timed_loop(fn, steps, warmup, 1)
+    return dict(value=round(dt * 1e6 / (steps * n), 6), unit='us/RoI', us_per_step=round(dt * 1e6 / steps, 2),
+                rois_per_step=n, steps=steps,
+                launch='hipGraph replay' if graph is not None else 'eager launches',
+                what='gs_head_loss_fused (label remap + others sampling + per-bin loss fwd + bwd) + box '
+                     'loss + reductions + autograd plumbing; launch-latency bound (the fused kernel '
+                     'itself: ~12 us)')
+
+
 def finish_line(out, args, dev, world):
     """Secondary measurements + per-kernel rooflines + CPU baseline, then the ONE JSON line."""
     if world == 1 and not args.no_extras and args.selectp == 1 and not args.mask \
@@ -647,6 +664,8 @@ def finish_line(out, args, dev, world):
             out['roofline_f32_mfma_kernel'] = conv_roofline(dev, 'f32')
         gs_inp = make_inputs(1024, seed=1000, dev=dev)
         out['roofline_gs_loss'] = kernel_roofline(gs_inp, 1024)
+        if world == 1:
+            out['gs_head'] = gs_head_metric(gs_inp, 1024)
     if world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(1024, args.cpu_seconds)
         cb['note'] = ('GroupSoftmax loss()+backward() only: the reference cannot run the whole '
