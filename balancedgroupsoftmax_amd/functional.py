@@ -316,14 +316,24 @@ def bbox_smooth_l1_loss(bbox_pred, labels, bbox_targets, bbox_weights, num_reg_c
 #   math 'bf16':             operands rounded to bf16 for the MFMA, fp32 accumulate / storage: the
 #                            arithmetic of the reference's fp16 autocast (mmdet/core/fp16/) — cfg[4]
 # ----------------------------------------------------------------------------------------
-_CONV_MATH = [os.environ.get('BGS_CONV_MATH', 'bf16x6')]
+_CONV_MATHS = ('bf16x6', 'f32', 'bf16')
+
+
+def _checked_conv_math(mode, origin):
+    if mode not in _CONV_MATHS:
+        raise ValueError('%s: unknown conv math %r (expected one of %s)' % (origin, mode, _CONV_MATHS))
+    return mode
+
+
+# a typo in the environment ('fp32', 'BF16X6') must not select an arithmetic silently: validated at import
+_CONV_MATH = [_checked_conv_math(os.environ.get('BGS_CONV_MATH', 'bf16x6'), 'BGS_CONV_MATH')]
 
 
 def set_conv_math(mode):
     """'bf16x6' | 'f32' | 'bf16'; returns the previous mode.  The first two give fp32-accurate
     results (the split kernel's error against fp64 is not above the fp32 MFMA kernel's; 'f32'
     keeps the bit-exact fp32 fma chain); 'bf16' is the reduced-precision mode of cfg[4]."""
-    assert mode in ('bf16x6', 'f32', 'bf16'), mode
+    _checked_conv_math(mode, 'set_conv_math')
     prev = _CONV_MATH[0]
     _CONV_MATH[0] = mode
     return prev
@@ -333,32 +343,58 @@ def conv_math():
     return _CONV_MATH[0]
 
 
+class conv_math_scope(object):
+    """``with conv_math_scope('bf16'): ...`` — the mode is restored on exit (also on error)."""
+
+    def __init__(self, mode):
+        self.mode = _checked_conv_math(mode, 'conv_math_scope')
+
+    def __enter__(self):
+        self.prev = set_conv_math(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_conv_math(self.prev)
+        return False
+
+
+# Split planes of FROZEN filters only, one entry per storage address: {data_ptr: (version, shape,
+# source tensor, planes)}.  The source is kept alive so that its address cannot be handed to another
+# tensor while the entry exists; an entry whose version went stale is overwritten in place, so the
+# cache never holds more than one split per live frozen tensor.  Trained filters (and per-step
+# temporaries such as the folded copies of a trained trunk) are NEVER cached: their split launch is
+# part of every step — inside a captured hipGraph it is re-run by every replay, so an eager forward
+# after replayed optimizer steps (which do not bump ``_version``) cannot read stale planes.
 _SPLIT_CACHE = {}
+_SPLIT_CACHE_MAX = 1024
+
+
+def clear_split_cache():
+    _SPLIT_CACHE.clear()
 
 
 def bfx_split_weights(w2d, cache=True):
     """``w2d [rows, K]`` fp32 -> the three bf16 planes ``bgs_conv2d_nhwc_f32_bfx_ws`` streams.
-    Frozen tensors (``requires_grad == False``) are split once and cached per (storage, version);
-    trained ones are split on every call (inside a captured step the split launch is part of the
-    graph, so replays see the updated weights)."""
+    ``cache=True`` declares the tensor FROZEN (the caller decides: a detached view of a trained
+    parameter has ``requires_grad == False`` too)."""
     _require_cuda(w2d)
     lib = capi.load()
     assert w2d.dtype == torch.float32 and w2d.dim() == 2 and w2d.is_contiguous()
     rows, K = w2d.shape
     cacheable = cache and not w2d.requires_grad
-    key = (w2d.data_ptr(), w2d._version, rows, K)
+    key = w2d.data_ptr()
     if cacheable:
         hit = _SPLIT_CACHE.get(key)
-        if hit is not None:
-            return hit[1]
+        if hit is not None and hit[0] == w2d._version and hit[1] == (rows, K):
+            return hit[3]
     out = torch.empty(lib.bgs_conv_bfx_weight_bytes(rows, K), dtype=torch.uint8, device=w2d.device)
     rc = lib.bgs_conv_bfx_split_weights(capi.ptr(w2d), capi.ptr(out), rows, K,
                                         capi.current_stream(w2d.device))
     capi.check('bgs_conv_bfx_split_weights', rc)
     if cacheable:
-        if len(_SPLIT_CACHE) > 4096:
-            _SPLIT_CACHE.clear()
-        _SPLIT_CACHE[key] = (w2d, out)      # the source is kept alive: its address cannot be reused
+        if key not in _SPLIT_CACHE and len(_SPLIT_CACHE) >= _SPLIT_CACHE_MAX:
+            _SPLIT_CACHE.pop(next(iter(_SPLIT_CACHE)))      # oldest entry (insertion order)
+        _SPLIT_CACHE[key] = (w2d._version, (rows, K), w2d, out)
     return out
 
 
@@ -419,9 +455,11 @@ def _use_halo_kernel(M, Cout):
 
 
 def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None,
-                residual_mode=0, out=None):
+                residual_mode=0, out=None, frozen_weight=True):
     """``y = act(conv(x, w) + bias + residual)``; x ``[N,H,W,Cin]``, w ``[Cout,R,S,Cin]``.
-    Forward only (the shipped BAGS configs freeze every conv: selectp=1, tools/train.py:49-57)."""
+    Forward only (the shipped BAGS configs freeze every conv: selectp=1, tools/train.py:49-57).
+    ``frozen_weight=False``: ``w_krsc`` is (a detached view of) a tensor that changes from step to
+    step — its bf16 planes are split on every call and never cached."""
     _require_cuda(x, w_krsc, bias, residual)
     lib = capi.load()
     assert x.dtype == torch.float32 and w_krsc.dtype == torch.float32
@@ -441,7 +479,7 @@ def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None
     halo_ok = R == 3 and S == 3 and stride == 1 and pad == 1 and residual is None and Cin % 16 == 0
     if _CONV_MATH[0] != 'f32':
         planes = 3 if _CONV_MATH[0] == 'bf16x6' else 1
-        wsplit = bfx_split_weights(w_krsc.view(Cout, R * S * Cin))
+        wsplit = bfx_split_weights(w_krsc.view(Cout, R * S * Cin), cache=bool(frozen_weight))
         st = capi.current_stream(x.device)
         if halo_ok and _use_halo_bfx(N * Ho * Wo, Cout):
             wsb = lib.bgs_conv3x3_halo_bfx_workspace_bytes(N, H, W, Cin, Cout)
@@ -585,12 +623,15 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, residual, stride, pad, relu, residual_mode, mask_input):
+        # w.requires_grad: a trained parameter or the per-step fold of one (its detached view has
+        # requires_grad == False, so the decision is taken HERE): split every step, never cached
         y = conv2d_nhwc(x.detach(), w.detach(), None if bias is None else bias.detach(),
                         stride=stride, pad=pad, relu=bool(relu),
                         residual=None if residual is None else residual.detach(),
-                        residual_mode=residual_mode)
+                        residual_mode=residual_mode, frozen_weight=not w.requires_grad)
         ctx.cfg = (stride, pad, relu, residual_mode if residual is not None else 0,
                    bias is not None, mask_input)
+        ctx.math = _CONV_MATH[0]          # backward replays in the arithmetic of this forward
         ctx.save_for_backward(x, w, y if relu is True else None)
         return y
 
@@ -604,12 +645,13 @@ class _ConvFn(torch.autograd.Function):
             dz = torch.ops.aten.threshold_backward(dz, y, 0.0)
         need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
         dx = dw = db = dres = None
-        if need_x:
-            dx = conv2d_dgrad_nhwc(dz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad,
-                                   mask=x if mask_input else None)
-        if need_w or (has_bias and need_b):
-            out = conv2d_wgrad_nhwc(x, dz, w.shape[1], stride=stride, pad=pad, bias=has_bias)
-            dw, db = out if has_bias else (out, None)
+        with conv_math_scope(ctx.math):
+            if need_x:
+                dx = conv2d_dgrad_nhwc(dz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad,
+                                       mask=x if mask_input else None)
+            if need_w or (has_bias and need_b):
+                out = conv2d_wgrad_nhwc(x, dz, w.shape[1], stride=stride, pad=pad, bias=has_bias)
+                dw, db = out if has_bias else (out, None)
         if res_mode and need_r:
             if res_mode == 1:
                 dres = dz
@@ -666,13 +708,17 @@ def conv2d_autograd(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=
                        residual=residual, residual_mode=residual_mode)
 
 
-def linear(x, weight, bias=None, relu=False):
-    """``act(x @ weight.T + bias)`` for ``x [M,K]``, ``weight [Cout,K]`` (nn.Linear layout)."""
+def linear(x, weight, bias=None, relu=False, frozen_weight=None):
+    """``act(x @ weight.T + bias)`` for ``x [M,K]``, ``weight [Cout,K]`` (nn.Linear layout).
+    ``frozen_weight`` (default: ``not weight.requires_grad``, evaluated BEFORE detaching) decides
+    whether the bf16 planes of the weight may be cached (see :func:`bfx_split_weights`)."""
     M, K = x.shape
+    if frozen_weight is None:
+        frozen_weight = not weight.requires_grad
     x = _f32c(x)
     weight = _f32c(weight)
     y = conv2d_nhwc(x.view(M, 1, 1, K), weight.view(weight.shape[0], 1, 1, K),
-                    None if bias is None else _f32c(bias), relu=relu)
+                    None if bias is None else _f32c(bias), relu=relu, frozen_weight=frozen_weight)
     return y.view(M, weight.shape[0])
 
 
@@ -687,7 +733,8 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return linear(x.detach(), weight.detach(), None if bias is None else bias.detach())
+        return linear(x.detach(), weight.detach(), None if bias is None else bias.detach(),
+                      frozen_weight=not weight.requires_grad)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -698,7 +745,7 @@ class _LinearFn(torch.autograd.Function):
         M, K = x.shape
         Nout = weight.shape[0]
         if ctx.needs_input_grad[0]:
-            gx = linear(gy, weight.detach().t().contiguous())            # [M,N] x [K,N]^T
+            gx = linear(gy, weight.detach().t().contiguous(), frozen_weight=False)   # [M,N] x [K,N]^T
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_b:
             # dW[n,k] = sum_m gy[m,n] x[m,k]: the split-reduction wgrad kernel, no transposes
@@ -708,7 +755,7 @@ class _LinearFn(torch.autograd.Function):
                 gw, gb = (out[0], out[1]) if want_b else (out, None)
                 gw = gw.view(Nout, K)
             else:
-                gw = linear(gy.t().contiguous(), x.detach().t().contiguous())
+                gw = linear(gy.t().contiguous(), x.detach().t().contiguous(), frozen_weight=False)
                 gb = gy.sum(0) if want_b else None
         return gx, gw, gb
 

@@ -239,12 +239,36 @@ def wrap_fp16_model(model, math='bf16'):
     matrix cores (``planes = 1`` of csrc/conv_bfx.hip) and accumulates in fp32.  Parameters and
     activations stay fp32 in HBM, so the parameters ARE the fp32 master weights (no copy, no
     copy-back), eval-mode BatchNorm is folded in fp32, and the losses see fp32 logits — what
-    ``patch_norm_fp32`` / ``force_fp32`` arrange in the reference.  Returns the previous mode."""
+    ``patch_norm_fp32`` / ``force_fp32`` arrange in the reference.
+
+    The mode is scoped to THIS model, as ``model.half()`` is: forward pre / post hooks switch the
+    process-wide conv arithmetic for the duration of ``model(...)`` only, and every conv autograd
+    node replays its backward in the mode its forward ran in — another model of the process (an
+    fp32 teacher, an evaluation copy) keeps its own arithmetic.  Returns the conv math that stays
+    in force OUTSIDE the model (``unwrap_fp16_model`` removes the hooks)."""
     from . import functional as BF
     assert math in ('bf16',), math
-    prev = BF.set_conv_math(math)
+    unwrap_fp16_model(model)
     model._conv_math = math
-    return prev
+    stack = []
+
+    def _enter(_m, _args, _kwargs=None):
+        stack.append(BF.set_conv_math(model._conv_math))
+
+    def _exit(_m, _args, _out):
+        if stack:
+            BF.set_conv_math(stack.pop())
+
+    model._conv_math_hooks = (model.register_forward_pre_hook(_enter),
+                              model.register_forward_hook(_exit, always_call=True))
+    return BF.conv_math()
+
+
+def unwrap_fp16_model(model):
+    for h in getattr(model, '_conv_math_hooks', ()):
+        h.remove()
+    model._conv_math_hooks = ()
+    model._conv_math = None
 
 
 class Fp16OptimizerStep(DistOptimizerStep):

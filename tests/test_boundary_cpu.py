@@ -175,3 +175,48 @@ def test_reference_config_loads_unmodified():
     assert cfg.selectp == 1 and cfg.data.imgs_per_gpu == 2
     assert cfg.train_cfg.rcnn.sampler.num == 512
     assert cfg.optimizer_config.grad_clip.max_norm == 35
+
+
+def test_conv_math_env_is_validated_and_scope_restores():
+    """a typo in BGS_CONV_MATH must raise at import instead of silently selecting the
+    reduced-precision kernels; conv_math_scope restores the mode on exit, also on error."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BGS_CONV_MATH='fp32')
+    r = subprocess.run([sys.executable, '-c', 'import balancedgroupsoftmax_amd.functional'],
+                       env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b'unknown conv math' in r.stderr
+    from balancedgroupsoftmax_amd import functional as BF
+    before = BF.conv_math()
+    with pytest.raises(ValueError):
+        BF.set_conv_math('BF16X6')
+    try:
+        with BF.conv_math_scope('f32'):
+            assert BF.conv_math() == 'f32'
+            raise KeyError('x')
+    except KeyError:
+        pass
+    assert BF.conv_math() == before
+
+
+def test_wrap_fp16_model_is_scoped_to_the_model():
+    """the bf16 mode lives in forward hooks of the wrapped model, not in a process global."""
+    import torch
+    from balancedgroupsoftmax_amd import functional as BF
+    from balancedgroupsoftmax_amd import train
+    seen = []
+
+    class M(torch.nn.Module):
+        def forward(self, x):
+            seen.append(BF.conv_math())
+            return x
+
+    m, other = M(), M()
+    outside = train.wrap_fp16_model(m, 'bf16')
+    assert outside == BF.conv_math() != 'bf16'
+    m(torch.zeros(1))
+    other(torch.zeros(1))
+    assert seen == ['bf16', outside] and BF.conv_math() == outside
+    train.unwrap_fp16_model(m)
+    m(torch.zeros(1))
+    assert seen[-1] == outside

@@ -278,10 +278,15 @@ def test_cascade_bf16_mode_vs_fp32_golden_and_fp16_optimizer_step():
 
     model = build()
     params = train.select_training_param(model, 3)
-    prev = train.wrap_fp16_model(model, 'bf16')
+    outside = train.wrap_fp16_model(model, 'bf16')
     try:
-        assert BF.conv_math() == 'bf16'
+        # the mode is scoped to the wrapped model (as model.half() is): unchanged outside its forward
+        assert BF.conv_math() == outside != 'bf16' and model._conv_math == 'bf16'
+        seen = []
+        probe = model.backbone.register_forward_pre_hook(lambda m, a: seen.append(BF.conv_math()))
         losses = run(model)
+        probe.remove()
+        assert seen == ['bf16'] and BF.conv_math() == outside
         total_exp = float(z['cascade/loss/total'][0])
         worst = 0.0
         for k, v in losses.items():
@@ -310,7 +315,8 @@ def test_cascade_bf16_mode_vs_fp32_golden_and_fp16_optimizer_step():
             assert float(step) > 0
             assert float((a - p.detach()).abs().max()) <= 1e-5 * float(step) + 1e-9
     finally:
-        BF.set_conv_math(prev)
+        train.unwrap_fp16_model(model)
+        assert BF.conv_math() == outside
 
 
 def test_htc_training_iteration_vs_executed_reference_detector():
