@@ -151,6 +151,12 @@ class TwoStageDetector(nn.Module):
         if proposal_cfg is None:
             proposal_cfg = self.test_cfg.rpn
         proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_meta, proposal_cfg)
+        if samplers is not None and 'proposals' in samplers:
+            # test hook (tests/test_gpu_e2e.py, shipped-sampler golden): the RoI stage runs on a
+            # caller-supplied proposal list so that recorded sampler indices name the same boxes on
+            # both sides; the detector's own proposals stay inspectable
+            self._own_proposals = proposal_list
+            proposal_list = samplers['proposals'](proposal_list)
         # the head's stash of its own outputs carries this iteration's autograd graph when the
         # trunk trains (selectp=0): drop it, or the graph (and its AccumulateGrad nodes, bound to
         # the stream they were created on) would outlive the iteration

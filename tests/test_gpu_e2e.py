@@ -474,3 +474,119 @@ def test_mask_rcnn_test_pass_vs_executed_reference_detector():
             worst = max(worst, float(np.abs(masks[j[0]] - z['mask/mask_probs'][k]).max()))
     assert hit >= 48, hit
     assert worst < 2e-3, worst
+
+
+@pytest.mark.parametrize('math', ['bf16x6', 'f32'])
+def test_fullsize_iteration_with_the_shipped_sampler_sizes_and_the_references_recorded_draws(math, monkeypatch):
+    """The configuration ``bench.py`` TIMES — cfg[1] at 2 x 3x800x1344 with the shipped sampler
+    sizes (RPN 256 of 268,569 anchors at 50 % positives, 512 RoI / image at 25 % positives, "others"
+    ratio 8) — against the executed reference (tests/golden/make_golden_shipped.py).  The
+    reference's host-side numpy draws (random_sampler.py:19-53, base_sampler.py:31-78,
+    gs_bbox_head_with0.py:63-89) were RECORDED while it ran as shipped and are injected through the
+    package's sampler hooks; everything else runs on the HIP path.  8 loss terms to 1e-4; the
+    ``fc_cls`` / ``fc_reg`` gradients (no ReLU between them and the loss) to 1e-5 of their largest
+    entry; trunk gradients with the ReLU-flip-tolerant criterion."""
+    from balancedgroupsoftmax_amd import functional as BF
+    from balancedgroupsoftmax_amd import train
+    from tests.golden import make_golden_fullsize as F
+    from tests.golden import make_golden_shipped as T
+    z = np.load(os.path.join(os.path.dirname(T.__file__), 'e2e_train_shipped_samplers_golden.npz'))
+    prev = BF.set_conv_math(math)
+    model = None
+    try:
+        tmp = tempfile.mkdtemp(prefix='bgs_shipped_')
+        model_cfg, train_cfg = T.configs(tmp)
+        assert train_cfg['rpn']['sampler']['num'] == 256 and train_cfg['rcnn']['sampler']['num'] == 512
+        assert model_cfg['bbox_head']['gs_config']['others_sample_ratio'] == 8.0
+        model_cfg['bbox_head']['gs_config']['sampler'] = 'numpy'      # the reference's draw, replayed below
+        model = bgs.build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
+                                   test_cfg=to_config_dict(G.TEST_CFG))
+        with torch.no_grad():
+            det_oracle.fill_detector(model.state_dict(), T.SEED)
+        model.to(DEV)
+        train.select_training_param(model, 0)
+        model.train()
+        calls = dict(rpn=0, rcnn=0, gs=0)
+
+        def rpn_hook(assigned, num, pos_fraction, neg_pos_ub):
+            i = calls['rpn']
+            calls['rpn'] += 1
+            pos = torch.zeros(assigned.numel(), dtype=torch.bool, device=DEV)
+            neg = torch.zeros_like(pos)
+            pi = torch.from_numpy(z['rpn/pos%d' % i].astype(np.int64)).to(DEV)
+            ni = torch.from_numpy(z['rpn/neg%d' % i].astype(np.int64)).to(DEV)
+            # the recorded draws are subsets of THIS path's positive / negative anchors
+            assert bool((assigned[pi] > 0).all()) and bool((assigned[ni] == 0).all())
+            assert len(pi) + len(ni) == num
+            pos[pi] = True
+            neg[ni] = True
+            return pos, neg
+
+        def rcnn_hook(assigned, num, pos_fraction):
+            i = calls['rcnn']
+            calls['rcnn'] += 1
+            pi = torch.from_numpy(z['rcnn/pos%d' % i].astype(np.int64)).to(DEV)
+            ni = torch.from_numpy(z['rcnn/neg%d' % i].astype(np.int64)).to(DEV)
+            assert bool((assigned[pi] > 0).all()) and bool((assigned[ni] == 0).all())
+            inds = torch.cat([pi, ni])
+            assert inds.numel() == num
+            is_pos = torch.cat([torch.ones_like(pi), torch.zeros_like(ni)]).bool()
+            return inds, is_pos, torch.ones(num, dtype=torch.bool, device=DEV)
+
+        def proposals_hook(own):
+            out = []
+            for i, (p, v) in enumerate(own):
+                ref = torch.from_numpy(z['proposals%d' % i]).to(DEV)
+                assert tuple(ref.shape) == tuple(p.shape), (ref.shape, p.shape)
+                frac = match_boxes(p[v].cpu().numpy(), z['proposals%d' % i], tol_px=0.05, tol_score=2e-4)
+                print('image %d: %.4f of the reference proposals reproduced by the HIP RPN' % (i, frac))
+                assert frac >= 0.97, frac
+                out.append((ref.contiguous(), torch.ones(ref.shape[0], dtype=torch.bool, device=DEV)))
+            return out
+
+        def choice_replay(a, size=None, replace=True, p=None):
+            j = calls['gs']
+            calls['gs'] += 1
+            assert len(a) == int(z['gs/cand%d' % j][0]) and not replace
+            draw = z['gs/draw%d' % j].astype(np.int64)
+            assert tuple(np.atleast_1d(size)) == (len(draw),) and np.isin(draw, a).all()
+            return draw
+        monkeypatch.setattr(np.random, 'choice', choice_replay)
+
+        boxes, labels = F.gt()
+        g = torch.Generator().manual_seed(T.SEED)
+        img = torch.randn(F.IMGS, 3, F.H, F.W, generator=g)
+        losses = model(img.to(DEV), F.img_meta(), return_loss=True,
+                       gt_bboxes=[torch.from_numpy(b).to(DEV) for b in boxes],
+                       gt_labels=[torch.from_numpy(l).to(DEV) for l in labels],
+                       samplers=dict(rpn=rpn_hook, rcnn=rcnn_hook, proposals=proposals_hook))
+        assert calls == dict(rpn=2, rcnn=2, gs=4), calls
+        bad = []
+        for k in ['loss_rpn_cls', 'loss_rpn_bbox'] + ['loss_cls_bin%d' % i for i in range(5)] + ['loss_bbox']:
+            v = losses[k]
+            got = np.array([float(t.detach().sum()) for t in (v if isinstance(v, list) else [v])], np.float32)
+            exp = z['loss/' + k]
+            if np.abs(got - exp).max() > 1e-4 * np.abs(exp).max() + 1e-7:
+                bad.append((k, got.tolist(), exp.tolist()))
+        assert not bad, bad
+        loss, _ = train.parse_losses(losses)
+        assert abs(float(loss.detach()) - float(z['loss/total'][0])) < 1e-4 * float(z['loss/total'][0])
+        loss.backward()
+        params = dict(model.named_parameters())
+        bad = []
+        for name, idx in T.GRADS:
+            g = params[name].grad
+            assert g is not None, name
+            a, b = g[idx].cpu().numpy(), z['grad/' + name]
+            if name.startswith(('bbox_head.fc_cls', 'bbox_head.fc_reg')):
+                rel = float(np.abs(a - b).max() / np.abs(b).max())
+                print('%s: max |diff| / max |g| = %.2e' % (name, rel))
+                if rel > 1e-5:
+                    bad.append((name, rel))
+            elif not grad_close(a, b):
+                bad.append(name)
+        assert not bad, bad
+    finally:
+        BF.set_conv_math(prev)
+        del model
+        torch.cuda.empty_cache()
