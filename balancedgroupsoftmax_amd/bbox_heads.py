@@ -365,6 +365,7 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
         self.register_buffer('bin_loss_weight', torch.tensor(
             [float(lb.loss_weight) for lb in self.loss_bins], dtype=torch.float32),
             persistent=False)
+        self._bin_loss_weight_host = [float(lb.loss_weight) for lb in self.loss_bins]
         self.others_sample_ratio = gs.others_sample_ratio
         self.sampler = gs.get('sampler', 'device') if hasattr(gs, 'get') else 'device'
         self.cls_weights = None        # Reweight variant: list of per-bin arrays
@@ -458,21 +459,33 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
                                       'kernel (no detector on the BAGS path requests it)')
         losses = dict()
         n_real = None
+        fused = cls_score is not None and self.sampler == 'device' and \
+            self.cls_weight_table is None and \
+            0 < cls_score.shape[0] <= BF.GS_FUSED_MAX_ROWS and self.num_bins <= 15 and \
+            2 * cls_score.shape[1] * 4 + 2 * cls_score.shape[0] < 60000    # rows + flags in the LDS window
+        if fused and (bbox_pred is None or type(self.loss_bbox).__name__ == 'SmoothL1Loss'):
+            # TWO launches for the whole loss(): label remap + "others" sampling + per-bin losses
+            # (x their loss weights) + gradient + the box branch in the streaming kernel, then the
+            # fixed-order reduce, which also advances the draw counter
+            if self._seed is None:
+                self._seed = (torch.initial_seed() * 0x9E3779B1) & 0xFFFFFFFFFFFFFFFF
+            vec, _avg = BF.gs_head_step(
+                cls_score, labels, self.label2binlabel, self.pred_slice_host,
+                self.others_sample_ratio, self._seed, draw_counter=self._draw,
+                row_weights=label_weights, bin_loss_weight=self._bin_loss_weight_host,
+                bbox_pred=bbox_pred, bbox_targets=bbox_targets, bbox_weights=bbox_weights,
+                num_reg_classes=self.num_reg_classes,
+                beta=self.loss_bbox.beta if bbox_pred is not None else 1.0,
+                box_loss_weight=self.loss_bbox.loss_weight if bbox_pred is not None else 1.0)
+            for i in range(self.num_bins):
+                losses['loss_cls_bin{}'.format(i)] = vec[i]
+            if bbox_pred is not None:
+                losses['loss_bbox'] = vec[self.num_bins]
+            return losses
         if cls_score is not None:
-            if self.sampler == 'device' and self.cls_weight_table is None and \
-                    0 < cls_score.shape[0] <= BF.GS_FUSED_MAX_ROWS and self.num_bins <= 15:
-                # ONE streaming launch: label remap + "others" sampling inside the loss kernel
-                if self._seed is None:
-                    self._seed = (torch.initial_seed() * 0x9E3779B1) & 0xFFFFFFFFFFFFFFFF
-                self._draw += 1
-                per_bin, avg = BF.gs_head_loss_fused(
-                    cls_score, labels, self.label2binlabel, self.pred_slice_host,
-                    self.others_sample_ratio, self._seed, seed_offset=self._draw,
-                    row_weights=label_weights)
-            else:
-                bin_labels, weights, avg = self._remap_labels(labels, label_weights)
-                per_bin = BF.group_softmax_loss(cls_score, bin_labels, self.pred_slice_host,
-                                                weights, avg)
+            bin_labels, weights, avg = self._remap_labels(labels, label_weights)
+            per_bin = BF.group_softmax_loss(cls_score, bin_labels, self.pred_slice_host,
+                                            weights, avg)
             # bin 0 weighs every real row 1 (gs_bbox_head_with0.py:100-102; the reweight variant's
             # tables start at bin 1): its avg factor is max(#real rows, 1)
             n_real = avg[0]

@@ -134,4 +134,36 @@ __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint32_t stream, uin
   return (uint32_t)(x >> 32);
 }
 
+// Sampling keys of the GroupSoftmax "others" draw: one 64-bit hash per (draw, bin) gives a 32-bit
+// salt, the per-row key is the lowbias32 mixer (a bijection of 32-bit words, two multiplies) of
+// row ^ salt — an order of magnitude fewer VALU instructions than a 64-bit hash per row (the fused
+// head kernel evaluates N keys per row and sampled bin), and distinct rows always have distinct
+// keys (no ties inside a bin).
+__device__ __forceinline__ uint32_t gs_bin_salt(uint64_t seed, uint32_t bin) {
+  return hash_u32(seed, bin, 0x5bd1e995u);
+}
+__device__ __forceinline__ uint32_t gs_key(uint32_t salt, uint32_t row) {
+  uint32_t x = row ^ salt;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+// integer wave sum on the DPP path (wave_sum_i above is six dependent ds_bpermute round trips)
+#ifndef BGS_NO_DPP
+// (same recipe as BGS_DPP_REDUCE: only lane 63's value is the full sum)
+__device__ __forceinline__ int wave_sum_i_fast(int v) {
+  v += __builtin_amdgcn_update_dpp(v, v, 0xb1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(v, v, 0x4e, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false);  // row_ror:4
+  v += __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);  // row_ror:8
+  v += __builtin_amdgcn_update_dpp(v, v, 0x142, 0xf, 0xf, false);  // row_bcast:15
+  v += __builtin_amdgcn_update_dpp(v, v, 0x143, 0xf, 0xf, false);  // row_bcast:31
+  return __builtin_amdgcn_readlane(v, 63);
+}
+#else
+__device__ __forceinline__ int wave_sum_i_fast(int v) { return wave_sum_i(v); }
+#endif
+
 }  // namespace bgs

@@ -24,6 +24,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "bgs_common.h"
 #include "gs_rowwave.h"
 
@@ -218,57 +220,172 @@ __global__ __launch_bounds__(kBlock) void gs_scale_grad_kernel(float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused head kernel: _remap_labels + _sample_others (gs_prepare.hip) INSIDE the loss kernel, for
-// N <= 4096 rows and no per-class reweighting — one launch instead of prepare -> boundary -> loss.
-// Every workgroup derives what it needs itself:
-//   prologue (all rows, 8 B per row from L2): per row a 16-bit flag word {real, foreground in bin
-//   b} in LDS and the per-bin foreground counts -> k_b = int(n_fg * ratio), mode_b and, in closed
-//   form, avg_b = max(sum_r w_b[r], 1) = n_real (all-ones modes) | n_fg + k_b (sampled) | 1;
-//   per own row: w_b[r] = foreground, or "rank of (key(b, r), r) among the bin's background rows
-//   < k_b" — the same exact-k, ties-by-row-index selection over the same counter-based keys as
-//   gs_prepare_kernel's radix select, evaluated for ONE row by counting (N / 256 hashes per lane).
-// Results are bitwise those of bgs_gs_prepare + bgs_gs_loss_fwd_bwd (tests/test_gpu_gs.py).
+// Fused head kernel (second version): GSBBoxHeadWith0.loss() in ONE streaming launch —
+//   _remap_labels + _sample_others (gs_bbox_head_with0.py:63-112), the per-bin losses and their
+//   gradient (:160-171), and the box branch (:173-185: SmoothL1 on the positive rows' own class,
+//   optionally its dense [N, 4R] gradient) — for N <= 4096 rows and no per-class reweighting.
+// What the first version got wrong (profiles/r4h: 20 us per 1024-row launch, 4x the plain loss
+// kernel): every one of the N workgroups hashed N 64-bit keys per sampled bin with all four waves
+// and exchanged the rank through LDS + a barrier per bin.  Now:
+//   * prologue, once per workgroup: the 16-bit flag word {real, foreground in bin b} of EVERY row
+//     (8 B of label + B table gathers per row, all loads of a thread's rows in flight together)
+//     and the per-bin foreground counts by wave ballots — no LDS atomics;
+//   * the "others" decision of the workgroup's own row in bin b is taken by THE WAVE THAT OWNS
+//     BIN b (bins are independent, one wave each): rank of the row's key among the bin's background
+//     rows by counting, N / 64 cheap 32-bit keys per lane (bgs::gs_key), one DPP wave sum — no
+//     cross-wave exchange, so a row costs the same two barriers as the plain loss kernel;
+//   * closed forms as before: k_b = int(n_fg * ratio), avg_b = n_real | n_fg + k_b | 1;
+//   * the per-bin loss weights ride in the kernel arguments (coef = w / avg * loss_weight);
+//   * the box branch of the row is four lanes of the last wave.
+// Results are bitwise those of bgs_gs_prepare + bgs_gs_loss_fwd_bwd (+ bgs_bbox_smooth_l1_fwd_bwd)
+// (tests/test_gpu_gs.py).
 constexpr int kFusedMaxN = 4096;
+constexpr int kFusedRowsPerPass = 4;           // rows of the prologue a thread keeps in flight
+__device__ const float g_one = 1.0f;           // "no row_weights": every row reads this 1
 
-template <int VEC, bool WRITE_GRAD>
-__global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(
-    const float* __restrict__ logits, const int64_t* __restrict__ labels,
-    const int64_t* __restrict__ l2b, const float* __restrict__ row_weights, bgs::BinGeom geom,
-    int N, int C, int B, int W, int wpad, double ratio, uint64_t seed,
-    const uint64_t* __restrict__ seed_offset, float* __restrict__ partial,
-    float* __restrict__ dlogits, float* __restrict__ avg_out, int32_t* __restrict__ bl_out,
-    float* __restrict__ w_out) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][wpad] rows (+ slack)
-  __shared__ unsigned short sh_flags[kFusedMaxN];               // bit 15: real row, bit b: fg in bin b
-  __shared__ int sh_cnt[BGS_MAX_BINS + 1];                      // n_fg per bin, [B] = n_real
-  __shared__ int sh_rank[kWaves][BGS_MAX_BINS];
+struct GsHeadArgs {
+  const float* logits;
+  const int64_t* labels;
+  const int64_t* l2b;
+  const float* row_weights;
+  bgs::BinGeom geom;
+  float lw[BGS_MAX_BINS];        // per-bin loss weight (CrossEntropyLoss.loss_weight)
+  int N, C, B, W, wpad;
+  double ratio;
+  uint64_t seed;
+  const uint64_t* seed_offset;
+  float* partial;                // [B + 1][gridDim.x]: per-bin loss partials, then the box partials
+  float* dlogits;
+  float* avg_out;
+  int32_t* bl_out;
+  float* w_out;
+  // box branch (bbox_pred == nullptr: none)
+  const float* bbox_pred;
+  const float* bbox_targets;
+  const float* bbox_weights;
+  float* dbbox;                  // dense [N, 4R] gradient or nullptr
+  int R;
+  float beta, box_w;
+};
+
+__device__ __forceinline__ float gs_sl1(float d, float beta, float& grad) {
+  const float ad = fabsf(d);
+  if (ad < beta) {
+    grad = d / beta;
+    return 0.5f * ad * ad / beta;
+  }
+  grad = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  return ad - 0.5f * beta;
+}
+
+// LDS layout (dynamic): [2][wpad] rows + read slack | flags u16 [N rounded to 8] | counts int
+// [kWaves][MAX_BINS + 1] | box gradient float [4]
+__host__ __device__ inline size_t gs_head_lds_bytes(int N, int wpad) {
+  return sizeof(float) * (2 * (size_t)wpad + BGS_WAVE * bgs::kSweep) + 2 * (size_t)((N + 7) & ~7) +
+         sizeof(int) * kWaves * (BGS_MAX_BINS + 1) + sizeof(float) * 4;
+}
+
+template <int VEC, bool WRITE_GRAD, bool BOX>
+__global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = a.N, C = a.C, B = a.B, W = a.W, wpad = a.wpad;
+  unsigned short* sh_flags = reinterpret_cast<unsigned short*>(smem + 2 * (size_t)wpad + BGS_WAVE * bgs::kSweep);
+  int* sh_cntw = reinterpret_cast<int*>(sh_flags + ((N + 7) & ~7));
+  float* sh_box = reinterpret_cast<float*>(sh_cntw + kWaves * (BGS_MAX_BINS + 1));
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = bgs::uniform(tid >> 6);
-  if (seed_offset) seed += 0x2545F4914F6CDD1Dull * seed_offset[0];   // device-side draw counter
+  uint64_t seed = a.seed;
+  if (a.seed_offset) seed += 0x2545F4914F6CDD1Dull * a.seed_offset[0];   // device-side draw counter
 
-  // ---- prologue: flags of every row + per-bin foreground counts
-  if (tid <= BGS_MAX_BINS) sh_cnt[tid] = 0;
-  __syncthreads();
-  for (int r = tid; r < N; r += kBlock) {
-    int64_t y = labels[r];
-    y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
-    const bool real = !row_weights || row_weights[r] > 0.f;
-    unsigned bits = 0u;
-    for (int b = 0; b < B; ++b)
-      if (l2b[(size_t)b * C + y] > 0) bits |= 1u << b;
-    if (real) {
-      atomicAdd(&sh_cnt[B], 1);
-      for (unsigned m = bits; m; m &= m - 1) atomicAdd(&sh_cnt[__builtin_ctz(m)], 1);
+  // ---- prologue: flag word of every row, per-bin foreground counts (lane b <= B of every wave
+  //      counts bin b over the wave's share of the rows; b == B: real rows).  Written as
+  //      straight-line passes of kFusedRowsPerPass rows per thread with UNCONDITIONAL loads
+  //      (addresses are selected, not the loads: a branch around a load makes hipcc wait for it
+  //      where it is issued): the label / row-weight loads of a pass and — in pass 0 — the
+  //      workgroup's first logits row are in flight together, then the B table gathers of all rows.
+  int mycnt = 0;
+  const float* rw_base = a.row_weights ? a.row_weights : &g_one;
+  const int rw_step = a.row_weights ? 1 : 0;
+  auto prologue_pass = [&](int base, auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    int64_t y[kFusedRowsPerPass];
+    float rwv[kFusedRowsPerPass];
+#pragma unroll
+    for (int i = 0; i < kFusedRowsPerPass; ++i) {
+      const int r = base + tid + kBlock * i;
+      const int rc = r < N ? r : 0;
+      y[i] = a.labels[rc];
+      rwv[i] = rw_base[(size_t)rc * rw_step];
     }
-    sh_flags[r] = (unsigned short)(real ? (bits | 0x8000u) : 0u);
-  }
-  __syncthreads();
+    float t0[VEC], t1[VEC];
+    const int c0 = tid * VEC, c1 = c0 + kBlock * VEC;
+    if (FIRST) {   // (W >= VEC * kBlock is not required: out-of-range lanes re-read column 0)
+      const float* g = a.logits + (size_t)blockIdx.x * W;
+      bgs::load_vec<VEC>(g + (c0 < W ? c0 : 0), t0);
+      bgs::load_vec<VEC>(g + (c1 < W ? c1 : 0), t1);
+    }
+    unsigned bits[kFusedRowsPerPass];
+#pragma unroll
+    for (int i = 0; i < kFusedRowsPerPass; ++i) {
+      y[i] = y[i] < 0 ? 0 : (y[i] >= C ? (int64_t)C - 1 : y[i]);
+      bits[i] = 0u;
+    }
+    for (int b0 = 0; b0 < B; b0 += 8) {     // groups of 8 bins: 8 x kFusedRowsPerPass gathers in flight
+      int64_t v[8][kFusedRowsPerPass];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int bc = b0 + j < B ? b0 + j : 0;   // bins past B re-read bin 0 (same cache lines)
+#pragma unroll
+        for (int i = 0; i < kFusedRowsPerPass; ++i) v[j][i] = a.l2b[(size_t)bc * C + y[i]];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < kFusedRowsPerPass; ++i)
+          if (b0 + j < B && v[j][i] > 0) bits[i] |= 1u << (b0 + j);
+    }
+    if (FIRST) {
+      if (c0 < W) bgs::store_vec<VEC>(smem + c0, t0);
+      if (c1 < W) bgs::store_vec<VEC>(smem + c1, t1);
+      for (int c = c1 + kBlock * VEC; c < W; c += kBlock * VEC) {   // rows wider than 2 x 256 x VEC
+        float t[VEC];
+        bgs::load_vec<VEC>(a.logits + (size_t)blockIdx.x * W + c, t);
+        bgs::store_vec<VEC>(smem + c, t);
+      }
+    }
+    bool real[kFusedRowsPerPass];
+#pragma unroll
+    for (int i = 0; i < kFusedRowsPerPass; ++i) {
+      const int r = base + tid + kBlock * i;
+      real[i] = r < N && rwv[i] > 0.f;
+      if (r < N) sh_flags[r] = (unsigned short)(real[i] ? (bits[i] | 0x8000u) : 0u);
+    }
+    for (int b = 0; b <= B; ++b) {
+      int pop = 0;
+#pragma unroll
+      for (int i = 0; i < kFusedRowsPerPass; ++i)
+        pop += __popcll(__builtin_amdgcn_ballot_w64(real[i] && (b == B || ((bits[i] >> b) & 1u))));
+      if (lane == b) mycnt += pop;
+    }
+  };
+  prologue_pass(0, std::true_type{});
+  for (int base = kBlock * kFusedRowsPerPass; base < N; base += kBlock * kFusedRowsPerPass)
+    prologue_pass(base, std::false_type{});
+  if (lane <= B) sh_cntw[wave * (BGS_MAX_BINS + 1) + lane] = mycnt;
+  __syncthreads();                        // flags, counts and the first row are in LDS
+
   // lane b < B of every wave: constants of bin b (gs_prepare_kernel's mode / k / avg)
-  int my_mode = 0, my_k = 0;          // 0 = all zero, 1 = all one, 2 = sampled
-  float my_inv_avg = 0.f;
+  int my_mode = 0, my_k = 0;              // 0 = all zero, 1 = all one, 2 = sampled
+  float my_scale = 0.f;                   // loss_weight / avg
+  int n_real = 0;
+#pragma unroll
+  for (int v = 0; v < kWaves; ++v) n_real += sh_cntw[v * (BGS_MAX_BINS + 1) + B];
   if (lane < B) {
-    const int n_real = sh_cnt[B], n_fg = sh_cnt[lane], n_bg = n_real - n_fg;
+    int n_fg = 0;
+#pragma unroll
+    for (int v = 0; v < kWaves; ++v) n_fg += sh_cntw[v * (BGS_MAX_BINS + 1) + lane];
+    const int n_bg = n_real - n_fg;
     float total;
     if (lane == 0) {
       my_mode = 1;
@@ -277,71 +394,62 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(
       my_mode = 0;
       total = 0.f;
     } else {
-      my_k = (int)((double)n_fg * ratio);
+      my_k = (int)((double)n_fg * a.ratio);
       my_mode = (my_k >= n_bg) ? 1 : 2;
       total = my_mode == 1 ? (float)n_real : (float)(n_fg + my_k);
     }
-    const float a = fmaxf(total, 1.f);
-    my_inv_avg = 1.f / a;
-    if (blockIdx.x == 0 && wave == 0 && avg_out) avg_out[lane] = a;
+    const float av = fmaxf(total, 1.f);
+    my_scale = (1.f / av) * a.lw[lane];
+    if (blockIdx.x == 0 && wave == 0 && a.avg_out) a.avg_out[lane] = av;
   }
-  float lacc = 0.f;
+  const float box_scale = a.box_w / fmaxf((float)n_real, 1.f);
+  float lacc = 0.f, box_acc = 0.f;
 
   int par = 0;
   for (int r = blockIdx.x; r < N; r += gridDim.x, par ^= 1) {
     float* row = smem + (size_t)par * wpad;
-    bgs::stage_row<VEC>(logits + (size_t)r * W, row, W, tid, kBlock);
+    const bool first = r == (int)blockIdx.x;
+    if (!first) bgs::stage_row<VEC>(a.logits + (size_t)r * W, row, W, tid, kBlock);
     const unsigned fr = sh_flags[r];
-    // ---- sampling decision of this row in the sampled bins: rank among the bin's background rows
-    for (int b = 1; b < B; ++b) {
-      const int mode_b = __builtin_amdgcn_readlane(my_mode, b);
-      const bool need = mode_b == 2 && (fr & 0x8000u) && !((fr >> b) & 1u);   // block-uniform
-      int cnt = 0;
-      if (need) {
-        const unsigned mine = bgs::hash_u32(seed, (uint32_t)b, (uint32_t)r);
-        for (int q = tid; q < N; q += kBlock) {
-          const unsigned f = sh_flags[q];
-          if ((f & 0x8000u) && !((f >> b) & 1u)) {
-            const unsigned key = bgs::hash_u32(seed, (uint32_t)b, (uint32_t)q);
-            cnt += (key < mine || (key == mine && q < r)) ? 1 : 0;
-          }
-        }
-        cnt = bgs::wave_sum_i(cnt);
-      }
-      if (lane == 0) sh_rank[wave][b] = cnt;
-    }
-    int64_t yr = labels[r];
-    yr = yr < 0 ? 0 : (yr >= C ? (int64_t)C - 1 : yr);
+    const bool real_r = (fr & 0x8000u) != 0u;
+    const int64_t yraw = a.labels[r];
+    const int64_t yr = yraw < 0 ? 0 : (yraw >= C ? (int64_t)C - 1 : yraw);
     int my_bl = 0;
-    if (lane < B) my_bl = (int)l2b[(size_t)lane * C + yr];
-    __syncthreads();                      // row staged + ranks published
-    float my_coef = 0.f;
-    if (lane < B) {
+    if (lane < B) my_bl = (int)a.l2b[(size_t)lane * C + yr];
+    if (!first) __syncthreads();          // row staged (the previous row left through the other buffer)
+    for (int b = wave; b < B; b += kWaves) {  // bins are independent: one wave each
+      const int s = a.geom.start[b], n = a.geom.len[b];
+      const int mode_b = __builtin_amdgcn_readlane(my_mode, b);
+      const int bl_b = __builtin_amdgcn_readlane(my_bl, b);
       float w = 0.f;
-      if (fr & 0x8000u) {
-        if (my_mode == 1) {
+      if (real_r) {
+        if (mode_b == 1 || (mode_b == 2 && bl_b > 0)) {
           w = 1.f;
-        } else if (my_mode == 2) {
-          if (my_bl > 0) {
-            w = 1.f;
-          } else {
-            int rank = 0;
+        } else if (mode_b == 2) {
+          // rank of (key, row) among the background rows of bin b: selected iff rank < k_b
+          const int k_b = __builtin_amdgcn_readlane(my_k, b);
+          const unsigned salt = bgs::gs_bin_salt(seed, (uint32_t)b);
+          const unsigned mine = bgs::gs_key(salt, (uint32_t)r);
+          int cnt = 0;
+          for (int q0 = lane; q0 < N; q0 += BGS_WAVE * 4) {
 #pragma unroll
-            for (int v = 0; v < kWaves; ++v) rank += sh_rank[v][lane];
-            w = rank < my_k ? 1.f : 0.f;
+            for (int u = 0; u < 4; ++u) {
+              const int q = q0 + BGS_WAVE * u;
+              const unsigned f = sh_flags[q < N ? q : 0];
+              const bool cand = q < N && (f & 0x8000u) && !((f >> b) & 1u);
+              const unsigned key = bgs::gs_key(salt, (uint32_t)q);
+              cnt += (cand && (key < mine || (key == mine && q < r))) ? 1 : 0;
+            }
           }
+          w = bgs::wave_sum_i_fast(cnt) < k_b ? 1.f : 0.f;
         }
       }
-      my_coef = w * my_inv_avg;
-      if (wave == 0) {
-        if (bl_out) bl_out[(size_t)lane * N + r] = my_bl;
-        if (w_out) w_out[(size_t)lane * N + r] = w;
+      const float coef = w * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_scale), b));
+      if (lane == 0) {
+        if (a.bl_out) a.bl_out[(size_t)b * N + r] = bl_b;
+        if (a.w_out) a.w_out[(size_t)b * N + r] = w;
       }
-    }
-    for (int b = wave; b < B; b += kWaves) {  // bins are independent: one wave each
-      const int s = geom.start[b], n = geom.len[b];
-      const float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_coef), b));
-      const int tgt = min(max(__builtin_amdgcn_readlane(my_bl, b), 0), n - 1);
+      const int tgt = min(max(bl_b, 0), n - 1);
       float* seg = row + s;
       if (coef == 0.f) {
         if (WRITE_GRAD)
@@ -360,11 +468,108 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(
       }
       if (lane == b) lacc += term;
     }
-    __syncthreads();                      // gradient row complete; sh_rank free for the next row
-    if (WRITE_GRAD) bgs::unstage_row<VEC>(row, dlogits + (size_t)r * W, W, tid, kBlock);
+    // ---- box branch of this row (bbox_head.py:117-129 / gs_bbox_head_with0.py:173-185): the
+    //      positive row's own class slot, four lanes of the last wave
+    const int64_t slot = (a.R == 1) ? 0 : yraw;
+    const bool pos = BOX && yraw > 0 && slot < a.R;
+    if (BOX && wave == kWaves - 1) {
+      float val = 0.f, g = 0.f;
+      if (pos && lane < 4) {
+        const float p = a.bbox_pred[((size_t)r * a.R + (size_t)slot) * 4 + lane];
+        const float t = a.bbox_targets[(size_t)r * 4 + lane];
+        const float bw = a.bbox_weights[(size_t)r * 4 + lane];
+        val = gs_sl1(p - t, a.beta, g) * bw;
+        g = g * bw * box_scale;
+      }
+      val = bgs::wave_sum(val);
+      if (lane == 0) box_acc += val;
+      if (a.dbbox && lane < 4) sh_box[lane] = g;
+    }
+    __syncthreads();                      // gradient row (and the box gradient) complete
+    if (WRITE_GRAD) bgs::unstage_row<VEC>(row, a.dlogits + (size_t)r * W, W, tid, kBlock);
+    if (BOX && a.dbbox) {                 // dense [N, 4R] gradient: zeros but for the positive slot
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const f32x4 gp = {sh_box[0], sh_box[1], sh_box[2], sh_box[3]};
+      f32x4* drow = reinterpret_cast<f32x4*>(a.dbbox + (size_t)r * a.R * 4);
+      for (int c = tid; c < a.R; c += kBlock)
+        drow[c] = (pos && c == (int)slot) ? gp : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (r + (int)gridDim.x < N) __syncthreads();   // sh_box is rewritten by the next row
+    }
   }
   if (lane < B && (lane % kWaves) == wave)
-    partial[(size_t)lane * gridDim.x + blockIdx.x] = lacc;
+    a.partial[(size_t)lane * gridDim.x + blockIdx.x] = lacc;
+  if (BOX && wave == kWaves - 1 && lane == 0)
+    a.partial[(size_t)B * gridDim.x + blockIdx.x] = box_acc;
+}
+
+// out[b] = sum_g partial[b][g] for b < B (loss weights are already inside), out[B] = box loss
+// (scaled by loss_weight / avg[0]; 0 without a box branch), out[B + 1] = their sum — the scalar the
+// reference forms in parse_losses; fixed summation order.  `counter` (the device draw counter read
+// by the NEXT call's main kernel) is advanced here, behind every reader of this call.
+__global__ __launch_bounds__(1024) void gs_head_reduce_kernel(const float* __restrict__ partial, int G,
+                                                              int B, int has_box, float box_w,
+                                                              const float* __restrict__ avg,
+                                                              float* __restrict__ out,
+                                                              uint64_t* __restrict__ counter) {
+  __shared__ float sm[BGS_MAX_BINS + 1][16];
+  __shared__ float fin[BGS_MAX_BINS + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rows = B + (has_box ? 1 : 0);
+  for (int b = 0; b < rows; ++b) {
+    float acc = 0.f;
+    for (int g = tid; g < G; g += 1024) acc += partial[(size_t)b * G + g];
+    const float s = bgs::wave_sum(acc);
+    if (lane == 0) sm[b][wave] = s;
+  }
+  __syncthreads();
+  if (tid <= B) {
+    float s = 0.f;
+    if (tid < rows) {
+#pragma unroll
+      for (int w = 0; w < 16; ++w) s += sm[tid][w];
+      if (tid == B) s *= box_w / avg[0];
+    }
+    fin[tid] = s;
+    out[tid] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int b = 0; b <= B; ++b) t += fin[b];
+    out[B + 1] = t;
+    if (counter) counter[0] += 1ull;
+  }
+}
+
+// dlogits[:, bin b] *= g[b] + g[B + 1];  dbbox *= g[B] + g[B + 1]  (g = the upstream gradient of
+// the [B + 2] loss vector {bins, box, total}); early-out when every factor is 1 (the usual case).
+__global__ __launch_bounds__(kBlock) void gs_head_scale_grad_kernel(float* __restrict__ dlogits,
+                                                                    float* __restrict__ dbbox,
+                                                                    bgs::BinGeom geom,
+                                                                    const float* __restrict__ g, int N,
+                                                                    int B, int W, int R4) {
+  const float gt = g[B + 1];
+  bool all_one = true;
+  for (int b = 0; b < B; ++b) all_one = all_one && (g[b] + gt == 1.f);
+  const float gbox = g[B] + gt;
+  extern __shared__ __attribute__((aligned(16))) float scale[];
+  if (dlogits && !all_one) {
+    for (int c = threadIdx.x; c < W; c += kBlock) {
+      float sc = 0.f;
+      for (int b = 0; b < B; ++b)
+        if (c >= geom.start[b] && c < geom.start[b] + geom.len[b]) sc = g[b] + gt;
+      scale[c] = sc;
+    }
+    __syncthreads();
+    const size_t total = (size_t)N * W;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock)
+      dlogits[i] *= scale[(int)(i % (size_t)W)];
+  }
+  if (dbbox && gbox != 1.f) {
+    const size_t total = (size_t)N * R4;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock)
+      dbbox[i] *= gbox;
+  }
 }
 
 template <int VEC>
@@ -390,7 +595,7 @@ inline int loss_grid(int N) { return N <= 0 ? 1 : (N < kMaxGrid ? N : kMaxGrid);
 extern "C" size_t bgs_gs_loss_workspace_bytes(int N, int B) {
   (void)N;
   (void)B;
-  return (size_t)kMaxGrid * BGS_MAX_BINS * sizeof(float);
+  return (size_t)kMaxGrid * (BGS_MAX_BINS + 1) * sizeof(float);
 }
 
 // Test hook: BGS_GS_FORCE_GENERIC=1 (read at every call) routes through the fallback kernel.
@@ -445,10 +650,50 @@ extern "C" int bgs_gs_loss_fwd_bwd(const float* logits, const int32_t* bin_label
   BGS_RETURN_LAUNCH_STATUS();
 }
 
+namespace {
+
+// shared launcher of the fused head kernel; returns the grid in *grid_out
+int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* host_bin_loss_weight,
+                   hipStream_t st, int* grid_out) {
+  if (a.N <= 0 || a.C <= 0 || a.B <= 0 || a.W <= 0) return BGS_ERR_INVALID_ARG;
+  if (a.B > BGS_MAX_BINS - 1 || a.N > kFusedMaxN) return BGS_ERR_UNSUPPORTED;
+  int tiles = 0;
+  const int rc = bgs::make_bin_geom(host_pred_slice, a.B, a.W, &a.geom, &tiles);
+  if (rc != BGS_OK) return rc;
+  if (!tiles) return BGS_ERR_UNSUPPORTED;
+  for (int b = 0; b < BGS_MAX_BINS; ++b)
+    a.lw[b] = (host_bin_loss_weight && b < a.B) ? host_bin_loss_weight[b] : 1.f;
+  a.wpad = (a.W + 3) & ~3;
+  const size_t lds = gs_head_lds_bytes(a.N, a.wpad);
+  if (lds > 64 * 1024) return BGS_ERR_UNSUPPORTED;      // the default LDS window (callers fall back
+                                                         // to bgs_gs_prepare + bgs_gs_loss_fwd_bwd)
+  const int grid = loss_grid(a.N);
+  *grid_out = grid;
+  const uintptr_t al = (uintptr_t)a.logits | (uintptr_t)(a.dlogits ? a.dlogits : a.logits);
+  const bool grad = a.dlogits != nullptr;
+  const bool box = a.bbox_pred != nullptr;
+#define BGS_HEAD_LAUNCH(VEC_, GRAD_, BOX_)                                                       \
+  hipLaunchKernelGGL((gs_head_fused_kernel<VEC_, GRAD_, BOX_>), dim3(grid), dim3(kBlock), lds, st, a)
+#define BGS_HEAD_VEC(VEC_)                                                                        \
+  do {                                                                                            \
+    if (grad) { if (box) BGS_HEAD_LAUNCH(VEC_, true, true); else BGS_HEAD_LAUNCH(VEC_, true, false); }   \
+    else { if (box) BGS_HEAD_LAUNCH(VEC_, false, true); else BGS_HEAD_LAUNCH(VEC_, false, false); }      \
+  } while (0)
+  if (a.W % 4 == 0 && al % 16 == 0) BGS_HEAD_VEC(4);
+  else if (a.W % 2 == 0 && al % 8 == 0) BGS_HEAD_VEC(2);
+  else BGS_HEAD_VEC(1);
+#undef BGS_HEAD_VEC
+#undef BGS_HEAD_LAUNCH
+  return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
+}
+
+}  // namespace
+
 // _remap_labels + _sample_others + loss forward + backward in ONE launch (+ the partial reduce):
 // see gs_head_fused_kernel.  N <= 4096, bins must tile [0, W), no per-class reweighting (those
-// cases use bgs_gs_prepare + bgs_gs_loss_fwd_bwd).  avg_out [B] is always written (the box loss
-// normaliser reads bin 0's); bin_labels_out / weights_out [B, N] are optional (tests).
+// cases use bgs_gs_prepare + bgs_gs_loss_fwd_bwd; BGS_ERR_UNSUPPORTED also when the rows do not fit
+// the 64 KB LDS window).  avg_out [B] is always written (the box loss normaliser reads bin 0's);
+// bin_labels_out / weights_out [B, N] are optional (tests).
 extern "C" int bgs_gs_head_loss_fused(const float* logits, const int64_t* labels,
                                       const int64_t* label2binlabel, const float* row_weights,
                                       const int64_t* host_pred_slice, int N, int C, int B, int W,
@@ -456,34 +701,83 @@ extern "C" int bgs_gs_head_loss_fused(const float* logits, const int64_t* labels
                                       const uint64_t* seed_offset, float* loss_out, float* dlogits,
                                       float* avg_out, int32_t* bin_labels_out, float* weights_out,
                                       void* workspace, bgs_stream_t stream) {
-  if (N <= 0 || C <= 0 || B <= 0 || W <= 0) return BGS_ERR_INVALID_ARG;
-  if (B > BGS_MAX_BINS - 1 || N > kFusedMaxN) return BGS_ERR_UNSUPPORTED;
   if (!logits || !labels || !label2binlabel || !host_pred_slice || !loss_out || !avg_out || !workspace)
     return BGS_ERR_INVALID_ARG;
-  bgs::BinGeom geom;
-  int tiles = 0;
-  const int rc = bgs::make_bin_geom(host_pred_slice, B, W, &geom, &tiles);
+  GsHeadArgs a = {};
+  a.logits = logits; a.labels = labels; a.l2b = label2binlabel; a.row_weights = row_weights;
+  a.N = N; a.C = C; a.B = B; a.W = W; a.ratio = others_sample_ratio; a.seed = seed;
+  a.seed_offset = seed_offset; a.partial = (float*)workspace; a.dlogits = dlogits;
+  a.avg_out = avg_out; a.bl_out = bin_labels_out; a.w_out = weights_out;
+  int grid = 0;
+  const int rc = launch_gs_head(a, host_pred_slice, nullptr, (hipStream_t)stream, &grid);
   if (rc != BGS_OK) return rc;
-  if (!tiles || W > 7936) return BGS_ERR_UNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
-  float* partial = (float*)workspace;
-  const int grid = loss_grid(N);
-  const uintptr_t al = (uintptr_t)logits | (uintptr_t)(dlogits ? dlogits : logits);
-  const int wpad = (W + 3) & ~3;
-  const size_t lds = sizeof(float) * (2 * (size_t)wpad + BGS_WAVE * bgs::kSweep);
-#define BGS_FUSED_LAUNCH(VEC_, GRAD_)                                                             \
-  hipLaunchKernelGGL((gs_head_fused_kernel<VEC_, GRAD_>), dim3(grid), dim3(kBlock), lds, st, logits, \
-                     labels, label2binlabel, row_weights, geom, N, C, B, W, wpad,                  \
-                     others_sample_ratio, seed, seed_offset, partial, dlogits, avg_out,            \
-                     bin_labels_out, weights_out)
-  const bool grad = dlogits != nullptr;
-  if (W % 4 == 0 && al % 16 == 0) { if (grad) BGS_FUSED_LAUNCH(4, true); else BGS_FUSED_LAUNCH(4, false); }
-  else if (W % 2 == 0 && al % 8 == 0) { if (grad) BGS_FUSED_LAUNCH(2, true); else BGS_FUSED_LAUNCH(2, false); }
-  else { if (grad) BGS_FUSED_LAUNCH(1, true); else BGS_FUSED_LAUNCH(1, false); }
-#undef BGS_FUSED_LAUNCH
-  if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, st, partial, grid, B, loss_out,
-                     1.0f);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a.partial,
+                     grid, B, loss_out, 1.0f);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+// The whole GSBBoxHeadWith0.loss() (gs_bbox_head_with0.py:147-186) as two launches:
+//   main kernel  = label remap + "others" sampling + per-bin loss fwd + bwd + the box branch
+//   reduce       = loss_out[0..B-1] per-bin losses (x bin_loss_weight), loss_out[B] = loss_bbox
+//                  (x box_loss_weight / #real rows), loss_out[B+1] = their sum; advances
+//                  *draw_counter (device uint64, read by the main kernel as the draw index).
+// bbox_pred == NULL: no box branch (loss_out[B] = 0).  dbbox_pred (dense [N, 4R] gradient) only
+// when the box branch trains.  loss_out == NULL: main kernel only (profiling hook; the counter is
+// not advanced).  Same limits as bgs_gs_head_loss_fused.
+extern "C" int bgs_gs_head_step(const float* logits, const int64_t* labels,
+                                const int64_t* label2binlabel, const float* row_weights,
+                                const int64_t* host_pred_slice, const float* host_bin_loss_weight,
+                                int N, int C, int B, int W, double others_sample_ratio,
+                                uint64_t seed, uint64_t* draw_counter, const float* bbox_pred,
+                                const float* bbox_targets, const float* bbox_weights,
+                                int num_reg_classes, float beta, float box_loss_weight,
+                                float* loss_out, float* dlogits, float* dbbox_pred, float* avg_out,
+                                int32_t* bin_labels_out, float* weights_out, void* workspace,
+                                bgs_stream_t stream) {
+  if (!logits || !labels || !label2binlabel || !host_pred_slice || !avg_out || !workspace)
+    return BGS_ERR_INVALID_ARG;
+  if (bbox_pred) {
+    if (!bbox_targets || !bbox_weights || num_reg_classes <= 0 || !(beta > 0.f)) return BGS_ERR_INVALID_ARG;
+    if (((uintptr_t)bbox_pred | (uintptr_t)bbox_targets | (uintptr_t)bbox_weights |
+         (uintptr_t)dbbox_pred) % 16 != 0)
+      return BGS_ERR_INVALID_ARG;
+  } else if (dbbox_pred) {
+    return BGS_ERR_INVALID_ARG;
+  }
+  GsHeadArgs a = {};
+  a.logits = logits; a.labels = labels; a.l2b = label2binlabel; a.row_weights = row_weights;
+  a.N = N; a.C = C; a.B = B; a.W = W; a.ratio = others_sample_ratio; a.seed = seed;
+  a.seed_offset = draw_counter; a.partial = (float*)workspace; a.dlogits = dlogits;
+  a.avg_out = avg_out; a.bl_out = bin_labels_out; a.w_out = weights_out;
+  a.bbox_pred = bbox_pred; a.bbox_targets = bbox_targets; a.bbox_weights = bbox_weights;
+  a.dbbox = dbbox_pred; a.R = num_reg_classes; a.beta = beta; a.box_w = box_loss_weight;
+  int grid = 0;
+  const int rc = launch_gs_head(a, host_pred_slice, host_bin_loss_weight, (hipStream_t)stream, &grid);
+  if (rc != BGS_OK || !loss_out) return rc;
+  hipLaunchKernelGGL(gs_head_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a.partial,
+                     grid, B, bbox_pred ? 1 : 0, box_loss_weight, avg_out, loss_out, draw_counter);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+// Backward of bgs_gs_head_step's loss vector: grad_loss [B + 2] = upstream gradient of {bins, box,
+// total}; scales dlogits per bin by grad[b] + grad[B+1] and dbbox_pred by grad[B] + grad[B+1] in
+// place (one launch, early-out when every factor is 1).
+extern "C" int bgs_gs_head_step_scale_grad(float* dlogits, float* dbbox_pred,
+                                           const int64_t* host_pred_slice, const float* grad_loss,
+                                           int N, int B, int W, int num_reg_classes,
+                                           bgs_stream_t stream) {
+  if (N < 0 || B <= 0 || W <= 0 || B > BGS_MAX_BINS - 1) return BGS_ERR_INVALID_ARG;
+  if (N == 0 || (!dlogits && !dbbox_pred)) return BGS_OK;
+  if (!host_pred_slice || !grad_loss) return BGS_ERR_INVALID_ARG;
+  bgs::BinGeom geom;
+  const int rc = bgs::make_bin_geom(host_pred_slice, B, W, &geom, nullptr);
+  if (rc != BGS_OK) return rc;
+  const size_t total = (size_t)N * (dbbox_pred ? (size_t)num_reg_classes * 4 : (size_t)W);
+  size_t blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gs_head_scale_grad_kernel, dim3((unsigned)blocks), dim3(kBlock),
+                     sizeof(float) * (size_t)W, (hipStream_t)stream, dlogits, dbbox_pred, geom,
+                     grad_loss, N, B, W, num_reg_classes * 4);
   BGS_RETURN_LAUNCH_STATUS();
 }
 

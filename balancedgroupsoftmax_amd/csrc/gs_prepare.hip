@@ -10,7 +10,7 @@
 //   bl[r]  = label2binlabel[b, labels[r]]                       (int64 gather, bit-exact)
 //   n_fg   = #{bl > 0};  k = int(n_fg * ratio);  M = N - n_fg
 //   n_fg == 0 -> w = 0;   k >= M -> w = 1;   else  w = fg OR (row is among the k smallest
-//   32-bit counter-based random keys of the non-fg rows)  == uniform sampling of exactly k
+//   32-bit counter-based random keys (bgs::gs_key) of the non-fg rows)  == uniform sampling of exactly k
 //   rows without replacement (ties broken by row index), found by a 4-pass radix select.
 //   avg    = max(sum_r w[r], 1)
 // Fixed-shape batches: `row_weights` (the detector's label_weights) marks padding slots with a
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t* map = l2b + (size_t)b * C;
   if (seed_offset) seed += 0x2545F4914F6CDD1Dull * seed_offset[0];  // device-side draw counter
+  const unsigned salt = bgs::gs_bin_salt(seed, (uint32_t)b);          // keys: bgs::gs_key(salt, row)
 
   // pass 0: bin labels + foreground count (+ number of real rows)
   int nfg_local = 0, nreal_local = 0;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
         int64_t y = labels[r];
         y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
         if (map[y] > 0 || (row_weights && !(row_weights[r] > 0.f))) continue;
-        const unsigned key = bgs::hash_u32(seed, (uint32_t)b, (uint32_t)r);
+        const unsigned key = bgs::gs_key(salt, (uint32_t)r);
         if ((key & himask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 0xFFu], 1);
       }
       __syncthreads();
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
           int64_t y = labels[r];
           y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
           if (map[y] > 0 || (row_weights && !(row_weights[r] > 0.f))) continue;
-          if (bgs::hash_u32(seed, (uint32_t)b, (uint32_t)r) == T) {
+          if (bgs::gs_key(salt, (uint32_t)r) == T) {
             if (++got == need) { bound = r + 1; break; }
           }
         }
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
       if (mode == 2) {
         sel = bl > 0;
         if (!sel && k > 0) {
-          const unsigned key = bgs::hash_u32(seed, (uint32_t)b, (uint32_t)r);
+          const unsigned key = bgs::gs_key(salt, (uint32_t)r);
           sel = (key < T) || (key == T && r < tie_bound);
         }
       }

@@ -5,6 +5,7 @@ edges.  All arithmetic happens in the hand-written gfx950 kernels of ``libbgs.so
 Every wrapper requires CUDA(ROCm) tensors and raises otherwise — there is no CPU
 path in the product.
 """
+import ctypes
 import itertools
 import os
 
@@ -193,6 +194,103 @@ class _GsHeadFusedLoss(torch.autograd.Function):
     def backward(ctx, grad_loss, *_unused):
         out = _GroupSoftmaxLoss.backward(ctx, grad_loss)[0]
         return (out,) + (None,) * 8
+
+
+class _GsHeadStepFn(torch.autograd.Function):
+    """``bgs_gs_head_step``: the whole ``GSBBoxHeadWith0.loss()`` as main kernel + reduce.  Returns
+    the loss vector ``[B + 2]`` = {per-bin losses (x loss weights), loss_bbox, their sum} and
+    ``avg [B]``; backward is ONE scaling launch over the gradients the forward already produced
+    (early-out on the device when the upstream factors are 1)."""
+
+    @staticmethod
+    def forward(ctx, logits, bbox_pred, labels, l2b, pred_slice_host, bin_loss_weight_host, ratio,
+                seed, counter, row_weights, bbox_targets, bbox_weights, num_reg_classes, beta,
+                box_loss_weight, debug):
+        import numpy as np
+        lib = capi.load()
+        z = _f32c(logits)
+        N, W = z.shape
+        B, C = l2b.shape
+        dev = z.device
+        box = bbox_pred is not None
+        p = _f32c(bbox_pred) if box else None
+        R = int(num_reg_classes) if box else 1
+        if box:
+            assert tuple(p.shape) == (N, 4 * R), (p.shape, N, R)
+        loss = torch.empty((B + 2,), dtype=torch.float32, device=dev)
+        avg = torch.empty((B,), dtype=torch.float32, device=dev)
+        dlogits = torch.empty_like(z) if logits.requires_grad else None
+        dbbox = torch.empty_like(p) if (box and bbox_pred.requires_grad) else None
+        bl = torch.empty((B, N), dtype=torch.int32, device=dev) if debug else None
+        w = torch.empty((B, N), dtype=torch.float32, device=dev) if debug else None
+        ws = _workspace(lib.bgs_gs_loss_workspace_bytes(N, B), dev)
+        ps_keep, ps_ptr = capi.host_i64(pred_slice_host)
+        lw_keep = None if bin_loss_weight_host is None else \
+            np.ascontiguousarray(bin_loss_weight_host, dtype=np.float32)
+        lw_ptr = None if lw_keep is None else lw_keep.ctypes.data_as(ctypes.c_void_p)
+        rw = None if row_weights is None else _f32c(row_weights)
+        rc = lib.bgs_gs_head_step(
+            capi.ptr(z), capi.ptr(labels), capi.ptr(l2b), capi.ptr(rw), ps_ptr, lw_ptr, N, C, B, W,
+            float(ratio), int(seed), capi.ptr(counter), capi.ptr(p),
+            capi.ptr(_f32c(bbox_targets)) if box else None,
+            capi.ptr(_f32c(bbox_weights)) if box else None, R, float(beta), float(box_loss_weight),
+            capi.ptr(loss), capi.ptr(dlogits), capi.ptr(dbbox), capi.ptr(avg), capi.ptr(bl),
+            capi.ptr(w), capi.ptr(ws), capi.current_stream(dev))
+        capi.check('bgs_gs_head_step', rc)
+        ctx.grads = (dlogits, dbbox)
+        ctx.meta = (pred_slice_host, N, B, W, R, logits.dtype, None if not box else bbox_pred.dtype)
+        ctx.consumed = False
+        ctx.mark_non_differentiable(avg)
+        if debug:
+            ctx.mark_non_differentiable(bl, w)
+            return loss, avg, bl, w
+        return loss, avg
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_loss, *_unused):
+        dlogits, dbbox = ctx.grads
+        ps_host, N, B, W, R, zdt, pdt = ctx.meta
+        if dlogits is None and dbbox is None:
+            return (None,) * 16
+        if ctx.consumed:     # the buffers are scaled in place and handed to autograd (see _GroupSoftmaxLoss)
+            raise RuntimeError('gs_head_step: the fused gradient buffers were consumed by the first '
+                               'backward; call the loss again')
+        lib = capi.load()
+        g = grad_loss.detach().to(torch.float32).contiguous()
+        ps_keep, ps_ptr = capi.host_i64(ps_host)
+        dev = (dlogits if dlogits is not None else dbbox).device
+        rc = lib.bgs_gs_head_step_scale_grad(capi.ptr(dlogits), capi.ptr(dbbox), ps_ptr, capi.ptr(g),
+                                             N, B, W, R, capi.current_stream(dev))
+        capi.check('bgs_gs_head_step_scale_grad', rc)
+        ctx.consumed = True
+        gz = dlogits if (dlogits is None or zdt == torch.float32) else dlogits.to(zdt)
+        gp = dbbox if (dbbox is None or pdt == torch.float32) else dbbox.to(pdt)
+        return (gz, gp) + (None,) * 14
+
+
+def gs_head_step(cls_score, labels, label2binlabel, pred_slice, others_sample_ratio, seed,
+                 draw_counter=None, row_weights=None, bin_loss_weight=None, bbox_pred=None,
+                 bbox_targets=None, bbox_weights=None, num_reg_classes=1, beta=1.0,
+                 box_loss_weight=1.0, debug=False):
+    """The whole BAGS head loss as two launches (``bgs_gs_head_step``): returns ``(loss_vec, avg)``
+    with ``loss_vec [B + 2]`` = per-bin classification losses (times ``bin_loss_weight``, a HOST
+    sequence), ``loss_bbox`` (0 without ``bbox_pred``) and their sum.  ``draw_counter``: device
+    int64 ``[1]``, read as this call's draw index and advanced BY THE KERNEL (fresh "others" samples
+    under hipGraph replay without a tensor op).  Same limits as :func:`gs_head_loss_fused`."""
+    _require_cuda(cls_score, labels, label2binlabel, row_weights, bbox_pred, bbox_targets,
+                  bbox_weights, draw_counter)
+    assert labels.dtype == torch.int64 and label2binlabel.dtype == torch.int64
+    assert cls_score.dim() == 2 and 0 < cls_score.shape[0] <= GS_FUSED_MAX_ROWS
+    if draw_counter is not None:
+        assert draw_counter.dtype == torch.int64 and draw_counter.numel() == 1
+    if bbox_pred is not None:
+        assert bbox_targets is not None and bbox_weights is not None
+    return _GsHeadStepFn.apply(cls_score, bbox_pred, labels.contiguous(), label2binlabel.contiguous(),
+                               _host_pred_slice(pred_slice), bin_loss_weight,
+                               float(others_sample_ratio), int(seed), draw_counter, row_weights,
+                               bbox_targets, bbox_weights, int(num_reg_classes), float(beta),
+                               float(box_loss_weight), bool(debug))
 
 
 GS_FUSED_MAX_ROWS = 4096

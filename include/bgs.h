@@ -119,6 +119,36 @@ int bgs_gs_head_loss_fused(const float* logits, const int64_t* labels, const int
                            const uint64_t* seed_offset, float* loss_out, float* dlogits,
                            float* avg_out, int32_t* bin_labels_out, float* weights_out,
                            void* workspace, bgs_stream_t stream);
+/* The WHOLE GSBBoxHeadWith0.loss() (gs_bbox_head_with0.py:147-186: _remap_labels :91-112,
+ * _sample_others :63-89, the per-bin CrossEntropyLoss terms :160-171 and the SmoothL1 box branch
+ * :173-185, plus the sum parse_losses forms, mmdet/apis/train.py:24-47) as TWO launches:
+ *   main kernel = bgs_gs_head_loss_fused's streaming kernel, with the per-bin loss weights
+ *                 (host_bin_loss_weight [B] HOST or NULL = 1) folded into losses and gradient and
+ *                 the box branch of every row evaluated by the row's workgroup: SmoothL1(beta) of
+ *                 bbox_pred [N, 4*num_reg_classes] at the row's own class slot (class-agnostic:
+ *                 num_reg_classes = 1) against bbox_targets / bbox_weights [N,4], normalised by
+ *                 box_loss_weight / max(#real rows, 1); dbbox_pred = its dense [N, 4R] gradient
+ *                 (NULL: not wanted — the shipped selectp=1 mode);
+ *   reduce      = loss_out[0..B-1] per-bin losses, loss_out[B] = loss_bbox (0 when bbox_pred is
+ *                 NULL), loss_out[B+1] = their sum (fixed order: bitwise reproducible); advances
+ *                 *draw_counter (device uint64 or NULL), which the main kernel read as the index of
+ *                 this call's "others" draw — hipGraph replays draw fresh samples with no extra launch.
+ * loss_out == NULL: main kernel only (profiling hook).  Limits of bgs_gs_head_loss_fused;
+ * BGS_ERR_UNSUPPORTED also when two rows + the flag words exceed the 64 KB LDS window. */
+int bgs_gs_head_step(const float* logits, const int64_t* labels, const int64_t* label2binlabel,
+                     const float* row_weights, const int64_t* host_pred_slice,
+                     const float* host_bin_loss_weight, int N, int C, int B, int W,
+                     double others_sample_ratio, uint64_t seed, uint64_t* draw_counter,
+                     const float* bbox_pred, const float* bbox_targets, const float* bbox_weights,
+                     int num_reg_classes, float beta, float box_loss_weight, float* loss_out,
+                     float* dlogits, float* dbbox_pred, float* avg_out, int32_t* bin_labels_out,
+                     float* weights_out, void* workspace, bgs_stream_t stream);
+/* Backward of bgs_gs_head_step's loss vector: grad_loss [B+2] (device) = upstream gradient of
+ * {bins, box, total}; dlogits[:, bin b] *= grad[b] + grad[B+1], dbbox_pred *= grad[B] + grad[B+1],
+ * in place, one launch, early-out on the device when every factor is 1. */
+int bgs_gs_head_step_scale_grad(float* dlogits, float* dbbox_pred, const int64_t* host_pred_slice,
+                                const float* grad_loss, int N, int B, int W, int num_reg_classes,
+                                bgs_stream_t stream);
 /* Second phase of bgs_gs_loss_fwd_bwd(loss_out = NULL): loss_out[b] = sum of the partials. */
 int bgs_gs_loss_reduce(const void* workspace, int N, int B, float* loss_out, bgs_stream_t stream);
 

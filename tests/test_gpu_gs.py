@@ -493,3 +493,103 @@ def test_fused_head_kernel_large_batch_and_forward_only():
         n_fg = int((blh[b] > 0).sum())
         if n_fg:
             assert int(w1[b].sum()) == n_fg + min(int(n_fg * 8.0), 4096 - n_fg)
+
+
+@pytest.mark.parametrize('name', ['n7', 'n512_cfg1', 'n1024_cfg2', 'n64_allbg', 'n40_allfg',
+                                  'n256_ratio2', 'n96_9bins'])
+@pytest.mark.parametrize('train_box', [False, True])
+def test_head_step_two_launches_equal_the_separate_kernels(name, train_box):
+    """``bgs_gs_head_step`` (the whole ``GSBBoxHeadWith0.loss()`` as main kernel + reduce: remap,
+    "others" draw, per-bin losses x loss weights, gradient, box branch, total, draw counter) against
+    ``bgs_gs_prepare`` + ``bgs_gs_loss_fwd_bwd`` + ``bgs_bbox_smooth_l1_fwd_bwd``: bitwise-equal
+    sampling, classification losses and logit gradient; box loss / gradient to fp32 summation
+    order; the loss vector's last entry is the sum of the others; the kernel advances the draw
+    counter; upstream factors (cascade stage weights) scale the stored gradients."""
+    case, l2b, ps, _, _, batch = case_setup(name)
+    n = case['n']
+    B = l2b.shape[0]
+    ratio = float(case.get('ratio', 8.0))
+    labels, l2b_t = dev(batch['labels']), dev(l2b)
+    rs = np.random.RandomState(5)
+    R = C
+    bp = rs.standard_normal((n, 4 * R)).astype(np.float32)
+    bt = rs.standard_normal((n, 4)).astype(np.float32)
+    bw = np.repeat((batch['labels'] > 0)[:, None], 4, 1).astype(np.float32)
+    lw = [1.0 + 0.25 * b for b in range(B)]
+    for rw in (None, (np.arange(n) % 5 != 3).astype(np.float32)):
+        rw_t = None if rw is None else dev(rw)
+        counter = torch.full((1,), 11, dtype=torch.int64, device=DEV)
+        bl, w, avg = BF.gs_prepare(labels, l2b_t, ratio, seed=4242, seed_offset=counter.clone(),
+                                   row_weights=rw_t)
+        z0 = dev(batch['logits']).requires_grad_(True)
+        ref = BF.group_softmax_loss(z0, bl, ps, w, avg) * dev(np.array(lw, np.float32))
+        p0 = dev(bp).requires_grad_(train_box)
+        n_real = float(avg[0])
+        refb = BF.bbox_smooth_l1_loss(p0, labels, dev(bt), dev(bw), R, beta=1.0, avg_factor=n_real,
+                                      loss_weight=0.75)
+        g = dev(np.array([0.5 + 0.1 * b for b in range(B)] + [2.0, 0.25], np.float32))   # bins, box, total
+        ((ref * (g[:B] + g[B + 1])).sum() + refb * (g[B] + g[B + 1])).backward()
+        z1 = dev(batch['logits']).requires_grad_(True)
+        p1 = dev(bp).requires_grad_(train_box)
+        vec, avg1, bl1, w1 = BF.gs_head_step(z1, labels, l2b_t, ps, ratio, 4242, draw_counter=counter,
+                                             row_weights=rw_t, bin_loss_weight=lw, bbox_pred=p1,
+                                             bbox_targets=dev(bt), bbox_weights=dev(bw),
+                                             num_reg_classes=R, beta=1.0, box_loss_weight=0.75,
+                                             debug=True)
+        assert int(counter) == 12                                   # advanced by the reduce kernel
+        (vec * g).sum().backward()
+        np.testing.assert_array_equal(bl1.cpu().numpy(), bl.cpu().numpy())
+        np.testing.assert_array_equal(w1.cpu().numpy(), w.cpu().numpy())
+        np.testing.assert_array_equal(avg1.cpu().numpy(), avg.cpu().numpy())
+        v = vec.detach().cpu().numpy()
+        np.testing.assert_allclose(v[:B], ref.detach().cpu().numpy(), rtol=1e-6, atol=0)
+        np.testing.assert_allclose(v[B], float(refb.detach()), rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(v[B + 1], v[:B + 1].astype(np.float64).sum(), rtol=1e-6)
+        np.testing.assert_allclose(z1.grad.cpu().numpy(), z0.grad.cpu().numpy(), rtol=1e-6, atol=1e-12)
+        if train_box:
+            np.testing.assert_allclose(p1.grad.cpu().numpy(), p0.grad.cpu().numpy(), rtol=1e-6, atol=1e-12)
+            assert int((p1.grad != 0).sum()) <= 4 * int((batch['labels'] > 0).sum())
+        else:
+            assert p1.grad is None
+
+
+def test_head_step_without_box_branch_and_unit_factors_is_bitwise_the_fused_loss():
+    """No ``bbox_pred``: loss_vec[B] == 0; with unit loss weights and a unit upstream gradient the
+    per-bin losses and dlogits are bitwise those of prepare + loss (the scaling launch early-outs)."""
+    case, l2b, ps, _, _, batch = case_setup('n1024_cfg2')
+    B = l2b.shape[0]
+    labels, l2b_t = dev(batch['labels']), dev(l2b)
+    counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+    bl, w, avg = BF.gs_prepare(labels, l2b_t, 8.0, seed=31, seed_offset=counter.clone())
+    z0 = dev(batch['logits']).requires_grad_(True)
+    ref = BF.group_softmax_loss(z0, bl, ps, w, avg)
+    ref.sum().backward()
+    z1 = dev(batch['logits']).requires_grad_(True)
+    vec, _ = BF.gs_head_step(z1, labels, l2b_t, ps, 8.0, 31, draw_counter=counter)
+    vec[B + 1].backward()
+    v = vec.detach().cpu().numpy()
+    np.testing.assert_array_equal(v[:B], ref.detach().cpu().numpy())
+    assert v[B] == 0.0
+    np.testing.assert_array_equal(z1.grad.cpu().numpy(), z0.grad.cpu().numpy())
+    # a second call draws a different "others" sample (the counter moved), a reset counter repeats it
+    vec2, _ = BF.gs_head_step(dev(batch['logits']), labels, l2b_t, ps, 8.0, 31, draw_counter=counter)
+    assert not np.array_equal(vec2.cpu().numpy()[1:B], v[1:B])
+    counter.zero_()
+    vec3, _ = BF.gs_head_step(dev(batch['logits']), labels, l2b_t, ps, 8.0, 31, draw_counter=counter)
+    np.testing.assert_array_equal(vec3.cpu().numpy(), v)
+
+
+def test_head_step_refuses_rows_beyond_the_lds_window():
+    """two staged rows + flags must fit the 64 KB LDS window — BGS_ERR_UNSUPPORTED (the
+    head then takes the two-kernel path) instead of a failed launch."""
+    from balancedgroupsoftmax_amd import capi
+    Wbig = 7600
+    ps = np.array([[0, 2], [2, Wbig - 2]], np.int64)
+    l2b = np.zeros((2, Wbig - 1), np.int64)
+    l2b[0, 1:] = 1
+    l2b[1, 1:] = np.arange(1, Wbig - 1)
+    z = torch.zeros(8, Wbig, device=DEV)
+    lab = torch.zeros(8, dtype=torch.int64, device=DEV)
+    with pytest.raises(capi.BgsCallError) as e:
+        BF.gs_head_step(z, lab, dev(l2b), ps, 8.0, 1)
+    assert e.value.code == 2
