@@ -16,6 +16,9 @@
     return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH; \
   } while (0)
 
+// launch census (capi.hip): bgs_census_bump(BGS_CENSUS_*) at the launch site of a kernel family
+extern "C" void bgs_internal_census_bump(int family);
+
 namespace bgs {
 
 // ---- wave64 all-reduce -------------------------------------------------------------

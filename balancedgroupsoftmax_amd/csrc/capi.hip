@@ -14,6 +14,21 @@ extern "C" const char* bgs_error_string(int code) {
 }
 
 namespace {
+int g_census[BGS_CENSUS_FAMILIES];
+}  // namespace
+
+extern "C" void bgs_internal_census_bump(int family) {
+  if (family >= 0 && family < BGS_CENSUS_FAMILIES) ++g_census[family];
+}
+
+extern "C" int bgs_launch_census(int family, int reset) {
+  const int v = (family >= 0 && family < BGS_CENSUS_FAMILIES) ? g_census[family] : -1;
+  if (reset)
+    for (int i = 0; i < BGS_CENSUS_FAMILIES; ++i) g_census[i] = 0;
+  return v;
+}
+
+namespace {
 // out[0..1] = DPP wave max / sum, out[2..3] = ds_bpermute butterflies, for lane values in[lane].
 __global__ void selftest_wave_reduce_kernel(const float* __restrict__ in, float* __restrict__ out) {
   const float v = in[threadIdx.x & 63];

@@ -1529,6 +1529,7 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   if (ring8) {
     g_last_dma = 1;
     g_last_nst = 3;
+    bgs_internal_census_bump(BGS_CENSUS_BF16_RING8);
     if (p.R == 1 && p.S == 1 && p.pad == 0)
       hipLaunchKernelGGL((conv_igemm_bf16_ring8_kernel<true>), grid, dim3(512), 0, st, q);
     else
@@ -1538,6 +1539,7 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   else if (tile == 12) BFX_T(1, 2);
   else if (knobs.dma && q.ns == 1) {
     g_last_dma = 1;
+    bgs_internal_census_bump(BGS_CENSUS_DMA_RING64);
     const bool p1x1 = up == 1 && p.R == 1 && p.S == 1 && p.pad == 0;
     if (knobs.nst != 3) {         // default: 4 x 6 KB, six workgroups per CU (cascade X101 bf16: 10.06 vs 10.15 ms)
       if (up == 2) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<2, false, 0, 1, 4>), grid, dim3(kThreads), 0, st, q);
@@ -1551,6 +1553,7 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
     }
   } else if (knobs.dma && q.ns == 3 && bfx_ring_stages(knobs, (long long)p.tiles_m * p.tiles_n * splits) == 3) {
     g_last_dma = 1;
+    bgs_internal_census_bump(BGS_CENSUS_DMA_RING64);
     g_last_nst = 3;
     if (up == 2)
       hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<2, false, 0, 3, 3>), grid, dim3(kThreads), 0, st, q);
@@ -1560,6 +1563,7 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
       hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<1, false, 0, 3, 3>), grid, dim3(kThreads), 0, st, q);
   } else if (knobs.dma && q.ns == 3) {
     g_last_dma = 1;
+    bgs_internal_census_bump(BGS_CENSUS_DMA_RING64);
     const bool p1x1 = up == 1 && p.R == 1 && p.S == 1 && p.pad == 0;
     if (up == 2) hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<2, false>), grid, dim3(kThreads), 0, st, q);
 #ifdef BGS_ABLATE
@@ -1769,6 +1773,7 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit,
   if (v4) {
     q.zero = zero_page_device();
     if (!q.zero) return BGS_ERR_LAUNCH;
+    bgs_internal_census_bump(BGS_CENSUS_HALO_BFX4);
     if (q.ns == 1) {
       if (nb == 1) hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
       else hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);

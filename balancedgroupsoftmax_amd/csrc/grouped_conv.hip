@@ -257,6 +257,7 @@ int launch_grouped_s1(const float* x, const float* w, const float* bias, float* 
                       int C, int cg, int relu, hipStream_t st, bool bf = false) {
   const int tiles_y = (H + GTH - 1) / GTH, tiles_x = (W + GTW - 1) / GTW;
   dim3 grid((unsigned)(N * tiles_y * tiles_x), (unsigned)(C / 64));
+  bgs_internal_census_bump(BGS_CENSUS_GROUPED_LDS);
 #define BGS_GL_LAUNCH(CG_)                                                                              \
   do {                                                                                                  \
     if (bf)                                                                                             \

@@ -669,6 +669,7 @@ int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* h
                                                          // to bgs_gs_prepare + bgs_gs_loss_fwd_bwd)
   const int grid = loss_grid(a.N);
   *grid_out = grid;
+  bgs_internal_census_bump(BGS_CENSUS_GS_HEAD_FUSED);
   const uintptr_t al = (uintptr_t)a.logits | (uintptr_t)(a.dlogits ? a.dlogits : a.logits);
   const bool grad = a.dlogits != nullptr;
   const bool box = a.bbox_pred != nullptr;

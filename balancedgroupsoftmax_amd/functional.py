@@ -514,6 +514,19 @@ def conv_bfx_last_launch():
                 halo_nb=d.value & 0xff, halo_variant=d.value >> 8, halo_splits=e.value)
 
 
+CENSUS = dict(bf16_ring8=0, grouped_lds=1, halo_bfx4=2, dma_ring64=3, gs_head_fused=4, conv1x1_bres=5,
+              wgrad_bfx=6, roi_bwd_gather=7)
+
+
+def launch_census(reset=False):
+    """-> {family: launches since the last reset} (``bgs_launch_census``; include/bgs.h BGS_CENSUS_*)."""
+    lib = capi.load()
+    out = {k: lib.bgs_launch_census(v, 0) for k, v in CENSUS.items()}
+    if reset:
+        lib.bgs_launch_census(0, 1)
+    return out
+
+
 def conv_tuning(tile=0, bk=0, splitk=0, noswizzle=0):
     """Process-wide tuning / test hook of the fp32 MFMA conv kernel (see include/bgs.h)."""
     capi.load().bgs_conv_tuning(int(tile), int(bk), int(splitk), int(noswizzle))

@@ -140,23 +140,25 @@ def make_inputs(n, seed, dev):
 class GsHeadStep(object):
     """One step of the BAGS RoI-head loss: everything the reference's
     GSBBoxHeadWith0.loss() + backward() does for a 1024-RoI batch (selectp=1: the box branch
-    contributes its loss value only; cls_score gets its full gradient)."""
+    contributes its loss value only; cls_score gets its full gradient) — ``bgs_gs_head_step``:
+    main kernel (label remap, "others" draw, per-bin losses, gradient, box branch) + reduce (the
+    6 loss terms, their sum, the draw counter), then the autograd edge (one scaling launch)."""
 
     def __init__(self, inp):
         self.inp = inp
         self.logits = inp['logits'].clone().requires_grad_(True)
+        # device-side draw counter, advanced by the reduce kernel: a new sample every step, also under graph replay
         self.draw = torch.zeros(1, dtype=torch.int64, device=inp['logits'].device)
+        self.nb = inp['ps_np'].shape[0]
 
     def __call__(self):
         i = self.inp
         self.logits.grad = None
-        self.draw += 1            # device-side draw counter: a new sample every step, also under graph replay
-        per_bin, _avg = BF.gs_head_loss_fused(self.logits, i['labels'], i['l2b'], i['ps_np'], 8.0,
-                                              seed=12345, seed_offset=self.draw)
-        lbox = BF.bbox_smooth_l1_loss(i['bbox_pred'], i['labels'], i['bbox_targets'],
-                                      i['bbox_weights'], NUM_CLASSES, beta=1.0,
-                                      avg_factor=i['labels'].numel())
-        total = per_bin.sum() + lbox
+        vec, _avg = BF.gs_head_step(self.logits, i['labels'], i['l2b'], i['ps_np'], 8.0, 12345,
+                                    draw_counter=self.draw, bbox_pred=i['bbox_pred'],
+                                    bbox_targets=i['bbox_targets'], bbox_weights=i['bbox_weights'],
+                                    num_reg_classes=NUM_CLASSES, beta=1.0, box_loss_weight=1.0)
+        total = vec[self.nb + 1]
         total.backward()
         return total
 
@@ -437,6 +439,7 @@ def timed_loop(fn, steps, warmup, world):
     barrier(world)
     t1 = time.perf_counter()
     dt = t1 - t0
+    timed_loop.last_local_dt = dt
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
@@ -470,25 +473,8 @@ def try_graph(step):
         return None
 
 
-def kernel_roofline(inp, n, iters=300):
-    """HIP-event timing of the dominant kernel alone (the fused streaming kernel: main launch
-    of bgs_gs_loss_fwd_bwd with loss_out=NULL), back to back on the current stream.
-    Algorithmic bytes per RoI: W*4 read + W*4 written + 8 (label) + B*4 (weights)."""
-    lib = capi.load()
-    W, B = inp['W'], inp['ps_np'].shape[0]
-    dev = inp['logits'].device
-    bl, w, avg = BF.gs_prepare(inp['labels'], inp['l2b'], 8.0, seed=1)
-    ps_keep, ps_ptr = capi.host_i64(inp['ps_np'])
-    dl = torch.empty_like(inp['logits'])
-    ws = torch.empty(lib.bgs_gs_loss_workspace_bytes(n, B), dtype=torch.uint8, device=dev)
-    st = capi.current_stream(dev)
-
-    def launch():
-        rc = lib.bgs_gs_loss_fwd_bwd(capi.ptr(inp['logits']), capi.ptr(bl), ps_ptr, capi.ptr(w),
-                                     capi.ptr(avg), n, B, W, None, capi.ptr(dl), capi.ptr(ws), st)
-        capi.check('bgs_gs_loss_fwd_bwd', rc)
-
-    for _ in range(20):
+def _event_time_us(launch, iters, warm=20):
+    for _ in range(warm):
         launch()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -497,68 +483,150 @@ def kernel_roofline(inp, n, iters=300):
         launch()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / iters
-    bytes_per_roi = W * 4 + W * 4 + 8 + B * 4
-    achieved = bytes_per_roi * n / (us * 1e-6) / 1e9
-    # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 passes of this
-    # same command (tools/pmc_traffic.sh), corrected as the microarch guide prescribes, and
-    # committed under profiles/ — bench.py itself cannot run the profiler.
-    traffic = None
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def _pmc_traffic(kernel, n):
+    """HBM bytes per launch from the PMC counters: collected in separate rocprofv3 passes
+    (tools/pmc_traffic.sh), corrected as the microarch guide prescribes, and committed under
+    profiles/ — bench.py itself cannot run the profiler."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
-            traffic = json.load(f)['gs_loss_rowwave_kernel<4,true>'][str(n)]['traffic_bytes_per_launch']
+            ent = json.load(f)[kernel][str(n)]
+        return ent['traffic_bytes_per_launch'], ent.get('source')
     except Exception:
-        pass
+        return None, None
+
+
+def kernel_roofline(inp, n, iters=300, kernel='fused'):
+    """HIP-event timing of ONE GroupSoftmax kernel alone, back to back on the current stream.
+    ``kernel='fused'``: the kernel the detector step and the gs_head step actually launch for
+    N <= 4096 (``gs_head_fused_kernel``: main launch of bgs_gs_head_step with loss_out = NULL — label
+    remap + "others" draw + loss + gradient + box branch).  ``kernel='rowwave'``: the plain loss
+    kernel (main launch of bgs_gs_loss_fwd_bwd; the path for N > 4096 / reweighted heads).
+    Algorithmic bytes per RoI: W*4 read + W*4 written + 8 (label) + B*4."""
+    lib = capi.load()
+    W, B = inp['W'], inp['ps_np'].shape[0]
+    dev = inp['logits'].device
+    ps_keep, ps_ptr = capi.host_i64(inp['ps_np'])
+    dl = torch.empty_like(inp['logits'])
+    ws = torch.empty(lib.bgs_gs_loss_workspace_bytes(n, B), dtype=torch.uint8, device=dev)
+    st = capi.current_stream(dev)
+    if kernel == 'fused':
+        avg = torch.empty(B, dtype=torch.float32, device=dev)
+        kname = 'gs_head_fused_kernel<4,true,true>'
+
+        def launch():
+            rc = lib.bgs_gs_head_step(capi.ptr(inp['logits']), capi.ptr(inp['labels']), capi.ptr(inp['l2b']),
+                                      None, ps_ptr, None, n, NUM_CLASSES, B, W, 8.0, 12345, None,
+                                      capi.ptr(inp['bbox_pred']), capi.ptr(inp['bbox_targets']),
+                                      capi.ptr(inp['bbox_weights']), NUM_CLASSES, 1.0, 1.0, None,
+                                      capi.ptr(dl), None, capi.ptr(avg), None, None, capi.ptr(ws), st)
+            capi.check('bgs_gs_head_step', rc)
+    else:
+        bl, w, avg = BF.gs_prepare(inp['labels'], inp['l2b'], 8.0, seed=1)
+        kname = 'gs_loss_rowwave_kernel<4,true>'
+
+        def launch():
+            rc = lib.bgs_gs_loss_fwd_bwd(capi.ptr(inp['logits']), capi.ptr(bl), ps_ptr, capi.ptr(w),
+                                         capi.ptr(avg), n, B, W, None, capi.ptr(dl), capi.ptr(ws), st)
+            capi.check('bgs_gs_loss_fwd_bwd', rc)
+
+    us = _event_time_us(launch, iters)
+    bytes_per_roi = W * 4 + W * 4 + 8 + B * 4
+    achieved = bytes_per_roi * n / (us * 1e-6) / 1e9
+    traffic, src = _pmc_traffic(kname, n)
     return dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                kernel='gs_loss_rowwave_kernel<4,true>', us_per_launch=round(us, 3),
+                traffic_source=('committed PMC measurement, not collected in this run: %s' % src) if src else None,
+                kernel=kname, us_per_launch=round(us, 3),
+                launched_by=('the detector step and the gs_head step (N <= 4096)' if kernel == 'fused'
+                             else 'heads with N > 4096 rows or per-class reweighting (after gs_prepare)'),
                 algorithmic_bytes_per_roi=bytes_per_roi, rois_per_launch=n,
                 timing='hipEvent over %d back-to-back launches (includes the ~1.5 us '
                        'inter-kernel boundary)' % iters)
 
 
+def _cpu_time_threads(fn, n, seconds, cores):
+    """median time of fn() per thread count; best of 1 / 8 / 32 / min(cores, 64)."""
+    best, tried = None, {}
+    counts = [nt for nt in sorted(set([1, 8, 32, min(cores, 64)])) if nt <= cores]
+    for nt in counts:
+        torch.set_num_threads(nt)
+        for _ in range(3):
+            fn(0)
+        times = []
+        t_end = time.perf_counter() + seconds / max(len(counts), 1)
+        while time.perf_counter() < t_end and len(times) < 500:
+            t0 = time.perf_counter()
+            fn(len(times))
+            times.append(time.perf_counter() - t0)
+        med = float(np.median(times))
+        tried[str(nt)] = round(med * 1e6 / n, 4)
+        if best is None or med < best[0]:
+            best = (med, nt, len(times))
+    return best, tried
+
+
 def cpu_baseline(n, seconds):
-    """Reference CPU path (torch-CPU port, oracle/gs_torch_port.py) on this host's cores."""
-    from oracle import gs_oracle, gs_torch_port
+    """The reference's CPU path on THIS host's cores: the reference's own
+    ``GSBBoxHeadWith0.loss()`` + ``backward()`` (gs_bbox_head_with0.py:147-186), imported from the
+    head closure that oracle/build_ref.py stages under oracle/_ref/ (``kind: "reference"``); when
+    that is absent, the torch-CPU port of it (oracle/gs_torch_port.py, ``kind: "port"``)."""
+    import tempfile
+    from oracle import build_ref, gs_oracle, gs_torch_port
     counts = gs_tables.synthetic_instance_counts(NUM_CLASSES, seed=0)
     l2b, ps, _ = gs_tables.build_group_tables(counts)
     batch = gs_oracle.make_roi_batch(n, int(ps[:, 1].sum()), NUM_CLASSES, seed=0)
     z, lab = torch.from_numpy(batch['logits']), torch.from_numpy(batch['labels'])
     l2b_t, ps_t = torch.from_numpy(l2b), torch.from_numpy(ps)
     cores = os.cpu_count() or 1
-    best = None
-    tried = {}
-    # torch-CPU oversubscribes badly on many-core hosts: report the best thread count tried
-    for nt in sorted(set([1, 8, 32, min(cores, 64)])):
-        if nt > cores:
-            continue
-        torch.set_num_threads(nt)
-        for _ in range(3):
-            gs_torch_port.gs_loss_fwd_bwd(z, lab, l2b_t, ps_t, 8.0)
-        times = []
-        t_end = time.perf_counter() + seconds / 4.0
-        while time.perf_counter() < t_end and len(times) < 500:
-            np.random.seed(len(times))
-            t0 = time.perf_counter()
-            gs_torch_port.gs_loss_fwd_bwd(z, lab, l2b_t, ps_t, 8.0)
-            times.append(time.perf_counter() - t0)
-        med = float(np.median(times))
-        tried[str(nt)] = round(med * 1e6 / n, 4)
-        if best is None or med < best[0]:
-            best = (med, nt, len(times))
-    med, nt, cnt = best
-    return dict(value=round(med * 1e6 / n, 4), unit='us/RoI', cores=nt, kind='port',
-                host_cores=cores, threads_tried=tried,
-                sample='%d x (loss+backward) of the torch-CPU port of GSBBoxHeadWith0.loss '
-                       '(oracle/gs_torch_port.py) on N=%d RoIs x 1236 logits (cls branch, numpy '
-                       'sampling incl.), median; best of 1/8/32/64 threads = %d; torch %s'
-                       % (cnt, n, nt, torch.__version__),
-                port_vs_reference_class='the port is ~3x FASTER than the executed reference class '
-                                        'it stands in for (BASELINE.md section 2: GSBBoxHeadWith0.'
-                                        'loss()+backward() itself, N=1024: 3.11 us/RoI at 8 threads, '
-                                        '12.04 us/RoI at 1 thread, authoring container) — it fuses '
-                                        'the per-bin python loop; the reference class cannot be '
-                                        'timed on the GPU box (/root/reference does not travel)')
+
+    def port(i):
+        np.random.seed(i)
+        gs_torch_port.gs_loss_fwd_bwd(z, lab, l2b_t, ps_t, 8.0)
+
+    out = None
+    root = build_ref.reference_python_root()
+    if root is not None:
+        try:
+            from oracle import ref_import
+            ref_import.install_stubs(root=root)
+            tmp = tempfile.mkdtemp(prefix='bgs_ref_tables_')
+            gs_tables.save_group_tables(tmp, *gs_tables.synthetic_group_tables())
+            head = ref_import.build_reference_head(tmp)
+            zr = z.clone().requires_grad_(True)
+
+            def ref(i):
+                np.random.seed(i)
+                zr.grad = None
+                losses = head.loss(zr, None, lab, None, None, None)
+                sum(losses.values()).backward()
+
+            (med, nt, cnt), tried = _cpu_time_threads(ref, n, seconds * 0.7, cores)
+            out = dict(value=round(med * 1e6 / n, 4), unit='us/RoI', cores=nt, kind='reference',
+                       host_cores=cores, threads_tried=tried,
+                       sample='%d x (loss()+backward()) of the reference class GSBBoxHeadWith0 itself '
+                              '(mmdet/models/bbox_heads/gs_bbox_head_with0.py, imported from %s under the '
+                              'dependency stubs of oracle/ref_import.py) on N=%d RoIs x 1236 logits (cls '
+                              'branch, numpy sampling incl.), median; best of 1/8/32/64 threads = %d; '
+                              'torch %s' % (cnt, 'the reference tree' if root == build_ref.REF else
+                                            'oracle/_ref/reference_py (staged by oracle/build_ref.py)',
+                                            n, nt, torch.__version__))
+            seconds *= 0.3
+        except Exception as e:  # pragma: no cover
+            sys.stderr.write('reference-class cpu_baseline failed (%r); timing the port\n' % (e,))
+            out = None
+    (med, nt, cnt), tried = _cpu_time_threads(port, n, seconds, cores)
+    pd = dict(value=round(med * 1e6 / n, 4), unit='us/RoI', cores=nt, kind='port',
+              host_cores=cores, threads_tried=tried,
+              sample='%d x (loss+backward) of the torch-CPU port of GSBBoxHeadWith0.loss '
+                     '(oracle/gs_torch_port.py) on N=%d RoIs x 1236 logits, median; best thread count = %d'
+                     % (cnt, n, nt))
+    if out is None:
+        return pd
+    out['port'] = pd
+    return out
 
 
 def cpu_baseline_detector():
@@ -653,6 +721,37 @@ def gs_head_metric(inp, n, steps=300, warmup=20):
                      'itself: ~12 us)')
 
 
+STEP_GFLOP = {
+    # algorithmic flops of one 2-image step (~212 GMAC = 424 GFLOP forward per
+    # image; selectp=1 adds dW_cls only, selectp=0 ~3x minus the frozen stem + layer1)
+    1: 2 * 426.0, 0: 2 * 1200.0,
+}
+
+
+def roofline_step(out, args):
+    """The WHOLE step against the matrix-pipe ceiling (the line's `roofline` describes the best
+    layer of the dominant kernel only): algorithmic GFLOP per step / ms_per_step / ceiling, plus the
+    per-family kernel time of the last committed rocprofv3 trace (profiles/step_families.json)."""
+    if args.mask or args.cascade or args.htc or args.selectp not in STEP_GFLOP:
+        return None
+    gf = STEP_GFLOP[args.selectp] * args.imgs / 2.0
+    peak = {'bf16x6': 2500.0 / 6.0, 'f32': 157.3, 'bf16': 2500.0}[args.conv_math]
+    tf = gf / out['ms_per_step']          # GFLOP / ms = TFLOP/s
+    r = dict(bound='mfma', achieved=round(tf, 1), peak=round(peak, 1), unit='TFLOP/s',
+             frac=round(tf / peak, 4), gflop_per_step=gf, ms_per_step=out['ms_per_step'],
+             note='algorithmic flops of the whole iteration (conv + FC; SURVEY.md 8d) per GPU / wall '
+                  'time per step / the arithmetic mode\'s matrix-pipe ceiling; the step also holds '
+                  'HBM- and latency-bound kernels (targets, NMS, RoIAlign, losses, optimizer)')
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'step_families.json')) as f:
+            fam = json.load(f)
+        r['families_ms'] = fam['families_ms']
+        r['families_source'] = fam['source']
+    except Exception:
+        pass
+    return r
+
+
 def finish_line(out, args, dev, world):
     """Secondary measurements + per-kernel rooflines + CPU baseline, then the ONE JSON line."""
     if world == 1 and not args.no_extras and args.selectp == 1 and not args.mask \
@@ -662,8 +761,15 @@ def finish_line(out, args, dev, world):
         out['roofline'] = conv_roofline(dev, args.conv_math)
         if args.conv_math != 'f32':
             out['roofline_f32_mfma_kernel'] = conv_roofline(dev, 'f32')
+        rs = roofline_step(out, args)
+        if rs:
+            out['roofline_step'] = rs
         gs_inp = make_inputs(1024, seed=1000, dev=dev)
-        out['roofline_gs_loss'] = kernel_roofline(gs_inp, 1024)
+        out['roofline_gs_loss'] = kernel_roofline(gs_inp, 1024, kernel='fused')
+        out['roofline_gs_loss_rowwave'] = kernel_roofline(gs_inp, 1024, kernel='rowwave')
+        big = make_inputs(65536, seed=7, dev=dev)
+        out['roofline_gs_loss_n65536'] = kernel_roofline(big, 65536, iters=30, kernel='rowwave')
+        del big
         if world == 1:
             out['gs_head'] = gs_head_metric(gs_inp, 1024)
     if world == 1 and not args.no_cpu_baseline:
@@ -673,11 +779,105 @@ def finish_line(out, args, dev, world):
                       'see cpu_baseline_detector for the whole iteration with its ops built for the host')
         out['cpu_baseline'] = cb
         out['cpu_baseline_1thread'] = {'value': cb['threads_tried'].get('1'), 'unit': 'us/RoI',
-                                       'cores': 1, 'kind': 'port'}
+                                       'cores': 1, 'kind': cb['kind']}
         cbd = cpu_baseline_detector()
         if cbd:
             out['cpu_baseline_detector'] = cbd
     print(json.dumps(out), flush=True)
+
+
+def exchange_check(step, world):
+    """the N-rank exchanged gradient == the mean of the N single-rank
+    gradients on the same per-rank inputs.  One untimed iteration: forward + backward, keep the
+    local gradients, run the product's exchange (train.allreduce_grads: flat SUM all-reduce / world,
+    mmdet/core/utils/dist_utils.py:9-41), all-gather the local ones and compare."""
+    import torch.distributed as dist
+    if step.step_fn.overlap is not None:
+        return dict(checked=False, why='bucketed exchange overlapped with backward (selectp=0): the '
+                                       'local gradients are replaced bucket by bucket')
+    step.compute()
+    params = [p for p in step.params if p.grad is not None]
+    local = torch.cat([p.grad.reshape(-1) for p in params]).float().clone()
+    step.train.allreduce_grads(step.params, world)
+    got = torch.cat([p.grad.reshape(-1) for p in params]).float()
+    if dist.get_backend() != 'nccl':      # (gloo test hook: collectives of host tensors)
+        local, got = local.cpu(), got.cpu()
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    mean = torch.stack(gathered).sum(0) / world
+    diff = float((got - mean).abs().max())
+    scale = float(mean.abs().max())
+    differ = float((gathered[0] - gathered[-1]).abs().max()) if world > 1 else 0.0
+    step.step_fn.optimizer.zero_grad(set_to_none=False)
+    ok = diff <= 1e-5 * scale + 1e-12
+    return dict(checked=True, ok=bool(ok), max_abs_diff=diff, max_abs_grad=scale,
+                ranks_see_different_data=bool(differ > 0), elements=int(local.numel()),
+                what='allreduce_grads(fc_cls grads) vs mean of the all-gathered per-rank gradients')
+
+
+def allreduce_us(step, world, iters=10):
+    """hipEvent time of the gradient exchange alone (flat fp32 all-reduce + /world + unflatten)."""
+    for p in step.params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    for _ in range(3):
+        step.train.allreduce_grads(step.params, world)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        step.train.allreduce_grads(step.params, world)
+    e1.record()
+    torch.cuda.synchronize()
+    step.step_fn.optimizer.zero_grad(set_to_none=False)
+    return round(e0.elapsed_time(e1) * 1e3 / iters, 2)
+
+
+def run_dist_graph_children(args, rank, local, world):
+    """N > 1: the whole-step hipGraph policy (RCCL all-reduce captured with the rest of the step)
+    measured in CHILD processes — one per rank, forming their own process group on another port —
+    exactly as the 1-GPU path isolates its graph replay: a fault or a hang inside a replay cannot
+    take the parent's eager measurement (and its JSON line) down.  Runs BEFORE the parent builds its
+    model, so the GPU is the child's alone.  Returns a dict on rank 0 (None elsewhere)."""
+    import socket
+    import subprocess
+    import torch.distributed as dist
+    port = torch.zeros(1, dtype=torch.int64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+    if rank == 0:
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port[0] = sk.getsockname()[1]
+    dist.broadcast(port, 0)
+    env = dict(os.environ, MASTER_PORT=str(int(port.item())), RANK=str(rank), WORLD_SIZE=str(world),
+               LOCAL_RANK=str(local))
+    env.setdefault('MASTER_ADDR', '127.0.0.1')
+    for k in list(env):
+        if k.startswith('TORCHELASTIC_'):
+            env.pop(k)
+    cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'detector', '--child', '--dist-graph',
+           '--gpus', str(world), '--steps', str(min(args.steps, 10)), '--warmup', '3',
+           '--imgs', str(args.imgs), '--selectp', str(args.selectp), '--no-extras', '--no-cpu-baseline',
+           '--no-roofline', '--conv-math', args.conv_math]
+    res = dict(ok=False)
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        try:
+            so, se = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            p.kill()                      # exactly the child this rank started
+            so, se = p.communicate()
+            res['error'] = 'timeout'
+        line = [ln for ln in so.decode().splitlines() if ln.startswith('{')]
+        if p.returncode == 0 and line:
+            d = json.loads(line[-1])
+            res = dict(ok='hipGraph' in d['config']['launch'], ms_per_step=d['ms_per_step'],
+                       img_per_s=d['value'], launch=d['config']['launch'], steps=d['steps'])
+        elif 'error' not in res:
+            res['error'] = 'rc=%s %s' % (p.returncode, se.decode()[-200:])
+    except Exception as e:  # pragma: no cover
+        res['error'] = repr(e)[:200]
+    barrier(world)
+    return res if rank == 0 else None
 
 
 def main_detector(args, rank, local, world, dev):
@@ -691,8 +891,17 @@ def main_detector(args, rank, local, world, dev):
         args.no_graph = True
     if args.child and os.environ.get('BGS_BENCH_CHILD_FAIL'):     # test hook for the fallback path
         os._exit(134)
+    dist_graph = None
+    if world > 1 and not args.child and not args.no_graph and not args.dist_graph \
+            and not os.environ.get('BGS_BENCH_NO_DIST_GRAPH_CHILD'):
+        dist_graph = run_dist_graph_children(args, rank, local, world)
     step = DetectorStep(dev, rank, world, args.imgs, args.selectp, args.mask, args.cascade,
                         args.htc, conv_math=args.conv_math)
+    diag = None
+    if world > 1 and not args.child:
+        diag = dict(grad_exchange_check=exchange_check(step, world))
+        if step.step_fn.overlap is None:
+            diag['allreduce_us'] = allreduce_us(step, world)
     # Launch policy.  The iteration is free of host synchronisation, so on ONE GPU the whole
     # step (forward, losses, backward, clip, SGD: ~560 launches) is captured into a single
     # hipGraph and replayed.  The graph must own the ENTIRE step: on ROCm 7.2 a large graph whose
@@ -714,6 +923,14 @@ def main_detector(args, rank, local, world, dev):
     dt = timed_loop(fn, args.steps, args.warmup, world)
     ms_per_step = dt * 1e3 / args.steps
     imgs_per_s = args.imgs * world * args.steps / dt
+    rank_ms = None
+    if world > 1:       # every rank's own wall time of the timed region (the line reports the max)
+        import torch.distributed as dist
+        mine = torch.tensor([timed_loop.last_local_dt * 1e3 / args.steps], dtype=torch.float64,
+                            device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_ms = [round(float(t.item()), 3) for t in allr]
     ms_eager = None
     if graph is not None:       # every rank: the same step launched eagerly, for the graph-vs-eager figure
         ms_eager = round(timed_loop(step, 5, 2, world) * 1e3 / 5, 3)
@@ -767,6 +984,16 @@ def main_detector(args, rank, local, world, dev):
         }
         if ms_eager is not None:
             out['ms_per_step_eager'] = ms_eager
+        if world > 1:
+            import torch.distributed as dist
+            out['rccl_ranks'] = world if dist.get_backend() == 'nccl' else 0
+            out['launch_policy'] = 'hipGraph replay incl. the RCCL all-reduce' if graph else \
+                'eager launches (the RCCL all-reduce between backward and the optimizer)'
+            out['ms_per_step_by_rank'] = dict(min=min(rank_ms), max=max(rank_ms), all=rank_ms)
+            if diag:
+                out.update(diag)
+            if dist_graph is not None:
+                out['dist_graph_policy'] = dist_graph
         if self_group:
             out['config']['collective_backend'] = 'nccl (1-rank group: test hook BGS_BENCH_SELF_GROUP)'
         if fallback_note:

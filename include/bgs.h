@@ -308,6 +308,21 @@ size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int Cin, int Co
 int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias, float* y,
                                   int N, int H, int W, int Cin, int Cout, int relu, int planes,
                                   void* workspace, size_t workspace_bytes, bgs_stream_t stream);
+/* Launch census (tests / bench evidence): how often a kernel family was launched by this process
+ * since the last reset — lets a test ASSERT that the instantiation it means to pin really ran
+ * (e.g. the 8-wave bf16 ring and the LDS-resident grouped conv inside a whole X101 iteration).
+ * Returns the count of `family` (a BGS_CENSUS_* id; -1 for an unknown id); reset != 0 zeroes every
+ * counter after reading.  Process-wide, not thread-safe (like the tuning hooks). */
+#define BGS_CENSUS_BF16_RING8 0      /* conv_igemm_bf16_ring8_kernel                      */
+#define BGS_CENSUS_GROUPED_LDS 1     /* grouped_conv3x3_lds_kernel                        */
+#define BGS_CENSUS_HALO_BFX4 2       /* conv3x3_halo_bfx4_kernel                          */
+#define BGS_CENSUS_DMA_RING64 3      /* conv_igemm_bfx_dma_kernel (64 x 64 operand ring)  */
+#define BGS_CENSUS_GS_HEAD_FUSED 4   /* gs_head_fused_kernel                              */
+#define BGS_CENSUS_CONV1X1_BRES 5    /* conv1x1_bres_kernel (filter-resident 1x1)         */
+#define BGS_CENSUS_WGRAD_BFX 6       /* conv_wgrad_bfx_kernel                             */
+#define BGS_CENSUS_ROI_BWD_GATHER 7  /* roi_align backward without global atomics         */
+#define BGS_CENSUS_FAMILIES 16
+int bgs_launch_census(int family, int reset);
 void bgs_conv_bfx_tuning(int tile, int splitk);
 int bgs_conv_bfx_last_launch(int* tile, int* splits);
 void bgs_conv3x3_halo_bfx_tuning(int splits, int variant);

@@ -52,11 +52,16 @@ def _obj_from_dict(info, parent=None, default_args=None):
 _INSTALLED = False
 
 
-def install_stubs():
-    """Install the import stubs and put the reference tree on sys.path (idempotent)."""
-    global _INSTALLED
+def install_stubs(root=None):
+    """Install the import stubs and put the reference tree on sys.path (idempotent).
+    ``root``: an alternative location of the reference's python modules — bench.py's
+    ``cpu_baseline`` leg passes the head closure staged by oracle/build_ref.py
+    (``oracle/_ref/reference_py``) on the GPU box, where ``/root/reference`` does not exist."""
+    global _INSTALLED, REFERENCE_ROOT
     if _INSTALLED:
         return
+    if root is not None:
+        REFERENCE_ROOT = root
     if not reference_available():
         raise RuntimeError('reference tree not found at %s' % REFERENCE_ROOT)
     import torch

@@ -590,3 +590,80 @@ def test_fullsize_iteration_with_the_shipped_sampler_sizes_and_the_references_re
         BF.set_conv_math(prev)
         del model
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('math', ['bf16x6', 'bf16'])
+def test_cascade_x101_fullsize_iteration_vs_executed_reference(math):
+    """BASELINE cfg[4] AT ITS OWN TRUNK AND SIZE: ``gs_cascade_rcnn_x101_64x4d`` (ResNeXt-101-64x4d,
+    three GroupSoftmax stages, class-agnostic regression, stage weights 1 / 0.5 / 0.25) on
+    1 x 3x800x1344 against the executed reference (tests/golden/make_golden_cascade_x101.py;
+    resnext.py:12-91, cascade_rcnn.py:152-298).  ``bf16x6`` (fp32-faithful): every loss term to
+    1e-4 (2e-4 for the later stages, whose RoIs are the previous stage's regressed boxes) and the
+    three ``fc_cls`` gradients.  ``bf16`` (the mode BASELINE names for this config: operands rounded
+    to bf16, fp32 accumulate — the reference's fp16 autocast contract): the documented budget of
+    3e-2 of the total per term, 2e-2 on the total.  The launch census ASSERTS that the kernels the
+    X101 bench numbers come from ran inside this iteration: the LDS-resident grouped 3x3 conv on
+    the large maps and, in the bf16 mode, the 8-wave 128x128 operand ring."""
+    from balancedgroupsoftmax_amd import functional as BF
+    from balancedgroupsoftmax_amd import train
+    from tests.golden import make_golden_cascade_x101 as T
+    z = np.load(os.path.join(os.path.dirname(T.__file__), 'e2e_cascade_x101_fullsize_golden.npz'))
+    model = None
+    prev = BF.set_conv_math(math)
+    try:
+        tmp = tempfile.mkdtemp(prefix='bgs_x101_')
+        model_cfg, train_cfg = T.configs(tmp)
+        model = bgs.build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
+                                   test_cfg=to_config_dict(G.TEST_CFG))
+        with torch.no_grad():
+            det_oracle.fill_detector(model.state_dict(), T.SEED)
+        model.to(DEV)
+        train.select_training_param(model, 2)          # the three box heads train (fc_cls, fc_reg, shared FCs)
+        model.train()
+        boxes, labels = T.gt()
+        BF.launch_census(reset=True)
+        losses = model(T.image().to(DEV), T.img_meta(), return_loss=True,
+                       gt_bboxes=[torch.from_numpy(b).to(DEV) for b in boxes],
+                       gt_labels=[torch.from_numpy(l).to(DEV) for l in labels])
+        census = BF.launch_census()
+        assert census['grouped_lds'] >= 30, census       # 30 of the 33 grouped convs of an X101 forward
+        assert census['halo_bfx4'] >= 5, census
+        if math == 'bf16':
+            assert census['bf16_ring8'] >= 40, census
+        total_exp = float(z['loss/total'][0])
+        bad, worst = [], 0.0
+        for k, v in losses.items():
+            if 'loss' not in k:
+                continue
+            got = np.array([float(t.detach().sum()) for t in (v if isinstance(v, list) else [v])], np.float32)
+            exp = z['loss/' + k]
+            d = float(np.abs(got - exp).max())
+            worst = max(worst, d)
+            if math == 'bf16x6':
+                tol = (1e-4 if (k.startswith('s0.') or 'rpn' in k) else 2e-4) * max(float(np.abs(exp).max()), 1.0)
+            else:
+                tol = 3e-2 * total_exp
+            if d > tol:
+                bad.append((k, got.tolist(), exp.tolist()))
+        loss, _ = train.parse_losses(losses)
+        print('%s cascade X101 @800x1344: total %.5f vs executed reference %.5f, worst term diff %.2e'
+              % (math, float(loss.detach()), total_exp, worst))
+        assert not bad, bad
+        assert abs(float(loss.detach()) - total_exp) < (2e-4 if math == 'bf16x6' else 2e-2) * total_exp
+        if math == 'bf16x6':
+            loss.backward()
+            params = dict(model.named_parameters())
+            gbad = []
+            for name, idx in T.GRADS:
+                g = params[name].grad
+                assert g is not None, name
+                a, b = g[idx].cpu().numpy(), z['grad/' + name]
+                rel = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-20))
+                print('%s: max |diff| / max |g| = %.2e' % (name, rel))
+                if rel > (1e-4 if 'fc_cls' in name or 'fc_reg' in name else 2e-3):
+                    gbad.append((name, rel))
+            assert not gbad, gbad
+    finally:
+        BF.set_conv_math(prev)
+        del model
+        torch.cuda.empty_cache()

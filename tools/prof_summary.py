@@ -32,6 +32,11 @@ def categories(rows, steps):
         tot[c][0] += d
         tot[c][1] += 1
     alln = sum(v[0] for v in tot.values())
+    global LAST_FAMILIES
+    LAST_FAMILIES = collections.OrderedDict(
+        (c, dict(ms=round(ns / steps / 1e6, 4), launches=round(n / steps, 1))) for c, (ns, n) in tot.items())
+    LAST_FAMILIES['all kernels'] = dict(ms=round(alln / steps / 1e6, 4),
+                                        launches=round(sum(v[1] for v in tot.values()) / steps, 1))
     print('| kernel family | ms / step | launches / step | % |')
     print('|---|---|---|---|')
     for c, (ns, n) in tot.items():
@@ -80,5 +85,15 @@ def main(path, steps=None):
             100.0 * sum(v) / total))
 
 
+LAST_FAMILIES = None
+
+
 if __name__ == '__main__':
+    # prof_summary.py trace.csv [steps] [families.json source-label]: the third argument also writes
+    # the per-family table as JSON (bench.py reads profiles/step_families.json into roofline_step)
     main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else None)
+    if len(sys.argv) > 3 and LAST_FAMILIES is not None:
+        import json
+        with open(sys.argv[3], 'w') as f:
+            json.dump(dict(families_ms=LAST_FAMILIES,
+                           source=sys.argv[4] if len(sys.argv) > 4 else sys.argv[1]), f, indent=1)
