@@ -462,14 +462,14 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
         fused = cls_score is not None and self.sampler == 'device' and \
             self.cls_weight_table is None and \
             0 < cls_score.shape[0] <= BF.GS_FUSED_MAX_ROWS and self.num_bins <= 15 and \
-            2 * cls_score.shape[1] * 4 + 2 * cls_score.shape[0] < 60000    # rows + flags in the LDS window
+            8 * cls_score.shape[1] + 2 * cls_score.shape[0] + 2 * self.num_classes < 60000   # rows + flags + class bits in the LDS window
         if fused and (bbox_pred is None or type(self.loss_bbox).__name__ == 'SmoothL1Loss'):
             # TWO launches for the whole loss(): label remap + "others" sampling + per-bin losses
             # (x their loss weights) + gradient + the box branch in the streaming kernel, then the
             # fixed-order reduce, which also advances the draw counter
             if self._seed is None:
                 self._seed = (torch.initial_seed() * 0x9E3779B1) & 0xFFFFFFFFFFFFFFFF
-            vec, _avg = BF.gs_head_step(
+            terms, _total, _avg = BF.gs_head_step(
                 cls_score, labels, self.label2binlabel, self.pred_slice_host,
                 self.others_sample_ratio, self._seed, draw_counter=self._draw,
                 row_weights=label_weights, bin_loss_weight=self._bin_loss_weight_host,
@@ -477,10 +477,11 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
                 num_reg_classes=self.num_reg_classes,
                 beta=self.loss_bbox.beta if bbox_pred is not None else 1.0,
                 box_loss_weight=self.loss_bbox.loss_weight if bbox_pred is not None else 1.0)
+            parts = terms.unbind(0)          # ONE autograd node (its backward: one stack) for all terms
             for i in range(self.num_bins):
-                losses['loss_cls_bin{}'.format(i)] = vec[i]
+                losses['loss_cls_bin{}'.format(i)] = parts[i]
             if bbox_pred is not None:
-                losses['loss_bbox'] = vec[self.num_bins]
+                losses['loss_bbox'] = parts[self.num_bins]
             return losses
         if cls_score is not None:
             bin_labels, weights, avg = self._remap_labels(labels, label_weights)

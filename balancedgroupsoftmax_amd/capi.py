@@ -44,12 +44,13 @@ SIGNATURES = {
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_double, ctypes.c_uint64, c_ptr, c_f32p,
                                               c_f32p, c_f32p, c_ptr, c_f32p, c_ptr, c_ptr]),
-    'bgs_gs_head_step': (ctypes.c_int, [c_f32p, c_i64p, c_i64p, c_f32p, c_ptr, c_ptr, ctypes.c_int,
+    'bgs_gs_head_step': (ctypes.c_int, [c_f32p, c_i64p, c_i64p, c_ptr, c_f32p, c_ptr, c_ptr, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                         ctypes.c_uint64, c_ptr, c_f32p, c_f32p, c_f32p, ctypes.c_int,
-                                        ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p,
+                                        ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, c_f32p,
                                         c_f32p, c_ptr, c_f32p, c_ptr, c_ptr]),
-    'bgs_gs_head_step_scale_grad': (ctypes.c_int, [c_f32p, c_f32p, c_ptr, c_f32p, ctypes.c_int,
+    'bgs_gs_class_bin_mask': (ctypes.c_int, [c_i64p, ctypes.c_int, ctypes.c_int, c_ptr, c_ptr]),
+    'bgs_gs_head_step_scale_grad': (ctypes.c_int, [c_f32p, c_f32p, c_ptr, c_f32p, c_f32p, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, c_ptr]),
     'bgs_gs_loss_reduce': (ctypes.c_int, [c_ptr, ctypes.c_int, ctypes.c_int, c_f32p, c_ptr]),
     'bgs_gs_scale_grad': (ctypes.c_int, [c_f32p, c_i64p, c_f32p, ctypes.c_int, ctypes.c_int,

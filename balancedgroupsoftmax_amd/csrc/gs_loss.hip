@@ -247,6 +247,7 @@ struct GsHeadArgs {
   const float* logits;
   const int64_t* labels;
   const int64_t* l2b;
+  const uint16_t* class_bits;    // [C] bit b: class is foreground in bin b (l2b[b][c] > 0), or null
   const float* row_weights;
   bgs::BinGeom geom;
   float lw[BGS_MAX_BINS];        // per-bin loss weight (CrossEntropyLoss.loss_weight)
@@ -278,11 +279,11 @@ __device__ __forceinline__ float gs_sl1(float d, float beta, float& grad) {
   return ad - 0.5f * beta;
 }
 
-// LDS layout (dynamic): [2][wpad] rows + read slack | flags u16 [N rounded to 8] | counts int
-// [kWaves][MAX_BINS + 1] | box gradient float [4]
-__host__ __device__ inline size_t gs_head_lds_bytes(int N, int wpad) {
+// LDS layout (dynamic): [2][wpad] rows + read slack | flags u16 [N rounded to 8] | class bits u16
+// [C rounded to 8] | counts int [kWaves][MAX_BINS + 1] | box gradient float [4]
+__host__ __device__ inline size_t gs_head_lds_bytes(int N, int C, int wpad) {
   return sizeof(float) * (2 * (size_t)wpad + BGS_WAVE * bgs::kSweep) + 2 * (size_t)((N + 7) & ~7) +
-         sizeof(int) * kWaves * (BGS_MAX_BINS + 1) + sizeof(float) * 4;
+         2 * (size_t)((C + 7) & ~7) + sizeof(int) * kWaves * (BGS_MAX_BINS + 1) + sizeof(float) * 4;
 }
 
 template <int VEC, bool WRITE_GRAD, bool BOX>
@@ -290,7 +291,8 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = a.N, C = a.C, B = a.B, W = a.W, wpad = a.wpad;
   unsigned short* sh_flags = reinterpret_cast<unsigned short*>(smem + 2 * (size_t)wpad + BGS_WAVE * bgs::kSweep);
-  int* sh_cntw = reinterpret_cast<int*>(sh_flags + ((N + 7) & ~7));
+  unsigned short* sh_cbits = sh_flags + ((N + 7) & ~7);
+  int* sh_cntw = reinterpret_cast<int*>(sh_cbits + ((C + 7) & ~7));
   float* sh_box = reinterpret_cast<float*>(sh_cntw + kWaves * (BGS_MAX_BINS + 1));
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -298,80 +300,98 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
   uint64_t seed = a.seed;
   if (a.seed_offset) seed += 0x2545F4914F6CDD1Dull * a.seed_offset[0];   // device-side draw counter
 
-  // ---- prologue: flag word of every row, per-bin foreground counts (lane b <= B of every wave
-  //      counts bin b over the wave's share of the rows; b == B: real rows).  Written as
-  //      straight-line passes of kFusedRowsPerPass rows per thread with UNCONDITIONAL loads
-  //      (addresses are selected, not the loads: a branch around a load makes hipcc wait for it
-  //      where it is issued): the label / row-weight loads of a pass and — in pass 0 — the
-  //      workgroup's first logits row are in flight together, then the B table gathers of all rows.
+  // ---- prologue.  The flag word of a row is a function of its label alone: {foreground in bin b}
+  //      = class_bits[label] — a C-entry 16-bit table (2.4 KB for LVIS) that every workgroup copies
+  //      into LDS with a handful of coalesced loads, instead of B scattered 8-byte gathers into the
+  //      [B, C] int64 table per row (N x B cache lines per workgroup: what the first version of this
+  //      kernel spent its time on).  Without a prebuilt table (class_bits == null) the workgroup
+  //      derives it from label2binlabel by a coalesced sweep.  All loads are unconditional
+  //      (addresses are selected, not loads: a branch around a load makes hipcc wait for it where
+  //      it is issued); the labels, the table and the workgroup's first logits row are in flight
+  //      together.  Lane b <= B of every wave counts bin b over the wave's share of the rows by
+  //      ballots (b == B: real rows) — no LDS atomics.
   int mycnt = 0;
   const float* rw_base = a.row_weights ? a.row_weights : &g_one;
   const int rw_step = a.row_weights ? 1 : 0;
-  auto prologue_pass = [&](int base, auto first_tag) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    int64_t y[kFusedRowsPerPass];
-    float rwv[kFusedRowsPerPass];
+  constexpr int RP = kFusedRowsPerPass;
+  int64_t y0[RP];
+  float rwv0[RP];
 #pragma unroll
-    for (int i = 0; i < kFusedRowsPerPass; ++i) {
-      const int r = base + tid + kBlock * i;
-      const int rc = r < N ? r : 0;
-      y[i] = a.labels[rc];
-      rwv[i] = rw_base[(size_t)rc * rw_step];
-    }
-    float t0[VEC], t1[VEC];
-    const int c0 = tid * VEC, c1 = c0 + kBlock * VEC;
-    if (FIRST) {   // (W >= VEC * kBlock is not required: out-of-range lanes re-read column 0)
-      const float* g = a.logits + (size_t)blockIdx.x * W;
-      bgs::load_vec<VEC>(g + (c0 < W ? c0 : 0), t0);
-      bgs::load_vec<VEC>(g + (c1 < W ? c1 : 0), t1);
-    }
-    unsigned bits[kFusedRowsPerPass];
+  for (int i = 0; i < RP; ++i) {
+    const int r = tid + kBlock * i;
+    const int rc = r < N ? r : 0;
+    y0[i] = a.labels[rc];
+    rwv0[i] = rw_base[(size_t)rc * rw_step];
+  }
+  float t0[VEC], t1[VEC];
+  const int c0 = tid * VEC, c1 = c0 + kBlock * VEC;
+  {   // (W >= 2 * VEC * kBlock is not required: out-of-range lanes re-read column 0)
+    const float* g = a.logits + (size_t)blockIdx.x * W;
+    bgs::load_vec<VEC>(g + (c0 < W ? c0 : 0), t0);
+    bgs::load_vec<VEC>(g + (c1 < W ? c1 : 0), t1);
+  }
+  if (a.class_bits) {
+    // 8 table entries (16 B) per thread and pass
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const int cpad = (C + 7) & ~7;
+    for (int c = tid * 8; c < cpad; c += kBlock * 8) {
+      u32x4_t v;
+      if (c + 8 <= C && (reinterpret_cast<uintptr_t>(a.class_bits) & 15) == 0) {
+        v = *reinterpret_cast<const u32x4_t*>(a.class_bits + c);
+      } else {
+        unsigned short e[8];
 #pragma unroll
-    for (int i = 0; i < kFusedRowsPerPass; ++i) {
-      y[i] = y[i] < 0 ? 0 : (y[i] >= C ? (int64_t)C - 1 : y[i]);
-      bits[i] = 0u;
-    }
-    for (int b0 = 0; b0 < B; b0 += 8) {     // groups of 8 bins: 8 x kFusedRowsPerPass gathers in flight
-      int64_t v[8][kFusedRowsPerPass];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int bc = b0 + j < B ? b0 + j : 0;   // bins past B re-read bin 0 (same cache lines)
-#pragma unroll
-        for (int i = 0; i < kFusedRowsPerPass; ++i) v[j][i] = a.l2b[(size_t)bc * C + y[i]];
+        for (int j = 0; j < 8; ++j) e[j] = c + j < C ? a.class_bits[c + j] : (unsigned short)0;
+        v = u32x4_t{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                    (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
       }
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int i = 0; i < kFusedRowsPerPass; ++i)
-          if (b0 + j < B && v[j][i] > 0) bits[i] |= 1u << (b0 + j);
+      *reinterpret_cast<u32x4_t*>(sh_cbits + c) = v;
     }
-    if (FIRST) {
-      if (c0 < W) bgs::store_vec<VEC>(smem + c0, t0);
-      if (c1 < W) bgs::store_vec<VEC>(smem + c1, t1);
-      for (int c = c1 + kBlock * VEC; c < W; c += kBlock * VEC) {   // rows wider than 2 x 256 x VEC
-        float t[VEC];
-        bgs::load_vec<VEC>(a.logits + (size_t)blockIdx.x * W + c, t);
-        bgs::store_vec<VEC>(smem + c, t);
-      }
+  } else {
+    for (int c = tid; c < C; c += kBlock) {
+      unsigned bits = 0u;
+      for (int b = 0; b < B; ++b)
+        if (a.l2b[(size_t)b * C + c] > 0) bits |= 1u << b;
+      sh_cbits[c] = (unsigned short)bits;
     }
-    bool real[kFusedRowsPerPass];
+  }
+  if (c0 < W) bgs::store_vec<VEC>(smem + c0, t0);
+  if (c1 < W) bgs::store_vec<VEC>(smem + c1, t1);
+  for (int c = c1 + kBlock * VEC; c < W; c += kBlock * VEC) {   // rows wider than 2 x 256 x VEC
+    float t[VEC];
+    bgs::load_vec<VEC>(a.logits + (size_t)blockIdx.x * W + c, t);
+    bgs::store_vec<VEC>(smem + c, t);
+  }
+  __syncthreads();                        // class bits (and the first row) are in LDS
+  for (int base = 0; base < N; base += kBlock * RP) {
+    bool real[RP];
+    unsigned bits[RP];
 #pragma unroll
-    for (int i = 0; i < kFusedRowsPerPass; ++i) {
+    for (int i = 0; i < RP; ++i) {
       const int r = base + tid + kBlock * i;
-      real[i] = r < N && rwv[i] > 0.f;
+      int64_t y;
+      float rwv;
+      if (base == 0) {
+        y = y0[i];
+        rwv = rwv0[i];
+      } else {
+        const int rc = r < N ? r : 0;
+        y = a.labels[rc];
+        rwv = rw_base[(size_t)rc * rw_step];
+      }
+      y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
+      bits[i] = sh_cbits[(int)y];
+      real[i] = r < N && rwv > 0.f;
       if (r < N) sh_flags[r] = (unsigned short)(real[i] ? (bits[i] | 0x8000u) : 0u);
     }
     for (int b = 0; b <= B; ++b) {
       int pop = 0;
 #pragma unroll
-      for (int i = 0; i < kFusedRowsPerPass; ++i)
+      for (int i = 0; i < RP; ++i)
         pop += __popcll(__builtin_amdgcn_ballot_w64(real[i] && (b == B || ((bits[i] >> b) & 1u))));
       if (lane == b) mycnt += pop;
     }
-  };
-  prologue_pass(0, std::true_type{});
-  for (int base = kBlock * kFusedRowsPerPass; base < N; base += kBlock * kFusedRowsPerPass)
-    prologue_pass(base, std::false_type{});
+  }
   if (lane <= B) sh_cntw[wave * (BGS_MAX_BINS + 1) + lane] = mycnt;
   __syncthreads();                        // flags, counts and the first row are in LDS
 
@@ -503,61 +523,58 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
 }
 
 // out[b] = sum_g partial[b][g] for b < B (loss weights are already inside), out[B] = box loss
-// (scaled by loss_weight / avg[0]; 0 without a box branch), out[B + 1] = their sum — the scalar the
-// reference forms in parse_losses; fixed summation order.  `counter` (the device draw counter read
+// (scaled by loss_weight / avg[0]; 0 without a box branch), total[0] = their sum — the scalar the
+// reference forms in parse_losses; fixed summation order.  One wave per row of partials (all loads
+// of a row in flight at once, one DPP sum), one barrier.  `counter` (the device draw counter read
 // by the NEXT call's main kernel) is advanced here, behind every reader of this call.
 __global__ __launch_bounds__(1024) void gs_head_reduce_kernel(const float* __restrict__ partial, int G,
                                                               int B, int has_box, float box_w,
                                                               const float* __restrict__ avg,
                                                               float* __restrict__ out,
+                                                              float* __restrict__ total,
                                                               uint64_t* __restrict__ counter) {
-  __shared__ float sm[BGS_MAX_BINS + 1][16];
   __shared__ float fin[BGS_MAX_BINS + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;     // 16 waves >= B + 1 rows
   const int rows = B + (has_box ? 1 : 0);
-  for (int b = 0; b < rows; ++b) {
+  if (wave <= B) {
     float acc = 0.f;
-    for (int g = tid; g < G; g += 1024) acc += partial[(size_t)b * G + g];
-    const float s = bgs::wave_sum(acc);
-    if (lane == 0) sm[b][wave] = s;
-  }
-  __syncthreads();
-  if (tid <= B) {
-    float s = 0.f;
-    if (tid < rows) {
-#pragma unroll
-      for (int w = 0; w < 16; ++w) s += sm[tid][w];
-      if (tid == B) s *= box_w / avg[0];
+    if (wave < rows)
+      for (int g = lane; g < G; g += BGS_WAVE) acc += partial[(size_t)wave * G + g];
+    float s = bgs::wave_sum(acc);
+    if (wave == B && has_box) s *= box_w / avg[0];
+    if (lane == 0) {
+      fin[wave] = s;
+      out[wave] = s;
     }
-    fin[tid] = s;
-    out[tid] = s;
   }
   __syncthreads();
   if (tid == 0) {
     float t = 0.f;
     for (int b = 0; b <= B; ++b) t += fin[b];
-    out[B + 1] = t;
+    if (total) total[0] = t;
     if (counter) counter[0] += 1ull;
   }
 }
 
-// dlogits[:, bin b] *= g[b] + g[B + 1];  dbbox *= g[B] + g[B + 1]  (g = the upstream gradient of
-// the [B + 2] loss vector {bins, box, total}); early-out when every factor is 1 (the usual case).
+// dlogits[:, bin b] *= gt[b] + gT;  dbbox *= gt[B] + gT  (gt [B + 1] = upstream gradient of the loss
+// terms or null = 0, gT = upstream gradient of the total or null = 0); early-out when every factor
+// is 1 (the usual case: total.backward()).
 __global__ __launch_bounds__(kBlock) void gs_head_scale_grad_kernel(float* __restrict__ dlogits,
                                                                     float* __restrict__ dbbox,
                                                                     bgs::BinGeom geom,
-                                                                    const float* __restrict__ g, int N,
-                                                                    int B, int W, int R4) {
-  const float gt = g[B + 1];
+                                                                    const float* __restrict__ gterms,
+                                                                    const float* __restrict__ gtotal,
+                                                                    int N, int B, int W, int R4) {
+  const float gt = gtotal ? gtotal[0] : 0.f;
   bool all_one = true;
-  for (int b = 0; b < B; ++b) all_one = all_one && (g[b] + gt == 1.f);
-  const float gbox = g[B] + gt;
+  for (int b = 0; b < B; ++b) all_one = all_one && ((gterms ? gterms[b] : 0.f) + gt == 1.f);
+  const float gbox = (gterms ? gterms[B] : 0.f) + gt;
   extern __shared__ __attribute__((aligned(16))) float scale[];
   if (dlogits && !all_one) {
     for (int c = threadIdx.x; c < W; c += kBlock) {
       float sc = 0.f;
       for (int b = 0; b < B; ++b)
-        if (c >= geom.start[b] && c < geom.start[b] + geom.len[b]) sc = g[b] + gt;
+        if (c >= geom.start[b] && c < geom.start[b] + geom.len[b]) sc = (gterms ? gterms[b] : 0.f) + gt;
       scale[c] = sc;
     }
     __syncthreads();
@@ -664,7 +681,7 @@ int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* h
   for (int b = 0; b < BGS_MAX_BINS; ++b)
     a.lw[b] = (host_bin_loss_weight && b < a.B) ? host_bin_loss_weight[b] : 1.f;
   a.wpad = (a.W + 3) & ~3;
-  const size_t lds = gs_head_lds_bytes(a.N, a.wpad);
+  const size_t lds = gs_head_lds_bytes(a.N, a.C, a.wpad);
   if (lds > 64 * 1024) return BGS_ERR_UNSUPPORTED;      // the default LDS window (callers fall back
                                                          // to bgs_gs_prepare + bgs_gs_loss_fwd_bwd)
   const int grid = loss_grid(a.N);
@@ -720,19 +737,20 @@ extern "C" int bgs_gs_head_loss_fused(const float* logits, const int64_t* labels
 // The whole GSBBoxHeadWith0.loss() (gs_bbox_head_with0.py:147-186) as two launches:
 //   main kernel  = label remap + "others" sampling + per-bin loss fwd + bwd + the box branch
 //   reduce       = loss_out[0..B-1] per-bin losses (x bin_loss_weight), loss_out[B] = loss_bbox
-//                  (x box_loss_weight / #real rows), loss_out[B+1] = their sum; advances
+//                  (x box_loss_weight / #real rows), total_out[0] = their sum; advances
 //                  *draw_counter (device uint64, read by the main kernel as the draw index).
 // bbox_pred == NULL: no box branch (loss_out[B] = 0).  dbbox_pred (dense [N, 4R] gradient) only
 // when the box branch trains.  loss_out == NULL: main kernel only (profiling hook; the counter is
 // not advanced).  Same limits as bgs_gs_head_loss_fused.
 extern "C" int bgs_gs_head_step(const float* logits, const int64_t* labels,
-                                const int64_t* label2binlabel, const float* row_weights,
-                                const int64_t* host_pred_slice, const float* host_bin_loss_weight,
-                                int N, int C, int B, int W, double others_sample_ratio,
-                                uint64_t seed, uint64_t* draw_counter, const float* bbox_pred,
-                                const float* bbox_targets, const float* bbox_weights,
-                                int num_reg_classes, float beta, float box_loss_weight,
-                                float* loss_out, float* dlogits, float* dbbox_pred, float* avg_out,
+                                const int64_t* label2binlabel, const uint16_t* class_bin_mask,
+                                const float* row_weights, const int64_t* host_pred_slice,
+                                const float* host_bin_loss_weight, int N, int C, int B, int W,
+                                double others_sample_ratio, uint64_t seed, uint64_t* draw_counter,
+                                const float* bbox_pred, const float* bbox_targets,
+                                const float* bbox_weights, int num_reg_classes, float beta,
+                                float box_loss_weight, float* loss_out, float* total_out,
+                                float* dlogits, float* dbbox_pred, float* avg_out,
                                 int32_t* bin_labels_out, float* weights_out, void* workspace,
                                 bgs_stream_t stream) {
   if (!logits || !labels || !label2binlabel || !host_pred_slice || !avg_out || !workspace)
@@ -746,7 +764,8 @@ extern "C" int bgs_gs_head_step(const float* logits, const int64_t* labels,
     return BGS_ERR_INVALID_ARG;
   }
   GsHeadArgs a = {};
-  a.logits = logits; a.labels = labels; a.l2b = label2binlabel; a.row_weights = row_weights;
+  a.logits = logits; a.labels = labels; a.l2b = label2binlabel; a.class_bits = class_bin_mask;
+  a.row_weights = row_weights;
   a.N = N; a.C = C; a.B = B; a.W = W; a.ratio = others_sample_ratio; a.seed = seed;
   a.seed_offset = draw_counter; a.partial = (float*)workspace; a.dlogits = dlogits;
   a.avg_out = avg_out; a.bl_out = bin_labels_out; a.w_out = weights_out;
@@ -756,29 +775,53 @@ extern "C" int bgs_gs_head_step(const float* logits, const int64_t* labels,
   const int rc = launch_gs_head(a, host_pred_slice, host_bin_loss_weight, (hipStream_t)stream, &grid);
   if (rc != BGS_OK || !loss_out) return rc;
   hipLaunchKernelGGL(gs_head_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a.partial,
-                     grid, B, bbox_pred ? 1 : 0, box_loss_weight, avg_out, loss_out, draw_counter);
+                     grid, B, bbox_pred ? 1 : 0, box_loss_weight, avg_out, loss_out, total_out,
+                     draw_counter);
   BGS_RETURN_LAUNCH_STATUS();
 }
 
-// Backward of bgs_gs_head_step's loss vector: grad_loss [B + 2] = upstream gradient of {bins, box,
-// total}; scales dlogits per bin by grad[b] + grad[B+1] and dbbox_pred by grad[B] + grad[B+1] in
-// place (one launch, early-out when every factor is 1).
+// class_bin_mask[c] = sum_b (label2binlabel[b][c] > 0) << b — the per-class foreground-bin table
+// bgs_gs_head_step copies into LDS (built once per table; B <= 15).
+namespace {
+__global__ __launch_bounds__(256) void gs_class_bits_kernel(const int64_t* __restrict__ l2b, int C, int B,
+                                                            uint16_t* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  unsigned bits = 0u;
+  for (int b = 0; b < B; ++b)
+    if (l2b[(size_t)b * C + c] > 0) bits |= 1u << b;
+  out[c] = (uint16_t)bits;
+}
+}  // namespace
+
+extern "C" int bgs_gs_class_bin_mask(const int64_t* label2binlabel, int C, int B, uint16_t* out,
+                                     bgs_stream_t stream) {
+  if (!label2binlabel || !out || C <= 0 || B <= 0) return BGS_ERR_INVALID_ARG;
+  if (B > BGS_MAX_BINS - 1) return BGS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gs_class_bits_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, label2binlabel, C, B, out);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+// Backward of bgs_gs_head_step: grad_terms [B + 1] (upstream gradient of {bins, box}; NULL = 0) and
+// grad_total [1] (of the total; NULL = 0); scales dlogits per bin by grad_terms[b] + grad_total and
+// dbbox_pred by grad_terms[B] + grad_total in place (one launch, early-out when every factor is 1).
 extern "C" int bgs_gs_head_step_scale_grad(float* dlogits, float* dbbox_pred,
-                                           const int64_t* host_pred_slice, const float* grad_loss,
-                                           int N, int B, int W, int num_reg_classes,
-                                           bgs_stream_t stream) {
+                                           const int64_t* host_pred_slice, const float* grad_terms,
+                                           const float* grad_total, int N, int B, int W,
+                                           int num_reg_classes, bgs_stream_t stream) {
   if (N < 0 || B <= 0 || W <= 0 || B > BGS_MAX_BINS - 1) return BGS_ERR_INVALID_ARG;
   if (N == 0 || (!dlogits && !dbbox_pred)) return BGS_OK;
-  if (!host_pred_slice || !grad_loss) return BGS_ERR_INVALID_ARG;
+  if (!host_pred_slice || (!grad_terms && !grad_total)) return BGS_ERR_INVALID_ARG;
   bgs::BinGeom geom;
   const int rc = bgs::make_bin_geom(host_pred_slice, B, W, &geom, nullptr);
   if (rc != BGS_OK) return rc;
   const size_t total = (size_t)N * (dbbox_pred ? (size_t)num_reg_classes * 4 : (size_t)W);
   size_t blocks = (total + kBlock - 1) / kBlock;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 512) blocks = 512;       // two workgroups per CU: the usual call early-outs
   hipLaunchKernelGGL(gs_head_scale_grad_kernel, dim3((unsigned)blocks), dim3(kBlock),
                      sizeof(float) * (size_t)W, (hipStream_t)stream, dlogits, dbbox_pred, geom,
-                     grad_loss, N, B, W, num_reg_classes * 4);
+                     grad_terms, grad_total, N, B, W, num_reg_classes * 4);
   BGS_RETURN_LAUNCH_STATUS();
 }
 

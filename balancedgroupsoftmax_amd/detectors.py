@@ -94,6 +94,7 @@ class TwoStageDetector(nn.Module):
         assigned = BF.iou_assign(props, gt_cat, offs, ac.pos_iou_thr, ac.neg_iou_thr,
                                  ac.get('min_pos_iou', 0.0), valid=pvalid, shared_boxes=False)
         add_gt = sc.get('add_gt_as_proposals', True)
+        rcnn_hook = samplers.get('rcnn') if samplers else None
         boxes_l, assigned_l, inds_l, valid_l = [], [], [], []
         for i in range(N):
             b, a = props[i, :, :4], assigned[i]
@@ -103,11 +104,11 @@ class TwoStageDetector(nn.Module):
                 a = torch.cat([torch.arange(1, G + 1, device=a.device, dtype=torch.int32), a])
             boxes_l.append(b.contiguous())
             assigned_l.append(a.contiguous())
-            if samplers is not None:       # test hook: caller-supplied draw
-                inds, _, valid = samplers['rcnn'](a, sc.num, sc.pos_fraction)
+            if rcnn_hook is not None:      # test hook: caller-supplied draw
+                inds, _, valid = rcnn_hook(a, sc.num, sc.pos_fraction)
                 inds_l.append(inds.contiguous())
                 valid_l.append(valid)
-        if samplers is None:
+        if rcnn_hook is None:
             if any(a.numel() > 4096 for a in assigned_l):
                 raise NotImplementedError('bgs_sample_rois sorts <= 4096 candidates per image in LDS '
                                           '(rpn_proposal.max_num + GT boxes)')

@@ -196,16 +196,39 @@ class _GsHeadFusedLoss(torch.autograd.Function):
         return (out,) + (None,) * 8
 
 
+_CLASS_BITS = {}
+
+
+def gs_class_bin_mask(label2binlabel):
+    """``[C]`` uint16 device table, bit b = class is foreground in bin b
+    (``bgs_gs_class_bin_mask``); cached per table tensor (the tables are constants of a head)."""
+    _require_cuda(label2binlabel)
+    key = (label2binlabel.data_ptr(), label2binlabel._version, tuple(label2binlabel.shape))
+    hit = _CLASS_BITS.get(key)
+    if hit is not None:
+        return hit[1]
+    lib = capi.load()
+    B, C = label2binlabel.shape
+    out = torch.empty((C,), dtype=torch.int16, device=label2binlabel.device)
+    rc = lib.bgs_gs_class_bin_mask(capi.ptr(label2binlabel), C, B, capi.ptr(out),
+                                   capi.current_stream(label2binlabel.device))
+    capi.check('bgs_gs_class_bin_mask', rc)
+    if len(_CLASS_BITS) > 64:
+        _CLASS_BITS.clear()
+    _CLASS_BITS[key] = (label2binlabel, out)
+    return out
+
+
 class _GsHeadStepFn(torch.autograd.Function):
     """``bgs_gs_head_step``: the whole ``GSBBoxHeadWith0.loss()`` as main kernel + reduce.  Returns
-    the loss vector ``[B + 2]`` = {per-bin losses (x loss weights), loss_bbox, their sum} and
+    ``terms [B + 1]`` = {per-bin losses (x loss weights), loss_bbox}, ``total [1]`` = their sum and
     ``avg [B]``; backward is ONE scaling launch over the gradients the forward already produced
     (early-out on the device when the upstream factors are 1)."""
 
     @staticmethod
-    def forward(ctx, logits, bbox_pred, labels, l2b, pred_slice_host, bin_loss_weight_host, ratio,
-                seed, counter, row_weights, bbox_targets, bbox_weights, num_reg_classes, beta,
-                box_loss_weight, debug):
+    def forward(ctx, logits, bbox_pred, labels, l2b, class_bits, pred_slice_host,
+                bin_loss_weight_host, ratio, seed, counter, row_weights, bbox_targets, bbox_weights,
+                num_reg_classes, beta, box_loss_weight, debug):
         import numpy as np
         lib = capi.load()
         z = _f32c(logits)
@@ -217,7 +240,8 @@ class _GsHeadStepFn(torch.autograd.Function):
         R = int(num_reg_classes) if box else 1
         if box:
             assert tuple(p.shape) == (N, 4 * R), (p.shape, N, R)
-        loss = torch.empty((B + 2,), dtype=torch.float32, device=dev)
+        terms = torch.empty((B + 1,), dtype=torch.float32, device=dev)
+        total = torch.empty((1,), dtype=torch.float32, device=dev)
         avg = torch.empty((B,), dtype=torch.float32, device=dev)
         dlogits = torch.empty_like(z) if logits.requires_grad else None
         dbbox = torch.empty_like(p) if (box and bbox_pred.requires_grad) else None
@@ -230,54 +254,58 @@ class _GsHeadStepFn(torch.autograd.Function):
         lw_ptr = None if lw_keep is None else lw_keep.ctypes.data_as(ctypes.c_void_p)
         rw = None if row_weights is None else _f32c(row_weights)
         rc = lib.bgs_gs_head_step(
-            capi.ptr(z), capi.ptr(labels), capi.ptr(l2b), capi.ptr(rw), ps_ptr, lw_ptr, N, C, B, W,
-            float(ratio), int(seed), capi.ptr(counter), capi.ptr(p),
+            capi.ptr(z), capi.ptr(labels), capi.ptr(l2b), capi.ptr(class_bits), capi.ptr(rw), ps_ptr,
+            lw_ptr, N, C, B, W, float(ratio), int(seed), capi.ptr(counter), capi.ptr(p),
             capi.ptr(_f32c(bbox_targets)) if box else None,
             capi.ptr(_f32c(bbox_weights)) if box else None, R, float(beta), float(box_loss_weight),
-            capi.ptr(loss), capi.ptr(dlogits), capi.ptr(dbbox), capi.ptr(avg), capi.ptr(bl),
-            capi.ptr(w), capi.ptr(ws), capi.current_stream(dev))
+            capi.ptr(terms), capi.ptr(total), capi.ptr(dlogits), capi.ptr(dbbox), capi.ptr(avg),
+            capi.ptr(bl), capi.ptr(w), capi.ptr(ws), capi.current_stream(dev))
         capi.check('bgs_gs_head_step', rc)
         ctx.grads = (dlogits, dbbox)
         ctx.meta = (pred_slice_host, N, B, W, R, logits.dtype, None if not box else bbox_pred.dtype)
         ctx.consumed = False
-        ctx.mark_non_differentiable(avg)
+        ctx.set_materialize_grads(False)     # an unused output (terms or total) arrives as None, not zeros
         if debug:
-            ctx.mark_non_differentiable(bl, w)
-            return loss, avg, bl, w
-        return loss, avg
+            ctx.mark_non_differentiable(avg, bl, w)
+            return terms, total, avg, bl, w
+        ctx.mark_non_differentiable(avg)
+        return terms, total, avg
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, grad_loss, *_unused):
+    def backward(ctx, g_terms, g_total, *_unused):
         dlogits, dbbox = ctx.grads
         ps_host, N, B, W, R, zdt, pdt = ctx.meta
-        if dlogits is None and dbbox is None:
-            return (None,) * 16
+        if (dlogits is None and dbbox is None) or (g_terms is None and g_total is None):
+            return (None,) * 17
         if ctx.consumed:     # the buffers are scaled in place and handed to autograd (see _GroupSoftmaxLoss)
             raise RuntimeError('gs_head_step: the fused gradient buffers were consumed by the first '
                                'backward; call the loss again')
         lib = capi.load()
-        g = grad_loss.detach().to(torch.float32).contiguous()
+        gt = None if g_terms is None else g_terms.detach().to(torch.float32).contiguous()
+        gT = None if g_total is None else g_total.detach().to(torch.float32).contiguous()
         ps_keep, ps_ptr = capi.host_i64(ps_host)
         dev = (dlogits if dlogits is not None else dbbox).device
-        rc = lib.bgs_gs_head_step_scale_grad(capi.ptr(dlogits), capi.ptr(dbbox), ps_ptr, capi.ptr(g),
-                                             N, B, W, R, capi.current_stream(dev))
+        rc = lib.bgs_gs_head_step_scale_grad(capi.ptr(dlogits), capi.ptr(dbbox), ps_ptr, capi.ptr(gt),
+                                             capi.ptr(gT), N, B, W, R, capi.current_stream(dev))
         capi.check('bgs_gs_head_step_scale_grad', rc)
         ctx.consumed = True
         gz = dlogits if (dlogits is None or zdt == torch.float32) else dlogits.to(zdt)
         gp = dbbox if (dbbox is None or pdt == torch.float32) else dbbox.to(pdt)
-        return (gz, gp) + (None,) * 14
+        return (gz, gp) + (None,) * 15
 
 
 def gs_head_step(cls_score, labels, label2binlabel, pred_slice, others_sample_ratio, seed,
                  draw_counter=None, row_weights=None, bin_loss_weight=None, bbox_pred=None,
                  bbox_targets=None, bbox_weights=None, num_reg_classes=1, beta=1.0,
-                 box_loss_weight=1.0, debug=False):
-    """The whole BAGS head loss as two launches (``bgs_gs_head_step``): returns ``(loss_vec, avg)``
-    with ``loss_vec [B + 2]`` = per-bin classification losses (times ``bin_loss_weight``, a HOST
-    sequence), ``loss_bbox`` (0 without ``bbox_pred``) and their sum.  ``draw_counter``: device
-    int64 ``[1]``, read as this call's draw index and advanced BY THE KERNEL (fresh "others" samples
-    under hipGraph replay without a tensor op).  Same limits as :func:`gs_head_loss_fused`."""
+                 box_loss_weight=1.0, debug=False, class_bits='auto'):
+    """The whole BAGS head loss as two launches (``bgs_gs_head_step``): returns ``(terms, total,
+    avg)`` with ``terms [B + 1]`` = per-bin classification losses (times ``bin_loss_weight``, a HOST
+    sequence) followed by ``loss_bbox`` (0 without ``bbox_pred``), ``total [1]`` = their sum (both
+    differentiable) and ``avg [B]``.  ``draw_counter``: device int64 ``[1]``, read as this call's
+    draw index and advanced BY THE KERNEL (fresh "others" samples under hipGraph replay without a
+    tensor op).  ``class_bits``: ``'auto'`` builds / reuses :func:`gs_class_bin_mask`, ``None`` lets
+    every workgroup derive the table from ``label2binlabel``.  Limits of :func:`gs_head_loss_fused`."""
     _require_cuda(cls_score, labels, label2binlabel, row_weights, bbox_pred, bbox_targets,
                   bbox_weights, draw_counter)
     assert labels.dtype == torch.int64 and label2binlabel.dtype == torch.int64
@@ -286,7 +314,10 @@ def gs_head_step(cls_score, labels, label2binlabel, pred_slice, others_sample_ra
         assert draw_counter.dtype == torch.int64 and draw_counter.numel() == 1
     if bbox_pred is not None:
         assert bbox_targets is not None and bbox_weights is not None
-    return _GsHeadStepFn.apply(cls_score, bbox_pred, labels.contiguous(), label2binlabel.contiguous(),
+    label2binlabel = label2binlabel.contiguous()
+    if isinstance(class_bits, str):
+        class_bits = gs_class_bin_mask(label2binlabel)
+    return _GsHeadStepFn.apply(cls_score, bbox_pred, labels.contiguous(), label2binlabel, class_bits,
                                _host_pred_slice(pred_slice), bin_loss_weight,
                                float(others_sample_ratio), int(seed), draw_counter, row_weights,
                                bbox_targets, bbox_weights, int(num_reg_classes), float(beta),

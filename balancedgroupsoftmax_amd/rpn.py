@@ -228,7 +228,7 @@ class RPNHead(nn.Module):
             raise NotImplementedError('gt_max_assign_all=False')
         assigned = BF.iou_assign(anchors, gt_cat, offs, ac.pos_iou_thr, ac.neg_iou_thr,
                                  ac.get('min_pos_iou', 0.0), valid=inside, shared_boxes=True)
-        if samplers is None:      # one launch for the batch (csrc/sampler.hip)
+        if not samplers or samplers.get('rpn') is None:      # one launch for the batch (csrc/sampler.hip)
             pos_m, neg_m = BF.sample_pos_neg(assigned, sc.num, sc.pos_fraction,
                                              sc.get('neg_pos_ub', -1))
         else:                     # test hook: caller-supplied draw (oracle/tensor_forms.sampler_hooks)

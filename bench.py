@@ -149,17 +149,17 @@ class GsHeadStep(object):
         self.logits = inp['logits'].clone().requires_grad_(True)
         # device-side draw counter, advanced by the reduce kernel: a new sample every step, also under graph replay
         self.draw = torch.zeros(1, dtype=torch.int64, device=inp['logits'].device)
-        self.nb = inp['ps_np'].shape[0]
+        self.one = torch.ones(1, dtype=torch.float32, device=inp['logits'].device)
 
     def __call__(self):
         i = self.inp
         self.logits.grad = None
-        vec, _avg = BF.gs_head_step(self.logits, i['labels'], i['l2b'], i['ps_np'], 8.0, 12345,
-                                    draw_counter=self.draw, bbox_pred=i['bbox_pred'],
-                                    bbox_targets=i['bbox_targets'], bbox_weights=i['bbox_weights'],
-                                    num_reg_classes=NUM_CLASSES, beta=1.0, box_loss_weight=1.0)
-        total = vec[self.nb + 1]
-        total.backward()
+        _terms, total, _avg = BF.gs_head_step(self.logits, i['labels'], i['l2b'], i['ps_np'], 8.0, 12345,
+                                              draw_counter=self.draw, bbox_pred=i['bbox_pred'],
+                                              bbox_targets=i['bbox_targets'],
+                                              bbox_weights=i['bbox_weights'],
+                                              num_reg_classes=NUM_CLASSES, beta=1.0, box_loss_weight=1.0)
+        total.backward(self.one)      # the root gradient is a persistent tensor, not a fill per step
         return total
 
 
@@ -514,14 +514,16 @@ def kernel_roofline(inp, n, iters=300, kernel='fused'):
     st = capi.current_stream(dev)
     if kernel == 'fused':
         avg = torch.empty(B, dtype=torch.float32, device=dev)
+        cbits = BF.gs_class_bin_mask(inp['l2b'])
         kname = 'gs_head_fused_kernel<4,true,true>'
 
         def launch():
             rc = lib.bgs_gs_head_step(capi.ptr(inp['logits']), capi.ptr(inp['labels']), capi.ptr(inp['l2b']),
-                                      None, ps_ptr, None, n, NUM_CLASSES, B, W, 8.0, 12345, None,
-                                      capi.ptr(inp['bbox_pred']), capi.ptr(inp['bbox_targets']),
-                                      capi.ptr(inp['bbox_weights']), NUM_CLASSES, 1.0, 1.0, None,
-                                      capi.ptr(dl), None, capi.ptr(avg), None, None, capi.ptr(ws), st)
+                                      capi.ptr(cbits), None, ps_ptr, None, n, NUM_CLASSES, B, W, 8.0,
+                                      12345, None, capi.ptr(inp['bbox_pred']),
+                                      capi.ptr(inp['bbox_targets']), capi.ptr(inp['bbox_weights']),
+                                      NUM_CLASSES, 1.0, 1.0, None, None, capi.ptr(dl), None,
+                                      capi.ptr(avg), None, None, capi.ptr(ws), st)
             capi.check('bgs_gs_head_step', rc)
     else:
         bl, w, avg = BF.gs_prepare(inp['labels'], inp['l2b'], 8.0, seed=1)
@@ -716,9 +718,9 @@ def gs_head_metric(inp, n, steps=300, warmup=20):
     return dict(value=round(dt * 1e6 / (steps * n), 6), unit='us/RoI', us_per_step=round(dt * 1e6 / steps, 2),
                 rois_per_step=n, steps=steps,
                 launch='hipGraph replay' if graph is not None else 'eager launches',
-                what='gs_head_loss_fused (label remap + others sampling + per-bin loss fwd + bwd) + box '
-                     'loss + reductions + autograd plumbing; launch-latency bound (the fused kernel '
-                     'itself: ~12 us)')
+                what='bgs_gs_head_step: main kernel (label remap + others sampling + per-bin loss fwd + bwd '
+                     '+ box branch) + reduce (6 terms, total, draw counter) + the autograd edge (one '
+                     'scaling launch); launch-latency bound')
 
 
 STEP_GFLOP = {

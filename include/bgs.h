@@ -130,25 +130,32 @@ int bgs_gs_head_loss_fused(const float* logits, const int64_t* labels, const int
  *                 box_loss_weight / max(#real rows, 1); dbbox_pred = its dense [N, 4R] gradient
  *                 (NULL: not wanted — the shipped selectp=1 mode);
  *   reduce      = loss_out[0..B-1] per-bin losses, loss_out[B] = loss_bbox (0 when bbox_pred is
- *                 NULL), loss_out[B+1] = their sum (fixed order: bitwise reproducible); advances
+ *                 NULL), total_out[0] (or NULL) = their sum (fixed order: bitwise reproducible); advances
  *                 *draw_counter (device uint64 or NULL), which the main kernel read as the index of
  *                 this call's "others" draw — hipGraph replays draw fresh samples with no extra launch.
  * loss_out == NULL: main kernel only (profiling hook).  Limits of bgs_gs_head_loss_fused;
  * BGS_ERR_UNSUPPORTED also when two rows + the flag words exceed the 64 KB LDS window. */
 int bgs_gs_head_step(const float* logits, const int64_t* labels, const int64_t* label2binlabel,
-                     const float* row_weights, const int64_t* host_pred_slice,
-                     const float* host_bin_loss_weight, int N, int C, int B, int W,
-                     double others_sample_ratio, uint64_t seed, uint64_t* draw_counter,
+                     const uint16_t* class_bin_mask, const float* row_weights,
+                     const int64_t* host_pred_slice, const float* host_bin_loss_weight, int N, int C,
+                     int B, int W, double others_sample_ratio, uint64_t seed, uint64_t* draw_counter,
                      const float* bbox_pred, const float* bbox_targets, const float* bbox_weights,
                      int num_reg_classes, float beta, float box_loss_weight, float* loss_out,
-                     float* dlogits, float* dbbox_pred, float* avg_out, int32_t* bin_labels_out,
-                     float* weights_out, void* workspace, bgs_stream_t stream);
-/* Backward of bgs_gs_head_step's loss vector: grad_loss [B+2] (device) = upstream gradient of
- * {bins, box, total}; dlogits[:, bin b] *= grad[b] + grad[B+1], dbbox_pred *= grad[B] + grad[B+1],
- * in place, one launch, early-out on the device when every factor is 1. */
+                     float* total_out, float* dlogits, float* dbbox_pred, float* avg_out,
+                     int32_t* bin_labels_out, float* weights_out, void* workspace,
+                     bgs_stream_t stream);
+/* class_bin_mask [C] uint16 (device): bit b = class is foreground in bin b (label2binlabel[b][c] > 0).
+ * Built once per table; bgs_gs_head_step copies it into LDS instead of gathering the [B,C] int64
+ * table per row (NULL there: every workgroup derives it from label2binlabel, slower). */
+int bgs_gs_class_bin_mask(const int64_t* label2binlabel, int C, int B, uint16_t* out,
+                          bgs_stream_t stream);
+/* Backward of bgs_gs_head_step: grad_terms [B+1] (device; upstream gradient of {bins, box}, NULL = 0)
+ * and grad_total [1] (of total_out, NULL = 0): dlogits[:, bin b] *= grad_terms[b] + grad_total,
+ * dbbox_pred *= grad_terms[B] + grad_total, in place, one launch, early-out on the device when
+ * every factor is 1. */
 int bgs_gs_head_step_scale_grad(float* dlogits, float* dbbox_pred, const int64_t* host_pred_slice,
-                                const float* grad_loss, int N, int B, int W, int num_reg_classes,
-                                bgs_stream_t stream);
+                                const float* grad_terms, const float* grad_total, int N, int B, int W,
+                                int num_reg_classes, bgs_stream_t stream);
 /* Second phase of bgs_gs_loss_fwd_bwd(loss_out = NULL): loss_out[b] = sum of the partials. */
 int bgs_gs_loss_reduce(const void* workspace, int N, int B, float* loss_out, bgs_stream_t stream);
 

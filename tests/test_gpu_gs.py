@@ -531,20 +531,20 @@ def test_head_step_two_launches_equal_the_separate_kernels(name, train_box):
         ((ref * (g[:B] + g[B + 1])).sum() + refb * (g[B] + g[B + 1])).backward()
         z1 = dev(batch['logits']).requires_grad_(True)
         p1 = dev(bp).requires_grad_(train_box)
-        vec, avg1, bl1, w1 = BF.gs_head_step(z1, labels, l2b_t, ps, ratio, 4242, draw_counter=counter,
-                                             row_weights=rw_t, bin_loss_weight=lw, bbox_pred=p1,
-                                             bbox_targets=dev(bt), bbox_weights=dev(bw),
-                                             num_reg_classes=R, beta=1.0, box_loss_weight=0.75,
-                                             debug=True)
+        terms, total, avg1, bl1, w1 = BF.gs_head_step(
+            z1, labels, l2b_t, ps, ratio, 4242, draw_counter=counter, row_weights=rw_t,
+            bin_loss_weight=lw, bbox_pred=p1, bbox_targets=dev(bt), bbox_weights=dev(bw),
+            num_reg_classes=R, beta=1.0, box_loss_weight=0.75, debug=True,
+            class_bits='auto' if rw is None else None)       # both ways of getting the class-bits table
         assert int(counter) == 12                                   # advanced by the reduce kernel
-        (vec * g).sum().backward()
+        ((terms * g[:B + 1]).sum() + total[0] * g[B + 1]).backward()
         np.testing.assert_array_equal(bl1.cpu().numpy(), bl.cpu().numpy())
         np.testing.assert_array_equal(w1.cpu().numpy(), w.cpu().numpy())
         np.testing.assert_array_equal(avg1.cpu().numpy(), avg.cpu().numpy())
-        v = vec.detach().cpu().numpy()
+        v = terms.detach().cpu().numpy()
         np.testing.assert_allclose(v[:B], ref.detach().cpu().numpy(), rtol=1e-6, atol=0)
         np.testing.assert_allclose(v[B], float(refb.detach()), rtol=2e-6, atol=1e-9)
-        np.testing.assert_allclose(v[B + 1], v[:B + 1].astype(np.float64).sum(), rtol=1e-6)
+        np.testing.assert_allclose(float(total.detach()), v.astype(np.float64).sum(), rtol=1e-6)
         np.testing.assert_allclose(z1.grad.cpu().numpy(), z0.grad.cpu().numpy(), rtol=1e-6, atol=1e-12)
         if train_box:
             np.testing.assert_allclose(p1.grad.cpu().numpy(), p0.grad.cpu().numpy(), rtol=1e-6, atol=1e-12)
@@ -565,25 +565,26 @@ def test_head_step_without_box_branch_and_unit_factors_is_bitwise_the_fused_loss
     ref = BF.group_softmax_loss(z0, bl, ps, w, avg)
     ref.sum().backward()
     z1 = dev(batch['logits']).requires_grad_(True)
-    vec, _ = BF.gs_head_step(z1, labels, l2b_t, ps, 8.0, 31, draw_counter=counter)
-    vec[B + 1].backward()
-    v = vec.detach().cpu().numpy()
+    terms, total, _ = BF.gs_head_step(z1, labels, l2b_t, ps, 8.0, 31, draw_counter=counter)
+    total.backward(torch.ones(1, device=DEV))
+    v = terms.detach().cpu().numpy()
     np.testing.assert_array_equal(v[:B], ref.detach().cpu().numpy())
     assert v[B] == 0.0
     np.testing.assert_array_equal(z1.grad.cpu().numpy(), z0.grad.cpu().numpy())
     # a second call draws a different "others" sample (the counter moved), a reset counter repeats it
-    vec2, _ = BF.gs_head_step(dev(batch['logits']), labels, l2b_t, ps, 8.0, 31, draw_counter=counter)
-    assert not np.array_equal(vec2.cpu().numpy()[1:B], v[1:B])
+    t2, _, _ = BF.gs_head_step(dev(batch['logits']), labels, l2b_t, ps, 8.0, 31, draw_counter=counter)
+    assert not np.array_equal(t2.cpu().numpy()[1:B], v[1:B])
     counter.zero_()
-    vec3, _ = BF.gs_head_step(dev(batch['logits']), labels, l2b_t, ps, 8.0, 31, draw_counter=counter)
-    np.testing.assert_array_equal(vec3.cpu().numpy(), v)
+    t3, tot3, _ = BF.gs_head_step(dev(batch['logits']), labels, l2b_t, ps, 8.0, 31, draw_counter=counter)
+    np.testing.assert_array_equal(t3.cpu().numpy(), v)
+    np.testing.assert_array_equal(tot3.cpu().numpy(), total.detach().cpu().numpy())
 
 
 def test_head_step_refuses_rows_beyond_the_lds_window():
     """two staged rows + flags must fit the 64 KB LDS window — BGS_ERR_UNSUPPORTED (the
     head then takes the two-kernel path) instead of a failed launch."""
     from balancedgroupsoftmax_amd import capi
-    Wbig = 7600
+    Wbig = 8100
     ps = np.array([[0, 2], [2, Wbig - 2]], np.int64)
     l2b = np.zeros((2, Wbig - 1), np.int64)
     l2b[0, 1:] = 1
