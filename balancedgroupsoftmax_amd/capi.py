@@ -85,6 +85,8 @@ SIGNATURES = {
     'bgs_conv3x3_halo_bfx_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 5),
     'bgs_conv3x3_halo_nhwc_f32_bfx': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, c_f32p]
                                       + [ctypes.c_int] * 7 + [c_ptr, ctypes.c_size_t, c_ptr]),
+    'bgs_conv1x1_bres_enable': (None, [ctypes.c_int]),
+    'bgs_conv1x1_bres_last_launch': (ctypes.c_int, []),
     'bgs_launch_census': (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     'bgs_conv_bfx_tuning': (None, [ctypes.c_int] * 2),
     'bgs_conv_bfx_last_launch': (ctypes.c_int, [c_ptr, c_ptr]),

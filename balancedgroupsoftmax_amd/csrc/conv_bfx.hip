@@ -42,6 +42,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // wait for the load right where it is issued (in front of the MFMAs instead of behind them).
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[16];
 
+}  // namespace
+
+// conv1x1_bres.hip
+int bgs_internal_conv1x1_bres(const bgs_conv::ConvArgs& p, const void* wsplit, int KC, int planes,
+                              const unsigned* zero, hipStream_t st);
+
+namespace {
+
 struct BfxArgs {
   const unsigned* zero;  // device address of g_zero_page (read through SGPRs by the DMA kernel)
   int ns;                // operand planes used: 3 = fp32-faithful (six products), 1 = bf16 operands
@@ -1482,6 +1490,19 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   q.zero = zero_page_device();
   if (!q.zero) return BGS_ERR_LAUNCH;
   const BfxKnobs& knobs = bfx_knobs();
+  if (up == 1 && knobs.tile == 0 && knobs.splitk < 0 && knobs.dma) {
+    // short-reduction 1x1 layers with Cout % 256 == 0: filter resident in registers, activations
+    // read once (conv1x1_bres.hip); -1 = not eligible
+    p.partial = nullptr;
+    p.kt_per_split = 0;
+    const int rc = bgs_internal_conv1x1_bres(p, q.ws, q.KC, q.ns, q.zero, st);
+    if (rc >= 0) {
+      g_last_tile = 0x1000;      // bit 12: the filter-resident 1x1 kernel ran
+      g_last_splits = 1;
+      g_last_dma = 0;
+      return rc;
+    }
+  }
   const long long M = p.M;
   int tile, bk, want;
   bfx_plan(M, p.Cout, q.KC, tile, bk, want);

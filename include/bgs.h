@@ -333,6 +333,13 @@ int bgs_launch_census(int family, int reset);
 void bgs_conv_bfx_tuning(int tile, int splitk);
 int bgs_conv_bfx_last_launch(int* tile, int* splits);
 void bgs_conv3x3_halo_bfx_tuning(int splits, int variant);
+/* Filter-resident 1x1 kernel (csrc/conv1x1_bres.hip: K = Cin in {64,128,256}, Cout % 256 == 0,
+ * M >= 4096, bf16x6 mode): on by default wherever eligible inside bgs_conv2d_nhwc_f32_bfx_ws /
+ * bgs_conv2d_dgrad_nhwc_f32_bfx_ws (bit-identical results); enable(0) routes those layers back
+ * to the 64 x 64 operand ring (A/B runs, tests).  last_launch: 1 when the last eligible-path call
+ * ran it. */
+void bgs_conv1x1_bres_enable(int on);
+int bgs_conv1x1_bres_last_launch(void);
 int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits);
 
 /* Grouped 3x3 convolution (pad 1, stride 1 or 2) + bias + ReLU, NHWC: conv2 of the ResNeXt

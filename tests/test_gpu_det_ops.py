@@ -796,3 +796,80 @@ def test_conv_bf16_mode_large_layers_run_the_8_wave_128x128_ring(monkeypatch, ca
     finally:
         BF.conv_bfx_tuning()
         BF.set_conv_math(prev)
+
+
+@pytest.mark.parametrize('shape', [
+    # (N, H, W, Cin, Cout, stride, residual mode)
+    (1, 67, 75, 256, 256, 1, 0),      # M = 5025: last tile has 1 row
+    (2, 50, 84, 256, 256, 1, 2),      # fpn lateral with the nearest-2x-upsampled top-down add
+    (1, 80, 96, 64, 256, 1, 1),       # layer1 conv3: K = 64, residual + ReLU
+    (2, 50, 84, 128, 512, 1, 1),      # layer2 conv3: K = 128, two 256-channel slabs
+    (1, 100, 168, 256, 512, 2, 0),    # layer2 projection shortcut: stride 2
+    (2, 50, 84, 256, 1024, 1, 1),     # layer3 conv3: four slabs
+])
+def test_conv1x1_filter_resident_kernel_is_bit_identical_to_the_operand_ring(shape):
+    """``conv1x1_bres_kernel`` (csrc/conv1x1_bres.hip: split filter resident in registers, activation
+    tiles DMA'd once) against the 64 x 64 operand ring it replaces on the short-reduction 1x1 layers:
+    BIT-IDENTICAL outputs (same products, same accumulation order), and both against torch-CPU
+    ``F.conv2d`` incl. bias / residual / ReLU; dispatch asserted through the last-launch query."""
+    import torch.nn.functional as F
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    N, H, W, Cin, Cout, stride, rmode = shape
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + stride)
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, 1, 1, Cin, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = None
+    if rmode == 1:
+        res = torch.randn(N, Ho, Wo, Cout, generator=g)
+    elif rmode == 2:
+        res = torch.randn(N, Ho // 2, Wo // 2, Cout, generator=g)
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        outs = []
+        for on in (1, 0):
+            lib.bgs_conv1x1_bres_enable(on)
+            y = BF.conv2d_nhwc(dev(x), dev(w), dev(b), stride=stride, relu=True,
+                               residual=None if res is None else dev(res), residual_mode=rmode)
+            assert lib.bgs_conv1x1_bres_last_launch() == on
+            outs.append(y.cpu())
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        lib.bgs_conv1x1_bres_enable(1)
+        BF.set_conv_math(prev)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), stride=stride)
+    if rmode == 1:
+        ref = ref + res.permute(0, 3, 1, 2).double()
+    elif rmode == 2:
+        ref = ref + F.interpolate(res.permute(0, 3, 1, 2).double(), scale_factor=2, mode='nearest')
+    ref = torch.relu(ref).permute(0, 2, 3, 1)
+    err = float((outs[0].double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+
+
+def test_conv1x1_filter_resident_kernel_as_data_gradient_with_mask():
+    """The same kernel under ``bgs_conv2d_dgrad_nhwc_f32_bfx_ws`` (1x1, stride 1: the data gradient of
+    a 1x1 conv is a 1x1 conv with the transposed filter) with the ReLU-backward mask and a residual
+    gradient in the epilogue: bit-identical to the ring kernel."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    g = torch.Generator().manual_seed(5)
+    N, H, W, Cin, Cout = 2, 50, 84, 1024, 256          # dgrad: K = Cout = 256 -> Cin = 1024 channels
+    dy = torch.randn(N, H, W, Cout, generator=g)
+    w = torch.randn(Cout, 1, 1, Cin, generator=g) * 0.05
+    res = torch.randn(N, H, W, Cin, generator=g)
+    mask = torch.randn(N, H, W, Cin, generator=g)
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        outs = []
+        for on in (1, 0):
+            lib.bgs_conv1x1_bres_enable(on)
+            dx = BF.conv2d_dgrad_nhwc(dev(dy), dev(w), (H, W), residual=dev(res), mask=dev(mask))
+            assert lib.bgs_conv1x1_bres_last_launch() == on
+            outs.append(dx.cpu())
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        lib.bgs_conv1x1_bres_enable(1)
+        BF.set_conv_math(prev)
