@@ -73,6 +73,10 @@ SIGNATURES = {
     'bgs_conv2d_wgrad_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 9),
     'bgs_conv2d_wgrad_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p]
                                   + [ctypes.c_int] * 10 + [c_ptr, c_ptr]),
+    'bgs_conv2d_wgrad_bfx_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 9),
+    'bgs_conv2d_wgrad_nhwc_f32_bfx': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p]
+                                      + [ctypes.c_int] * 11 + [c_ptr, c_ptr]),
+    'bgs_conv2d_wgrad_bfx_enable': (None, [ctypes.c_int]),
     'bgs_conv3x3_halo_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 6
                                   + [c_ptr]),
     'bgs_conv_bfx_weight_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),

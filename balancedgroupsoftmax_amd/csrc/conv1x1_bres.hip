@@ -13,7 +13,7 @@
 // Cout / 64 times and the split filter once per pixel tile — fpn.lat0: ~1.5 GB through L1/TA for
 // 310 MB of algorithmic traffic, texture path 80 % busy, matrix pipe 0.30.  With K <= 256 the split
 // filter slice of 32 output channels is 16 K steps x 3 planes x 4 VGPRs = 192 registers: a workgroup
-// of EIGHT waves holds a 256-channel slab of the filter in its register files for its whole life
+// of FOUR waves holds a 256-channel slab of the filter in its register files for its whole life
 // and streams pixel tiles past it:
 //   * persistent workgroups (one per CU and column slab), each loads its filter fragments ONCE and
 //     loops over its share of the 32-pixel tiles;
@@ -21,7 +21,8 @@
 //     no VGPR staging) into a ring of three slots, two tiles in flight; every wave reads the SAME A
 //     fragments (bank-conflict-free through an XOR swizzle of the 16-byte quads applied to the DMA
 //     source addresses), splits them into the three bf16 planes and issues 6 MFMAs per K step
-//     against its resident B fragments: 96 MFMAs per wave between two barriers instead of 6;
+//     against each of its two resident B column blocks: 192 MFMAs per wave between two barriers
+//     instead of 6;
 //   * through the vector-memory path: A once (x Cout / 256 column slabs, from L2), the filter once
 //     per workgroup — fpn.lat0: ~0.2 GB instead of ~1.5 GB; the layer becomes HBM-bound;
 //   * epilogue (bias, residual same-shape or nearest-2x-upsampled, ReLU, ReLU-backward mask) through
@@ -72,20 +73,27 @@ struct BresArgs {
   int wg_per_cg;         // workgroups per slab (grid = ncg * wg_per_cg)
 };
 
-constexpr int kWaves8 = 8, kThreads8 = 512, kBM = 32, kNST = 3;
+constexpr int kWaves8 = 4, kThreads8 = 256, kBM = 32, kNST = 3;   // (names kept: the workgroup WAS 8 waves)
 
-// KS = K / 16 (4, 8, 16); NCB = 32-column blocks per wave (BN = 256 NCB; KS * NCB <= 16; only NCB = 1
-// is instantiated: <8, 2> — a 512-channel slab for K = 128 — spills 47 VGPRs)
+// KS = K / 16 (4, 8, 16); NCB = 32-column blocks per wave (BN = 128 NCB = 256).
+// First version: EIGHT waves x 32 columns (192 filter registers of the 256 a wave of an 8-wave
+// workgroup can have): hipcc spilled 23-47 VGPRs, and every scratch reload inside the tile loop is a
+// VMEM load whose s_waitcnt also drains the tile DMAs in flight — 10 us per tile instead of 2.6
+// (profiles/r5b: SLOWER than the operand ring on every layer but K = 64).  Now FOUR waves x 64
+// columns with the whole 512-register file of a SIMD per wave (one wave per SIMD): 384 filter
+// registers for K = 256, no spill; the wave hides its own LDS / VALU latency under its 12 MFMAs per
+// K step (the loop is fully unrolled: the next step's fragment reads and splits are independent
+// of the current step's MFMAs).
 // S2: stride 2 (the projection shortcuts); otherwise a tile is 32 consecutive rows of x
 template <int KS, int NCB, bool S2>
-__global__ __launch_bounds__(kThreads8, KS == 4 ? 4 : 2) void conv1x1_bres_kernel(BresArgs q) {
+__global__ __launch_bounds__(kThreads8, KS >= 8 ? 1 : 2) void conv1x1_bres_kernel(BresArgs q) {
   const ConvArgs& p = q.c;
-  constexpr int BN = 256 * NCB;
+  constexpr int BN = 128 * NCB;
   constexpr int KB = KS * 64;                  // bytes of a tile row (K fp32)
   constexpr int SLOT = kBM * KB;               // one A tile
   constexpr int QPR = KS * 4;                  // 16-byte quads per row (16 / 32 / 64)
   constexpr int RPP = 64 / QPR;                // rows per 1 KB DMA piece (4 / 2 / 1)
-  constexpr int PPW = (kBM / RPP) / kWaves8;   // DMA pieces per wave and tile (1 / 2 / 4)
+  constexpr int PPW = (kBM / RPP) / kWaves8;   // DMA pieces per wave and tile (2 / 4 / 8)
   constexpr int EPI = kBM * BN * 4;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[kNST * SLOT + EPI];
   float* scratch = reinterpret_cast<float*>(lds + kNST * SLOT);
@@ -162,9 +170,9 @@ __global__ __launch_bounds__(kThreads8, KS == 4 ? 4 : 2) void conv1x1_bres_kerne
   for (int tile = slot0; tile < q.tiles_m; tile += stride_t, ++it) {
     // this wave's pieces of stage `it` have landed once at most the PPW younger DMAs (tile + stride)
     // are outstanding (loads return in order; the previous epilogue's stores are older still)
-    if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (PPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    if (PPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // every wave's pieces are visible; every wave is done
     asm volatile("" ::: "memory");         // with the slot refilled next and with the epilogue tile
     issue(tile + 2 * stride_t, (it + 2) % kNST);
@@ -273,8 +281,8 @@ int bgs_internal_conv1x1_bres(const bgs_conv::ConvArgs& p, const void* wsplit, i
   q.KC = KC;
   q.tiles_m = (p.M + kBM - 1) / kBM;
   q.ncg = p.Cout / bn;
-  // one workgroup per CU (8 waves, <= 160 KB of LDS); K = 64 tiles are small: two per CU
-  const int per_cu = p.Cin == 64 ? 2 : 1;
+  // one workgroup per CU for K >= 128 (more than 256 registers per wave); two for K = 64
+  const int per_cu = p.Cin >= 128 ? 1 : 2;
   int wpc = (256 * per_cu) / q.ncg;
   if (wpc < 1) wpc = 1;
   if (wpc > q.tiles_m) wpc = q.tiles_m;
@@ -289,9 +297,9 @@ int bgs_internal_conv1x1_bres(const bgs_conv::ConvArgs& p, const void* wsplit, i
     else                                                                                               \
       hipLaunchKernelGGL((conv1x1_bres_kernel<KS_, NCB_, false>), grid, dim3(kThreads8), 0, st, q);    \
   } while (0)
-  if (p.Cin == 256) BRES_L(16, 1);
-  else if (p.Cin == 128) BRES_L(8, 1);
-  else BRES_L(4, 1);
+  if (p.Cin == 256) BRES_L(16, 2);
+  else if (p.Cin == 128) BRES_L(8, 2);
+  else BRES_L(4, 2);
 #undef BRES_L
   return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
 }

@@ -226,6 +226,201 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_f32_kernel(WgradArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same weight gradient on the bf16 matrix cores with fp32-faithful results ("bf16x6", see
+// conv_bfx.hip): D[co][k] = sum_m dy[m][co] * x[m][k] with every product formed from the exact
+// three-way bf16 split of BOTH operands (six v_mfma_f32_32x32x16_bf16 per 16 reduction rows instead
+// of eight v_mfma_f32_32x32x2_f32 per 16: 6/16 of the matrix-pipe time).
+// The MFMA wants, per lane, 8 consecutive reduction indices m of ONE output row (co or k) in 16
+// contiguous bytes, but both operands are stored m-major.  The transpose happens in registers on the
+// way to LDS: a staging thread loads a 4 (m) x 4 (co or k) block with four 16-byte loads, and for
+// each of its 4 columns splits the 4 m-values into the three bf16 planes and writes them with one
+// ds_write_b64 per plane into the [row][16 m] image (48-byte rows as in conv_igemm_bfx_kernel) —
+// 12 LDS writes per 64 loaded bytes, the same ratio as the forward kernel's A staging, no
+// ds_read_tr / ds_bpermute.  Threads 0-127 stage dy (and accumulate the bias gradient), 128-255 the
+// im2col rows of x.  128 x 128 tile, 2 x 2 waves, 24 MFMAs per wave and stage, LDS double-buffered
+// (72 KB: two workgroups per CU); reduction split over gridDim.z and summed in a fixed order as above.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __attribute__((aligned(16))) float g_wgrad_zero[4];
+
+__device__ __forceinline__ unsigned wg_pack_bf16(float a, float b) {
+  const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);   // v_cvt_pk_bf16_f32 (RNE)
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ float wg_bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float wg_bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ void wg_split3(const f32x4 v, u32x2& hi, u32x2& mid, u32x2& lo) {
+  hi = u32x2{wg_pack_bf16(v[0], v[1]), wg_pack_bf16(v[2], v[3])};
+  const f32x4 r = {v[0] - wg_bf16_lo(hi[0]), v[1] - wg_bf16_hi(hi[0]), v[2] - wg_bf16_lo(hi[1]),
+                   v[3] - wg_bf16_hi(hi[1])};
+  mid = u32x2{wg_pack_bf16(r[0], r[1]), wg_pack_bf16(r[2], r[3])};
+  const f32x4 r2 = {r[0] - wg_bf16_lo(mid[0]), r[1] - wg_bf16_hi(mid[0]), r[2] - wg_bf16_lo(mid[1]),
+                    r[3] - wg_bf16_hi(mid[1])};
+  lo = u32x2{wg_pack_bf16(r2[0], r2[1]), wg_pack_bf16(r2[2], r2[3])};
+}
+
+// NS = 3: fp32-faithful; NS = 1: operands rounded to bf16 (the bf16 mode of cfg[4])
+template <int NS>
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_bfx_kernel(WgradArgs p) {
+  constexpr int BT = 128;                       // tile: 128 co x 128 k
+  constexpr int LDR = 48;                       // LDS row: 16 m as bf16 (32 B) + 16 B pad
+  constexpr int PLANE = BT * LDR;               // one operand plane
+  constexpr int BUF = 2 * NS * PLANE;           // A planes, then B planes
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int co0 = blockIdx.x * BT, k0 = blockIdx.y * BT;
+  const int m_begin = blockIdx.z * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+
+  // ---- staging roles: part 0 (threads 0-127) = dy, part 1 = x; block (mg, q): m rows 4 mg .. 4 mg + 3
+  //      of the stage, column quad q (4 consecutive co, or 4 consecutive k = channels of one tap)
+  const bool is_b = tid >= 128;
+  const int u = tid & 127;
+  const int mg = u & 3, cq = u >> 2;
+  const int colq = (is_b ? k0 : co0) + cq * 4;
+  const bool col_ok = colq < (is_b ? p.K : p.Cout);     // Cout % 4 == 0, K % 4 == 0: whole quad in or out
+  int kr = 0, ks = 0, kc = 0;
+  if (is_b && col_ok) {
+    const int rs = colq / p.Cin;
+    kc = colq - rs * p.Cin;
+    kr = rs / p.S;
+    ks = rs - kr * p.S;
+  }
+  // (n, ho, wo) of this thread's 4 rows (x part), advanced by kBKM per stage
+  int bn_[4], bho[4], bwo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m_begin + 4 * mg + i;
+    const int hw = p.Ho * p.Wo;
+    bn_[i] = m / hw;
+    const int rem = m - bn_[i] * hw;
+    bho[i] = rem / p.Wo;
+    bwo[i] = rem - bho[i] * p.Wo;
+  }
+  const int dst = (is_b ? NS * PLANE : 0) + (cq * 4) * LDR + mg * 8;     // + j * LDR + s * PLANE
+
+  f32x4 v[4];
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const bool want_db = p.db_part != nullptr && blockIdx.y == 0;
+  int m_stage = m_begin;
+  auto load_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m_stage + 4 * mg + i;
+      const float* src = g_wgrad_zero;
+      if (!is_b) {
+        if (col_ok && m < m_end) src = p.dy + (size_t)m * p.Cout + colq;
+      } else {
+        const int hi = bho[i] * p.stride - p.pad + kr, wi = bwo[i] * p.stride - p.pad + ks;
+        if (col_ok && m < m_end && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
+          src = p.x + (((size_t)bn_[i] * p.H + hi) * p.W + wi) * p.Cin + kc;
+        bwo[i] += kBKM;
+        while (bwo[i] >= p.Wo) {
+          bwo[i] -= p.Wo;
+          if (++bho[i] == p.Ho) {
+            bho[i] = 0;
+            ++bn_[i];
+          }
+        }
+      }
+      v[i] = *reinterpret_cast<const f32x4*>(src);
+    }
+    m_stage += kBKM;
+  };
+  auto store_stage = [&](int buf) {
+    unsigned char* base = lds + buf * BUF + dst;
+    if (want_db && !is_b) bsum += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u32x2 h, m, l;
+      wg_split3(f32x4{v[0][j], v[1][j], v[2][j], v[3][j]}, h, m, l);
+      *reinterpret_cast<u32x2*>(base + j * LDR) = h;
+      if (NS >= 2) *reinterpret_cast<u32x2*>(base + j * LDR + PLANE) = m;
+      if (NS >= 3) *reinterpret_cast<u32x2*>(base + j * LDR + 2 * PLANE) = l;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int frow = lane & 31, fk = lane >> 5;
+  const int a_frag = (wm * 64 + frow) * LDR + fk * 16;
+  const int b_frag = NS * PLANE + (wn * 64 + frow) * LDR + fk * 16;
+  const int nst = (m_end - m_begin + kBKM - 1) / kBKM;
+  if (nst > 0) {
+    load_stage();
+    store_stage(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    const bool more = st + 1 < nst;
+    if (more) load_stage();                    // global loads of stage st + 1 in flight under the MFMAs
+    const unsigned char* base = lds + buf * BUF;
+    bf16x8 fa[NS][2], fb[NS][2];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        fa[s][a] = *reinterpret_cast<const bf16x8*>(base + a_frag + s * PLANE + a * 32 * LDR);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        fb[s][b] = *reinterpret_cast<const bf16x8*>(base + b_frag + s * PLANE + b * 32 * LDR);
+    }
+    // products (i, j) with i + j <= NS - 1, smallest terms first
+#pragma unroll
+    for (int t = NS - 1; t >= 0; --t)
+#pragma unroll
+      for (int i = 0; i <= t; ++i)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[t - i][b], acc[a][b], 0, 0, 0);
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (want_db) {   // block-uniform; the loop ended with a barrier: the LDS is free
+    f32x4* red = reinterpret_cast<f32x4*>(lds);      // [4 mg][32 cq]
+    if (!is_b) red[mg * 32 + cq] = bsum;
+    __syncthreads();
+    if (!is_b && mg == 0 && col_ok) {
+      const f32x4 t = (red[cq] + red[32 + cq]) + (red[64 + cq] + red[96 + cq]);
+      *reinterpret_cast<f32x4*>(p.db_part + (size_t)blockIdx.z * p.Cout + colq) = t;
+    }
+  }
+
+  // ---- partial tile: C/D layout col = lane & 31 (k), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (co)
+  float* out = p.out + (size_t)blockIdx.z * p.Cout * p.K;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int co = co0 + wm * 64 + a * 32 + i;
+      if (co >= p.Cout) continue;
+      float* row = out + (size_t)co * p.K;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int k = k0 + wn * 64 + b * 32 + (lane & 31);
+        if (k < p.K) row[k] = acc[a][b][r];
+      }
+    }
+}
+
 // dW[i] (+)= scale-free sum over the splits, fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws,
                                                            float* __restrict__ dw, size_t n4,
@@ -243,13 +438,14 @@ struct WgradPlan {
   int splits, m_per_split;
 };
 
-WgradPlan plan_wgrad(int M, int Cout, int K) {
+WgradPlan plan_wgrad(int M, int Cout, int K, bool bfx = false) {
   WgradPlan pl;
   pl.tile = (Cout >= 128 && K >= 128) ? 22 : 11;
   if (const char* e = getenv("BGS_WGRAD_TILE")) {
     const int f = atoi(e);
     if (f == 22 || f == 11) pl.tile = f;
   }
+  if (bfx) pl.tile = 22;          // the bf16x6 kernel has the 128 x 128 tile only
   const int bm = pl.tile == 22 ? 128 : 64;
   const long long tiles = (long long)((Cout + bm - 1) / bm) * ((K + bm - 1) / bm);
   // Split count from the per-layer sweep of the cfg[1] shapes (tools/wgrad_sweep.py,
@@ -348,3 +544,83 @@ extern "C" int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float*
   }
   BGS_RETURN_LAUNCH_STATUS();
 }
+
+// bf16x6 / bf16 flavour (conv_wgrad_bfx_kernel): same contract and workspace as
+// bgs_conv2d_wgrad_nhwc_f32; planes = 3 (fp32-faithful) or 1 (operands rounded to bf16).  Layers
+// with Cout < 96 or K < 96 (the 128 x 128 tile would be mostly padding: stem, RPN heads) are routed
+// to the fp32-MFMA kernel, which is exact.
+int g_wgrad_bfx_enabled = -1;
+
+extern "C" size_t bgs_conv2d_wgrad_bfx_workspace_bytes(int N, int H, int W, int Cin, int Cout, int R,
+                                                       int S, int stride, int pad) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0)
+    return 0;
+  const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return 0;
+  const long long M = (long long)N * Ho * Wo;
+  const int K = R * S * Cin;
+  const WgradPlan a = plan_wgrad((int)M, Cout, K, true), b = plan_wgrad((int)M, Cout, K, false);
+  const int splits = a.splits > b.splits ? a.splits : b.splits;
+  return ((size_t)splits * Cout * K + (size_t)splits * Cout) * sizeof(float) + 256;
+}
+
+extern "C" int bgs_conv2d_wgrad_nhwc_f32_bfx(const float* x, const float* dy, float* dw, float* db,
+                                             int N, int H, int W, int Cin, int Cout, int R, int S,
+                                             int stride, int pad, int accumulate, int planes,
+                                             void* workspace, bgs_stream_t stream) {
+  if (planes != 1 && planes != 3) return BGS_ERR_INVALID_ARG;
+  if (g_wgrad_bfx_enabled < 0) {
+    const char* e = getenv("BGS_WGRAD_BFX");
+    g_wgrad_bfx_enabled = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  if (!g_wgrad_bfx_enabled || Cout < 96 || R * S * Cin < 96)
+    return bgs_conv2d_wgrad_nhwc_f32(x, dy, dw, db, N, H, W, Cin, Cout, R, S, stride, pad, accumulate,
+                                     workspace, stream);
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
+      pad < 0)
+    return BGS_ERR_INVALID_ARG;
+  if (!x || !dy || !dw || !workspace) return BGS_ERR_INVALID_ARG;
+  if (Cin % 4 != 0 || Cout % 4 != 0) return BGS_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)workspace) % 16 != 0)
+    return BGS_ERR_INVALID_ARG;
+  WgradArgs p;
+  p.x = x; p.dy = dy;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S;
+  p.stride = stride; p.pad = pad;
+  p.Ho = (H + 2 * pad - R) / stride + 1;
+  p.Wo = (W + 2 * pad - S) / stride + 1;
+  if (p.Ho <= 0 || p.Wo <= 0) return BGS_ERR_INVALID_ARG;
+  const long long M = (long long)N * p.Ho * p.Wo;
+  if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  p.M = (int)M;
+  p.K = R * S * Cin;
+  const WgradPlan pl = plan_wgrad(p.M, Cout, p.K, true);
+  p.m_per_split = pl.m_per_split;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  const bool direct = pl.splits == 1 && !accumulate;
+  p.out = direct ? dw : ws;
+  const size_t n = (size_t)Cout * p.K;
+  p.db_part = db ? ws + (size_t)pl.splits * n : nullptr;
+  dim3 grid((unsigned)((Cout + 127) / 128), (unsigned)((p.K + 127) / 128), (unsigned)pl.splits);
+  bgs_internal_census_bump(BGS_CENSUS_WGRAD_BFX);
+  if (planes == 3) hipLaunchKernelGGL((conv_wgrad_bfx_kernel<3>), grid, dim3(kThreads), 0, st, p);
+  else hipLaunchKernelGGL((conv_wgrad_bfx_kernel<1>), grid, dim3(kThreads), 0, st, p);
+  if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
+  if (!direct) {
+    const size_t n4 = n / 4;
+    size_t g = (n4 + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, ws, dw, n4,
+                       pl.splits, accumulate);
+    if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
+  }
+  if (db) {
+    const size_t c4 = (size_t)Cout / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, st,
+                       p.db_part, db, c4, pl.splits, accumulate);
+  }
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" void bgs_conv2d_wgrad_bfx_enable(int on) { g_wgrad_bfx_enabled = on ? 1 : 0; }

@@ -311,6 +311,13 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
   //      together.  Lane b <= B of every wave counts bin b over the wave's share of the rows by
   //      ballots (b == B: real rows) — no LDS atomics.
   int mycnt = 0;
+  // the workgroup's first row: label and bin labels (a dependent pair of loads) start now
+  const int64_t yraw_first = a.labels[blockIdx.x];
+  int my_bl_first = 0;
+  if (lane < B) {
+    const int64_t yc = yraw_first < 0 ? 0 : (yraw_first >= C ? (int64_t)C - 1 : yraw_first);
+    my_bl_first = (int)a.l2b[(size_t)lane * C + yc];
+  }
   const float* rw_base = a.row_weights ? a.row_weights : &g_one;
   const int rw_step = a.row_weights ? 1 : 0;
   constexpr int RP = kFusedRowsPerPass;
@@ -432,11 +439,15 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
     if (!first) bgs::stage_row<VEC>(a.logits + (size_t)r * W, row, W, tid, kBlock);
     const unsigned fr = sh_flags[r];
     const bool real_r = (fr & 0x8000u) != 0u;
-    const int64_t yraw = a.labels[r];
-    const int64_t yr = yraw < 0 ? 0 : (yraw >= C ? (int64_t)C - 1 : yraw);
-    int my_bl = 0;
-    if (lane < B) my_bl = (int)a.l2b[(size_t)lane * C + yr];
-    if (!first) __syncthreads();          // row staged (the previous row left through the other buffer)
+    int64_t yraw = yraw_first;
+    int my_bl = my_bl_first;
+    if (!first) {
+      yraw = a.labels[r];
+      const int64_t yr = yraw < 0 ? 0 : (yraw >= C ? (int64_t)C - 1 : yraw);
+      my_bl = 0;
+      if (lane < B) my_bl = (int)a.l2b[(size_t)lane * C + yr];
+      __syncthreads();                    // row staged (the previous row left through the other buffer)
+    }
     for (int b = wave; b < B; b += kWaves) {  // bins are independent: one wave each
       const int s = a.geom.start[b], n = a.geom.len[b];
       const int mode_b = __builtin_amdgcn_readlane(my_mode, b);
@@ -538,8 +549,19 @@ __global__ __launch_bounds__(1024) void gs_head_reduce_kernel(const float* __res
   const int rows = B + (has_box ? 1 : 0);
   if (wave <= B) {
     float acc = 0.f;
-    if (wave < rows)
-      for (int g = lane; g < G; g += BGS_WAVE) acc += partial[(size_t)wave * G + g];
+    if (wave < rows) {
+      const float* row = partial + (size_t)wave * G;
+      for (int g0 = 0; g0 < G; g0 += BGS_WAVE * 16) {       // 16 loads in flight per lane (G <= 2048)
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int g = g0 + lane + BGS_WAVE * u;
+          v[u] = row[g < G ? g : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += (g0 + lane + BGS_WAVE * u < G) ? v[u] : 0.f;
+      }
+    }
     float s = bgs::wave_sum(acc);
     if (wave == B && has_box) s *= box_w / avg[0];
     if (lane == 0) {

@@ -290,8 +290,10 @@ class _GsHeadStepFn(torch.autograd.Function):
                                              capi.ptr(gT), N, B, W, R, capi.current_stream(dev))
         capi.check('bgs_gs_head_step_scale_grad', rc)
         ctx.consumed = True
+        ctx.grads = (None, None)      # sole owner now: AccumulateGrad can take the buffer instead of cloning it
         gz = dlogits if (dlogits is None or zdt == torch.float32) else dlogits.to(zdt)
         gp = dbbox if (dbbox is None or pdt == torch.float32) else dbbox.to(pdt)
+        del dlogits, dbbox
         return (gz, gp) + (None,) * 15
 
 
@@ -742,6 +744,15 @@ def conv2d_wgrad_nhwc(x, dy, ksize, stride=1, pad=0, bias=False, dw=None, db=Non
     if bias and db is None:
         assert not accumulate
         db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+    if _CONV_MATH[0] != 'f32':      # bf16 matrix cores: bf16x6 (fp32-faithful) or bf16 operands
+        ws = _workspace(lib.bgs_conv2d_wgrad_bfx_workspace_bytes(N, H, W, Cin, Cout, R, S, stride, pad), dev)
+        rc = lib.bgs_conv2d_wgrad_nhwc_f32_bfx(capi.ptr(x), capi.ptr(dy), capi.ptr(dw),
+                                               capi.ptr(db) if bias else None, N, H, W, Cin, Cout, R,
+                                               S, stride, pad, int(bool(accumulate)),
+                                               3 if _CONV_MATH[0] == 'bf16x6' else 1, capi.ptr(ws),
+                                               capi.current_stream(dev))
+        capi.check('bgs_conv2d_wgrad_nhwc_f32_bfx', rc)
+        return (dw, db) if bias else dw
     ws = _workspace(lib.bgs_conv2d_wgrad_workspace_bytes(N, H, W, Cin, Cout, R, S, stride, pad), dev)
     rc = lib.bgs_conv2d_wgrad_nhwc_f32(capi.ptr(x), capi.ptr(dy), capi.ptr(dw),
                                        capi.ptr(db) if bias else None, N, H, W, Cin, Cout, R, S,

@@ -258,6 +258,18 @@ size_t bgs_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, 
 int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, float* db, int N, int H,
                               int W, int Cin, int Cout, int R, int S, int stride, int pad,
                               int accumulate, void* workspace, bgs_stream_t stream);
+/* The same weight gradient on the bf16 matrix cores (csrc/conv_wgrad.hip, conv_wgrad_bfx_kernel):
+ * planes = 3: fp32-faithful "bf16x6" (every product from the exact three-way bf16 split of BOTH
+ * dy and x, fp32 accumulate; error vs fp64 not above the fp32-MFMA kernel's), planes = 1: operands
+ * rounded to bf16 (the bf16 mode of cfg[4]).  Same layout, split-M reduction in a fixed order and
+ * workspace contract (>= bgs_conv2d_wgrad_bfx_workspace_bytes); layers with Cout < 96 or K < 96 run
+ * the fp32-MFMA kernel (exact).  bgs_conv2d_wgrad_bfx_enable(0) routes every call there (A/B). */
+size_t bgs_conv2d_wgrad_bfx_workspace_bytes(int N, int H, int W, int Cin, int Cout, int R, int S,
+                                            int stride, int pad);
+int bgs_conv2d_wgrad_nhwc_f32_bfx(const float* x, const float* dy, float* dw, float* db, int N, int H,
+                                  int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                  int accumulate, int planes, void* workspace, bgs_stream_t stream);
+void bgs_conv2d_wgrad_bfx_enable(int on);
 
 /* Tuning / test hooks of the fp32 MFMA conv kernel (process-wide): tile 0 = auto | 11 | 21 | 22
  * (MB*10+NB blocks of 64), bk 0 = auto | 16 | 32, splitk 0 = auto | 1..16, noswizzle 1 = plain tile

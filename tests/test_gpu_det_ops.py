@@ -873,3 +873,57 @@ def test_conv1x1_filter_resident_kernel_as_data_gradient_with_mask():
     finally:
         lib.bgs_conv1x1_bres_enable(1)
         BF.set_conv_math(prev)
+
+
+@pytest.mark.parametrize('case', [
+    # name, N, H, W, Cin, Cout, k, stride, pad
+    ('3x3s1', 2, 40, 56, 128, 128, 3, 1, 1),
+    ('3x3s2', 1, 41, 55, 64, 256, 3, 2, 1),
+    ('1x1', 2, 50, 84, 256, 512, 1, 1, 0),
+    ('fc_cls', 1, 1, 1024, 1024, 1236, 1, 1, 0),
+    ('ragged', 1, 19, 23, 100, 132, 3, 1, 1),      # Cout, K and M not multiples of the tile
+], ids=lambda c: c[0])
+def test_wgrad_bf16x6_kernel_vs_fp64_and_not_worse_than_the_fp32_mfma_kernel(case):
+    """``conv_wgrad_bfx_kernel`` (weight gradient on the bf16 matrix cores, both operands split
+    exactly into three bf16 planes after an in-register transpose): dw / db against fp64 torch
+    autograd; its error is bounded by 1.5x the fp32-MFMA wgrad kernel's own on the same inputs
+    (it is an fp32-faithful mode, not a reduced-precision one); bitwise reproducible; the bf16 mode
+    (planes = 1) equals the fp64 product of bf16-ROUNDED operands; accumulate adds."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    name, N, H, W, Cin, Cout, k, stride, pad = case
+    rs = np.random.RandomState(len(name) * 31 + Cout)
+    x = (rs.randn(N, H, W, Cin) * np.exp(rs.uniform(-3, 3, size=(N, H, W, 1)))).astype(np.float32)
+    w = (rs.randn(Cout, Cin, k, k) / np.sqrt(Cin * k * k)).astype(np.float32)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dy = (rs.randn(N, Ho, Wo, Cout) * np.exp(rs.uniform(-3, 3, size=(N, Ho, Wo, 1)))).astype(np.float32)
+    _, edw = _torch_conv_grads(x, w, dy, stride, pad)
+    edb = dy.astype(np.float64).sum((0, 1, 2))
+    scale = np.abs(edw).max()
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        BF.launch_census(reset=True)
+        dw, db = BF.conv2d_wgrad_nhwc(dev(x), dev(dy), k, stride=stride, pad=pad, bias=True)
+        assert BF.launch_census()['wgrad_bfx'] == 1
+        dw2 = BF.conv2d_wgrad_nhwc(dev(x), dev(dy), k, stride=stride, pad=pad)
+        assert torch.equal(dw, dw2)                                  # fixed-order reduction
+        err_bfx = np.abs(dw.cpu().numpy() - edw).max() / scale
+        assert np.abs(db.cpu().numpy() - edb).max() <= 2e-5 * max(1.0, np.abs(edb).max())
+        lib.bgs_conv2d_wgrad_bfx_enable(0)
+        dwf = BF.conv2d_wgrad_nhwc(dev(x), dev(dy), k, stride=stride, pad=pad)
+        lib.bgs_conv2d_wgrad_bfx_enable(1)
+        err_f32 = np.abs(dwf.cpu().numpy() - edw).max() / scale
+        print('%s: wgrad error vs fp64: bf16x6 %.2e, fp32 MFMA %.2e' % (name, err_bfx, err_f32))
+        assert err_bfx <= max(1.5 * err_f32, 2e-7) and err_bfx < 2e-5
+        BF.conv2d_wgrad_nhwc(dev(x), dev(dy), k, stride=stride, pad=pad, bias=True, dw=dw, db=db,
+                             accumulate=True)
+        assert np.abs(dw.cpu().numpy() - 2 * edw).max() <= 4e-5 * scale
+        BF.set_conv_math('bf16')
+        dwb = BF.conv2d_wgrad_nhwc(dev(x), dev(dy), k, stride=stride, pad=pad)
+        rx = torch.from_numpy(x).bfloat16().float().numpy()
+        rdy = torch.from_numpy(dy).bfloat16().float().numpy()
+        _, edwb = _torch_conv_grads(rx, w, rdy, stride, pad)
+        assert np.abs(dwb.cpu().numpy() - edwb).max() <= 2e-5 * np.abs(edwb).max()
+    finally:
+        lib.bgs_conv2d_wgrad_bfx_enable(1)
+        BF.set_conv_math(prev)

@@ -554,8 +554,9 @@ def test_head_step_two_launches_equal_the_separate_kernels(name, train_box):
 
 
 def test_head_step_without_box_branch_and_unit_factors_is_bitwise_the_fused_loss():
-    """No ``bbox_pred``: loss_vec[B] == 0; with unit loss weights and a unit upstream gradient the
-    per-bin losses and dlogits are bitwise those of prepare + loss (the scaling launch early-outs)."""
+    """No ``bbox_pred``: terms[B] == 0; with unit loss weights and a unit upstream gradient dlogits
+    is BITWISE that of prepare + loss (the scaling launch early-outs), the losses agree to the last bit
+    or two (different fixed reduction order)."""
     case, l2b, ps, _, _, batch = case_setup('n1024_cfg2')
     B = l2b.shape[0]
     labels, l2b_t = dev(batch['labels']), dev(l2b)
@@ -568,7 +569,9 @@ def test_head_step_without_box_branch_and_unit_factors_is_bitwise_the_fused_loss
     terms, total, _ = BF.gs_head_step(z1, labels, l2b_t, ps, 8.0, 31, draw_counter=counter)
     total.backward(torch.ones(1, device=DEV))
     v = terms.detach().cpu().numpy()
-    np.testing.assert_array_equal(v[:B], ref.detach().cpu().numpy())
+    # (the partial sums are reduced wave-per-bin here and by 1024 threads in the two-kernel path:
+    #  same addends, different fixed order -> last-bit differences in the loss VALUES only)
+    np.testing.assert_allclose(v[:B], ref.detach().cpu().numpy(), rtol=5e-7, atol=0)
     assert v[B] == 0.0
     np.testing.assert_array_equal(z1.grad.cpu().numpy(), z0.grad.cpu().numpy())
     # a second call draws a different "others" sample (the counter moved), a reset counter repeats it
