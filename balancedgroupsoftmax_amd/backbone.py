@@ -42,8 +42,19 @@ def _trainable(*modules):
 
 
 def _fold_conv_bn(conv, bn, pad_cin_to=None):
-    """-> (w [Cout,R,S,Cin] contiguous, bias [Cout]) with the eval-mode BN folded in.  When the
-    conv / BN parameters are being trained the fold stays on the autograd tape."""
+    """-> (w [Cout,R,S,Cin] contiguous, bias [Cout]) with the eval-mode BN folded in.  On the GPU the
+    fold is ONE launch (``functional.fold_conv_bn``: csrc/bn_fold.hip) and, when the conv / BN
+    parameters are being trained, ONE more in backward (dW, dgamma, dbeta, dbias from dW', db');
+    CPU tensors (module construction / state-dict tests: the product never computes there) take the
+    tensor-op form of the same formula."""
+    w = conv.weight
+    if w.is_cuda:
+        ctx = contextlib.nullcontext() if _trainable(conv, bn) else torch.no_grad()
+        with ctx:
+            if bn is not None:
+                return BF.fold_conv_bn(w, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                                       bn.running_var, bn.eps, cin_padded=pad_cin_to)
+            return BF.fold_conv_bn(w, conv.bias, cin_padded=pad_cin_to)
     ctx = contextlib.nullcontext() if _trainable(conv, bn) else torch.no_grad()
     with ctx:
         w = conv.weight.float()

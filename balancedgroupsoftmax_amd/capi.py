@@ -73,6 +73,10 @@ SIGNATURES = {
     'bgs_conv2d_wgrad_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 9),
     'bgs_conv2d_wgrad_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p]
                                   + [ctypes.c_int] * 10 + [c_ptr, c_ptr]),
+    'bgs_fold_conv_bn_fwd': (ctypes.c_int, [c_f32p] * 6 + [ctypes.c_float] + [ctypes.c_int] * 5
+                             + [c_f32p, c_f32p, c_ptr]),
+    'bgs_fold_conv_bn_bwd': (ctypes.c_int, [c_f32p] * 7 + [ctypes.c_float] + [ctypes.c_int] * 5
+                             + [c_f32p] * 4 + [c_ptr]),
     'bgs_conv2d_wgrad_bfx_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 9),
     'bgs_conv2d_wgrad_nhwc_f32_bfx': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p]
                                       + [ctypes.c_int] * 11 + [c_ptr, c_ptr]),
@@ -89,6 +93,8 @@ SIGNATURES = {
     'bgs_conv3x3_halo_bfx_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 5),
     'bgs_conv3x3_halo_nhwc_f32_bfx': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, c_f32p]
                                       + [ctypes.c_int] * 7 + [c_ptr, ctypes.c_size_t, c_ptr]),
+    'bgs_conv3x3_halo_nhwc_f32_bfx_ex': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, c_f32p, c_f32p]
+                                         + [ctypes.c_int] * 7 + [c_ptr, ctypes.c_size_t, c_ptr]),
     'bgs_conv1x1_bres_enable': (None, [ctypes.c_int]),
     'bgs_conv1x1_bres_last_launch': (ctypes.c_int, []),
     'bgs_launch_census': (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),

@@ -271,6 +271,13 @@ int bgs_internal_conv1x1_bres(const bgs_conv::ConvArgs& p, const void* wsplit, i
   const int bn = 256;
   if (p.Cout % bn != 0) return -1;
   if (p.M < 4096) return -1;
+  // Measured (profiles/r5c_bres_ab.txt, interleaved A/B against the operand ring, bit-identical): the
+  // filter-resident kernel wins only where a workgroup streams many tiles past its filter slab and
+  // the layer is large enough to be bound by the memory path — fpn.lat0 (M = 134,400, K = Cout = 256:
+  // 0.127 vs 0.135 ms); on the smaller layers the 32-row tile's fixed costs (two barriers, the LDS
+  // transpose, 8 DMA pieces per wave) and ONE wave per SIMD lose to the ring (l3.c3 0.055 vs 0.041,
+  // l2.c3 0.064 vs 0.044 ms).  g_bres_enabled == 2 (tests, A/B) lifts the restriction.
+  if (g_bres_enabled != 2 && !(p.Cin == 256 && p.Cout == 256 && p.M >= 65536)) return -1;
   const uintptr_t al = (uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.mask | (uintptr_t)p.bias |
                        (uintptr_t)p.x | (uintptr_t)wsplit;
   if (al & 15) return -1;
@@ -304,6 +311,7 @@ int bgs_internal_conv1x1_bres(const bgs_conv::ConvArgs& p, const void* wsplit, i
   return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
 }
 
-// test / A-B hook: 0 = never, 1 = wherever eligible (default; env BGS_CONV1X1_BRES)
-extern "C" void bgs_conv1x1_bres_enable(int on) { g_bres_enabled = on ? 1 : 0; }
+// test / A-B hook: 0 = never, 1 = where it was measured faster (default; env BGS_CONV1X1_BRES), 2 = on
+// every layer the kernel can run
+extern "C" void bgs_conv1x1_bres_enable(int on) { g_bres_enabled = on < 0 ? 0 : (on > 2 ? 2 : on); }
 extern "C" int bgs_conv1x1_bres_last_launch(void) { return g_bres_last; }

@@ -782,14 +782,20 @@ __device__ __forceinline__ void halo_store_tile_lds(const ConvArgs& p, const f32
         const int ho = ty * TH + (m >> 4), wo = tx * TW + (m & 15);
         if (ho >= p.H || wo >= p.W) continue;
         f32x4 v = *reinterpret_cast<const f32x4*>(scratch + i * LD + c4);
+        const size_t off = (((size_t)n * p.H + ho) * p.W + wo) * p.Cout + j;
         if (!p.partial) {
           v += bias;
           if (p.relu) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
           }
+          if (p.mask) {      // data gradient: ReLU backward of the conv's input
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + off);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = mk[t] > 0.f ? v[t] : 0.f;
+          }
         }
-        *reinterpret_cast<f32x4*>(dst + (((size_t)n * p.H + ho) * p.W + wo) * p.Cout + j) = v;
+        *reinterpret_cast<f32x4*>(dst + off) = v;
       }
     }
     if (h == 0) __syncthreads();
@@ -1212,7 +1218,10 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxA
 // layer's epilogue was built and measured too — no faster, 1.5x the activation bytes: removed.
 // LDS: 24 KB filter double buffer + 1 KB scratch (dummy pieces) + 25.3 KB patch.
 // (NS = 1: the bf16 mode — hi planes only, one MFMA per product.)
-template <int NB, int NS = 3>
+// PF (variant 5): the A fragments of tap t + 1 are read from the patch DURING tap t's MFMAs — the
+// patch does not change inside a channel chunk, so those reads need not sit behind the step's
+// barrier; after the barrier only the six filter fragments remain between a wave and its MFMAs.
+template <int NB, int NS = 3, bool PF = false>
 __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxArgs q) {
   const ConvArgs& p = q.c;
   constexpr int BN = 64 * NB;
@@ -1325,6 +1334,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0, nxt = B_BUF;                                      // byte offsets of the two B buffers
+  bf16x8 fa_next[NS][2];
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     const bool last_chunk = chunk + 1 >= c_end;
 #pragma unroll
@@ -1339,11 +1349,21 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-          fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a] + tap_off + s * A_PLANE);
+        for (int a = 0; a < 2; ++a) {
+          if (PF && tap > 0) fa[s][a] = fa_next[s][a];
+          else fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a] + tap_off + s * A_PLANE);
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b)
           fb[s][b] = *reinterpret_cast<const bf16x8*>(lds + rd + b_frag + s * B_PLANE + b * 32 * 32);
+      }
+      if (PF && tap < 8) {                                         // tap + 1's patch rows: in flight under the MFMAs
+        const int nxt_off = (((tap + 1) / 3) * PW + ((tap + 1) % 3)) * HLDR;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+            fa_next[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a] + nxt_off + s * A_PLANE);
       }
 #pragma unroll
       for (int tt = NS - 1; tt >= 0; --tt)
@@ -1394,6 +1414,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
         } else {
           if (p.bias) v += p.bias[j];
           if (p.relu) v = fmaxf(v, 0.f);
+          if (p.mask) v = p.mask[row + j] > 0.f ? v : 0.f;
           p.y[row + j] = v;
         }
       }
@@ -1402,7 +1423,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
 }
 
 int g_halo_last_nb = 0, g_halo_last_splits = 0, g_halo_last_variant = 0;
-int g_halo_force_splits = -1, g_halo_variant = 4;
+int g_halo_force_splits = -1, g_halo_variant = 4, g_halo_pf = 0;
 
 int halo_bfx_plan(long long M, int tiles_m, int Cin, int Cout, int& nb) {
   nb = Cout <= 64 ? 1 : 2;
@@ -1740,6 +1761,7 @@ extern "C" void bgs_conv3x3_halo_bfx_tuning(int splits, int variant) {
   // 1 = first version (2 workgroups / CU), 2 = taps unrolled + 3 workgroups / CU (register-staged
   // filter slices), 4 (and 0 = the default) = filter slices by LDS-DMA
   g_halo_variant = variant == 1 ? 1 : (variant == 2 ? 2 : 4);
+  g_halo_pf = variant == 5 ? 1 : 0;        // 5 = variant 4 + A-fragment prefetch across the barrier
 }
 
 extern "C" int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits) {
@@ -1749,21 +1771,39 @@ extern "C" int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits) {
 }
 
 // 3x3 / stride 1 / pad 1, Cin % 16 == 0; wsplit = bgs_conv_bfx_split_weights of [Cout][3][3][Cin].
+extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wsplit, const float* bias,
+                                                const float* mask, float* y, int N, int H, int W,
+                                                int Cin, int Cout, int relu, int planes, void* workspace,
+                                                size_t workspace_bytes, bgs_stream_t stream);
+
 extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias,
                                              float* y, int N, int H, int W, int Cin, int Cout,
                                              int relu, int planes, void* workspace,
                                              size_t workspace_bytes, bgs_stream_t stream) {
+  return bgs_conv3x3_halo_nhwc_f32_bfx_ex(x, wsplit, bias, nullptr, y, N, H, W, Cin, Cout, relu, planes,
+                                          workspace, workspace_bytes, stream);
+}
+
+// ... with `mask` [N,H,W,Cout] or NULL: y = mask > 0 ? y : 0 in the epilogue — the DATA GRADIENT of a
+// 3x3 / stride 1 / pad 1 conv is the same conv of dy with the flipped, transposed filter
+// (x := dy [N,H,W,Cout_fwd], wsplit := split of wt [Cin_fwd][3][3][Cout_fwd], y := dx), and the mask is
+// the ReLU backward of the forward conv's input (variant 4 only).
+extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wsplit, const float* bias,
+                                                const float* mask, float* y, int N, int H, int W,
+                                                int Cin, int Cout, int relu, int planes, void* workspace,
+                                                size_t workspace_bytes, bgs_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return BGS_ERR_INVALID_ARG;
   if (!x || !wsplit || !y) return BGS_ERR_INVALID_ARG;
   if (planes != 1 && planes != 3) return BGS_ERR_INVALID_ARG;
   if (Cin % 16 != 0) return BGS_ERR_UNSUPPORTED;
+  if (mask && g_halo_variant != 4) return BGS_ERR_UNSUPPORTED;
   if ((uintptr_t)x % 16 != 0 || (uintptr_t)wsplit % 16 != 0) return BGS_ERR_UNSUPPORTED;
   const long long M = (long long)N * H * W;
   if (M > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
   HaloBfxArgs q;
   q.ns = planes;
   ConvArgs& p = q.c;
-  p.x = x; p.w = nullptr; p.bias = bias; p.res = nullptr; p.mask = nullptr; p.y = y;
+  p.x = x; p.w = nullptr; p.bias = bias; p.res = nullptr; p.mask = mask; p.y = y;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = 3; p.S = 3; p.stride = 1; p.pad = 1;
   p.Ho = H; p.Wo = W; p.M = (int)M; p.K = 9 * Cin; p.relu = relu; p.res_mode = 0;
   p.partial = nullptr; p.kt_per_split = 0;
@@ -1800,6 +1840,8 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit,
       else hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
     } else if (nb == 1) {
       hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, 3>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    } else if (g_halo_pf) {
+      hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, 3, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
     } else {
       hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, 3>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
     }

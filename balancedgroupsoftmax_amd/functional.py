@@ -697,6 +697,21 @@ def conv2d_dgrad_nhwc(dy, w_krsc, in_hw, stride=1, pad=0, residual=None, residua
     dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dy.device)
     if _CONV_MATH[0] != 'f32':
         wt_split = bfx_split_weights(wt.view(Cin, R * S * Cout), cache=not wt_is_temp)
+        if R == 3 and S == 3 and stride == 1 and pad == 1 and residual is None and Cout % 16 == 0 \
+                and _use_halo_bfx(N * H * W, Cin) and os.environ.get('BGS_DGRAD_HALO', '1') != '0':
+            # the data gradient of a 3x3 / stride 1 / pad 1 conv is the same conv of dy with the
+            # flipped, transposed filter: the halo-resident kernel of the forward pass (ReLU-backward
+            # mask in its epilogue) instead of the general operand ring
+            wsb = lib.bgs_conv3x3_halo_bfx_workspace_bytes(N, H, W, Cout, Cin)
+            ws = _workspace(wsb, dy.device) if wsb else None
+            rc = lib.bgs_conv3x3_halo_nhwc_f32_bfx_ex(
+                capi.ptr(dy), capi.ptr(wt_split), None, capi.ptr(mask), capi.ptr(dx), N, H, W, Cout,
+                Cin, 0, 3 if _CONV_MATH[0] == 'bf16x6' else 1, capi.ptr(ws), wsb,
+                capi.current_stream(dy.device))
+            if rc == 0:
+                return dx
+            if rc != 2:          # BGS_ERR_UNSUPPORTED (an A/B variant without the mask): general path
+                capi.check('bgs_conv3x3_halo_nhwc_f32_bfx_ex', rc)
         wsb = lib.bgs_conv_bfx_workspace_bytes(N * H * W, Cin, R * S * Cout)
         ws = _workspace(wsb, dy.device) if wsb else None
         rc = lib.bgs_conv2d_dgrad_nhwc_f32_bfx_ws(capi.ptr(dy), capi.ptr(wt_split),
@@ -760,6 +775,62 @@ def conv2d_wgrad_nhwc(x, dy, ksize, stride=1, pad=0, bias=False, dw=None, db=Non
                                        capi.current_stream(dev))
     capi.check('bgs_conv2d_wgrad_nhwc_f32', rc)
     return (dw, db) if bias else dw
+
+
+class _FoldConvBNFn(torch.autograd.Function):
+    """``(w [Cout,Cin,R,S], conv_bias, gamma, beta) -> (wf [Cout,R,S,CinP], bf [Cout])``: eval-mode
+    BatchNorm folded into the filter (``bgs_fold_conv_bn_fwd``) with the fold's backward as ONE launch
+    (``bgs_fold_conv_bn_bwd``: dw, dconv_bias, dgamma, dbeta) — as tensor ops the fold is ~20
+    elementwise / permute launches per conv and step on the `selectp = 0` path."""
+
+    @staticmethod
+    def forward(ctx, w, conv_bias, gamma, beta, mean, var, eps, cin_padded):
+        lib = capi.load()
+        wc = _f32c(w)
+        Cout, Cin, R, S = wc.shape
+        cinp = int(cin_padded) if cin_padded else Cin
+        dev = wc.device
+        cb = None if conv_bias is None else _f32c(conv_bias)
+        bn = gamma is not None
+        g, b_, m, v = (_f32c(t) for t in (gamma, beta, mean, var)) if bn else (None,) * 4
+        wf = torch.empty((Cout, R, S, cinp), dtype=torch.float32, device=dev)
+        bf = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        rc = lib.bgs_fold_conv_bn_fwd(capi.ptr(wc), capi.ptr(cb), capi.ptr(g), capi.ptr(b_),
+                                      capi.ptr(m), capi.ptr(v), float(eps), Cout, Cin, R, S, cinp,
+                                      capi.ptr(wf), capi.ptr(bf), capi.current_stream(dev))
+        capi.check('bgs_fold_conv_bn_fwd', rc)
+        ctx.save_for_backward(wc, cb, g, m, v)
+        ctx.cfg = (float(eps), cinp, conv_bias is not None, bn)
+        return wf, bf
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dwf, dbf):
+        wc, cb, g, m, v = ctx.saved_tensors
+        eps, cinp, has_cb, bn = ctx.cfg
+        lib = capi.load()
+        Cout, Cin, R, S = wc.shape
+        dev = wc.device
+        need = ctx.needs_input_grad
+        dw = torch.empty_like(wc) if need[0] else None
+        dcb = torch.empty((Cout,), dtype=torch.float32, device=dev) if (has_cb and need[1]) else None
+        dg = torch.empty((Cout,), dtype=torch.float32, device=dev) if (bn and need[2]) else None
+        db = torch.empty((Cout,), dtype=torch.float32, device=dev) if (bn and need[3]) else None
+        rc = lib.bgs_fold_conv_bn_bwd(capi.ptr(dwf.contiguous()), capi.ptr(dbf.contiguous()),
+                                      capi.ptr(wc), capi.ptr(cb), capi.ptr(g), capi.ptr(m), capi.ptr(v),
+                                      eps, Cout, Cin, R, S, cinp, capi.ptr(dw), capi.ptr(dcb),
+                                      capi.ptr(dg), capi.ptr(db), capi.current_stream(dev))
+        capi.check('bgs_fold_conv_bn_bwd', rc)
+        return dw, dcb, dg, db, None, None, None, None
+
+
+def fold_conv_bn(weight, conv_bias=None, bn_weight=None, bn_bias=None, running_mean=None,
+                 running_var=None, eps=1e-5, cin_padded=None):
+    """-> ``(wf [Cout,R,S,CinP], bf [Cout])``, differentiable w.r.t. ``weight``, ``conv_bias``,
+    ``bn_weight``, ``bn_bias`` (one launch forward, one backward)."""
+    _require_cuda(weight, conv_bias, bn_weight, bn_bias, running_mean, running_var)
+    return _FoldConvBNFn.apply(weight, conv_bias, bn_weight, bn_bias, running_mean, running_var,
+                               float(eps), cin_padded)
 
 
 class _ConvFn(torch.autograd.Function):

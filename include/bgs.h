@@ -271,6 +271,21 @@ int bgs_conv2d_wgrad_nhwc_f32_bfx(const float* x, const float* dy, float* dw, fl
                                   int accumulate, int planes, void* workspace, bgs_stream_t stream);
 void bgs_conv2d_wgrad_bfx_enable(int on);
 
+/* Eval-mode BatchNorm folded into the filter, and the backward of the fold (csrc/bn_fold.hip;
+ * resnet.py:535-542 `norm_eval=True`): w [Cout,Cin,R,S] (the reference's parameter layout), optional
+ * conv_bias [Cout], BN gamma / beta / running mean / var [Cout] (all NULL: no BN, scale 1) ->
+ * wf [Cout,R,S,cin_padded] (KRSC, channels zero-padded) = w * s, bf [Cout] = beta - mean * s
+ * (+ conv_bias * s), s = gamma / sqrt(var + eps).  Backward: dwf, dbf (NULL = 0) -> dw (NULL:
+ * skipped), dconv_bias, dgamma, dbeta (each NULL: skipped).  R * S * cin_padded <= 8192. */
+int bgs_fold_conv_bn_fwd(const float* w, const float* conv_bias, const float* gamma,
+                         const float* beta, const float* mean, const float* var, float eps, int Cout,
+                         int Cin, int R, int S, int cin_padded, float* wf, float* bf,
+                         bgs_stream_t stream);
+int bgs_fold_conv_bn_bwd(const float* dwf, const float* dbf, const float* w, const float* conv_bias,
+                         const float* gamma, const float* mean, const float* var, float eps, int Cout,
+                         int Cin, int R, int S, int cin_padded, float* dw, float* dconv_bias,
+                         float* dgamma, float* dbeta, bgs_stream_t stream);
+
 /* Tuning / test hooks of the fp32 MFMA conv kernel (process-wide): tile 0 = auto | 11 | 21 | 22
  * (MB*10+NB blocks of 64), bk 0 = auto | 16 | 32, splitk 0 = auto | 1..16, noswizzle 1 = plain tile
  * order; bgs_conv_last_launch reports the instantiation the last launch used. */
@@ -327,6 +342,13 @@ size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int Cin, int Co
 int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias, float* y,
                                   int N, int H, int W, int Cin, int Cout, int relu, int planes,
                                   void* workspace, size_t workspace_bytes, bgs_stream_t stream);
+/* ... with `mask` [N,H,W,Cout] or NULL (y = mask > 0 ? y : 0): the data gradient of a 3x3 / stride 1
+ * / pad 1 conv IS this conv of dy with the flipped, transposed filter, the mask being the ReLU
+ * backward of the forward conv's input (functional.conv2d_dgrad_nhwc routes those layers here). */
+int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wsplit, const float* bias,
+                                     const float* mask, float* y, int N, int H, int W, int Cin,
+                                     int Cout, int relu, int planes, void* workspace,
+                                     size_t workspace_bytes, bgs_stream_t stream);
 /* Launch census (tests / bench evidence): how often a kernel family was launched by this process
  * since the last reset — lets a test ASSERT that the instantiation it means to pin really ran
  * (e.g. the 8-wave bf16 ring and the LDS-resident grouped conv inside a whole X101 iteration).
@@ -346,10 +368,10 @@ void bgs_conv_bfx_tuning(int tile, int splitk);
 int bgs_conv_bfx_last_launch(int* tile, int* splits);
 void bgs_conv3x3_halo_bfx_tuning(int splits, int variant);
 /* Filter-resident 1x1 kernel (csrc/conv1x1_bres.hip: K = Cin in {64,128,256}, Cout % 256 == 0,
- * M >= 4096, bf16x6 mode): on by default wherever eligible inside bgs_conv2d_nhwc_f32_bfx_ws /
- * bgs_conv2d_dgrad_nhwc_f32_bfx_ws (bit-identical results); enable(0) routes those layers back
- * to the 64 x 64 operand ring (A/B runs, tests).  last_launch: 1 when the last eligible-path call
- * ran it. */
+ * M >= 4096, bf16x6 mode; bit-identical to the 64 x 64 operand ring): enable(1) (default) = on the
+ * layers where it was measured faster (K = Cout = 256, M >= 65536: fpn.lat0), enable(2) = on every
+ * layer it can run (tests, A/B), enable(0) = never.  last_launch: 1 when the last call that could
+ * have taken it did. */
 void bgs_conv1x1_bres_enable(int on);
 int bgs_conv1x1_bres_last_launch(void);
 int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits);

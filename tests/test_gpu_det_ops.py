@@ -829,11 +829,11 @@ def test_conv1x1_filter_resident_kernel_is_bit_identical_to_the_operand_ring(sha
     prev = BF.set_conv_math('bf16x6')
     try:
         outs = []
-        for on in (1, 0):
+        for on in (2, 0):
             lib.bgs_conv1x1_bres_enable(on)
             y = BF.conv2d_nhwc(dev(x), dev(w), dev(b), stride=stride, relu=True,
                                residual=None if res is None else dev(res), residual_mode=rmode)
-            assert lib.bgs_conv1x1_bres_last_launch() == on
+            assert lib.bgs_conv1x1_bres_last_launch() == (1 if on else 0)
             outs.append(y.cpu())
         assert torch.equal(outs[0], outs[1])
     finally:
@@ -864,10 +864,10 @@ def test_conv1x1_filter_resident_kernel_as_data_gradient_with_mask():
     prev = BF.set_conv_math('bf16x6')
     try:
         outs = []
-        for on in (1, 0):
+        for on in (2, 0):
             lib.bgs_conv1x1_bres_enable(on)
             dx = BF.conv2d_dgrad_nhwc(dev(dy), dev(w), (H, W), residual=dev(res), mask=dev(mask))
-            assert lib.bgs_conv1x1_bres_last_launch() == on
+            assert lib.bgs_conv1x1_bres_last_launch() == (1 if on else 0)
             outs.append(dx.cpu())
         assert torch.equal(outs[0], outs[1])
     finally:
@@ -927,3 +927,92 @@ def test_wgrad_bf16x6_kernel_vs_fp64_and_not_worse_than_the_fp32_mfma_kernel(cas
     finally:
         lib.bgs_conv2d_wgrad_bfx_enable(1)
         BF.set_conv_math(prev)
+
+
+@pytest.mark.parametrize('case', [
+    # Cout, Cin, k, with BN, conv bias, cin padded to
+    (64, 3, 7, True, False, 4),        # stem
+    (128, 256, 1, True, False, None),
+    (256, 256, 3, True, False, None),
+    (512, 512, 3, True, False, None),  # largest filter row: 4608 floats
+    (256, 256, 3, False, True, None),  # FPN / RPN conv: no BN, a bias
+    (12, 256, 1, False, True, None),
+    (1024, 16, 3, True, False, None),  # ResNeXt grouped conv2 (Cin / groups)
+])
+def test_fused_bn_fold_forward_and_backward_vs_torch_autograd(case):
+    """``bgs_fold_conv_bn_fwd`` / ``_bwd`` (csrc/bn_fold.hip: eval-mode BN folded into the filter, one
+    launch each way) against torch autograd of the tensor-op formula it replaces
+    (w * gamma / sqrt(var + eps) permuted to KRSC, beta - mean * scale): folded filter / bias exactly
+    equal up to 1 ulp, gradients of w, gamma, beta and the conv bias to fp32 rounding."""
+    Cout, Cin, k, with_bn, with_cb, cinp = case
+    g = torch.Generator().manual_seed(Cout + Cin + k)
+    w = torch.randn(Cout, Cin, k, k, generator=g)
+    cb = torch.randn(Cout, generator=g) if with_cb else None
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    mean, var = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.1
+    eps = 1e-5
+    leaves = [t.clone().double().requires_grad_(True) for t in (w, gamma, beta)] + \
+        ([cb.clone().double().requires_grad_(True)] if with_cb else [])
+    wd, gd, bd = leaves[:3]
+    if with_bn:
+        scale = gd / torch.sqrt(var.double() + eps)
+        wf_ref = (wd * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1)
+        bf_ref = bd - mean.double() * scale + (leaves[3] * scale if with_cb else 0)
+    else:
+        wf_ref = wd.permute(0, 2, 3, 1)
+        bf_ref = leaves[3] if with_cb else torch.zeros(Cout, dtype=torch.float64)
+    if cinp:
+        wf_ref = torch.nn.functional.pad(wf_ref, (0, cinp - Cin))
+    gw = torch.randn(wf_ref.shape, generator=g).double()
+    gb = torch.randn(Cout, generator=g).double()
+    ((wf_ref * gw).sum() + (bf_ref * gb).sum()).backward()
+    params = [dev(t).requires_grad_(True) for t in (w, gamma, beta)]
+    cbd = dev(cb).requires_grad_(True) if with_cb else None
+    if with_bn:
+        wf, bf = BF.fold_conv_bn(params[0], cbd, params[1], params[2], dev(mean), dev(var), eps,
+                                 cin_padded=cinp)
+    else:
+        wf, bf = BF.fold_conv_bn(params[0], cbd, cin_padded=cinp)
+    assert tuple(wf.shape) == tuple(wf_ref.shape) and wf.is_contiguous()
+    np.testing.assert_allclose(wf.detach().cpu().numpy(), wf_ref.detach().numpy(), rtol=3e-7, atol=1e-30)
+    np.testing.assert_allclose(bf.detach().cpu().numpy(), bf_ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    ((wf * dev(gw.float())).sum() + (bf * dev(gb.float())).sum()).backward()
+    np.testing.assert_allclose(params[0].grad.cpu().numpy(), wd.grad.numpy(), rtol=1e-5, atol=1e-6)
+    if with_bn:
+        tol = 1e-4 * max(1.0, float(gd.grad.abs().max()))
+        assert float((params[1].grad.cpu().double() - gd.grad).abs().max()) < tol
+        np.testing.assert_allclose(params[2].grad.cpu().numpy(), bd.grad.numpy(), rtol=1e-5, atol=1e-6)
+    else:
+        assert params[1].grad is None and params[2].grad is None
+    if with_cb:
+        np.testing.assert_allclose(cbd.grad.cpu().numpy(), leaves[3].grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('shape', [(2, 40, 56, 128, 128), (1, 50, 84, 256, 256), (2, 25, 42, 512, 512)])
+def test_conv3x3_data_gradient_runs_the_halo_kernel_and_equals_the_operand_ring(shape, monkeypatch):
+    """3x3 / stride 1 / pad 1 data gradients (bottleneck conv2, FPN outputs, RPN convs) go through the
+    halo-resident forward kernel on the flipped, transposed filter, with the ReLU-backward mask in
+    its epilogue: == the general operand-ring path (same products; summation order differs between
+    the two kernels) and == fp64 torch autograd."""
+    N, H, W, Cin, Cout = shape
+    rs = np.random.RandomState(Cin + H)
+    x = rs.randn(N, H, W, Cin).astype(np.float32)
+    w = (rs.randn(Cout, Cin, 3, 3) / np.sqrt(Cin * 9)).astype(np.float32)
+    dy = rs.randn(N, H, W, Cout).astype(np.float32)
+    edx, _ = _torch_conv_grads(x, w, dy, 1, 1)
+    wk = dev(krsc(w))
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        BF.launch_census(reset=True)
+        a = BF.conv2d_dgrad_nhwc(dev(dy), wk, (H, W), 1, 1, mask=dev(x))
+        assert BF.launch_census()['halo_bfx4'] == 1
+        monkeypatch.setenv('BGS_DGRAD_HALO', '0')
+        BF.launch_census(reset=True)
+        b = BF.conv2d_dgrad_nhwc(dev(dy), wk, (H, W), 1, 1, mask=dev(x))
+        assert BF.launch_census()['halo_bfx4'] == 0
+    finally:
+        BF.set_conv_math(prev)
+    exp = np.where(x > 0, edx, 0)
+    scale = np.abs(exp).max()
+    assert np.abs(a.cpu().numpy() - exp).max() <= 2e-5 * scale
+    assert np.abs(a.cpu().numpy() - b.cpu().numpy()).max() <= 2e-6 * scale
