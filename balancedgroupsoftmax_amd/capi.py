@@ -49,6 +49,7 @@ SIGNATURES = {
                                         ctypes.c_uint64, c_ptr, c_f32p, c_f32p, c_f32p, ctypes.c_int,
                                         ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, c_f32p,
                                         c_f32p, c_ptr, c_f32p, c_ptr, c_ptr]),
+    'bgs_gs_head_debug_timestamps': (None, [c_ptr]),
     'bgs_gs_class_bin_mask': (ctypes.c_int, [c_i64p, ctypes.c_int, ctypes.c_int, c_ptr, c_ptr]),
     'bgs_gs_head_step_scale_grad': (ctypes.c_int, [c_f32p, c_f32p, c_ptr, c_f32p, c_f32p, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, c_ptr]),

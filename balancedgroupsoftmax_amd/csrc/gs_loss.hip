@@ -267,6 +267,7 @@ struct GsHeadArgs {
   float* dbbox;                  // dense [N, 4R] gradient or nullptr
   int R;
   float beta, box_w;
+  unsigned long long* tstamps;   // debug (bgs_gs_head_debug_timestamps): [gridDim.x][8] s_memtime marks, or null
 };
 
 __device__ __forceinline__ float gs_sl1(float d, float beta, float& grad) {
@@ -299,6 +300,11 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
   const int wave = bgs::uniform(tid >> 6);
   uint64_t seed = a.seed;
   if (a.seed_offset) seed += 0x2545F4914F6CDD1Dull * a.seed_offset[0];   // device-side draw counter
+#define GS_MARK(i_)                                                                     \
+  do {                                                                                  \
+    if (a.tstamps && tid == 0) a.tstamps[(size_t)blockIdx.x * 8 + (i_)] = clock64();    \
+  } while (0)
+  GS_MARK(0);
 
   // ---- prologue.  The flag word of a row is a function of its label alone: {foreground in bin b}
   //      = class_bits[label] — a C-entry 16-bit table (2.4 KB for LVIS) that every workgroup copies
@@ -321,6 +327,12 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
   const float* rw_base = a.row_weights ? a.row_weights : &g_one;
   const int rw_step = a.row_weights ? 1 : 0;
   constexpr int RP = kFusedRowsPerPass;
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const int cpad = (C + 7) & ~7;
+  // (no table: the address of the labels stands in — the value is not used)
+  const uint16_t* cb_src = a.class_bits ? a.class_bits + (tid * 8 < cpad ? tid * 8 : 0)
+                                        : reinterpret_cast<const uint16_t*>(a.labels);
+  const u32x4_t cb0 = *reinterpret_cast<const u32x4_t*>(cb_src);
   int64_t y0[RP];
   float rwv0[RP];
 #pragma unroll
@@ -338,22 +350,11 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
     bgs::load_vec<VEC>(g + (c1 < W ? c1 : 0), t1);
   }
   if (a.class_bits) {
-    // 8 table entries (16 B) per thread and pass
-    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    const int cpad = (C + 7) & ~7;
-    for (int c = tid * 8; c < cpad; c += kBlock * 8) {
-      u32x4_t v;
-      if (c + 8 <= C && (reinterpret_cast<uintptr_t>(a.class_bits) & 15) == 0) {
-        v = *reinterpret_cast<const u32x4_t*>(a.class_bits + c);
-      } else {
-        unsigned short e[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = c + j < C ? a.class_bits[c + j] : (unsigned short)0;
-        v = u32x4_t{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
-                    (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
-      }
-      *reinterpret_cast<u32x4_t*>(sh_cbits + c) = v;
-    }
+    // 8 table entries (16 B) per thread and pass; the table is padded to a multiple of 8 entries and
+    // 16-byte aligned (bgs_gs_class_bin_mask): the first pass was loaded at the top of the kernel
+    *reinterpret_cast<u32x4_t*>(sh_cbits + (tid * 8 < cpad ? tid * 8 : 0)) = cb0;
+    for (int c = (tid + kBlock) * 8; c < cpad; c += kBlock * 8)
+      *reinterpret_cast<u32x4_t*>(sh_cbits + c) = *reinterpret_cast<const u32x4_t*>(a.class_bits + c);
   } else {
     for (int c = tid; c < C; c += kBlock) {
       unsigned bits = 0u;
@@ -369,7 +370,9 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
     bgs::load_vec<VEC>(a.logits + (size_t)blockIdx.x * W + c, t);
     bgs::store_vec<VEC>(smem + c, t);
   }
+  GS_MARK(1);                             // loads landed, LDS written
   __syncthreads();                        // class bits (and the first row) are in LDS
+  GS_MARK(2);
   for (int base = 0; base < N; base += kBlock * RP) {
     bool real[RP];
     unsigned bits[RP];
@@ -400,7 +403,9 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
     }
   }
   if (lane <= B) sh_cntw[wave * (BGS_MAX_BINS + 1) + lane] = mycnt;
+  GS_MARK(3);                             // flags + ballots done
   __syncthreads();                        // flags, counts and the first row are in LDS
+  GS_MARK(4);
 
   // lane b < B of every wave: constants of bin b (gs_prepare_kernel's mode / k / avg)
   int my_mode = 0, my_k = 0;              // 0 = all zero, 1 = all one, 2 = sampled
@@ -516,7 +521,9 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
       if (lane == 0) box_acc += val;
       if (a.dbbox && lane < 4) sh_box[lane] = g;
     }
+    if (first) GS_MARK(5);                // wave 0: rank scan + softmax of its bins done
     __syncthreads();                      // gradient row (and the box gradient) complete
+    if (first) GS_MARK(6);
     if (WRITE_GRAD) bgs::unstage_row<VEC>(row, a.dlogits + (size_t)r * W, W, tid, kBlock);
     if (BOX && a.dbbox) {                 // dense [N, 4R] gradient: zeros but for the positive slot
       typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -531,6 +538,8 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
     a.partial[(size_t)lane * gridDim.x + blockIdx.x] = lacc;
   if (BOX && wave == kWaves - 1 && lane == 0)
     a.partial[(size_t)B * gridDim.x + blockIdx.x] = box_acc;
+  GS_MARK(7);
+#undef GS_MARK
 }
 
 // out[b] = sum_g partial[b][g] for b < B (loss weights are already inside), out[B] = box loss
@@ -692,8 +701,11 @@ extern "C" int bgs_gs_loss_fwd_bwd(const float* logits, const int32_t* bin_label
 namespace {
 
 // shared launcher of the fused head kernel; returns the grid in *grid_out
+unsigned long long* g_gs_tstamps = nullptr;
+
 int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* host_bin_loss_weight,
                    hipStream_t st, int* grid_out) {
+  a.tstamps = g_gs_tstamps;
   if (a.N <= 0 || a.C <= 0 || a.B <= 0 || a.W <= 0) return BGS_ERR_INVALID_ARG;
   if (a.B > BGS_MAX_BINS - 1 || a.N > kFusedMaxN) return BGS_ERR_UNSUPPORTED;
   int tiles = 0;
@@ -777,6 +789,7 @@ extern "C" int bgs_gs_head_step(const float* logits, const int64_t* labels,
                                 bgs_stream_t stream) {
   if (!logits || !labels || !label2binlabel || !host_pred_slice || !avg_out || !workspace)
     return BGS_ERR_INVALID_ARG;
+  if ((uintptr_t)class_bin_mask & 15) return BGS_ERR_INVALID_ARG;
   if (bbox_pred) {
     if (!bbox_targets || !bbox_weights || num_reg_classes <= 0 || !(beta > 0.f)) return BGS_ERR_INVALID_ARG;
     if (((uintptr_t)bbox_pred | (uintptr_t)bbox_targets | (uintptr_t)bbox_weights |
@@ -808,7 +821,11 @@ namespace {
 __global__ __launch_bounds__(256) void gs_class_bits_kernel(const int64_t* __restrict__ l2b, int C, int B,
                                                             uint16_t* __restrict__ out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  if (c >= ((C + 7) & ~7)) return;
+  if (c >= C) {            // padding entries (the table is read in 16-byte pieces)
+    out[c] = 0;
+    return;
+  }
   unsigned bits = 0u;
   for (int b = 0; b < B; ++b)
     if (l2b[(size_t)b * C + c] > 0) bits |= 1u << b;
@@ -816,9 +833,14 @@ __global__ __launch_bounds__(256) void gs_class_bits_kernel(const int64_t* __res
 }
 }  // namespace
 
+// Debug / profiling hook: when buf != NULL every later fused-head launch records 8 s_memtime marks per
+// workgroup into buf[grid][8] (kernel start, loads landed, barrier 1, flags done, barrier 2, bins done,
+// barrier 3, end); NULL switches it off (the default).  tools/gs_phase_times.py.
+extern "C" void bgs_gs_head_debug_timestamps(unsigned long long* buf) { g_gs_tstamps = buf; }
+
 extern "C" int bgs_gs_class_bin_mask(const int64_t* label2binlabel, int C, int B, uint16_t* out,
                                      bgs_stream_t stream) {
-  if (!label2binlabel || !out || C <= 0 || B <= 0) return BGS_ERR_INVALID_ARG;
+  if (!label2binlabel || !out || C <= 0 || B <= 0 || ((uintptr_t)out & 15)) return BGS_ERR_INVALID_ARG;
   if (B > BGS_MAX_BINS - 1) return BGS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(gs_class_bits_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, label2binlabel, C, B, out);

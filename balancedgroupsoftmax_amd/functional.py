@@ -209,7 +209,7 @@ def gs_class_bin_mask(label2binlabel):
         return hit[1]
     lib = capi.load()
     B, C = label2binlabel.shape
-    out = torch.empty((C,), dtype=torch.int16, device=label2binlabel.device)
+    out = torch.empty(((C + 7) // 8 * 8,), dtype=torch.int16, device=label2binlabel.device)   # padded: read in 16-byte pieces
     rc = lib.bgs_gs_class_bin_mask(capi.ptr(label2binlabel), C, B, capi.ptr(out),
                                    capi.current_stream(label2binlabel.device))
     capi.check('bgs_gs_class_bin_mask', rc)

@@ -320,7 +320,10 @@ class DetectorStep(object):
         losses = self.model(self.img, self.metas, return_loss=True, gt_bboxes=self.gt_bboxes,
                             gt_labels=self.gt_labels, gt_masks=self.gt_masks, **self.extra)
         loss, log_vars = self.train.parse_losses(losses)
-        self.step_fn.optimizer.zero_grad(set_to_none=False)
+        # grads set to None: backward then STORES each gradient (AccumulateGrad takes the tensor)
+        # instead of a zero fill + an add per parameter — 2 x 160 launches of the selectp=0 step.
+        # Same values as the reference's zero_grad() + accumulation into zeros.
+        self.step_fn.optimizer.zero_grad(set_to_none=os.environ.get('BGS_ZERO_GRAD_FILL') != '1')
         (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
         # detached copies only: holding the loss would keep the autograd graph (and its
         # AccumulateGrad nodes) alive across iterations

@@ -144,11 +144,16 @@ int bgs_gs_head_step(const float* logits, const int64_t* labels, const int64_t* 
                      float* total_out, float* dlogits, float* dbbox_pred, float* avg_out,
                      int32_t* bin_labels_out, float* weights_out, void* workspace,
                      bgs_stream_t stream);
-/* class_bin_mask [C] uint16 (device): bit b = class is foreground in bin b (label2binlabel[b][c] > 0).
- * Built once per table; bgs_gs_head_step copies it into LDS instead of gathering the [B,C] int64
- * table per row (NULL there: every workgroup derives it from label2binlabel, slower). */
+/* class_bin_mask: uint16 (device), ((C + 7) & ~7) entries, 16-byte aligned: entry c < C has bit b set
+ * iff class c is foreground in bin b (label2binlabel[b][c] > 0), the padding entries are 0.  Built
+ * once per table; bgs_gs_head_step copies it into LDS instead of gathering the [B,C] int64 table per
+ * row (NULL there: every workgroup derives it from label2binlabel, slower). */
 int bgs_gs_class_bin_mask(const int64_t* label2binlabel, int C, int B, uint16_t* out,
                           bgs_stream_t stream);
+/* Profiling hook of the fused head kernel: buf != NULL (device, [2048][8] uint64) makes every later
+ * launch record 8 shader-clock marks per workgroup (start, loads landed, barrier 1, flags done,
+ * barrier 2, bins done, barrier 3, end); NULL (default) switches it off.  tools/gs_phase_times.py. */
+void bgs_gs_head_debug_timestamps(unsigned long long* buf);
 /* Backward of bgs_gs_head_step: grad_terms [B+1] (device; upstream gradient of {bins, box}, NULL = 0)
  * and grad_total [1] (of total_out, NULL = 0): dlogits[:, bin b] *= grad_terms[b] + grad_total,
  * dbbox_pred *= grad_terms[B] + grad_total, in place, one launch, early-out on the device when
