@@ -153,6 +153,33 @@ __device__ __forceinline__ uint32_t gs_key(uint32_t salt, uint32_t row) {
   return x;
 }
 
+// Exact-k sampling without replacement in O(1) per row: the candidates of a bin are numbered in
+// row order (pos = number of candidate rows before this one, a prefix count), a keyed pseudo-random
+// PERMUTATION of [0, M) is applied to the position, and the row is selected iff the image is < k —
+// exactly k of the M candidates, every k-subset being the image of the first k positions under the
+// permutation.  The permutation is a 6-round Feistel network on 2h bits (4^h >= M, round function =
+// the lowbias32 mixer keyed by salt and round) made a bijection of [0, M) by cycle walking.  This
+// replaces "rank of the row's key among all candidates" (a radix select in the prepare kernel, an
+// O(N) hash scan per row and bin in the fused head kernel).
+__device__ __forceinline__ uint32_t gs_perm(uint32_t salt, uint32_t x, uint32_t M) {
+  uint32_t h = 1;
+  while (h < 16 && (1u << (2 * h)) < M) ++h;
+  const uint32_t mask = (1u << h) - 1u;
+  for (int guard = 0; guard < 4096; ++guard) {        // cycle walking: expected < 4 rounds (2^(2h) < 4M)
+    uint32_t L = x >> h, R = x & mask;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const uint32_t F = gs_key(salt + 0x9E3779B9u * (uint32_t)(i + 1), R) & mask;
+      const uint32_t t = L ^ F;
+      L = R;
+      R = t;
+    }
+    x = (L << h) | R;
+    if (x < M) break;
+  }
+  return x;
+}
+
 // integer wave sum on the DPP path (wave_sum_i above is six dependent ds_bpermute round trips)
 #ifndef BGS_NO_DPP
 // (same recipe as BGS_DPP_REDUCE: only lane 63's value is the full sum)

@@ -231,9 +231,11 @@ __global__ __launch_bounds__(kBlock) void gs_scale_grad_kernel(float* __restrict
 //     (8 B of label + B table gathers per row, all loads of a thread's rows in flight together)
 //     and the per-bin foreground counts by wave ballots — no LDS atomics;
 //   * the "others" decision of the workgroup's own row in bin b is taken by THE WAVE THAT OWNS
-//     BIN b (bins are independent, one wave each): rank of the row's key among the bin's background
-//     rows by counting, N / 64 cheap 32-bit keys per lane (bgs::gs_key), one DPP wave sum — no
-//     cross-wave exchange, so a row costs the same two barriers as the plain loss kernel;
+//     BIN b (bins are independent, one wave each): the row's position among the bin's candidates
+//     (a count over the flag words below the row, one DPP wave sum) goes through the bin's keyed
+//     pseudo-random permutation of [0, n_bg) (bgs::gs_perm, wave-uniform: scalar ALU) — drawn iff
+//     the image is < k_b: exact-k sampling without a key per row, no cross-wave exchange, so a row
+//     costs the same two barriers as the plain loss kernel;
 //   * closed forms as before: k_b = int(n_fg * ratio), avg_b = n_real | n_fg + k_b | 1;
 //   * the per-bin loss weights ride in the kernel arguments (coef = w / avg * loss_weight);
 //   * the box branch of the row is four lanes of the last wave.
@@ -373,6 +375,7 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
   GS_MARK(1);                             // loads landed, LDS written
   __syncthreads();                        // class bits (and the first row) are in LDS
   GS_MARK(2);
+  unsigned pk[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
   for (int base = 0; base < N; base += kBlock * RP) {
     bool real[RP];
     unsigned bits[RP];
@@ -394,13 +397,28 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
       real[i] = r < N && rwv > 0.f;
       if (r < N) sh_flags[r] = (unsigned short)(real[i] ? (bits[i] | 0x8000u) : 0u);
     }
-    for (int b = 0; b <= B; ++b) {
-      int pop = 0;
+    // per-thread counters, two 16-bit fields per register: bins 2 f and 2 f + 1 (a wave's share of
+    // the rows is <= 64 * 16: no carry), field 15 = real rows
 #pragma unroll
-      for (int i = 0; i < RP; ++i)
-        pop += __popcll(__builtin_amdgcn_ballot_w64(real[i] && (b == B || ((bits[i] >> b) & 1u))));
-      if (lane == b) mycnt += pop;
+    for (int i = 0; i < RP; ++i) {
+      const unsigned wbits = real[i] ? (bits[i] | 0x8000u) : 0u;
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+        if (2 * f < B || f == 7) pk[f] += ((wbits >> (2 * f)) & 1u) | (((wbits >> (2 * f + 1)) & 1u) << 16);
     }
+  }
+  // one DPP sum per used register; lane b <= B then picks its field (b == B: the real rows, field 15)
+  {
+    const int fsel = lane == B ? 15 : lane;
+    unsigned mine = 0u;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      if (2 * f < B || f == 7) {
+        const unsigned t = (unsigned)bgs::wave_sum_i_fast((int)pk[f]);
+        if ((fsel >> 1) == f) mine = t;
+      }
+    }
+    mycnt = (int)((mine >> (16 * (fsel & 1))) & 0xffffu);
   }
   if (lane <= B) sh_cntw[wave * (BGS_MAX_BINS + 1) + lane] = mycnt;
   GS_MARK(3);                             // flags + ballots done
@@ -408,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
   GS_MARK(4);
 
   // lane b < B of every wave: constants of bin b (gs_prepare_kernel's mode / k / avg)
-  int my_mode = 0, my_k = 0;              // 0 = all zero, 1 = all one, 2 = sampled
+  int my_mode = 0, my_k = 0, my_nbg = 0;  // 0 = all zero, 1 = all one, 2 = sampled
   float my_scale = 0.f;                   // loss_weight / avg
   int n_real = 0;
 #pragma unroll
@@ -418,6 +436,7 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
 #pragma unroll
     for (int v = 0; v < kWaves; ++v) n_fg += sh_cntw[v * (BGS_MAX_BINS + 1) + lane];
     const int n_bg = n_real - n_fg;
+    my_nbg = n_bg;
     float total;
     if (lane == 0) {
       my_mode = 1;
@@ -462,22 +481,22 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
         if (mode_b == 1 || (mode_b == 2 && bl_b > 0)) {
           w = 1.f;
         } else if (mode_b == 2) {
-          // rank of (key, row) among the background rows of bin b: selected iff rank < k_b
+          // position of the row among the bin's candidates (real, non-foreground rows) in row
+          // order, then the bin's keyed permutation of [0, n_bg): drawn iff the image is < k_b
           const int k_b = __builtin_amdgcn_readlane(my_k, b);
-          const unsigned salt = bgs::gs_bin_salt(seed, (uint32_t)b);
-          const unsigned mine = bgs::gs_key(salt, (uint32_t)r);
+          const int nbg_b = __builtin_amdgcn_readlane(my_nbg, b);
           int cnt = 0;
-          for (int q0 = lane; q0 < N; q0 += BGS_WAVE * 4) {
+          for (int q0 = lane; q0 < r; q0 += BGS_WAVE * 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int q = q0 + BGS_WAVE * u;
-              const unsigned f = sh_flags[q < N ? q : 0];
-              const bool cand = q < N && (f & 0x8000u) && !((f >> b) & 1u);
-              const unsigned key = bgs::gs_key(salt, (uint32_t)q);
-              cnt += (cand && (key < mine || (key == mine && q < r))) ? 1 : 0;
+              const unsigned f = sh_flags[q < r ? q : 0];
+              cnt += (q < r && (f & 0x8000u) && !((f >> b) & 1u)) ? 1 : 0;
             }
           }
-          w = bgs::wave_sum_i_fast(cnt) < k_b ? 1.f : 0.f;
+          const unsigned pos = (unsigned)bgs::wave_sum_i_fast(cnt);
+          const unsigned salt = bgs::gs_bin_salt(seed, (uint32_t)b);
+          w = (k_b > 0 && bgs::gs_perm(salt, pos, (unsigned)nbg_b) < (unsigned)k_b) ? 1.f : 0.f;
         }
       }
       const float coef = w * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_scale), b));

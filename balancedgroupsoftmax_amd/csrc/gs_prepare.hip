@@ -9,9 +9,9 @@
 // Here: ONE launch, one workgroup per bin, no host involvement:
 //   bl[r]  = label2binlabel[b, labels[r]]                       (int64 gather, bit-exact)
 //   n_fg   = #{bl > 0};  k = int(n_fg * ratio);  M = N - n_fg
-//   n_fg == 0 -> w = 0;   k >= M -> w = 1;   else  w = fg OR (row is among the k smallest
-//   32-bit counter-based random keys (bgs::gs_key) of the non-fg rows)  == uniform sampling of exactly k
-//   rows without replacement (ties broken by row index), found by a 4-pass radix select.
+//   n_fg == 0 -> w = 0;   k >= M -> w = 1;   else  w = fg OR (a keyed pseudo-random permutation of
+//   [0, M) maps the row's position among the non-fg rows below k: bgs::gs_perm)  == uniform
+//   sampling of exactly k rows without replacement, O(1) per row after a prefix count.
 //   avg    = max(sum_r w[r], 1)
 // Fixed-shape batches: `row_weights` (the detector's label_weights) marks padding slots with a
 // value <= 0 — the reference's sampler returns FEWER RoIs instead (two_stage.py:200-210), so such
@@ -24,12 +24,9 @@ constexpr int kThreads = 1024;
 constexpr int kNW = kThreads / BGS_WAVE;
 
 struct PrepShared {
-  int hist[256];
   int wsum_i[kNW];
   double wsum_d[kNW];
-  unsigned prefix;  // selected high bits so far
-  int rem;          // rank still to be resolved inside the current prefix
-  int tie_row_bound;
+  int wtot[kNW];   // candidates per wave of the current chunk (block-wide prefix count)
 };
 
 __device__ __forceinline__ int block_sum_i(int v, int* sm) {
@@ -63,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t* map = l2b + (size_t)b * C;
   if (seed_offset) seed += 0x2545F4914F6CDD1Dull * seed_offset[0];  // device-side draw counter
-  const unsigned salt = bgs::gs_bin_salt(seed, (uint32_t)b);          // keys: bgs::gs_key(salt, row)
+  const unsigned salt = bgs::gs_bin_salt(seed, (uint32_t)b);          // key of the bin's permutation
 
   // pass 0: bin labels + foreground count (+ number of real rows)
   int nfg_local = 0, nreal_local = 0;
@@ -91,93 +88,46 @@ __global__ __launch_bounds__(kThreads) void gs_prepare_kernel(
     mode = (k >= n_bg) ? 1 : 2;
   }
 
-  unsigned T = 0u;       // threshold key
-  int tie_bound = N;     // rows with key == T and row < tie_bound are selected
-  if (mode == 2 && k > 0) {
-    if (tid == 0) {
-      sh.prefix = 0u;
-      sh.rem = k;  // rank (1-based) of the largest selected key among the non-fg rows
-    }
-    for (int pass = 0; pass < 4; ++pass) {
-      const int shift = 24 - 8 * pass;
-      if (tid < 256) sh.hist[tid] = 0;
-      __syncthreads();
-      const unsigned prefix = sh.prefix;
-      const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-      for (int r = tid; r < N; r += kThreads) {
-        int64_t y = labels[r];
-        y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
-        if (map[y] > 0 || (row_weights && !(row_weights[r] > 0.f))) continue;
-        const unsigned key = bgs::gs_key(salt, (uint32_t)r);
-        if ((key & himask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 0xFFu], 1);
-      }
-      __syncthreads();
-      if (wave == 0) {
-        const int rem = sh.rem;
-        const int h0 = sh.hist[4 * lane], h1 = sh.hist[4 * lane + 1], h2 = sh.hist[4 * lane + 2],
-                  h3 = sh.hist[4 * lane + 3];
-        const int s = h0 + h1 + h2 + h3;
-        int incl = s;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const int t = __shfl_up(incl, off, BGS_WAVE);
-          if (lane >= off) incl += t;
-        }
-        const int excl = incl - s;
-        if (excl < rem && rem <= incl) {  // exactly one lane
-          int c = excl, d = 4 * lane;
-          if (rem > c + h0) { c += h0; ++d;
-            if (rem > c + h1) { c += h1; ++d;
-              if (rem > c + h2) { c += h2; ++d; } } }
-          sh.prefix = prefix | ((unsigned)d << shift);
-          sh.rem = rem - c;  // rank inside digit d (>= 1)
-          if (pass == 3) sh.hist[0] = sh.hist[d] == rem - c ? 1 : 0;  // all ties selected?
-        }
-      }
-      __syncthreads();
-    }
-    T = sh.prefix;
-    const int need = sh.rem;           // number of rows with key == T to select (>= 1)
-    const bool all_ties = sh.hist[0] == 1;
-    if (!all_ties) {
-      // more rows share the threshold key than we may take: keep the `need` lowest row ids.
-      // (probability ~ N / 2^32 per call; a serial scan by one thread is fine.)
-      if (tid == 0) {
-        int got = 0, bound = N;
-        for (int r = 0; r < N; ++r) {
-          int64_t y = labels[r];
-          y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
-          if (map[y] > 0 || (row_weights && !(row_weights[r] > 0.f))) continue;
-          if (bgs::gs_key(salt, (uint32_t)r) == T) {
-            if (++got == need) { bound = r + 1; break; }
-          }
-        }
-        sh.tie_row_bound = bound;
-      }
-      __syncthreads();
-      tie_bound = sh.tie_row_bound;
-    }
-  }
-
-  // weights + their sum
+  // weights + their sum.  Sampled bins: the candidates (real, non-foreground rows) are numbered in
+  // row order by a block-wide prefix count, chunk by chunk; row r is drawn iff the keyed
+  // permutation of [0, n_bg) maps its position below k (bgs::gs_perm): exactly k rows.
   const float* cw = (cls_weight && b >= 1) ? cls_weight + (size_t)(b - 1) * cw_stride : nullptr;
   double wsum = 0.0;
-  for (int r = tid; r < N; r += kThreads) {
-    int64_t y = labels[r];
-    y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
-    const int64_t bl = map[y];
+  int base = 0;                      // candidates in the chunks before this one (block-uniform)
+  for (int r0 = 0; r0 < N; r0 += kThreads) {
+    const int r = r0 + tid;
+    const bool in = r < N;
+    int64_t bl = 0;
+    bool real = false;
+    if (in) {
+      int64_t y = labels[r];
+      y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
+      bl = map[y];
+      real = !row_weights || row_weights[r] > 0.f;
+    }
+    const bool cand = in && real && !(bl > 0);
+    bool sel = true;
+    if (mode == 2) {                 // block-uniform
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
+      const int before = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) sh.wtot[wave] = __popcll(m);
+      __syncthreads();
+      int off = 0, tot = 0;
+      for (int v = 0; v < kNW; ++v) {
+        const int t = sh.wtot[v];
+        off += v < wave ? t : 0;
+        tot += t;
+      }
+      __syncthreads();               // wtot is rewritten by the next chunk
+      sel = bl > 0;
+      if (cand && k > 0) sel = bgs::gs_perm(salt, (uint32_t)(base + off + before), (uint32_t)n_bg) < (uint32_t)k;
+      base += tot;
+    }
+    if (!in) continue;
     float w;
-    if (mode == 0 || (row_weights && !(row_weights[r] > 0.f))) {
+    if (mode == 0 || !real) {
       w = 0.f;  // (padding slot, or) the reference returns zeros BEFORE the class-weight multiply (reweight.py:65-66)
     } else {
-      bool sel = true;
-      if (mode == 2) {
-        sel = bl > 0;
-        if (!sel && k > 0) {
-          const unsigned key = bgs::gs_key(salt, (uint32_t)r);
-          sel = (key < T) || (key == T && r < tie_bound);
-        }
-      }
       w = sel ? 1.f : 0.f;
       if (cw) {
         int64_t idx = bl < 0 ? 0 : (bl >= cw_stride ? (int64_t)cw_stride - 1 : bl);
