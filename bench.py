@@ -1071,9 +1071,10 @@ def main():
         }
         if dt_eager is not None:
             out['ms_per_step_eager'] = round(dt_eager, 5)
-        out['roofline'] = kernel_roofline(inp, n)
+        out['roofline'] = kernel_roofline(inp, n, kernel='fused' if n <= BF.GS_FUSED_MAX_ROWS else 'rowwave')
+        out['roofline_rowwave'] = kernel_roofline(inp, n, kernel='rowwave')
         big = make_inputs(65536, seed=7, dev=dev)
-        out['roofline_n65536'] = kernel_roofline(big, 65536, iters=30)
+        out['roofline_n65536'] = kernel_roofline(big, 65536, iters=30, kernel='rowwave')
         del big
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(n, args.cpu_seconds)
