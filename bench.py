@@ -867,7 +867,7 @@ def run_dist_graph_children(args, rank, local, world):
     try:
         p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         try:
-            so, se = p.communicate(timeout=420)
+            so, se = p.communicate(timeout=180)
         except subprocess.TimeoutExpired:
             p.kill()                      # exactly the child this rank started
             so, se = p.communicate()
