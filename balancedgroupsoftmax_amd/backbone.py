@@ -122,7 +122,23 @@ class Bottleneck(nn.Module):
             f['ds'] = _fold_conv_bn(self.downsample[0], self.downsample[1])
         return f
 
+    def run_bf16_storage(self, x, f):
+        """The frozen block with bf16 activations in HBM (cfg[4] bf16 mode, csrc/conv_bf16s.hip):
+        bf16 in, bf16 out, fp32 accumulate / bias / residual add / ReLU inside the kernels."""
+        identity = x
+        if 'ds' in f:
+            identity = BF.conv2d_nhwc(x, f['ds'][0], f['ds'][1], stride=self.stride)
+        out = BF.conv2d_nhwc(x, f['c1'][0], f['c1'][1], relu=True)
+        if self.groups > 1:
+            out = BF.grouped_conv3x3_nhwc(out, f['c2'][0], f['c2'][1], self.groups, stride=self.stride,
+                                          relu=True)
+        else:
+            out = BF.conv2d_nhwc(out, f['c2'][0], f['c2'][1], stride=self.stride, pad=1, relu=True)
+        return BF.conv2d_nhwc(out, f['c3'][0], f['c3'][1], relu=True, residual=identity)
+
     def run(self, x, f):
+        if x.dtype == torch.bfloat16:
+            return self.run_bf16_storage(x, f)
         identity = x
         if 'ds' in f:
             identity = BF.conv2d_autograd(x, f['ds'][0], f['ds'][1], stride=self.stride)
@@ -240,7 +256,11 @@ class ResNet(nn.Module):
         stem = self._cache.get(nn.ModuleList([self.conv1, self.bn1]), self._build_stem)
         x = self.to_nhwc4(img)
         x = BF.conv2d_autograd(x, stem[0], stem[1], stride=2, pad=3, relu=True)
-        x = BF.maxpool3x3s2_nhwc(x)
+        # cfg[4] bf16 mode with a frozen trunk: the activations of layer1..4 live in HBM as bf16
+        # (the storage side of wrap_fp16_model, mmdet/core/fp16/decorators.py:8-80)
+        storage = (BF.bf16_storage_active() and not x.requires_grad and
+                   not _trainable(*[getattr(self, n) for n in self.res_layers]))
+        x = BF.maxpool3x3s2_nhwc(x, out_dtype=torch.bfloat16 if storage else torch.float32)
         outs = []
         for i, name in enumerate(self.res_layers):
             for blk in getattr(self, name):
@@ -313,11 +333,14 @@ class FPN(nn.Module):
         assert len(inputs) == self.num_ins
         f = self._cache.get(self, self._build_fold)
         n = self.num_ins
+        if inputs[0].dtype != torch.float32 and torch.is_grad_enabled() and _trainable(self):
+            inputs = [t.float() for t in inputs]      # a trainable neck records fp32 operands
         lat = [None] * n
-        lat[n - 1] = BF.conv2d_autograd(inputs[n - 1], *f['lat'][n - 1])
+        # bf16-stored trunk maps (cfg[4] bf16 mode) are read as they are; the pyramid itself is fp32
+        lat[n - 1] = BF.conv2d_autograd(inputs[n - 1], *f['lat'][n - 1], out_dtype=torch.float32)
         for i in range(n - 2, -1, -1):   # lateral_i + nearest_2x(lateral_{i+1}), fused
             lat[i] = BF.conv2d_autograd(inputs[i], *f['lat'][i], residual=lat[i + 1],
-                                        residual_mode=2)
+                                        residual_mode=2, out_dtype=torch.float32)
         outs = [BF.conv2d_autograd(lat[i], *f['out'][i], pad=1) for i in range(n)]
         for _ in range(self.num_outs - n):   # F.max_pool2d(x, 1, stride=2) == subsampling
             outs.append(outs[-1][:, ::2, ::2, :].contiguous())

@@ -116,6 +116,11 @@ SIGNATURES = {
                                            + [ctypes.c_int] * 7 + [c_ptr, c_ptr]),
     'bgs_maxpool3x3s2_bwd_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 4 + [c_ptr]),
     'bgs_maxpool3x3s2_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p] + [ctypes.c_int] * 4 + [c_ptr]),
+    'bgs_conv2d_nhwc_bf16s': (ctypes.c_int, [c_ptr, c_ptr, c_f32p, c_ptr, ctypes.c_int, ctypes.c_int, c_ptr]
+                              + [ctypes.c_int] * 11 + [c_ptr]),
+    'bgs_grouped_conv3x3_nhwc_bf16s': (ctypes.c_int, [c_ptr, c_f32p, c_f32p, c_ptr] + [ctypes.c_int] * 7
+                                       + [c_ptr]),
+    'bgs_maxpool3x3s2_nhwc_f32_to_bf16': (ctypes.c_int, [c_f32p, c_ptr] + [ctypes.c_int] * 4 + [c_ptr]),
     'bgs_roi_align_nhwc_fwd': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int,

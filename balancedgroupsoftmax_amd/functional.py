@@ -496,6 +496,23 @@ class conv_math_scope(object):
 # temporaries such as the folded copies of a trained trunk) are NEVER cached: their split launch is
 # part of every step — inside a captured hipGraph it is re-run by every replay, so an eager forward
 # after replayed optimizer steps (which do not bump ``_version``) cannot read stale planes.
+# bf16 STORAGE of the frozen trunk's activations in the 'bf16' arithmetic mode (csrc/conv_bf16s.hip;
+# the memory side of the reference's wrap_fp16_model, mmdet/core/fp16/decorators.py:8-80).
+# BGS_BF16_STORAGE=0 keeps fp32 tensors in HBM (operands rounded inside the kernels), the A/B arm.
+_BF16_STORAGE = [os.environ.get('BGS_BF16_STORAGE', '1') != '0']
+
+
+def set_bf16_storage(on):
+    """-> previous value.  Effective only while the arithmetic mode is ``'bf16'``."""
+    prev = _BF16_STORAGE[0]
+    _BF16_STORAGE[0] = bool(on)
+    return prev
+
+
+def bf16_storage_active():
+    return _CONV_MATH[0] == 'bf16' and _BF16_STORAGE[0]
+
+
 _SPLIT_CACHE = {}
 _SPLIT_CACHE_MAX = 1024
 
@@ -548,7 +565,7 @@ def conv_bfx_last_launch():
 
 
 CENSUS = dict(bf16_ring8=0, grouped_lds=1, halo_bfx4=2, dma_ring64=3, gs_head_fused=4, conv1x1_bres=5,
-              wgrad_bfx=6, roi_bwd_gather=7)
+              wgrad_bfx=6, roi_bwd_gather=7, bf16s=8, grouped_bf16s=9)
 
 
 def launch_census(reset=False):
@@ -599,14 +616,16 @@ def _use_halo_kernel(M, Cout):
 
 
 def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None,
-                residual_mode=0, out=None, frozen_weight=True):
+                residual_mode=0, out=None, frozen_weight=True, out_dtype=None):
     """``y = act(conv(x, w) + bias + residual)``; x ``[N,H,W,Cin]``, w ``[Cout,R,S,Cin]``.
     Forward only (the shipped BAGS configs freeze every conv: selectp=1, tools/train.py:49-57).
     ``frozen_weight=False``: ``w_krsc`` is (a detached view of) a tensor that changes from step to
-    step — its bf16 planes are split on every call and never cached."""
+    step — its bf16 planes are split on every call and never cached.
+    ``x`` in bf16 selects the bf16 storage kernels (cfg[4] bf16 mode; ``out_dtype``: bf16 (default)
+    or fp32 for consumers outside the trunk)."""
     _require_cuda(x, w_krsc, bias, residual)
     lib = capi.load()
-    assert x.dtype == torch.float32 and w_krsc.dtype == torch.float32
+    assert x.dtype in (torch.float32, torch.bfloat16) and w_krsc.dtype == torch.float32
     assert x.is_contiguous() and w_krsc.is_contiguous() and x.dim() == 4 and w_krsc.dim() == 4
     N, H, W, Cin = x.shape
     Cout, R, S, Cin2 = w_krsc.shape
@@ -618,6 +637,26 @@ def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None
     if residual is not None:
         exp = (N, Ho, Wo, Cout) if residual_mode == 1 else (N, Ho // 2, Wo // 2, Cout)
         assert tuple(residual.shape) == exp and residual.is_contiguous(), (residual.shape, exp)
+    if x.dtype == torch.bfloat16:
+        # bf16 storage mode (csrc/conv_bf16s.hip): bf16 activations, the bf16(w) plane, fp32 accumulate
+        if out_dtype is None:
+            out_dtype = torch.bfloat16
+        assert out_dtype in (torch.float32, torch.bfloat16)
+        assert residual is None or residual.dtype in (torch.float32, torch.bfloat16)
+        if out is None:
+            out = torch.empty((N, Ho, Wo, Cout), dtype=out_dtype, device=x.device)
+        assert out.dtype == out_dtype
+        wsplit = bfx_split_weights(w_krsc.view(Cout, R * S * Cin), cache=bool(frozen_weight))
+        rc = lib.bgs_conv2d_nhwc_bf16s(capi.ptr(x), capi.ptr(wsplit), capi.ptr(bias), capi.ptr(residual),
+                                       residual_mode if residual is not None else 0,
+                                       int(residual is not None and residual.dtype == torch.bfloat16),
+                                       capi.ptr(out), int(out_dtype == torch.bfloat16), N, H, W, Cin,
+                                       Cout, R, S, stride, pad, int(bool(relu)),
+                                       capi.current_stream(x.device))
+        capi.check('bgs_conv2d_nhwc_bf16s', rc)
+        return out
+    assert out_dtype in (None, torch.float32), 'fp32 activations produce fp32 (bf16 out needs bf16 in)'
+    assert residual is None or residual.dtype == torch.float32
     if out is None:
         out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
     halo_ok = R == 3 and S == 3 and stride == 1 and pad == 1 and residual is None and Cin % 16 == 0
@@ -910,7 +949,7 @@ def relu_gate(y):
 
 
 def conv2d_autograd(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None,
-                    residual_mode=0, mask_input=False):
+                    residual_mode=0, mask_input=False, out_dtype=None):
     """:func:`conv2d_nhwc` that records an autograd node when any input requires grad.
     ``relu``: False / True / ``'consumers'`` (see :class:`_ConvFn`); ``mask_input``: ``x`` is the
     output of a ``relu='consumers'`` conv.  The contract is checked where it can be: outputs of
@@ -918,6 +957,9 @@ def conv2d_autograd(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=
     ``mask_input=True`` raises (its gradient would skip the ReLU gate)."""
     ts = [t for t in (x, w_krsc, bias, residual) if t is not None]
     if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
+        if x.dtype != torch.float32:
+            raise RuntimeError('conv2d_autograd: bf16-stored activations are forward-only (frozen trunk); '
+                               'convert to fp32 before a trainable layer')
         if getattr(x, '_bgs_consumers_mask', False) and not mask_input:
             raise RuntimeError("conv2d_autograd: x is the output of a relu='consumers' conv (its ReLU "
                                "backward is delegated to its consumers) but mask_input is False")
@@ -929,7 +971,7 @@ def conv2d_autograd(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=
             y._bgs_consumers_mask = True
         return y
     return conv2d_nhwc(x, w_krsc, bias, stride=stride, pad=pad, relu=bool(relu),
-                       residual=residual, residual_mode=residual_mode)
+                       residual=residual, residual_mode=residual_mode, out_dtype=out_dtype)
 
 
 def linear(x, weight, bias=None, relu=False, frozen_weight=None):
@@ -1003,6 +1045,14 @@ def linear_autograd(x, weight, bias=None, relu=False, mask_input=False):
 def _grouped_conv3x3_launch(x, w, bias, groups, stride, relu):
     lib = capi.load()
     N, H, W, C = x.shape
+    if x.dtype == torch.bfloat16:      # bf16 storage mode: bf16 in, bf16 out (csrc/conv_bf16s.hip)
+        out = torch.empty((N, (H - 1) // stride + 1, (W - 1) // stride + 1, C), dtype=torch.bfloat16,
+                          device=x.device)
+        rc = lib.bgs_grouped_conv3x3_nhwc_bf16s(capi.ptr(x), capi.ptr(w), capi.ptr(bias), capi.ptr(out),
+                                                N, H, W, C, int(groups), int(stride), int(bool(relu)),
+                                                capi.current_stream(x.device))
+        capi.check('bgs_grouped_conv3x3_nhwc_bf16s', rc)
+        return out
     out = torch.empty((N, (H - 1) // stride + 1, (W - 1) // stride + 1, C), dtype=torch.float32,
                       device=x.device)
     if _CONV_MATH[0] == 'bf16' and stride == 1 and C % 64 == 0:
@@ -1076,18 +1126,27 @@ def grouped_conv3x3_nhwc(x, w, bias, groups, stride=1, relu=False):
     """Grouped 3x3 / pad 1 conv (ResNeXt conv2): x ``[N,H,W,C]``, w ``[C,3,3,C/groups]``; records
     an autograd node when an input requires grad."""
     _require_cuda(x, w, bias)
-    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and w.is_contiguous()
+    assert x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous() and x.dim() == 4
+    assert w.is_contiguous() and w.dtype == torch.float32
     N, H, W, C = x.shape
     assert tuple(w.shape) == (C, 3, 3, C // groups), (w.shape, C, groups)
     if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or
                                     (bias is not None and bias.requires_grad)):
+        if x.dtype != torch.float32:
+            raise RuntimeError('grouped_conv3x3_nhwc: bf16-stored activations are forward-only')
         return _GroupedConvFn.apply(x, w, bias, int(groups), int(stride), bool(relu))
     return _grouped_conv3x3_launch(x, w, bias, groups, stride, relu)
 
 
-def _maxpool_launch(x):
+def _maxpool_launch(x, out_dtype=torch.float32):
     lib = capi.load()
     N, H, W, C = x.shape
+    if out_dtype == torch.bfloat16:    # entry of the bf16-stored trunk
+        out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.bfloat16, device=x.device)
+        rc = lib.bgs_maxpool3x3s2_nhwc_f32_to_bf16(capi.ptr(x), capi.ptr(out), N, H, W, C,
+                                                   capi.current_stream(x.device))
+        capi.check('bgs_maxpool3x3s2_nhwc_f32_to_bf16', rc)
+        return out
     out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float32,
                       device=x.device)
     rc = lib.bgs_maxpool3x3s2_nhwc_f32(capi.ptr(x), capi.ptr(out), N, H, W, C,
@@ -1115,14 +1174,15 @@ class _MaxPoolFn(torch.autograd.Function):
         return dx
 
 
-def maxpool3x3s2_nhwc(x):
+def maxpool3x3s2_nhwc(x, out_dtype=torch.float32):
     """3x3 / stride 2 / pad 1 max pooling (ResNet stem); differentiable when ``x`` requires grad
-    (``frozen_stages < 1``)."""
+    (``frozen_stages < 1``).  ``out_dtype=torch.bfloat16``: the pooled map is stored in bf16."""
     _require_cuda(x)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
     if torch.is_grad_enabled() and x.requires_grad:
+        assert out_dtype == torch.float32
         return _MaxPoolFn.apply(x)
-    return _maxpool_launch(x)
+    return _maxpool_launch(x, out_dtype)
 
 
 # ----------------------------------------------------------------------------------------

@@ -346,8 +346,11 @@ CONV_MATH_NOTE = {
               '(tests/test_gpu_det_ops.py::test_bfx_error_not_above_f32_mfma)',
     'f32': 'v_mfma_f32_32x32x2_f32: fp32 in / fp32 accumulate, bit-exact fma chain',
     'bf16': 'REDUCED PRECISION (cfg[4] only): conv / linear operands rounded to bf16 for '
-            'v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 storage and master weights, fp32 '
-            'GroupSoftmax / box / mask losses (force_fp32), loss scale 512 (Fp16OptimizerHook)',
+            'v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 master weights, fp32 '
+            'GroupSoftmax / box / mask losses (force_fp32), loss scale 512 (Fp16OptimizerHook); '
+            'the activations of the frozen trunk (ResNe(X)t layer1-4) are STORED in bf16 '
+            '(csrc/conv_bf16s.hip; the pyramid, RoI features and heads stay fp32) unless '
+            'BGS_BF16_STORAGE=0, which keeps fp32 tensors and rounds inside the kernels',
 }
 
 
@@ -661,15 +664,19 @@ def extras(dev, args):
             ('mask_rcnn_selectp0', ['--mask', '--selectp', '0']),
             ('cascade_x101_64x4d_selectp3_fp32', ['--cascade', '--selectp', '3']),
             ('cascade_x101_64x4d_selectp3_bf16', ['--cascade', '--selectp', '3', '--conv-math', 'bf16']),
+            ('cascade_x101_64x4d_selectp3_bf16_fp32storage',
+             ['--cascade', '--selectp', '3', '--conv-math', 'bf16'], {'BGS_BF16_STORAGE': '0'}),
             ('htc_x101_64x4d_selectp3_fp32', ['--htc', '--selectp', '3']),
             ('htc_x101_64x4d_selectp3_bf16', ['--htc', '--selectp', '3', '--conv-math', 'bf16']))
-    for key, flags in runs:
+    for run in runs:
+        key, flags = run[0], run[1]
+        env = dict(os.environ, **run[2]) if len(run) > 2 else None
         cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'detector', '--steps', '10',
                '--warmup', '3', '--imgs', str(args.imgs), '--no-extras', '--no-cpu-baseline',
                '--no-roofline'] + (['--conv-math', args.conv_math] if '--conv-math' not in flags else []) \
             + flags + (['--no-graph'] if args.no_graph else [])
         try:
-            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420, env=env)
             line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')]
             if out.returncode != 0 or not line:
                 res[key] = {'error': 'rc=%d %s' % (out.returncode, out.stderr.decode()[-160:])}
@@ -954,8 +961,11 @@ def main_detector(args, rank, local, world, dev):
             'value': round(imgs_per_s, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'f32': 'f32', 'bf16': 'bf16 (conv/linear operands rounded to bf16, fp32 '
-                                                   'accumulate; fp32 storage, master weights and losses)',
+            'dtype': {'f32': 'f32', 'bf16': 'bf16 (conv/linear operands rounded to bf16, fp32 accumulate; %s; '
+                                                   'fp32 master weights and losses)'
+                                                   % ('bf16 storage of the frozen trunk activations'
+                                                      if os.environ.get('BGS_BF16_STORAGE', '1') != '0'
+                                                      else 'fp32 storage'),
                       'bf16x6': 'f32 (conv/linear products on the bf16 MFMA from exact 3-way bf16 '
                                 'splits, fp32 accumulate: fp32-faithful)'}[args.conv_math],
             'data': 'synthetic',

@@ -367,6 +367,8 @@ int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wsplit, const f
 #define BGS_CENSUS_CONV1X1_BRES 5    /* conv1x1_bres_kernel (filter-resident 1x1)         */
 #define BGS_CENSUS_WGRAD_BFX 6       /* conv_wgrad_bfx_kernel                             */
 #define BGS_CENSUS_ROI_BWD_GATHER 7  /* roi_align backward without global atomics         */
+#define BGS_CENSUS_BF16S 8           /* conv_bf16s_kernel (bf16 activations in HBM)       */
+#define BGS_CENSUS_GROUPED_BF16S 9   /* grouped 3x3 conv with bf16 activations in HBM     */
 #define BGS_CENSUS_FAMILIES 16
 int bgs_launch_census(int family, int reset);
 void bgs_conv_bfx_tuning(int tile, int splitk);
@@ -395,6 +397,27 @@ int bgs_grouped_conv3x3_nhwc_f32(const float* x, const float* w, const float* bi
 int bgs_grouped_conv3x3_nhwc_bf16ops(const float* x, const float* w, const float* bias, float* y,
                                      int N, int H, int W, int C, int groups, int stride, int relu,
                                      bgs_stream_t stream);
+
+/* bf16 STORAGE mode of BASELINE cfg[4] (csrc/conv_bf16s.hip): the reference trains its X101 configurations
+ * under Fp16OptimizerHook + wrap_fp16_model (mmdet/core/fp16/hooks.py:11-127, decorators.py:8-160): every
+ * trunk activation is a HALF tensor in memory, products are half x half with fp32 accumulation.  These entry
+ * points are the conv / linear, grouped-conv and max-pool call sites of `bgs_conv2d_nhwc_f32*`,
+ * `bgs_grouped_conv3x3_nhwc_f32` and `bgs_maxpool3x3s2_nhwc_f32` with bf16 NHWC activations:
+ *   bgs_conv2d_nhwc_bf16s: x bf16 [N,H,W,Cin]; w_hi = the first plane of bgs_conv_bfx_split_weights
+ *     (bf16(w), [2 ceil(K/32)][Cout][16]); bias fp32 or NULL; residual_mode 0 | 1 (same shape) | 2 (nearest-2x
+ *     upsampled, [N,Ho/2,Wo/2,Cout]); residual_bf16 / y_bf16: element type of residual / y (1 = bf16, 0 = fp32:
+ *     consumers outside the trunk, e.g. the FPN laterals fpn.py:118-127).  y = act(bf16(x) * bf16(w) + bias +
+ *     residual), fp32 accumulate, rounded once on store.  Cin % 8 == 0, Cout % 8 == 0, 16-byte aligned pointers.
+ *   bgs_grouped_conv3x3_nhwc_bf16s: x, y bf16; w [C,3,3,C/groups] fp32 (rounded to bf16 in registers).
+ *   bgs_maxpool3x3s2_nhwc_f32_to_bf16: the fp32 stem output pooled into the bf16 trunk. */
+int bgs_conv2d_nhwc_bf16s(const void* x, const void* w_hi, const float* bias, const void* residual,
+                          int residual_mode, int residual_bf16, void* y, int y_bf16, int N, int H, int W,
+                          int Cin, int Cout, int R, int S, int stride, int pad, int relu,
+                          bgs_stream_t stream);
+int bgs_grouped_conv3x3_nhwc_bf16s(const void* x, const float* w, const float* bias, void* y, int N, int H,
+                                   int W, int C, int groups, int stride, int relu, bgs_stream_t stream);
+int bgs_maxpool3x3s2_nhwc_f32_to_bf16(const float* x, void* y, int N, int H, int W, int C,
+                                      bgs_stream_t stream);
 
 /* Backward of bgs_grouped_conv3x3_nhwc_f32 (`selectp = 0` on the ResNeXt configs; the reference
  * gets it from cuDNN through autograd of nn.Conv2d(groups=...), resnext.py:47-57).

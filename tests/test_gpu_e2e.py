@@ -592,7 +592,7 @@ def test_fullsize_iteration_with_the_shipped_sampler_sizes_and_the_references_re
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize('math', ['bf16x6', 'bf16'])
+@pytest.mark.parametrize('math', ['bf16x6', 'bf16', 'bf16-fp32storage'])
 def test_cascade_x101_fullsize_iteration_vs_executed_reference(math):
     """BASELINE cfg[4] AT ITS OWN TRUNK AND SIZE: ``gs_cascade_rcnn_x101_64x4d`` (ResNeXt-101-64x4d,
     three GroupSoftmax stages, class-agnostic regression, stage weights 1 / 0.5 / 0.25) on
@@ -603,13 +603,18 @@ def test_cascade_x101_fullsize_iteration_vs_executed_reference(math):
     to bf16, fp32 accumulate — the reference's fp16 autocast contract): the documented budget of
     3e-2 of the total per term, 2e-2 on the total.  The launch census ASSERTS that the kernels the
     X101 bench numbers come from ran inside this iteration: the LDS-resident grouped 3x3 conv on
-    the large maps and, in the bf16 mode, the 8-wave 128x128 operand ring."""
+    the large maps and, in the bf16 mode, the bf16-STORAGE kernels of the frozen trunk
+    (csrc/conv_bf16s.hip: bf16 activations in HBM; ``bf16-fp32storage`` = the same arithmetic on fp32
+    tensors, the 8-wave 128x128 operand ring)."""
     from balancedgroupsoftmax_amd import functional as BF
     from balancedgroupsoftmax_amd import train
     from tests.golden import make_golden_cascade_x101 as T
     z = np.load(os.path.join(os.path.dirname(T.__file__), 'e2e_cascade_x101_fullsize_golden.npz'))
     model = None
+    storage = math == 'bf16'
+    label, math = math, math.split('-')[0]
     prev = BF.set_conv_math(math)
+    prev_storage = BF.set_bf16_storage(storage)
     try:
         tmp = tempfile.mkdtemp(prefix='bgs_x101_')
         model_cfg, train_cfg = T.configs(tmp)
@@ -646,10 +651,16 @@ def test_cascade_x101_fullsize_iteration_vs_executed_reference(math):
                        gt_labels=[torch.from_numpy(l).to(DEV) for l in labels],
                        samplers=dict(proposals=proposals_hook))
         census = BF.launch_census()
-        assert census['grouped_lds'] >= 30, census       # 30 of the 33 grouped convs of an X101 forward
         assert census['halo_bfx4'] >= 5, census
-        if math == 'bf16':
-            assert census['bf16_ring8'] >= 40, census
+        if math == 'bf16' and storage:
+            # the frozen trunk ran on bf16 tensors: 33 grouped convs, 66 + 4 1x1 convs, 4 FPN laterals
+            assert census['grouped_bf16s'] == 33 and census['bf16s'] >= 74, census
+            assert census['grouped_lds'] == 0 and census['bf16_ring8'] == 0, census
+        else:
+            assert census['grouped_lds'] >= 30, census   # 30 of the 33 grouped convs of an X101 forward
+            assert census['bf16s'] == 0 and census['grouped_bf16s'] == 0, census
+            if math == 'bf16':
+                assert census['bf16_ring8'] >= 40, census
         total_exp = float(z['loss/total'][0])
         bad, worst = [], 0.0
         for k, v in losses.items():
@@ -667,7 +678,7 @@ def test_cascade_x101_fullsize_iteration_vs_executed_reference(math):
                 bad.append((k, got.tolist(), exp.tolist()))
         loss, _ = train.parse_losses(losses)
         print('%s cascade X101 @800x1344: total %.5f vs executed reference %.5f, worst term diff %.2e'
-              % (math, float(loss.detach()), total_exp, worst))
+              % (label, float(loss.detach()), total_exp, worst))
         assert not bad, bad
         assert abs(float(loss.detach()) - total_exp) < (2e-4 if math == 'bf16x6' else 2e-2) * total_exp
         if math == 'bf16x6':
@@ -685,5 +696,6 @@ def test_cascade_x101_fullsize_iteration_vs_executed_reference(math):
             assert not gbad, gbad
     finally:
         BF.set_conv_math(prev)
+        BF.set_bf16_storage(prev_storage)
         del model
         torch.cuda.empty_cache()

@@ -8,9 +8,9 @@ import csv
 import sys
 
 
-CATS = [('conv: halo 3x3', ('conv3x3_halo',)), ('conv: implicit GEMM', ('conv_igemm',)),
+CATS = [('conv: halo 3x3', ('conv3x3_halo',)), ('conv: implicit GEMM', ('conv_igemm', 'conv_bf16s', 'conv1x1_bres')),
         ('conv: split-K epilogue', ('conv_splitk',)), ('conv: weight split / wgrad / grouped / pool',
-                                                       ('bfx_split', 'conv_wgrad', 'grouped_conv', 'maxpool')),
+                                                       ('bfx_split', 'conv_wgrad', 'grouped_conv', 'maxpool', 'fold_', 'wgrad_reduce')),
         ('torch glue (elementwise / copy / cat / reduce / index)', ('at::native', 'rocclr', 'at::cuda', 'cub::', 'rocprim', 'hipcub')),
         ('GroupSoftmax + box loss', ('gs_', 'bbox_sl1', 'reduce_partials')),
         ('targets / sampling / RPN loss', ('iou_', 'rpn_loss', 'sample_', 'rcnn_targets', 'random_keys', 'decode_proposals')),
