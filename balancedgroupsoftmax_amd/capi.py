@@ -50,6 +50,7 @@ SIGNATURES = {
                                         ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, c_f32p,
                                         c_f32p, c_ptr, c_f32p, c_ptr, c_ptr]),
     'bgs_gs_head_debug_timestamps': (None, [c_ptr]),
+    'bgs_gs_head_tuning': (None, [ctypes.c_int]),
     'bgs_gs_class_bin_mask': (ctypes.c_int, [c_i64p, ctypes.c_int, ctypes.c_int, c_ptr, c_ptr]),
     'bgs_gs_head_step_scale_grad': (ctypes.c_int, [c_f32p, c_f32p, c_ptr, c_f32p, c_f32p, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, c_ptr]),
@@ -121,6 +122,7 @@ SIGNATURES = {
     'bgs_grouped_conv3x3_nhwc_bf16s': (ctypes.c_int, [c_ptr, c_f32p, c_f32p, c_ptr] + [ctypes.c_int] * 7
                                        + [c_ptr]),
     'bgs_maxpool3x3s2_nhwc_f32_to_bf16': (ctypes.c_int, [c_f32p, c_ptr] + [ctypes.c_int] * 4 + [c_ptr]),
+    'bgs_conv_bf16s_tuning': (None, [ctypes.c_int]),
     'bgs_roi_align_nhwc_fwd': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -260,8 +260,12 @@ int g_bres_enabled = -1, g_bres_last = 0;
 int bgs_internal_conv1x1_bres(const bgs_conv::ConvArgs& p, const void* wsplit, int KC, int planes,
                               const unsigned* zero, hipStream_t st) {
   if (g_bres_enabled < 0) {
+    // OFF by default: in the detector step the one layer it won in isolation (fpn.lat0) runs 186 us
+    // against the ring's ~160 (its 137 MB input is not cache-resident there), step 6.807 vs 6.782 ms
+    // (profiles/r5l_*).  BGS_CONV1X1_BRES=1: fpn.lat0-shaped layers only; =2: every eligible layer.
     const char* e = getenv("BGS_CONV1X1_BRES");
-    g_bres_enabled = (e && atoi(e) == 0) ? 0 : 1;
+    g_bres_enabled = e ? atoi(e) : 0;
+    if (g_bres_enabled < 0 || g_bres_enabled > 2) g_bres_enabled = 0;
   }
   g_bres_last = 0;
   if (!g_bres_enabled || planes != 3) return -1;

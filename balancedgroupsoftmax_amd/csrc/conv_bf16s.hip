@@ -69,6 +69,106 @@ __device__ __forceinline__ float bf16_hi(unsigned u) {
   return __builtin_bit_cast(float, u & 0xffff0000u);
 }
 
+// Epilogue of a 128 x 128 tile held by eight waves (4 x 2, each 32 x 64 as two 32 x 32 accumulators):
+// LDS transpose in two halves of 64 rows (scratch 64 x 132 floats at the start of `lds`, which no wave reads
+// any more: callers have drained their DMAs / loads), then bias + residual + ReLU and 16-byte stores.
+template <bool YBF>
+__device__ __forceinline__ void bf16s_epilogue(const Bf16sArgs& p, const f32x16 (&acc)[2], unsigned char* lds,
+                                               int m0, int n0, int wm, int wn, int lane, int tid) {
+  // ---- epilogue through LDS, two halves of 64 rows: scratch 64 x 132 floats
+  float* scratch = reinterpret_cast<float*>(lds);
+  constexpr int LD = 132;
+  constexpr int CPT = YBF ? 8 : 4;                       // channels per thread
+  constexpr int TPR = 128 / CPT, RPP = 512 / TPR;        // threads per row, rows per pass
+  const int c0 = (tid % TPR) * CPT, r0 = tid / TPR;
+  const int j = n0 + c0;
+  float bias[CPT];
+#pragma unroll
+  for (int t = 0; t < CPT; ++t) bias[t] = 0.f;
+  if (p.bias && j < p.Cout) {
+#pragma unroll
+    for (int t = 0; t < CPT; t += 4) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + j + t);
+      bias[t] = bv[0]; bias[t + 1] = bv[1]; bias[t + 2] = bv[2]; bias[t + 3] = bv[3];
+    }
+  }
+  const int hw = p.Ho * p.Wo;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();                                     // ring (h = 0) / previous half (h = 1) no longer read
+    if ((wm >> 1) == h) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (wm & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          scratch[i * LD + wn * 64 + b * 32 + (lane & 31)] = acc[b][r];
+        }
+    }
+    __syncthreads();
+    if (j >= p.Cout) continue;
+#pragma unroll
+    for (int ps = 0; ps < 64 / RPP; ++ps) {
+      const int i = r0 + ps * RPP;
+      const int m = m0 + h * 64 + i;
+      if (m >= p.M) break;
+      float v[CPT];
+#pragma unroll
+      for (int t = 0; t < CPT; t += 4) {
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(scratch + i * LD + c0 + t);
+        v[t] = s4[0] + bias[t]; v[t + 1] = s4[1] + bias[t + 1];
+        v[t + 2] = s4[2] + bias[t + 2]; v[t + 3] = s4[3] + bias[t + 3];
+      }
+      if (p.res_mode) {
+        size_t rrow = (size_t)m * p.Cout;
+        if (p.res_mode == 2) {
+          const int n = m / hw;
+          const int rem = m - n * hw;
+          const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+          rrow = (((size_t)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout;
+        }
+        if (p.res_bf16) {
+          const __bf16* rp = reinterpret_cast<const __bf16*>(p.res) + rrow + j;
+          if constexpr (CPT == 8) {
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(rp);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              v[2 * t] += bf16_lo(rv[t]);
+              v[2 * t + 1] += bf16_hi(rv[t]);
+            }
+          } else {
+            const u32x2 rv = *reinterpret_cast<const u32x2*>(rp);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              v[2 * t] += bf16_lo(rv[t]);
+              v[2 * t + 1] += bf16_hi(rv[t]);
+            }
+          }
+        } else {
+          const float* rp = reinterpret_cast<const float*>(p.res) + rrow + j;
+#pragma unroll
+          for (int t = 0; t < CPT; t += 4) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(rp + t);
+            v[t] += rv[0]; v[t + 1] += rv[1]; v[t + 2] += rv[2]; v[t + 3] += rv[3];
+          }
+        }
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int t = 0; t < CPT; ++t) v[t] = fmaxf(v[t], 0.f);
+      }
+      if constexpr (YBF) {
+        __bf16* yp = reinterpret_cast<__bf16*>(p.y) + (size_t)m * p.Cout + j;
+        *reinterpret_cast<u32x4*>(yp) = u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]),
+                                              pack_bf16(v[CPT - 4], v[CPT - 3]), pack_bf16(v[CPT - 2], v[CPT - 1])};
+      } else {
+        float* yp = reinterpret_cast<float*>(p.y) + (size_t)m * p.Cout + j;
+        *reinterpret_cast<f32x4*>(yp) = f32x4{v[0], v[1], v[2], v[3]};
+      }
+    }
+  }
+}
+
 template <bool P1X1, bool YBF>
 __global__ __launch_bounds__(512, 2) void conv_bf16s_kernel(Bf16sArgs p) {
   const unsigned* __restrict__ zero_page = p.zero;
@@ -184,98 +284,154 @@ __global__ __launch_bounds__(512, 2) void conv_bf16s_kernel(Bf16sArgs p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the (zero-page) tail DMAs
 
-  // ---- epilogue through LDS, two halves of 64 rows: scratch 64 x 132 floats
-  float* scratch = reinterpret_cast<float*>(lds);
-  constexpr int LD = 132;
-  constexpr int CPT = YBF ? 8 : 4;                       // channels per thread
-  constexpr int TPR = 128 / CPT, RPP = 512 / TPR;        // threads per row, rows per pass
-  const int c0 = (tid % TPR) * CPT, r0 = tid / TPR;
-  const int j = n0 + c0;
-  float bias[CPT];
-#pragma unroll
-  for (int t = 0; t < CPT; ++t) bias[t] = 0.f;
-  if (p.bias && j < p.Cout) {
-#pragma unroll
-    for (int t = 0; t < CPT; t += 4) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + j + t);
-      bias[t] = bv[0]; bias[t + 1] = bv[1]; bias[t + 2] = bv[2]; bias[t + 3] = bv[3];
-    }
+  bf16s_epilogue<YBF>(p, acc, lds, m0, n0, wm, wn, lane, tid);
+}
+
+// The same tile with the operands staged THROUGH REGISTERS (global_load_dwordx4 -> VGPR -> ds_write_b128)
+// instead of by LDS-DMA.  bf16 operands need no conversion on the way, so the register path is a pure
+// copy: two 16-byte loads + two 16-byte LDS writes per thread and stage, placed exactly where the DMA
+// would put them (lane-linear 1 KB pieces, the swizzle in the source address).  Two LDS stage buffers;
+// the loads of stage kt + 2 are in flight while stage kt is multiplied (raw s_barrier: a plain
+// __syncthreads() would wait for them).  Why: the LDS-DMA path of a CU sustains about one 1 KB piece per
+// ~64 cycles (16 B/clk: profiles/r5i_bf16s_ab.txt — 0.75 us per 16 KB stage at two workgroups per CU),
+// a quarter of what the vector-memory return path delivers into registers.
+template <bool P1X1, bool YBF>
+__global__ __launch_bounds__(512, 2) void conv_bf16s_reg_kernel(Bf16sArgs p) {
+  const unsigned* __restrict__ zero_page = p.zero;
+  constexpr int NB = 2, A_BYTES = 128 * 64, B_BLOCK = 128 * 32, STAGE = A_BYTES + 2 * B_BLOCK;
+  constexpr int LDS_BYTES = NB * STAGE > 64 * 132 * 4 ? NB * STAGE : 64 * 132 * 4;   // epilogue scratch
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = bgs::uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int vtile = (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3));
+  if (vtile >= p.tiles_m * p.tiles_n) return;
+  const int m0 = (vtile / p.tiles_n) * 128, n0 = (vtile % p.tiles_n) * 128;
+  const int nk = p.KC >> 1;
+
+  const int arow = wave * 16 + (lane >> 2);
+  const int aq = (lane & 3) ^ ((arow >> 2) & 3);
+  int a_hi0, a_wi0;
+  const __bf16* a_base;
+  bool a_ok;
+  {
+    const int m = m0 + arow;
+    a_ok = m < p.M;
+    const int mm = a_ok ? m : 0;
+    const int hw = p.Ho * p.Wo;
+    const int n = mm / hw;
+    const int rem = mm - n * hw;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    a_hi0 = ho * p.stride - p.pad;
+    a_wi0 = wo * p.stride - p.pad;
+    a_base = p.x + (size_t)n * p.H * p.W * p.Cin;
   }
-  const int hw = p.Ho * p.Wo;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    __syncthreads();                                     // ring (h = 0) / previous half (h = 1) no longer read
-    if ((wm >> 1) == h) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = (wm & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          scratch[i * LD + wn * 64 + b * 32 + (lane & 31)] = acc[b][r];
-        }
-    }
-    __syncthreads();
-    if (j >= p.Cout) continue;
-#pragma unroll
-    for (int ps = 0; ps < 64 / RPP; ++ps) {
-      const int i = r0 + ps * RPP;
-      const int m = m0 + h * 64 + i;
-      if (m >= p.M) break;
-      float v[CPT];
-#pragma unroll
-      for (int t = 0; t < CPT; t += 4) {
-        const f32x4 s4 = *reinterpret_cast<const f32x4*>(scratch + i * LD + c0 + t);
-        v[t] = s4[0] + bias[t]; v[t + 1] = s4[1] + bias[t + 1];
-        v[t + 2] = s4[2] + bias[t + 2]; v[t + 3] = s4[3] + bias[t + 3];
-      }
-      if (p.res_mode) {
-        size_t rrow = (size_t)m * p.Cout;
-        if (p.res_mode == 2) {
-          const int n = m / hw;
-          const int rem = m - n * hw;
-          const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-          rrow = (((size_t)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout;
-        }
-        if (p.res_bf16) {
-          const __bf16* rp = reinterpret_cast<const __bf16*>(p.res) + rrow + j;
-          if constexpr (CPT == 8) {
-            const u32x4 rv = *reinterpret_cast<const u32x4*>(rp);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              v[2 * t] += bf16_lo(rv[t]);
-              v[2 * t + 1] += bf16_hi(rv[t]);
-            }
-          } else {
-            const u32x2 rv = *reinterpret_cast<const u32x2*>(rp);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              v[2 * t] += bf16_lo(rv[t]);
-              v[2 * t + 1] += bf16_hi(rv[t]);
-            }
-          }
-        } else {
-          const float* rp = reinterpret_cast<const float*>(p.res) + rrow + j;
-#pragma unroll
-          for (int t = 0; t < CPT; t += 4) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(rp + t);
-            v[t] += rv[0]; v[t + 1] += rv[1]; v[t + 2] += rv[2]; v[t + 3] += rv[3];
-          }
-        }
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int t = 0; t < CPT; ++t) v[t] = fmaxf(v[t], 0.f);
-      }
-      if constexpr (YBF) {
-        __bf16* yp = reinterpret_cast<__bf16*>(p.y) + (size_t)m * p.Cout + j;
-        *reinterpret_cast<u32x4*>(yp) = u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]),
-                                              pack_bf16(v[CPT - 4], v[CPT - 3]), pack_bf16(v[CPT - 2], v[CPT - 1])};
-      } else {
-        float* yp = reinterpret_cast<float*>(p.y) + (size_t)m * p.Cout + j;
-        *reinterpret_cast<f32x4*>(yp) = f32x4{v[0], v[1], v[2], v[3]};
-      }
-    }
+  const int bkb = wave >> 2;
+  const int brow_d = (wave & 3) * 32 + (lane >> 1);
+  const int bhalf_d = (lane & 1) ^ ((brow_d >> 3) & 1);
+  const bool b_ok = n0 + brow_d < p.Cout;
+  const __bf16* b_ptr = p.ws + ((size_t)bkb * p.Cout + (b_ok ? n0 + brow_d : 0)) * 16 + bhalf_d * 8;
+  int kg = aq * 8;
+  int kc, kr, ks;
+  {
+    const int rs = kg / p.Cin;
+    kc = kg - rs * p.Cin;
+    kr = rs / p.S;
+    ks = rs - kr * p.S;
   }
+  const __bf16* a_ptr = nullptr;
+  if (P1X1) a_ptr = a_base + ((size_t)a_hi0 * p.W + a_wi0) * p.Cin + kg;
+  const size_t b_step = (size_t)p.Cout * 32;
+  const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page);
+  int kt_issue = 0;
+  u32x4 ra, rb;
+  auto gload = [&]() {
+    const bool live = kt_issue < nk;
+    const __bf16* asrc;
+    if (P1X1) {
+      asrc = (live && a_ok && kg < p.K) ? a_ptr : zp;
+      a_ptr += 32;
+      kg += 32;
+    } else {
+      const int hi = a_hi0 + kr, wi = a_wi0 + ks;
+      const bool ok = live && a_ok && kg < p.K && hi >= 0 && wi >= 0 && hi < p.H && wi < p.W;
+      asrc = ok ? a_base + ((size_t)hi * p.W + wi) * p.Cin + kc : zp;
+      kg += 32;
+      kc += 32;
+      while (kc >= p.Cin) {
+        kc -= p.Cin;
+        if (++ks == p.S) {
+          ks = 0;
+          ++kr;
+        }
+      }
+    }
+    // issued HERE (volatile asm keeps program order; hipcc otherwise sinks the loads below the MFMAs and
+    // waits for them at the top of the next iteration); the consumer waits with an explicit vmcnt
+    const __bf16* bsrc = (live && b_ok) ? b_ptr : zp;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ra) : "v"(asrc) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rb) : "v"(bsrc) : "memory");
+    b_ptr += b_step;
+    ++kt_issue;
+  };
+  const int w_off = wave * 1024 + lane * 16;
+  auto lwrite = [&](int buf) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra), "+v"(rb) : : "memory");
+    *reinterpret_cast<u32x4*>(lds + buf * STAGE + w_off) = ra;
+    *reinterpret_cast<u32x4*>(lds + buf * STAGE + A_BYTES + w_off) = rb;
+  };
+
+  const int frow = lane & 31, fk = lane >> 5;
+  const int ar = wm * 32 + frow;
+  const int ac = (ar >> 2) & 3;
+  const int a_off0 = ar * 64 + ((fk ^ ac) << 4);
+  const int a_off1 = ar * 64 + (((2 + fk) ^ ac) << 4);
+  const int br = wn * 64 + frow;
+  const int b_off = A_BYTES + br * 32 + ((fk ^ ((br >> 3) & 1)) << 4);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  gload();                 // stage 0
+  lwrite(0);
+  gload();                 // stage 1 stays in registers
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  for (int kt = 0; kt < nk; ++kt) {
+    lwrite((kt + 1) & 1);  // stage kt + 1 (its buffer was last read in iteration kt - 1)
+    gload();               // stage kt + 2: in flight under this iteration's MFMAs
+    const unsigned char* st = lds + (kt & 1) * STAGE;
+    const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(st + a_off0);
+    const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(st + a_off1);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(st + b_off + b * 1024);
+      const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(st + b_off + B_BLOCK + b * 1024);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[b], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes and reads are done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bf16s_epilogue<YBF>(p, acc, lds, m0, n0, wm, wn, lane, tid);
+}
+
+int g_bf16s_variant = -1;    // 0 = LDS-DMA ring (conv_bf16s_kernel), 1 = register-staged (conv_bf16s_reg_kernel)
+int bf16s_variant() {
+  if (g_bf16s_variant < 0) {
+    const char* e = getenv("BGS_BF16S_VARIANT");
+    g_bf16s_variant = e ? atoi(e) : 0;
+    if (g_bf16s_variant < 0 || g_bf16s_variant > 1) g_bf16s_variant = 0;
+  }
+  return g_bf16s_variant;
 }
 
 const unsigned* bf16s_zero_page() {
@@ -338,15 +494,24 @@ extern "C" int bgs_conv2d_nhwc_bf16s(const void* x, const void* w_hi, const floa
   const bool p1x1 = R == 1 && S == 1 && pad == 0;
   ++g_bf16s_launches;
   bgs_internal_census_bump(BGS_CENSUS_BF16S);
-  if (y_bf16) {
-    if (p1x1) hipLaunchKernelGGL((conv_bf16s_kernel<true, true>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((conv_bf16s_kernel<false, true>), grid, dim3(512), 0, st, p);
-  } else {
-    if (p1x1) hipLaunchKernelGGL((conv_bf16s_kernel<true, false>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((conv_bf16s_kernel<false, false>), grid, dim3(512), 0, st, p);
-  }
+#define BGS_BF16S_LAUNCH(KERNEL_)                                                                  \
+  do {                                                                                            \
+    if (y_bf16) {                                                                                 \
+      if (p1x1) hipLaunchKernelGGL((KERNEL_<true, true>), grid, dim3(512), 0, st, p);             \
+      else hipLaunchKernelGGL((KERNEL_<false, true>), grid, dim3(512), 0, st, p);                 \
+    } else {                                                                                      \
+      if (p1x1) hipLaunchKernelGGL((KERNEL_<true, false>), grid, dim3(512), 0, st, p);            \
+      else hipLaunchKernelGGL((KERNEL_<false, false>), grid, dim3(512), 0, st, p);                \
+    }                                                                                             \
+  } while (0)
+  if (bf16s_variant() == 1) BGS_BF16S_LAUNCH(conv_bf16s_reg_kernel);
+  else BGS_BF16S_LAUNCH(conv_bf16s_kernel);
+#undef BGS_BF16S_LAUNCH
   BGS_RETURN_LAUNCH_STATUS();
 }
+
+// tuning / test hook: 0 = LDS-DMA operand ring (default), 1 = register-staged operands.  Process-wide.
+extern "C" void bgs_conv_bf16s_tuning(int variant) { g_bf16s_variant = (variant == 1) ? 1 : 0; }
 
 // ---------------------------------------------------------------------------------------------
 // Grouped 3x3 conv (conv2 of the ResNeXt bottleneck, resnext.py:47-57 + BN eval + ReLU) with bf16

@@ -722,6 +722,20 @@ namespace {
 // shared launcher of the fused head kernel; returns the grid in *grid_out
 unsigned long long* g_gs_tstamps = nullptr;
 
+// Rows per workgroup of the fused head kernel.  Every workgroup recounts the N labels (flags, per-bin
+// counts) before its first row; with R rows per workgroup that prologue is paid N / R times instead of
+// N times, against fewer workgroups to hide latency with.  0 = default; BGS_GS_HEAD_ROWS / the tuning
+// entry override (sweep: profiles/r5k_gs_head_rows_sweep.txt).
+int g_head_rows = -1;
+int head_rows_per_wg() {
+  if (g_head_rows < 0) {
+    const char* e = getenv("BGS_GS_HEAD_ROWS");
+    g_head_rows = e ? atoi(e) : 0;
+    if (g_head_rows < 0 || g_head_rows > 64) g_head_rows = 0;
+  }
+  return g_head_rows;
+}
+
 int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* host_bin_loss_weight,
                    hipStream_t st, int* grid_out) {
   a.tstamps = g_gs_tstamps;
@@ -737,7 +751,9 @@ int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* h
   const size_t lds = gs_head_lds_bytes(a.N, a.C, a.wpad);
   if (lds > 64 * 1024) return BGS_ERR_UNSUPPORTED;      // the default LDS window (callers fall back
                                                          // to bgs_gs_prepare + bgs_gs_loss_fwd_bwd)
-  const int grid = loss_grid(a.N);
+  int grid = loss_grid(a.N);
+  const int rows_per_wg = head_rows_per_wg();
+  if (rows_per_wg > 1) grid = (a.N + rows_per_wg - 1) / rows_per_wg;
   *grid_out = grid;
   bgs_internal_census_bump(BGS_CENSUS_GS_HEAD_FUSED);
   const uintptr_t al = (uintptr_t)a.logits | (uintptr_t)(a.dlogits ? a.dlogits : a.logits);
@@ -856,6 +872,10 @@ __global__ __launch_bounds__(256) void gs_class_bits_kernel(const int64_t* __res
 // workgroup into buf[grid][8] (kernel start, loads landed, barrier 1, flags done, barrier 2, bins done,
 // barrier 3, end); NULL switches it off (the default).  tools/gs_phase_times.py.
 extern "C" void bgs_gs_head_debug_timestamps(unsigned long long* buf) { g_gs_tstamps = buf; }
+
+extern "C" void bgs_gs_head_tuning(int rows_per_workgroup) {
+  g_head_rows = (rows_per_workgroup >= 0 && rows_per_workgroup <= 64) ? rows_per_workgroup : 0;
+}
 
 extern "C" int bgs_gs_class_bin_mask(const int64_t* label2binlabel, int C, int B, uint16_t* out,
                                      bgs_stream_t stream) {

@@ -154,6 +154,8 @@ int bgs_gs_class_bin_mask(const int64_t* label2binlabel, int C, int B, uint16_t*
  * launch record 8 shader-clock marks per workgroup (start, loads landed, barrier 1, flags done,
  * barrier 2, bins done, barrier 3, end); NULL (default) switches it off.  tools/gs_phase_times.py. */
 void bgs_gs_head_debug_timestamps(unsigned long long* buf);
+/* Tuning / test hook: rows per workgroup of the fused head kernel (0 = default; process-wide). */
+void bgs_gs_head_tuning(int rows_per_workgroup);
 /* Backward of bgs_gs_head_step: grad_terms [B+1] (device; upstream gradient of {bins, box}, NULL = 0)
  * and grad_total [1] (of total_out, NULL = 0): dlogits[:, bin b] *= grad_terms[b] + grad_total,
  * dbbox_pred *= grad_terms[B] + grad_total, in place, one launch, early-out on the device when
@@ -418,6 +420,9 @@ int bgs_grouped_conv3x3_nhwc_bf16s(const void* x, const float* w, const float* b
                                    int W, int C, int groups, int stride, int relu, bgs_stream_t stream);
 int bgs_maxpool3x3s2_nhwc_f32_to_bf16(const float* x, void* y, int N, int H, int W, int C,
                                       bgs_stream_t stream);
+/* Tuning / test hook of bgs_conv2d_nhwc_bf16s: 0 = operands by LDS-DMA (default), 1 = operands staged
+ * through registers (bit-identical results).  Process-wide; not for concurrent use. */
+void bgs_conv_bf16s_tuning(int variant);
 
 /* Backward of bgs_grouped_conv3x3_nhwc_f32 (`selectp = 0` on the ResNeXt configs; the reference
  * gets it from cuDNN through autograd of nn.Conv2d(groups=...), resnext.py:47-57).

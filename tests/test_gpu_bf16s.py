@@ -90,6 +90,37 @@ def test_conv2d_bf16_storage_vs_fp64_of_the_same_bf16_operands(case):
     check_bf16(y, ref, name)
 
 
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_bf16_storage_register_staged_variant_is_bit_identical(case):
+    """``bgs_conv_bf16s_tuning(1)``: the operands reach LDS through registers instead of by LDS-DMA —
+    the same tile, the same summation order, the same bits."""
+    from balancedgroupsoftmax_amd import capi
+    name, N, H, W, Cin, Cout, R, stride, pad, use_bias, relu, res, out = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) + 1)
+    x = torch.randn(N, H, W, Cin, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(Cout, R, R, Cin, generator=g) * (2.0 / (R * R * Cin)) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV) if use_bias else None
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    r, rmode = None, 0
+    if res in ('bf16', 'f32'):
+        r, rmode = torch.randn(N, Ho, Wo, Cout, generator=g).to(DEV), 1
+        if res == 'bf16':
+            r = r.to(torch.bfloat16)
+    elif res == 'up_f32':
+        r, rmode = torch.randn(N, Ho // 2, Wo // 2, Cout, generator=g).to(DEV), 2
+    od = torch.bfloat16 if out == 'bf16' else torch.float32
+    ys = []
+    lib = capi.load()
+    try:
+        for variant in (0, 1):
+            lib.bgs_conv_bf16s_tuning(variant)
+            ys.append(BF.conv2d_nhwc(x, w, b, stride=stride, pad=pad, relu=relu, residual=r,
+                                     residual_mode=rmode, out_dtype=od))
+    finally:
+        lib.bgs_conv_bf16s_tuning(0)
+    assert torch.equal(ys[0], ys[1])
+
+
 def test_conv2d_bf16_storage_equals_the_bf16_operand_mode_on_fp32_tensors():
     """The storage kernel computes what the operand-rounding mode computes: the same bf16 x bf16
     products with fp32 accumulation — on inputs that are already bf16 values the fp32 results agree

@@ -837,7 +837,7 @@ def test_conv1x1_filter_resident_kernel_is_bit_identical_to_the_operand_ring(sha
             outs.append(y.cpu())
         assert torch.equal(outs[0], outs[1])
     finally:
-        lib.bgs_conv1x1_bres_enable(1)
+        lib.bgs_conv1x1_bres_enable(0)
         BF.set_conv_math(prev)
     ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), stride=stride)
     if rmode == 1:
@@ -871,7 +871,7 @@ def test_conv1x1_filter_resident_kernel_as_data_gradient_with_mask():
             outs.append(dx.cpu())
         assert torch.equal(outs[0], outs[1])
     finally:
-        lib.bgs_conv1x1_bres_enable(1)
+        lib.bgs_conv1x1_bres_enable(0)
         BF.set_conv_math(prev)
 
 

@@ -43,8 +43,10 @@ def main():
         ('l4.c3 2048->2048 +res', 25, 42, 2048, 2048, True),
         ('fpn.lat0 256->256 f32out', 200, 336, 256, 256, False),
     ]
-    print('| layer | fp32 tensors us | bf16 tensors us | speed-up | bf16s TFLOP/s |')
-    print('|---|---|---|---|---|')
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    print('| layer | fp32 tensors us | bf16 tensors us | speed-up | bf16s TFLOP/s | bf16 tensors, register-staged us |')
+    print('|---|---|---|---|---|---|')
     tot = [0.0, 0.0]
     for name, H, W, Cin, Cout, res in convs:
         x = torch.randn(N, H, W, Cin, device=DEV)
@@ -59,10 +61,14 @@ def main():
         t0 = timeit(lambda: BF.conv2d_nhwc(x, w, b, relu=True, residual=r, out=o32))
         t1 = timeit(lambda: BF.conv2d_nhwc(xb, w, b, relu=True, residual=rb, out=ob,
                                            out_dtype=ob.dtype))
+        lib.bgs_conv_bf16s_tuning(1)
+        t2 = timeit(lambda: BF.conv2d_nhwc(xb, w, b, relu=True, residual=rb, out=ob,
+                                           out_dtype=ob.dtype))
+        lib.bgs_conv_bf16s_tuning(0)
         fl = 2.0 * N * H * W * Cin * Cout
         tot[0] += t0
         tot[1] += t1
-        print('| %s | %.1f | %.1f | %.2f | %.0f |' % (name, t0, t1, t0 / t1, fl / t1 * 1e-6))
+        print('| %s | %.1f | %.1f | %.2f | %.0f | %.1f |' % (name, t0, t1, t0 / t1, fl / t1 * 1e-6, t2))
     grouped = [('l1 C256 cg4', 200, 336, 256), ('l2 C512 cg8', 100, 168, 512),
                ('l3 C1024 cg16', 50, 84, 1024), ('l4 C2048 cg32', 25, 42, 2048)]
     for name, H, W, C in grouped:
