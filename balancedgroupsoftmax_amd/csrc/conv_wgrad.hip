@@ -243,6 +243,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_f32_kernel(WgradArgs p) {
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __attribute__((aligned(16))) float g_wgrad_zero[4];
 
@@ -263,13 +264,20 @@ __device__ __forceinline__ void wg_split3(const f32x4 v, u32x2& hi, u32x2& mid, 
 }
 
 // NS = 3: fp32-faithful; NS = 1: operands rounded to bf16 (the bf16 mode of cfg[4])
-template <int NS>
-__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_bfx_kernel(WgradArgs p) {
+// ABL (only instantiated != 0 under -DBGS_ABLATE, tools/wgrad_ablate.py): timing-only variants that drop one
+// component of the loop — 1: MFMAs, 2: global loads after the first stage, 4: the operand split, 8: LDS stores,
+// 16: fragment ds_reads.
+// NBUF = 2: two LDS stage buffers (74 KB: two workgroups per CU), one barrier per stage.  NBUF = 1: one buffer
+// (37 KB: THREE workgroups per CU at 160 VGPRs), two barriers per stage — the component ablation (profiles/r5m_wgrad_ablate.txt)
+// shows the operand loads (0.70 ms alone on fpn.out0) and the MFMAs (0.64 ms alone) NOT overlapping (1.50 ms
+// together): with two workgroups per CU the memory path idles whenever both are multiplying.
+template <int NS, int ABL = 0, int NBUF = 2>
+__global__ __launch_bounds__(kThreads, NBUF == 1 ? 3 : 2) void conv_wgrad_bfx_kernel(WgradArgs p) {
   constexpr int BT = 128;                       // tile: 128 co x 128 k
   constexpr int LDR = 48;                       // LDS row: 16 m as bf16 (32 B) + 16 B pad
   constexpr int PLANE = BT * LDR;               // one operand plane
   constexpr int BUF = 2 * NS * PLANE;           // A planes, then B planes
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * BUF];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -337,10 +345,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_bfx_kernel(WgradArgs p
   auto store_stage = [&](int buf) {
     unsigned char* base = lds + buf * BUF + dst;
     if (want_db && !is_b) bsum += (v[0] + v[1]) + (v[2] + v[3]);
+    if (ABL & 8) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       u32x2 h, m, l;
-      wg_split3(f32x4{v[0][j], v[1][j], v[2][j], v[3][j]}, h, m, l);
+      if (ABL & 4) {
+        h = u32x2{__float_as_uint(v[0][j]), __float_as_uint(v[1][j])};
+        m = u32x2{__float_as_uint(v[2][j]), __float_as_uint(v[3][j])};
+        l = h;
+      } else {
+        wg_split3(f32x4{v[0][j], v[1][j], v[2][j], v[3][j]}, h, m, l);
+      }
       *reinterpret_cast<u32x2*>(base + j * LDR) = h;
       if (NS >= 2) *reinterpret_cast<u32x2*>(base + j * LDR + PLANE) = m;
       if (NS >= 3) *reinterpret_cast<u32x2*>(base + j * LDR + 2 * PLANE) = l;
@@ -365,19 +380,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_bfx_kernel(WgradArgs p
   }
   __syncthreads();
   for (int st = 0; st < nst; ++st) {
-    const int buf = st & 1;
+    const int buf = NBUF == 2 ? (st & 1) : 0;
     const bool more = st + 1 < nst;
-    if (more) load_stage();                    // global loads of stage st + 1 in flight under the MFMAs
+    if (more && !((ABL & 2) && st > 0)) load_stage();   // global loads of stage st + 1 in flight under the MFMAs
     const unsigned char* base = lds + buf * BUF;
     bf16x8 fa[NS][2], fb[NS][2];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
-        fa[s][a] = *reinterpret_cast<const bf16x8*>(base + a_frag + s * PLANE + a * 32 * LDR);
+      for (int a = 0; a < 2; ++a) {
+        if (ABL & 16) fa[s][a] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)st, (unsigned)s, (unsigned)a, 0u});
+        else fa[s][a] = *reinterpret_cast<const bf16x8*>(base + a_frag + s * PLANE + a * 32 * LDR);
+      }
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
-        fb[s][b] = *reinterpret_cast<const bf16x8*>(base + b_frag + s * PLANE + b * 32 * LDR);
+      for (int b = 0; b < 2; ++b) {
+        if (ABL & 16) fb[s][b] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)st, (unsigned)s, (unsigned)b, 1u});
+        else fb[s][b] = *reinterpret_cast<const bf16x8*>(base + b_frag + s * PLANE + b * 32 * LDR);
+      }
     }
     // products (i, j) with i + j <= NS - 1, smallest terms first
 #pragma unroll
@@ -388,8 +407,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_bfx_kernel(WgradArgs p
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int b = 0; b < 2; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[t - i][b], acc[a][b], 0, 0, 0);
-    if (more) store_stage(buf ^ 1);
+          {
+            if (ABL & 1) acc[a][b][(i + t) & 15] += __builtin_bit_cast(u32x4, fa[i][a])[0] * 1e-30f +
+                                                    __builtin_bit_cast(u32x4, fb[t - i][b])[1] * 1e-30f;
+            else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[t - i][b], acc[a][b], 0, 0, 0);
+          }
+    if (NBUF == 1) __syncthreads();             // every wave has read the (only) buffer
+    if (more) store_stage(NBUF == 2 ? (buf ^ 1) : 0);
     __syncthreads();
   }
 
@@ -550,6 +574,14 @@ extern "C" int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float*
 // with Cout < 96 or K < 96 (the 128 x 128 tile would be mostly padding: stem, RPN heads) are routed
 // to the fp32-MFMA kernel, which is exact.
 int g_wgrad_bfx_enabled = -1;
+int g_wgrad_nbuf = -1;     // BGS_WGRAD_NBUF = 1 | 2 (LDS stage buffers of conv_wgrad_bfx_kernel<3>)
+static int wgrad_nbuf() {
+  if (g_wgrad_nbuf < 0) {
+    const char* e = getenv("BGS_WGRAD_NBUF");
+    g_wgrad_nbuf = (e && atoi(e) == 2) ? 2 : 1;      // default 1: 8.91 -> 8.16 ms over a selectp=0 backward
+  }
+  return g_wgrad_nbuf;
+}
 
 extern "C" size_t bgs_conv2d_wgrad_bfx_workspace_bytes(int N, int H, int W, int Cin, int Cout, int R,
                                                        int S, int stride, int pad) {
@@ -573,7 +605,11 @@ extern "C" int bgs_conv2d_wgrad_nhwc_f32_bfx(const float* x, const float* dy, fl
     const char* e = getenv("BGS_WGRAD_BFX");
     g_wgrad_bfx_enabled = (e && atoi(e) == 0) ? 0 : 1;
   }
-  if (!g_wgrad_bfx_enabled || Cout < 96 || R * S * Cin < 96)
+  // (M <= 1536 rows — the FC heads at 1024 RoIs: the reduction is too short for the 128 x 128 tile's
+  //  staging to amortise; fp32 kernel 0.755 vs 0.96 ms over fc1 / fc2 / fc_cls / fc_reg, profiles/r5n_*)
+  const long long m_rows = (long long)N * ((H + 2 * pad - R) / (stride > 0 ? stride : 1) + 1) *
+                           ((W + 2 * pad - S) / (stride > 0 ? stride : 1) + 1);
+  if (!g_wgrad_bfx_enabled || Cout < 96 || R * S * Cin < 96 || (m_rows <= 1536 && g_wgrad_bfx_enabled != 2))
     return bgs_conv2d_wgrad_nhwc_f32(x, dy, dw, db, N, H, W, Cin, Cout, R, S, stride, pad, accumulate,
                                      workspace, stream);
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
@@ -604,7 +640,18 @@ extern "C" int bgs_conv2d_wgrad_nhwc_f32_bfx(const float* x, const float* dy, fl
   p.db_part = db ? ws + (size_t)pl.splits * n : nullptr;
   dim3 grid((unsigned)((Cout + 127) / 128), (unsigned)((p.K + 127) / 128), (unsigned)pl.splits);
   bgs_internal_census_bump(BGS_CENSUS_WGRAD_BFX);
-  if (planes == 3) hipLaunchKernelGGL((conv_wgrad_bfx_kernel<3>), grid, dim3(kThreads), 0, st, p);
+#ifdef BGS_ABLATE
+  int abl = 0;
+  if (const char* e = getenv("BGS_WGRAD_ABLATE")) abl = atoi(e);     // read at every launch (tools/wgrad_ablate.py)
+#define WG_ABL(A_) case A_: hipLaunchKernelGGL((conv_wgrad_bfx_kernel<3, A_>), grid, dim3(kThreads), 0, st, p); break;
+  if (planes == 3 && abl) {
+    switch (abl) { WG_ABL(1) WG_ABL(2) WG_ABL(4) WG_ABL(8) WG_ABL(16) WG_ABL(17) WG_ABL(12) WG_ABL(14) WG_ABL(31) WG_ABL(29)
+      default: return BGS_ERR_UNSUPPORTED; }
+  } else
+#undef WG_ABL
+#endif
+  if (planes == 3 && wgrad_nbuf() == 1) hipLaunchKernelGGL((conv_wgrad_bfx_kernel<3, 0, 1>), grid, dim3(kThreads), 0, st, p);
+  else if (planes == 3) hipLaunchKernelGGL((conv_wgrad_bfx_kernel<3>), grid, dim3(kThreads), 0, st, p);
   else hipLaunchKernelGGL((conv_wgrad_bfx_kernel<1>), grid, dim3(kThreads), 0, st, p);
   if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
   if (!direct) {
@@ -623,4 +670,5 @@ extern "C" int bgs_conv2d_wgrad_nhwc_f32_bfx(const float* x, const float* dy, fl
   BGS_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" void bgs_conv2d_wgrad_bfx_enable(int on) { g_wgrad_bfx_enabled = on ? 1 : 0; }
+// 0 = fp32-MFMA kernel everywhere, 1 = default routing, 2 = the bf16x6 kernel also on short reductions (tests)
+extern "C" void bgs_conv2d_wgrad_bfx_enable(int on) { g_wgrad_bfx_enabled = on < 0 ? 0 : (on > 2 ? 2 : on); }
