@@ -722,6 +722,41 @@ __global__ __launch_bounds__(256) void bfx_split_weights_kernel(const float* __r
   }
 }
 
+// The same planes for the DATA-GRADIENT filter, straight from the forward filter: the data gradient is a
+// convolution with wt[ci][r'][s'][co] = w[co][R-1-r'][S-1-s'][ci] (rows = Cin, K = R*S*Cout).  As tensor ops
+// that is a flip + permute + contiguous (two launches) in front of the split, per trained conv and step.
+__global__ __launch_bounds__(256) void bfx_split_weights_dgrad_kernel(const float* __restrict__ w,
+                                                                      __bf16* __restrict__ out, int Cout,
+                                                                      int R, int S, int Cin, int KC) {
+  const int rows = Cin, K = R * S * Cout, RS = R * S;
+  const size_t total = (size_t)KC * rows * 8;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * 256) {
+    const int kk = (int)(e & 7) * 2;
+    const size_t t = e >> 3;
+    const int row = (int)(t % rows);
+    const int kc = (int)(t / rows);
+    float v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = kc * 16 + kk + u;
+      v[u] = 0.f;
+      if (k < K) {
+        const int rs = k / Cout, co = k - rs * Cout;
+        v[u] = w[((size_t)co * RS + (RS - 1 - rs)) * Cin + row];      // (R-1-r', S-1-s') = RS-1-rs
+      }
+    }
+    const unsigned h = pack_bf16(v[0], v[1]);
+    const float r0 = v[0] - bf16_lo(h), r1 = v[1] - bf16_hi(h);
+    const unsigned m = pack_bf16(r0, r1);
+    const unsigned l = pack_bf16(r0 - bf16_lo(m), r1 - bf16_hi(m));
+    unsigned* o = reinterpret_cast<unsigned*>(out) + e;
+    o[0] = h;
+    o[total] = m;
+    o[2 * total] = l;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 with a halo-resident A operand (the structure of conv_halo.hip, DESIGN.md
 // appendix A) on split operands: the workgroup's 8 x 16 output pixels plus halo (10 x 18 pixels x
@@ -1646,6 +1681,22 @@ extern "C" int bgs_conv_bfx_split_weights(const float* w, void* out, int rows, i
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(bfx_split_weights_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
                      w, reinterpret_cast<__bf16*>(out), rows, K, KC, 3);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+// w [Cout][R][S][Cin] (the forward filter) -> the split planes of its data-gradient filter
+// (= bgs_conv_bfx_split_weights of the flipped, transposed filter [Cin][R][S][Cout]: rows = Cin,
+// K = R*S*Cout; out: bgs_conv_bfx_weight_bytes(Cin, R*S*Cout) bytes) in ONE launch.
+extern "C" int bgs_conv_bfx_split_weights_dgrad(const float* w, void* out, int Cout, int R, int S, int Cin,
+                                                bgs_stream_t stream) {
+  if (!w || !out || Cout <= 0 || R <= 0 || S <= 0 || Cin <= 0) return BGS_ERR_INVALID_ARG;
+  if ((uintptr_t)out % 16 != 0) return BGS_ERR_INVALID_ARG;
+  const int KC = bfx_kc(R * S * Cout);
+  const size_t total = (size_t)KC * Cin * 8;
+  size_t g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(bfx_split_weights_dgrad_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                     w, reinterpret_cast<__bf16*>(out), Cout, R, S, Cin, KC);
   BGS_RETURN_LAUNCH_STATUS();
 }
 

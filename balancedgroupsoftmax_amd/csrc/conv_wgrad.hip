@@ -445,16 +445,44 @@ __global__ __launch_bounds__(kThreads, NBUF == 1 ? 3 : 2) void conv_wgrad_bfx_ke
     }
 }
 
-// dW[i] (+)= scale-free sum over the splits, fixed order.
+// dW[i] (+)= scale-free sum over the splits, fixed order; the last `gb` workgroups of the launch do the same
+// for the bias-gradient partials (ONE launch for both: 63 launches less per `selectp=0` backward).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws,
                                                            float* __restrict__ dw, size_t n4,
+                                                           const float* __restrict__ ws_b,
+                                                           float* __restrict__ db, size_t c4, unsigned gb,
                                                            int splits, int accumulate) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+  const unsigned gw = gridDim.x - gb;
+  if (blockIdx.x >= gw) {
+    for (size_t i = (size_t)(blockIdx.x - gw) * 256 + threadIdx.x; i < c4; i += (size_t)gb * 256) {
+      f32x4 s = *reinterpret_cast<const f32x4*>(ws_b + i * 4);
+      for (int z = 1; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(ws_b + (z * c4 + i) * 4);
+      if (accumulate) s += *reinterpret_cast<const f32x4*>(db + i * 4);
+      *reinterpret_cast<f32x4*>(db + i * 4) = s;
+    }
+    return;
+  }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gw * 256) {
     f32x4 s = *reinterpret_cast<const f32x4*>(ws + i * 4);
     for (int z = 1; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(ws + (z * n4 + i) * 4);
     if (accumulate) s += *reinterpret_cast<const f32x4*>(dw + i * 4);
     *reinterpret_cast<f32x4*>(dw + i * 4) = s;
   }
+}
+
+// the reduction launch shared by both kernels' entry points: weight slabs (unless the kernel wrote dw
+// directly) and bias partials
+int launch_wgrad_reduce(const float* ws, float* dw, size_t n, bool direct, const float* db_part, float* db,
+                        int Cout, int splits, int accumulate, hipStream_t st) {
+  const size_t n4 = direct ? 0 : n / 4;     // Cin % 4 == 0 -> n % 4 == 0
+  size_t g = (n4 + 255) / 256;
+  if (g > 4096) g = 4096;
+  const size_t c4 = db ? (size_t)Cout / 4 : 0;
+  const unsigned gb = (unsigned)((c4 + 255) / 256);
+  if (g + gb == 0) return BGS_OK;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g + gb), dim3(256), 0, st, ws, dw, n4, db_part, db,
+                     c4, gb, splits, accumulate);
+  return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
 }
 
 struct WgradPlan {
@@ -553,20 +581,7 @@ extern "C" int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float*
   else
     hipLaunchKernelGGL((conv_wgrad_f32_kernel<1, 1>), grid, dim3(kThreads), 0, st, p);
   if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
-  if (!direct) {
-    const size_t n4 = n / 4;   // Cin % 4 == 0 -> n % 4 == 0
-    size_t g = (n4 + 255) / 256;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, ws, dw, n4,
-                       pl.splits, accumulate);
-    if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
-  }
-  if (db) {
-    const size_t c4 = (size_t)Cout / 4;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, st,
-                       p.db_part, db, c4, pl.splits, accumulate);
-  }
-  BGS_RETURN_LAUNCH_STATUS();
+  return launch_wgrad_reduce(ws, dw, n, direct, p.db_part, db, Cout, pl.splits, accumulate, st);
 }
 
 // bf16x6 / bf16 flavour (conv_wgrad_bfx_kernel): same contract and workspace as
@@ -654,20 +669,7 @@ extern "C" int bgs_conv2d_wgrad_nhwc_f32_bfx(const float* x, const float* dy, fl
   else if (planes == 3) hipLaunchKernelGGL((conv_wgrad_bfx_kernel<3>), grid, dim3(kThreads), 0, st, p);
   else hipLaunchKernelGGL((conv_wgrad_bfx_kernel<1>), grid, dim3(kThreads), 0, st, p);
   if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
-  if (!direct) {
-    const size_t n4 = n / 4;
-    size_t g = (n4 + 255) / 256;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, ws, dw, n4,
-                       pl.splits, accumulate);
-    if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
-  }
-  if (db) {
-    const size_t c4 = (size_t)Cout / 4;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, st,
-                       p.db_part, db, c4, pl.splits, accumulate);
-  }
-  BGS_RETURN_LAUNCH_STATUS();
+  return launch_wgrad_reduce(ws, dw, n, direct, p.db_part, db, Cout, pl.splits, accumulate, st);
 }
 
 // 0 = fp32-MFMA kernel everywhere, 1 = default routing, 2 = the bf16x6 kernel also on short reductions (tests)

@@ -546,6 +546,32 @@ def bfx_split_weights(w2d, cache=True):
     return out
 
 
+def bfx_split_weights_dgrad(w_krsc, cache=True):
+    """The split planes of the DATA-GRADIENT filter of ``w_krsc [Cout,R,S,Cin]`` (= ``bfx_split_weights``
+    of ``dgrad_filter(w_krsc).view(Cin, R*S*Cout)``) in one launch (``bgs_conv_bfx_split_weights_dgrad``).
+    ``cache`` as in :func:`bfx_split_weights`."""
+    _require_cuda(w_krsc)
+    lib = capi.load()
+    assert w_krsc.dtype == torch.float32 and w_krsc.dim() == 4 and w_krsc.is_contiguous()
+    Cout, R, S, Cin = w_krsc.shape
+    cacheable = cache and not w_krsc.requires_grad
+    key = (w_krsc.data_ptr(), 'dgrad')
+    if cacheable:
+        hit = _SPLIT_CACHE.get(key)
+        if hit is not None and hit[0] == w_krsc._version and hit[1] == (Cout, R, S, Cin):
+            return hit[3]
+    out = torch.empty(lib.bgs_conv_bfx_weight_bytes(Cin, R * S * Cout), dtype=torch.uint8,
+                      device=w_krsc.device)
+    rc = lib.bgs_conv_bfx_split_weights_dgrad(capi.ptr(w_krsc), capi.ptr(out), Cout, R, S, Cin,
+                                              capi.current_stream(w_krsc.device))
+    capi.check('bgs_conv_bfx_split_weights_dgrad', rc)
+    if cacheable:
+        if key not in _SPLIT_CACHE and len(_SPLIT_CACHE) >= _SPLIT_CACHE_MAX:
+            _SPLIT_CACHE.pop(next(iter(_SPLIT_CACHE)))
+        _SPLIT_CACHE[key] = (w_krsc._version, (Cout, R, S, Cin), w_krsc, out)
+    return out
+
+
 def conv_bfx_tuning(tile=0, splitk=-1, halo_splits=-1, halo_variant=0):
     """Process-wide tuning / test hook of the bf16x6 kernels (see include/bgs.h)."""
     lib = capi.load()
@@ -705,7 +731,7 @@ def dgrad_filter(w_krsc):
 
 
 def conv2d_dgrad_nhwc(dy, w_krsc, in_hw, stride=1, pad=0, residual=None, residual_mode=0,
-                      mask=None, wt=None):
+                      mask=None, wt=None, frozen_weight=False):
     """Data gradient of :func:`conv2d_nhwc`: ``dy [N,Ho,Wo,Cout]`` -> ``dx [N,H,W,Cin]``.
     ``residual`` is added (mode 1 same shape, mode 3: ``[N,2H,2W,Cin]`` 2x2-sum-pooled), then
     ``mask > 0`` gates the result (ReLU backward of the conv's input)."""
@@ -724,7 +750,8 @@ def conv2d_dgrad_nhwc(dy, w_krsc, in_hw, stride=1, pad=0, residual=None, residua
         Cout += padc
         wt = None
     wt_is_temp = wt is None
-    if wt is None:
+    fused_split = wt is None and _CONV_MATH[0] != 'f32' and os.environ.get('BGS_DGRAD_FUSED_SPLIT', '1') != '0'
+    if wt is None and not fused_split:
         wt = dgrad_filter(w_krsc)
     if residual is not None and residual_mode == 0:
         residual_mode = 1
@@ -735,7 +762,13 @@ def conv2d_dgrad_nhwc(dy, w_krsc, in_hw, stride=1, pad=0, residual=None, residua
         assert tuple(mask.shape) == (N, H, W, Cin) and mask.is_contiguous()
     dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dy.device)
     if _CONV_MATH[0] != 'f32':
-        wt_split = bfx_split_weights(wt.view(Cin, R * S * Cout), cache=not wt_is_temp)
+        if fused_split:
+            # flip + transpose + split in one launch; cached for frozen filters (a detached view of a
+            # trained filter changes from step to step: w_krsc.requires_grad tells nothing about it,
+            # so only tensors the caller passes as frozen parameters are cached — see _ConvFn.backward)
+            wt_split = bfx_split_weights_dgrad(w_krsc.detach().contiguous(), cache=bool(frozen_weight))
+        else:
+            wt_split = bfx_split_weights(wt.view(Cin, R * S * Cout), cache=not wt_is_temp)
         if R == 3 and S == 3 and stride == 1 and pad == 1 and residual is None and Cout % 16 == 0 \
                 and _use_halo_bfx(N * H * W, Cin) and os.environ.get('BGS_DGRAD_HALO', '1') != '0':
             # the data gradient of a 3x3 / stride 1 / pad 1 conv is the same conv of dy with the
@@ -911,7 +944,8 @@ class _ConvFn(torch.autograd.Function):
         with conv_math_scope(ctx.math):
             if need_x:
                 dx = conv2d_dgrad_nhwc(dz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad,
-                                       mask=x if mask_input else None)
+                                       mask=x if mask_input else None,
+                                       frozen_weight=not w.requires_grad)
             if need_w or (has_bias and need_b):
                 out = conv2d_wgrad_nhwc(x, dz, w.shape[1], stride=stride, pad=pad, bias=has_bias)
                 dw, db = out if has_bias else (out, None)

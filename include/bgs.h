@@ -334,6 +334,12 @@ int bgs_conv3x3_halo_nhwc_f32(const float* x, const float* w, const float* bias,
  * ---------------------------------------------------------------------------------- */
 size_t bgs_conv_bfx_weight_bytes(int rows, int K);
 int bgs_conv_bfx_split_weights(const float* w, void* out, int rows, int K, bgs_stream_t stream);
+/* The split planes of the DATA-GRADIENT filter straight from the forward filter w [Cout,R,S,Cin]:
+ * = bgs_conv_bfx_split_weights of wt[ci][r'][s'][co] = w[co][R-1-r'][S-1-s'][ci] (rows = Cin, K = R*S*Cout;
+ * `out`: bgs_conv_bfx_weight_bytes(Cin, R*S*Cout) bytes) — one launch instead of flip + permute + split per
+ * trained conv and step (`selectp = 0`). */
+int bgs_conv_bfx_split_weights_dgrad(const float* w, void* out, int Cout, int R, int S, int Cin,
+                                     bgs_stream_t stream);
 size_t bgs_conv_bfx_workspace_bytes(long long M, int Cout, int K);
 int bgs_conv2d_nhwc_f32_bfx_ws(const float* x, const void* wsplit, const float* bias,
                                const float* residual, float* y, int N, int H, int W, int Cin,

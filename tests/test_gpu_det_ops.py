@@ -1019,3 +1019,15 @@ def test_conv3x3_data_gradient_runs_the_halo_kernel_and_equals_the_operand_ring(
     scale = np.abs(exp).max()
     assert np.abs(a.cpu().numpy() - exp).max() <= 2e-5 * scale
     assert np.abs(a.cpu().numpy() - b.cpu().numpy()).max() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize('shape', [(256, 3, 3, 128), (512, 1, 1, 256), (15, 1, 1, 256), (64, 3, 3, 20), (100, 7, 7, 4)])
+def test_fused_dgrad_filter_split_equals_flip_permute_split(shape):
+    """``bgs_conv_bfx_split_weights_dgrad``: the split planes of the data-gradient filter in one launch
+    are byte-identical to flip + permute + contiguous + ``bgs_conv_bfx_split_weights``."""
+    Cout, R, S, Cin = shape
+    g = torch.Generator().manual_seed(Cout * 7 + Cin)
+    w = (torch.randn(Cout, R, S, Cin, generator=g) * torch.exp(torch.rand(Cout, 1, 1, 1, generator=g) * 8 - 4)).to(DEV)
+    a = BF.bfx_split_weights_dgrad(w, cache=False)
+    b = BF.bfx_split_weights(BF.dgrad_filter(w).view(Cin, R * S * Cout), cache=False)
+    assert a.shape == b.shape and torch.equal(a, b)
