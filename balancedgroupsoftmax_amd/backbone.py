@@ -139,20 +139,44 @@ class Bottleneck(nn.Module):
     def run(self, x, f):
         if x.dtype == torch.bfloat16:
             return self.run_bf16_storage(x, f)
+        # Residual fork (x feeds conv1 / the projection shortcut AND the identity path): with a trainable
+        # predecessor the first conv hands an alias of x to the other consumer (`passthrough`), so both
+        # gradients meet in ITS backward and their sum — and the ReLU gate of x, when x is the
+        # `relu='consumers'` output of the previous block — ride in that conv's dgrad epilogue instead of
+        # an add pass and a threshold pass over the map per block (functional._ConvFn).
+        tagged = bool(getattr(x, '_bgs_consumers_mask', False))
+        fuse = BF.fork_fusion_enabled() and torch.is_grad_enabled() and x.requires_grad
+        if tagged and not fuse:
+            raise RuntimeError("Bottleneck.run: x is a relu='consumers' block output but fork fusion is off")
+        out_relu = 'consumers' if BF.fork_fusion_enabled() else True
+        xin = x
         identity = x
         if 'ds' in f:
-            identity = BF.conv2d_autograd(x, f['ds'][0], f['ds'][1], stride=self.stride)
+            if fuse:
+                identity, xin = BF.conv2d_autograd(x, f['ds'][0], f['ds'][1], stride=self.stride,
+                                                   mask_input=tagged, passthrough=True)
+            else:
+                identity = BF.conv2d_autograd(x, f['ds'][0], f['ds'][1], stride=self.stride)
+        first_pt = fuse and 'ds' not in f          # conv1 is the fork's first conv
+        first_mask = tagged and 'ds' not in f      # (behind a projection shortcut the alias is ungated:
+        #                                             the shortcut's epilogue gates the sum)
         # conv1 -> conv2 -> conv3 is a chain of single consumers: the ReLU backward of o1 / o2
         # rides in the epilogue of the next conv's dgrad (relu='consumers' + mask_input)
         if self.groups > 1:      # ResNeXt: grouped 3x3 (csrc/grouped_conv.hip)
-            out = BF.conv2d_autograd(x, f['c1'][0], f['c1'][1], relu=True)
+            out = BF.conv2d_autograd(xin, f['c1'][0], f['c1'][1], relu=True, mask_input=first_mask,
+                                     passthrough=first_pt)
+            if first_pt:
+                out, identity = out
             out = BF.grouped_conv3x3_nhwc(out, f['c2'][0], f['c2'][1], self.groups,
                                           stride=self.stride, relu=True)
-            return BF.conv2d_autograd(out, f['c3'][0], f['c3'][1], relu=True, residual=identity)
-        out = BF.conv2d_autograd(x, f['c1'][0], f['c1'][1], relu='consumers')
+            return BF.conv2d_autograd(out, f['c3'][0], f['c3'][1], relu=out_relu, residual=identity)
+        out = BF.conv2d_autograd(xin, f['c1'][0], f['c1'][1], relu='consumers', mask_input=first_mask,
+                                 passthrough=first_pt)
+        if first_pt:
+            out, identity = out
         out = BF.conv2d_autograd(out, f['c2'][0], f['c2'][1], stride=self.stride, pad=1,
                                  relu='consumers', mask_input=True)
-        return BF.conv2d_autograd(out, f['c3'][0], f['c3'][1], relu=True, residual=identity,
+        return BF.conv2d_autograd(out, f['c3'][0], f['c3'][1], relu=out_relu, residual=identity,
                                   mask_input=True)
 
 
@@ -266,7 +290,10 @@ class ResNet(nn.Module):
             for blk in getattr(self, name):
                 x = blk.run(x, blk.folded())
             if i in self.out_indices:
-                outs.append(x)
+                # a trainable stage hands on a `relu='consumers'` tensor (its ReLU backward rides in the
+                # next block's dgrad epilogue); what LEAVES the trunk is an ordinary tensor any consumer
+                # may use: relu_gate applies the gate to the gradient coming back (a no-op otherwise)
+                outs.append(BF.relu_gate(x))
         return tuple(outs)
 
     def train(self, mode=True):
@@ -337,10 +364,13 @@ class FPN(nn.Module):
             inputs = [t.float() for t in inputs]      # a trainable neck records fp32 operands
         lat = [None] * n
         # bf16-stored trunk maps (cfg[4] bf16 mode) are read as they are; the pyramid itself is fp32
-        lat[n - 1] = BF.conv2d_autograd(inputs[n - 1], *f['lat'][n - 1], out_dtype=torch.float32)
+        # (trunk maps that are `relu='consumers'` block outputs: the lateral's dgrad epilogue gates them)
+        gate = [bool(getattr(t, '_bgs_consumers_mask', False)) for t in inputs]
+        lat[n - 1] = BF.conv2d_autograd(inputs[n - 1], *f['lat'][n - 1], out_dtype=torch.float32,
+                                        mask_input=gate[n - 1])
         for i in range(n - 2, -1, -1):   # lateral_i + nearest_2x(lateral_{i+1}), fused
             lat[i] = BF.conv2d_autograd(inputs[i], *f['lat'][i], residual=lat[i + 1],
-                                        residual_mode=2, out_dtype=torch.float32)
+                                        residual_mode=2, out_dtype=torch.float32, mask_input=gate[i])
         outs = [BF.conv2d_autograd(lat[i], *f['out'][i], pad=1) for i in range(n)]
         for _ in range(self.num_outs - n):   # F.max_pool2d(x, 1, stride=2) == subsampling
             outs.append(outs[-1][:, ::2, ::2, :].contiguous())

@@ -40,6 +40,11 @@ struct WgradArgs {
                     // by the k-tile-0 workgroups from the dy tiles they stage anyway
   int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
   int M, K, m_per_split;
+  // XCD-aware order (bf16x6 kernel): 1-D launch of 8 * chunk workgroups; workgroup b runs on XCD b % 8 and
+  // takes tile (b % 8) * chunk + b / 8 of the (co tile, k tile, M slice) list, M slice slowest — all tiles of
+  // one M slice (they re-read the same dy / x rows: 18 k tiles x 2 co tiles x 9 taps on the FPN convs) share
+  // ONE XCD's L2 instead of pulling the slice through the fabric into all eight.  chunk == 0: 3-D grid.
+  int gx, gy, gz, chunk;
 };
 
 template <int T>
@@ -283,8 +288,17 @@ __global__ __launch_bounds__(kThreads, NBUF == 1 ? 3 : 2) void conv_wgrad_bfx_ke
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int co0 = blockIdx.x * BT, k0 = blockIdx.y * BT;
-  const int m_begin = blockIdx.z * p.m_per_split;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.chunk) {
+    const int v = (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3));
+    if (v >= p.gx * p.gy * p.gz) return;          // workgroup-uniform
+    bx = v % p.gx;
+    const int t = v / p.gx;
+    by = t % p.gy;
+    bz = t / p.gy;
+  }
+  const int co0 = bx * BT, k0 = by * BT;
+  const int m_begin = bz * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
 
   // ---- staging roles: part 0 (threads 0-127) = dy, part 1 = x; block (mg, q): m rows 4 mg .. 4 mg + 3
@@ -316,7 +330,7 @@ __global__ __launch_bounds__(kThreads, NBUF == 1 ? 3 : 2) void conv_wgrad_bfx_ke
 
   f32x4 v[4];
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-  const bool want_db = p.db_part != nullptr && blockIdx.y == 0;
+  const bool want_db = p.db_part != nullptr && by == 0;
   int m_stage = m_begin;
   auto load_stage = [&]() {
 #pragma unroll
@@ -423,12 +437,12 @@ __global__ __launch_bounds__(kThreads, NBUF == 1 ? 3 : 2) void conv_wgrad_bfx_ke
     __syncthreads();
     if (!is_b && mg == 0 && col_ok) {
       const f32x4 t = (red[cq] + red[32 + cq]) + (red[64 + cq] + red[96 + cq]);
-      *reinterpret_cast<f32x4*>(p.db_part + (size_t)blockIdx.z * p.Cout + colq) = t;
+      *reinterpret_cast<f32x4*>(p.db_part + (size_t)bz * p.Cout + colq) = t;
     }
   }
 
   // ---- partial tile: C/D layout col = lane & 31 (k), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (co)
-  float* out = p.out + (size_t)blockIdx.z * p.Cout * p.K;
+  float* out = p.out + (size_t)bz * p.Cout * p.K;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -556,6 +570,7 @@ extern "C" int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float*
   if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)workspace) % 16 != 0)
     return BGS_ERR_INVALID_ARG;
   WgradArgs p;
+  p.gx = p.gy = p.gz = p.chunk = 0;
   p.x = x; p.dy = dy;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S;
   p.stride = stride; p.pad = pad;
@@ -589,6 +604,14 @@ extern "C" int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float*
 // with Cout < 96 or K < 96 (the 128 x 128 tile would be mostly padding: stem, RPN heads) are routed
 // to the fp32-MFMA kernel, which is exact.
 int g_wgrad_bfx_enabled = -1;
+int g_wgrad_xcd = -1;      // BGS_WGRAD_XCD=0: the plain 3-D grid (A/B)
+static bool wgrad_xcd_order() {
+  if (g_wgrad_xcd < 0) {
+    const char* e = getenv("BGS_WGRAD_XCD");
+    g_wgrad_xcd = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return g_wgrad_xcd != 0;
+}
 int g_wgrad_nbuf = -1;     // BGS_WGRAD_NBUF = 1 | 2 (LDS stage buffers of conv_wgrad_bfx_kernel<3>)
 static int wgrad_nbuf() {
   if (g_wgrad_nbuf < 0) {
@@ -654,6 +677,12 @@ extern "C" int bgs_conv2d_wgrad_nhwc_f32_bfx(const float* x, const float* dy, fl
   const size_t n = (size_t)Cout * p.K;
   p.db_part = db ? ws + (size_t)pl.splits * n : nullptr;
   dim3 grid((unsigned)((Cout + 127) / 128), (unsigned)((p.K + 127) / 128), (unsigned)pl.splits);
+  p.gx = (int)grid.x; p.gy = (int)grid.y; p.gz = (int)grid.z;
+  p.chunk = 0;
+  if (wgrad_xcd_order()) {
+    p.chunk = (p.gx * p.gy * p.gz + 7) / 8;
+    grid = dim3((unsigned)(8 * p.chunk));
+  }
   bgs_internal_census_bump(BGS_CENSUS_WGRAD_BFX);
 #ifdef BGS_ABLATE
   int abl = 0;

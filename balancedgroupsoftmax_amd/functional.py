@@ -513,6 +513,22 @@ def bf16_storage_active():
     return _CONV_MATH[0] == 'bf16' and _BF16_STORAGE[0]
 
 
+# Residual-fork fusion on the trainable trunk (backbone.Bottleneck.run): the block output's ReLU backward and
+# the fork's gradient sum ride in the dgrad epilogue of the next block's first conv.  BGS_FORK_FUSION=0: the
+# separate threshold / add passes (A/B).
+_FORK_FUSION = [os.environ.get('BGS_FORK_FUSION', '1') != '0']
+
+
+def fork_fusion_enabled():
+    return _FORK_FUSION[0]
+
+
+def set_fork_fusion(on):
+    prev = _FORK_FUSION[0]
+    _FORK_FUSION[0] = bool(on)
+    return prev
+
+
 _SPLIT_CACHE = {}
 _SPLIT_CACHE_MAX = 1024
 
@@ -918,7 +934,8 @@ class _ConvFn(torch.autograd.Function):
     equals gating their sum) and this node skips the separate masking pass over ``dy``."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, stride, pad, relu, residual_mode, mask_input):
+    def forward(ctx, x, w, bias, residual, stride, pad, relu, residual_mode, mask_input,
+                passthrough=False):
         # w.requires_grad: a trained parameter or the per-step fold of one (its detached view has
         # requires_grad == False, so the decision is taken HERE): split every step, never cached
         y = conv2d_nhwc(x.detach(), w.detach(), None if bias is None else bias.detach(),
@@ -929,13 +946,22 @@ class _ConvFn(torch.autograd.Function):
                    bias is not None, mask_input)
         ctx.math = _CONV_MATH[0]          # backward replays in the arithmetic of this forward
         ctx.save_for_backward(x, w, y if relu is True else None)
+        if passthrough:
+            # second output: an alias of x for the OTHER consumer of x at a fork (the identity path
+            # of a residual block).  Its gradient arrives in this node's backward together with
+            # dy, so the fork's `g_conv + g_identity` is the dgrad kernel's residual epilogue
+            # instead of a separate pass over the map
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, dalias=None):
         x, w, y = ctx.saved_tensors
         stride, pad, relu, res_mode, has_bias, mask_input = ctx.cfg
+        if dy is None:            # (passthrough nodes only: y itself had no consumer)
+            return (dalias,) + (None,) * 9
         dz = dy.contiguous()
         if relu is True:          # one fused pass: dy * (y > 0)
             dz = torch.ops.aten.threshold_backward(dz, y, 0.0)
@@ -944,6 +970,7 @@ class _ConvFn(torch.autograd.Function):
         with conv_math_scope(ctx.math):
             if need_x:
                 dx = conv2d_dgrad_nhwc(dz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad,
+                                       residual=None if dalias is None else dalias.contiguous(),
                                        mask=x if mask_input else None,
                                        frozen_weight=not w.requires_grad)
             if need_w or (has_bias and need_b):
@@ -955,7 +982,7 @@ class _ConvFn(torch.autograd.Function):
             else:
                 n, h, wd, c = dz.shape
                 dres = dz.view(n, h // 2, 2, wd // 2, 2, c).sum(dim=(2, 4))
-        return dx, dw, db, dres, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None
 
 
 class _ReluGateFn(torch.autograd.Function):
@@ -983,10 +1010,12 @@ def relu_gate(y):
 
 
 def conv2d_autograd(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None,
-                    residual_mode=0, mask_input=False, out_dtype=None):
+                    residual_mode=0, mask_input=False, out_dtype=None, passthrough=False):
     """:func:`conv2d_nhwc` that records an autograd node when any input requires grad.
     ``relu``: False / True / ``'consumers'`` (see :class:`_ConvFn`); ``mask_input``: ``x`` is the
-    output of a ``relu='consumers'`` conv.  The contract is checked where it can be: outputs of
+    output of a ``relu='consumers'`` conv; ``passthrough``: returns ``(y, x_alias)`` — hand ``x_alias``
+    to the other consumer of ``x`` (a residual identity path) and the fork's gradient sum rides in
+    this conv's dgrad epilogue.  The contract is checked where it can be: outputs of
     ``relu='consumers'`` convs are tagged, and feeding a tagged tensor to a conv WITHOUT
     ``mask_input=True`` raises (its gradient would skip the ReLU gate)."""
     ts = [t for t in (x, w_krsc, bias, residual) if t is not None]
@@ -999,13 +1028,15 @@ def conv2d_autograd(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=
                                "backward is delegated to its consumers) but mask_input is False")
         if residual is not None and residual_mode == 0:
             residual_mode = 1
-        y = _ConvFn.apply(x, w_krsc, bias, residual, stride, pad, relu, residual_mode,
-                          bool(mask_input))
+        out = _ConvFn.apply(x, w_krsc, bias, residual, stride, pad, relu, residual_mode,
+                            bool(mask_input), bool(passthrough))
+        y = out[0] if passthrough else out
         if relu == 'consumers':
             y._bgs_consumers_mask = True
-        return y
-    return conv2d_nhwc(x, w_krsc, bias, stride=stride, pad=pad, relu=bool(relu),
-                       residual=residual, residual_mode=residual_mode, out_dtype=out_dtype)
+        return out
+    y = conv2d_nhwc(x, w_krsc, bias, stride=stride, pad=pad, relu=bool(relu),
+                    residual=residual, residual_mode=residual_mode, out_dtype=out_dtype)
+    return (y, x) if passthrough else y
 
 
 def linear(x, weight, bias=None, relu=False, frozen_weight=None):
