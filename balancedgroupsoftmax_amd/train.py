@@ -195,6 +195,68 @@ class OverlappedGradExchange(object):
         self._handles = []
 
 
+def _fused_sgd_eligible(optimizer, params, grad_clip):
+    """The fused clip + SGD kernels (csrc/optim.hip) cover what the BAGS configs use: ONE param group of
+    torch.optim.SGD without dampening / nesterov / maximize, L2 clipping, fp32 CUDA parameters."""
+    import os
+    if os.environ.get('BGS_FUSED_SGD', '1') == '0' or type(optimizer) is not torch.optim.SGD:
+        return False
+    if len(optimizer.param_groups) != 1:
+        return False
+    g = optimizer.param_groups[0]
+    if g.get('dampening', 0) != 0 or g.get('nesterov', False) or g.get('maximize', False):
+        return False
+    if grad_clip is not None and float(grad_clip.get('norm_type', 2)) != 2.0:
+        return False
+    return all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params)
+
+
+class FusedClipSGD(object):
+    """``clip_grad_norm_`` + ``torch.optim.SGD.step`` for all trainable tensors as two launch phases
+    (``bgs_sgd_clip_step``; the reference's ``DistOptimizerHook.after_train_iter`` tail, dist_utils.py:55-58).
+    The momentum buffers ARE the wrapped optimizer's ``state[p]['momentum_buffer']`` (created as zeros
+    — ``momentum * 0 + d`` is torch's first-step clone), so ``optimizer.state_dict()`` stays what a
+    torch-driven run would save.  Parameters whose ``.grad`` is None are skipped, as torch does."""
+
+    def __init__(self, optimizer, params, grad_clip=None):
+        self.optimizer = optimizer
+        self.params = list(params)
+        self.max_norm = float(grad_clip['max_norm']) if grad_clip is not None else 0.0
+        self.total_norm = None
+        self._ws = None
+
+    def step(self, grad_scale=1.0):
+        import ctypes
+        from . import capi
+        lib = capi.load()
+        group = self.optimizer.param_groups[0]
+        ps = [p for p in self.params if p.grad is not None]
+        if not ps:
+            return
+        dev = ps[0].device
+        bufs = []
+        for p in ps:
+            st = self.optimizer.state[p]
+            if st.get('momentum_buffer') is None:
+                st['momentum_buffer'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            bufs.append(st['momentum_buffer'])
+            if not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
+        n = len(ps)
+        arr = ctypes.c_void_p * n
+        numel = (ctypes.c_longlong * n)(*[p.numel() for p in ps])
+        wsb = lib.bgs_sgd_clip_workspace_bytes(numel, n)
+        if self._ws is None or self._ws.numel() < wsb or self._ws.device != dev:
+            self._ws = torch.empty(max(wsb, 1 << 16), dtype=torch.uint8, device=dev)
+            self.total_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        rc = lib.bgs_sgd_clip_step(arr(*[p.data_ptr() for p in ps]), arr(*[p.grad.data_ptr() for p in ps]),
+                                   arr(*[b.data_ptr() for b in bufs]), numel, n, self.max_norm,
+                                   float(grad_scale), float(group['lr']), float(group.get('momentum', 0.0)),
+                                   float(group.get('weight_decay', 0.0)), capi.ptr(self._ws),
+                                   self._ws.numel(), capi.ptr(self.total_norm), capi.current_stream(dev))
+        capi.check('bgs_sgd_clip_step', rc)
+
+
 class DistOptimizerStep(object):
     """One optimizer step with the reference's hook order (dist_utils.py:51-58)."""
 
@@ -211,6 +273,23 @@ class DistOptimizerStep(object):
             overlap = world_size > 1 and nbytes > bucket_bytes
         self.overlap = OverlappedGradExchange(self.params, world_size, bucket_bytes) \
             if (overlap and world_size > 1) else None
+        # clip + SGD as two launch phases over all tensors (csrc/optim.hip) where the configuration
+        # allows; the torch foreach path otherwise (and under BGS_FUSED_SGD=0)
+        self.fused = FusedClipSGD(optimizer, self.params, grad_clip) \
+            if _fused_sgd_eligible(optimizer, self.params, grad_clip) else None
+
+    def _clip_and_step(self, grad_scale=1.0):
+        if self.fused is not None:
+            self.fused.step(grad_scale)
+            return
+        if grad_scale != 1.0:
+            grads = [p.grad for p in self.params if p.grad is not None]
+            if grads:
+                torch._foreach_div_(grads, 1.0 / grad_scale)      # (exact for power-of-two loss scales)
+        if self.grad_clip is not None:
+            torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip['max_norm'],
+                                           self.grad_clip.get('norm_type', 2))
+        self.optimizer.step()
 
     def exchange_and_update(self):
         """all-reduce -> clip -> step, for gradients already produced by backward."""
@@ -218,10 +297,7 @@ class DistOptimizerStep(object):
             self.overlap.finish()          # buckets were launched from the backward hooks
         else:
             allreduce_grads(self.params, self.world_size)
-        if self.grad_clip is not None:
-            torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip['max_norm'],
-                                           self.grad_clip.get('norm_type', 2))
-        self.optimizer.step()
+        self._clip_and_step()
 
     def __call__(self, loss):
         self.optimizer.zero_grad(set_to_none=False)
@@ -286,13 +362,7 @@ class Fp16OptimizerStep(DistOptimizerStep):
             self.overlap.finish()
         else:
             allreduce_grads(self.params, self.world_size)
-        grads = [p.grad for p in self.params if p.grad is not None]
-        if grads and self.loss_scale != 1.0:
-            torch._foreach_div_(grads, self.loss_scale)
-        if self.grad_clip is not None:
-            torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip['max_norm'],
-                                           self.grad_clip.get('norm_type', 2))
-        self.optimizer.step()
+        self._clip_and_step(1.0 / self.loss_scale)
 
     def __call__(self, loss):
         self.optimizer.zero_grad(set_to_none=False)

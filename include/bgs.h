@@ -706,6 +706,23 @@ int bgs_mask_bce(const float* feat, const float* weight, const float* bias, cons
                  int C, int num_classes, float* partial_out, float* dfeat, float* dweight,
                  float* dbias, bgs_stream_t stream);
 
+/* Gradient clipping + SGD update of ALL trainable tensors (csrc/optim.hip): the reference's optimizer hook
+ * `DistOptimizerHook.after_train_iter` (mmdet/core/utils/dist_utils.py:51-58): `clip_grads` (max_norm = 35, L2:
+ * torch.nn.utils.clip_grad_norm_) -> `optimizer.step()` (torch.optim.SGD with momentum and weight decay,
+ * configs/bags/ `optimizer` entries), and the unscale step of `Fp16OptimizerHook` (mmdet/core/fp16/hooks.py:73-79)
+ * through `grad_scale` = 1 / loss_scale.  host_params / host_grads / host_momentum / host_numel: HOST arrays of
+ * n_tensors device pointers / element counts (fp32; momentum buffers zero before the first step); they are
+ * read during the call and passed to the kernels by value (hipGraph-capturable).  max_norm <= 0: no clipping.
+ *   g <- g * grad_scale * min(1, max_norm / (||g * grad_scale||_2 + 1e-6))   (in place, as the hook does)
+ *   buf <- momentum * buf + (g + weight_decay * p);   p <- p - lr * buf      (torch's operation order)
+ * total_norm_out: device float[1] receiving the unclipped norm, or NULL.
+ * workspace >= bgs_sgd_clip_workspace_bytes(host_numel, n_tensors). */
+size_t bgs_sgd_clip_workspace_bytes(const long long* host_numel, int n_tensors);
+int bgs_sgd_clip_step(const void* const* host_params, const void* const* host_grads,
+                      const void* const* host_momentum, const long long* host_numel, int n_tensors,
+                      float max_norm, float grad_scale, float lr, float momentum, float weight_decay,
+                      void* workspace, size_t workspace_bytes, float* total_norm_out, bgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

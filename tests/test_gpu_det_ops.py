@@ -1031,3 +1031,61 @@ def test_fused_dgrad_filter_split_equals_flip_permute_split(shape):
     a = BF.bfx_split_weights_dgrad(w, cache=False)
     b = BF.bfx_split_weights(BF.dgrad_filter(w).view(Cin, R * S * Cout), cache=False)
     assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize('clip', [35.0, 1e9, None])
+def test_fused_clip_sgd_step_vs_torch_clip_grad_norm_and_sgd(clip):
+    """``bgs_sgd_clip_step`` (csrc/optim.hip) against ``torch.nn.utils.clip_grad_norm_`` +
+    ``torch.optim.SGD.step`` (the reference's DistOptimizerHook tail, dist_utils.py:55-58) over three
+    steps: 70 tensors (two launches per phase), sizes around the 16K chunk and the 16-byte vector width,
+    clipping active (max_norm 35 against a norm of ~1e3), inactive (1e9) and absent; a parameter without
+    a gradient is skipped; the Fp16 hook's unscale (grad_scale = 1 / 512) rides in the same pass."""
+    from balancedgroupsoftmax_amd import train
+    g = torch.Generator().manual_seed(11)
+    sizes = [(3,), (17,), (16384,), (16385,), (70000,), (257, 129), (64, 3, 7, 7), (1236, 1024)] + [(50 + i,) for i in range(62)]
+    init = [torch.randn(*sz, generator=g) for sz in sizes]
+    grads = [[torch.randn(*sz, generator=g) * 3.0 for sz in sizes] for _ in range(3)]
+    grad_clip = None if clip is None else dict(max_norm=clip, norm_type=2)
+
+    def run(fused, scale):
+        ps = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+        extra = torch.nn.Parameter(torch.ones(5, device=DEV))          # never gets a gradient
+        opt = torch.optim.SGD(ps + [extra], lr=0.02, momentum=0.9, weight_decay=1e-4)
+        norms = []
+        for step in range(3):
+            for p, gr in zip(ps, grads[step]):
+                p.grad = (gr * scale).to(DEV)
+            if fused:
+                f = train.FusedClipSGD(opt, ps + [extra], grad_clip) if step == 0 else f
+                f.step(1.0 / scale)
+                norms.append(float(f.total_norm))
+            else:
+                if scale != 1.0:
+                    torch._foreach_div_([p.grad for p in ps], scale)
+                if grad_clip is not None:
+                    norms.append(float(torch.nn.utils.clip_grad_norm_(ps, clip, 2)))
+                opt.step()
+        return ps, [opt.state[p]['momentum_buffer'] for p in ps], norms, extra
+
+    for scale in (1.0, 512.0):
+        pa, ma, na, ea = run(True, scale)
+        pb, mb, nb, eb = run(False, scale)
+        assert torch.equal(ea, eb)
+        for a, b in zip(pa, pb):
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), a.shape
+        for a, b in zip(ma, mb):
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), a.shape
+        for a, b in zip(pa, pb):       # the clipped gradient is written back, as the hook clips in place
+            assert float((a.grad - b.grad).abs().max()) <= 2e-6 * float(b.grad.abs().max())
+        if grad_clip is not None:
+            assert np.allclose(na, nb, rtol=1e-5), (na, nb)
+
+
+def test_dist_optimizer_step_uses_the_fused_kernels_on_the_gpu_and_torch_under_the_switch(monkeypatch):
+    from balancedgroupsoftmax_amd import train
+    ps = [torch.nn.Parameter(torch.randn(300, 20, device=DEV)), torch.nn.Parameter(torch.randn(7, device=DEV))]
+    opt = train.build_optimizer(ps, dict(type='SGD', lr=0.01, momentum=0.9, weight_decay=1e-4))
+    assert train.DistOptimizerStep(ps, opt, dict(max_norm=35, norm_type=2)).fused is not None
+    assert train.DistOptimizerStep(ps, opt, dict(max_norm=35, norm_type=1)).fused is None
+    monkeypatch.setenv('BGS_FUSED_SGD', '0')
+    assert train.DistOptimizerStep(ps, opt, dict(max_norm=35, norm_type=2)).fused is None
