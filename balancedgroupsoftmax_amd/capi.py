@@ -121,6 +121,7 @@ SIGNATURES = {
                                            + [ctypes.c_int] * 7 + [c_ptr, c_ptr]),
     'bgs_maxpool3x3s2_bwd_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 4 + [c_ptr]),
     'bgs_maxpool3x3s2_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p] + [ctypes.c_int] * 4 + [c_ptr]),
+    'bgs_nchw_to_nhwc4_f32': (ctypes.c_int, [c_f32p, c_f32p] + [ctypes.c_int] * 4 + [c_ptr]),
     'bgs_conv2d_nhwc_bf16s': (ctypes.c_int, [c_ptr, c_ptr, c_f32p, c_ptr, ctypes.c_int, ctypes.c_int, c_ptr]
                               + [ctypes.c_int] * 11 + [c_ptr]),
     'bgs_grouped_conv3x3_nhwc_bf16s': (ctypes.c_int, [c_ptr, c_f32p, c_f32p, c_ptr] + [ctypes.c_int] * 7
@@ -162,6 +163,9 @@ SIGNATURES = {
     'bgs_nms_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     'bgs_nms_batched': (ctypes.c_int, [c_f32p, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                        ctypes.c_int, ctypes.c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'bgs_nms_gather': (ctypes.c_int, [c_f32p, c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_ptr]),
+    'bgs_gather_boxes': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
+                                        c_ptr, c_ptr]),
     'bgs_iou_assign_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 3),
     'bgs_iou_assign': (ctypes.c_int, [c_f32p, ctypes.c_longlong, ctypes.c_int, c_ptr, c_f32p, c_ptr,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,

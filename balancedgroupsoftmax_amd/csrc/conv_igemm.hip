@@ -612,6 +612,34 @@ extern "C" int bgs_conv2d_dgrad_nhwc_f32_ws(const float* dy, const float* wt,
   return launch_conv(p, stride, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
+// [N, C <= 4, H, W] image batch -> [N, H, W, 4] (channels zero-padded to 16-byte pixels): the stem conv's
+// input layout.  As tensor ops: permute + pad + contiguous = a fill and a strided copy.
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            int C, size_t hw, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t n = i / hw, pix = i - n * hw;
+    const float* src = x + n * C * hw + pix;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    v[0] = src[0];
+    if (C > 1) v[1] = src[hw];
+    if (C > 2) v[2] = src[2 * hw];
+    if (C > 3) v[3] = src[3 * hw];
+    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+  }
+}
+
+extern "C" int bgs_nchw_to_nhwc4_f32(const float* x, float* y, int N, int C, int H, int W,
+                                     bgs_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 4 || !x || !y) return BGS_ERR_INVALID_ARG;
+  if ((uintptr_t)y % 16 != 0) return BGS_ERR_INVALID_ARG;
+  const size_t hw = (size_t)H * W, total = (size_t)N * hw;
+  size_t grid = (total + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, y, C,
+                     hw, total);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int bgs_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C,
                                          bgs_stream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || !x || !y) return BGS_ERR_INVALID_ARG;

@@ -287,3 +287,75 @@ extern "C" int bgs_nms_batched(const float* boxes, const int* counts, int P, int
                        max_keep, keep, keep_count);
   BGS_RETURN_LAUNCH_STATUS();
 }
+
+// ---------------------------------------------------------------------------------------------
+// The two gathers of RPNHead.get_bboxes_single around the NMS (rpn_head.py:92-103): the kept boxes of
+// every (image, level) problem into fixed-shape rows (slots past keep_count score -1), and the final
+// per-image top `max_num` selection — each ONE launch instead of six element-wise / gather / where
+// launches (the proposal tail is pure launch latency: ~12 launches of ~4.5 us).
+namespace {
+
+__global__ __launch_bounds__(256) void nms_gather_kernel(const float* __restrict__ boxes,
+                                                         const int* __restrict__ keep,
+                                                         const int* __restrict__ keep_n, int total,
+                                                         int nmax, float* __restrict__ out_boxes,
+                                                         float* __restrict__ out_scores) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int r = i / nmax, slot = i - r * nmax;
+  int k = keep[i];
+  k = k < 0 ? 0 : (k > nmax - 1 ? nmax - 1 : k);
+  const float* src = boxes + ((size_t)r * nmax + k) * 5;
+  float* dst = out_boxes + (size_t)i * 5;
+  const float s = src[4];
+  dst[0] = src[0];
+  dst[1] = src[1];
+  dst[2] = src[2];
+  dst[3] = src[3];
+  dst[4] = s;
+  out_scores[i] = slot < keep_n[r] ? s : -1.f;
+}
+
+__global__ __launch_bounds__(256) void gather_boxes_kernel(const float* __restrict__ flat,
+                                                           const long long* __restrict__ idx,
+                                                           const float* __restrict__ scores, int N, int T,
+                                                           int num, float* __restrict__ props,
+                                                           unsigned char* __restrict__ valid) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * num) return;
+  const int n = i / num;
+  long long t = idx[i];
+  t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+  const float* src = flat + ((size_t)n * T + t) * 5;
+  float* dst = props + (size_t)i * 5;
+#pragma unroll
+  for (int c = 0; c < 5; ++c) dst[c] = src[c];
+  valid[i] = scores[i] >= 0.f ? 1 : 0;
+}
+
+}  // namespace
+
+// boxes [R, nmax, 5], keep [R, nmax] / keep_count [R] of bgs_nms_batched -> out_boxes [R, nmax, 5] =
+// boxes[r, clamp(keep[r, slot])], out_scores [R, nmax] = that box's score for slot < keep_count[r], else -1.
+extern "C" int bgs_nms_gather(const float* boxes, const int* keep, const int* keep_count, int R, int nmax,
+                              float* out_boxes, float* out_scores, bgs_stream_t stream) {
+  if (!boxes || !keep || !keep_count || !out_boxes || !out_scores || R <= 0 || nmax <= 0)
+    return BGS_ERR_INVALID_ARG;
+  if ((long long)R * nmax > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  const int total = R * nmax;
+  hipLaunchKernelGGL(nms_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, boxes, keep, keep_count, total, nmax, out_boxes, out_scores);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+// flat [N, T, 5], idx [N, num] int64 (row positions, e.g. of bgs_topk_sorted_f32), scores [N, num] ->
+// props [N, num, 5] = flat[n, idx[n, j]], valid [N, num] uint8 = scores >= 0.
+extern "C" int bgs_gather_boxes(const float* flat, const long long* idx, const float* scores, int N, int T,
+                                int num, float* props, unsigned char* valid, bgs_stream_t stream) {
+  if (!flat || !idx || !scores || !props || !valid || N <= 0 || T <= 0 || num <= 0)
+    return BGS_ERR_INVALID_ARG;
+  if ((long long)N * num > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gather_boxes_kernel, dim3((unsigned)((N * num + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, flat, idx, scores, N, T, num, props, valid);
+  BGS_RETURN_LAUNCH_STATUS();
+}

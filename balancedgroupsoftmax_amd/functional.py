@@ -1203,6 +1203,19 @@ def grouped_conv3x3_nhwc(x, w, bias, groups, stride=1, relu=False):
     return _grouped_conv3x3_launch(x, w, bias, groups, stride, relu)
 
 
+def nchw_to_nhwc4(img):
+    """``[N, C <= 4, H, W]`` image batch -> ``[N, H, W, 4]`` fp32, channels zero-padded (the stem conv's
+    16-byte pixels) in one launch (``bgs_nchw_to_nhwc4_f32``)."""
+    _require_cuda(img)
+    lib = capi.load()
+    x = img.detach().to(torch.float32).contiguous()
+    N, C, H, W = x.shape
+    out = torch.empty((N, H, W, 4), dtype=torch.float32, device=x.device)
+    rc = lib.bgs_nchw_to_nhwc4_f32(capi.ptr(x), capi.ptr(out), N, C, H, W, capi.current_stream(x.device))
+    capi.check('bgs_nchw_to_nhwc4_f32', rc)
+    return out
+
+
 def _maxpool_launch(x, out_dtype=torch.float32):
     lib = capi.load()
     N, H, W, C = x.shape
@@ -1455,6 +1468,41 @@ def nms_batched(boxes, counts, iou_thr, iou_mode=0, max_keep=0):
                              capi.ptr(ws), capi.current_stream(dev))
     capi.check('bgs_nms_batched', rc)
     return keep, keep_count
+
+
+def nms_gather(boxes, keep, keep_count):
+    """``boxes [R,nmax,5]``, ``keep [R,nmax]`` / ``keep_count [R]`` of :func:`nms_batched` ->
+    ``(kept [R,nmax,5], scores [R,nmax])``: the kept boxes in fixed-shape rows, score -1 in the slots
+    past ``keep_count`` (``bgs_nms_gather``: one launch)."""
+    _require_cuda(boxes, keep, keep_count)
+    lib = capi.load()
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.dim() == 3 and boxes.shape[2] == 5
+    assert keep.dtype == torch.int32 and keep.is_contiguous() and keep_count.dtype == torch.int32
+    R, nmax, _ = boxes.shape
+    out = torch.empty_like(boxes)
+    sc = torch.empty((R, nmax), dtype=torch.float32, device=boxes.device)
+    rc = lib.bgs_nms_gather(capi.ptr(boxes), capi.ptr(keep), capi.ptr(keep_count.contiguous()), R, nmax,
+                            capi.ptr(out), capi.ptr(sc), capi.current_stream(boxes.device))
+    capi.check('bgs_nms_gather', rc)
+    return out, sc
+
+
+def gather_boxes(flat, idx, scores):
+    """``props [N,num,5] = flat[n, idx[n,j]]``, ``valid [N,num] (bool) = scores >= 0``
+    (``bgs_gather_boxes``: one launch)."""
+    _require_cuda(flat, idx, scores)
+    lib = capi.load()
+    assert flat.dtype == torch.float32 and flat.is_contiguous() and flat.dim() == 3 and flat.shape[2] == 5
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and scores.dtype == torch.float32 \
+        and scores.is_contiguous() and idx.shape == scores.shape
+    N, T, _ = flat.shape
+    num = idx.shape[1]
+    props = torch.empty((N, num, 5), dtype=torch.float32, device=flat.device)
+    valid = torch.empty((N, num), dtype=torch.uint8, device=flat.device)
+    rc = lib.bgs_gather_boxes(capi.ptr(flat), capi.ptr(idx), capi.ptr(scores), N, T, num, capi.ptr(props),
+                              capi.ptr(valid), capi.current_stream(flat.device))
+    capi.check('bgs_gather_boxes', rc)
+    return props, valid.view(torch.bool)
 
 
 # ----------------------------------------------------------------------------------------

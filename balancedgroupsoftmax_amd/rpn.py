@@ -282,19 +282,15 @@ class RPNHead(nn.Module):
         cnt = self._anchor_cache[ckey]
         keep, keep_n = BF.nms_batched(boxes.view(N * L, nmax, 5), cnt, cfg.nms_thr, iou_mode=0,
                                       max_keep=cfg.nms_post)
-        keep = keep.view(N, L, nmax).long()
-        keep_n = keep_n.view(N, L, 1)
-        slot_ok = torch.arange(nmax, device=dev).view(1, 1, nmax) < keep_n
-        kept = torch.gather(boxes, 2, keep.clamp(min=0, max=nmax - 1)[..., None].expand(-1, -1, -1, 5))
-        kept_scores = torch.where(slot_ok, kept[..., 4], kept.new_full((), -1.0))
+        # kept boxes into fixed-shape rows (padding slots score -1), then the per-image top `max_num`
+        # over the levels: two gathers, one launch each (csrc/nms.hip)
+        kept, kept_scores = BF.nms_gather(boxes.view(N * L, nmax, 5), keep, keep_n)
         flat = kept.view(N, L * nmax, 5)
         flat_s = kept_scores.view(N, L * nmax)
         num = min(cfg.max_num, L * nmax)
         if N > 64 or num > 4096:
             raise NotImplementedError('bgs_topk_sorted: <= 64 rows / <= 4096 selected (got %d, %d)'
                                       % (N, num))
-        top_s, top_i = BF.topk_sorted([flat_s.contiguous()], [num], num)
-        top_s, top_i = top_s[:, 0], top_i[:, 0]
-        props = torch.gather(flat, 1, top_i[..., None].expand(-1, -1, 5))
-        valid = top_s >= 0
+        top_s, top_i = BF.topk_sorted([flat_s], [num], num)
+        props, valid = BF.gather_boxes(flat, top_i.view(N, num), top_s.view(N, num))
         return [(props[i], valid[i]) for i in range(N)]

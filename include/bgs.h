@@ -445,6 +445,10 @@ int bgs_grouped_conv3x3_wgrad_nhwc_f32(const float* x, const float* dy, float* d
                                        int H, int W, int C, int groups, int stride, int accumulate,
                                        void* workspace, bgs_stream_t stream);
 
+/* Image batch [N, C <= 4, H, W] fp32 (the reference's NCHW input, resnet.py:522) -> [N, H, W, 4] with the
+ * channel axis zero-padded: the 16-byte-pixel input of the stem conv (one launch instead of pad + copy). */
+int bgs_nchw_to_nhwc4_f32(const float* x, float* y, int N, int C, int H, int W, bgs_stream_t stream);
+
 /* 3x3 / stride 2 / pad 1 max pooling, NHWC (ResNet stem, resnet.py:452). C % 4 == 0.
  * y [N, (H-1)/2+1, (W-1)/2+1, C]. */
 int bgs_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C,
@@ -547,6 +551,17 @@ size_t bgs_nms_workspace_bytes(int P, int nmax);
 int bgs_nms_batched(const float* boxes, const int* counts, int P, int nmax, float iou_thr,
                     int iou_mode, int max_keep, int* keep, int* keep_count, void* workspace,
                     bgs_stream_t stream);
+
+/* The gathers around the RPN's NMS (RPNHead.get_bboxes_single, rpn_head.py:92-103: `proposals = proposals[keep]`,
+ * the concatenation over levels and the final `topk(max_num)` selection), fixed-shape, one launch each:
+ *   bgs_nms_gather: out_boxes [R,nmax,5] = boxes[r, clamp(keep[r,slot], 0, nmax-1)]; out_scores [R,nmax] = that
+ *     box's score for slot < keep_count[r], -1 otherwise (padding slots lose every later top-k);
+ *   bgs_gather_boxes: props [N,num,5] = flat[n, idx[n,j]] (idx int64 row positions, e.g. of bgs_topk_sorted_f32),
+ *     valid [N,num] uint8 = scores[n,j] >= 0. */
+int bgs_nms_gather(const float* boxes, const int* keep, const int* keep_count, int R, int nmax,
+                   float* out_boxes, float* out_scores, bgs_stream_t stream);
+int bgs_gather_boxes(const float* flat, const long long* idx, const float* scores, int N, int T, int num,
+                     float* props, unsigned char* valid, bgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Target assignment without the [G, A] IoU matrix.  Replaces MaxIoUAssigner.assign /

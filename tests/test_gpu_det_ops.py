@@ -1089,3 +1089,9 @@ def test_dist_optimizer_step_uses_the_fused_kernels_on_the_gpu_and_torch_under_t
     assert train.DistOptimizerStep(ps, opt, dict(max_norm=35, norm_type=1)).fused is None
     monkeypatch.setenv('BGS_FUSED_SGD', '0')
     assert train.DistOptimizerStep(ps, opt, dict(max_norm=35, norm_type=2)).fused is None
+
+
+def test_image_batch_to_padded_nhwc_in_one_launch():
+    img = torch.randn(2, 3, 37, 53, generator=torch.Generator().manual_seed(2))
+    ref = F.pad(img.permute(0, 2, 3, 1), (0, 1)).contiguous()
+    assert torch.equal(BF.nchw_to_nhwc4(img.to(DEV)).cpu(), ref)

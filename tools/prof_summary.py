@@ -10,11 +10,12 @@ import sys
 
 CATS = [('conv: halo 3x3', ('conv3x3_halo',)), ('conv: implicit GEMM', ('conv_igemm', 'conv_bf16s', 'conv1x1_bres')),
         ('conv: split-K epilogue', ('conv_splitk',)), ('conv: weight split / wgrad / grouped / pool',
-                                                       ('bfx_split', 'conv_wgrad', 'grouped_conv', 'maxpool', 'fold_', 'wgrad_reduce')),
+                                                       ('bfx_split', 'conv_wgrad', 'grouped_conv', 'maxpool', 'fold_', 'wgrad_reduce', 'nchw_to')),
         ('torch glue (elementwise / copy / cat / reduce / index)', ('at::native', 'rocclr', 'at::cuda', 'cub::', 'rocprim', 'hipcub')),
+        ('optimizer (fused clip + SGD)', ('sgd_',)),
         ('GroupSoftmax + box loss', ('gs_', 'bbox_sl1', 'reduce_partials')),
         ('targets / sampling / RPN loss', ('iou_', 'rpn_loss', 'sample_', 'rcnn_targets', 'random_keys', 'decode_proposals')),
-        ('top-k / NMS', ('topk_', 'nms_')), ('RoIAlign', ('roi_align',)), ('mask / resize', ('mask_', 'resize_'))]
+        ('top-k / NMS', ('topk_', 'nms_', 'gather_boxes')), ('RoIAlign', ('roi_align',)), ('mask / resize', ('mask_', 'resize_'))]
 
 
 def categories(rows, steps):
