@@ -338,6 +338,8 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
     ``np.random.choice`` draw, bit-identical weights for parity runs, costs a D2H sync).
     """
 
+    fused_loss_scale = True       # loss(..., loss_scale=w) folds a stage weight into the kernel's weights
+
     def __init__(self, num_fcs=2, fc_out_channels=1024, gs_config=None, *args, **kwargs):
         super().__init__(num_fcs=num_fcs, fc_out_channels=fc_out_channels, *args, **kwargs)
         gs = gs_config
@@ -450,8 +452,11 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
 
     @force_fp32(apply_to=('cls_score', 'bbox_pred'))
     def loss(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights,
-             reduction_override=None):
-        """Keys: ``loss_cls_bin0..B-1`` and ``loss_bbox`` (no ``acc``), gs_bbox_head_with0.py:147-186."""
+             reduction_override=None, loss_scale=1.0):
+        """Keys: ``loss_cls_bin0..B-1`` and ``loss_bbox`` (no ``acc``), gs_bbox_head_with0.py:147-186.
+        ``loss_scale``: a factor on every term (the cascade's ``stage_loss_weights``,
+        cascade_rcnn.py:283-286) folded into the fused kernel's per-bin / box weights instead of one
+        multiply launch per term."""
         if reduction_override not in (None, 'mean'):
             if reduction_override == 'sum':
                 raise ValueError('avg_factor can not be used with reduction="sum"')
@@ -472,11 +477,13 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
             terms, _total, _avg = BF.gs_head_step(
                 cls_score, labels, self.label2binlabel, self.pred_slice_host,
                 self.others_sample_ratio, self._seed, draw_counter=self._draw,
-                row_weights=label_weights, bin_loss_weight=self._bin_loss_weight_host,
+                row_weights=label_weights,
+                bin_loss_weight=[w * loss_scale for w in self._bin_loss_weight_host]
+                if loss_scale != 1.0 else self._bin_loss_weight_host,
                 bbox_pred=bbox_pred, bbox_targets=bbox_targets, bbox_weights=bbox_weights,
                 num_reg_classes=self.num_reg_classes,
                 beta=self.loss_bbox.beta if bbox_pred is not None else 1.0,
-                box_loss_weight=self.loss_bbox.loss_weight if bbox_pred is not None else 1.0)
+                box_loss_weight=(self.loss_bbox.loss_weight if bbox_pred is not None else 1.0) * loss_scale)
             parts = terms.unbind(0)          # ONE autograd node (its backward: one stack) for all terms
             for i in range(self.num_bins):
                 losses['loss_cls_bin{}'.format(i)] = parts[i]
@@ -496,6 +503,8 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
         if bbox_pred is not None:
             losses['loss_bbox'] = self._loss_bbox(bbox_pred, labels, bbox_targets, bbox_weights,
                                                   reduction_override, label_weights, n_real)
+        if loss_scale != 1.0:
+            losses = {k: v * loss_scale for k, v in losses.items()}
         return losses
 
     @force_fp32(apply_to=('cls_score', ))

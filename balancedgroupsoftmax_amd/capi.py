@@ -185,6 +185,8 @@ SIGNATURES = {
                                           c_ptr]),
     'bgs_sample_rois': (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                        ctypes.c_uint64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'bgs_sample_rois_ex': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                          ctypes.c_uint64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'bgs_random_keys': (ctypes.c_int, [ctypes.c_uint64, c_ptr, ctypes.c_int, c_ptr, c_ptr]),
     'bgs_decode_proposals': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, c_f32p,
                                             c_ptr, c_f32p, ctypes.c_int, c_ptr, c_ptr, c_ptr,

@@ -302,6 +302,9 @@ constexpr int kMaxImgsS = 16;
 struct CandTable {
   const int* assigned[kMaxImgsS];   // [count] int32: -1 / 0 / gt index + 1
   int count[kMaxImgsS];
+  int n_gt[kMaxImgsS];              // leading candidates that are GT boxes (add_gt_as_proposals)
+  int* gt_ind;                      // null, or [N, num]: assigned[inds] - 1 (pos_assigned_gt_inds; -1 = none)
+  uint8_t* is_gt;                   // null, or [N, num]: inds < n_gt (SamplingResult.pos_is_gt)
 };
 
 __global__ __launch_bounds__(kThreadsS) void sample_rois_kernel(CandTable T, int num, int n_exp_pos,
@@ -376,15 +379,35 @@ __global__ __launch_bounds__(kThreadsS) void sample_rois_kernel(CandTable T, int
     inds[(size_t)n * num + j] = idx;
     is_pos[(size_t)n * num + j] = p;
     valid[(size_t)n * num + j] = v;
+    if (T.gt_ind) T.gt_ind[(size_t)n * num + j] = T.assigned[n][idx] - 1;
+    if (T.is_gt) T.is_gt[(size_t)n * num + j] = idx < (long long)T.n_gt[n] ? 1 : 0;
   }
 }
 
 }  // namespace
 
+extern "C" int bgs_sample_rois_ex(const int* const* host_assigned, const int* host_counts,
+                                  const int* host_gt_counts, int N, int num, float pos_fraction,
+                                  uint64_t seed, const long long* draw_counter, long long* inds,
+                                  uint8_t* is_pos, uint8_t* valid, int* gt_ind, uint8_t* is_gt,
+                                  bgs_stream_t stream);
+
 extern "C" int bgs_sample_rois(const int* const* host_assigned, const int* host_counts, int N,
                                int num, float pos_fraction, uint64_t seed,
                                const long long* draw_counter, long long* inds, uint8_t* is_pos,
                                uint8_t* valid, bgs_stream_t stream) {
+  return bgs_sample_rois_ex(host_assigned, host_counts, nullptr, N, num, pos_fraction, seed, draw_counter,
+                            inds, is_pos, valid, nullptr, nullptr, stream);
+}
+
+// + gt_ind [N, num] int32 = assigned[inds] - 1 (`pos_assigned_gt_inds` of the sampled rows, sampling_result.py:
+// 7-24; -1 for negatives) and is_gt [N, num] uint8 = inds < host_gt_counts[n] (`pos_is_gt`: the GT boxes that
+// `add_gt_as_proposals` put in front of the candidates); either may be NULL.
+extern "C" int bgs_sample_rois_ex(const int* const* host_assigned, const int* host_counts,
+                                  const int* host_gt_counts, int N, int num, float pos_fraction,
+                                  uint64_t seed, const long long* draw_counter, long long* inds,
+                                  uint8_t* is_pos, uint8_t* valid, int* gt_ind, uint8_t* is_gt,
+                                  bgs_stream_t stream) {
   if (N < 0 || N > kMaxImgsS || num <= 0 || !(pos_fraction >= 0.f && pos_fraction <= 1.f))
     return BGS_ERR_INVALID_ARG;
   if (N == 0) return BGS_OK;
@@ -393,11 +416,15 @@ extern "C" int bgs_sample_rois(const int* const* host_assigned, const int* host_
   for (int i = 0; i < kMaxImgsS; ++i) {
     T.assigned[i] = nullptr;
     T.count[i] = 0;
+    T.n_gt[i] = 0;
   }
+  T.gt_ind = gt_ind;
+  T.is_gt = is_gt;
   for (int i = 0; i < N; ++i) {
     if (host_counts[i] <= 0 || host_counts[i] > kMaxCand || !host_assigned[i]) return BGS_ERR_UNSUPPORTED;
     T.assigned[i] = host_assigned[i];
     T.count[i] = host_counts[i];
+    T.n_gt[i] = host_gt_counts ? host_gt_counts[i] : 0;
   }
   const int n_exp_pos = (int)((double)num * (double)pos_fraction);
   hipLaunchKernelGGL(sample_rois_kernel, dim3(N), dim3(kThreadsS), 0, (hipStream_t)stream, T, num,

@@ -19,6 +19,22 @@ from . import builder
 from .registry import DETECTORS
 
 
+_GT_ROWS = {}
+
+
+def _gt_index_row(G, device):
+    """``[1 .. G]`` int32 on ``device`` (the assignment of the GT boxes `add_gt_as_proposals` puts in front
+    of the candidates, AssignResult.add_gt_): cached per (G, device) instead of an arange launch per
+    image, stage and iteration."""
+    key = (int(G), str(device))
+    t = _GT_ROWS.get(key)
+    if t is None:
+        if len(_GT_ROWS) > 4096:
+            _GT_ROWS.clear()
+        t = _GT_ROWS[key] = torch.arange(1, int(G) + 1, device=device, dtype=torch.int32)
+    return t
+
+
 @DETECTORS.register_module
 class TwoStageDetector(nn.Module):
 
@@ -101,7 +117,7 @@ class TwoStageDetector(nn.Module):
             if add_gt:      # base_sampler.py:49-53 + AssignResult.add_gt_
                 G = gt_bboxes[i].size(0)
                 b = torch.cat([gt_bboxes[i][:, :4].float(), b], 0)
-                a = torch.cat([torch.arange(1, G + 1, device=a.device, dtype=torch.int32), a])
+                a = torch.cat([_gt_index_row(G, a.device), a])
             boxes_l.append(b.contiguous())
             assigned_l.append(a.contiguous())
             if rcnn_hook is not None:      # test hook: caller-supplied draw
@@ -113,10 +129,21 @@ class TwoStageDetector(nn.Module):
                 raise NotImplementedError('bgs_sample_rois sorts <= 4096 candidates per image in LDS '
                                           '(rpn_proposal.max_num + GT boxes)')
             # one launch for the batch (csrc/sampler.hip: sort of (class, random key) composites)
-            inds_all, _, valid_all = BF.sample_rois(assigned_l, sc.num, sc.pos_fraction)
+            need_extra = self.with_mask or isinstance(self.bbox_head, nn.ModuleList)
+            res = BF.sample_rois(assigned_l, sc.num, sc.pos_fraction,
+                                 gt_counts=[int(g.size(0)) if add_gt else 0 for g in gt_bboxes]
+                                 if need_extra else None)
+            inds_all, valid_all = res[0], res[2].view(torch.bool)
             inds_l = [inds_all[i] for i in range(N)]
-            valid_l = [valid_all[i].bool() for i in range(N)]
-        if self.with_mask or isinstance(self.bbox_head, nn.ModuleList):
+            valid_l = [valid_all[i] for i in range(N)]
+            if need_extra:
+                # what the mask branch and the cascade refinement read from the SamplingResult come out
+                # of the sampling launch itself (bgs_sample_rois_ex) instead of ~13 gather / compare /
+                # stack launches per stage
+                self._sampled_gt_inds = res[3]
+                self._sampled_valid = valid_all
+                self._sampled_is_gt = res[4].view(torch.bool)
+        if rcnn_hook is not None and (self.with_mask or isinstance(self.bbox_head, nn.ModuleList)):
             # (only the mask branch and the cascade refinement read these: skipped for the plain
             #  box detectors, ~10 small launches)
             # gt index of every sampled RoI (pos_assigned_gt_inds for the mask targets), -1 = none
@@ -376,8 +403,12 @@ class CascadeRCNN(TwoStageDetector):
                                                     rc=rc, head=head)
             feats = ext(x[:ext.num_inputs], rois)
             cls_score, bbox_pred = head(feats, nhwc=True)
-            for name, value in head.loss(cls_score, bbox_pred, *targets).items():
-                losses['s{}.{}'.format(i, name)] = value * lw if 'loss' in name else value
+            if getattr(head, 'fused_loss_scale', False):      # GS heads: the stage weight rides in the kernel
+                for name, value in head.loss(cls_score, bbox_pred, *targets, loss_scale=lw).items():
+                    losses['s{}.{}'.format(i, name)] = value
+            else:
+                for name, value in head.loss(cls_score, bbox_pred, *targets).items():
+                    losses['s{}.{}'.format(i, name)] = value * lw if 'loss' in name else value
             if i < self.num_stages - 1:       # refine (cascade_rcnn.py:291-296), fixed shape
                 proposal_list = self._refined_proposals(head, rois, targets[0], bbox_pred, img_meta,
                                                         rc.sampler.num)
@@ -520,8 +551,12 @@ class HybridTaskCascade(CascadeRCNN):
                                                     rc=rc, head=head)
             feats = self._fused_roi_feats(ext, x, rois, semantic_feat, 'bbox')
             cls_score, bbox_pred = head(feats, nhwc=True)
-            for name, value in head.loss(cls_score, bbox_pred, *targets).items():
-                losses['s{}.{}'.format(i, name)] = value * lw if 'loss' in name else value
+            if getattr(head, 'fused_loss_scale', False):      # GS heads: the stage weight rides in the kernel
+                for name, value in head.loss(cls_score, bbox_pred, *targets, loss_scale=lw).items():
+                    losses['s{}.{}'.format(i, name)] = value
+            else:
+                for name, value in head.loss(cls_score, bbox_pred, *targets).items():
+                    losses['s{}.{}'.format(i, name)] = value * lw if 'loss' in name else value
             refined = None
             if self.interleaved or i < self.num_stages - 1:
                 refined = self._refined_proposals(head, rois, targets[0], bbox_pred, img_meta, num)

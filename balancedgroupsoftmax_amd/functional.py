@@ -1694,10 +1694,12 @@ def sample_pos_neg(assigned, num, pos_fraction, neg_pos_ub=-1):
     return pos, neg
 
 
-def sample_rois(assigned_list, num, pos_fraction):
+def sample_rois(assigned_list, num, pos_fraction, gt_counts=None):
     """RoI-head RandomSampler for a batch: per image ``assigned [A_n]`` int32 (candidates = GT
     boxes then proposals) -> ``inds [N, num]`` int64 (positives first), ``is_pos``, ``valid``
-    ``[N, num]`` uint8.  One launch; ``A_n <= 4096``."""
+    ``[N, num]`` uint8.  One launch; ``A_n <= 4096``.  ``gt_counts`` (list of ints: the GT boxes in
+    front of each image's candidates): also returns ``gt_ind [N, num]`` int32 (assigned gt index of
+    every sampled row, -1 = none) and ``is_gt [N, num]`` uint8 from the same launch."""
     _require_cuda(*assigned_list)
     lib = capi.load()
     N = len(assigned_list)
@@ -1709,6 +1711,17 @@ def sample_rois(assigned_list, num, pos_fraction):
     is_pos = torch.empty((N, num), dtype=torch.uint8, device=dev)
     valid = torch.empty((N, num), dtype=torch.uint8, device=dev)
     seed = (torch.initial_seed() * 0x9E3779B1 + 0x68E31DA4) & 0xFFFFFFFFFFFFFFFF
+    if gt_counts is not None:
+        gt_ind = torch.empty((N, num), dtype=torch.int32, device=dev)
+        is_gt = torch.empty((N, num), dtype=torch.uint8, device=dev)
+        rc = lib.bgs_sample_rois_ex(_c_ptr_array(assigned_list),
+                                    _c_int_array([int(a.numel()) for a in assigned_list]),
+                                    _c_int_array([int(g) for g in gt_counts]), N, int(num),
+                                    float(pos_fraction), seed, capi.ptr(ctr), capi.ptr(inds),
+                                    capi.ptr(is_pos), capi.ptr(valid), capi.ptr(gt_ind), capi.ptr(is_gt),
+                                    capi.current_stream(dev))
+        capi.check('bgs_sample_rois_ex', rc)
+        return inds, is_pos, valid, gt_ind, is_gt
     rc = lib.bgs_sample_rois(_c_ptr_array(assigned_list),
                              _c_int_array([int(a.numel()) for a in assigned_list]), N, int(num),
                              float(pos_fraction), seed, capi.ptr(ctr), capi.ptr(inds),

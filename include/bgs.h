@@ -629,6 +629,15 @@ int bgs_sample_pos_neg(const int* assigned, int N, int A, int num, float pos_fra
 int bgs_sample_rois(const int* const* host_assigned, const int* host_counts, int N, int num,
                     float pos_fraction, uint64_t seed, const long long* draw_counter, long long* inds,
                     uint8_t* is_pos, uint8_t* valid, bgs_stream_t stream);
+/* The same draw, also emitting what the mask branch and the cascade refinement read from the SamplingResult
+ * (mmdet/core/bbox/samplers/sampling_result.py:7-24): gt_ind [N, num] int32 = assigned[inds] - 1
+ * (`pos_assigned_gt_inds`; -1 for negatives) and is_gt [N, num] uint8 = inds < host_gt_counts[n] (`pos_is_gt`:
+ * the GT boxes `add_gt_as_proposals` put in front of the candidates, base_sampler.py:49-53).  Either output and
+ * host_gt_counts may be NULL. */
+int bgs_sample_rois_ex(const int* const* host_assigned, const int* host_counts, const int* host_gt_counts,
+                       int N, int num, float pos_fraction, uint64_t seed, const long long* draw_counter,
+                       long long* inds, uint8_t* is_pos, uint8_t* valid, int* gt_ind, uint8_t* is_gt,
+                       bgs_stream_t stream);
 
 /* Sampling keys for RandomSampler (mmdet/core/bbox/samplers/random_sampler.py:19-53) drawn on the
  *   device: out[i] = 62-bit splitmix64(seed, *draw_counter, i), i < n.  draw_counter: device int64
