@@ -101,8 +101,13 @@ class TwoStageDetector(nn.Module):
         rc = self.train_cfg.rcnn if rc is None else rc
         ac, sc = rc.assigner, rc.sampler
         N = len(proposal_list)
-        props = torch.stack([p for p, _ in proposal_list]).contiguous()            # [N, P, 5]
-        pvalid = torch.stack([v for _, v in proposal_list]).to(torch.uint8).contiguous()
+        if hasattr(proposal_list, 'batched'):       # rpn.ProposalList: the batch tensors themselves
+            props, pv = proposal_list.batched
+            props = props.contiguous()
+            pvalid = (pv.view(torch.uint8) if pv.dtype == torch.bool else pv.to(torch.uint8)).contiguous()
+        else:
+            props = torch.stack([p for p, _ in proposal_list]).contiguous()            # [N, P, 5]
+            pvalid = torch.stack([v for _, v in proposal_list]).to(torch.uint8).contiguous()
         gt_cat = torch.cat([g[:, :4] for g in gt_bboxes]).float().contiguous()
         offs = [0]
         for g in gt_bboxes:
@@ -386,7 +391,8 @@ class CascadeRCNN(TwoStageDetector):
                                     [m['img_shape'] for m in img_meta], head.target_means,
                                     head.target_stds)
             keep = self._sampled_valid & ~self._sampled_is_gt
-            return [(boxes[j * num:(j + 1) * num], keep[j]) for j in range(n_img)]
+            from .rpn import ProposalList
+            return ProposalList(boxes.view(n_img, num, 4), keep)
 
     def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
                       gt_masks=None, proposals=None, samplers=None):

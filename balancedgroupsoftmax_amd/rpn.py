@@ -77,6 +77,17 @@ class AnchorGenerator(object):
         return valid[:, None].expand(valid.size(0), self.num_base_anchors).reshape(-1)
 
 
+class ProposalList(list):
+    """``[(props_i [P, C], valid_i [P]) ...]`` — the per-image list the reference passes around — that also
+    carries the batch tensors ``(props [N, P, C], valid [N, P] bool)`` its entries are views of, so the
+    fixed-shape consumers (`_sample_rois_fused`) read them without re-stacking (two cat launches and a cast
+    per stage)."""
+
+    def __init__(self, props, valid):
+        super().__init__([(props[i], valid[i]) for i in range(props.shape[0])])
+        self.batched = (props, valid)
+
+
 @HEADS.register_module
 class RPNHead(nn.Module):
 
@@ -293,4 +304,4 @@ class RPNHead(nn.Module):
                                       % (N, num))
         top_s, top_i = BF.topk_sorted([flat_s], [num], num)
         props, valid = BF.gather_boxes(flat, top_i.view(N, num), top_s.view(N, num))
-        return [(props[i], valid[i]) for i in range(N)]
+        return ProposalList(props, valid)
