@@ -531,7 +531,9 @@ __device__ __forceinline__ bf16x4_bits gcs_pack_bf16(const f32x4 v) {
 // Stride-1 layers: LDS-resident patch.  Workgroup = 8 x 16 pixel tile x 64 channels; its 10 x 18
 // pixel patch (180 pixels x 128 B = 23 KB, half of the fp32 kernel's) reaches LDS once by DMA.
 //   * LDS layout: pixel PAIR pp at 256 pp bytes = 16 chunks of 16 B (chunk id = 8 * parity + channel
-//     octet); chunk id sits in slot id ^ (pp & 15).  The DMA writes lane-linearly, so the swizzle is
+//     octet); chunk id sits in slot id ^ (pp % 9) — the pair's position within its 9-pair patch row, so the
+//     address is AFFINE in the tile row (the first version keyed on pp & 15: hipcc materialised the 72
+//     addresses of a wave in registers, 164 VGPRs, three waves per SIMD).  The DMA writes lane-linearly, so the swizzle is
 //     applied to the SOURCE chunk each lane fetches.  A fragment read (ds_read_b64: 16 consecutive
 //     pixels, the same channel quad; four quads per pixel = two adjacent chunks) touches every slot
 //     exactly twice: 512 B in the minimal two LDS cycles.
@@ -540,7 +542,7 @@ constexpr int SGPAIRS = (SGPIX + 1) / 2;                                        
 constexpr int SGDMA = (SGPAIRS + 3) / 4;                                                      // 23 pieces
 
 template <int CG>
-__global__ __launch_bounds__(256, CG == 32 ? 2 : 3) void grouped_conv3x3_bf16s_lds_kernel(
+__global__ __launch_bounds__(256, CG >= 16 ? 3 : 5) void grouped_conv3x3_bf16s_lds_kernel(
     const __bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     __bf16* __restrict__ y, const unsigned* __restrict__ zero_page, int N, int H, int W, int C,
     int tiles_y, int tiles_x, int relu) {
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(256, CG == 32 ? 2 : 3) void grouped_conv3x3_bf16s_l
   const __bf16* xn = x + (size_t)n * H * W * C + c0;
   for (int d = wave; d < SGDMA; d += 4) {
     const int pp = 4 * d + (lane >> 4);
-    const int id = (lane & 15) ^ (pp & 15);        // source chunk of this slot
+    const int id = (lane & 15) ^ (pp % (SGPW / 2)); // source chunk of this slot (key: pair within the patch row)
     const int P = 2 * pp + (id >> 3);
     const int pr = P / SGPW, pc = P - pr * SGPW;
     const int hi = h0 + pr, wi = w0 + pc;
@@ -606,14 +608,17 @@ __global__ __launch_bounds__(256, CG == 32 ? 2 : 3) void grouped_conv3x3_bf16s_l
     for (int s2 = 0; s2 < 3; ++s2) {
 #pragma unroll
       for (int a = 0; a < SGTH; ++a) {
-        const int P = (a + r) * SGPW + i + s2;
-        const int pp = P >> 1;
+        // pair index written as (row) * 9 + (column pair): the row term is a compile-time constant
+        const int cp = (i + s2) >> 1, par = (i + s2) & 1;
+        const int pp = (a + r) * (SGPW / 2) + cp;
 #pragma unroll
         for (int kh = 0; kh < KH; ++kh) {
           const int q = qbase + kh * 4;
-          const int id = ((P & 1) << 3) | (q >> 1);
+          const int id = (par << 3) | (q >> 1);
+          // swizzle key = the pair's position within its patch row, (i + s2) >> 1: independent of the
+          // tile row a, so the eight reads of a tap differ by the compile-time offset 9 * 256 * a
           const bf16x4_bits av = *reinterpret_cast<const bf16x4_bits*>(
-              lds + pp * 256 + ((id ^ (pp & 15)) << 4) + ((q & 1) << 3));
+              lds + pp * 256 + ((id ^ cp) << 4) + ((q & 1) << 3));
           acc[a] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bv[r * 3 + s2][kh], av, acc[a], 0, 0, 0);
         }
       }
