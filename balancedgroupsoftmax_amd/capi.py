@@ -90,6 +90,7 @@ SIGNATURES = {
                                   + [c_ptr]),
     'bgs_conv_bfx_weight_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     'bgs_conv_bfx_split_weights': (ctypes.c_int, [c_f32p, c_ptr, ctypes.c_int, ctypes.c_int, c_ptr]),
+    'bgs_conv_dgrad_parity_enable': (None, [ctypes.c_int]),
     'bgs_conv_bfx_split_weights_dgrad': (ctypes.c_int, [c_f32p, c_ptr] + [ctypes.c_int] * 4 + [c_ptr]),
     'bgs_conv_bfx_workspace_bytes': (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int]),
     'bgs_conv2d_nhwc_f32_bfx_ws': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, c_f32p, c_f32p]

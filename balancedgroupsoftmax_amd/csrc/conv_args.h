@@ -41,7 +41,23 @@ struct ConvArgs {
   // re-read of the same pixels for the next Cout tile hit that XCD's L2 (PMC: 2.46 GB fetched per
   // 158-GFLOP layer before, profiles/r2d_pmc_conv.md).
   int tiles_m, tiles_n, chunk;
+  // Parity-class row order (stride-2 data gradients, conv_bfx.hip UP == 3): the GEMM rows are the output
+  // pixels GROUPED BY (y & 1, x & 1) — class c = 2 (y & 1) + (x & 1) occupies virtual rows
+  // [c * rm_mcp, c * rm_mcp + rm_mc), rm_mcp = rm_mc rounded up to the 64-row tile — so that the filter
+  // taps that meet a tile's rows are the same for the whole tile (the other taps see the zeros of the
+  // upsampled input and are skipped).  conv_out_row maps a virtual row to its pixel.
+  int rowmap = 0, rm_hh = 0, rm_wh = 0, rm_mc = 0, rm_mcp = 0;
 };
+
+// virtual GEMM row -> output pixel index (n * Ho + y) * Wo + x; -1 for the padding rows of a class
+__device__ __forceinline__ long long conv_out_row(const ConvArgs& p, int m) {
+  const int cls = m / p.rm_mcp, r = m - cls * p.rm_mcp;
+  if (r >= p.rm_mc) return -1;
+  const int hw = p.rm_hh * p.rm_wh;
+  const int n = r / hw, rem = r - n * hw;
+  const int i = rem / p.rm_wh, j = rem - i * p.rm_wh;
+  return ((long long)n * p.Ho + 2 * i + (cls >> 1)) * p.Wo + 2 * j + (cls & 1);
+}
 
 // Fused epilogue of a (64*MB) x (64*NB) workgroup tile held as MB x NB accumulators of the 32x32
 // MFMA per wave (2 x 2 waves).  C/D layout of every 32x32 MFMA on gfx950 (dtype-independent):
@@ -165,10 +181,16 @@ __device__ __forceinline__ void conv_store_tile_lds(const ConvArgs& p, const f32
     const int i = r0 + ps * RPP;
     const int m = m0 + i;
     if (m >= p.M) break;
+    size_t orow = (size_t)m;                             // output pixel of this GEMM row
+    if (p.rowmap) {
+      const long long rr = conv_out_row(p, m);
+      if (rr < 0) continue;
+      orow = (size_t)rr;
+    }
     f32x4 v = *reinterpret_cast<const f32x4*>(scratch + i * LD + c4);
     v += bias;
     if (p.res_mode == 1) {
-      v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + j);
+      v += *reinterpret_cast<const f32x4*>(p.res + orow * p.Cout + j);
     } else if (p.res_mode == 2) {
       const int n = m / hw;
       const int rem = m - n * hw;
@@ -181,11 +203,11 @@ __device__ __forceinline__ void conv_store_tile_lds(const ConvArgs& p, const f32
       for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
     }
     if (p.mask) {
-      const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m * p.Cout + j);
+      const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + orow * p.Cout + j);
 #pragma unroll
       for (int t = 0; t < 4; ++t) v[t] = mk[t] > 0.f ? v[t] : 0.f;
     }
-    *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + j) = v;
+    *reinterpret_cast<f32x4*>(p.y + orow * p.Cout + j) = v;
   }
 }
 

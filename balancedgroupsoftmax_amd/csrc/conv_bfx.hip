@@ -329,7 +329,29 @@ __global__ __launch_bounds__(kThreads, NS == 1 ? (DMA_NST == 3 ? 8 : 6) : (DMA_N
   int a_hi0, a_wi0;
   const float* a_base;
   bool a_ok;
-  {
+  // UP == 3: stride-2 data gradient with the rows grouped by output-pixel parity (ConvArgs::rowmap): the
+  // tile's rows share (y & 1, x & 1), so only the taps kr = r_first, r_first + 2, .. / ks = s_first, .. meet
+  // non-zero entries of the zero-upsampled dy — the K loop runs over those taps alone (1, 2 or 4 of the 9
+  // of a 3x3 filter: a quarter of the MFMAs and operand loads of the UP == 2 form; none at all for three of
+  // the four classes of a 1x1 filter, whose rows are just residual / mask epilogues)
+  int r_first = 0, s_first = 0, n_r = 0, n_s = 0;
+  if (UP == 3) {
+    const int cls = m0 / p.rm_mcp;                      // tile-uniform: rm_mcp is a multiple of the tile
+    const int r = m0 + arow - cls * p.rm_mcp;
+    a_ok = r < p.rm_mc;
+    const int rr = a_ok ? r : 0;
+    const int hw = p.rm_hh * p.rm_wh;
+    const int n = rr / hw;
+    const int rem = rr - n * hw;
+    const int i = rem / p.rm_wh, j = rem - i * p.rm_wh;
+    a_hi0 = 2 * i + (cls >> 1) - p.pad;
+    a_wi0 = 2 * j + (cls & 1) - p.pad;
+    a_base = p.x + (size_t)n * p.H * p.W * p.Cin;
+    r_first = (p.pad - (cls >> 1)) & 1;
+    s_first = (p.pad - (cls & 1)) & 1;
+    n_r = r_first < p.R ? (p.R - r_first + 1) / 2 : 0;
+    n_s = s_first < p.S ? (p.S - s_first + 1) / 2 : 0;
+  } else {
     const int m = m0 + arow;
     a_ok = m < p.M;
     const int mm = a_ok ? m : 0;
@@ -361,7 +383,9 @@ __global__ __launch_bounds__(kThreads, NS == 1 ? (DMA_NST == 3 ? 8 : 6) : (DMA_N
   const int nk_all = q.KC;
   const int kt_begin = p.partial ? blockIdx.z * p.kt_per_split : 0;
   const int kt_end = p.partial ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
-  const int nk = kt_end - kt_begin;
+  const int c16n = p.Cin >> 4;                          // (UP == 3: Cin % 16 == 0, no split-K)
+  const int nk = UP == 3 ? n_r * n_s * c16n : kt_end - kt_begin;
+  int t_a = 0, t_b = 0, c16 = 0;                        // UP == 3: tap (r_first + 2 t_a, s_first + 2 t_b), channel chunk
   int kg = kt_begin * 16 + aq * 4;
   int kc, kr, ks;
   {
@@ -388,6 +412,22 @@ __global__ __launch_bounds__(kThreads, NS == 1 ? (DMA_NST == 3 ? 8 : 6) : (DMA_N
       asrc = (live && a_ok && kg < p.K) ? a_ptr : reinterpret_cast<const float*>(zero_page);
       a_ptr += 16;
       kg += 16;
+    } else if (UP == 3) {
+      const int tkr = r_first + 2 * t_a, tks = s_first + 2 * t_b;
+      const int hi = (a_hi0 + tkr) >> 1, wi = (a_wi0 + tks) >> 1;     // both sums are even
+      const bool ok = live && a_ok && hi >= 0 && wi >= 0 && hi < p.H && wi < p.W;
+      asrc = ok ? a_base + ((size_t)hi * p.W + wi) * p.Cin + c16 * 16 + aq * 4
+                : reinterpret_cast<const float*>(zero_page);
+      const size_t kstep = (size_t)((tkr * p.S + tks) * c16n + c16) * b_step;
+      b_ptr0 = b_src[0] + kstep;
+      b_ptr1 = b_src[1] + kstep;
+      if (++c16 == c16n) {
+        c16 = 0;
+        if (++t_b == n_s) {
+          t_b = 0;
+          ++t_a;
+        }
+      }
     } else {
       int hi = a_hi0 + kr, wi = a_wi0 + ks;
       bool ok = live && a_ok && kg < p.K && hi >= 0 && wi >= 0;
@@ -1662,6 +1702,48 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   BGS_RETURN_LAUNCH_STATUS();
 }
 
+// Stride-2 data gradient with parity-class rows (UP == 3 of the operand ring): q.c describes the
+// zero-upsampled problem exactly as for UP == 2 (x = dy [N, H, W, Cin], y = dx [N, Ho, Wo, Cout], stride 1,
+// pad = R - 1 - pad_fwd).  Eligible: even Ho / Wo, Cin % 16 == 0, the vectorised epilogue, residual mode 0 / 1.
+// Returns -1 when not eligible (the caller takes the UP == 2 path).
+int g_dgrad_parity = -1;     // BGS_DGRAD_S2_PARITY=0: the zero-upsampled form everywhere (A/B)
+int launch_conv_bfx_dgrad_parity(BfxArgs& q, hipStream_t st) {
+  ConvArgs& p = q.c;
+  if (g_dgrad_parity < 0) {
+    const char* e = getenv("BGS_DGRAD_S2_PARITY");
+    g_dgrad_parity = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  if (!g_dgrad_parity) return -1;
+  if ((p.Ho & 1) || (p.Wo & 1) || (p.Cin & 15) || p.R != p.S || (p.res_mode != 0 && p.res_mode != 1)) return -1;
+  p.partial = nullptr;
+  p.kt_per_split = 0;
+  const uintptr_t al = (uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.mask | (uintptr_t)p.x;
+  if ((p.Cout & 3) || (al & 15)) return -1;
+  q.zero = zero_page_device();
+  if (!q.zero) return BGS_ERR_LAUNCH;
+  p.rowmap = 1;
+  p.rm_hh = p.Ho >> 1;
+  p.rm_wh = p.Wo >> 1;
+  p.rm_mc = p.N * p.rm_hh * p.rm_wh;
+  p.rm_mcp = (p.rm_mc + 63) & ~63;
+  if ((long long)4 * p.rm_mcp > 0x7fffffffLL) return -1;
+  p.M = 4 * p.rm_mcp;                                   // virtual rows (the four classes, each padded to the tile)
+  p.tiles_m = p.M / 64;
+  p.tiles_n = (p.Cout + 63) / 64;
+  p.chunk = (p.tiles_m * p.tiles_n + 7) / 8;
+  dim3 grid((unsigned)(8 * p.chunk));
+  g_last_tile = 0x2000 | 11;                            // bit 13: the parity-class data-gradient order ran
+  g_last_splits = 1;
+  g_last_dma = 1;
+  g_last_nst = 3;
+  bgs_internal_census_bump(BGS_CENSUS_DMA_RING64);
+  if (q.ns == 1)
+    hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<3, false, 0, 1, 3>), grid, dim3(kThreads), 0, st, q);
+  else
+    hipLaunchKernelGGL((conv_igemm_bfx_dma_kernel<3, false, 0, 3, 3>), grid, dim3(kThreads), 0, st, q);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
 inline int bfx_kc(int K) { return 2 * ((K + 31) / 32); }
 
 }  // namespace
@@ -1794,8 +1876,15 @@ extern "C" int bgs_conv2d_dgrad_nhwc_f32_bfx_ws(const float* dy, const void* wt_
   p.res_mode = residual_mode;
   q.ws = reinterpret_cast<const __bf16*>(wt_split);
   q.KC = bfx_kc(p.K);
+  if (stride == 2) {       // rows grouped by output-pixel parity: only the taps that meet non-zeros are multiplied
+    const int rc = launch_conv_bfx_dgrad_parity(q, (hipStream_t)stream);
+    if (rc >= 0) return rc;
+  }
   return launch_conv_bfx(q, stride, (hipStream_t)stream, workspace, workspace_bytes);
 }
+
+// tuning / test hook: 0 = stride-2 data gradients in the zero-upsampled form, 1 = parity-class rows (default)
+extern "C" void bgs_conv_dgrad_parity_enable(int on) { g_dgrad_parity = on ? 1 : 0; }
 
 extern "C" size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;

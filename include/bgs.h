@@ -351,6 +351,10 @@ int bgs_conv2d_dgrad_nhwc_f32_bfx_ws(const float* dy, const void* wt_split, cons
                                      int Cout, int R, int S, int stride, int pad,
                                      int residual_mode, int planes, void* workspace,
                                      size_t workspace_bytes, bgs_stream_t stream);
+/* Tuning / test hook: stride-2 data gradients with the GEMM rows grouped by output-pixel parity (only the
+ * filter taps that meet non-zeros of the zero-upsampled dy are multiplied: 1, 2 or 4 of 9; default 1) or in the
+ * plain zero-upsampled form (0).  Bit-identical results.  Process-wide. */
+void bgs_conv_dgrad_parity_enable(int on);
 size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias, float* y,
                                   int N, int H, int W, int Cin, int Cout, int relu, int planes,

@@ -1095,3 +1095,52 @@ def test_image_batch_to_padded_nhwc_in_one_launch():
     img = torch.randn(2, 3, 37, 53, generator=torch.Generator().manual_seed(2))
     ref = F.pad(img.permute(0, 2, 3, 1), (0, 1)).contiguous()
     assert torch.equal(BF.nchw_to_nhwc4(img.to(DEV)).cpu(), ref)
+
+
+@pytest.mark.parametrize('case', [
+    # name, N, H, W (input of the forward conv), Cin, Cout, k, pad, residual + mask
+    ('l2.0.conv2', 2, 40, 56, 128, 128, 3, 1, False),
+    ('l3.0.conv2 + fork', 1, 24, 36, 64, 256, 3, 1, True),
+    ('l3.0.downsample', 2, 20, 28, 256, 512, 1, 0, True),
+    ('ragged tiles', 1, 18, 22, 48, 80, 3, 1, False),
+])
+@pytest.mark.parametrize('math', ['bf16x6', 'bf16'])
+def test_stride2_data_gradient_parity_rows_equal_the_zero_upsampled_form(case, math):
+    """Stride-2 data gradients with the GEMM rows grouped by output-pixel parity (conv_bfx.hip UP == 3: only
+    the taps that meet non-zeros of the zero-upsampled dy are multiplied; three of the four classes of a 1x1
+    filter are pure epilogues) against the zero-upsampled form (the skipped products are exact zeros; equal up to
+    the summation order of a split-K run) and against torch autograd."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    name, N, H, W, Cin, Cout, k, pad, fork = case
+    rs = np.random.RandomState(len(name) + Cout)
+    x = rs.randn(N, H, W, Cin).astype(np.float32)
+    w = (rs.randn(Cout, Cin, k, k) / np.sqrt(Cin * k * k)).astype(np.float32)
+    Ho, Wo = (H + 2 * pad - k) // 2 + 1, (W + 2 * pad - k) // 2 + 1
+    dy = rs.randn(N, Ho, Wo, Cout).astype(np.float32)
+    res = rs.randn(N, H, W, Cin).astype(np.float32) if fork else None
+    mask = rs.randn(N, H, W, Cin).astype(np.float32) if fork else None
+    edx, _ = _torch_conv_grads(x, w, dy, 2, pad)
+    if fork:
+        edx = (edx + res) * (mask > 0)
+    wk = dev(krsc(w))
+    prev = BF.set_conv_math(math)
+    outs = []
+    try:
+        for on in (1, 0):
+            lib.bgs_conv_dgrad_parity_enable(on)
+            dx = BF.conv2d_dgrad_nhwc(dev(dy), wk, (H, W), stride=2, pad=pad,
+                                      residual=None if res is None else dev(res),
+                                      mask=None if mask is None else dev(mask))
+            tile = BF.conv_bfx_last_launch()['tile']
+            assert bool(tile & 0x2000) == bool(on), hex(tile)
+            outs.append(dx.cpu())
+    finally:
+        lib.bgs_conv_dgrad_parity_enable(1)
+        BF.set_conv_math(prev)
+    # (the zero-upsampled arm may take split-K: same products, another summation order)
+    scale = float(outs[1].abs().max())
+    assert float((outs[0] - outs[1]).abs().max()) <= (2e-6 if math == 'bf16x6' else 2e-6) * scale, \
+        float((outs[0] - outs[1]).abs().max()) / scale
+    tol = 2e-5 if math == 'bf16x6' else 3e-2
+    assert np.abs(outs[0].numpy() - edx).max() <= tol * np.abs(edx).max()
