@@ -53,6 +53,11 @@ struct Bf16sArgs {
   int M, K, KC;
   int relu, res_mode, res_bf16;
   int tiles_m, tiles_n, chunk;
+  // tile order inside an XCD's band of row tiles (mpx row tiles per XCD): sub-bands of `sb` row tiles, inside a
+  // sub-band column-tile-major — the workgroups in flight on an XCD (96) then share ONE sub-band of A (<= ~2 MB:
+  // L2-resident, re-read by every column tile as L2 hits) instead of spanning a dozen row tiles whose A rows plus
+  // the whole filter exceed the 4 MB of the XCD's L2.  sb == 0: row-tile-major (column tiles fastest).
+  int mpx, sb;
 };
 
 __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
@@ -169,18 +174,43 @@ __device__ __forceinline__ void bf16s_epilogue(const Bf16sArgs& p, const f32x16 
   }
 }
 
-template <bool P1X1, bool YBF>
+// workgroup -> (row tile, column tile); false = no tile (grid padding)
+__device__ __forceinline__ bool bf16s_tile(const Bf16sArgs& p, int& tm, int& tn) {
+  if (p.sb == 0) {
+    const int vtile = (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3));
+    if (vtile >= p.tiles_m * p.tiles_n) return false;
+    tm = vtile / p.tiles_n;
+    tn = vtile - tm * p.tiles_n;
+    return true;
+  }
+  const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+  const int m_first = x * p.mpx;
+  const int mc = min(p.mpx, p.tiles_m - m_first);          // row tiles of this XCD
+  const int per = p.sb * p.tiles_n;
+  const int j = i / per, r = i - j * per;
+  const int ms = min(p.sb, mc - j * p.sb);                 // row tiles of sub-band j
+  if (ms <= 0) return false;
+  tn = r / ms;
+  if (tn >= p.tiles_n) return false;
+  tm = m_first + j * p.sb + (r - tn * ms);
+  return true;
+}
+
+// NST: ring stages (NST - 1 in flight).  The loop is bound by Little's law, not by a bandwidth: operand bytes in
+// flight per CU / the ~1.5-2 us an L2-missing DMA takes under load (tools/l2_stream_bench.hip) — NST = 3 keeps
+// 32 KB per workgroup in flight (48 KB of LDS: three workgroups per CU), NST = 4 keeps 48 KB (64 KB: two).
+template <bool P1X1, bool YBF, int NST = 3>
 __global__ __launch_bounds__(512, 2) void conv_bf16s_kernel(Bf16sArgs p) {
   const unsigned* __restrict__ zero_page = p.zero;
-  constexpr int NST = 3, A_BYTES = 128 * 64, B_BLOCK = 128 * 32, STAGE = A_BYTES + 2 * B_BLOCK;
+  constexpr int A_BYTES = 128 * 64, B_BLOCK = 128 * 32, STAGE = A_BYTES + 2 * B_BLOCK;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = bgs::uniform(tid >> 6);               // 0..7
   const int wm = wave >> 1, wn = wave & 1;
-  const int vtile = (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3));
-  if (vtile >= p.tiles_m * p.tiles_n) return;            // workgroup-uniform
-  const int m0 = (vtile / p.tiles_n) * 128, n0 = (vtile % p.tiles_n) * 128;
+  int tile_m, tile_n;
+  if (!bf16s_tile(p, tile_m, tile_n)) return;            // workgroup-uniform
+  const int m0 = tile_m * 128, n0 = tile_n * 128;
   const int nk = p.KC >> 1;                              // KC is even (K padded to 32)
 
   // ---- A DMA role: row 16 wave + (lane >> 2); lane -> physical chunk, logical = physical ^ ((row >> 2) & 3)
@@ -264,10 +294,12 @@ __global__ __launch_bounds__(512, 2) void conv_bf16s_kernel(Bf16sArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
-  issue();
-  issue();
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i) issue();
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // one younger stage (2 DMAs) may be in flight
+    // NST - 2 younger stages (2 DMAs each) may still be in flight
+    if (NST == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     issue();
@@ -305,9 +337,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16s_reg_kernel(Bf16sArgs p) {
   const int lane = tid & 63;
   const int wave = bgs::uniform(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int vtile = (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3));
-  if (vtile >= p.tiles_m * p.tiles_n) return;
-  const int m0 = (vtile / p.tiles_n) * 128, n0 = (vtile % p.tiles_n) * 128;
+  int tile_m, tile_n;
+  if (!bf16s_tile(p, tile_m, tile_n)) return;
+  const int m0 = tile_m * 128, n0 = tile_n * 128;
   const int nk = p.KC >> 1;
 
   const int arow = wave * 16 + (lane >> 2);
@@ -424,12 +456,22 @@ __global__ __launch_bounds__(512, 2) void conv_bf16s_reg_kernel(Bf16sArgs p) {
   bf16s_epilogue<YBF>(p, acc, lds, m0, n0, wm, wn, lane, tid);
 }
 
+int g_bf16s_order = -1;      // BGS_BF16S_ORDER: 0 = row-tile-major, 1 = L2-sized sub-bands (auto), n > 1 = n row tiles per sub-band
+int bf16s_order() {
+  if (g_bf16s_order < 0) {
+    const char* e = getenv("BGS_BF16S_ORDER");
+    g_bf16s_order = e ? atoi(e) : 0;
+    if (g_bf16s_order < 0 || g_bf16s_order > 4096) g_bf16s_order = 0;
+  }
+  return g_bf16s_order;
+}
+
 int g_bf16s_variant = -1;    // 0 = LDS-DMA ring (conv_bf16s_kernel), 1 = register-staged (conv_bf16s_reg_kernel)
 int bf16s_variant() {
   if (g_bf16s_variant < 0) {
     const char* e = getenv("BGS_BF16S_VARIANT");
     g_bf16s_variant = e ? atoi(e) : 0;
-    if (g_bf16s_variant < 0 || g_bf16s_variant > 1) g_bf16s_variant = 0;
+    if (g_bf16s_variant < 0 || g_bf16s_variant > 2) g_bf16s_variant = 0;
   }
   return g_bf16s_variant;
 }
@@ -489,7 +531,20 @@ extern "C" int bgs_conv2d_nhwc_bf16s(const void* x, const void* w_hi, const floa
   p.tiles_m = (int)((M + 127) / 128);
   p.tiles_n = (Cout + 127) / 128;
   p.chunk = (p.tiles_m * p.tiles_n + 7) / 8;
+  p.mpx = (p.tiles_m + 7) / 8;
+  p.sb = 0;
   dim3 grid((unsigned)(8 * p.chunk));
+  const int order = bf16s_order();
+  if (order) {
+    // sub-band = as many 128-row tiles as keep its A rows within ~2 MB (order > 1: that many tiles, forced)
+    const long long row_bytes = (long long)p.K * 2;
+    long long sb = order > 1 ? order : (2ll << 20) / (128 * row_bytes);
+    if (sb < 1) sb = 1;
+    if (sb > p.mpx) sb = p.mpx;
+    p.sb = (int)sb;
+    const int nsb = (p.mpx + p.sb - 1) / p.sb;
+    grid = dim3((unsigned)(8 * nsb * p.sb * p.tiles_n));
+  }
   hipStream_t st = (hipStream_t)stream;
   const bool p1x1 = R == 1 && S == 1 && pad == 0;
   ++g_bf16s_launches;
@@ -505,13 +560,21 @@ extern "C" int bgs_conv2d_nhwc_bf16s(const void* x, const void* w_hi, const floa
     }                                                                                             \
   } while (0)
   if (bf16s_variant() == 1) BGS_BF16S_LAUNCH(conv_bf16s_reg_kernel);
-  else BGS_BF16S_LAUNCH(conv_bf16s_kernel);
+  else if (bf16s_variant() == 2) {
+    if (y_bf16) {
+      if (p1x1) hipLaunchKernelGGL((conv_bf16s_kernel<true, true, 4>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((conv_bf16s_kernel<false, true, 4>), grid, dim3(512), 0, st, p);
+    } else {
+      if (p1x1) hipLaunchKernelGGL((conv_bf16s_kernel<true, false, 4>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((conv_bf16s_kernel<false, false, 4>), grid, dim3(512), 0, st, p);
+    }
+  } else BGS_BF16S_LAUNCH(conv_bf16s_kernel);
 #undef BGS_BF16S_LAUNCH
   BGS_RETURN_LAUNCH_STATUS();
 }
 
 // tuning / test hook: 0 = LDS-DMA operand ring (default), 1 = register-staged operands.  Process-wide.
-extern "C" void bgs_conv_bf16s_tuning(int variant) { g_bf16s_variant = (variant == 1) ? 1 : 0; }
+extern "C" void bgs_conv_bf16s_tuning(int variant) { g_bf16s_variant = (variant >= 0 && variant <= 2) ? variant : 0; }
 
 // ---------------------------------------------------------------------------------------------
 // Grouped 3x3 conv (conv2 of the ResNeXt bottleneck, resnext.py:47-57 + BN eval + ReLU) with bf16
