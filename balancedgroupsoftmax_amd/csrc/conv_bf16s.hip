@@ -199,7 +199,11 @@ __device__ __forceinline__ bool bf16s_tile(const Bf16sArgs& p, int& tm, int& tn)
 // NST: ring stages (NST - 1 in flight).  The loop is bound by Little's law, not by a bandwidth: operand bytes in
 // flight per CU / the ~1.5-2 us an L2-missing DMA takes under load (tools/l2_stream_bench.hip) — NST = 3 keeps
 // 32 KB per workgroup in flight (48 KB of LDS: three workgroups per CU), NST = 4 keeps 48 KB (64 KB: two).
-template <bool P1X1, bool YBF, int NST = 3>
+// PF (with NST = 4): the fragments of stage kt + 1 are read from LDS while stage kt is multiplied from registers —
+// the ds_read latency leaves the per-stage dependency chain (barrier -> DMA issue -> ds_read -> wait -> MFMA).
+// ABL (only instantiated != 0 under -DBGS_ABLATE, tools/bf16s_ablate.py): timing-only variants of the NST = 3
+// loop without 1: the MFMAs, 2: the DMA issue (after the prologue), 4: the fragment ds_reads, 8: the barrier.
+template <bool P1X1, bool YBF, int NST = 3, bool PF = false, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void conv_bf16s_kernel(Bf16sArgs p) {
   const unsigned* __restrict__ zero_page = p.zero;
   constexpr int A_BYTES = 128 * 64, B_BLOCK = 128 * 32, STAGE = A_BYTES + 2 * B_BLOCK;
@@ -250,9 +254,10 @@ __global__ __launch_bounds__(512, 2) void conv_bf16s_kernel(Bf16sArgs p) {
   if (P1X1) a_ptr = a_base + ((size_t)a_hi0 * p.W + a_wi0) * p.Cin + kg;
   const size_t b_step = (size_t)p.Cout * 32;             // two 16-deep blocks per stage
   const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page);
-  int kt_issue = 0;
+  int kt_issue = 0, slot_issue = 0;                      // slot_issue = (kt_issue % NST) * STAGE, kept by rotation
   auto issue = [&]() {
-    unsigned char* st = lds + (kt_issue % NST) * STAGE;
+    unsigned char* st = lds + slot_issue;
+    slot_issue = slot_issue + STAGE == NST * STAGE ? 0 : slot_issue + STAGE;
     const bool live = kt_issue < nk;
     const __bf16* asrc;
     if (P1X1) {
@@ -273,8 +278,10 @@ __global__ __launch_bounds__(512, 2) void conv_bf16s_kernel(Bf16sArgs p) {
         }
       }
     }
-    glds16(asrc, st + wave * 1024);
-    glds16((live && b_ok) ? b_ptr : zp, st + A_BYTES + wave * 1024);
+    if (!(ABL & 2) || kt_issue < NST - 1) {
+      glds16(asrc, st + wave * 1024);
+      glds16((live && b_ok) ? b_ptr : zp, st + A_BYTES + wave * 1024);
+    }
     b_ptr += b_step;
     ++kt_issue;
   };
@@ -296,22 +303,79 @@ __global__ __launch_bounds__(512, 2) void conv_bf16s_kernel(Bf16sArgs p) {
 
 #pragma unroll
   for (int i = 0; i < NST - 1; ++i) issue();
-  for (int kt = 0; kt < nk; ++kt) {
-    // NST - 2 younger stages (2 DMAs each) may still be in flight
-    if (NST == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  int slot_read = 0;
+  if (PF) {
+    static_assert(!PF || NST == 4, "fragment prefetch needs the 4-stage ring");
+    bf16x8 fa[2], fb[2][2];
+    auto read_frags = [&](const unsigned char* st) {
+      fa[0] = *reinterpret_cast<const bf16x8*>(st + a_off0);
+      fa[1] = *reinterpret_cast<const bf16x8*>(st + a_off1);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        fb[0][b] = *reinterpret_cast<const bf16x8*>(st + b_off + b * 1024);
+        fb[1][b] = *reinterpret_cast<const bf16x8*>(st + b_off + B_BLOCK + b * 1024);
+      }
+    };
+    // stage 0 landed -> registers
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (nk > 0) read_frags(lds);
+    slot_read = STAGE;
+    for (int kt = 0; kt < nk; ++kt) {
+      // stage kt + 1 has landed once at most one younger stage (2 DMAs) is in flight; every wave has its stage
+      // kt fragments in registers, so slot kt % 4 may be refilled (by stage kt + 4... issued below as kt + 3's
+      // successor: the ring keeps three stages in flight)
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue();
+      const bf16x8 ca0 = fa[0], ca1 = fa[1], cb00 = fb[0][0], cb01 = fb[0][1], cb10 = fb[1][0], cb11 = fb[1][1];
+      if (kt + 1 < nk) read_frags(lds + slot_read);        // stage kt + 1 -> registers, under the MFMAs below
+      slot_read = slot_read + STAGE == NST * STAGE ? 0 : slot_read + STAGE;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca0, cb00, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca0, cb01, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca1, cb10, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca1, cb11, acc[1], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bf16s_epilogue<YBF>(p, acc, lds, m0, n0, wm, wn, lane, tid);
+    return;
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    // NST - 2 younger stages (2 DMAs each) may still be in flight
+    if (ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (NST == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     issue();
-    const unsigned char* st = lds + (kt % NST) * STAGE;
-    const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(st + a_off0);
-    const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(st + a_off1);
+    const unsigned char* st = lds + slot_read;
+    slot_read = slot_read + STAGE == NST * STAGE ? 0 : slot_read + STAGE;
+    bf16x8 fa0, fa1;
+    if (ABL & 4) {
+      fa0 = __builtin_bit_cast(bf16x8, u32x4{(unsigned)kt, 1u, 2u, 3u});
+      fa1 = __builtin_bit_cast(bf16x8, u32x4{(unsigned)kt, 5u, 6u, 7u});
+    } else {
+      fa0 = *reinterpret_cast<const bf16x8*>(st + a_off0);
+      fa1 = *reinterpret_cast<const bf16x8*>(st + a_off1);
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(st + b_off + b * 1024);
-      const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(st + b_off + B_BLOCK + b * 1024);
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[b], 0, 0, 0);
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[b], 0, 0, 0);
+      bf16x8 fb0, fb1;
+      if (ABL & 4) {
+        fb0 = __builtin_bit_cast(bf16x8, u32x4{(unsigned)kt, (unsigned)b, 2u, 3u});
+        fb1 = __builtin_bit_cast(bf16x8, u32x4{(unsigned)kt, (unsigned)b, 6u, 7u});
+      } else {
+        fb0 = *reinterpret_cast<const bf16x8*>(st + b_off + b * 1024);
+        fb1 = *reinterpret_cast<const bf16x8*>(st + b_off + B_BLOCK + b * 1024);
+      }
+      if (ABL & 1) {
+        asm volatile("" ::"v"(fa0), "v"(fb0), "v"(fa1), "v"(fb1));
+      } else {
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[b], 0, 0, 0);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the (zero-page) tail DMAs
@@ -471,7 +535,7 @@ int bf16s_variant() {
   if (g_bf16s_variant < 0) {
     const char* e = getenv("BGS_BF16S_VARIANT");
     g_bf16s_variant = e ? atoi(e) : 0;
-    if (g_bf16s_variant < 0 || g_bf16s_variant > 2) g_bf16s_variant = 0;
+    if (g_bf16s_variant < 0 || g_bf16s_variant > 3) g_bf16s_variant = 0;
   }
   return g_bf16s_variant;
 }
@@ -568,13 +632,30 @@ extern "C" int bgs_conv2d_nhwc_bf16s(const void* x, const void* w_hi, const floa
       if (p1x1) hipLaunchKernelGGL((conv_bf16s_kernel<true, false, 4>), grid, dim3(512), 0, st, p);
       else hipLaunchKernelGGL((conv_bf16s_kernel<false, false, 4>), grid, dim3(512), 0, st, p);
     }
-  } else BGS_BF16S_LAUNCH(conv_bf16s_kernel);
+  } else if (bf16s_variant() == 3) {
+    if (y_bf16) {
+      if (p1x1) hipLaunchKernelGGL((conv_bf16s_kernel<true, true, 4, true>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((conv_bf16s_kernel<false, true, 4, true>), grid, dim3(512), 0, st, p);
+    } else {
+      if (p1x1) hipLaunchKernelGGL((conv_bf16s_kernel<true, false, 4, true>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((conv_bf16s_kernel<false, false, 4, true>), grid, dim3(512), 0, st, p);
+    }
+  } else
+#ifdef BGS_ABLATE
+  if (getenv("BGS_BF16S_ABLATE") && atoi(getenv("BGS_BF16S_ABLATE")) && p1x1 && y_bf16) {
+#define BS_ABL(A_) case A_: hipLaunchKernelGGL((conv_bf16s_kernel<true, true, 3, false, A_>), grid, dim3(512), 0, st, p); break;
+    switch (atoi(getenv("BGS_BF16S_ABLATE"))) { BS_ABL(1) BS_ABL(2) BS_ABL(4) BS_ABL(8) BS_ABL(3) BS_ABL(5) BS_ABL(6) BS_ABL(7) BS_ABL(12) BS_ABL(14) BS_ABL(15)
+      default: return BGS_ERR_UNSUPPORTED; }
+#undef BS_ABL
+  } else
+#endif
+  BGS_BF16S_LAUNCH(conv_bf16s_kernel);
 #undef BGS_BF16S_LAUNCH
   BGS_RETURN_LAUNCH_STATUS();
 }
 
 // tuning / test hook: 0 = LDS-DMA operand ring (default), 1 = register-staged operands.  Process-wide.
-extern "C" void bgs_conv_bf16s_tuning(int variant) { g_bf16s_variant = (variant >= 0 && variant <= 2) ? variant : 0; }
+extern "C" void bgs_conv_bf16s_tuning(int variant) { g_bf16s_variant = (variant >= 0 && variant <= 3) ? variant : 0; }
 
 // ---------------------------------------------------------------------------------------------
 // Grouped 3x3 conv (conv2 of the ResNeXt bottleneck, resnext.py:47-57 + BN eval + ReLU) with bf16
