@@ -220,3 +220,72 @@ def test_wrap_fp16_model_is_scoped_to_the_model():
     train.unwrap_fp16_model(m)
     m(torch.zeros(1))
     assert seen[-1] == outside
+
+
+def test_parse_losses_batched_segment_sums_equal_the_per_key_formula_with_gradients():
+    """``train.parse_losses`` computes every per-key sum and the total from ONE stack and one 0/1 segment
+    product; values and gradients equal mmdet/apis/train.py:24-47 (per key: mean of a tensor / sum of the
+    means of a list; total over the keys containing 'loss')."""
+    import torch
+    from balancedgroupsoftmax_amd import train
+    g = torch.Generator().manual_seed(0)
+    leaves = [torch.randn((), generator=g, requires_grad=True) for _ in range(14)]
+    d = dict(loss_rpn_cls=leaves[0:5], loss_rpn_bbox=leaves[5:10], loss_cls_bin0=leaves[10],
+             acc=leaves[11], loss_bbox=leaves[12], loss_vec=torch.stack([leaves[13], leaves[13] * 3]))
+    loss, log_vars = train.parse_losses(d)
+    exp = dict(loss_rpn_cls=sum(leaves[0:5]), loss_rpn_bbox=sum(leaves[5:10]), loss_cls_bin0=leaves[10],
+               acc=leaves[11], loss_bbox=leaves[12], loss_vec=leaves[13] * 2)
+    for k, v in exp.items():
+        assert abs(float(log_vars[k]) - float(v)) < 1e-6, k
+    total = sum(v for k, v in exp.items() if 'loss' in k)
+    assert abs(float(loss) - float(total)) < 1e-6 and abs(float(log_vars['loss']) - float(total)) < 1e-6
+    loss.backward()
+    for i, t in enumerate(leaves):
+        want = 0.0 if i == 11 else (2.0 if i == 13 else 1.0)
+        assert abs(float(t.grad) - want) < 1e-6, i
+    assert len(train._SEGMENT_MATS) >= 1          # cached per structure: a second call builds nothing new
+    n = len(train._SEGMENT_MATS)
+    train.parse_losses({k: ([t.detach() for t in v] if isinstance(v, list) else v.detach()) for k, v in d.items()})
+    assert len(train._SEGMENT_MATS) == n
+
+
+def test_fused_clip_sgd_is_chosen_only_where_it_is_the_same_computation():
+    """``DistOptimizerStep`` takes the fused clip + SGD kernels only for what they implement (one param
+    group of plain torch.optim.SGD, L2 clipping, fp32 CUDA parameters); everything else — and CPU
+    parameters, as here — keeps the torch path."""
+    import torch
+    from balancedgroupsoftmax_amd import train
+    ps = [torch.nn.Parameter(torch.randn(4, 3))]
+    opt = torch.optim.SGD(ps, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    assert not train._fused_sgd_eligible(opt, ps, dict(max_norm=35, norm_type=2))       # CPU tensors
+    step = train.DistOptimizerStep(ps, opt, dict(max_norm=35, norm_type=2))
+    assert step.fused is None
+    ps[0].grad = torch.ones_like(ps[0])
+    before = ps[0].detach().clone()
+    step.exchange_and_update()                                   # the torch path still steps
+    assert not torch.equal(ps[0].detach(), before)
+
+    class FakeCuda(torch.nn.Parameter):                          # eligibility rules without a GPU
+        is_cuda = True
+    fp = [FakeCuda(torch.randn(2, 2))]
+    for kwargs, clip, ok in ((dict(), dict(max_norm=35, norm_type=2), True),
+                             (dict(nesterov=True), dict(max_norm=35, norm_type=2), False),
+                             (dict(dampening=0.1), dict(max_norm=35, norm_type=2), False),
+                             (dict(), dict(max_norm=35, norm_type=1), False),
+                             (dict(), None, True)):
+        o = torch.optim.SGD(fp, lr=0.1, momentum=0.9, **kwargs)
+        assert train._fused_sgd_eligible(o, fp, clip) == ok, (kwargs, clip)
+    two = torch.optim.SGD([dict(params=fp), dict(params=[FakeCuda(torch.randn(2))], lr=0.5)], lr=0.1, momentum=0.9)
+    assert not train._fused_sgd_eligible(two, fp, None)
+    assert not train._fused_sgd_eligible(torch.optim.Adam(fp), fp, None)
+
+
+def test_proposal_list_is_the_reference_list_plus_its_batch_tensors():
+    import torch
+    from balancedgroupsoftmax_amd.rpn import ProposalList
+    props, valid = torch.randn(2, 7, 5), torch.rand(2, 7) > 0.5
+    pl = ProposalList(props, valid)
+    assert len(pl) == 2 and isinstance(pl, list)
+    for i, (p, v) in enumerate(pl):
+        assert p.data_ptr() == props[i].data_ptr() and torch.equal(v, valid[i])
+    assert pl.batched[0] is props and pl.batched[1] is valid
