@@ -90,6 +90,18 @@ class _FoldCache(object):
         return self.data
 
 
+def cached_fold(conv, bn=None, pad_cin_to=None):
+    """:func:`_fold_conv_bn` through a per-module :class:`_FoldCache` (kept on ``conv``): a frozen layer is
+    folded — and, downstream, split into its bf16 planes — ONCE per parameter version instead of on every
+    forward call (the mask / semantic heads call their convs 24+ times per HTC iteration); a trained layer is
+    folded on this step's tape, as before."""
+    cache = conv.__dict__.get('_bgs_fold_cache')
+    if cache is None:
+        cache = conv.__dict__['_bgs_fold_cache'] = _FoldCache()
+    mods = nn.ModuleList([conv] + ([bn] if bn is not None else []))
+    return cache.get(mods, lambda: _fold_conv_bn(conv, bn, pad_cin_to=pad_cin_to))
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 

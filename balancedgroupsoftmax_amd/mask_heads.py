@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as BF
-from .backbone import ConvModule, _fold_conv_bn
+from .backbone import ConvModule, _FoldCache, _fold_conv_bn, cached_fold
 from .builder import build_loss
 from .registry import HEADS
 
@@ -62,11 +62,17 @@ class FCNMaskHead(nn.Module):
     def _deconv_as_conv(self):
         """ConvTranspose2d(k=2, s=2) weight ``[Cin, Cout, 2, 2]`` -> 1x1 conv ``[(a,b,co), 1, 1, Cin]``
         (differentiable when trained)."""
-        wt = self.upsample.weight.float()
-        cin, cout = wt.shape[0], wt.shape[1]
-        w = wt.permute(2, 3, 1, 0).reshape(4 * cout, 1, 1, cin).contiguous()
-        b = self.upsample.bias.float().repeat(4)
-        return w, b
+        def build():
+            wt = self.upsample.weight.float()
+            cin, cout = wt.shape[0], wt.shape[1]
+            w = wt.permute(2, 3, 1, 0).reshape(4 * cout, 1, 1, cin).contiguous()
+            b = self.upsample.bias.float().repeat(4)
+            return w, b
+        # frozen: re-laid-out (and, downstream, split into bf16 planes) once per parameter version
+        cache = self.__dict__.get('_deconv_cache')
+        if cache is None:
+            cache = self.__dict__['_deconv_cache'] = _FoldCache()
+        return cache.get(self.upsample, build)
 
     def conv_features(self, x):
         """The ``convs`` stack on NHWC RoI features; the result is a ``relu='consumers'`` output
@@ -75,7 +81,7 @@ class FCNMaskHead(nn.Module):
         ``mask_input=True``); hand it to foreign code through ``BF.relu_gate`` only."""
         first = True
         for m in self.convs:
-            w, b = _fold_conv_bn(m.conv, None)
+            w, b = cached_fold(m.conv)
             x = BF.conv2d_autograd(x, w, b, pad=m.padding, relu='consumers',
                                    mask_input=not first)
             first = False
@@ -178,7 +184,7 @@ class HTCMaskHead(FCNMaskHead):
         """NHWC ``x [P,h,w,C]`` (+ previous stage's ``res_feat``) -> this stage's ``res_feat``
         (htc_mask_head.py:23-28)."""
         if res_feat is not None:
-            w, b = _fold_conv_bn(self.conv_res.conv, None)
+            w, b = cached_fold(self.conv_res.conv)
             x = x + BF.conv2d_autograd(res_feat, w, b, relu=True, mask_input=self.num_convs > 0)
         return self.conv_features(x)
 

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as BF
-from .backbone import ConvModule, _fold_conv_bn
+from .backbone import ConvModule, _fold_conv_bn, cached_fold
 from .registry import HEADS
 
 
@@ -59,23 +59,23 @@ class FusedSemanticHead(nn.Module):
         value checks against the reference: oracle/tensor_forms.semantic_forward.)"""
         BF._require_cuda(*feats)
         lvl = self.fusion_level
-        w, b = _fold_conv_bn(self.lateral_convs[lvl].conv, None)
+        w, b = cached_fold(self.lateral_convs[lvl].conv)
         x = BF.conv2d_autograd(feats[lvl], w, b, relu=True)
         size = (x.shape[1], x.shape[2])
         for i, feat in enumerate(feats):
             if i == lvl:
                 continue
-            w, b = _fold_conv_bn(self.lateral_convs[i].conv, None)
+            w, b = cached_fold(self.lateral_convs[i].conv)
             x = x + BF.conv2d_autograd(BF.resize_bilinear_nhwc_autograd(feat, size), w, b, relu=True)
         first = True
         for m in self.convs:
-            w, b = _fold_conv_bn(m.conv, None)
+            w, b = cached_fold(m.conv)
             x = BF.conv2d_autograd(x, w, b, pad=1, relu='consumers', mask_input=not first)
             first = False
         gate = self.num_convs > 0          # x is then a relu='consumers' output
-        w, b = _fold_conv_bn(self.conv_logits, None)
+        w, b = cached_fold(self.conv_logits)
         mask_pred = BF.conv2d_autograd(x, w, b, mask_input=gate)
-        w, b = _fold_conv_bn(self.conv_embedding.conv, None)
+        w, b = cached_fold(self.conv_embedding.conv)
         semantic_feat = BF.conv2d_autograd(x, w, b, relu=True, mask_input=gate)
         return mask_pred, semantic_feat
 
