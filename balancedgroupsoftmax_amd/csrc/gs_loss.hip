@@ -844,7 +844,7 @@ extern "C" int bgs_gs_head_step(const float* logits, const int64_t* labels,
   int grid = 0;
   const int rc = launch_gs_head(a, host_pred_slice, host_bin_loss_weight, (hipStream_t)stream, &grid);
   if (rc != BGS_OK || !loss_out) return rc;
-  hipLaunchKernelGGL(gs_head_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a.partial,
+  hipLaunchKernelGGL(gs_head_reduce_kernel, dim3(1), dim3((unsigned)(BGS_WAVE * (a.B + 1))), 0, (hipStream_t)stream, a.partial,
                      grid, B, bbox_pred ? 1 : 0, box_loss_weight, avg_out, loss_out, total_out,
                      draw_counter);
   BGS_RETURN_LAUNCH_STATUS();
