@@ -180,6 +180,23 @@ __device__ __forceinline__ uint32_t gs_perm(uint32_t salt, uint32_t x, uint32_t 
   return x;
 }
 
+// Bitonic networks in LDS with one thread per compare-exchange pair (pair j: lo = 2 j - (j & (stride - 1)),
+// hi = lo + stride): for stride <= 64 the 64 pairs of a wave lie in ONE contiguous 128-element block that no
+// other wave touches in that stage, so the stages with stride <= 64 only need the wave's own LDS writes to be
+// visible to its own lanes — a wave-scope fence instead of a workgroup barrier (51 of the 66 stages of a
+// 2048-element sort).  A workgroup barrier is needed after a stage with stride >= 128, and after the last
+// stage (stride 1) of a size whose successor starts with stride >= 128.
+__device__ __forceinline__ void bitonic_stage_sync(int size, int stride) {
+  const bool block = stride >= 128 || (stride == 1 && size >= 128);
+  if (block) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 // integer wave sum on the DPP path (wave_sum_i above is six dependent ds_bpermute round trips)
 #ifndef BGS_NO_DPP
 // (same recipe as BGS_DPP_REDUCE: only lane 63's value is the full sum)

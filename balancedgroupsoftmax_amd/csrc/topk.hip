@@ -191,9 +191,10 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(TopkProblems pr, TopkWs
           buf[hi] = a;
         }
       }
-      __syncthreads();
+      bgs::bitonic_stage_sync(size, stride);               // wave-scope for stride <= 64 (bgs_common.h)
     }
   }
+  __syncthreads();                                         // (sorts of < 128 elements end on a wave-scope stage)
   float* ov = out_val + (size_t)p * kmax;
   long long* oi = out_idx + (size_t)p * kmax;
   for (int i = tid; i < kmax; i += 1024) {
