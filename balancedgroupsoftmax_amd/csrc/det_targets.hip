@@ -87,8 +87,14 @@ __global__ __launch_bounds__(256) void iou_gtmax_kernel(const float* __restrict_
       // per-gt maximum: wave reduction, one LDS atomic per wave (no block barrier per gt).
       // signed-int order == float order for the values used here: -1.0f (negative int) < any
       // IoU >= 0 (non-negative ints, monotone in the float value)
-      const float wm = bgs::wave_max(v);
-      if (lane == 0 && wm >= 0.f) atomicMax(&smax[g], __float_as_int(wm));
+      // (the six-step wave reduction only when some lane beats the maximum seen so far — a same-address LDS
+      //  read is a broadcast and a racy LOWER bound of the running maximum, so skipping is exact: almost every
+      //  wave of anchors misses a given gt)
+      const float seen = __int_as_float(smax[g]);
+      if (__ballot(v > seen)) {
+        const float wm = bgs::wave_max(v);
+        if (lane == 0) atomicMax(&smax[g], __float_as_int(wm));
+      }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < cn; t += 256)
