@@ -32,21 +32,31 @@ namespace {
 
 constexpr int kTile = 64;
 
-__device__ __forceinline__ float iou_legacy(const float* a, const float* b) {
+
+// "IoU(a, b) > thr" (mode 0) / ">= thr" (mode 1) with the SAME decision as the division, mostly without it: the
+// mask kernel is bound by its 64 fp32 divisions per lane (40 us for the RPN's ten problems).  v = fl(inter / u)
+// differs from the real ratio by at most 2^-24 relative, so outside the band |inter - thr u| <= 2^-21 thr u the
+// decision is the sign of inter - thr u — which the fp32 product and difference give reliably at that margin;
+// inside the band (and for degenerate unions, u <= 0) the division decides, exactly as before.
+__device__ __forceinline__ bool iou_exceeds(const float* a, const float* b, float thr, int mode) {
   const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
   const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
   const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
   const float inter = width * height;
   const float sa = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f);
   const float sb = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
-  return inter / (sa + sb - inter);
+  const float u = sa + sb - inter;
+  const float m = thr * u;
+  const float d = inter - m;
+  if (u > 0.f && m > 0.f && fabsf(d) > 4.8e-7f * m) return d > 0.f;
+  const float v = inter / u;
+  return mode ? (v >= thr) : (v > thr);
 }
 
 // boxes [P, nmax, 5] (x1,y1,x2,y2,score), counts [P]; mask [P, nmax, cb] u64.
-// Four 64 x 64 tiles per workgroup (one per wave: column tiles 4 blockIdx.x + wave of row tile blockIdx.y): the
-// one-wave-per-workgroup form launched 10,240 workgroups for the RPN's ten problems, half of them empty — the
-// kernel was dispatch-bound (39.7 us for 9 us of IoUs).  Every wave stages its own column tile in its own LDS slice
-// and only synchronises with itself.
+// Four 64 x 64 tiles per workgroup (one per wave: column tiles 4 blockIdx.x + wave of row tile blockIdx.y), every
+// wave staging its own column tile in its own LDS slice and only synchronising with itself (measured equal to the
+// one-wave-per-workgroup form: the kernel is bound by the IoU arithmetic, not by its 10,240 dispatches).
 constexpr int kMaskWaves = 4;
 __global__ __launch_bounds__(kTile * kMaskWaves) void nms_mask_kernel(const float* __restrict__ boxes,
                                                                       const int* __restrict__ counts,
@@ -85,9 +95,7 @@ __global__ __launch_bounds__(kTile * kMaskWaves) void nms_mask_kernel(const floa
     const int self = (row_start == col_start) ? lane : -1;
     for (int j = 0; j < col_size; ++j) {
       if (j == self) continue;
-      const float v = iou_legacy(cur, cbx + j * 4);
-      const bool sup = iou_mode ? (v >= thr) : (v > thr);
-      if (sup) t |= 1ull << j;
+      if (iou_exceeds(cur, cbx + j * 4, thr, iou_mode)) t |= 1ull << j;
     }
     mask[((size_t)p * nmax + i) * cb + col_start] = t;
   }

@@ -97,7 +97,9 @@ def test_roi_align_cuda_signature_vs_compiled_reference_kernels(out_size, scale)
     # backward ACCUMULATES into the caller's buffer (the reference kernel's atomicAdd)
     acc = torch.ones((N, C, H, W), device=DEV)
     assert roi_align_cuda.backward(torch.from_numpy(g).to(DEV), r, oh, ow, scale, 2, acc) == 1
-    assert torch.allclose(acc - 1.0, f.grad, rtol=1e-5, atol=1e-5)
+    # (two runs of an fp32-atomics scatter: the summation order differs from launch to launch, and `acc`
+    #  starts at 1.0 — the comparison carries the rounding of up to a few hundred unordered additions)
+    assert torch.allclose(acc - 1.0, f.grad, rtol=1e-4, atol=1e-4)
 
 
 def test_roi_align_cuda_error_convention():
