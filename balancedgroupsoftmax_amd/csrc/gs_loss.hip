@@ -272,6 +272,21 @@ struct GsHeadArgs {
   unsigned long long* tstamps;   // debug (bgs_gs_head_debug_timestamps): [gridDim.x][8] s_memtime marks, or null
 };
 
+// v_writelane_b32 with a run-time lane (hipcc has no builtin for it).  gfx9 VALU instructions read ONE SGPR
+// over the constant bus; the lane select of v_writelane is exempt when it is M0.  (M0 is a reserved register
+// to the compiler, hence the diagnostic; nothing else in this file's kernels uses it — no LDS-DMA, no s_movrel,
+// no s_sendmsg — which the disassembly confirms.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ int gs_writelane(int val, int lane, int old) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0"
+               : "+v"(old)
+               : "s"(val), "s"(lane)
+               : "m0");
+  return old;
+}
+#pragma clang diagnostic pop
+
 __device__ __forceinline__ float gs_sl1(float d, float beta, float& grad) {
   const float ad = fabsf(d);
   if (ad < beta) {
@@ -282,19 +297,30 @@ __device__ __forceinline__ float gs_sl1(float d, float beta, float& grad) {
   return ad - 0.5f * beta;
 }
 
-// LDS layout (dynamic): [2][wpad] rows + read slack | flags u16 [N rounded to 8] | class bits u16
+// LDS layout (dynamic): [2][wpad] rows + read slack | flags u16 [N rounded to 64] (VAR 1: 16 bit planes of
+// N / 64 64-bit words, the same bytes) | class bits u16
 // [C rounded to 8] | counts int [kWaves][MAX_BINS + 1] | box gradient float [4]
 __host__ __device__ inline size_t gs_head_lds_bytes(int N, int C, int wpad) {
-  return sizeof(float) * (2 * (size_t)wpad + BGS_WAVE * bgs::kSweep) + 2 * (size_t)((N + 7) & ~7) +
+  return sizeof(float) * (2 * (size_t)wpad + BGS_WAVE * bgs::kSweep) + 2 * (size_t)((N + 63) & ~63) +
          2 * (size_t)((C + 7) & ~7) + sizeof(int) * kWaves * (BGS_MAX_BINS + 1) + sizeof(float) * 4;
 }
 
-template <int VEC, bool WRITE_GRAD, bool BOX>
+// VAR 1 (round 3, `bgs_gs_head_variant`): BIT PLANES instead of per-row flag words.  The prologue turns the
+// flag words of a wave's 64 rows into one 64-bit ballot per plane (plane b = "real and foreground in bin b",
+// plane 15 = "real") and lane p of the wave stores plane p's word: sh_pl[p][row / 64].  Then the number of
+// real rows is one popcount pass over plane 15 (lane w = word w), and for a bin b both its foreground count
+// and the row's position among the bin's candidates come out of ONE pass over plane b + ONE wave sum
+// (popc(F) << 16 | popc((R ^ F) & below-the-row mask)) in the wave that owns the bin — instead of four packed
+// counter registers with a wave sum each, an LDS exchange of the per-wave counts, and a scan over the flag words
+// below the row.  Same decisions, same arithmetic behind them: bitwise the results of VAR 0.
+template <int VEC, bool WRITE_GRAD, bool BOX, int VAR>
 __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = a.N, C = a.C, B = a.B, W = a.W, wpad = a.wpad;
   unsigned short* sh_flags = reinterpret_cast<unsigned short*>(smem + 2 * (size_t)wpad + BGS_WAVE * bgs::kSweep);
-  unsigned short* sh_cbits = sh_flags + ((N + 7) & ~7);
+  unsigned long long* sh_pl = reinterpret_cast<unsigned long long*>(sh_flags);   // VAR 1: [16][NW]
+  const int NW = (N + 63) >> 6;
+  unsigned short* sh_cbits = sh_flags + ((N + 63) & ~63);
   int* sh_cntw = reinterpret_cast<int*>(sh_cbits + ((C + 7) & ~7));
   float* sh_box = reinterpret_cast<float*>(sh_cntw + kWaves * (BGS_MAX_BINS + 1));
   const int tid = threadIdx.x;
@@ -319,13 +345,11 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
   //      together.  Lane b <= B of every wave counts bin b over the wave's share of the rows by
   //      ballots (b == B: real rows) — no LDS atomics.
   int mycnt = 0;
-  // the workgroup's first row: label and bin labels (a dependent pair of loads) start now
+  // the workgroup's first row: its label is the OLDEST load of the kernel; the dependent gather of its bin
+  // labels is issued below, behind every independent load (the label is wave-uniform, so its first use is a
+  // v_readfirstlane behind an s_waitcnt: taken here, that wait was a full memory round trip in front of all
+  // the other loads — round 3, from the ISA)
   const int64_t yraw_first = a.labels[blockIdx.x];
-  int my_bl_first = 0;
-  if (lane < B) {
-    const int64_t yc = yraw_first < 0 ? 0 : (yraw_first >= C ? (int64_t)C - 1 : yraw_first);
-    my_bl_first = (int)a.l2b[(size_t)lane * C + yc];
-  }
   const float* rw_base = a.row_weights ? a.row_weights : &g_one;
   const int rw_step = a.row_weights ? 1 : 0;
   constexpr int RP = kFusedRowsPerPass;
@@ -350,6 +374,11 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
     const float* g = a.logits + (size_t)blockIdx.x * W;
     bgs::load_vec<VEC>(g + (c0 < W ? c0 : 0), t0);
     bgs::load_vec<VEC>(g + (c1 < W ? c1 : 0), t1);
+  }
+  int my_bl_first = 0;
+  if (lane < B) {     // counted wait: only the label load has to have landed
+    const int64_t yc = yraw_first < 0 ? 0 : (yraw_first >= C ? (int64_t)C - 1 : yraw_first);
+    my_bl_first = (int)a.l2b[(size_t)lane * C + yc];
   }
   if (a.class_bits) {
     // 8 table entries (16 B) per thread and pass; the table is padded to a multiple of 8 entries and
@@ -376,39 +405,69 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
   __syncthreads();                        // class bits (and the first row) are in LDS
   GS_MARK(2);
   unsigned pk[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-  for (int base = 0; base < N; base += kBlock * RP) {
-    bool real[RP];
+  // one pass = RP rows per thread (labels + row weights in registers); the first pass uses the loads of the top
+  // of the kernel and is straight-line code, batches of N > kBlock * RP rows loop
+  auto pass = [&](const int base, const int64_t (&yv)[RP], const float (&rwv)[RP]) {
     unsigned bits[RP];
+    // the RP table lookups are issued together, their consumers sit behind ONE wait (read -> wait -> write per
+    // row was RP serial LDS round trips)
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      const int64_t y = yv[i] < 0 ? 0 : (yv[i] >= C ? (int64_t)C - 1 : yv[i]);
+      bits[i] = sh_cbits[(int)y];
+    }
+    if constexpr (VAR == 1) {
+#pragma unroll
+      for (int i = 0; i < RP; ++i) {
+        const int r = base + tid + kBlock * i;
+        const unsigned wbits = (r < N && rwv[i] > 0.f) ? (bits[i] | 0x8000u) : 0u;
+        int lo = 0, hi = 0;                      // lane p: plane p's word of this wave's 64 rows
+        for (int p = 1; p < B; ++p) {
+          const unsigned long long m = __ballot((wbits >> p) & 1u);
+          lo = gs_writelane((int)(unsigned)m, p, lo);
+          hi = gs_writelane((int)(unsigned)(m >> 32), p, hi);
+        }
+        const unsigned long long mr = __ballot(wbits >> 15);
+        lo = gs_writelane((int)(unsigned)mr, 15, lo);
+        hi = gs_writelane((int)(unsigned)(mr >> 32), 15, hi);
+        const int w = ((base + kBlock * i) >> 6) + wave;
+        if (lane < 16 && w < NW)
+          sh_pl[lane * NW + w] = ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+      }
+    } else {
+      bool real[RP];
+#pragma unroll
+      for (int i = 0; i < RP; ++i) {
+        const int r = base + tid + kBlock * i;
+        real[i] = r < N && rwv[i] > 0.f;
+        if (r < N) sh_flags[r] = (unsigned short)(real[i] ? (bits[i] | 0x8000u) : 0u);
+      }
+      // per-thread counters, two 16-bit fields per register: bins 2 f and 2 f + 1 (a wave's share of
+      // the rows is <= 64 * 16: no carry), field 15 = real rows
+#pragma unroll
+      for (int i = 0; i < RP; ++i) {
+        const unsigned wbits = real[i] ? (bits[i] | 0x8000u) : 0u;
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+          if (2 * f < B || f == 7) pk[f] += ((wbits >> (2 * f)) & 1u) | (((wbits >> (2 * f + 1)) & 1u) << 16);
+      }
+    }
+  };
+  pass(0, y0, rwv0);
+  for (int base = kBlock * RP; base < N; base += kBlock * RP) {
+    int64_t yv[RP];
+    float rwv[RP];
 #pragma unroll
     for (int i = 0; i < RP; ++i) {
       const int r = base + tid + kBlock * i;
-      int64_t y;
-      float rwv;
-      if (base == 0) {
-        y = y0[i];
-        rwv = rwv0[i];
-      } else {
-        const int rc = r < N ? r : 0;
-        y = a.labels[rc];
-        rwv = rw_base[(size_t)rc * rw_step];
-      }
-      y = y < 0 ? 0 : (y >= C ? (int64_t)C - 1 : y);
-      bits[i] = sh_cbits[(int)y];
-      real[i] = r < N && rwv > 0.f;
-      if (r < N) sh_flags[r] = (unsigned short)(real[i] ? (bits[i] | 0x8000u) : 0u);
+      const int rc = r < N ? r : 0;
+      yv[i] = a.labels[rc];
+      rwv[i] = rw_base[(size_t)rc * rw_step];
     }
-    // per-thread counters, two 16-bit fields per register: bins 2 f and 2 f + 1 (a wave's share of
-    // the rows is <= 64 * 16: no carry), field 15 = real rows
-#pragma unroll
-    for (int i = 0; i < RP; ++i) {
-      const unsigned wbits = real[i] ? (bits[i] | 0x8000u) : 0u;
-#pragma unroll
-      for (int f = 0; f < 8; ++f)
-        if (2 * f < B || f == 7) pk[f] += ((wbits >> (2 * f)) & 1u) | (((wbits >> (2 * f + 1)) & 1u) << 16);
-    }
+    pass(base, yv, rwv);
   }
   // one DPP sum per used register; lane b <= B then picks its field (b == B: the real rows, field 15)
-  {
+  if constexpr (VAR == 0) {
     const int fsel = lane == B ? 15 : lane;
     unsigned mine = 0u;
 #pragma unroll
@@ -420,7 +479,7 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
     }
     mycnt = (int)((mine >> (16 * (fsel & 1))) & 0xffffu);
   }
-  if (lane <= B) sh_cntw[wave * (BGS_MAX_BINS + 1) + lane] = mycnt;
+  if (VAR == 0 && lane <= B) sh_cntw[wave * (BGS_MAX_BINS + 1) + lane] = mycnt;
   GS_MARK(3);                             // flags + ballots done
   __syncthreads();                        // flags, counts and the first row are in LDS
   GS_MARK(4);
@@ -429,9 +488,15 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
   int my_mode = 0, my_k = 0, my_nbg = 0;  // 0 = all zero, 1 = all one, 2 = sampled
   float my_scale = 0.f;                   // loss_weight / avg
   int n_real = 0;
+  unsigned long long Rw = 0ull;             // VAR 1: lane w holds word w of the "real" plane
+  if constexpr (VAR == 1) {
+    Rw = lane < NW ? sh_pl[15 * NW + lane] : 0ull;
+    n_real = bgs::wave_sum_i_fast(__popcll(Rw));
+  } else {
 #pragma unroll
-  for (int v = 0; v < kWaves; ++v) n_real += sh_cntw[v * (BGS_MAX_BINS + 1) + B];
-  if (lane < B) {
+    for (int v = 0; v < kWaves; ++v) n_real += sh_cntw[v * (BGS_MAX_BINS + 1) + B];
+  }
+  if (VAR == 0 && lane < B) {
     int n_fg = 0;
 #pragma unroll
     for (int v = 0; v < kWaves; ++v) n_fg += sh_cntw[v * (BGS_MAX_BINS + 1) + lane];
@@ -461,8 +526,15 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
     float* row = smem + (size_t)par * wpad;
     const bool first = r == (int)blockIdx.x;
     if (!first) bgs::stage_row<VEC>(a.logits + (size_t)r * W, row, W, tid, kBlock);
-    const unsigned fr = sh_flags[r];
-    const bool real_r = (fr & 0x8000u) != 0u;
+    bool real_r;
+    if constexpr (VAR == 1) {
+      const int wr = bgs::uniform(r >> 6);
+      const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)Rw, wr);
+      const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(Rw >> 32), wr);
+      real_r = (((r & 32) ? rhi : rlo) >> (r & 31)) & 1u;
+    } else {
+      real_r = (sh_flags[r] & 0x8000u) != 0u;
+    }
     int64_t yraw = yraw_first;
     int my_bl = my_bl_first;
     if (!first) {
@@ -474,32 +546,74 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
     }
     for (int b = wave; b < B; b += kWaves) {  // bins are independent: one wave each
       const int s = a.geom.start[b], n = a.geom.len[b];
-      const int mode_b = __builtin_amdgcn_readlane(my_mode, b);
+      int mode_b;
       const int bl_b = __builtin_amdgcn_readlane(my_bl, b);
-      float w = 0.f;
-      if (real_r) {
-        if (mode_b == 1 || (mode_b == 2 && bl_b > 0)) {
-          w = 1.f;
-        } else if (mode_b == 2) {
-          // position of the row among the bin's candidates (real, non-foreground rows) in row
-          // order, then the bin's keyed permutation of [0, n_bg): drawn iff the image is < k_b
-          const int k_b = __builtin_amdgcn_readlane(my_k, b);
-          const int nbg_b = __builtin_amdgcn_readlane(my_nbg, b);
-          int cnt = 0;
-          for (int q0 = lane; q0 < r; q0 += BGS_WAVE * 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int q = q0 + BGS_WAVE * u;
-              const unsigned f = sh_flags[q < r ? q : 0];
-              cnt += (q < r && (f & 0x8000u) && !((f >> b) & 1u)) ? 1 : 0;
-            }
+      float w = 0.f, scale_b;
+      if constexpr (VAR == 1) {
+        // one pass over the bin's plane: foreground count and the row's candidate position together
+        int k_b = 0, nbg_b = 0;
+        unsigned pos = 0u;
+        float total;
+        if (b == 0) {
+          mode_b = 1;
+          total = (float)n_real;
+        } else {
+          const unsigned long long Fw = lane < NW ? sh_pl[b * NW + lane] : 0ull;
+          const int wr = r >> 6;
+          const unsigned long long below = (1ull << (r & 63)) - 1ull;
+          const unsigned long long msk = lane < wr ? ~0ull : (lane == wr ? below : 0ull);
+          const unsigned tot =
+              (unsigned)bgs::wave_sum_i_fast((__popcll(Fw) << 16) | __popcll((Rw ^ Fw) & msk));
+          const int n_fg = (int)(tot >> 16);
+          pos = tot & 0xffffu;
+          nbg_b = n_real - n_fg;
+          if (n_fg == 0) {
+            mode_b = 0;
+            total = 0.f;
+          } else {
+            k_b = (int)((double)n_fg * a.ratio);
+            mode_b = (k_b >= nbg_b) ? 1 : 2;
+            total = mode_b == 1 ? (float)n_real : (float)(n_fg + k_b);
           }
-          const unsigned pos = (unsigned)bgs::wave_sum_i_fast(cnt);
-          const unsigned salt = bgs::gs_bin_salt(seed, (uint32_t)b);
-          w = (k_b > 0 && bgs::gs_perm(salt, pos, (unsigned)nbg_b) < (unsigned)k_b) ? 1.f : 0.f;
+        }
+        const float av = fmaxf(total, 1.f);
+        scale_b = (1.f / av) * a.lw[b];
+        if (first && blockIdx.x == 0 && lane == 0 && a.avg_out) a.avg_out[b] = av;
+        if (real_r) {
+          if (mode_b == 1 || (mode_b == 2 && bl_b > 0)) {
+            w = 1.f;
+          } else if (mode_b == 2) {
+            const unsigned salt = bgs::gs_bin_salt(seed, (uint32_t)b);
+            w = (k_b > 0 && bgs::gs_perm(salt, pos, (unsigned)nbg_b) < (unsigned)k_b) ? 1.f : 0.f;
+          }
+        }
+      } else {
+        mode_b = __builtin_amdgcn_readlane(my_mode, b);
+        scale_b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_scale), b));
+        if (real_r) {
+          if (mode_b == 1 || (mode_b == 2 && bl_b > 0)) {
+            w = 1.f;
+          } else if (mode_b == 2) {
+            // position of the row among the bin's candidates (real, non-foreground rows) in row
+            // order, then the bin's keyed permutation of [0, n_bg): drawn iff the image is < k_b
+            const int k_b = __builtin_amdgcn_readlane(my_k, b);
+            const int nbg_b = __builtin_amdgcn_readlane(my_nbg, b);
+            int cnt = 0;
+            for (int q0 = lane; q0 < r; q0 += BGS_WAVE * 4) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int q = q0 + BGS_WAVE * u;
+                const unsigned f = sh_flags[q < r ? q : 0];
+                cnt += (q < r && (f & 0x8000u) && !((f >> b) & 1u)) ? 1 : 0;
+              }
+            }
+            const unsigned pos = (unsigned)bgs::wave_sum_i_fast(cnt);
+            const unsigned salt = bgs::gs_bin_salt(seed, (uint32_t)b);
+            w = (k_b > 0 && bgs::gs_perm(salt, pos, (unsigned)nbg_b) < (unsigned)k_b) ? 1.f : 0.f;
+          }
         }
       }
-      const float coef = w * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_scale), b));
+      const float coef = w * scale_b;
       if (lane == 0) {
         if (a.bl_out) a.bl_out[(size_t)b * N + r] = bl_b;
         if (a.w_out) a.w_out[(size_t)b * N + r] = w;
@@ -575,6 +689,10 @@ __global__ __launch_bounds__(1024) void gs_head_reduce_kernel(const float* __res
   __shared__ float fin[BGS_MAX_BINS + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;     // 16 waves >= B + 1 rows
   const int rows = B + (has_box ? 1 : 0);
+  // the two values the tail depends on start with the partials (behind the sum / the barrier each was one more
+  // memory round trip on the kernel's only path)
+  const uint64_t draw = (tid == 0 && counter) ? counter[0] : 0ull;
+  const float avg0 = (has_box && wave == B) ? avg[0] : 1.f;
   if (wave <= B) {
     float acc = 0.f;
     if (wave < rows) {
@@ -591,7 +709,7 @@ __global__ __launch_bounds__(1024) void gs_head_reduce_kernel(const float* __res
       }
     }
     float s = bgs::wave_sum(acc);
-    if (wave == B && has_box) s *= box_w / avg[0];
+    if (wave == B && has_box) s *= box_w / avg0;
     if (lane == 0) {
       fin[wave] = s;
       out[wave] = s;
@@ -602,7 +720,7 @@ __global__ __launch_bounds__(1024) void gs_head_reduce_kernel(const float* __res
     float t = 0.f;
     for (int b = 0; b <= B; ++b) t += fin[b];
     if (total) total[0] = t;
-    if (counter) counter[0] += 1ull;
+    if (counter) counter[0] = draw + 1ull;
   }
 }
 
@@ -736,6 +854,16 @@ int head_rows_per_wg() {
   return g_head_rows;
 }
 
+int g_head_variant = -1;
+int head_variant() {
+  if (g_head_variant < 0) {
+    const char* e = getenv("BGS_GS_HEAD_VARIANT");
+    g_head_variant = e ? atoi(e) : 0;
+    if (g_head_variant < 0 || g_head_variant > 1) g_head_variant = 0;
+  }
+  return g_head_variant;
+}
+
 int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* host_bin_loss_weight,
                    hipStream_t st, int* grid_out) {
   a.tstamps = g_gs_tstamps;
@@ -759,8 +887,14 @@ int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* h
   const uintptr_t al = (uintptr_t)a.logits | (uintptr_t)(a.dlogits ? a.dlogits : a.logits);
   const bool grad = a.dlogits != nullptr;
   const bool box = a.bbox_pred != nullptr;
-#define BGS_HEAD_LAUNCH(VEC_, GRAD_, BOX_)                                                       \
-  hipLaunchKernelGGL((gs_head_fused_kernel<VEC_, GRAD_, BOX_>), dim3(grid), dim3(kBlock), lds, st, a)
+  const bool planes = head_variant() == 1;
+#define BGS_HEAD_LAUNCH(VEC_, GRAD_, BOX_)                                                              \
+  do {                                                                                                  \
+    if (planes)                                                                                         \
+      hipLaunchKernelGGL((gs_head_fused_kernel<VEC_, GRAD_, BOX_, 1>), dim3(grid), dim3(kBlock), lds, st, a); \
+    else                                                                                                \
+      hipLaunchKernelGGL((gs_head_fused_kernel<VEC_, GRAD_, BOX_, 0>), dim3(grid), dim3(kBlock), lds, st, a); \
+  } while (0)
 #define BGS_HEAD_VEC(VEC_)                                                                        \
   do {                                                                                            \
     if (grad) { if (box) BGS_HEAD_LAUNCH(VEC_, true, true); else BGS_HEAD_LAUNCH(VEC_, true, false); }   \
@@ -872,6 +1006,10 @@ __global__ __launch_bounds__(256) void gs_class_bits_kernel(const int64_t* __res
 // workgroup into buf[grid][8] (kernel start, loads landed, barrier 1, flags done, barrier 2, bins done,
 // barrier 3, end); NULL switches it off (the default).  tools/gs_phase_times.py.
 extern "C" void bgs_gs_head_debug_timestamps(unsigned long long* buf) { g_gs_tstamps = buf; }
+
+extern "C" void bgs_gs_head_variant(int variant) {      // < 0: back to the default (BGS_GS_HEAD_VARIANT or 0)
+  g_head_variant = variant < 0 ? -1 : ((variant == 1) ? 1 : 0);
+}
 
 extern "C" void bgs_gs_head_tuning(int rows_per_workgroup) {
   g_head_rows = (rows_per_workgroup >= 0 && rows_per_workgroup <= 64) ? rows_per_workgroup : 0;

@@ -219,11 +219,36 @@ def gs_class_bin_mask(label2binlabel):
     return out
 
 
+_UNIT_GRAD = {}
+
+
+def unit_gradient(device):
+    """The library's constant ``ones(1)`` float32 tensor of a device: a root gradient for
+    ``total.backward(unit_gradient(dev))`` that is not refilled every step (``backward()`` without an
+    argument launches a fill) and that :func:`gs_head_step`'s backward RECOGNISES (same storage): the
+    gradient the forward produced is already the answer, so the scaling launch is skipped instead of
+    launched to find out on the device that every factor is 1.  Read-only by contract."""
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    t = _UNIT_GRAD.get(device)
+    if t is None:
+        t = _UNIT_GRAD[device] = torch.ones(1, dtype=torch.float32, device=device)
+    return t
+
+
+def _is_unit_gradient(g):
+    t = _UNIT_GRAD.get(g.device)
+    return (t is not None and g.dtype == torch.float32 and g.numel() == 1
+            and g.data_ptr() == t.data_ptr())
+
+
 class _GsHeadStepFn(torch.autograd.Function):
     """``bgs_gs_head_step``: the whole ``GSBBoxHeadWith0.loss()`` as main kernel + reduce.  Returns
     ``terms [B + 1]`` = {per-bin losses (x loss weights), loss_bbox}, ``total [1]`` = their sum and
     ``avg [B]``; backward is ONE scaling launch over the gradients the forward already produced
-    (early-out on the device when the upstream factors are 1)."""
+    (early-out on the device when the upstream factors are 1), and NO launch when the upstream
+    gradient of ``total`` is :func:`unit_gradient` itself."""
 
     @staticmethod
     def forward(ctx, logits, bbox_pred, labels, l2b, class_bits, pred_slice_host,
@@ -281,14 +306,17 @@ class _GsHeadStepFn(torch.autograd.Function):
         if ctx.consumed:     # the buffers are scaled in place and handed to autograd (see _GroupSoftmaxLoss)
             raise RuntimeError('gs_head_step: the fused gradient buffers were consumed by the first '
                                'backward; call the loss again')
-        lib = capi.load()
-        gt = None if g_terms is None else g_terms.detach().to(torch.float32).contiguous()
-        gT = None if g_total is None else g_total.detach().to(torch.float32).contiguous()
-        ps_keep, ps_ptr = capi.host_i64(ps_host)
-        dev = (dlogits if dlogits is not None else dbbox).device
-        rc = lib.bgs_gs_head_step_scale_grad(capi.ptr(dlogits), capi.ptr(dbbox), ps_ptr, capi.ptr(gt),
-                                             capi.ptr(gT), N, B, W, R, capi.current_stream(dev))
-        capi.check('bgs_gs_head_step_scale_grad', rc)
+        if g_terms is None and _is_unit_gradient(g_total):
+            pass          # total.backward(unit_gradient(dev)): every factor is 1 by identity — no launch
+        else:
+            lib = capi.load()
+            gt = None if g_terms is None else g_terms.detach().to(torch.float32).contiguous()
+            gT = None if g_total is None else g_total.detach().to(torch.float32).contiguous()
+            ps_keep, ps_ptr = capi.host_i64(ps_host)
+            dev = (dlogits if dlogits is not None else dbbox).device
+            rc = lib.bgs_gs_head_step_scale_grad(capi.ptr(dlogits), capi.ptr(dbbox), ps_ptr, capi.ptr(gt),
+                                                 capi.ptr(gT), N, B, W, R, capi.current_stream(dev))
+            capi.check('bgs_gs_head_step_scale_grad', rc)
         ctx.consumed = True
         ctx.grads = (None, None)      # sole owner now: AccumulateGrad can take the buffer instead of cloning it
         gz = dlogits if (dlogits is None or zdt == torch.float32) else dlogits.to(zdt)

@@ -144,12 +144,16 @@ class GsHeadStep(object):
     main kernel (label remap, "others" draw, per-bin losses, gradient, box branch) + reduce (the
     6 loss terms, their sum, the draw counter), then the autograd edge (one scaling launch)."""
 
-    def __init__(self, inp):
+    def __init__(self, inp, unit_root=True):
         self.inp = inp
         self.logits = inp['logits'].clone().requires_grad_(True)
         # device-side draw counter, advanced by the reduce kernel: a new sample every step, also under graph replay
         self.draw = torch.zeros(1, dtype=torch.int64, device=inp['logits'].device)
-        self.one = torch.ones(1, dtype=torch.float32, device=inp['logits'].device)
+        # root gradient: a persistent tensor, not a fill per step.  unit_root: the library's constant
+        # (functional.unit_gradient) — the head's backward recognises it and launches nothing; otherwise some
+        # other ones tensor — the scaling launch runs and finds out on the device that every factor is 1
+        dev = inp['logits'].device
+        self.one = BF.unit_gradient(dev) if unit_root else torch.ones(1, dtype=torch.float32, device=dev)
 
     def __call__(self):
         i = self.inp
@@ -159,7 +163,7 @@ class GsHeadStep(object):
                                               bbox_targets=i['bbox_targets'],
                                               bbox_weights=i['bbox_weights'],
                                               num_reg_classes=NUM_CLASSES, beta=1.0, box_loss_weight=1.0)
-        total.backward(self.one)      # the root gradient is a persistent tensor, not a fill per step
+        total.backward(self.one)
         return total
 
 
@@ -725,12 +729,19 @@ def gs_head_metric(inp, n, steps=300, warmup=20):
     graph = try_graph(step)
     fn = graph.replay if graph is not None else step
     dt = timed_loop(fn, steps, warmup, 1)
+    # the same step under an arbitrary upstream gradient (the scaling launch of the autograd edge runs)
+    step_g = GsHeadStep(inp, unit_root=False)
+    graph_g = try_graph(step_g)
+    dt_g = timed_loop(graph_g.replay if graph_g is not None else step_g, steps, warmup, 1)
     return dict(value=round(dt * 1e6 / (steps * n), 6), unit='us/RoI', us_per_step=round(dt * 1e6 / steps, 2),
+                us_per_step_any_upstream=round(dt_g * 1e6 / steps, 2),
                 rois_per_step=n, steps=steps,
                 launch='hipGraph replay' if graph is not None else 'eager launches',
-                what='bgs_gs_head_step: main kernel (label remap + others sampling + per-bin loss fwd + bwd '
-                     '+ box branch) + reduce (6 terms, total, draw counter) + the autograd edge (one '
-                     'scaling launch); launch-latency bound')
+                what='bgs_gs_head_step + total.backward(unit_gradient): main kernel (label remap + others '
+                     'sampling + per-bin loss fwd + bwd + box branch) + reduce (6 terms, total, draw counter); '
+                     'the gradient the forward wrote is the answer when the root gradient is the library\'s '
+                     'constant 1 (no launch on the autograd edge); us_per_step_any_upstream = the same step '
+                     'under any other upstream gradient (one scaling launch more); launch-latency bound')
 
 
 STEP_GFLOP = {

@@ -289,3 +289,15 @@ def test_proposal_list_is_the_reference_list_plus_its_batch_tensors():
     for i, (p, v) in enumerate(pl):
         assert p.data_ptr() == props[i].data_ptr() and torch.equal(v, valid[i])
     assert pl.batched[0] is props and pl.batched[1] is valid
+
+
+def test_unit_gradient_is_one_cached_tensor_per_device_and_recognised_by_storage():
+    """functional.unit_gradient: the constant root gradient the GroupSoftmax head step recognises (no
+    scaling launch); a different ones tensor is NOT it, a view of the same storage is."""
+    import torch
+    from balancedgroupsoftmax_amd import functional as BF
+    u = BF.unit_gradient('cpu')
+    assert u is BF.unit_gradient(torch.device('cpu')) and u.shape == (1,) and u.dtype == torch.float32
+    assert BF._is_unit_gradient(u) and BF._is_unit_gradient(u.detach())
+    assert not BF._is_unit_gradient(torch.ones(1))
+    assert not BF._is_unit_gradient(u.double())

@@ -444,9 +444,56 @@ def test_head_forward_loss_backward_device_sampler(tmp_path):
     assert scores.shape == (64, C) and torch.isfinite(scores).all()
 
 
+@pytest.fixture(params=[0, 1], ids=['flagwords', 'bitplanes'])
+def head_variant(request):
+    """Both counting schemes of the fused head kernel (``bgs_gs_head_variant``): per-row flag words + packed
+    counters + a scan below the row, or one ballot word per (64 rows, bin) + one popcount pass per bin."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    lib.bgs_gs_head_variant(request.param)
+    yield request.param
+    lib.bgs_gs_head_variant(-1)
+
+
+def test_head_variants_are_bitwise_equal_on_ragged_batches():
+    """Flag words vs bit planes on batch sizes around the 64-row word and the 1024-row pass boundaries, with
+    padding rows and the box branch: every output of the step is bitwise the same."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    counts = gs_tables.synthetic_instance_counts(C, seed=0)
+    l2b, ps, _ = gs_tables.build_group_tables(counts)
+    W = int(ps[:, 1].sum())
+    l2b_t = dev(l2b)
+    try:
+        for n in (1, 2, 63, 64, 65, 127, 129, 1000, 1023, 1024, 1025, 2050, 4096):
+            batch = gs_oracle.make_roi_batch(n, W, C, seed=100 + n)
+            rs = np.random.RandomState(n)
+            rw = (rs.uniform(size=n) > 0.2).astype(np.float32)
+            bp = rs.standard_normal((n, 4 * C)).astype(np.float32)
+            bt = rs.standard_normal((n, 4)).astype(np.float32)
+            bw = np.repeat((batch['labels'] > 0)[:, None], 4, 1).astype(np.float32)
+            outs = []
+            for variant in (0, 1):
+                lib.bgs_gs_head_variant(variant)
+                z = dev(batch['logits']).requires_grad_(True)
+                p = dev(bp).requires_grad_(True)
+                counter = torch.full((1,), 5, dtype=torch.int64, device=DEV)
+                terms, total, avg, bl, w = BF.gs_head_step(
+                    z, dev(batch['labels']), l2b_t, ps, 3.0, 2024, draw_counter=counter, row_weights=dev(rw),
+                    bbox_pred=p, bbox_targets=dev(bt), bbox_weights=dev(bw), num_reg_classes=C, beta=1.0,
+                    box_loss_weight=1.0, debug=True)
+                total.backward(BF.unit_gradient(DEV))
+                outs.append([t.detach().cpu().numpy() for t in (terms, total, avg, bl, w, z.grad, p.grad)])
+            for x, y in zip(*outs):
+                np.testing.assert_array_equal(x, y)
+            assert outs[0][4][1:].sum() > 0 or n < 8          # "others" were drawn
+    finally:
+        lib.bgs_gs_head_variant(-1)
+
+
 @pytest.mark.parametrize('name', ['n1', 'n7', 'n512_cfg1', 'n1024_cfg2', 'n64_allbg', 'n40_allfg',
                                   'n96_onebin', 'n256_ratio2', 'n96_3bins', 'n96_9bins'])
-def test_fused_head_kernel_equals_prepare_plus_loss(name):
+def test_fused_head_kernel_equals_prepare_plus_loss(name, head_variant):
     """``bgs_gs_head_loss_fused`` (remap + sampling inside the loss kernel) == ``bgs_gs_prepare`` +
     ``bgs_gs_loss_fwd_bwd`` with the same seed: the same rows sampled (exact-k, ties by row), the
     same avg factors, bitwise-equal losses and gradients — incl. padding rows (``row_weights``)."""
@@ -474,7 +521,7 @@ def test_fused_head_kernel_equals_prepare_plus_loss(name):
         np.testing.assert_array_equal(z1.grad.cpu().numpy(), z0.grad.cpu().numpy())
 
 
-def test_fused_head_kernel_large_batch_and_forward_only():
+def test_fused_head_kernel_large_batch_and_forward_only(head_variant):
     """N = 4096 (the fused kernel's limit; each workgroup owns two rows) and the forward-only
     launch; exact sample counts per bin."""
     counts = gs_tables.synthetic_instance_counts(C, seed=0)
@@ -498,7 +545,7 @@ def test_fused_head_kernel_large_batch_and_forward_only():
 @pytest.mark.parametrize('name', ['n7', 'n512_cfg1', 'n1024_cfg2', 'n64_allbg', 'n40_allfg',
                                   'n256_ratio2', 'n96_9bins'])
 @pytest.mark.parametrize('train_box', [False, True])
-def test_head_step_two_launches_equal_the_separate_kernels(name, train_box):
+def test_head_step_two_launches_equal_the_separate_kernels(name, train_box, head_variant):
     """``bgs_gs_head_step`` (the whole ``GSBBoxHeadWith0.loss()`` as main kernel + reduce: remap,
     "others" draw, per-bin losses x loss weights, gradient, box branch, total, draw counter) against
     ``bgs_gs_prepare`` + ``bgs_gs_loss_fwd_bwd`` + ``bgs_bbox_smooth_l1_fwd_bwd``: bitwise-equal
@@ -581,6 +628,27 @@ def test_head_step_without_box_branch_and_unit_factors_is_bitwise_the_fused_loss
     t3, tot3, _ = BF.gs_head_step(dev(batch['logits']), labels, l2b_t, ps, 8.0, 31, draw_counter=counter)
     np.testing.assert_array_equal(t3.cpu().numpy(), v)
     np.testing.assert_array_equal(tot3.cpu().numpy(), total.detach().cpu().numpy())
+
+
+def test_head_step_backward_under_the_unit_gradient_launches_nothing_and_changes_nothing():
+    """``total.backward(BF.unit_gradient(dev))``: the head's backward recognises the library's constant
+    root gradient by identity and skips the scaling launch — the gradient is bitwise that of the general
+    edge (which launches and finds out on the device that every factor is 1); any other tensor, a ones
+    tensor included, still goes through the launch, and a non-unit factor still scales."""
+    case, l2b, ps, _, _, batch = case_setup('n1024_cfg2')
+    labels, l2b_t = dev(batch['labels']), dev(l2b)
+    unit = BF.unit_gradient(DEV)
+    assert unit is BF.unit_gradient(DEV) and float(unit.item()) == 1.0
+    grads = []
+    for root in (unit, torch.ones(1, device=DEV), torch.full((1,), 2.0, device=DEV)):
+        z = dev(batch['logits']).requires_grad_(True)
+        counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+        _, total, _ = BF.gs_head_step(z, labels, l2b_t, ps, 8.0, 77, draw_counter=counter)
+        total.backward(root)
+        grads.append(z.grad.cpu().numpy())
+    np.testing.assert_array_equal(grads[0], grads[1])
+    np.testing.assert_array_equal(2.0 * grads[0], grads[2])
+    assert float(unit.item()) == 1.0                  # read-only by contract: nobody wrote into it
 
 
 def test_head_step_refuses_rows_beyond_the_lds_window():

@@ -79,6 +79,13 @@ gsprof)
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/gsprof -o gs -- python $R/bench.py --workload gs_head --steps 50 --warmup 5 --no-graph --no-cpu-baseline > $OUT/gsprof_bench.json 2> $OUT/gsprof.err; echo "rocprof rc=$?")
   for f in $(find $OUT/gsprof -name "*kernel_stats.csv"); do cut -c1-150 $f | head -14; done
   ;;
+gstests)
+  timeout 600 python -m pytest tests/test_gpu_gs.py -m gpu -q --timeout 300 > $OUT/pytest_gs.log 2>&1; echo "pytest gs rc=$?" | tee -a $OUT/pytest_gs.log
+  grep -E "passed|failed|error" $OUT/pytest_gs.log | tail -3; grep -E "^FAILED|^ERROR|Error|assert " $OUT/pytest_gs.log | head -20
+  ;;
+gsab)
+  timeout 600 python tools/gs_head_ab.py 3 > $OUT/gs_head_ab.txt 2> $OUT/gs_head_ab.err; echo "gsab rc=$?"; cat $OUT/gs_head_ab.txt; tail -3 $OUT/gs_head_ab.err
+  ;;
 *) echo "running: $what"; bash -c "$what" ;;
 esac
 done
