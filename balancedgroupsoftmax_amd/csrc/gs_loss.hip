@@ -675,6 +675,274 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
 #undef GS_MARK
 }
 
+// ---- variants 2 / 3 (round 3): RPAR rows per workgroup IN PARALLEL, one 4-wave group each ----------------------------
+// The prologue of the kernel above (every workgroup recounts the N labels) is paid once per ROW; more rows per
+// workgroup one after the other were slower (the kernel is bound by a workgroup's serial path).  Here a workgroup is
+// RPAR x 256 threads: all of them share ONE prologue (N labels over RPAR x 256 threads: 4 / RPAR label rows per
+// thread, bit planes as in variant 1), then each 4-wave group runs its own row exactly as before — the serial path of
+// a row is unchanged, the redundant counting drops RPAR x (1024 rows: 256 workgroups of 16 waves, one per CU, each
+// label is looked at by 256 workgroups instead of 1024).  One row per group, no grid stride: N <= kMaxGrid, and the
+// partials are written per ROW (column r of [B + 1][N]) — the same values in the same places as the one-row-per-
+// workgroup kernels at grid = N, so everything downstream is bitwise unchanged.  Without row weights every row is
+// real: the "real" plane is known in closed form (no ballots, no popcount pass).
+__host__ __device__ inline size_t gs_head_multi_lds_bytes(int N, int C, int wpad, int rpar) {
+  return sizeof(float) * ((size_t)rpar * wpad + BGS_WAVE * bgs::kSweep) + 2 * (size_t)((N + 63) & ~63) +
+         2 * (size_t)((C + 7) & ~7) + sizeof(float) * 4 * rpar;
+}
+
+// sum over the wave of values that are zero outside lanes 0..15: four DPP steps inside row 0 (every lane of the row
+// ends up with the row's sum)
+__device__ __forceinline__ int gs_row0_sum_i(int v) {
+#ifndef BGS_NO_DPP
+  v += __builtin_amdgcn_update_dpp(v, v, 0xb1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(v, v, 0x4e, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false);  // row_ror:4
+  v += __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);  // row_ror:8
+  return __builtin_amdgcn_readlane(v, 0);
+#else
+  return bgs::wave_sum_i(v);
+#endif
+}
+
+template <int VEC, bool WRITE_GRAD, bool BOX, int RPAR>
+__global__ __launch_bounds__(kBlock * RPAR) void gs_head_multi_kernel(GsHeadArgs a) {
+  constexpr int T = kBlock * RPAR;
+  constexpr int RP = kFusedRowsPerPass / RPAR;      // label rows per thread and pass (a pass = 1024 rows)
+  static_assert(RP >= 1, "RPAR <= 4");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = a.N, C = a.C, B = a.B, W = a.W, wpad = a.wpad;
+  const int NW = (N + 63) >> 6;
+  const int cpad = (C + 7) & ~7;
+  unsigned long long* sh_pl =
+      reinterpret_cast<unsigned long long*>(smem + (size_t)RPAR * wpad + BGS_WAVE * bgs::kSweep);   // [16][NW]
+  unsigned short* sh_cbits = reinterpret_cast<unsigned short*>(sh_pl) + ((N + 63) & ~63);
+  float* sh_box = reinterpret_cast<float*>(sh_cbits + cpad);                                        // [RPAR][4]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int gw = bgs::uniform(tid >> 6);            // wave of the workgroup
+  const int grp = gw >> 2;                          // 4-wave group = row slot
+  const int wave = gw & 3;                          // wave of the group
+  const int htid = tid & (kBlock - 1);
+  const int r = (int)blockIdx.x * RPAR + grp;       // the group's row
+  const bool has_row = r < N;
+  const int rc0 = has_row ? r : 0;
+  uint64_t seed = a.seed;
+  if (a.seed_offset) seed += 0x2545F4914F6CDD1Dull * a.seed_offset[0];
+  const bool all_real = a.row_weights == nullptr;
+  // (a load behind a branch is waited for where it is issued: without row weights the same load reads the labels'
+  //  bytes and its value is ignored)
+  const float* rw_src = all_real ? reinterpret_cast<const float*>(a.labels) : a.row_weights;
+
+  // ---- loads: the group's label first (oldest), then everything independent, then the dependent gather
+  const int64_t yraw = a.labels[rc0];
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const uint16_t* cb_src = a.class_bits ? a.class_bits + (tid * 8 < cpad ? tid * 8 : 0)
+                                        : reinterpret_cast<const uint16_t*>(a.labels);
+  const u32x4_t cb0 = *reinterpret_cast<const u32x4_t*>(cb_src);
+  int64_t y0[RP];
+  float rwv0[RP];
+#pragma unroll
+  for (int i = 0; i < RP; ++i) {
+    const int q = tid + T * i;
+    const int qc = q < N ? q : 0;
+    y0[i] = a.labels[qc];
+    rwv0[i] = rw_src[qc];
+  }
+  float* row = smem + (size_t)grp * wpad;
+  float t0[VEC], t1[VEC];
+  const int c0 = htid * VEC, c1 = c0 + kBlock * VEC;
+  {
+    const float* g = a.logits + (size_t)rc0 * W;
+    bgs::load_vec<VEC>(g + (c0 < W ? c0 : 0), t0);
+    bgs::load_vec<VEC>(g + (c1 < W ? c1 : 0), t1);
+  }
+  int my_bl = 0;
+  if (lane < B) {
+    const int64_t yc = yraw < 0 ? 0 : (yraw >= C ? (int64_t)C - 1 : yraw);
+    my_bl = (int)a.l2b[(size_t)lane * C + yc];
+  }
+  if (a.class_bits) {
+    if (tid * 8 < cpad) *reinterpret_cast<u32x4_t*>(sh_cbits + tid * 8) = cb0;
+    for (int c = (tid + T) * 8; c < cpad; c += T * 8)
+      *reinterpret_cast<u32x4_t*>(sh_cbits + c) = *reinterpret_cast<const u32x4_t*>(a.class_bits + c);
+  } else {
+    for (int c = tid; c < C; c += T) {
+      unsigned bits = 0u;
+      for (int b = 0; b < B; ++b)
+        if (a.l2b[(size_t)b * C + c] > 0) bits |= 1u << b;
+      sh_cbits[c] = (unsigned short)bits;
+    }
+  }
+  if (c0 < W) bgs::store_vec<VEC>(row + c0, t0);
+  if (c1 < W) bgs::store_vec<VEC>(row + c1, t1);
+  for (int c = c1 + kBlock * VEC; c < W; c += kBlock * VEC) {
+    float t[VEC];
+    bgs::load_vec<VEC>(a.logits + (size_t)rc0 * W + c, t);
+    bgs::store_vec<VEC>(row + c, t);
+  }
+  __syncthreads();                          // class bits and the rows are in LDS
+
+  // ---- bit planes: lane p of a wave stores plane p's ballot word of the wave's 64 rows
+  auto pass = [&](const int base, const int64_t (&yv)[RP], const float (&rwv)[RP]) {
+    unsigned bits[RP];
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      const int64_t y = yv[i] < 0 ? 0 : (yv[i] >= C ? (int64_t)C - 1 : yv[i]);
+      bits[i] = sh_cbits[(int)y];
+    }
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      const int q = base + tid + T * i;
+      const unsigned wbits = (q < N && (all_real || rwv[i] > 0.f)) ? (bits[i] | 0x8000u) : 0u;
+      int lo = 0, hi = 0;
+      for (int p = 1; p < B; ++p) {
+        const unsigned long long m = __ballot((wbits >> p) & 1u);
+        lo = gs_writelane((int)(unsigned)m, p, lo);
+        hi = gs_writelane((int)(unsigned)(m >> 32), p, hi);
+      }
+      if (!all_real) {
+        const unsigned long long mr = __ballot(wbits >> 15);
+        lo = gs_writelane((int)(unsigned)mr, 15, lo);
+        hi = gs_writelane((int)(unsigned)(mr >> 32), 15, hi);
+      }
+      const int w = ((base + T * i) >> 6) + gw;
+      if (lane < 16 && w < NW)
+        sh_pl[lane * NW + w] = ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+    }
+  };
+  pass(0, y0, rwv0);
+  for (int base = T * RP; base < N; base += T * RP) {
+    int64_t yv[RP];
+    float rwv[RP];
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      const int q = base + tid + T * i;
+      const int qc = q < N ? q : 0;
+      yv[i] = a.labels[qc];
+      rwv[i] = rw_src[qc];
+    }
+    pass(base, yv, rwv);
+  }
+  __syncthreads();                          // planes are in LDS
+
+  const bool narrow = NW <= 16;             // the plane words sit in lanes 0..15: 4-step sums
+  unsigned long long Rw;                    // lane w: word w of the "real" plane
+  int n_real;
+  if (all_real) {
+    const int wn = N >> 6;
+    Rw = lane < wn ? ~0ull : (lane == wn ? ((1ull << (N & 63)) - 1ull) : 0ull);
+    n_real = N;
+  } else {
+    Rw = lane < NW ? sh_pl[15 * NW + lane] : 0ull;
+    n_real = narrow ? gs_row0_sum_i(__popcll(Rw)) : bgs::wave_sum_i_fast(__popcll(Rw));
+  }
+  const float box_scale = a.box_w / fmaxf((float)n_real, 1.f);
+  float lacc = 0.f, box_acc = 0.f;
+  const int64_t slot = (a.R == 1) ? 0 : yraw;
+  const bool pos_row = BOX && has_row && yraw > 0 && slot < a.R;
+
+  if (has_row) {                            // wave-uniform
+    const int wr = r >> 6;
+    bool real_r;
+    {
+      const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)Rw, wr);
+      const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(Rw >> 32), wr);
+      real_r = (((r & 32) ? rhi : rlo) >> (r & 31)) & 1u;
+    }
+    for (int b = wave; b < B; b += kWaves) {  // bins are independent: one wave each
+      const int s = a.geom.start[b], n = a.geom.len[b];
+      const int bl_b = __builtin_amdgcn_readlane(my_bl, b);
+      int mode_b, k_b = 0, nbg_b = 0;
+      unsigned pos = 0u;
+      float total, w = 0.f;
+      if (b == 0) {
+        mode_b = 1;
+        total = (float)n_real;
+      } else {
+        // one pass over the bin's plane: foreground count and the row's candidate position together
+        const unsigned long long Fw = lane < NW ? sh_pl[b * NW + lane] : 0ull;
+        const unsigned long long below = (1ull << (r & 63)) - 1ull;
+        const unsigned long long msk = lane < wr ? ~0ull : (lane == wr ? below : 0ull);
+        const int packed = (__popcll(Fw) << 16) | __popcll((Rw ^ Fw) & msk);
+        const unsigned tot = (unsigned)(narrow ? gs_row0_sum_i(packed) : bgs::wave_sum_i_fast(packed));
+        const int n_fg = (int)(tot >> 16);
+        pos = tot & 0xffffu;
+        nbg_b = n_real - n_fg;
+        if (n_fg == 0) {
+          mode_b = 0;
+          total = 0.f;
+        } else {
+          k_b = (int)((double)n_fg * a.ratio);
+          mode_b = (k_b >= nbg_b) ? 1 : 2;
+          total = mode_b == 1 ? (float)n_real : (float)(n_fg + k_b);
+        }
+      }
+      const float av = fmaxf(total, 1.f);
+      const float scale_b = (1.f / av) * a.lw[b];
+      if (r == 0 && lane == 0 && a.avg_out) a.avg_out[b] = av;
+      if (real_r) {
+        if (mode_b == 1 || (mode_b == 2 && bl_b > 0)) {
+          w = 1.f;
+        } else if (mode_b == 2) {
+          const unsigned salt = bgs::gs_bin_salt(seed, (uint32_t)b);
+          w = (k_b > 0 && bgs::gs_perm(salt, pos, (unsigned)nbg_b) < (unsigned)k_b) ? 1.f : 0.f;
+        }
+      }
+      const float coef = w * scale_b;
+      if (lane == 0) {
+        if (a.bl_out) a.bl_out[(size_t)b * N + r] = bl_b;
+        if (a.w_out) a.w_out[(size_t)b * N + r] = w;
+      }
+      const int tgt = min(max(bl_b, 0), n - 1);
+      float* seg = row + s;
+      if (coef == 0.f) {
+        if (WRITE_GRAD)
+          for (int j = lane; j < n; j += BGS_WAVE) seg[j] = 0.f;
+        continue;
+      }
+      float term;
+      if (n <= BGS_WAVE * bgs::kSweep) {
+        term = bgs::bin_loss_registers<WRITE_GRAD>(seg, n, lane, coef, tgt);
+      } else {
+        const float zt = seg[tgt];
+        float m, S;
+        bgs::bin_softmax_inplace(seg, n, lane, m, S);
+        term = coef * ((m + logf(S)) - zt);
+        if (WRITE_GRAD) bgs::bin_grad_inplace(seg, n, lane, coef / S, coef, tgt);
+      }
+      if (lane == b) lacc += term;
+    }
+    // box branch of the row: four lanes of the group's last wave
+    if (BOX && wave == kWaves - 1) {
+      float val = 0.f, g = 0.f;
+      if (pos_row && lane < 4) {
+        const float p = a.bbox_pred[((size_t)r * a.R + (size_t)slot) * 4 + lane];
+        const float t = a.bbox_targets[(size_t)r * 4 + lane];
+        const float bw = a.bbox_weights[(size_t)r * 4 + lane];
+        val = gs_sl1(p - t, a.beta, g) * bw;
+        g = g * bw * box_scale;
+      }
+      val = bgs::wave_sum(val);
+      if (lane == 0) box_acc += val;
+      if (a.dbbox && lane < 4) sh_box[grp * 4 + lane] = g;
+    }
+  }
+  __syncthreads();                          // gradient rows (and the box gradients) complete
+  if (has_row) {
+    if (WRITE_GRAD) bgs::unstage_row<VEC>(row, a.dlogits + (size_t)r * W, W, htid, kBlock);
+    if (BOX && a.dbbox) {                   // dense [N, 4R] gradient: zeros but for the positive slot
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const f32x4 gp = {sh_box[grp * 4 + 0], sh_box[grp * 4 + 1], sh_box[grp * 4 + 2], sh_box[grp * 4 + 3]};
+      f32x4* drow = reinterpret_cast<f32x4*>(a.dbbox + (size_t)r * a.R * 4);
+      for (int c = htid; c < a.R; c += kBlock)
+        drow[c] = (pos_row && c == (int)slot) ? gp : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // partials per ROW: [B + 1][N]
+    if (lane < B && (lane % kWaves) == wave) a.partial[(size_t)lane * N + r] = lacc;
+    if (BOX && wave == kWaves - 1 && lane == 0) a.partial[(size_t)B * N + r] = box_acc;
+  }
+}
+
 // out[b] = sum_g partial[b][g] for b < B (loss weights are already inside), out[B] = box loss
 // (scaled by loss_weight / avg[0]; 0 without a box branch), total[0] = their sum — the scalar the
 // reference forms in parse_losses; fixed summation order.  One wave per row of partials (all loads
@@ -859,7 +1127,7 @@ int head_variant() {
   if (g_head_variant < 0) {
     const char* e = getenv("BGS_GS_HEAD_VARIANT");
     g_head_variant = e ? atoi(e) : 0;
-    if (g_head_variant < 0 || g_head_variant > 1) g_head_variant = 0;
+    if (g_head_variant < 0 || g_head_variant > 3) g_head_variant = 0;
   }
   return g_head_variant;
 }
@@ -887,7 +1155,33 @@ int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* h
   const uintptr_t al = (uintptr_t)a.logits | (uintptr_t)(a.dlogits ? a.dlogits : a.logits);
   const bool grad = a.dlogits != nullptr;
   const bool box = a.bbox_pred != nullptr;
-  const bool planes = head_variant() == 1;
+  // variants 2 / 3: RPAR rows per workgroup in parallel (partials per row: N columns)
+  const int rpar = head_variant() == 3 ? 4 : (head_variant() == 2 ? 2 : 1);
+  if (rpar > 1 && a.N <= kMaxGrid && rows_per_wg <= 1 &&
+      gs_head_multi_lds_bytes(a.N, a.C, a.wpad, rpar) <= 64 * 1024) {
+    const size_t mlds = gs_head_multi_lds_bytes(a.N, a.C, a.wpad, rpar);
+    const int mgrid = (a.N + rpar - 1) / rpar;
+    *grid_out = a.N;
+#define BGS_MULTI_LAUNCH(VEC_, GRAD_, BOX_)                                                                   \
+  do {                                                                                                        \
+    if (rpar == 4)                                                                                            \
+      hipLaunchKernelGGL((gs_head_multi_kernel<VEC_, GRAD_, BOX_, 4>), dim3(mgrid), dim3(kBlock * 4), mlds, st, a); \
+    else                                                                                                      \
+      hipLaunchKernelGGL((gs_head_multi_kernel<VEC_, GRAD_, BOX_, 2>), dim3(mgrid), dim3(kBlock * 2), mlds, st, a); \
+  } while (0)
+#define BGS_MULTI_VEC(VEC_)                                                                                   \
+  do {                                                                                                        \
+    if (grad) { if (box) BGS_MULTI_LAUNCH(VEC_, true, true); else BGS_MULTI_LAUNCH(VEC_, true, false); }      \
+    else { if (box) BGS_MULTI_LAUNCH(VEC_, false, true); else BGS_MULTI_LAUNCH(VEC_, false, false); }         \
+  } while (0)
+    if (a.W % 4 == 0 && al % 16 == 0) BGS_MULTI_VEC(4);
+    else if (a.W % 2 == 0 && al % 8 == 0) BGS_MULTI_VEC(2);
+    else BGS_MULTI_VEC(1);
+#undef BGS_MULTI_VEC
+#undef BGS_MULTI_LAUNCH
+    return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
+  }
+  const bool planes = head_variant() >= 1;
 #define BGS_HEAD_LAUNCH(VEC_, GRAD_, BOX_)                                                              \
   do {                                                                                                  \
     if (planes)                                                                                         \
@@ -1008,7 +1302,7 @@ __global__ __launch_bounds__(256) void gs_class_bits_kernel(const int64_t* __res
 extern "C" void bgs_gs_head_debug_timestamps(unsigned long long* buf) { g_gs_tstamps = buf; }
 
 extern "C" void bgs_gs_head_variant(int variant) {      // < 0: back to the default (BGS_GS_HEAD_VARIANT or 0)
-  g_head_variant = variant < 0 ? -1 : ((variant == 1) ? 1 : 0);
+  g_head_variant = variant < 0 ? -1 : ((variant <= 3) ? variant : 0);
 }
 
 extern "C" void bgs_gs_head_tuning(int rows_per_workgroup) {

@@ -158,8 +158,9 @@ void bgs_gs_head_debug_timestamps(unsigned long long* buf);
 void bgs_gs_head_tuning(int rows_per_workgroup);
 /* A/B hook: how the fused head kernel counts (process-wide; env BGS_GS_HEAD_VARIANT).  0 = per-row flag words +
  * packed per-thread counters + a scan below the row; 1 = one 64-bit ballot word per (64 rows, bin) — counts and the
- * row's candidate position from one popcount pass per bin.  Bitwise the same results.  variant < 0: back to the
- * default. */
+ * row's candidate position from one popcount pass per bin; 2 / 3 = variant 1 with 2 / 4 rows per workgroup in
+ * parallel behind ONE shared prologue (N <= 2048; beyond that variant 1 runs).  Bitwise the same results.
+ * variant < 0: back to the default. */
 void bgs_gs_head_variant(int variant);
 /* Backward of bgs_gs_head_step: grad_terms [B+1] (device; upstream gradient of {bins, box}, NULL = 0)
  * and grad_total [1] (of total_out, NULL = 0): dlogits[:, bin b] *= grad_terms[b] + grad_total,

@@ -444,10 +444,11 @@ def test_head_forward_loss_backward_device_sampler(tmp_path):
     assert scores.shape == (64, C) and torch.isfinite(scores).all()
 
 
-@pytest.fixture(params=[0, 1], ids=['flagwords', 'bitplanes'])
+@pytest.fixture(params=[0, 1, 2, 3], ids=['flagwords', 'bitplanes', 'bitplanes2rows', 'bitplanes4rows'])
 def head_variant(request):
-    """Both counting schemes of the fused head kernel (``bgs_gs_head_variant``): per-row flag words + packed
-    counters + a scan below the row, or one ballot word per (64 rows, bin) + one popcount pass per bin."""
+    """The variants of the fused head kernel (``bgs_gs_head_variant``): per-row flag words + packed counters + a
+    scan below the row; one ballot word per (64 rows, bin) + one popcount pass per bin; the latter with 2 / 4 rows
+    per workgroup in parallel behind one shared prologue."""
     from balancedgroupsoftmax_amd import capi
     lib = capi.load()
     lib.bgs_gs_head_variant(request.param)
@@ -456,8 +457,9 @@ def head_variant(request):
 
 
 def test_head_variants_are_bitwise_equal_on_ragged_batches():
-    """Flag words vs bit planes on batch sizes around the 64-row word and the 1024-row pass boundaries, with
-    padding rows and the box branch: every output of the step is bitwise the same."""
+    """All four variants on batch sizes around the 64-row word, the 1024-row pass and the 2048-row limit of the
+    multi-row kernels, with padding rows (and without: the closed-form "real" plane) and the box branch: every
+    output of the step is bitwise the same."""
     from balancedgroupsoftmax_amd import capi
     lib = capi.load()
     counts = gs_tables.synthetic_instance_counts(C, seed=0)
@@ -465,27 +467,28 @@ def test_head_variants_are_bitwise_equal_on_ragged_batches():
     W = int(ps[:, 1].sum())
     l2b_t = dev(l2b)
     try:
-        for n in (1, 2, 63, 64, 65, 127, 129, 1000, 1023, 1024, 1025, 2050, 4096):
+        for n in (1, 2, 3, 63, 64, 65, 127, 128, 129, 1000, 1023, 1024, 1025, 2047, 2048, 2050, 4096):
             batch = gs_oracle.make_roi_batch(n, W, C, seed=100 + n)
             rs = np.random.RandomState(n)
-            rw = (rs.uniform(size=n) > 0.2).astype(np.float32)
+            rw = (rs.uniform(size=n) > 0.2).astype(np.float32) if n % 2 else None
             bp = rs.standard_normal((n, 4 * C)).astype(np.float32)
             bt = rs.standard_normal((n, 4)).astype(np.float32)
             bw = np.repeat((batch['labels'] > 0)[:, None], 4, 1).astype(np.float32)
             outs = []
-            for variant in (0, 1):
+            for variant in (0, 1, 2, 3):
                 lib.bgs_gs_head_variant(variant)
                 z = dev(batch['logits']).requires_grad_(True)
                 p = dev(bp).requires_grad_(True)
                 counter = torch.full((1,), 5, dtype=torch.int64, device=DEV)
                 terms, total, avg, bl, w = BF.gs_head_step(
-                    z, dev(batch['labels']), l2b_t, ps, 3.0, 2024, draw_counter=counter, row_weights=dev(rw),
-                    bbox_pred=p, bbox_targets=dev(bt), bbox_weights=dev(bw), num_reg_classes=C, beta=1.0,
-                    box_loss_weight=1.0, debug=True)
+                    z, dev(batch['labels']), l2b_t, ps, 3.0, 2024, draw_counter=counter,
+                    row_weights=None if rw is None else dev(rw), bbox_pred=p, bbox_targets=dev(bt),
+                    bbox_weights=dev(bw), num_reg_classes=C, beta=1.0, box_loss_weight=1.0, debug=True)
                 total.backward(BF.unit_gradient(DEV))
                 outs.append([t.detach().cpu().numpy() for t in (terms, total, avg, bl, w, z.grad, p.grad)])
-            for x, y in zip(*outs):
-                np.testing.assert_array_equal(x, y)
+            for other in outs[1:]:
+                for x, y in zip(outs[0], other):
+                    np.testing.assert_array_equal(x, y)
             assert outs[0][4][1:].sum() > 0 or n < 8          # "others" were drawn
     finally:
         lib.bgs_gs_head_variant(-1)

@@ -1,5 +1,5 @@
 """A/B of the fused GroupSoftmax head kernel's counting scheme (bgs_gs_head_variant: 0 = flag words, 1 = bit
-planes): the main kernel under back-to-back HIP events and the whole head step under hipGraph replay, several
+planes, 2 / 3 = bit planes with 2 / 4 rows per workgroup): the main kernel under back-to-back HIP events and the whole head step under hipGraph replay, several
 interleaved rounds.  GPU only.  `python tools/gs_head_ab.py [rounds]`."""
 import json
 import os
@@ -17,10 +17,10 @@ def main():
     dev = torch.device('cuda', 0)
     lib = capi.load()
     out = {}
-    for n in (1024, 512, 4096):
+    for n in (1024, 512, 2048):
         inp = bench.make_inputs(n, 0, dev)
         for rnd in range(rounds):
-            for variant in (0, 1):
+            for variant in (0, 1, 2, 3):
                 lib.bgs_gs_head_variant(variant)
                 r = bench.kernel_roofline(inp, n, iters=300, kernel='fused')
                 rec = out.setdefault('n%d_v%d' % (n, variant), dict(kernel_us=[], step_us=[], step_any_us=[]))
