@@ -52,6 +52,7 @@ SIGNATURES = {
     'bgs_gs_head_debug_timestamps': (None, [c_ptr]),
     'bgs_gs_head_tuning': (None, [ctypes.c_int]),
     'bgs_gs_head_variant': (None, [ctypes.c_int]),
+    'bgs_gs_head_variant_used': (ctypes.c_int, [ctypes.c_int]),
     'bgs_sgd_clip_workspace_bytes': (ctypes.c_size_t, [c_ptr, ctypes.c_int]),
     'bgs_sgd_clip_step': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int] + [ctypes.c_float] * 5
                           + [c_ptr, ctypes.c_size_t, c_ptr, c_ptr]),

@@ -1122,14 +1122,22 @@ int head_rows_per_wg() {
   return g_head_rows;
 }
 
-int g_head_variant = -1;
-int head_variant() {
-  if (g_head_variant < 0) {
+// variant of the fused head kernel: explicit (bgs_gs_head_variant / BGS_GS_HEAD_VARIANT = 0..3) or automatic — rows
+// in parallel behind one prologue wherever the per-row partials fit the workspace (N <= kMaxGrid): four per
+// workgroup once that still gives every CU a workgroup (N >= 1024), else two; beyond, one row per workgroup with bit
+// planes (profiles/r6w_gs_head_ab.txt: 10.3 / 9.7 / 7.7 / 7.7 us at N = 1024, 8.9 / 8.6 / 7.2 / 8.4 at 512,
+// 21.3 / 20.8 / 14.9 / 14.0 at 2048 for variants 0 / 1 / 2 / 3)
+int g_head_variant = -2;                    // -2: not read yet, -1: automatic
+int head_variant_for(int N) {
+  if (g_head_variant == -2) {
     const char* e = getenv("BGS_GS_HEAD_VARIANT");
-    g_head_variant = e ? atoi(e) : 0;
-    if (g_head_variant < 0 || g_head_variant > 3) g_head_variant = 0;
+    g_head_variant = e ? atoi(e) : -1;
+    if (g_head_variant < -1 || g_head_variant > 3) g_head_variant = -1;
   }
-  return g_head_variant;
+  int v = g_head_variant;
+  if (v < 0) v = N >= 1024 ? 3 : 2;
+  if (v >= 2 && N > kMaxGrid) v = 1;
+  return v;
 }
 
 int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* host_bin_loss_weight,
@@ -1156,7 +1164,8 @@ int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* h
   const bool grad = a.dlogits != nullptr;
   const bool box = a.bbox_pred != nullptr;
   // variants 2 / 3: RPAR rows per workgroup in parallel (partials per row: N columns)
-  const int rpar = head_variant() == 3 ? 4 : (head_variant() == 2 ? 2 : 1);
+  const int variant = head_variant_for(a.N);
+  const int rpar = variant == 3 ? 4 : (variant == 2 ? 2 : 1);
   if (rpar > 1 && a.N <= kMaxGrid && rows_per_wg <= 1 &&
       gs_head_multi_lds_bytes(a.N, a.C, a.wpad, rpar) <= 64 * 1024) {
     const size_t mlds = gs_head_multi_lds_bytes(a.N, a.C, a.wpad, rpar);
@@ -1181,7 +1190,7 @@ int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* h
 #undef BGS_MULTI_LAUNCH
     return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
   }
-  const bool planes = head_variant() >= 1;
+  const bool planes = variant >= 1;
 #define BGS_HEAD_LAUNCH(VEC_, GRAD_, BOX_)                                                              \
   do {                                                                                                  \
     if (planes)                                                                                         \
@@ -1301,9 +1310,11 @@ __global__ __launch_bounds__(256) void gs_class_bits_kernel(const int64_t* __res
 // barrier 3, end); NULL switches it off (the default).  tools/gs_phase_times.py.
 extern "C" void bgs_gs_head_debug_timestamps(unsigned long long* buf) { g_gs_tstamps = buf; }
 
-extern "C" void bgs_gs_head_variant(int variant) {      // < 0: back to the default (BGS_GS_HEAD_VARIANT or 0)
-  g_head_variant = variant < 0 ? -1 : ((variant <= 3) ? variant : 0);
+extern "C" void bgs_gs_head_variant(int variant) {      // < 0: back to the default (BGS_GS_HEAD_VARIANT or automatic)
+  g_head_variant = variant < 0 ? -2 : ((variant <= 3) ? variant : 0);
 }
+
+extern "C" int bgs_gs_head_variant_used(int N) { return head_variant_for(N); }
 
 extern "C" void bgs_gs_head_tuning(int rows_per_workgroup) {
   g_head_rows = (rows_per_workgroup >= 0 && rows_per_workgroup <= 64) ? rows_per_workgroup : 0;

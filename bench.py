@@ -511,8 +511,9 @@ def _pmc_traffic(kernel, n):
 def kernel_roofline(inp, n, iters=300, kernel='fused'):
     """HIP-event timing of ONE GroupSoftmax kernel alone, back to back on the current stream.
     ``kernel='fused'``: the kernel the detector step and the gs_head step actually launch for
-    N <= 4096 (``gs_head_fused_kernel``: main launch of bgs_gs_head_step with loss_out = NULL — label
-    remap + "others" draw + loss + gradient + box branch).  ``kernel='rowwave'``: the plain loss
+    N <= 4096 (``gs_head_multi_kernel`` for N <= 2048 — 4 or 2 rows per workgroup behind one shared
+    prologue —, ``gs_head_fused_kernel`` beyond; ``bgs_gs_head_variant_used``: main launch of
+    bgs_gs_head_step with loss_out = NULL — label remap + "others" draw + loss + gradient + box branch).  ``kernel='rowwave'``: the plain loss
     kernel (main launch of bgs_gs_loss_fwd_bwd; the path for N > 4096 / reweighted heads).
     Algorithmic bytes per RoI: W*4 read + W*4 written + 8 (label) + B*4."""
     lib = capi.load()
@@ -525,7 +526,9 @@ def kernel_roofline(inp, n, iters=300, kernel='fused'):
     if kernel == 'fused':
         avg = torch.empty(B, dtype=torch.float32, device=dev)
         cbits = BF.gs_class_bin_mask(inp['l2b'])
-        kname = 'gs_head_fused_kernel<4,true,true>'
+        variant = lib.bgs_gs_head_variant_used(n)
+        kname = {0: 'gs_head_fused_kernel<4,true,true,0>', 1: 'gs_head_fused_kernel<4,true,true,1>',
+                 2: 'gs_head_multi_kernel<4,true,true,2>', 3: 'gs_head_multi_kernel<4,true,true,4>'}[variant]
 
         def launch():
             rc = lib.bgs_gs_head_step(capi.ptr(inp['logits']), capi.ptr(inp['labels']), capi.ptr(inp['l2b']),

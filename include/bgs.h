@@ -156,12 +156,14 @@ int bgs_gs_class_bin_mask(const int64_t* label2binlabel, int C, int B, uint16_t*
 void bgs_gs_head_debug_timestamps(unsigned long long* buf);
 /* Tuning / test hook: rows per workgroup of the fused head kernel (0 = default; process-wide). */
 void bgs_gs_head_tuning(int rows_per_workgroup);
-/* A/B hook: how the fused head kernel counts (process-wide; env BGS_GS_HEAD_VARIANT).  0 = per-row flag words +
- * packed per-thread counters + a scan below the row; 1 = one 64-bit ballot word per (64 rows, bin) — counts and the
- * row's candidate position from one popcount pass per bin; 2 / 3 = variant 1 with 2 / 4 rows per workgroup in
- * parallel behind ONE shared prologue (N <= 2048; beyond that variant 1 runs).  Bitwise the same results.
- * variant < 0: back to the default. */
+/* A/B hook: the variant of the fused head kernel (process-wide; env BGS_GS_HEAD_VARIANT).  0 = one row per
+ * workgroup, per-row flag words + packed per-thread counters + a scan below the row; 1 = one row per workgroup, one
+ * 64-bit ballot word per (64 rows, bin) — counts and the row's candidate position from one popcount pass per bin;
+ * 2 / 3 = variant 1 with 2 / 4 rows per workgroup in parallel behind ONE shared prologue (N <= 2048; beyond that
+ * variant 1 runs).  Bitwise the same results.  variant < 0 (the default): automatic — 3 for 1024 <= N <= 2048, 2 for
+ * N < 1024, 1 beyond.  bgs_gs_head_variant_used(N): the variant a launch with N rows takes. */
 void bgs_gs_head_variant(int variant);
+int bgs_gs_head_variant_used(int N);
 /* Backward of bgs_gs_head_step: grad_terms [B+1] (device; upstream gradient of {bins, box}, NULL = 0)
  * and grad_total [1] (of total_out, NULL = 0): dlogits[:, bin b] *= grad_terms[b] + grad_total,
  * dbbox_pred *= grad_terms[B] + grad_total, in place, one launch, early-out on the device when

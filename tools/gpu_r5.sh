@@ -86,6 +86,24 @@ gstests)
 gsab)
   timeout 600 python tools/gs_head_ab.py 3 > $OUT/gs_head_ab.txt 2> $OUT/gs_head_ab.err; echo "gsab rc=$?"; cat $OUT/gs_head_ab.txt; tail -3 $OUT/gs_head_ab.err
   ;;
+gspmc)
+  # HBM traffic of the head kernel: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes (kernel-trace only)
+  for C in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout -k 3 150 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/gspmc/$C -o p -- python $R/bench.py --workload gs_head --steps 20 --warmup 2 --no-graph --no-cpu-baseline > $OUT/gspmc_$C.log 2> $OUT/gspmc_$C.err; echo "pmc $C rc=$?")
+  done
+  python - <<PY
+import csv, glob, collections
+for f in sorted(glob.glob('$OUT/gspmc/**/*counter_collection.csv', recursive=True)):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        kn = r.get('Kernel_Name', '')
+        if 'gs_head_multi' in kn or 'gs_head_fused' in kn or 'gs_loss_rowwave' in kn:
+            agg[(kn.split('(')[0][-44:], r.get('Grid_Size'), r.get('Counter_Name'))].append(float(r.get('Counter_Value', 0)))
+    for k, v in sorted(agg.items()):
+        print('%-46s grid %-9s %-12s n=%d avg=%.6g' % (k[0], k[1], k[2], len(v), sum(v) / len(v)))
+PY
+  find $OUT/gspmc -name "*.csv" -size +5M -delete
+  ;;
 *) echo "running: $what"; bash -c "$what" ;;
 esac
 done
