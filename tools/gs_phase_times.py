@@ -1,10 +1,13 @@
 """Phase times of the fused GroupSoftmax head kernel from in-kernel s_memtime marks
-(bgs_gs_head_debug_timestamps): per workgroup, averaged over the grid."""
+(bgs_gs_head_debug_timestamps): per workgroup, averaged over the grid.  The marks live in the ONE-row-per-
+workgroup kernels (bgs_gs_head_variant 0 = flag words, 1 = bit planes; `python tools/gs_phase_times.py [variant]`,
+default 1); the multi-row kernel the library picks by default for N <= 2048 carries none."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from balancedgroupsoftmax_amd import capi, functional as BF
 from bench import make_inputs, NUM_CLASSES
 lib = capi.load()
+lib.bgs_gs_head_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 dev = torch.device('cuda:0')
 n = 1024
 inp = make_inputs(n, 1000, dev)
