@@ -704,7 +704,42 @@ __device__ __forceinline__ int gs_row0_sum_i(int v) {
 #endif
 }
 
-template <int VEC, bool WRITE_GRAD, bool BOX, int RPAR>
+// bgs::bin_loss_registers with the gradient of the bin going from the registers straight to its columns of the
+// global gradient row (64 consecutive floats per store instruction) instead of back into the LDS row: the wave that
+// owns a bin finishes it alone, the row needs no third barrier and no LDS round trip on the way out (variants 4 / 5).
+// The same arithmetic in the same order: bitwise the same gradient.
+__device__ __forceinline__ float gs_bin_loss_direct(const float* __restrict__ seg, float* __restrict__ gseg, int n,
+                                                    int lane, float coef, int tgt) {
+  float x[bgs::kSweep];
+  bool ok[bgs::kSweep];
+#pragma unroll
+  for (int u = 0; u < bgs::kSweep; ++u) {
+    const int j = lane + BGS_WAVE * u;
+    ok[u] = j < n;
+    x[u] = seg[j];
+  }
+  const float zt = seg[tgt];
+  float pm = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < bgs::kSweep; ++u) pm = fmaxf(pm, ok[u] ? x[u] : -INFINITY);
+  const float m = bgs::wave_max(pm);
+  float ps = 0.f;
+#pragma unroll
+  for (int u = 0; u < bgs::kSweep; ++u) {
+    x[u] = ok[u] ? __builtin_amdgcn_exp2f((x[u] - m) * bgs::kLog2e) : 0.f;
+    ps += x[u];
+  }
+  const float S = bgs::wave_sum(ps);
+  const float k = coef / S;
+#pragma unroll
+  for (int u = 0; u < bgs::kSweep; ++u) {
+    const int j = lane + BGS_WAVE * u;
+    if (ok[u]) gseg[j] = x[u] * k - (j == tgt ? coef : 0.f);
+  }
+  return coef * ((m + logf(S)) - zt);
+}
+
+template <int VEC, bool WRITE_GRAD, bool BOX, int RPAR, bool DIRECT>
 __global__ __launch_bounds__(kBlock * RPAR) void gs_head_multi_kernel(GsHeadArgs a) {
   constexpr int T = kBlock * RPAR;
   constexpr int RP = kFusedRowsPerPass / RPAR;      // label rows per thread and pass (a pass = 1024 rows)
@@ -761,6 +796,9 @@ __global__ __launch_bounds__(kBlock * RPAR) void gs_head_multi_kernel(GsHeadArgs
     const int64_t yc = yraw < 0 ? 0 : (yraw >= C ? (int64_t)C - 1 : yraw);
     my_bl = (int)a.l2b[(size_t)lane * C + yc];
   }
+  // the salt of the wave's first sampled bin (bin 0 is never sampled): scalar work in the shadow of the loads
+  const int first_sampled = wave ? wave : kWaves;
+  const unsigned salt_first = DIRECT ? bgs::gs_bin_salt(seed, (uint32_t)first_sampled) : 0u;
   if (a.class_bits) {
     if (tid * 8 < cpad) *reinterpret_cast<u32x4_t*>(sh_cbits + tid * 8) = cb0;
     for (int c = (tid + T) * 8; c < cpad; c += T * 8)
@@ -884,7 +922,7 @@ __global__ __launch_bounds__(kBlock * RPAR) void gs_head_multi_kernel(GsHeadArgs
         if (mode_b == 1 || (mode_b == 2 && bl_b > 0)) {
           w = 1.f;
         } else if (mode_b == 2) {
-          const unsigned salt = bgs::gs_bin_salt(seed, (uint32_t)b);
+          const unsigned salt = (DIRECT && b == first_sampled) ? salt_first : bgs::gs_bin_salt(seed, (uint32_t)b);
           w = (k_b > 0 && bgs::gs_perm(salt, pos, (unsigned)nbg_b) < (unsigned)k_b) ? 1.f : 0.f;
         }
       }
@@ -895,20 +933,26 @@ __global__ __launch_bounds__(kBlock * RPAR) void gs_head_multi_kernel(GsHeadArgs
       }
       const int tgt = min(max(bl_b, 0), n - 1);
       float* seg = row + s;
+      float* gseg = (WRITE_GRAD && DIRECT) ? a.dlogits + (size_t)r * W + s : nullptr;   // the bin's columns of the gradient row
       if (coef == 0.f) {
         if (WRITE_GRAD)
-          for (int j = lane; j < n; j += BGS_WAVE) seg[j] = 0.f;
+          for (int j = lane; j < n; j += BGS_WAVE) (DIRECT ? gseg : seg)[j] = 0.f;
         continue;
       }
       float term;
       if (n <= BGS_WAVE * bgs::kSweep) {
-        term = bgs::bin_loss_registers<WRITE_GRAD>(seg, n, lane, coef, tgt);
+        term = (WRITE_GRAD && DIRECT) ? gs_bin_loss_direct(seg, gseg, n, lane, coef, tgt)
+                                      : bgs::bin_loss_registers<WRITE_GRAD>(seg, n, lane, coef, tgt);
       } else {
         const float zt = seg[tgt];
         float m, S;
         bgs::bin_softmax_inplace(seg, n, lane, m, S);
         term = coef * ((m + logf(S)) - zt);
-        if (WRITE_GRAD) bgs::bin_grad_inplace(seg, n, lane, coef / S, coef, tgt);
+        if (WRITE_GRAD) {
+          bgs::bin_grad_inplace(seg, n, lane, coef / S, coef, tgt);
+          if (DIRECT)        // the wave's own LDS writes, read back in order: no barrier
+            for (int j = lane; j < n; j += BGS_WAVE) gseg[j] = seg[j];
+        }
       }
       if (lane == b) lacc += term;
     }
@@ -927,9 +971,10 @@ __global__ __launch_bounds__(kBlock * RPAR) void gs_head_multi_kernel(GsHeadArgs
       if (a.dbbox && lane < 4) sh_box[grp * 4 + lane] = g;
     }
   }
-  __syncthreads();                          // gradient rows (and the box gradients) complete
+  // gradient rows (and the box gradients) complete; with direct stores only the dense box gradient needs the barrier
+  if (!(WRITE_GRAD && DIRECT) || (BOX && a.dbbox)) __syncthreads();
   if (has_row) {
-    if (WRITE_GRAD) bgs::unstage_row<VEC>(row, a.dlogits + (size_t)r * W, W, htid, kBlock);
+    if (WRITE_GRAD && !DIRECT) bgs::unstage_row<VEC>(row, a.dlogits + (size_t)r * W, W, htid, kBlock);
     if (BOX && a.dbbox) {                   // dense [N, 4R] gradient: zeros but for the positive slot
       typedef float f32x4 __attribute__((ext_vector_type(4)));
       const f32x4 gp = {sh_box[grp * 4 + 0], sh_box[grp * 4 + 1], sh_box[grp * 4 + 2], sh_box[grp * 4 + 3]};
@@ -1132,7 +1177,7 @@ int head_variant_for(int N) {
   if (g_head_variant == -2) {
     const char* e = getenv("BGS_GS_HEAD_VARIANT");
     g_head_variant = e ? atoi(e) : -1;
-    if (g_head_variant < -1 || g_head_variant > 3) g_head_variant = -1;
+    if (g_head_variant < -1 || g_head_variant > 5) g_head_variant = -1;
   }
   int v = g_head_variant;
   if (v < 0) v = N >= 1024 ? 3 : 2;
@@ -1165,18 +1210,24 @@ int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* h
   const bool box = a.bbox_pred != nullptr;
   // variants 2 / 3: RPAR rows per workgroup in parallel (partials per row: N columns)
   const int variant = head_variant_for(a.N);
-  const int rpar = variant == 3 ? 4 : (variant == 2 ? 2 : 1);
+  const int rpar = (variant == 3 || variant == 5) ? 4 : ((variant == 2 || variant == 4) ? 2 : 1);
+  const bool direct = variant >= 4;
   if (rpar > 1 && a.N <= kMaxGrid && rows_per_wg <= 1 &&
       gs_head_multi_lds_bytes(a.N, a.C, a.wpad, rpar) <= 64 * 1024) {
     const size_t mlds = gs_head_multi_lds_bytes(a.N, a.C, a.wpad, rpar);
     const int mgrid = (a.N + rpar - 1) / rpar;
     *grid_out = a.N;
-#define BGS_MULTI_LAUNCH(VEC_, GRAD_, BOX_)                                                                   \
-  do {                                                                                                        \
-    if (rpar == 4)                                                                                            \
-      hipLaunchKernelGGL((gs_head_multi_kernel<VEC_, GRAD_, BOX_, 4>), dim3(mgrid), dim3(kBlock * 4), mlds, st, a); \
-    else                                                                                                      \
-      hipLaunchKernelGGL((gs_head_multi_kernel<VEC_, GRAD_, BOX_, 2>), dim3(mgrid), dim3(kBlock * 2), mlds, st, a); \
+#define BGS_MULTI_LAUNCH2(VEC_, GRAD_, BOX_, DIR_)                                                                  \
+  do {                                                                                                              \
+    if (rpar == 4)                                                                                                  \
+      hipLaunchKernelGGL((gs_head_multi_kernel<VEC_, GRAD_, BOX_, 4, DIR_>), dim3(mgrid), dim3(kBlock * 4), mlds, st, a); \
+    else                                                                                                            \
+      hipLaunchKernelGGL((gs_head_multi_kernel<VEC_, GRAD_, BOX_, 2, DIR_>), dim3(mgrid), dim3(kBlock * 2), mlds, st, a); \
+  } while (0)
+#define BGS_MULTI_LAUNCH(VEC_, GRAD_, BOX_)                                                                         \
+  do {                                                                                                              \
+    if (GRAD_ && direct) BGS_MULTI_LAUNCH2(VEC_, GRAD_, BOX_, GRAD_);                                               \
+    else BGS_MULTI_LAUNCH2(VEC_, GRAD_, BOX_, false);                                                               \
   } while (0)
 #define BGS_MULTI_VEC(VEC_)                                                                                   \
   do {                                                                                                        \
@@ -1188,6 +1239,7 @@ int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* h
     else BGS_MULTI_VEC(1);
 #undef BGS_MULTI_VEC
 #undef BGS_MULTI_LAUNCH
+#undef BGS_MULTI_LAUNCH2
     return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
   }
   const bool planes = variant >= 1;
@@ -1311,7 +1363,7 @@ __global__ __launch_bounds__(256) void gs_class_bits_kernel(const int64_t* __res
 extern "C" void bgs_gs_head_debug_timestamps(unsigned long long* buf) { g_gs_tstamps = buf; }
 
 extern "C" void bgs_gs_head_variant(int variant) {      // < 0: back to the default (BGS_GS_HEAD_VARIANT or automatic)
-  g_head_variant = variant < 0 ? -2 : ((variant <= 3) ? variant : 0);
+  g_head_variant = variant < 0 ? -2 : ((variant <= 5) ? variant : 0);
 }
 
 extern "C" int bgs_gs_head_variant_used(int N) { return head_variant_for(N); }

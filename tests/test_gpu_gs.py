@@ -444,11 +444,13 @@ def test_head_forward_loss_backward_device_sampler(tmp_path):
     assert scores.shape == (64, C) and torch.isfinite(scores).all()
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=['flagwords', 'bitplanes', 'bitplanes2rows', 'bitplanes4rows'])
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5], ids=['flagwords', 'bitplanes', 'bitplanes2rows', 'bitplanes4rows',
+                                                'bitplanes2rows_direct', 'bitplanes4rows_direct'])
 def head_variant(request):
     """The variants of the fused head kernel (``bgs_gs_head_variant``): per-row flag words + packed counters + a
     scan below the row; one ballot word per (64 rows, bin) + one popcount pass per bin; the latter with 2 / 4 rows
-    per workgroup in parallel behind one shared prologue."""
+    per workgroup in parallel behind one shared prologue; those with the gradient stored by the wave that owns the
+    bin (no third barrier)."""
     from balancedgroupsoftmax_amd import capi
     lib = capi.load()
     lib.bgs_gs_head_variant(request.param)
@@ -457,7 +459,7 @@ def head_variant(request):
 
 
 def test_head_variants_are_bitwise_equal_on_ragged_batches():
-    """All four variants on batch sizes around the 64-row word, the 1024-row pass and the 2048-row limit of the
+    """All six variants on batch sizes around the 64-row word, the 1024-row pass and the 2048-row limit of the
     multi-row kernels, with padding rows (and without: the closed-form "real" plane) and the box branch: every
     output of the step is bitwise the same."""
     from balancedgroupsoftmax_amd import capi
@@ -475,7 +477,7 @@ def test_head_variants_are_bitwise_equal_on_ragged_batches():
             bt = rs.standard_normal((n, 4)).astype(np.float32)
             bw = np.repeat((batch['labels'] > 0)[:, None], 4, 1).astype(np.float32)
             outs = []
-            for variant in (0, 1, 2, 3):
+            for variant in (0, 1, 2, 3, 4, 5):
                 lib.bgs_gs_head_variant(variant)
                 z = dev(batch['logits']).requires_grad_(True)
                 p = dev(bp).requires_grad_(True)

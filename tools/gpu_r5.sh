@@ -84,7 +84,7 @@ gstests)
   grep -E "passed|failed|error" $OUT/pytest_gs.log | tail -3; grep -E "^FAILED|^ERROR|Error|assert " $OUT/pytest_gs.log | head -20
   ;;
 gsab)
-  timeout 600 python tools/gs_head_ab.py 3 > $OUT/gs_head_ab.txt 2> $OUT/gs_head_ab.err; echo "gsab rc=$?"; cat $OUT/gs_head_ab.txt; tail -3 $OUT/gs_head_ab.err
+  timeout 600 python tools/gs_head_ab.py 3 ${GSAB_VARIANTS:-0,1,2,3,4,5} > $OUT/gs_head_ab.txt 2> $OUT/gs_head_ab.err; echo "gsab rc=$?"; cat $OUT/gs_head_ab.txt; tail -3 $OUT/gs_head_ab.err
   ;;
 gspmc)
   # HBM traffic of the head kernel: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes (kernel-trace only)
