@@ -528,7 +528,9 @@ def kernel_roofline(inp, n, iters=300, kernel='fused'):
         cbits = BF.gs_class_bin_mask(inp['l2b'])
         variant = lib.bgs_gs_head_variant_used(n)
         kname = {0: 'gs_head_fused_kernel<4,true,true,0>', 1: 'gs_head_fused_kernel<4,true,true,1>',
-                 2: 'gs_head_multi_kernel<4,true,true,2>', 3: 'gs_head_multi_kernel<4,true,true,4>'}[variant]
+                 2: 'gs_head_multi_kernel<4,true,true,2>', 3: 'gs_head_multi_kernel<4,true,true,4>',
+                 4: 'gs_head_multi_kernel<4,true,true,2,direct>',
+                 5: 'gs_head_multi_kernel<4,true,true,4,direct>'}.get(variant, 'gs_head kernel variant %d' % variant)
 
         def launch():
             rc = lib.bgs_gs_head_step(capi.ptr(inp['logits']), capi.ptr(inp['labels']), capi.ptr(inp['l2b']),
