@@ -1167,11 +1167,13 @@ int head_rows_per_wg() {
   return g_head_rows;
 }
 
-// variant of the fused head kernel: explicit (bgs_gs_head_variant / BGS_GS_HEAD_VARIANT = 0..3) or automatic — rows
+// variant of the fused head kernel: explicit (bgs_gs_head_variant / BGS_GS_HEAD_VARIANT = 0..5) or automatic — rows
 // in parallel behind one prologue wherever the per-row partials fit the workspace (N <= kMaxGrid): four per
 // workgroup once that still gives every CU a workgroup (N >= 1024), else two; beyond, one row per workgroup with bit
 // planes (profiles/r6w_gs_head_ab.txt: 10.3 / 9.7 / 7.7 / 7.7 us at N = 1024, 8.9 / 8.6 / 7.2 / 8.4 at 512,
-// 21.3 / 20.8 / 14.9 / 14.0 at 2048 for variants 0 / 1 / 2 / 3)
+// 21.3 / 20.8 / 14.9 / 14.0 at 2048 for variants 0 / 1 / 2 / 3).  Direct gradient stores (variants 4 / 5) win while
+// the launch is latency-bound and lose once the store instructions count (profiles/r6z_gs_head_ab.txt: 7.43 vs 7.68 us
+// at N = 1024, 7.07 vs 7.19 at 512, 15.3 vs 13.9 at 2048): taken up to N = 1024.
 int g_head_variant = -2;                    // -2: not read yet, -1: automatic
 int head_variant_for(int N) {
   if (g_head_variant == -2) {
@@ -1180,7 +1182,7 @@ int head_variant_for(int N) {
     if (g_head_variant < -1 || g_head_variant > 5) g_head_variant = -1;
   }
   int v = g_head_variant;
-  if (v < 0) v = N >= 1024 ? 3 : 2;
+  if (v < 0) v = N < 1024 ? 4 : (N == 1024 ? 5 : 3);
   if (v >= 2 && N > kMaxGrid) v = 1;
   return v;
 }
