@@ -161,8 +161,8 @@ void bgs_gs_head_tuning(int rows_per_workgroup);
  * 64-bit ballot word per (64 rows, bin) — counts and the row's candidate position from one popcount pass per bin;
  * 2 / 3 = variant 1 with 2 / 4 rows per workgroup in parallel behind ONE shared prologue (N <= 2048; beyond that
  * variant 1 runs); 4 / 5 = variants 2 / 3 with every bin's gradient stored to the gradient row by the wave that owns
- * the bin (no third barrier, no LDS round trip on the way out).  Bitwise the same results.  variant < 0 (the default): automatic — 3 for 1024 <= N <= 2048, 2 for
- * N < 1024, 1 beyond.  bgs_gs_head_variant_used(N): the variant a launch with N rows takes. */
+ * the bin (no third barrier, no LDS round trip on the way out).  Bitwise the same results.  variant < 0 (the default): automatic — 4 for N < 1024, 5 for N = 1024,
+ * 3 for 1024 < N <= 2048, 1 beyond.  bgs_gs_head_variant_used(N): the variant a launch with N rows takes. */
 void bgs_gs_head_variant(int variant);
 int bgs_gs_head_variant_used(int N);
 /* Backward of bgs_gs_head_step: grad_terms [B+1] (device; upstream gradient of {bins, box}, NULL = 0)
