@@ -67,3 +67,25 @@ def test_ops_refuse_cpu_tensors():
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         BF.group_softmax_loss(torch.zeros(2, 8), torch.zeros((2, 2), dtype=torch.int32),
                               torch.tensor([[0, 2], [2, 6]]))
+
+
+def test_head_kernel_variant_rule_is_a_host_decision():
+    """``bgs_gs_head_variant_used(N)``: which fused GroupSoftmax head kernel a launch with N rows takes — rows in
+    parallel behind one prologue while the per-row partials fit the workspace (N <= 2048), with direct gradient
+    stores while the launch is latency-bound (N <= 1024), one row per workgroup with bit planes beyond; an explicit
+    variant is honoured where it can run and the multi-row ones fall back beyond 2048 rows; < 0 restores the
+    rule.  Pure host logic: no GPU needed."""
+    lib = capi.load()
+    try:
+        lib.bgs_gs_head_variant(-1)
+        if os.environ.get('BGS_GS_HEAD_VARIANT') is None:
+            assert [lib.bgs_gs_head_variant_used(n) for n in (1, 512, 1023, 1024, 1025, 2048, 2049, 4096)] == \
+                [4, 4, 4, 5, 3, 3, 1, 1]
+        for v in range(6):
+            lib.bgs_gs_head_variant(v)
+            assert lib.bgs_gs_head_variant_used(1024) == v
+            assert lib.bgs_gs_head_variant_used(4096) == (v if v < 2 else 1)
+        lib.bgs_gs_head_variant(17)                   # unknown: the plain kernel
+        assert lib.bgs_gs_head_variant_used(1024) == 0
+    finally:
+        lib.bgs_gs_head_variant(-1)
