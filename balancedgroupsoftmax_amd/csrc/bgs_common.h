@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "bgs.h"
+#include "bgs_tuning.h"
 
 #define BGS_WAVE 64
 

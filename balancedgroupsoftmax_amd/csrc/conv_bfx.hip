@@ -47,6 +47,11 @@ __device__ __attribute__((aligned(16))) unsigned g_zero_page[16];
 // conv1x1_bres.hip
 int bgs_internal_conv1x1_bres(const bgs_conv::ConvArgs& p, const void* wsplit, int KC, int planes,
                               const unsigned* zero, hipStream_t st);
+// conv_bfx_wide.hip: 128 x 128 tile, four M-stacked waves (-1: not eligible)
+int bgs_internal_conv1x1_bfx_wide(const bgs_conv::ConvArgs& p, const void* wsplit, int KC, void* workspace,
+                                  size_t workspace_bytes, int forced_only, hipStream_t st);
+void bgs_internal_conv1x1_bfx_wide_clear_last();
+size_t bgs_internal_conv1x1_bfx_wide_workspace(long long M, int Cout, int K);
 
 namespace {
 
@@ -1586,17 +1591,34 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   q.zero = zero_page_device();
   if (!q.zero) return BGS_ERR_LAUNCH;
   const BfxKnobs& knobs = bfx_knobs();
-  if (up == 1 && knobs.tile == 0 && knobs.splitk < 0 && knobs.dma) {
-    // short-reduction 1x1 layers with Cout % 256 == 0: filter resident in registers, activations
-    // read once (conv1x1_bres.hip); -1 = not eligible
-    p.partial = nullptr;
-    p.kt_per_split = 0;
-    const int rc = bgs_internal_conv1x1_bres(p, q.ws, q.KC, q.ns, q.zero, st);
-    if (rc >= 0) {
-      g_last_tile = 0x1000;      // bit 12: the filter-resident 1x1 kernel ran
-      g_last_splits = 1;
-      g_last_dma = 0;
-      return rc;
+  bgs_internal_conv1x1_bfx_wide_clear_last();
+  const bool wide_ok = up == 1 && q.ns == 3 && knobs.tile == 0 && knobs.splitk < 0 && knobs.dma;
+  for (int pass = 0; pass < 2; ++pass) {
+    // wide-N 1x1 layers: 128 x 128 tile with four M-stacked waves (conv_bfx_wide.hip); -1 = not eligible.
+    // Pass 0 (ahead of the filter-resident kernel) only under its "every eligible layer" mode.
+    if (wide_ok) {
+      const int rc = bgs_internal_conv1x1_bfx_wide(p, q.ws, q.KC, workspace, workspace_bytes, pass == 0, st);
+      if (rc >= 0) {
+        g_last_tile = 0x4000;      // bit 14: the wide 1x1 kernel ran
+        g_last_splits = 1;
+        g_last_dma = 0;
+        return rc;
+      }
+      p.partial = nullptr;
+      p.kt_per_split = 0;
+    }
+    if (pass == 0 && up == 1 && knobs.tile == 0 && knobs.splitk < 0 && knobs.dma) {
+      // short-reduction 1x1 layers with Cout % 256 == 0: filter resident in registers, activations
+      // read once (conv1x1_bres.hip); -1 = not eligible
+      p.partial = nullptr;
+      p.kt_per_split = 0;
+      const int rc = bgs_internal_conv1x1_bres(p, q.ws, q.KC, q.ns, q.zero, st);
+      if (rc >= 0) {
+        g_last_tile = 0x1000;      // bit 12: the filter-resident 1x1 kernel ran
+        g_last_splits = 1;
+        g_last_dma = 0;
+        return rc;
+      }
     }
   }
   const long long M = p.M;
@@ -1608,11 +1630,13 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   if (ring8) {
     tile = 22;
     const long long wgs = ((M + 127) / 128) * ((p.Cout + 127) / 128);
-    want = 1;
+    const int want_ring64 = want;     // the workspace query sizes the scratch by the 64 x 64 plan (and, for three
+    want = 1;                         // planes, the wide kernel's): slice K only where that plan does
     if (wgs < 400) want = (int)((1100 + wgs - 1) / wgs);
     else if (wgs < 600 && q.KC >= 128) want = 2;
     if (want > q.KC / 8) want = q.KC / 8;
     if (want > 8) want = 8;
+    if (want_ring64 <= 1) want = 1;
     if (knobs.splitk >= 1 && knobs.splitk <= 16) want = knobs.splitk < q.KC ? knobs.splitk : q.KC;
     if (want < 1) want = 1;
   }
@@ -1786,7 +1810,9 @@ extern "C" size_t bgs_conv_bfx_workspace_bytes(long long M, int Cout, int K) {
   if (M <= 0 || Cout <= 0 || K <= 0) return 0;
   int tile, bk, want;
   bfx_plan(M, Cout, bfx_kc(K), tile, bk, want);
-  return want > 1 ? (size_t)want * (size_t)M * Cout * sizeof(float) : 0;
+  const size_t ring = want > 1 ? (size_t)want * (size_t)M * Cout * sizeof(float) : 0;
+  const size_t wide = bgs_internal_conv1x1_bfx_wide_workspace(M, Cout, K);   // (1x1 layers only; harmless otherwise)
+  return ring > wide ? ring : wide;
 }
 
 // tuning / test hook: tile 0 = auto | 11 | 12 | 21 | 22; splitk -1 = auto | 1..16.

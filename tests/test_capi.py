@@ -9,10 +9,15 @@ from balancedgroupsoftmax_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    text = open(os.path.join(ROOT, 'include', 'bgs.h')).read()
-    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(bgs_[a-z0-9_]+)\s*\(', text)))
+def header_functions(names=('bgs.h', 'bgs_tuning.h')):
+    """Every function include/*.h declares: the drop-in boundary (bgs.h) and the tuning / census hooks
+    (bgs_tuning.h)."""
+    out = set()
+    for name in names:
+        text = open(os.path.join(ROOT, 'include', name)).read()
+        text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+        out |= set(re.findall(r'\b(bgs_[a-z0-9_]+)\s*\(', text))
+    return sorted(out)
 
 
 def test_header_and_binding_agree():
