@@ -79,7 +79,9 @@ def build(variant='', force=False, verbose=True):
     for p, src in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed on %s' % src)
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs
+    # --no-undefined: a kernel template whose host stub failed to instantiate (seen with an inline-asm operand the
+    # HOST pass rejects silently) must fail the build, not the first dlopen on the GPU box
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--no-undefined', '-o', out] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -70,12 +70,17 @@ struct WideArgs {
   ConvArgs c;            // x, bias, res, mask, y, H, W, Cin, Ho, Wo, Cout, stride, M, K, relu, res_mode, partial, ..
   const __bf16* ws;      // split weights [3][KC][Cout][16]
   int KC;
+  int flags;             // bit 0: static wave priority by residency slot; bit 1: staggered start; bit 2: the step's
+                         // DMA pieces are issued between the two MFMA halves instead of behind the barrier
 };
 
 constexpr int W_A_WAVE = 32 * 64;            // a wave's private raw-A block: 32 rows x 16 fp32
 constexpr int W_A_BYTES = 4 * W_A_WAVE;      // 8 KB
 
-template <int NBW, int NST>
+// ABL (only instantiated != 0 under -DBGS_ABLATE, tools/wide_ablate.py): timing-only variants that drop one
+// component — 1: MFMAs, 2: DMA issue after the prologue, 4: the epilogue's global loads / stores, 8: the whole
+// epilogue, 16: the A split.
+template <int NBW, int NST, int ABL = 0>
 __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_kernel(WideArgs q) {
   const ConvArgs& p = q.c;
   constexpr int BN = 32 * NBW;
@@ -96,6 +101,24 @@ __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_k
   const int kt_begin = p.partial ? (int)blockIdx.z * p.kt_per_split : 0;
   const int kt_end = p.partial ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
   const int nk = kt_end - kt_begin;                            // >= 2 (launcher)
+  // Co-resident workgroups start together and every step takes every workgroup the same time, so the DMA-issue,
+  // fragment-read and MFMA phases of the workgroups of a CU coincide and their costs ADD (component ablation,
+  // profiles/r8b_wide_tile_ablation.txt: fpn.lat0 134 us = skeleton 21 + MFMA 57 + DMA 20 + epilogue 39).  Block b
+  // runs on XCD b % 8 and, within the XCD, the dispatcher fills the CUs round-robin: (b >> 8) is the residency
+  // slot of a first-round workgroup.  A static priority per slot lets one workgroup's MFMA phase finish first, so
+  // that its memory phase lies beside the other's MFMA phase from then on; a staggered start sets the same offset.
+  {
+    const int rslot = (int)((blockIdx.x >> 8) % 3);
+    if (q.flags & 1) {
+      if (rslot == 1) __builtin_amdgcn_s_setprio(1);
+      else if (rslot == 2) __builtin_amdgcn_s_setprio(2);
+    }
+    if ((q.flags & 2) && rslot) {
+      if (rslot == 1) __builtin_amdgcn_s_sleep(6);
+      else __builtin_amdgcn_s_sleep(12);
+    }
+  }
+  const bool late_issue = (q.flags & 4) != 0;
 
   // ---- A DMA role: piece j covers rows 16 j + (lane >> 2) of the wave's block; lane -> physical quad,
   //      logical quad = physical ^ ((row >> 2) & 3) (the XOR swizzle of conv_bfx.hip's ring, on the source side)
@@ -159,6 +182,12 @@ __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_k
     r1 = *reinterpret_cast<const f32x4*>(st + a_off1);
   };
   auto split_frag = [&](const f32x4 r0, const f32x4 r1, bf16x8 (&fa)[3]) {
+    if (ABL & 16) {
+      fa[0] = __builtin_bit_cast(bf16x8, r0);
+      fa[1] = __builtin_bit_cast(bf16x8, r1);
+      fa[2] = __builtin_bit_cast(bf16x8, r0 + r1);
+      return;
+    }
     u32x2 h0, m0_, l0, h1, m1, l1;
     split3(r0, h0, m0_, l0);
     split3(r1, h1, m1, l1);
@@ -178,6 +207,15 @@ __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_k
   auto mma = [&](const bf16x8 (&fa)[3], const bf16x8 (&fb)[3][2], int half) {
     // products (i, j), i + j <= 2, smallest terms first (conv_bfx.hip's order); consecutive MFMAs alternate
     // between the two accumulators of the half
+    if (ABL & 1) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+        for (int b = 0; b < 2; ++b) asm volatile("" ::"v"(fb[i][b]));
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 2; t >= 0; --t)
 #pragma unroll
@@ -218,12 +256,6 @@ __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_k
       asm volatile("" ::: "memory");
       s_cur = slot;
       s_nxt = slot + 1 == 3 ? 0 : slot + 1;
-      const int s_iss = s_nxt + 1 == 3 ? 0 : s_nxt + 1;        // slot of stage k + 2 = slot of stage k - 1
-      if (kt_a < nk) {
-        issue_a(s_iss);
-        issue_b(s_iss);
-        ++kt_a;
-      }
       slot = s_nxt;
     } else {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // B(k), A(k + 1): issued one step ago; reads returned
@@ -231,21 +263,35 @@ __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_k
       asm volatile("" ::: "memory");
       s_cur = k & 1;
       s_nxt = s_cur ^ 1;
-      if (kt_b < nk) {                                         // B(k + 1) -> the slot B(k - 1) left
-        issue_b(s_nxt);
-        ++kt_b;
-      }
-      if (kt_a < nk) {                                         // A(k + 2) -> the block raw A(k) left one step ago
-        issue_a(s_cur);
-        ++kt_a;
-      }
     }
+    auto issue_next = [&]() {
+      if (ABL & 2) return;
+      if (NST == 3) {
+        const int s_iss = s_nxt + 1 == 3 ? 0 : s_nxt + 1;      // slot of stage k + 2 = slot of stage k - 1
+        if (kt_a < nk) {
+          issue_a(s_iss);
+          issue_b(s_iss);
+          ++kt_a;
+        }
+      } else {
+        if (kt_b < nk) {                                       // B(k + 1) -> the slot B(k - 1) left
+          issue_b(s_nxt);
+          ++kt_b;
+        }
+        if (kt_a < nk) {                                       // A(k + 2) -> the block raw A(k) left one step ago
+          issue_a(s_cur);
+          ++kt_a;
+        }
+      }
+    };
+    if (!late_issue) issue_next();
     bf16x8 fb0[3][2], fb1[3][2];
     f32x4 r0, r1;
     read_b(s_cur, 0, fb0);
     read_raw(s_nxt, r0, r1);
     read_b(s_cur, 1, fb1);
     mma(fa, fb0, 0);
+    if (late_issue) issue_next();
     split_frag(r0, r1, fa_next);
     mma(fa, fb1, 1);
   };
@@ -272,6 +318,13 @@ __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_k
     last_step(k, fa0);
   }
 
+  if (ABL & 8) {
+#pragma unroll
+    for (int b = 0; b < NBW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[b][r]));
+    return;
+  }
   // ---- epilogue through an LDS transpose, two halves of 64 rows (waves 0,1 then 2,3); every thread then
   //      handles four consecutive channels of a row: one 16-byte residual load, one 16-byte store
   float* scratch = reinterpret_cast<float*>(lds);
@@ -303,6 +356,10 @@ __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_k
       const int m = m0 + h * 64 + i;
       if (m >= p.M) break;
       f32x4 v = *reinterpret_cast<const f32x4*>(scratch + i * LD + c4);
+      if (ABL & 4) {
+        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+        continue;
+      }
       if (!p.partial) {
         v += bias;
         if (p.res_mode == 1) {
@@ -333,6 +390,8 @@ int g_wide_mode = -1;        // -1: read BGS_BFX_WIDE once; 0 off; 1 auto; 2 eve
 int g_wide_nst = 0;          // 0 auto | 2 | 3
 int g_wide_splitk = -1;      // -1 auto | 1..16
 int g_wide_last = 0;         // bit 0: the wide kernel ran; bits 4..7: NST; bits 8..: K slices
+int g_wide_ablate = 0;       // -DBGS_ABLATE builds only
+int g_wide_flags = 0;        // WideArgs::flags (A/B: bits 16.. of the tuning hook's mode)
 
 }  // namespace
 
@@ -363,6 +422,7 @@ int bgs_internal_conv1x1_bfx_wide(const bgs_conv::ConvArgs& pc, const void* wspl
   ConvArgs& p = q.c;
   q.ws = reinterpret_cast<const __bf16*>(wsplit);
   q.KC = KC;
+  q.flags = g_wide_flags;
   p.tiles_m = (p.M + 127) / 128;
   p.tiles_n = (p.Cout + 127) / 128;
   const long long tiles = (long long)p.tiles_m * p.tiles_n;
@@ -370,13 +430,14 @@ int bgs_internal_conv1x1_bfx_wide(const bgs_conv::ConvArgs& pc, const void* wspl
   // K slices: one launch wants >= ~2 workgroups per CU; a slice keeps >= 8 K steps
   int want = 1;
   if (g_wide_mode == 1) {
-    // auto: the layers where the wide tile was measured ahead of the 64 x 64 ring (tools/wide_ab.py,
-    // profiles/r8a_wide_tile_ab.txt): the large grids with a reduction of >= 256 (fpn.lat0 147 -> 124 us,
-    // l2.b0.c1 77 -> 66, l2.ds 76 -> 64, l3.b0.c1 / l3.ds / fpn.lat1 74 -> 67), and the deep reductions on the
-    // stride-16 / 32 maps with K sliced (l3.c1 / fpn.lat2 51 -> 45, l4.ds 89 -> 78); the short reductions
-    // (K <= 128), the 528-tile K = 256 layers and the tiny grids stay on the ring
+    // auto: the layers where the wide tile was measured ahead of the 64 x 64 ring, per layer
+    // (tools/wide_ab.py, profiles/r8a_wide_tile_ab.txt: fpn.lat0 147 -> 124 us, l2.b0.c1 77 -> 66, l2.ds 76 -> 64,
+    // l3.b0.c1 / l3.ds / fpn.lat1 74 -> 67) AND inside the step (rocprofv3 of the graph-replayed cfg[1] step,
+    // profiles/r8d_wide_in_step.md): the large grids with a reduction of >= 256.  The deep reductions on the
+    // stride-16 / 32 maps need K sliced to fill the chip and lose the gain to the slab reduction launch
+    // (+11 us each in the step); K <= 128, the 528-tile K = 256 layers and the tiny grids stay on the ring.
     const bool big = tiles >= 500 && (long long)p.K * tiles >= 256000 && p.K >= 256;
-    const bool deep = tiles >= 100 && tiles < 300 && p.K >= 1024;
+    const bool deep = false;
     if (!big && !deep) return -1;
   }
   if (tiles < 384) want = (int)((640 + tiles - 1) / tiles);
@@ -408,6 +469,14 @@ int bgs_internal_conv1x1_bfx_wide(const bgs_conv::ConvArgs& pc, const void* wspl
   if (g_wide_nst == 2 || g_wide_nst == 3) nst = g_wide_nst;
   g_wide_last = 1 | (nst << 4) | (splits << 8);
   bgs_internal_census_bump(BGS_CENSUS_BFX_WIDE);
+#ifdef BGS_ABLATE
+  if (g_wide_ablate) {
+#define ABL_W(A_) case A_: if (nst == 3) hipLaunchKernelGGL((conv1x1_bfx_wide_kernel<4, 3, A_>), grid, dim3(kThreads), 0, st, q); \
+                           else hipLaunchKernelGGL((conv1x1_bfx_wide_kernel<4, 2, A_>), grid, dim3(kThreads), 0, st, q); break;
+    switch (g_wide_ablate) { ABL_W(1) ABL_W(2) ABL_W(3) ABL_W(4) ABL_W(8) ABL_W(9) ABL_W(10) ABL_W(11) ABL_W(16) ABL_W(5) default: return BGS_ERR_UNSUPPORTED; }
+#undef ABL_W
+  } else
+#endif
   if (nst == 3) hipLaunchKernelGGL((conv1x1_bfx_wide_kernel<4, 3>), grid, dim3(kThreads), 0, st, q);
   else hipLaunchKernelGGL((conv1x1_bfx_wide_kernel<4, 2>), grid, dim3(kThreads), 0, st, q);
   if (splits > 1) {
@@ -433,6 +502,9 @@ size_t bgs_internal_conv1x1_bfx_wide_workspace(long long M, int Cout, int K) {
 
 // tuning / test hook: mode 0 off | 1 auto | 2 every eligible layer; nst 0 auto | 2 | 3; splitk -1 auto | 1..16
 extern "C" void bgs_conv_bfx_wide_tuning(int mode, int nst, int splitk) {
+  g_wide_ablate = (mode >> 8) & 0xff;          // timing-only ablation modes (-DBGS_ABLATE builds)
+  g_wide_flags = (mode >> 16) & 0xff;          // WideArgs::flags
+  mode &= 0xff;
   g_wide_mode = mode;
   g_wide_nst = nst;
   g_wide_splitk = splitk;

@@ -875,6 +875,114 @@ def test_conv1x1_filter_resident_kernel_as_data_gradient_with_mask():
         BF.set_conv_math(prev)
 
 
+def _wide_last():
+    from balancedgroupsoftmax_amd import capi
+    v = capi.load().bgs_conv_bfx_wide_last_launch()
+    return dict(ran=v & 1, nst=(v >> 4) & 15, splits=v >> 8)
+
+
+@pytest.mark.parametrize('nst', [2, 3])
+@pytest.mark.parametrize('shape', [
+    # (N, H, W, Cin, Cout, stride, relu, residual mode)
+    (2, 50, 84, 256, 1024, 1, True, 1),       # layer3 conv3: residual + ReLU, 528 tiles
+    (1, 37, 29, 64, 256, 1, False, 0),        # M = 1073: the last row tile is clamped (49 live rows), K = 64
+    (2, 100, 168, 256, 512, 2, False, 0),     # layer2 projection shortcut: stride 2
+    (2, 50, 84, 512, 256, 1, False, 2),       # FPN lateral: nearest-2x-upsampled top-down add
+    (256, 1, 1, 1024, 1236, 1, False, 0),     # fc_cls: Cout % 128 = 84: clamped filter rows
+    (3, 17, 23, 128, 132, 1, True, 1),        # both edges ragged
+], ids=lambda c: 'x'.join(str(int(v)) for v in c))
+def test_bfx_wide_tile_kernel_is_bit_identical_to_the_operand_ring(shape, nst):
+    """``conv1x1_bfx_wide_kernel`` (csrc/conv_bfx_wide.hip: 128 x 128 tile, four M-stacked waves, wave-private A,
+    rows / columns past the edge clamped instead of zero-filled) in both ring depths against the 64 x 64 operand
+    ring on the 1x1 layers of mmdet/models/backbones/resnet.py:220-266, necks/fpn.py:101-141 and the FC heads:
+    BIT-IDENTICAL outputs when K is not sliced (same products, same order), both within fp32 rounding of fp64
+    torch; sliced K within the same bound; the dispatch asserted through the last-launch query."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    N, H, W, Cin, Cout, stride, relu, rm = shape
+    g = torch.Generator().manual_seed(Cin * 3 + Cout + stride)
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, 1, 1, Cin, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = None
+    if rm == 1:
+        res = torch.randn(N, Ho, Wo, Cout, generator=g)
+    elif rm == 2:
+        res = torch.randn(N, Ho // 2, Wo // 2, Cout, generator=g)
+    kw = dict(stride=stride, relu=relu, residual=None if res is None else dev(res), residual_mode=rm)
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        lib.bgs_conv_bfx_wide_tuning(0, 0, -1)
+        BF.conv_bfx_tuning(0, 1)                       # the ring unsliced (its plan slices K for the small grids)
+        ring = BF.conv2d_nhwc(dev(x), dev(w), dev(b), **kw).cpu()
+        BF.conv_bfx_tuning(0, -1)
+        assert not _wide_last()['ran']
+        lib.bgs_conv_bfx_wide_tuning(2, nst, 1)
+        wide = BF.conv2d_nhwc(dev(x), dev(w), dev(b), **kw).cpu()
+        assert _wide_last() == dict(ran=1, nst=nst, splits=1)
+        assert torch.equal(wide, ring)
+        lib.bgs_conv_bfx_wide_tuning(2, nst, 2)        # K sliced two ways through the slab epilogue
+        sliced = BF.conv2d_nhwc(dev(x), dev(w), dev(b), **kw).cpu()
+        assert _wide_last()['ran'] and _wide_last()['splits'] == 2
+    finally:
+        lib.bgs_conv_bfx_wide_tuning(1, 0, -1)
+        BF.conv_bfx_tuning()
+        BF.set_conv_math(prev)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), stride=stride)
+    if rm == 1:
+        ref = ref + res.permute(0, 3, 1, 2).double()
+    elif rm == 2:
+        ref = ref + F.interpolate(res.permute(0, 3, 1, 2).double(), scale_factor=2, mode='nearest')
+    if relu:
+        ref = torch.relu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    for got in (wide, sliced):
+        err = float((got.double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, err
+
+
+def test_bfx_wide_tile_kernel_as_data_gradient_with_mask_and_in_the_automatic_mode():
+    """(i) the wide kernel under ``bgs_conv2d_dgrad_nhwc_f32_bfx_ws`` (the data gradient of a 1x1 conv is a 1x1 conv
+    with the transposed filter) with the ReLU-backward mask and a residual gradient in the epilogue == the ring,
+    bit for bit; (ii) the automatic mode takes the large-grid K >= 256 layers (fpn.lat0-sized here) and leaves the
+    528-tile K = 256 layer and the K = 64 layers to the ring."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    g = torch.Generator().manual_seed(11)
+    N, H, W, Cin, Cout = 2, 50, 84, 1024, 256          # dgrad: K = Cout = 256 -> Cin = 1024 channels
+    dy = torch.randn(N, H, W, Cout, generator=g)
+    w = torch.randn(Cout, 1, 1, Cin, generator=g) * 0.05
+    res = torch.randn(N, H, W, Cin, generator=g)
+    mask = torch.randn(N, H, W, Cin, generator=g)
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        outs = []
+        for mode in (2, 0):
+            lib.bgs_conv_bfx_wide_tuning(mode, 0, 1)
+            lib.bgs_conv1x1_bres_enable(0)
+            BF.conv_bfx_tuning(0, -1 if mode else 1)
+            dx = BF.conv2d_dgrad_nhwc(dev(dy), dev(w), (H, W), residual=dev(res), mask=dev(mask))
+            BF.conv_bfx_tuning(0, -1)
+            assert _wide_last()['ran'] == (1 if mode else 0)
+            outs.append(dx.cpu())
+        assert torch.equal(outs[0], outs[1])
+        lib.bgs_conv_bfx_wide_tuning(1, 0, -1)
+        lib.bgs_conv1x1_bres_enable(0)
+        took = {}
+        for name, (n, h, wd, ci, co) in dict(lat0=(2, 200, 336, 256, 256), l3c3=(2, 50, 84, 256, 1024),
+                                             l1c3=(2, 100, 168, 64, 256), lat1=(2, 100, 168, 512, 256)).items():
+            BF.conv2d_nhwc(torch.randn(n, h, wd, ci, device=DEV), torch.randn(co, 1, 1, ci, device=DEV),
+                           torch.zeros(co, device=DEV))
+            took[name] = _wide_last()['ran']
+        assert took == dict(lat0=1, l3c3=0, l1c3=0, lat1=1), took
+    finally:
+        lib.bgs_conv_bfx_wide_tuning(1, 0, -1)
+        lib.bgs_conv1x1_bres_enable(1)
+        BF.conv_bfx_tuning()
+        BF.set_conv_math(prev)
+
+
 @pytest.mark.parametrize('case', [
     # name, N, H, W, Cin, Cout, k, stride, pad
     ('3x3s1', 2, 40, 56, 128, 128, 3, 1, 1),

@@ -30,8 +30,8 @@ def bench(fn, iters=20, warm=8):
     return e0.elapsed_time(e1) / iters * 1e3          # us
 
 
-def wide(mode, nst=0, splitk=-1):
-    capi.load().bgs_conv_bfx_wide_tuning(int(mode), int(nst), int(splitk))
+def wide(mode, nst=0, splitk=-1, flags=0):
+    capi.load().bgs_conv_bfx_wide_tuning(int(mode) | (int(flags) << 16), int(nst), int(splitk))
 
 
 def last():
@@ -151,12 +151,41 @@ def stress(dev, reps=60):
     return bad == 0
 
 
+def flags_sweep(dev):
+    """WideArgs::flags (bit 0 priority per residency slot, bit 1 staggered start, bit 2 DMA issue between the MFMA
+    halves) x ring depth on a few layers; every arm must equal the ring bit for bit."""
+    shapes = [('fpn.lat0', 2, 200, 336, 256, 256, 1), ('l2.ds', 2, 200, 336, 256, 512, 2), ('fpn.lat1', 2, 100, 168, 512, 256, 1),
+              ('l3.c3', 2, 50, 84, 256, 1024, 1), ('l3.ds', 2, 100, 168, 512, 1024, 2), ('l2.b0.c1', 2, 200, 336, 256, 128, 1)]
+    fl = [0, 1, 2, 4, 5, 6, 3, 7]
+    print('%-10s | ring | %s' % ('layer', '  '.join('n%d/f%d' % (n, f) for n in (2, 3) for f in fl)))
+    for name, N, H, W, Cin, Cout, stride in shapes:
+        x = torch.randn(N, H, W, Cin, device=dev)
+        w = torch.randn(Cout, 1, 1, Cin, device=dev) * 0.05
+        b = torch.randn(Cout, device=dev)
+        fn = lambda: BF.conv2d_nhwc(x, w, b, stride=stride, pad=0, relu=True)  # noqa: E731
+        wide(0)
+        y0 = fn().clone()
+        t0 = bench(fn)
+        row = []
+        for nst in (2, 3):
+            for f in fl:
+                wide(2, nst, 1, f)
+                y = fn()
+                assert last()['ran']
+                eq = torch.equal(y, y0)
+                row.append('%6.1f%s' % (bench(fn), '' if eq else '!'))
+        print('%-10s | %5.1f | %s' % (name, t0, '  '.join(row)), flush=True)
+    wide(1)
+
+
 def main():
     dev = 'cuda:0'
     quick = '--quick' in sys.argv
     os.environ['BGS_CONV_HALO'] = '0'
     if '--stress' in sys.argv:
         sys.exit(0 if stress(dev) else 1)
+    if '--flags' in sys.argv:
+        return flags_sweep(dev)
     if not correctness(dev):
         sys.exit(1)
     layers = [(n, H, W, Cin, Cout, R, s, c) for (n, H, W, Cin, Cout, R, s, c) in LAYERS if R == 1]
