@@ -484,7 +484,7 @@ class GSBBoxHeadWith0(SharedFCBBoxHead):
                 num_reg_classes=self.num_reg_classes,
                 beta=self.loss_bbox.beta if bbox_pred is not None else 1.0,
                 box_loss_weight=(self.loss_bbox.loss_weight if bbox_pred is not None else 1.0) * loss_scale)
-            parts = terms.unbind(0)          # ONE autograd node (its backward: one stack) for all terms
+            parts = BF.unbind_terms(terms)   # ONE autograd node for all terms; unit gradients pass by identity
             for i in range(self.num_bins):
                 losses['loss_cls_bin{}'.format(i)] = parts[i]
             if bbox_pred is not None:

@@ -220,27 +220,63 @@ def gs_class_bin_mask(label2binlabel):
 
 
 _UNIT_GRAD = {}
+_UNIT_LEN = 64
 
 
-def unit_gradient(device):
-    """The library's constant ``ones(1)`` float32 tensor of a device: a root gradient for
-    ``total.backward(unit_gradient(dev))`` that is not refilled every step (``backward()`` without an
-    argument launches a fill) and that :func:`gs_head_step`'s backward RECOGNISES (same storage): the
-    gradient the forward produced is already the answer, so the scaling launch is skipped instead of
-    launched to find out on the device that every factor is 1.  Read-only by contract."""
+def unit_gradient(device, n=1):
+    """The library's constant all-ones float32 tensor of a device (``[n]``, ``n <= 64``: a prefix view of ONE
+    cached buffer): a root gradient for ``total.backward(unit_gradient(dev))`` that is not refilled every step
+    (``backward()`` without an argument launches a fill) and that the loss edges of this package RECOGNISE —
+    :func:`gs_head_step`'s backward, the head's term split and ``train.parse_losses`` hand it on by identity, so
+    that "every upstream factor is 1" is known on the host and the gradient the forward produced is the answer
+    without a launch.  Recognition = same storage AND an untouched version counter: a tensor somebody wrote to
+    in place (the buffer is an ordinary CUDA tensor) is NOT taken for ones — the general path runs."""
     device = torch.device(device)
     if device.type == 'cuda' and device.index is None:
         device = torch.device('cuda', torch.cuda.current_device())
-    t = _UNIT_GRAD.get(device)
-    if t is None:
-        t = _UNIT_GRAD[device] = torch.ones(1, dtype=torch.float32, device=device)
-    return t
+    ent = _UNIT_GRAD.get(device)
+    if ent is None or ent[0]._version != ent[1]:
+        t = torch.ones(_UNIT_LEN, dtype=torch.float32, device=device)
+        ent = _UNIT_GRAD[device] = (t, t._version)
+    assert 1 <= n <= _UNIT_LEN
+    return ent[0][:n]
 
 
 def _is_unit_gradient(g):
-    t = _UNIT_GRAD.get(g.device)
-    return (t is not None and g.dtype == torch.float32 and g.numel() == 1
-            and g.data_ptr() == t.data_ptr())
+    """``g`` is (a view of the head of) the cached all-ones buffer, and nobody has written to that buffer."""
+    ent = _UNIT_GRAD.get(g.device)
+    if ent is None or g.dtype != torch.float32:
+        return False
+    t, ver = ent
+    return (t._version == ver and g.data_ptr() == t.data_ptr() and 1 <= g.numel() <= _UNIT_LEN
+            and g.is_contiguous())
+
+
+class _UnbindTermsFn(torch.autograd.Function):
+    """``terms.unbind(0)`` for the fused head's loss vector with a backward that keeps the identity of unit
+    gradients: when every term's upstream gradient IS the library's unit gradient (``loss.backward(
+    unit_gradient(dev))`` through ``train.parse_losses``), the vector handed to the head's backward is the cached
+    ones buffer itself — no stack launch, and the head launches nothing either.  Otherwise: one stack."""
+
+    @staticmethod
+    def forward(ctx, terms):
+        ctx.n = terms.shape[0]
+        ctx.set_materialize_grads(False)
+        return tuple(terms.detach().unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        if all(g is None for g in gs):
+            return None
+        if all(g is not None and g.numel() == 1 and _is_unit_gradient(g) for g in gs) and ctx.n <= _UNIT_LEN:
+            return unit_gradient(gs[0].device, ctx.n)
+        ref = next(g for g in gs if g is not None)
+        return torch.stack([ref.new_zeros(()) if g is None else g.reshape(()) for g in gs])
+
+
+def unbind_terms(terms):
+    """The fused head's ``terms [B + 1]`` as B + 1 scalars (see :class:`_UnbindTermsFn`)."""
+    return _UnbindTermsFn.apply(terms)
 
 
 class _GsHeadStepFn(torch.autograd.Function):
@@ -306,8 +342,10 @@ class _GsHeadStepFn(torch.autograd.Function):
         if ctx.consumed:     # the buffers are scaled in place and handed to autograd (see _GroupSoftmaxLoss)
             raise RuntimeError('gs_head_step: the fused gradient buffers were consumed by the first '
                                'backward; call the loss again')
-        if g_terms is None and _is_unit_gradient(g_total):
-            pass          # total.backward(unit_gradient(dev)): every factor is 1 by identity — no launch
+        if (g_terms is None and _is_unit_gradient(g_total)) or \
+                (g_total is None and g_terms is not None and g_terms.numel() == B + 1 and _is_unit_gradient(g_terms)):
+            pass          # the root gradient is the library's unit gradient, handed down by identity (directly to
+            #               `total`, or to every term through parse_losses): every factor is 1 — no launch
         else:
             lib = capi.load()
             gt = None if g_terms is None else g_terms.detach().to(torch.float32).contiguous()

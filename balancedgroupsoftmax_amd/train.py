@@ -38,18 +38,18 @@ _SEGMENT_MATS = {}
 
 
 def _segment_matrix(lengths, device):
-    """[n_keys + 1, n_scalars] 0/1 matrix: row k sums the scalars of key k, the last row the scalars of
+    """[n_keys + 1, n_scalars] boolean matrix: row k selects the scalars of key k, the last row the scalars of
     every key containing 'loss' — cached per (structure, device)."""
     key = (lengths, str(device))
     m = _SEGMENT_MATS.get(key)
     if m is None:
         n = sum(l for l, _ in lengths)
-        m = torch.zeros(len(lengths) + 1, n)
+        m = torch.zeros(len(lengths) + 1, n, dtype=torch.bool)
         off = 0
         for k, (l, is_loss) in enumerate(lengths):
-            m[k, off:off + l] = 1.0
+            m[k, off:off + l] = True
             if is_loss:
-                m[len(lengths), off:off + l] = 1.0
+                m[len(lengths), off:off + l] = True
             off += l
         m = m.to(device)
         if len(_SEGMENT_MATS) > 64:
@@ -85,13 +85,45 @@ def parse_losses(losses):
         loss = _total([v for k, v in log_vars.items() if 'loss' in k])
         log_vars['loss'] = loss
         return loss, log_vars
-    # (an elementwise product + row sums: no BLAS call for a 9 x 20 problem)
-    sums = (_segment_matrix(tuple(lengths), flat[0].device).to(flat[0].dtype) * torch.stack(flat)).sum(1)
+    sums = _LossSumsFn.apply(tuple(lengths), *flat)
     for k, name in enumerate(names):
         log_vars[name] = sums[k]
     loss = sums[len(names)]
     log_vars['loss'] = loss
     return loss, log_vars
+
+
+class _LossSumsFn(torch.autograd.Function):
+    """Every per-key sum and the total of ``parse_losses`` from ONE stack, ONE masked select and ONE row sum
+    (three launches forward whatever the number of keys).  `where`, not a product with a 0/1 matrix: 0 * NaN is
+    NaN, and one diverged term (or a non-finite metric such as ``acc``, which the total excludes) must poison only
+    its own key and the total it belongs to — as the reference's per-key sums do.
+
+    Backward hands each scalar the gradient of the sums it belongs to WITHOUT arithmetic when only the total is
+    differentiated (the training step): every 'loss' scalar receives the total's upstream gradient tensor
+    itself.  With ``loss.backward(functional.unit_gradient(dev).reshape(()))`` — what ``DistOptimizerStep`` does —
+    that tensor is the library's unit gradient, which the fused GroupSoftmax head recognises by identity: no launch
+    between the root and the head's gradient buffers."""
+
+    @staticmethod
+    def forward(ctx, lengths, *flat):
+        ctx.lengths = lengths
+        ctx.set_materialize_grads(False)
+        stacked = torch.stack([v.detach() for v in flat])
+        seg = _segment_matrix(lengths, flat[0].device)
+        sums = torch.where(seg, stacked.unsqueeze(0), 0.0).sum(1)
+        return tuple(sums.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        g_total = gs[-1]
+        out = [None]
+        for k, (l, is_loss) in enumerate(ctx.lengths):
+            g = gs[k]
+            if is_loss and g_total is not None:
+                g = g_total if g is None else g + g_total
+            out.extend([g] * l)
+        return tuple(out)
 
 
 def select_training_param(model, selectp):
@@ -298,6 +330,19 @@ class FusedClipSGD(object):
                                    float(group.get('weight_decay', 0.0)), capi.ptr(self._ws),
                                    self._ws.numel(), capi.ptr(self.total_norm), capi.current_stream(dev))
         capi.check('bgs_sgd_clip_step', rc)
+        _bump_versions(ps)
+
+
+def _bump_versions(tensors):
+    """The fused kernels write the parameters through raw pointers, which autograd's version counters do not
+    see; every cache in this package that is keyed on ``Parameter._version`` (split bf16 planes, folded BN,
+    permuted fc1 weights, the mask / semantic / deconv head folds) must notice the update exactly as it would
+    after ``torch.optim.SGD.step()``'s in-place ops.  ``increment_version`` is bookkeeping only — no launch,
+    legal under hipGraph capture."""
+    try:
+        torch.autograd.graph.increment_version(tensors)
+    except (AttributeError, TypeError):                      # older torch: a zero-add per tensor list
+        torch._foreach_add_(tensors, 0)
 
 
 class DistOptimizerStep(object):
@@ -321,14 +366,18 @@ class DistOptimizerStep(object):
         self.fused = FusedClipSGD(optimizer, self.params, grad_clip) \
             if _fused_sgd_eligible(optimizer, self.params, grad_clip) else None
 
-    def _clip_and_step(self, grad_scale=1.0):
+    def _clip_and_step(self, loss_scale=1.0):
+        """``loss_scale``: the factor the loss was multiplied by before backward (1: none).  The torch path
+        divides the gradients by it, as the reference does (hooks.py:72-76); the fused kernel multiplies by its
+        reciprocal — the same bits for the power-of-two scales the reference's configs use, one rounding apart
+        otherwise."""
         if self.fused is not None:
-            self.fused.step(grad_scale)
+            self.fused.step(1.0 / loss_scale if loss_scale != 1.0 else 1.0)
             return
-        if grad_scale != 1.0:
+        if loss_scale != 1.0:
             grads = [p.grad for p in self.params if p.grad is not None]
             if grads:
-                torch._foreach_div_(grads, 1.0 / grad_scale)      # (exact for power-of-two loss scales)
+                torch._foreach_div_(grads, float(loss_scale))
         if self.grad_clip is not None:
             torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip['max_norm'],
                                            self.grad_clip.get('norm_type', 2))
@@ -344,8 +393,19 @@ class DistOptimizerStep(object):
 
     def __call__(self, loss):
         self.optimizer.zero_grad(set_to_none=False)
-        loss.backward()
+        backward_unit(loss)
         self.exchange_and_update()
+
+
+def backward_unit(loss):
+    """``loss.backward()`` with the library's cached unit gradient as the root gradient (same values; saves
+    autograd's ones_like fill, and the loss edges of this package pass it down by identity — see
+    ``functional.unit_gradient``)."""
+    if loss.is_cuda and loss.dtype == torch.float32 and loss.numel() == 1:
+        from . import functional as BF
+        loss.backward(BF.unit_gradient(loss.device).reshape(loss.shape))
+    else:
+        loss.backward()
 
 
 def wrap_fp16_model(model, math='bf16'):
@@ -405,7 +465,7 @@ class Fp16OptimizerStep(DistOptimizerStep):
             self.overlap.finish()
         else:
             allreduce_grads(self.params, self.world_size)
-        self._clip_and_step(1.0 / self.loss_scale)
+        self._clip_and_step(self.loss_scale)
 
     def __call__(self, loss):
         self.optimizer.zero_grad(set_to_none=False)

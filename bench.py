@@ -328,7 +328,9 @@ class DetectorStep(object):
         # instead of a zero fill + an add per parameter — 2 x 160 launches of the selectp=0 step.
         # Same values as the reference's zero_grad() + accumulation into zeros.
         self.step_fn.optimizer.zero_grad(set_to_none=os.environ.get('BGS_ZERO_GRAD_FILL') != '1')
-        (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
+        # root gradient = the library's cached unit gradient (train.backward_unit): the same ones, no fill launch, and
+        # the fused GroupSoftmax head receives it by identity through parse_losses -> its backward launches nothing
+        self.train.backward_unit(loss * self.loss_scale if self.loss_scale != 1.0 else loss)
         # detached copies only: holding the loss would keep the autograd graph (and its
         # AccumulateGrad nodes) alive across iterations
         self.last = {k: v.detach() for k, v in log_vars.items()}

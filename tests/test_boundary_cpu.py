@@ -241,7 +241,10 @@ def test_parse_losses_batched_segment_sums_equal_the_per_key_formula_with_gradie
     assert abs(float(loss) - float(total)) < 1e-6 and abs(float(log_vars['loss']) - float(total)) < 1e-6
     loss.backward()
     for i, t in enumerate(leaves):
-        want = 0.0 if i == 11 else (2.0 if i == 13 else 1.0)
+        if i == 11:                     # `acc` is not part of the total: no gradient reaches it (as in the reference)
+            assert t.grad is None or float(t.grad) == 0.0
+            continue
+        want = 2.0 if i == 13 else 1.0
         assert abs(float(t.grad) - want) < 1e-6, i
     assert len(train._SEGMENT_MATS) >= 1          # cached per structure: a second call builds nothing new
     n = len(train._SEGMENT_MATS)
@@ -293,11 +296,79 @@ def test_proposal_list_is_the_reference_list_plus_its_batch_tensors():
 
 def test_unit_gradient_is_one_cached_tensor_per_device_and_recognised_by_storage():
     """functional.unit_gradient: the constant root gradient the GroupSoftmax head step recognises (no
-    scaling launch); a different ones tensor is NOT it, a view of the same storage is."""
+    scaling launch); a different ones tensor is NOT it, a view of the same storage is — and a buffer somebody
+    wrote to in place is no longer taken for ones (version counter), a fresh one is handed out instead."""
     import torch
     from balancedgroupsoftmax_amd import functional as BF
     u = BF.unit_gradient('cpu')
-    assert u is BF.unit_gradient(torch.device('cpu')) and u.shape == (1,) and u.dtype == torch.float32
-    assert BF._is_unit_gradient(u) and BF._is_unit_gradient(u.detach())
+    assert u.data_ptr() == BF.unit_gradient(torch.device('cpu')).data_ptr()
+    assert u.shape == (1,) and u.dtype == torch.float32 and float(u) == 1.0
+    assert BF._is_unit_gradient(u) and BF._is_unit_gradient(u.detach()) and BF._is_unit_gradient(u.reshape(()))
+    u6 = BF.unit_gradient('cpu', 6)
+    assert u6.shape == (6,) and u6.data_ptr() == u.data_ptr() and BF._is_unit_gradient(u6)
     assert not BF._is_unit_gradient(torch.ones(1))
     assert not BF._is_unit_gradient(u.double())
+    assert not BF._is_unit_gradient(BF.unit_gradient('cpu', 8)[2:5])          # not the head of the buffer
+    u.mul_(2.0)                                                               # a caller breaks the contract ..
+    assert not BF._is_unit_gradient(u)                                        # .. and the general path runs
+    fresh = BF.unit_gradient('cpu')
+    assert float(fresh) == 1.0 and fresh.data_ptr() != u.data_ptr() and BF._is_unit_gradient(fresh)
+
+
+def test_unit_gradient_reaches_the_head_terms_by_identity_through_parse_losses():
+    """``train.backward_unit(parse_losses(losses)[0])``: the root gradient is the cached unit gradient, every
+    'loss' scalar receives THAT tensor (no arithmetic), and the fused head's term split turns six of them back into
+    the cached ones vector — the chain the GPU head relies on to skip its gradient-scaling launch.  With a factor
+    anywhere on the way (a weighted total) the general path runs and the values are the weights."""
+    import torch
+    from balancedgroupsoftmax_amd import functional as BF
+    from balancedgroupsoftmax_amd import train
+
+    seen = []
+
+    class Head(torch.autograd.Function):            # stands in for _GsHeadStepFn: records what backward receives
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2.0
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append((BF._is_unit_gradient(g), g.detach().clone()))
+            return g * 2.0
+
+    x = torch.arange(6, dtype=torch.float32, requires_grad=True)
+    parts = BF.unbind_terms(Head.apply(x))
+    other = torch.tensor(3.0, requires_grad=True)
+    losses = dict(loss_cls_bin0=parts[0], loss_cls_bin1=parts[1], loss_cls_bin2=parts[2], loss_cls_bin3=parts[3],
+                  loss_cls_bin4=parts[4], loss_bbox=parts[5], loss_rpn_cls=[other * 1.0, other * 2.0], acc=other * 5.0)
+    loss, log_vars = train.parse_losses(losses)
+    assert abs(float(loss) - (2 * 15 + 9)) < 1e-6 and abs(float(log_vars['loss_rpn_cls']) - 9.0) < 1e-6
+    # (CPU tensors: backward_unit's CUDA fast path is taken on the GPU; hand the unit gradient over explicitly)
+    loss.backward(BF.unit_gradient('cpu').reshape(()))
+    assert len(seen) == 1 and seen[0][0] and seen[0][1].tolist() == [1.0] * 6
+    assert x.grad.tolist() == [2.0] * 6 and float(other.grad) == 3.0
+    # a weighted total: not the unit gradient any more
+    seen.clear()
+    x.grad = None
+    parts = BF.unbind_terms(Head.apply(x))
+    loss, _ = train.parse_losses(dict(loss_a=parts[0], loss_b=parts[1], loss_c=[parts[2], parts[3]], loss_d=parts[4],
+                                      acc=parts[5]))
+    (loss * 0.5).backward()
+    assert len(seen) == 1 and not seen[0][0] and seen[0][1].tolist() == [0.5] * 5 + [0.0]
+
+
+def test_parse_losses_contains_a_non_finite_term_to_its_own_key_and_the_total():
+    """A NaN loss term makes ITS key and the total NaN; an infinite metric (`acc` is not part of the total) touches
+    neither the other keys nor the total — the reference's per-key sums behave like this, a 0/1-matrix product
+    would not (0 * NaN = NaN)."""
+    import math
+    import torch
+    from balancedgroupsoftmax_amd import train
+    d = dict(loss_a=[torch.tensor(1.0), torch.tensor(2.0)], loss_b=torch.tensor(float('nan')),
+             acc=torch.tensor(float('inf')), loss_c=torch.tensor(3.0))
+    loss, lv = train.parse_losses(d)
+    assert float(lv['loss_a']) == 3.0 and float(lv['loss_c']) == 3.0 and math.isinf(float(lv['acc']))
+    assert math.isnan(float(lv['loss_b'])) and math.isnan(float(loss))
+    d.pop('loss_b')
+    loss, lv = train.parse_losses(d)
+    assert float(loss) == 6.0

@@ -1189,6 +1189,44 @@ def test_fused_clip_sgd_step_vs_torch_clip_grad_norm_and_sgd(clip):
             assert np.allclose(na, nb, rtol=1e-5), (na, nb)
 
 
+def test_fused_clip_sgd_step_invalidates_the_version_keyed_weight_caches():
+    """The fused step writes the parameters through raw pointers; every cache keyed on ``Parameter._version`` — the
+    split bf16 planes of a frozen-looking weight (``functional.bfx_split_weights``), the folded conv+BN weights of an
+    eval-mode module (``backbone._FoldCache``) — must see the update as it would after ``torch.optim.SGD.step()``:
+    eval, fused step, eval gives the NEW weights' output (a train / eval / train / eval sequence in one
+    process silently reused the first eval's planes)."""
+    from balancedgroupsoftmax_amd import train
+    from balancedgroupsoftmax_amd.backbone import cached_fold
+    g = torch.Generator().manual_seed(3)
+    conv = torch.nn.Conv2d(32, 64, 1, bias=True).to(DEV)
+    bn = torch.nn.BatchNorm2d(64).to(DEV).eval()
+    x = torch.randn(2, 16, 16, 32, generator=g).to(DEV)
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        def eval_out():
+            with torch.no_grad():
+                w, b = cached_fold(conv, bn)
+                return BF.conv2d_nhwc(x, w, b)                    # frozen_weight=True: planes cached by version
+        y0 = eval_out()
+        v0 = conv.weight._version
+        ps = list(conv.parameters())
+        opt = torch.optim.SGD(ps, lr=0.5, momentum=0.0)
+        for p_ in ps:
+            p_.grad = torch.ones_like(p_)
+        f = train.FusedClipSGD(opt, ps, None)
+        f.step()
+        assert conv.weight._version > v0 and conv.bias._version > 0
+        y1 = eval_out()
+        with torch.no_grad():
+            ref = F.conv2d(x.permute(0, 3, 1, 2).double(), conv.weight.double(), conv.bias.double())
+            ref = F.batch_norm(ref, bn.running_mean.double(), bn.running_var.double(), bn.weight.double(),
+                               bn.bias.double(), False, 0.0, bn.eps).permute(0, 2, 3, 1)
+        assert float((y1.double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+        assert float((y1 - y0).abs().max()) > 1.0          # lr 0.5 x ones moved every weight by 0.5
+    finally:
+        BF.set_conv_math(prev)
+
+
 def test_dist_optimizer_step_uses_the_fused_kernels_on_the_gpu_and_torch_under_the_switch(monkeypatch):
     from balancedgroupsoftmax_amd import train
     ps = [torch.nn.Parameter(torch.randn(300, 20, device=DEV)), torch.nn.Parameter(torch.randn(7, device=DEV))]

@@ -594,6 +594,21 @@ def test_fullsize_iteration_with_the_shipped_sampler_sizes_and_the_references_re
 
 @pytest.mark.parametrize('math', ['bf16x6', 'bf16', 'bf16-fp32storage'])
 def test_cascade_x101_fullsize_iteration_vs_executed_reference(math):
+    _cascade_x101_vs_executed_reference(math, two_images=False)
+
+
+@pytest.mark.parametrize('math', ['bf16x6', 'bf16'])
+def test_cascade_x101_two_images_non_saturating_rpn_vs_executed_reference(math):
+    """The X101 bench shape (2 x 3x800x1344) with an RPN whose objectness scores do not saturate
+    (tests/golden/make_golden_cascade_x101_v2.py: ``rpn_cls`` calibrated to a top logit of 8 after the seeded
+    fill, the factor stored in the golden and applied here the same way): in ``bf16x6`` the HIP RPN must reproduce
+    >= 97 % of the executed reference's 480 proposals of EACH image (what the cfg[1] full-size golden demands)
+    before the three RoI stages are compared on them; every loss term, the total and the head gradients as in the
+    one-image test."""
+    _cascade_x101_vs_executed_reference(math, two_images=True)
+
+
+def _cascade_x101_vs_executed_reference(math, two_images):
     """BASELINE cfg[4] AT ITS OWN TRUNK AND SIZE: ``gs_cascade_rcnn_x101_64x4d`` (ResNeXt-101-64x4d,
     three GroupSoftmax stages, class-agnostic regression, stage weights 1 / 0.5 / 0.25) on
     1 x 3x800x1344 against the executed reference (tests/golden/make_golden_cascade_x101.py;
@@ -608,8 +623,14 @@ def test_cascade_x101_fullsize_iteration_vs_executed_reference(math):
     tensors, the 8-wave 128x128 operand ring)."""
     from balancedgroupsoftmax_amd import functional as BF
     from balancedgroupsoftmax_amd import train
-    from tests.golden import make_golden_cascade_x101 as T
-    z = np.load(os.path.join(os.path.dirname(T.__file__), 'e2e_cascade_x101_fullsize_golden.npz'))
+    if two_images:
+        from tests.golden import make_golden_cascade_x101_v2 as T
+        z = np.load(os.path.join(os.path.dirname(T.__file__), 'e2e_cascade_x101_2img_golden.npz'))
+        assert int(z['saturated_scores0'][0]) == 0 and int(z['saturated_scores1'][0]) == 0
+    else:
+        from tests.golden import make_golden_cascade_x101 as T
+        z = np.load(os.path.join(os.path.dirname(T.__file__), 'e2e_cascade_x101_fullsize_golden.npz'))
+    min_frac = 0.97 if two_images else 0.5
     model = None
     storage = math == 'bf16'
     label, math = math, math.split('-')[0]
@@ -622,6 +643,8 @@ def test_cascade_x101_fullsize_iteration_vs_executed_reference(math):
                                    test_cfg=to_config_dict(G.TEST_CFG))
         with torch.no_grad():
             det_oracle.fill_detector(model.state_dict(), T.SEED)
+        if two_images:
+            T.apply_rpn_scale(model.state_dict(), float(z['rpn_cls_scale'][0]))
         model.to(DEV)
         train.select_training_param(model, 2)          # the three box heads train (fc_cls, fc_reg, shared FCs)
         model.train()
@@ -637,7 +660,7 @@ def test_cascade_x101_fullsize_iteration_vs_executed_reference(math):
                 print('image %d: %.4f of the reference proposals reproduced by the HIP RPN (%d reference '
                       'scores saturated at 1.0)' % (i, frac, int(z['saturated_scores%d' % i][0])))
                 if math == 'bf16x6':       # (bf16 operands move scores by more than the match tolerance)
-                    assert frac >= 0.5, frac
+                    assert frac >= min_frac, frac
                 n = min(ref.shape[0], p.shape[0])
                 pad = torch.zeros_like(p)
                 pad[:n] = ref[:n]
