@@ -1399,6 +1399,7 @@ extern "C" int bgs_gs_head_step_scale_grad(float* dlogits, float* dbbox_pred,
   const size_t total = (size_t)N * (dbbox_pred ? (size_t)num_reg_classes * 4 : (size_t)W);
   size_t blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 512) blocks = 512;       // two workgroups per CU: the usual call early-outs
+  bgs_internal_census_bump(BGS_CENSUS_GS_SCALE_GRAD);
   hipLaunchKernelGGL(gs_head_scale_grad_kernel, dim3((unsigned)blocks), dim3(kBlock),
                      sizeof(float) * (size_t)W, (hipStream_t)stream, dlogits, dbbox_pred, geom,
                      grad_terms, grad_total, N, B, W, num_reg_classes * 4);

@@ -391,6 +391,7 @@ int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wsplit, const f
 #define BGS_CENSUS_BF16S 8           /* conv_bf16s_kernel (bf16 activations in HBM)       */
 #define BGS_CENSUS_GROUPED_BF16S 9   /* grouped 3x3 conv with bf16 activations in HBM     */
 #define BGS_CENSUS_BFX_WIDE 10       /* conv1x1_bfx_wide_kernel (128 x 128, M-stacked waves) */
+#define BGS_CENSUS_GS_SCALE_GRAD 11   /* gs_head_scale_grad_kernel (a non-unit upstream gradient) */
 #define BGS_CENSUS_FAMILIES 16
 int bgs_launch_census(int family, int reset);
 void bgs_conv_bfx_tuning(int tile, int splitk);

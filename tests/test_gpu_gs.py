@@ -643,7 +643,7 @@ def test_head_step_backward_under_the_unit_gradient_launches_nothing_and_changes
     case, l2b, ps, _, _, batch = case_setup('n1024_cfg2')
     labels, l2b_t = dev(batch['labels']), dev(l2b)
     unit = BF.unit_gradient(DEV)
-    assert unit is BF.unit_gradient(DEV) and float(unit.item()) == 1.0
+    assert unit.data_ptr() == BF.unit_gradient(DEV).data_ptr() and float(unit.item()) == 1.0
     grads = []
     for root in (unit, torch.ones(1, device=DEV), torch.full((1,), 2.0, device=DEV)):
         z = dev(batch['logits']).requires_grad_(True)
@@ -654,6 +654,32 @@ def test_head_step_backward_under_the_unit_gradient_launches_nothing_and_changes
     np.testing.assert_array_equal(grads[0], grads[1])
     np.testing.assert_array_equal(2.0 * grads[0], grads[2])
     assert float(unit.item()) == 1.0                  # read-only by contract: nobody wrote into it
+    # the detector's own edge: losses dict -> train.parse_losses -> backward_unit.  The unit gradient reaches the
+    # head's TERMS by identity (functional._LossSumsFn / unbind_terms), so no scaling kernel is launched here either
+    from balancedgroupsoftmax_amd import capi, train
+    z = dev(batch['logits']).requires_grad_(True)
+    counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+    terms, _, _ = BF.gs_head_step(z, labels, l2b_t, ps, 8.0, 77, draw_counter=counter)
+    parts = BF.unbind_terms(terms)
+    losses = {'loss_cls_bin%d' % i: parts[i] for i in range(len(parts) - 1)}
+    losses['loss_bbox'] = parts[-1]
+    loss, _ = train.parse_losses(losses)
+    before = capi.load().bgs_launch_census(11, 0)
+    train.backward_unit(loss)
+    assert capi.load().bgs_launch_census(11, 0) == before, 'the gradient-scaling kernel ran under the unit gradient'
+    np.testing.assert_array_equal(z.grad.cpu().numpy(), grads[0])
+    # .. and it does run (and scales) once a factor sits on the way
+    z2 = dev(batch['logits']).requires_grad_(True)
+    counter.zero_()
+    terms, _, _ = BF.gs_head_step(z2, labels, l2b_t, ps, 8.0, 77, draw_counter=counter)
+    parts = BF.unbind_terms(terms)
+    loss, _ = train.parse_losses({'loss_%d' % i: p_ for i, p_ in enumerate(parts)})
+    (loss * 2.0).backward()
+    assert capi.load().bgs_launch_census(11, 0) == before + 1
+    np.testing.assert_array_equal(z2.grad.cpu().numpy(), grads[2])
+    # a written-to unit buffer is not trusted any more
+    unit.add_(0.0)
+    assert not BF._is_unit_gradient(unit) and BF._is_unit_gradient(BF.unit_gradient(DEV))
 
 
 def test_head_step_refuses_rows_beyond_the_lds_window():
