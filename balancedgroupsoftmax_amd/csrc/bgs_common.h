@@ -128,6 +128,32 @@ __device__ __forceinline__ void store_vec(float* p, const float (&in)[VEC]) {
   *reinterpret_cast<V*>(p) = v;
 }
 
+// The same with the non-temporal hint (global_load / global_store ... nt): data streamed through once
+template <int VEC>
+__device__ __forceinline__ void load_vec_nt(const float* p, float (&out)[VEC]) {
+  using V = typename VecT<VEC>::type;
+  const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+  if constexpr (VEC == 1) {
+    out[0] = v;
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) out[j] = v[j];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec_nt(float* p, const float (&in)[VEC]) {
+  using V = typename VecT<VEC>::type;
+  V v;
+  if constexpr (VEC == 1) {
+    v = in[0];
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = in[j];
+  }
+  __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
+}
+
 // splitmix64 finaliser: counter-based RNG keyed by (seed, stream, index).
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint32_t stream, uint32_t idx) {
   uint64_t x = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)idx + 1ull) +

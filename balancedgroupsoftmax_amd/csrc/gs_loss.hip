@@ -34,8 +34,17 @@ namespace {
 constexpr int kBlock = 256;   // generic fallback + helper kernels
 constexpr int kWaves = kBlock / BGS_WAVE;
 constexpr int kMaxGrid = 2048;
+int g_rowwave_pf = 3;        // bgs_gs_loss_tuning: 0 = no next-row prefetch | 1 = prefetch | 2 / 3 / 4 = prefetch + non-temporal
+                             // loads / stores / both (A/B; 3 = default: profiles/r8e_gs_rowwave_prefetch_ab.txt)
 
-template <int VEC, bool WRITE_GRAD>
+// PF (rows of at most 2 * 256 * VEC floats — W <= 2048 for the 16-byte path: every LVIS table): the NEXT row of the
+// workgroup is fetched into registers while the current one is processed, so that a workgroup's rows no longer cost
+// a global-memory round trip each in front of their first barrier.  NT bit 1: the gradient leaves with the
+// non-temporal hint (written once, read by a later kernel from HBM anyway at these sizes); bit 0: the row loads
+// carry it too (measured slower).  At N = 65,536 on one box: 4.53 TB/s (round-3 kernel) -> 5.06 (PF) -> 5.34
+// (PF + nt stores) = 0.67 of the 8 TB/s HBM peak against a 6.29 TB/s copy ceiling
+// (profiles/r8e_gs_rowwave_prefetch_ab.txt).  Same arithmetic, same order: bit-identical losses and gradients.
+template <int VEC, bool WRITE_GRAD, bool PF = false, int NT = 0>
 __global__ __launch_bounds__(kBlock) void gs_loss_rowwave_kernel(
     const float* __restrict__ logits, const int32_t* __restrict__ bin_labels,
     const float* __restrict__ weights, const float* __restrict__ avg, bgs::BinGeom geom, int N,
@@ -51,16 +60,45 @@ __global__ __launch_bounds__(kBlock) void gs_loss_rowwave_kernel(
   if (lane < B) my_inv_avg = 1.f / (avg ? avg[lane] : fmaxf((float)N, 1.f));
   float lacc = 0.f;  // wave (b % kWaves), lane b accumulates the loss of bin b
 
+  // PF: this thread's (at most two) VEC-wide pieces of a row, and the row's bin label / weight of lane b
+  const int c0 = tid * VEC, c1 = (tid + kBlock) * VEC;
+  float pf0[VEC], pf1[VEC];
+  int pf_bl = 0;
+  float pf_w = 1.f;
+  auto prefetch = [&](int r) {
+    const float* g = logits + (size_t)r * W;
+    if (NT & 1) {                        // streamed once: non-temporal
+      if (c0 < W) bgs::load_vec_nt<VEC>(g + c0, pf0);
+      if (c1 < W) bgs::load_vec_nt<VEC>(g + c1, pf1);
+    } else {
+      if (c0 < W) bgs::load_vec<VEC>(g + c0, pf0);
+      if (c1 < W) bgs::load_vec<VEC>(g + c1, pf1);
+    }
+    if (lane < B) {
+      pf_bl = bin_labels[(size_t)lane * N + r];
+      pf_w = weights ? weights[(size_t)lane * N + r] : 1.f;
+    }
+  };
+  if (PF && (int)blockIdx.x < N) prefetch(blockIdx.x);
+
   int par = 0;
   for (int r = blockIdx.x; r < N; r += gridDim.x, par ^= 1) {
     float* row = smem + (size_t)par * wpad;
-    bgs::stage_row<VEC>(logits + (size_t)r * W, row, W, tid, kBlock);
     int my_bl = 0;
     float my_coef = 0.f;
-    if (lane < B) {
-      my_bl = bin_labels[(size_t)lane * N + r];
-      const float w = weights ? weights[(size_t)lane * N + r] : 1.f;
-      my_coef = w * my_inv_avg;
+    if (PF) {
+      if (c0 < W) bgs::store_vec<VEC>(row + c0, pf0);
+      if (c1 < W) bgs::store_vec<VEC>(row + c1, pf1);
+      my_bl = pf_bl;
+      my_coef = lane < B ? pf_w * my_inv_avg : 0.f;
+      if (r + (int)gridDim.x < N) prefetch(r + gridDim.x);      // in flight under this row's sweeps
+    } else {
+      bgs::stage_row<VEC>(logits + (size_t)r * W, row, W, tid, kBlock);
+      if (lane < B) {
+        my_bl = bin_labels[(size_t)lane * N + r];
+        const float w = weights ? weights[(size_t)lane * N + r] : 1.f;
+        my_coef = w * my_inv_avg;
+      }
     }
     __syncthreads();
     for (int b = wave; b < B; b += kWaves) {  // bins are independent: one wave each
@@ -87,7 +125,16 @@ __global__ __launch_bounds__(kBlock) void gs_loss_rowwave_kernel(
     }
     if (WRITE_GRAD) {
       __syncthreads();
-      bgs::unstage_row<VEC>(row, dlogits + (size_t)r * W, W, tid, kBlock);
+      if (NT & 2) {
+        float* g = dlogits + (size_t)r * W;
+        for (int c = tid * VEC; c < W; c += kBlock * VEC) {
+          float t[VEC];
+          bgs::load_vec<VEC>(row + c, t);
+          bgs::store_vec_nt<VEC>(g + c, t);
+        }
+      } else {
+        bgs::unstage_row<VEC>(row, dlogits + (size_t)r * W, W, tid, kBlock);
+      }
     }
   }
   // bin b lives in wave b % kWaves, lane b: no cross-wave reduction needed
@@ -1077,7 +1124,16 @@ void launch_rowwave(bool grad, int grid, hipStream_t st, const float* logits, co
   const int wpad = (W + 3) & ~3;
   // + slack: the register sweep reads up to 64*kSweep floats from a bin's start
   const size_t lds = sizeof(float) * (2 * (size_t)wpad + BGS_WAVE * bgs::kSweep);
-  if (grad)
+  const bool pf = g_rowwave_pf && W <= 2 * kBlock * VEC && N > grid;    // a second row per workgroup to fetch ahead
+  if (grad && pf && g_rowwave_pf >= 2) {
+#define GS_NT(NT_) case NT_: hipLaunchKernelGGL((gs_loss_rowwave_kernel<VEC, true, true, NT_>), dim3(grid), dim3(kBlock), lds, st, \
+                                                logits, bl, w, avg, geom, N, B, W, wpad, partial, dlogits); break;
+    switch (g_rowwave_pf - 1) { GS_NT(1) GS_NT(2) default: GS_NT(3) }
+#undef GS_NT
+  } else if (grad && pf)
+    hipLaunchKernelGGL((gs_loss_rowwave_kernel<VEC, true, true>), dim3(grid), dim3(kBlock), lds, st,
+                       logits, bl, w, avg, geom, N, B, W, wpad, partial, dlogits);
+  else if (grad)
     hipLaunchKernelGGL((gs_loss_rowwave_kernel<VEC, true>), dim3(grid), dim3(kBlock), lds, st,
                        logits, bl, w, avg, geom, N, B, W, wpad, partial, dlogits);
   else
@@ -1089,6 +1145,10 @@ void launch_rowwave(bool grad, int grid, hipStream_t st, const float* logits, co
 inline int loss_grid(int N) { return N <= 0 ? 1 : (N < kMaxGrid ? N : kMaxGrid); }
 
 }  // namespace
+
+// tuning / test hook: 0 = the round-3 kernel | 1 = next row fetched ahead | 2 / 3 / 4 = .. + non-temporal row loads /
+// gradient stores / both (3 = default)
+extern "C" void bgs_gs_loss_tuning(int prefetch) { g_rowwave_pf = prefetch < 0 ? 0 : (prefetch > 4 ? 4 : prefetch); }
 
 extern "C" size_t bgs_gs_loss_workspace_bytes(int N, int B) {
   (void)N;

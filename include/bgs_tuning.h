@@ -24,6 +24,13 @@ extern "C" {
 void bgs_conv_bfx_wide_tuning(int mode, int nst, int splitk);
 int bgs_conv_bfx_wide_last_launch(void);
 
+/* Row-per-workgroup GroupSoftmax loss kernel (csrc/gs_loss.hip, bgs_gs_loss_fwd_bwd; the bandwidth-bound form
+ * of gs_bbox_head_with0.py:147-186 for N beyond the fused head's 4096 rows): prefetch 0 = every row pays its own
+ * global-memory round trip (the round-3 kernel) | 1 = the next row of a workgroup is fetched into registers under the
+ * current row's sweeps | 2 / 3 / 4 = 1 + non-temporal row loads / gradient stores / both.  3 is the default
+ * (N = 65,536: 4.5 -> 5.3 TB/s).  Bit-identical results in every mode. */
+void bgs_gs_loss_tuning(int prefetch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -212,6 +212,33 @@ def test_large_batch_properties():
         assert float(sl[inactive].abs().max() if inactive.any() else 0.0) == 0.0
 
 
+@pytest.mark.parametrize('N', [2049, 5000, 65536])
+def test_rowwave_next_row_prefetch_is_bit_identical(N):
+    """``gs_loss_rowwave_kernel<.., PF>`` (the next row of a workgroup fetched into registers under the current
+    row's sweeps, gradient stores with the non-temporal hint: the bandwidth-bound sizes, N > 2048 workgroups; the
+    default mode 3) == the round-3 kernel (mode 0) and the other arms, bit for bit — losses and the whole gradient;
+    N = 2049: exactly one workgroup has a second row."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    counts = gs_tables.synthetic_instance_counts(C, seed=0)
+    l2b, ps, _ = gs_tables.build_group_tables(counts)
+    batch = gs_oracle.make_roi_batch(N, 1236, C, seed=N)
+    bl_dev, w, avg = BF.gs_prepare(dev(batch['labels']), dev(l2b), 8.0, seed=9)
+    out = []
+    try:
+        for pf in (3, 0, 1, 4):
+            lib.bgs_gs_loss_tuning(pf)
+            z = dev(batch['logits']).requires_grad_(True)
+            losses = BF.group_softmax_loss(z, bl_dev, ps, w, avg)
+            losses.sum().backward()
+            out.append((losses.detach().cpu().numpy(), z.grad.cpu().numpy()))
+    finally:
+        lib.bgs_gs_loss_tuning(3)
+    for o in out[1:]:
+        np.testing.assert_array_equal(out[0][0], o[0])
+        np.testing.assert_array_equal(out[0][1], o[1])
+
+
 # ---------------------------------------------------------------------------------------
 # device-side _remap_labels / _sample_others
 # ---------------------------------------------------------------------------------------
