@@ -142,6 +142,14 @@ SIGNATURES = {
                                               ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, c_f32p, c_ptr]),
+    'bgs_roi_align_nhwc_fwd_f16': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, c_ptr, c_ptr, c_ptr]),
+    'bgs_roi_align_nhwc_bwd_f16': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, c_ptr, c_ptr]),
     'bgs_roi_align_nhwc_fwd_ex': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int,
                                                  ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_int,
                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -190,6 +190,101 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(RoiLevels L,
   }
 }
 
+
+// ---- any sample_num (0 = the reference's adaptive grid: ceil(roi_size / pooled_size) samples per bin and axis,
+// roi_align_kernel.cu:95-99) and fp16 tensors (AT_DISPATCH_FLOATING_TYPES_AND_HALF, roi_align_kernel.cu:136):
+// the rest of the `roi_align_cuda` interface.  Same wave-per-bin mapping; the taps of a sample point are
+// recomputed in the loop instead of held in a register array (their number is a per-RoI runtime value), features /
+// output (forward) and the incoming gradient (backward) are T = float or _Float16 with fp32 arithmetic, the
+// gradient maps are always fp32 (the caller adds them into its own-dtype bottom_grad: mmdet/ops/roi_align/
+// roi_align.py:45-52).  A degenerate RoI (zero height or width under sample_num = 0) has an empty sample grid
+// and produces 0 / 0 = NaN, as the reference kernel does.
+template <typename T>
+__device__ __forceinline__ f32x4 load4_as_f32(const T* p);
+template <>
+__device__ __forceinline__ f32x4 load4_as_f32<float>(const float* p) {
+  return *reinterpret_cast<const f32x4*>(p);
+}
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <>
+__device__ __forceinline__ f32x4 load4_as_f32<_Float16>(const _Float16* p) {
+  const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(_Float16* p, f32x4 v) {
+  *reinterpret_cast<f16x4*>(p) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void roi_align_nhwc_generic_kernel(RoiLevels L, const float* __restrict__ rois,
+                                                                     int K, int C, int PH, int PW, int sample_num,
+                                                                     T* __restrict__ out,
+                                                                     int* __restrict__ lvl_out) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int bins = PH * PW;
+  if (wave_global >= K * bins) return;
+  const int k = wave_global / bins;
+  const int bin = wave_global - k * bins;
+  const int ph = bin / PW, pw = bin - (bin / PW) * PW;
+  const float* roi = rois + (size_t)k * 5;
+  const int n = min(max((int)roi[0], 0), L.num_images - 1);
+  const float x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
+  const float scale = sqrtf((x2 - x1 + 1.f) * (y2 - y1 + 1.f));
+  float lf = floorf(log2f(scale / L.finest_scale + 1e-6f));
+  lf = fminf(fmaxf(lf, 0.f), (float)(L.num_levels - 1));
+  const int lvl = (int)lf;
+  if (lvl_out && bin == 0 && lane == 0) lvl_out[k] = lvl;
+  const int H = L.H[lvl], W = L.W[lvl];
+  const float ss = L.scale[lvl];
+  const float roi_start_w = x1 * ss, roi_start_h = y1 * ss;
+  const float roi_end_w = (x2 + 1.f) * ss, roi_end_h = (y2 + 1.f) * ss;
+  const float roi_width = fmaxf(roi_end_w - roi_start_w, 0.f);
+  const float roi_height = fmaxf(roi_end_h - roi_start_h, 0.f);
+  const float bin_size_h = roi_height / PH, bin_size_w = roi_width / PW;
+  const int sh = sample_num > 0 ? sample_num : (int)ceilf(roi_height / PH);
+  const int sw = sample_num > 0 ? sample_num : (int)ceilf(roi_width / PW);
+  const float count = (float)(sh * sw);
+  T* o = out + ((size_t)k * bins + bin) * C;
+  if (BWD) {
+    float* dfeat = const_cast<float*>(L.feat[lvl]) + (size_t)n * H * W * C;
+    for (int c = lane; c < C; c += 64) {
+      const float g = (float)o[c];
+      for (int iy = 0; iy < sh; ++iy) {
+        const float y = roi_start_h + ph * bin_size_h + (iy + .5f) * bin_size_h / (float)sh;
+        for (int ix = 0; ix < sw; ++ix) {
+          const float x = roi_start_w + pw * bin_size_w + (ix + .5f) * bin_size_w / (float)sw;
+          const Tap t = make_tap(y, x, H, W);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (t.w[q] == 0.f) continue;
+            unsafeAtomicAdd(dfeat + (size_t)t.o[q] * C + c, g * t.w[q] / count);
+          }
+        }
+      }
+    }
+    return;
+  }
+  const T* feat = reinterpret_cast<const T*>(L.feat[lvl]) + (size_t)n * H * W * C;
+  for (int c = lane * 4; c < C; c += 256) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int iy = 0; iy < sh; ++iy) {
+      const float y = roi_start_h + ph * bin_size_h + (iy + .5f) * bin_size_h / (float)sh;
+      for (int ix = 0; ix < sw; ++ix) {
+        const float x = roi_start_w + pw * bin_size_w + (ix + .5f) * bin_size_w / (float)sw;
+        const Tap t = make_tap(y, x, H, W);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v += t.w[q] * load4_as_f32<T>(feat + (size_t)t.o[q] * C + c);
+        acc += v;
+      }
+    }
+    acc /= count;
+    store4(o + c, acc);
+  }
+}
+
 }  // namespace
 
 static int fill_levels(RoiLevels& L, const float* const* feats, const int* host_heights,
@@ -226,14 +321,21 @@ extern "C" int bgs_roi_align_nhwc_fwd_ex(const float* const* host_feats, const i
   if (K == 0) return BGS_OK;
   if (!rois || !out) return BGS_ERR_INVALID_ARG;
   if (C % 4 != 0 || (uintptr_t)out % 16 != 0) return BGS_ERR_UNSUPPORTED;
-  if (sample_num != 2) return BGS_ERR_UNSUPPORTED;  // every shipped config uses sample_num=2
+  if (sample_num < 0) return BGS_ERR_INVALID_ARG;
   if (pool != 1 && !(pool == 2 && C <= 256)) return BGS_ERR_UNSUPPORTED;
+  if (sample_num != 2 && pool != 1) return BGS_ERR_UNSUPPORTED;   // the fused 2x2 pooling exists for sample_num = 2
   RoiLevels L;
   const int rc = fill_levels(L, host_feats, host_heights, host_widths, host_scales, num_levels,
                              num_images, finest_scale, true);
   if (rc != BGS_OK) return rc;
   const long long waves = (long long)K * pooled_h * pooled_w;
   const unsigned grid = (unsigned)((waves + 3) / 4);
+  if (sample_num != 2) {      // every shipped config uses sample_num = 2; the rest of the interface runs the generic kernel
+    if (accumulate) return BGS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((roi_align_nhwc_generic_kernel<float, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       L, rois, K, C, pooled_h, pooled_w, sample_num, out, levels_out);
+    BGS_RETURN_LAUNCH_STATUS();
+  }
 #define BGS_ROI_FWD(POOL_, ACC_)                                                              \
   hipLaunchKernelGGL((roi_align_nhwc_kernel<2, false, POOL_, ACC_>), dim3(grid), dim3(256), 0,   \
                      (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w, out, levels_out)
@@ -269,13 +371,19 @@ extern "C" int bgs_roi_align_nhwc_bwd_ex(float* const* host_dfeats, const int* h
   if (K == 0) return BGS_OK;
   if (!rois || !dout) return BGS_ERR_INVALID_ARG;
   if (C % 4 != 0 || (uintptr_t)dout % 16 != 0) return BGS_ERR_UNSUPPORTED;
-  if (sample_num != 2 || (pool != 1 && pool != 2)) return BGS_ERR_UNSUPPORTED;
+  if (sample_num < 0) return BGS_ERR_INVALID_ARG;
+  if ((pool != 1 && pool != 2) || (sample_num != 2 && pool != 1)) return BGS_ERR_UNSUPPORTED;
   RoiLevels L;
   const int rc = fill_levels(L, host_dfeats, host_heights, host_widths, host_scales, num_levels,
                              num_images, finest_scale, false);
   if (rc != BGS_OK) return rc;
   const long long waves = (long long)K * pooled_h * pooled_w;
   const unsigned grid = (unsigned)((waves + 3) / 4);
+  if (sample_num != 2) {
+    hipLaunchKernelGGL((roi_align_nhwc_generic_kernel<float, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       L, rois, K, C, pooled_h, pooled_w, sample_num, const_cast<float*>(dout), nullptr);
+    BGS_RETURN_LAUNCH_STATUS();
+  }
   if (pool == 1)
     hipLaunchKernelGGL((roi_align_nhwc_kernel<2, true, 1, false>), dim3(grid), dim3(256), 0,
                        (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w,
@@ -295,4 +403,54 @@ extern "C" int bgs_roi_align_nhwc_bwd(float* const* host_dfeats, const int* host
   return bgs_roi_align_nhwc_bwd_ex(host_dfeats, host_heights, host_widths, host_scales, num_levels,
                                    num_images, finest_scale, rois, K, C, pooled_h, pooled_w,
                                    sample_num, 1, dout, stream);
+}
+
+// fp16 tensors (the half instantiation of the reference's dispatch, roi_align_kernel.cu:136,281): features / output
+// (forward) and the incoming gradient (backward) are IEEE half, RoIs fp32 (the caller widens them: exact), arithmetic
+// and the gradient maps fp32.  Any sample_num >= 0 (0 = adaptive).
+extern "C" int bgs_roi_align_nhwc_fwd_f16(const void* const* host_feats, const int* host_heights,
+                                          const int* host_widths, const float* host_scales, int num_levels,
+                                          int num_images, float finest_scale, const float* rois, int K, int C,
+                                          int pooled_h, int pooled_w, int sample_num, void* out,
+                                          int* levels_out, bgs_stream_t stream) {
+  if (num_levels <= 0 || num_levels > kMaxLevels || num_images <= 0 || K < 0 || C <= 0 || pooled_h <= 0 ||
+      pooled_w <= 0 || sample_num < 0)
+    return BGS_ERR_INVALID_ARG;
+  if (!host_feats || !host_heights || !host_widths || !host_scales) return BGS_ERR_INVALID_ARG;
+  if (K == 0) return BGS_OK;
+  if (!rois || !out) return BGS_ERR_INVALID_ARG;
+  if (C % 4 != 0 || (uintptr_t)out % 8 != 0) return BGS_ERR_UNSUPPORTED;
+  RoiLevels L;
+  for (int i = 0; i < num_levels; ++i)
+    if (!host_feats[i] || (uintptr_t)host_feats[i] % 8 != 0) return BGS_ERR_INVALID_ARG;
+  const int rc = fill_levels(L, reinterpret_cast<const float* const*>(host_feats), host_heights, host_widths,
+                             host_scales, num_levels, num_images, finest_scale, false);
+  if (rc != BGS_OK) return rc;
+  const long long waves = (long long)K * pooled_h * pooled_w;
+  hipLaunchKernelGGL((roi_align_nhwc_generic_kernel<_Float16, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w, sample_num,
+                     reinterpret_cast<_Float16*>(out), levels_out);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int bgs_roi_align_nhwc_bwd_f16(float* const* host_dfeats, const int* host_heights,
+                                          const int* host_widths, const float* host_scales, int num_levels,
+                                          int num_images, float finest_scale, const float* rois, int K, int C,
+                                          int pooled_h, int pooled_w, int sample_num, const void* dout,
+                                          bgs_stream_t stream) {
+  if (num_levels <= 0 || num_levels > kMaxLevels || num_images <= 0 || K < 0 || C <= 0 || pooled_h <= 0 ||
+      pooled_w <= 0 || sample_num < 0)
+    return BGS_ERR_INVALID_ARG;
+  if (!host_dfeats || !host_heights || !host_widths || !host_scales) return BGS_ERR_INVALID_ARG;
+  if (K == 0) return BGS_OK;
+  if (!rois || !dout) return BGS_ERR_INVALID_ARG;
+  RoiLevels L;
+  const int rc = fill_levels(L, host_dfeats, host_heights, host_widths, host_scales, num_levels, num_images,
+                             finest_scale, false);
+  if (rc != BGS_OK) return rc;
+  const long long waves = (long long)K * pooled_h * pooled_w;
+  hipLaunchKernelGGL((roi_align_nhwc_generic_kernel<_Float16, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w, sample_num,
+                     const_cast<_Float16*>(reinterpret_cast<const _Float16*>(dout)), nullptr);
+  BGS_RETURN_LAUNCH_STATUS();
 }

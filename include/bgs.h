@@ -479,8 +479,10 @@ int bgs_maxpool3x3s2_bwd_nhwc_f32(const float* x, const float* dy, float* dx, in
  *   (mmdet/models/roi_extractors/single_level.py:54-73,89-107) + RoIAlignFunction.forward
  *   (mmdet/ops/roi_align/roi_align.py:12-29 -> src/roi_align_kernel.cu:16-124): level
  *   = clamp(floor(log2(sqrt(w*h)/finest_scale + 1e-6)), 0, L-1) is evaluated in the kernel,
- *   legacy box semantics (roi_end = (x2+1)*scale, samples outside [-1, H] x [-1, W] give 0),
- *   sample_num = 2.
+ *   legacy box semantics (roi_end = (x2+1)*scale, samples outside [-1, H] x [-1, W] give 0).
+ *   sample_num >= 0 as in the reference (roi_align_kernel.cu:95-99): n > 0 = an n x n sample grid per bin
+ *   (2 in every shipped config: its own unrolled kernel); 0 = adaptive, ceil(roi_size / pooled_size)
+ *   samples per axis and RoI (a degenerate RoI then has no samples: 0 / 0 = NaN, as in the reference).
  *   host_feats   [L] HOST array of device pointers to [num_images, H_l, W_l, C] float maps
  *   host_heights/host_widths/host_scales [L] HOST arrays (H_l, W_l, 1/stride_l)
  *   rois [K,5] float (batch_ind, x1, y1, x2, y2);  out [K, pooled_h, pooled_w, C] float
@@ -504,6 +506,21 @@ int bgs_roi_align_nhwc_bwd(float* const* host_dfeats, const int* host_heights,
                            int pooled_h, int pooled_w, int sample_num, const float* dout,
                            bgs_stream_t stream);
 
+/* The half instantiation of the reference's dtype dispatch (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ *   roi_align_kernel.cu:136,281): feature maps / `out` (forward) and `dout` (backward) are IEEE fp16, RoIs fp32
+ *   (widen them: exact), arithmetic fp32, the gradient maps fp32 (the caller adds them into its fp16
+ *   bottom_grad, mmdet/ops/roi_align/roi_align.py:45-52).  Any sample_num >= 0.  Same contract otherwise. */
+int bgs_roi_align_nhwc_fwd_f16(const void* const* host_feats, const int* host_heights,
+                               const int* host_widths, const float* host_scales, int num_levels,
+                               int num_images, float finest_scale, const float* rois, int K, int C,
+                               int pooled_h, int pooled_w, int sample_num, void* out, int* levels_out,
+                               bgs_stream_t stream);
+int bgs_roi_align_nhwc_bwd_f16(float* const* host_dfeats, const int* host_heights,
+                               const int* host_widths, const float* host_scales, int num_levels,
+                               int num_images, float finest_scale, const float* rois, int K, int C,
+                               int pooled_h, int pooled_w, int sample_num, const void* dout,
+                               bgs_stream_t stream);
+
 /* RoIAlign with a fused average pool and accumulate (HTC semantic fusion,
  *   mmdet/models/detectors/htc.py:57-64,88-96: `semantic_roi_extractor([semantic_feat], rois)`
  *   at 14x14 -> `F.adaptive_avg_pool2d(., 7)` -> `bbox_feats += .`).  Same contract as
@@ -511,6 +528,7 @@ int bgs_roi_align_nhwc_bwd(float* const* host_dfeats, const int* host_heights,
  *   pool        1 or 2: every output bin is the mean of pool x pool bins of the
  *               (pooled_h*pool) x (pooled_w*pool) RoIAlign grid (pool == 2 needs C <= 256);
  *   accumulate  != 0: out += result (out holds the box / mask RoI features).
+ *   (pool == 2 and accumulate exist for sample_num = 2 only: BGS_ERR_UNSUPPORTED otherwise.)
  *   The backward scatters dout / (4 * pool^2) per sample, atomically, into host_dfeats. */
 int bgs_roi_align_nhwc_fwd_ex(const float* const* host_feats, const int* host_heights,
                               const int* host_widths, const float* host_scales, int num_levels,

@@ -102,6 +102,77 @@ def test_roi_align_cuda_signature_vs_compiled_reference_kernels(out_size, scale)
     assert torch.allclose(acc - 1.0, f.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('sample_num', [0, 1, 2, 3])
+def test_roi_align_cuda_every_sample_num_vs_compiled_reference_kernels(sample_num):
+    """The whole ``sample_num`` range of the reference interface (roi_align_kernel.cu:95-99): n x n grids and the
+    ADAPTIVE grid (0: ceil(roi_size / pooled_size) samples per axis, different for every RoI), forward and backward,
+    against the reference's own ``ROIAlignForward`` / ``ROIAlignBackward`` compiled for the host (oracle/_ref)."""
+    rs = np.random.RandomState(31 + sample_num)
+    N, C, H, W, scale, K = 2, 16, 40, 56, 0.25, 41
+    feat = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    rois = _rois(rs, K, N, W / scale, H / scale)
+    f = torch.from_numpy(feat).to(DEV).requires_grad_(True)
+    r = torch.from_numpy(rois).to(DEV)
+    out = RoIAlignFunction.apply(f, r, 7, scale, sample_num)
+    exp = build_ref.roi_align_reference(feat, rois, scale, 7, sample_num)
+    assert np.abs(out.detach().cpu().numpy() - exp).max() < 1e-5 * max(1.0, np.abs(exp).max())
+    g = rs.standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(torch.from_numpy(g).to(DEV))
+    expg = build_ref.roi_align_reference_backward(g, rois, scale, (N, C, H, W), sample_num)
+    assert np.abs(f.grad.cpu().numpy() - expg).max() < 1e-4 * max(1.0, np.abs(expg).max())
+
+
+@pytest.mark.parametrize('sample_num', [0, 2])
+def test_roi_align_cuda_fp16_tensors(sample_num):
+    """The half instantiation of the reference's dispatch (roi_align_kernel.cu:136,281): fp16 features / rois /
+    output / gradients through the same signature; compared with the compiled reference kernels run in fp32 on the
+    fp16-rounded inputs, to fp16 resolution (this path accumulates in fp32 and rounds once)."""
+    rs = np.random.RandomState(7 + sample_num)
+    N, C, H, W, scale, K = 2, 32, 30, 44, 0.125, 29
+    feat = rs.standard_normal((N, C, H, W)).astype(np.float16)
+    rois = np.round(_rois(rs, K, N, W / scale, H / scale)).astype(np.float16)      # integers: exact in fp16
+    f = torch.from_numpy(feat).to(DEV).requires_grad_(True)
+    r = torch.from_numpy(rois).to(DEV)
+    out = RoIAlignFunction.apply(f, r, 7, scale, sample_num)
+    assert out.dtype == torch.float16
+    exp = build_ref.roi_align_reference(feat.astype(np.float32), rois.astype(np.float32), scale, 7, sample_num)
+    assert np.abs(out.detach().float().cpu().numpy() - exp).max() < 2e-3 * max(1.0, np.abs(exp).max())
+    g = rs.standard_normal(tuple(out.shape)).astype(np.float16)
+    out.backward(torch.from_numpy(g).to(DEV))
+    assert f.grad.dtype == torch.float16
+    expg = build_ref.roi_align_reference_backward(g.astype(np.float32), rois.astype(np.float32), scale,
+                                                  (N, C, H, W), sample_num)
+    assert np.abs(f.grad.float().cpu().numpy() - expg).max() < 4e-3 * max(1.0, np.abs(expg).max())
+
+
+def test_roi_align_cuda_passes_the_references_own_gradcheck_recipe():
+    """mmdet/ops/roi_align/gradcheck.py:11-30, restated (the file does not travel): 2 images of 16 x 15 x 15
+    features, 20 RoIs in the lower-right half, ``RoIAlign(3, 1 / 8)`` (sample_num = 0: the adaptive grid) and
+    ``RoIAlign(3, 1 / 8, 2)``, ``gradcheck(..., atol=1e-3, eps=1e-3)`` — through the compat module."""
+    from torch.autograd import gradcheck
+    rs = np.random.RandomState(0)
+    feat_size, spatial_scale, num_imgs, num_rois = 15, 1.0 / 8, 2, 20
+    img_size = feat_size / spatial_scale
+    batch_ind = rs.randint(num_imgs, size=(num_rois, 1))
+    rois = rs.rand(num_rois, 4) * img_size * 0.5
+    rois[:, 2:] += img_size * 0.5
+    rois = np.hstack((batch_ind, rois))
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(num_imgs, 16, feat_size, feat_size, generator=g).to(DEV).requires_grad_(True)
+    rois = torch.from_numpy(rois).float().to(DEV)
+
+    class RoIAlign(torch.nn.Module):                 # mmdet/ops/roi_align/roi_align.py:58-86 (use_torchvision=False)
+        def __init__(self, out_size, spatial_scale, sample_num=0):
+            super().__init__()
+            self.out_size, self.spatial_scale, self.sample_num = out_size, float(spatial_scale), int(sample_num)
+
+        def forward(self, features, rois):
+            return RoIAlignFunction.apply(features, rois, self.out_size, self.spatial_scale, self.sample_num)
+
+    assert gradcheck(RoIAlign(3, spatial_scale), (feat, rois), atol=1e-3, eps=1e-3)
+    assert gradcheck(RoIAlign(3, spatial_scale, 2), (feat, rois), atol=1e-3, eps=1e-3)
+
+
 def test_roi_align_cuda_error_convention():
     f = torch.zeros((1, 4, 8, 8), device=DEV)
     out = torch.zeros((3, 4, 7, 7), device=DEV)
@@ -113,8 +184,10 @@ def test_roi_align_cuda_error_convention():
     with pytest.raises(RuntimeError, match='contiguous'):
         roi_align_cuda.forward(f.permute(0, 1, 3, 2)[..., ::2], torch.zeros((3, 5), device=DEV), 7, 7,
                                1.0, 2, out)
-    with pytest.raises(NotImplementedError):
-        roi_align_cuda.forward(f, torch.zeros((3, 5), device=DEV), 7, 7, 1.0, 4, out)
+    with pytest.raises(NotImplementedError):          # float64: the one dtype of the reference's dispatch without a kernel
+        roi_align_cuda.forward(f.double(), torch.zeros((3, 5), device=DEV).double(), 7, 7, 1.0, 2, out.double())
+    with pytest.raises(RuntimeError, match='like the other operands'):
+        roi_align_cuda.forward(f.half(), torch.zeros((3, 5), device=DEV), 7, 7, 1.0, 2, out.half())
     empty = torch.zeros((0, 5), device=DEV)
     assert roi_align_cuda.forward(f, empty, 7, 7, 1.0, 2, torch.zeros((0, 4, 7, 7), device=DEV)) == 1
 
