@@ -583,11 +583,226 @@ def test_fullsize_iteration_with_the_shipped_sampler_sizes_and_the_references_re
                 print('%s: max |diff| / max |g| = %.2e' % (name, rel))
                 if rel > 1e-5:
                     bad.append((name, rel))
-            elif not grad_close(a, b):
+            elif not grad_close(a, b, l2tol=1e-3):         # ReLU-flip allowance + relative L2 <= 1e-3 per tensor
                 bad.append(name)
         assert not bad, bad
     finally:
         BF.set_conv_math(prev)
+        del model
+        torch.cuda.empty_cache()
+
+
+def test_mask_rcnn_fullsize_iteration_with_the_shipped_samplers_vs_executed_reference(monkeypatch):
+    """BASELINE cfg[3] AT THE SIZE ITS BENCH ROW TIMES: ``gs_mask_rcnn_r50_fpn_1x_lvis`` on 2 x 3x800x1344 with the
+    SHIPPED sampler sizes (RPN 256 @ 0.5, RCNN 512 @ 0.25 + GT, "others" ratio 8) and elliptic instance bitmaps,
+    against the executed reference (tests/golden/make_golden_mask_htc_fullsize.py: two_stage.py:134-265,
+    fcn_mask_head.py:94-123, mask_target.py:7-38).  The reference's recorded numpy draws are replayed through the
+    sampler hooks exactly as in the cfg[1] test; the mask branch then sees the same positive RoIs.  9 loss terms
+    (``loss_mask`` included) to 1e-4 / 2e-4, head gradients to 1e-5 of their largest entry, trunk gradients with the
+    ReLU-flip-tolerant criterion + a relative-L2 bound."""
+    from balancedgroupsoftmax_amd import functional as BF
+    from balancedgroupsoftmax_amd import train
+    from tests.golden import make_golden_mask_htc_fullsize as T
+    z = np.load(T.OUT_MASK)
+    prev = BF.set_conv_math('bf16x6')
+    model = None
+    try:
+        tmp = tempfile.mkdtemp(prefix='bgs_maskfull_')
+        model_cfg, train_cfg = T.mask_configs(tmp)
+        assert train_cfg['rpn']['sampler']['num'] == 256 and train_cfg['rcnn']['sampler']['num'] == 512
+        model_cfg['bbox_head']['gs_config']['sampler'] = 'numpy'
+        model = bgs.build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
+                                   test_cfg=to_config_dict(G.TEST_CFG))
+        with torch.no_grad():
+            det_oracle.fill_detector(model.state_dict(), T.MASK_SEED)
+        model.to(DEV)
+        train.select_training_param(model, 0)
+        model.train()
+        calls = dict(rpn=0, rcnn=0, gs=0)
+
+        def rpn_hook(assigned, num, pos_fraction, neg_pos_ub):
+            i = calls['rpn']
+            calls['rpn'] += 1
+            pos = torch.zeros(assigned.numel(), dtype=torch.bool, device=DEV)
+            neg = torch.zeros_like(pos)
+            pi = torch.from_numpy(z['rpn/pos%d' % i].astype(np.int64)).to(DEV)
+            ni = torch.from_numpy(z['rpn/neg%d' % i].astype(np.int64)).to(DEV)
+            assert bool((assigned[pi] > 0).all()) and bool((assigned[ni] == 0).all())
+            assert len(pi) + len(ni) == num
+            pos[pi] = True
+            neg[ni] = True
+            return pos, neg
+
+        def rcnn_hook(assigned, num, pos_fraction):
+            i = calls['rcnn']
+            calls['rcnn'] += 1
+            pi = torch.from_numpy(z['rcnn/pos%d' % i].astype(np.int64)).to(DEV)
+            ni = torch.from_numpy(z['rcnn/neg%d' % i].astype(np.int64)).to(DEV)
+            assert bool((assigned[pi] > 0).all()) and bool((assigned[ni] == 0).all())
+            inds = torch.cat([pi, ni])
+            assert inds.numel() == num
+            is_pos = torch.cat([torch.ones_like(pi), torch.zeros_like(ni)]).bool()
+            return inds, is_pos, torch.ones(num, dtype=torch.bool, device=DEV)
+
+        def proposals_hook(own):
+            out = []
+            for i, (p, v) in enumerate(own):
+                ref = torch.from_numpy(z['proposals%d' % i]).to(DEV)
+                assert tuple(ref.shape) == tuple(p.shape), (ref.shape, p.shape)
+                frac = match_boxes(p[v].cpu().numpy(), z['proposals%d' % i], tol_px=0.05, tol_score=2e-4)
+                print('image %d: %.4f of the reference proposals reproduced by the HIP RPN' % (i, frac))
+                assert frac >= 0.97, frac
+                out.append((ref.contiguous(), torch.ones(ref.shape[0], dtype=torch.bool, device=DEV)))
+            return out
+
+        def choice_replay(a, size=None, replace=True, p=None):
+            j = calls['gs']
+            calls['gs'] += 1
+            assert len(a) == int(z['gs/cand%d' % j][0]) and not replace
+            draw = z['gs/draw%d' % j].astype(np.int64)
+            assert tuple(np.atleast_1d(size)) == (len(draw),) and np.isin(draw, a).all()
+            return draw
+        monkeypatch.setattr(np.random, 'choice', choice_replay)
+
+        n = 2
+        boxes, labels = T.gt(T.MASK_SEED, n)
+        losses = model(T.image(T.MASK_SEED, n).to(DEV), T.img_meta(n), return_loss=True,
+                       gt_bboxes=[torch.from_numpy(b).to(DEV) for b in boxes],
+                       gt_labels=[torch.from_numpy(l).to(DEV) for l in labels],
+                       gt_masks=[torch.from_numpy(T.gt_masks(b)).to(DEV) for b in boxes],
+                       samplers=dict(rpn=rpn_hook, rcnn=rcnn_hook, proposals=proposals_hook))
+        assert calls['rpn'] == 2 and calls['rcnn'] == 2, calls
+        keys = [k[len('loss/'):] for k in z.files if k.startswith('loss/') and not k.endswith('total')]
+        assert set(keys) == set(losses.keys()), (sorted(keys), sorted(losses.keys()))
+        bad = []
+        for k in keys:
+            v = losses[k]
+            got = np.array([float(t.detach().sum()) for t in (v if isinstance(v, list) else [v])], np.float32)
+            exp = z['loss/' + k]
+            tol = (2e-4 if k == 'loss_mask' else 1e-4) * max(float(np.abs(exp).max()), 1e-3) + 1e-7
+            if np.abs(got - exp).max() > tol:
+                bad.append((k, got.tolist(), exp.tolist()))
+        assert not bad, bad
+        loss, _ = train.parse_losses(losses)
+        assert abs(float(loss.detach()) - float(z['loss/total'][0])) < 1e-4 * float(z['loss/total'][0])
+        train.backward_unit(loss)
+        params = dict(model.named_parameters())
+        bad = []
+        for name, idx in T.GRADS_MASK:
+            g = params[name].grad
+            assert g is not None, name
+            a, b = g[idx].cpu().numpy(), z['grad/' + name]
+            rel = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+            l2 = float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
+            print('%s: max |diff| / max |g| = %.2e, relative L2 = %.2e' % (name, rel, l2))
+            if name.startswith(('bbox_head.fc_cls', 'bbox_head.fc_reg')):
+                if rel > 1e-5:
+                    bad.append((name, rel))
+            elif not grad_close(a, b, l2tol=1e-3):         # + relative L2 <= 1e-3 per tensor (VERDICT r3 #3c)
+                bad.append((name, rel, l2))
+        assert not bad, bad
+    finally:
+        BF.set_conv_math(prev)
+        del model
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('math', ['bf16x6', 'bf16'])
+def test_htc_x101_fullsize_iteration_vs_executed_reference(math):
+    """The HTC row of BASELINE cfg[4] AT ITS OWN TRUNK AND SIZE: ``HybridTaskCascade.forward_train``
+    (htc.py:197-308: three box stages with semantic fusion, interleaved mask branches with information flow, the
+    semantic head) on ResNeXt-101-64x4d at 1 x 3x800x1344 with instance bitmaps and a semantic map, against the
+    executed reference (tests/golden/make_golden_mask_htc_fullsize.py; RPN calibrated to non-saturating scores,
+    every candidate taken: no draw).  ``bf16x6``: >= 97 % of the reference's proposals reproduced by the HIP RPN,
+    then all 27 loss terms to 2e-4 and the box / mask / semantic head gradients; ``bf16`` (what BASELINE names for
+    this config): the 3e-2 budget per term of the cascade test.  The launch census asserts the kernels the HTC
+    bench row's time comes from ran (halo kernel; the LDS-resident grouped 3x3 kernel in bf16x6, the bf16-STORAGE
+    kernels of the frozen trunk in bf16)."""
+    from balancedgroupsoftmax_amd import functional as BF
+    from balancedgroupsoftmax_amd import train
+    from tests.golden import make_golden_mask_htc_fullsize as T
+    z = np.load(T.OUT_HTC)
+    assert int(z['saturated_scores0'][0]) == 0
+    prev = BF.set_conv_math(math)
+    prev_storage = BF.set_bf16_storage(math == 'bf16')       # bf16: the frozen trunk on bf16 tensors, as benched
+    model = None
+    try:
+        tmp = tempfile.mkdtemp(prefix='bgs_htcfull_')
+        model_cfg, train_cfg = T.htc_configs(tmp)
+        model = bgs.build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
+                                   test_cfg=to_config_dict(G.TEST_CFG))
+        with torch.no_grad():
+            det_oracle.fill_detector(model.state_dict(), T.HTC_SEED)
+        T.apply_rpn_scale(model.state_dict(), float(z['rpn_cls_scale'][0]))
+        model.to(DEV)
+        for nme, p_ in model.named_parameters():
+            p_.requires_grad = nme.startswith(('bbox_head.', 'mask_head.', 'semantic_head.'))
+        model.train()
+        boxes, labels = T.gt(T.HTC_SEED, 1)
+        BF.launch_census(reset=True)
+
+        def proposals_hook(own):
+            out = []
+            for i, (p, v) in enumerate(own):
+                ref = torch.from_numpy(z['proposals%d' % i]).to(DEV)
+                frac = match_boxes(p[v].cpu().numpy(), z['proposals%d' % i], tol_px=0.05, tol_score=2e-4)
+                print('image %d: %.4f of the reference proposals reproduced by the HIP RPN' % (i, frac))
+                if math == 'bf16x6':
+                    assert frac >= 0.97, frac
+                nn_ = min(ref.shape[0], p.shape[0])
+                pad = torch.zeros_like(p)
+                pad[:nn_] = ref[:nn_]
+                ok = torch.zeros(p.shape[0], dtype=torch.bool, device=DEV)
+                ok[:nn_] = True
+                out.append((pad.contiguous(), ok))
+            return out
+
+        losses = model(T.image(T.HTC_SEED, 1).to(DEV), T.img_meta(1), return_loss=True,
+                       gt_bboxes=[torch.from_numpy(b).to(DEV) for b in boxes],
+                       gt_labels=[torch.from_numpy(l).to(DEV) for l in labels],
+                       gt_masks=[torch.from_numpy(T.gt_masks(b)).to(DEV) for b in boxes],
+                       gt_semantic_seg=torch.from_numpy(T.gt_semantic_seg(T.HTC_SEED)).to(DEV),
+                       samplers=dict(proposals=proposals_hook))
+        census = BF.launch_census()
+        assert census['halo_bfx4'] >= 5, census
+        if math == 'bf16':       # 33 grouped convs + the 1x1 convs of the frozen trunk ran on bf16 tensors
+            assert census['grouped_bf16s'] >= 30 and census['bf16s'] >= 70 and census['grouped_lds'] == 0, census
+        else:
+            assert census['grouped_lds'] >= 30 and census['bf16s'] == 0, census
+        keys = [k[len('loss/'):] for k in z.files if k.startswith('loss/') and not k.endswith('total')]
+        assert set(keys) == set(losses.keys()), (sorted(keys), sorted(losses.keys()))
+        total_exp = float(z['loss/total'][0])
+        bad, worst = [], 0.0
+        for k in keys:
+            v = losses[k]
+            got = np.array([float(t.detach().sum()) for t in (v if isinstance(v, list) else [v])], np.float32)
+            exp = z['loss/' + k]
+            d = float(np.abs(got - exp).max())
+            worst = max(worst, d)
+            tol = 2e-4 * max(float(np.abs(exp).max()), 1.0) if math == 'bf16x6' else 3e-2 * total_exp
+            if d > tol:
+                bad.append((k, got.tolist(), exp.tolist()))
+        loss, _ = train.parse_losses(losses)
+        print('%s HTC X101 @800x1344: total %.5f vs executed reference %.5f, worst term diff %.2e'
+              % (math, float(loss.detach()), total_exp, worst))
+        assert not bad, bad
+        assert abs(float(loss.detach()) - total_exp) < (2e-4 if math == 'bf16x6' else 2e-2) * total_exp
+        if math == 'bf16x6':
+            loss.backward()
+            params = dict(model.named_parameters())
+            gbad = []
+            for name, idx in T.GRADS_HTC:
+                g = params[name].grad
+                assert g is not None, name
+                a, b = g[idx].cpu().numpy(), z['grad/' + name]
+                rel = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-20))
+                print('%s: max |diff| / max |g| = %.2e' % (name, rel))
+                if rel > (1e-4 if 'fc_cls' in name or 'fc_reg' in name else 2e-3):
+                    gbad.append((name, rel))
+            assert not gbad, gbad
+    finally:
+        BF.set_conv_math(prev)
+        BF.set_bf16_storage(prev_storage)
         del model
         torch.cuda.empty_cache()
 
