@@ -124,6 +124,53 @@ def test_mask_target_kernel_bit_exact_vs_oracle():
     assert set(np.unique(got)) <= {0.0, 1.0} and 0.05 < got.mean() < 0.95
 
 
+def test_mask_target_kernel_is_bounded_by_an_independent_float_bilinear_resize():
+    """A second, INDEPENDENT implementation bounds ``bgs_mask_target`` (and the fixed-point restatement of OpenCV it
+    is bit-exact with, oracle/mask_oracle.py — "parity unpinned": cv2 itself is not installed): the same crops
+    resized by torch's float ``F.interpolate(bilinear, align_corners=False)`` — the half-pixel mapping of
+    cv2.INTER_LINEAR, mmdet/core/mask/mask_target.py:31.  OpenCV's 8-bit path computes
+    ``(floor(4 b0 r0) + floor(4 b1 r1) + 2) >> 2`` on a 0/1 bitmap (r = the horizontally interpolated rows, b their
+    weights: resize.cpp's FixedPtCast<int, uchar, 22> after two truncating shifts), so with v the exact bilinear
+    value it yields 0 whenever v < 1/2, 1 whenever v >= 3/4, and either in between — NOT round(v).  The float
+    resize must agree outside that band (a margin of 4 / 2048 for the 11-bit coefficients), on ellipses and on
+    noise; the band itself is reported."""
+    import torch.nn.functional as F
+    rs = np.random.RandomState(12)
+    H, W, P = 160, 224, 96
+    boxes = np.array([[10, 12, 150, 130], [40, 5, 200, 150], [0, 0, 60, 60], [100, 40, 220, 158]], np.float32)
+    masks = mask_oracle.make_gt_masks(4, H, W, boxes, 3)
+    masks[2, :60, :60] = (rs.rand(60, 60) > 0.5)               # noise: the worst case for an interpolation
+    gt = rs.randint(0, 4, P).astype(np.int32)
+    ctr = rs.uniform(0, 1, (P, 2)) * [W, H]
+    size = np.exp(rs.uniform(np.log(3), np.log(200), (P, 2)))
+    b = np.concatenate([ctr - size / 2, ctr + size / 2], 1)
+    b[:, [0, 2]] = np.clip(b[:, [0, 2]], 0, W - 1)
+    b[:, [1, 3]] = np.clip(b[:, [1, 3]], 0, H - 1)
+    rois = np.concatenate([np.zeros((P, 1)), b], 1).astype(np.float32)
+    got = BF.mask_target([torch.from_numpy(masks).to(DEV)], torch.from_numpy(rois).to(DEV),
+                         torch.from_numpy(gt).to(DEV), torch.ones(P, dtype=torch.bool, device=DEV), 28).cpu().numpy()
+    eps = 4.0 / 2048
+    band = total = ones_in_band = 0
+    for i in range(P):
+        x1, y1, x2, y2 = rois[i, 1:].astype(np.int32)
+        w, h = max(x2 - x1 + 1, 1), max(y2 - y1 + 1, 1)
+        crop = masks[gt[i]][y1:y1 + h, x1:x1 + w]
+        if crop.shape == (28, 28):
+            assert np.array_equal(got[i], crop.astype(np.float32))          # same size: cv2 copies
+            continue
+        ref = F.interpolate(torch.from_numpy(crop.astype(np.float64))[None, None], size=(28, 28), mode='bilinear',
+                            align_corners=False)[0, 0].numpy()
+        assert (got[i][ref < 0.5 - eps] == 0.0).all(), i
+        assert (got[i][ref >= 0.75 + eps] == 1.0).all(), i
+        amb = (ref >= 0.5 - eps) & (ref < 0.75 + eps)
+        band += int(amb.sum())
+        ones_in_band += int(got[i][amb].sum())
+        total += ref.size
+    print('float-bilinear bound: every pixel outside [1/2, 3/4) agrees; %d of %d pixels lie in the band (%d of them 1)'
+          % (band, total, ones_in_band))
+    assert band < 0.2 * total and 0 < ones_in_band < band
+
+
 def _mask_rcnn(tmp_path):
     paths = gs_tables.save_group_tables(str(tmp_path), *gs_tables.synthetic_group_tables())
     from tests.test_gpu_detector import _detector_cfg
