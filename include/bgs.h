@@ -37,13 +37,7 @@ typedef void* bgs_stream_t;     /* hipStream_t */
 int bgs_version(void);
 const char* bgs_error_string(int code);
 
-/* Device self-test of the wave64 reduction primitive: in [64] float, out [4] float =
- * {max, sum} by the build's primitive (DPP) followed by {max, sum} by a ds_bpermute butterfly. */
-int bgs_selftest_wave_reduce(const float* in, float* out, bgs_stream_t stream);
 
-/* Calibration: `blocks` workgroups x 4 waves x (4 * iters) v_mfma_f32_32x32x2_f32 with register
- * operands (4096 flop each) — the fp32 matrix rate the chip sustains under its power limit. */
-int bgs_selftest_mfma_peak(int blocks, int iters, float* out, bgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Group-softmax label remap + "others" sampling.
@@ -150,21 +144,6 @@ int bgs_gs_head_step(const float* logits, const int64_t* labels, const int64_t* 
  * row (NULL there: every workgroup derives it from label2binlabel, slower). */
 int bgs_gs_class_bin_mask(const int64_t* label2binlabel, int C, int B, uint16_t* out,
                           bgs_stream_t stream);
-/* Profiling hook of the fused head kernel: buf != NULL (device, [2048][8] uint64) makes every later
- * launch record 8 shader-clock marks per workgroup (start, loads landed, barrier 1, flags done,
- * barrier 2, bins done, barrier 3, end); NULL (default) switches it off.  tools/gs_phase_times.py. */
-void bgs_gs_head_debug_timestamps(unsigned long long* buf);
-/* Tuning / test hook: rows per workgroup of the fused head kernel (0 = default; process-wide). */
-void bgs_gs_head_tuning(int rows_per_workgroup);
-/* A/B hook: the variant of the fused head kernel (process-wide; env BGS_GS_HEAD_VARIANT).  0 = one row per
- * workgroup, per-row flag words + packed per-thread counters + a scan below the row; 1 = one row per workgroup, one
- * 64-bit ballot word per (64 rows, bin) — counts and the row's candidate position from one popcount pass per bin;
- * 2 / 3 = variant 1 with 2 / 4 rows per workgroup in parallel behind ONE shared prologue (N <= 2048; beyond that
- * variant 1 runs); 4 / 5 = variants 2 / 3 with every bin's gradient stored to the gradient row by the wave that owns
- * the bin (no third barrier, no LDS round trip on the way out).  Bitwise the same results.  variant < 0 (the default): automatic — 4 for N < 1024, 5 for N = 1024,
- * 3 for 1024 < N <= 2048, 1 beyond.  bgs_gs_head_variant_used(N): the variant a launch with N rows takes. */
-void bgs_gs_head_variant(int variant);
-int bgs_gs_head_variant_used(int N);
 /* Backward of bgs_gs_head_step: grad_terms [B+1] (device; upstream gradient of {bins, box}, NULL = 0)
  * and grad_total [1] (of total_out, NULL = 0): dlogits[:, bin b] *= grad_terms[b] + grad_total,
  * dbbox_pred *= grad_terms[B] + grad_total, in place, one launch, early-out on the device when
@@ -279,13 +258,12 @@ int bgs_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, float*
  * dy and x, fp32 accumulate; error vs fp64 not above the fp32-MFMA kernel's), planes = 1: operands
  * rounded to bf16 (the bf16 mode of cfg[4]).  Same layout, split-M reduction in a fixed order and
  * workspace contract (>= bgs_conv2d_wgrad_bfx_workspace_bytes); layers with Cout < 96 or K < 96 run
- * the fp32-MFMA kernel (exact).  bgs_conv2d_wgrad_bfx_enable(0) routes every call there (A/B). */
+ * the fp32-MFMA kernel (exact).  (A/B switch: bgs_conv2d_wgrad_bfx_enable in include/bgs_tuning.h.) */
 size_t bgs_conv2d_wgrad_bfx_workspace_bytes(int N, int H, int W, int Cin, int Cout, int R, int S,
                                             int stride, int pad);
 int bgs_conv2d_wgrad_nhwc_f32_bfx(const float* x, const float* dy, float* dw, float* db, int N, int H,
                                   int W, int Cin, int Cout, int R, int S, int stride, int pad,
                                   int accumulate, int planes, void* workspace, bgs_stream_t stream);
-void bgs_conv2d_wgrad_bfx_enable(int on);
 
 /* Eval-mode BatchNorm folded into the filter, and the backward of the fold (csrc/bn_fold.hip;
  * resnet.py:535-542 `norm_eval=True`): w [Cout,Cin,R,S] (the reference's parameter layout), optional
@@ -302,11 +280,6 @@ int bgs_fold_conv_bn_bwd(const float* dwf, const float* dbf, const float* w, con
                          int Cin, int R, int S, int cin_padded, float* dw, float* dconv_bias,
                          float* dgamma, float* dbeta, bgs_stream_t stream);
 
-/* Tuning / test hooks of the fp32 MFMA conv kernel (process-wide): tile 0 = auto | 11 | 21 | 22
- * (MB*10+NB blocks of 64), bk 0 = auto | 16 | 32, splitk 0 = auto | 1..16, noswizzle 1 = plain tile
- * order; bgs_conv_last_launch reports the instantiation the last launch used. */
-void bgs_conv_tuning(int tile, int bk, int splitk, int noswizzle);
-int bgs_conv_last_launch(int* tile, int* bk, int* up, int* splits);
 
 /* The 3x3 / stride 1 / pad 1 case of bgs_conv2d_nhwc_f32 (same call sites: fpn.py:131-134 output
  * convs, rpn_head.py:31 rpn_conv, resnet.py:244 conv2) with the workgroup's 8 x 16 output pixels
@@ -334,7 +307,7 @@ int bgs_conv3x3_halo_nhwc_f32(const float* x, const float* w, const float* bias,
  *   the matrix-pipe work (BASELINE cfg[4] "bf16"); the split buffer is the same (plane 0 = bf16(w)).
  * workspace: bgs_conv_bfx_workspace_bytes(M, Cout, K) / bgs_conv3x3_halo_bfx_workspace_bytes(...)
  * bytes of split-K scratch (0 / NULL is always legal).
- * bgs_conv_bfx_tuning / bgs_conv3x3_halo_bfx_tuning: process-wide tuning and test hooks
+ * Tuning / A/B hooks and the *_last_launch queries of these kernels: include/bgs_tuning.h
  * (halo variant: 0 = default = 4: filter slices by LDS-DMA; 2: register-staged slices; 1: first
  * version; bgs_conv3x3_halo_bfx_last_launch reports the variant in bits 8.. of *nb).
  * (tile 0 = auto | 11 | 12 | 21 | 22 as MB*10+NB blocks of 64; splitk -1 = auto | 1..16);
@@ -360,10 +333,6 @@ int bgs_conv2d_dgrad_nhwc_f32_bfx_ws(const float* dy, const void* wt_split, cons
                                      int Cout, int R, int S, int stride, int pad,
                                      int residual_mode, int planes, void* workspace,
                                      size_t workspace_bytes, bgs_stream_t stream);
-/* Tuning / test hook: stride-2 data gradients with the GEMM rows grouped by output-pixel parity (only the
- * filter taps that meet non-zeros of the zero-upsampled dy are multiplied: 1, 2 or 4 of 9; default 1) or in the
- * plain zero-upsampled form (0).  Bit-identical results.  Process-wide. */
-void bgs_conv_dgrad_parity_enable(int on);
 size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit, const float* bias, float* y,
                                   int N, int H, int W, int Cin, int Cout, int relu, int planes,
@@ -375,36 +344,6 @@ int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wsplit, const f
                                      const float* mask, float* y, int N, int H, int W, int Cin,
                                      int Cout, int relu, int planes, void* workspace,
                                      size_t workspace_bytes, bgs_stream_t stream);
-/* Launch census (tests / bench evidence): how often a kernel family was launched by this process
- * since the last reset — lets a test ASSERT that the instantiation it means to pin really ran
- * (e.g. the 8-wave bf16 ring and the LDS-resident grouped conv inside a whole X101 iteration).
- * Returns the count of `family` (a BGS_CENSUS_* id; -1 for an unknown id); reset != 0 zeroes every
- * counter after reading.  Process-wide, not thread-safe (like the tuning hooks). */
-#define BGS_CENSUS_BF16_RING8 0      /* conv_igemm_bf16_ring8_kernel                      */
-#define BGS_CENSUS_GROUPED_LDS 1     /* grouped_conv3x3_lds_kernel                        */
-#define BGS_CENSUS_HALO_BFX4 2       /* conv3x3_halo_bfx4_kernel                          */
-#define BGS_CENSUS_DMA_RING64 3      /* conv_igemm_bfx_dma_kernel (64 x 64 operand ring)  */
-#define BGS_CENSUS_GS_HEAD_FUSED 4   /* gs_head_fused_kernel                              */
-#define BGS_CENSUS_CONV1X1_BRES 5    /* conv1x1_bres_kernel (filter-resident 1x1)         */
-#define BGS_CENSUS_WGRAD_BFX 6       /* conv_wgrad_bfx_kernel                             */
-#define BGS_CENSUS_ROI_BWD_GATHER 7  /* roi_align backward without global atomics         */
-#define BGS_CENSUS_BF16S 8           /* conv_bf16s_kernel (bf16 activations in HBM)       */
-#define BGS_CENSUS_GROUPED_BF16S 9   /* grouped 3x3 conv with bf16 activations in HBM     */
-#define BGS_CENSUS_BFX_WIDE 10       /* conv1x1_bfx_wide_kernel (128 x 128, M-stacked waves) */
-#define BGS_CENSUS_GS_SCALE_GRAD 11   /* gs_head_scale_grad_kernel (a non-unit upstream gradient) */
-#define BGS_CENSUS_FAMILIES 16
-int bgs_launch_census(int family, int reset);
-void bgs_conv_bfx_tuning(int tile, int splitk);
-int bgs_conv_bfx_last_launch(int* tile, int* splits);
-void bgs_conv3x3_halo_bfx_tuning(int splits, int variant);
-/* Filter-resident 1x1 kernel (csrc/conv1x1_bres.hip: K = Cin in {64,128,256}, Cout % 256 == 0,
- * M >= 4096, bf16x6 mode; bit-identical to the 64 x 64 operand ring): enable(1) (default) = on the
- * layers where it was measured faster (K = Cout = 256, M >= 65536: fpn.lat0), enable(2) = on every
- * layer it can run (tests, A/B), enable(0) = never.  last_launch: 1 when the last call that could
- * have taken it did. */
-void bgs_conv1x1_bres_enable(int on);
-int bgs_conv1x1_bres_last_launch(void);
-int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits);
 
 /* Grouped 3x3 convolution (pad 1, stride 1 or 2) + bias + ReLU, NHWC: conv2 of the ResNeXt
  * bottleneck (mmdet/models/backbones/resnext.py:47-57, cfg 5 = X101-64x4d).  x [N,H,W,C],
@@ -441,9 +380,6 @@ int bgs_grouped_conv3x3_nhwc_bf16s(const void* x, const float* w, const float* b
                                    int W, int C, int groups, int stride, int relu, bgs_stream_t stream);
 int bgs_maxpool3x3s2_nhwc_f32_to_bf16(const float* x, void* y, int N, int H, int W, int C,
                                       bgs_stream_t stream);
-/* Tuning / test hook of bgs_conv2d_nhwc_bf16s: 0 = operands by LDS-DMA (default), 1 = operands staged
- * through registers (bit-identical results).  Process-wide; not for concurrent use. */
-void bgs_conv_bf16s_tuning(int variant);
 
 /* Backward of bgs_grouped_conv3x3_nhwc_f32 (`selectp = 0` on the ResNeXt configs; the reference
  * gets it from cuDNN through autograd of nn.Conv2d(groups=...), resnext.py:47-57).

@@ -15,6 +15,78 @@
 extern "C" {
 #endif
 
+/* ---- self-tests ---------------------------------------------------------------------------------
+ * bgs_selftest_wave_reduce: in [64] float, out [4] float = {max, sum} by the build's wave64 reduction
+ *   primitive (DPP) followed by {max, sum} by a ds_bpermute butterfly.
+ * bgs_selftest_mfma_peak: `blocks` workgroups x 4 waves x (4 * iters) v_mfma_f32_32x32x2_f32 with register
+ *   operands (4096 flop each) — the fp32 matrix rate the chip sustains under its power limit. */
+int bgs_selftest_wave_reduce(const float* in, float* out, bgs_stream_t stream);
+int bgs_selftest_mfma_peak(int blocks, int iters, float* out, bgs_stream_t stream);
+
+/* ---- launch census ------------------------------------------------------------------------------
+ * How often a kernel family was launched by this process since the last reset — lets a test ASSERT that the
+ * instantiation it means to pin really ran (e.g. the 8-wave bf16 ring and the LDS-resident grouped conv inside a
+ * whole X101 iteration).  Returns the count of `family` (-1 for an unknown id); reset != 0 zeroes every counter
+ * after reading. */
+#define BGS_CENSUS_BF16_RING8 0      /* conv_igemm_bf16_ring8_kernel                      */
+#define BGS_CENSUS_GROUPED_LDS 1     /* grouped_conv3x3_lds_kernel                        */
+#define BGS_CENSUS_HALO_BFX4 2       /* conv3x3_halo_bfx4_kernel                          */
+#define BGS_CENSUS_DMA_RING64 3      /* conv_igemm_bfx_dma_kernel (64 x 64 operand ring)  */
+#define BGS_CENSUS_GS_HEAD_FUSED 4   /* gs_head_fused_kernel                              */
+#define BGS_CENSUS_CONV1X1_BRES 5    /* conv1x1_bres_kernel (filter-resident 1x1)         */
+#define BGS_CENSUS_WGRAD_BFX 6       /* conv_wgrad_bfx_kernel                             */
+#define BGS_CENSUS_ROI_BWD_GATHER 7  /* roi_align backward without global atomics         */
+#define BGS_CENSUS_BF16S 8           /* conv_bf16s_kernel (bf16 activations in HBM)       */
+#define BGS_CENSUS_GROUPED_BF16S 9   /* grouped 3x3 conv with bf16 activations in HBM     */
+#define BGS_CENSUS_BFX_WIDE 10       /* conv1x1_bfx_wide_kernel (128 x 128, M-stacked waves) */
+#define BGS_CENSUS_GS_SCALE_GRAD 11   /* gs_head_scale_grad_kernel (a non-unit upstream gradient) */
+#define BGS_CENSUS_FAMILIES 16
+int bgs_launch_census(int family, int reset);
+
+/* ---- fused GroupSoftmax head (csrc/gs_loss.hip) ---------------------------------------------------
+ * bgs_gs_head_debug_timestamps: buf != NULL (device, [2048][8] uint64) makes every later launch record 8
+ *   shader-clock marks per workgroup (tools/gs_phase_times.py); NULL (default) switches it off.
+ * bgs_gs_head_tuning: rows per workgroup (0 = default).
+ * bgs_gs_head_variant: 0 = one row per workgroup with per-row flag words | 1 = one row per workgroup with ballot
+ *   bit planes | 2 / 3 = variant 1 with 2 / 4 rows per workgroup behind one shared prologue (N <= 2048) | 4 / 5 =
+ *   2 / 3 with the gradient stored by the wave that owns the bin; < 0 (default): automatic — 4 for N < 1024, 5
+ *   for N = 1024, 3 up to 2048, 1 beyond.  Bitwise the same results.  bgs_gs_head_variant_used(N): the variant a
+ *   launch with N rows takes. */
+void bgs_gs_head_debug_timestamps(unsigned long long* buf);
+void bgs_gs_head_tuning(int rows_per_workgroup);
+void bgs_gs_head_variant(int variant);
+int bgs_gs_head_variant_used(int N);
+
+/* ---- convolution kernels --------------------------------------------------------------------------
+ * bgs_conv_tuning (fp32 MFMA kernel): tile 0 = auto | 11 | 21 | 22 (MB*10+NB blocks of 64), bk 0 = auto | 16 |
+ *   32, splitk 0 = auto | 1..16, noswizzle 1 = plain tile order; bgs_conv_last_launch reports the instantiation
+ *   the last launch used.
+ * bgs_conv_bfx_tuning (bf16x6 / bf16 modes, csrc/conv_bfx.hip): tile 0 = auto | 11 | 12 | 21 | 22 (+ 0x100: the
+ *   register-staged 64 x 64 kernel instead of the LDS-DMA ring; + 0x400 / 0x800: force the 3- / 4-stage ring),
+ *   splitk -1 = auto | 1..16; bgs_conv_bfx_last_launch: *tile carries the tile | 0x200 (DMA ring) | 0x400
+ *   (3 stages) | 0x1000 (filter-resident 1x1) | 0x2000 (parity-class data gradient) | 0x4000 (wide 1x1).
+ * bgs_conv3x3_halo_bfx_tuning: splits -1 = auto | n; variant 0 = default = 4 (filter slices by LDS-DMA) | 2
+ *   (register-staged slices) | 1 (first version) | 5 (4 + A-fragment prefetch); bgs_conv3x3_halo_bfx_last_launch
+ *   reports the variant in bits 8.. of *nb.
+ * bgs_conv1x1_bres_enable (filter-resident 1x1, csrc/conv1x1_bres.hip): 1 (default) = where measured faster,
+ *   2 = every layer it can run, 0 = never; bgs_conv1x1_bres_last_launch: 1 when the last call that could have
+ *   taken it did.
+ * bgs_conv_dgrad_parity_enable: stride-2 data gradients with the GEMM rows grouped by output-pixel parity (1,
+ *   default) or in the zero-upsampled form (0).  Bit-identical.
+ * bgs_conv2d_wgrad_bfx_enable(0): every weight gradient on the fp32-MFMA kernel (A/B).
+ * bgs_conv_bf16s_tuning (bf16-storage kernels): 0 = operands by LDS-DMA (default), 1 = through registers. */
+void bgs_conv_tuning(int tile, int bk, int splitk, int noswizzle);
+int bgs_conv_last_launch(int* tile, int* bk, int* up, int* splits);
+void bgs_conv_bfx_tuning(int tile, int splitk);
+int bgs_conv_bfx_last_launch(int* tile, int* splits);
+void bgs_conv3x3_halo_bfx_tuning(int splits, int variant);
+int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits);
+void bgs_conv1x1_bres_enable(int on);
+int bgs_conv1x1_bres_last_launch(void);
+void bgs_conv_dgrad_parity_enable(int on);
+void bgs_conv2d_wgrad_bfx_enable(int on);
+void bgs_conv_bf16s_tuning(int variant);
+
 /* Wide-tile 1x1 kernel of the bf16x6 mode (csrc/conv_bfx_wide.hip: 128 x 128 tile, four M-stacked
  * waves, 24 MFMAs per wave and barrier; replaces the 64 x 64 operand ring on the wide-N 1x1 layers
  * of mmdet/models/backbones/resnet.py:220-266 / necks/fpn.py:101-141; bit-identical to it when K is

@@ -157,7 +157,7 @@ def test_htc_mask_head_chain_vs_executed_reference_golden():
     # (which pre-activations flip depends on the summation order of the kernel that ran: measured
     # 0.91 of the entries within tol under the fp32 MFMA kernels, 0.78 under bf16x6 — while dx and
     # the deepest gradient below come out CLOSER under bf16x6: 0.88 / 0.16 vs 0.84 / 0.11,
-    # tools/debug/htc_chain_metrics.py)
+    # a one-off script of round 2, since removed)
     assert close(h1.conv_res.conv.weight.grad[::2, ::2].cpu().numpy(), z['msk/dres_w'], frac=0.7)
     # the deepest weight gradient sums every position's (flip-perturbed) contribution: uniform
     # noise instead of a few outliers (measured: worst 0.58 % of the largest entry, rel-L2 4.8e-3)
