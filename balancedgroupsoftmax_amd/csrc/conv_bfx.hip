@@ -829,10 +829,11 @@ struct HaloBfxArgs {
 // (64 NB) channel tile leaves in two halves of 64 pixels (the accumulators of the waves wm = 0, then
 // wm = 1), every thread storing four consecutive channels of a pixel with one 16-byte access.
 // `scratch`: 64 x (64 NB + 4) floats of LDS no wave reads any more.
-template <int NB>
+template <int NB, int GTH = 8, int GTW = 16>
 __device__ __forceinline__ void halo_store_tile_lds(const ConvArgs& p, const f32x16 (&acc)[2][NB], int n,
                                                     int ty, int tx, int n0, int wm, int wn, int lane,
                                                     float* scratch) {
+  constexpr int TH = GTH, TW = GTW;                       // pixel tile (shadows the 8 x 16 default)
   constexpr int BN = 64 * NB, LD = BN + 4, TPR = BN / 4, RPP = kThreads / TPR;
   const int tid = threadIdx.x;
   const int c4 = (tid % TPR) * 4, r0 = tid / TPR;
@@ -859,7 +860,8 @@ __device__ __forceinline__ void halo_store_tile_lds(const ConvArgs& p, const f32
       for (int ps = 0; ps < 64 / RPP; ++ps) {
         const int i = r0 + ps * RPP;
         const int m = h * 64 + i;
-        const int ho = ty * TH + (m >> 4), wo = tx * TW + (m & 15);
+        if (TH * TW < 128 && m >= TH * TW) continue;              // padding rows of a tile of fewer than 128 pixels
+        const int ho = ty * TH + m / TW, wo = tx * TW + m % TW;
         if (ho >= p.H || wo >= p.W) continue;
         f32x4 v = *reinterpret_cast<const f32x4*>(scratch + i * LD + c4);
         const size_t off = (((size_t)n * p.H + ho) * p.W + wo) * p.Cout + j;
@@ -1301,9 +1303,16 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxA
 // PF (variant 5): the A fragments of tap t + 1 are read from the patch DURING tap t's MFMAs — the
 // patch does not change inside a channel chunk, so those reads need not sit behind the step's
 // barrier; after the barrier only the six filter fragments remain between a wave and its MFMAs.
-template <int NB, int NS = 3, bool PF = false>
+// GTH x GTW: the pixel tile (<= 128 pixels; the MFMA rows beyond GTH * GTW are padding: they read patch pixel
+// (0, 0) and are never stored).  8 x 16 everywhere but on the small maps, where the tile that wastes the fewest
+// rows is chosen per layer (halo_bfx_geom: 50 x 84 -> 10 x 12: 35 tiles per image instead of 42; 25 x 42 -> 5 x 21:
+// 10 instead of 12).
+template <int NB, int NS = 3, bool PF = false, int GTH = 8, int GTW = 16>
 __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxArgs q) {
   const ConvArgs& p = q.c;
+  constexpr int TH = GTH, TW = GTW, PH = TH + 2, PW = TW + 2, PROWS = PH * PW;      // (shadow the 8 x 16 default)
+  constexpr int AQ = PROWS * 4, AQT = (AQ + kThreads - 1) / kThreads;
+  static_assert(TH * TW <= 128 && PROWS <= 180 && AQT <= 3, "patch no larger than the 8 x 16 tile's");
   constexpr int BN = 64 * NB;
   constexpr int B_PLANE = BN * 32, B_BUF = NS * B_PLANE;
   constexpr int SCR = 2 * B_BUF;                         // 1 KB scratch: target of dummy pieces
@@ -1394,8 +1403,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
   int a_frag[2];
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
-    const int m = wm * 64 + a * 32 + frow;
-    a_frag[a] = A_OFF + ((m >> 4) * PW + (m & 15)) * HLDR + fk * 16;      // patch row of tap (0, 0)
+    int m = wm * 64 + a * 32 + frow;
+    if (TH * TW < 128 && m >= TH * TW) m = 0;                             // padding row: any valid patch pixel
+    a_frag[a] = A_OFF + ((m / TW) * PW + (m % TW)) * HLDR + fk * 16;      // patch row of tap (0, 0)
   }
   const int brow = wn * 32 * NB + frow;                           // + 32 b: same 8-row-group parity
   const int b_frag = brow * 32 + ((fk ^ ((brow >> 3) & 1)) << 4);
@@ -1470,7 +1480,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
 
   // (the loop's last barrier is behind every wave's last fragment read)
   if (sizeof(lds) >= (size_t)64 * (BN + 4) * 4 && conv_epilogue_vec_ok(p)) {
-    halo_store_tile_lds<NB>(p, acc, n, ty, tx, n0, wm, wn, lane, reinterpret_cast<float*>(lds));
+    halo_store_tile_lds<NB, GTH, GTW>(p, acc, n, ty, tx, n0, wm, wn, lane, reinterpret_cast<float*>(lds));
     return;
   }
   // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -1481,7 +1491,8 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       const int m = wm * 64 + a * 32 + i;
-      const int ho = ty * TH + (m >> 4), wo = tx * TW + (m & 15);
+      if (TH * TW < 128 && m >= TH * TW) continue;
+      const int ho = ty * TH + m / TW, wo = tx * TW + m % TW;
       if (ho >= p.H || wo >= p.W) continue;
       const size_t row = (((size_t)n * p.H + ho) * p.W + wo) * p.Cout;
 #pragma unroll
@@ -1504,6 +1515,43 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
 
 int g_halo_last_nb = 0, g_halo_last_splits = 0, g_halo_last_variant = 0;
 int g_halo_force_splits = -1, g_halo_variant = 4, g_halo_pf = 0;
+
+// Pixel-tile geometry of the v4 kernel for an H x W map: the instantiated tile with the fewest tiles per image
+// (every tile costs the same 128 MFMA rows), 8 x 16 unless another one saves at least 5 % — mode 3; modes 0 / 1 / 2
+// = 8 x 16 / 10 x 12 / 5 x 21 everywhere.
+int g_halo_geom = -1;      // -1 default (8 x 16; BGS_HALO_GEOM) | 0 | 1 | 2 | 3 = fewest tiles per image (bgs_conv3x3_halo_bfx_tuning)
+void halo_geom_dims(int g, int& th, int& tw) {
+  th = g == 1 ? 10 : (g == 2 ? 5 : 8);
+  tw = g == 1 ? 12 : (g == 2 ? 21 : 16);
+}
+int halo_bfx_geom(int H, int W) {
+  // Default: 8 x 16 everywhere.  The small-map launches of cfg[1] are single-round (560-672 workgroups on 768 slots
+  // after the channel-chunk split): their time is one workgroup's duration whatever the tile count, and the step did
+  // not move with the tighter tiles (6.59-6.60 ms with either, interleaved runs on one box, round 4) — the tighter
+  // tiles stay available (BGS_HALO_GEOM=auto | 1 | 2, the tuning hook) for grids that run several rounds.
+  static const int env = [] {
+    const char* e = getenv("BGS_HALO_GEOM");
+    if (!e) return 0;
+    if (e[0] == 'a') return 3;
+    const int v = atoi(e);
+    return v >= 0 && v <= 3 ? v : 0;
+  }();
+  const int mode = (g_halo_geom >= 0 && g_halo_geom <= 3) ? g_halo_geom : env;
+  if (mode != 3) return mode;
+  int best = 0;
+  long long best_tiles = (long long)((H + 7) / 8) * ((W + 15) / 16);
+  for (int g = 1; g <= 2; ++g) {
+    int th, tw;
+    halo_geom_dims(g, th, tw);
+    const long long t = (long long)((H + th - 1) / th) * ((W + tw - 1) / tw);
+    if (t * 100 <= best_tiles * 95 && (best == 0 || t < best_tiles)) {
+      best = g;
+      best_tiles = t;
+    }
+  }
+  return best;
+}
+int g_halo_last_geom = 0;
 
 int halo_bfx_plan(long long M, int tiles_m, int Cin, int Cout, int& nb) {
   nb = Cout <= 64 ? 1 : 2;
@@ -1914,7 +1962,9 @@ extern "C" void bgs_conv_dgrad_parity_enable(int on) { g_dgrad_parity = on ? 1 :
 
 extern "C" size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
-  const int tiles_m = N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  int th, tw;
+  halo_geom_dims(g_halo_variant == 4 ? halo_bfx_geom(H, W) : 0, th, tw);
+  const int tiles_m = N * ((H + th - 1) / th) * ((W + tw - 1) / tw);
   int nb;
   const int want = halo_bfx_plan((long long)N * H * W, tiles_m, Cin, Cout, nb);
   return want > 1 ? (size_t)want * (size_t)N * H * W * Cout * sizeof(float) : 0;
@@ -1922,6 +1972,8 @@ extern "C" size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int 
 
 extern "C" void bgs_conv3x3_halo_bfx_tuning(int splits, int variant) {
   g_ablate = (variant >> 8) & 0xff;          // timing-only ablation modes (-DBGS_ABLATE builds)
+  g_halo_geom = ((variant >> 16) & 0xf) - 1; // 0: default pixel tile | 1: 8 x 16 | 2: 10 x 12 | 3: 5 x 21 | 4: fewest tiles
+  if (g_halo_geom > 3) g_halo_geom = -1;
   variant &= 0xff;
   g_halo_force_splits = splits;
   // 1 = first version (2 workgroups / CU), 2 = taps unrolled + 3 workgroups / CU (register-staged
@@ -1931,7 +1983,7 @@ extern "C" void bgs_conv3x3_halo_bfx_tuning(int splits, int variant) {
 }
 
 extern "C" int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits) {
-  if (nb) *nb = g_halo_last_nb | (g_halo_last_variant << 8);   // bits 8..: the kernel variant that ran
+  if (nb) *nb = g_halo_last_nb | (g_halo_last_variant << 8) | (g_halo_last_geom << 16);   // bits 8..15: the kernel variant that ran; 16..: its pixel tile (0: 8 x 16, 1: 10 x 12, 2: 5 x 21)
   if (splits) *splits = g_halo_last_splits;
   return BGS_OK;
 }
@@ -1975,8 +2027,12 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wspl
   p.partial = nullptr; p.kt_per_split = 0;
   q.ws = reinterpret_cast<const __bf16*>(wsplit);
   q.KC = bfx_kc(p.K);
-  q.tiles_y = (H + TH - 1) / TH;
-  q.tiles_x = (W + TW - 1) / TW;
+  const int geom = (g_halo_variant == 4 && q.ns == 3) ? halo_bfx_geom(H, W) : 0;   // (the bf16 mode keeps 8 x 16)
+  int gth, gtw;
+  halo_geom_dims(geom, gth, gtw);
+  g_halo_last_geom = geom;
+  q.tiles_y = (H + gth - 1) / gth;
+  q.tiles_x = (W + gtw - 1) / gtw;
   p.tiles_m = N * q.tiles_y * q.tiles_x;
   int nb;
   int want = halo_bfx_plan(M, p.tiles_m, Cin, Cout, nb);
@@ -2004,6 +2060,12 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wspl
     if (q.ns == 1) {
       if (nb == 1) hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
       else hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    } else if (geom == 1) {
+      if (nb == 1) hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, 3, false, 10, 12>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+      else hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, 3, false, 10, 12>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    } else if (geom == 2) {
+      if (nb == 1) hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, 3, false, 5, 21>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+      else hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, 3, false, 5, 21>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
     } else if (nb == 1) {
       hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, 3>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
     } else if (g_halo_pf) {

@@ -654,11 +654,12 @@ def bfx_split_weights_dgrad(w_krsc, cache=True):
     return out
 
 
-def conv_bfx_tuning(tile=0, splitk=-1, halo_splits=-1, halo_variant=0):
-    """Process-wide tuning / test hook of the bf16x6 kernels (see include/bgs.h)."""
+def conv_bfx_tuning(tile=0, splitk=-1, halo_splits=-1, halo_variant=0, halo_geom=-1):
+    """Process-wide tuning / test hook of the bf16x6 kernels (see include/bgs_tuning.h).  ``halo_geom``: the
+    pixel tile of the halo kernel, -1 default | 0: 8 x 16 | 1: 10 x 12 | 2: 5 x 21 | 3: fewest tiles per image."""
     lib = capi.load()
     lib.bgs_conv_bfx_tuning(int(tile), int(splitk))
-    lib.bgs_conv3x3_halo_bfx_tuning(int(halo_splits), int(halo_variant))
+    lib.bgs_conv3x3_halo_bfx_tuning(int(halo_splits), int(halo_variant) | ((int(halo_geom) + 1) << 16))
 
 
 def conv_bfx_last_launch():
@@ -669,7 +670,8 @@ def conv_bfx_last_launch():
     lib.bgs_conv_bfx_last_launch(ctypes.byref(a), ctypes.byref(c))
     lib.bgs_conv3x3_halo_bfx_last_launch(ctypes.byref(d), ctypes.byref(e))
     return dict(tile=a.value & ~0x400, ring_stages=3 if a.value & 0x400 else 4, splits=c.value,
-                halo_nb=d.value & 0xff, halo_variant=d.value >> 8, halo_splits=e.value)
+                halo_nb=d.value & 0xff, halo_variant=(d.value >> 8) & 0xff, halo_geom=d.value >> 16,
+                halo_splits=e.value)
 
 
 CENSUS = dict(bf16_ring8=0, grouped_lds=1, halo_bfx4=2, dma_ring64=3, gs_head_fused=4, conv1x1_bres=5,

@@ -66,8 +66,11 @@ int bgs_gs_head_variant_used(int N);
  *   splitk -1 = auto | 1..16; bgs_conv_bfx_last_launch: *tile carries the tile | 0x200 (DMA ring) | 0x400
  *   (3 stages) | 0x1000 (filter-resident 1x1) | 0x2000 (parity-class data gradient) | 0x4000 (wide 1x1).
  * bgs_conv3x3_halo_bfx_tuning: splits -1 = auto | n; variant 0 = default = 4 (filter slices by LDS-DMA) | 2
- *   (register-staged slices) | 1 (first version) | 5 (4 + A-fragment prefetch); bgs_conv3x3_halo_bfx_last_launch
- *   reports the variant in bits 8.. of *nb.
+ *   (register-staged slices) | 1 (first version) | 5 (4 + A-fragment prefetch); bits 16..19 of `variant`: the pixel
+ *   tile of variant 4, 0 = default (8 x 16; env BGS_HALO_GEOM) | 1 = 8 x 16 | 2 = 10 x 12 | 3 = 5 x 21 | 4 = the
+ *   tile with the fewest tiles per image;
+ *   bgs_conv3x3_halo_bfx_last_launch reports the variant in bits 8..15 of *nb and the pixel tile in bits 16..
+ *   (0: 8 x 16, 1: 10 x 12, 2: 5 x 21).
  * bgs_conv1x1_bres_enable (filter-resident 1x1, csrc/conv1x1_bres.hip): 1 (default) = where measured faster,
  *   2 = every layer it can run, 0 = never; bgs_conv1x1_bres_last_launch: 1 when the last call that could have
  *   taken it did.

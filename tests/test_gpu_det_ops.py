@@ -875,6 +875,51 @@ def test_conv1x1_filter_resident_kernel_as_data_gradient_with_mask():
         BF.set_conv_math(prev)
 
 
+@pytest.mark.parametrize('shape', [
+    # (N, H, W, Cin, Cout, pixel tile the fewest-tiles mode takes: 0 = 8 x 16, 1 = 10 x 12, 2 = 5 x 21)
+    (2, 50, 84, 256, 256, 1),      # stride-16 maps (layer3 conv2, P4): 35 tiles per image instead of 42
+    (2, 25, 42, 512, 512, 2),      # stride-32 maps (layer4 conv2, P5): 10 instead of 12
+    (1, 37, 51, 64, 64, 0),        # ragged edges on both axes, NB = 1 (20 tiles either way: stays 8 x 16)
+    (2, 200, 336, 32, 128, 0),     # stride-4 map: stays 8 x 16
+    (2, 100, 168, 32, 128, 0),     # stride-8 map: 140 vs 143 tiles is inside the 5 % margin: stays 8 x 16
+], ids=lambda c: 'x'.join(str(v) for v in c))
+def test_halo_kernel_pixel_tile_geometries_are_bit_identical(shape, monkeypatch):
+    """``conv3x3_halo_bfx4_kernel<.., GTH, GTW>``: the 10 x 12 and 5 x 21 pixel tiles (the small maps of
+    mmdet/models/backbones/resnet.py:220-266 / necks/fpn.py:131-134, where the 8 x 16 tile wastes up to 28 % of its
+    MFMA rows on pixels outside the map) against the 8 x 16 tile: every output is the same sum in the same order —
+    BIT-IDENTICAL, unsliced and with the channel chunks sliced two ways; the fewest-tiles choice per map size
+    and the default (8 x 16: the tighter tiles measured flat in the cfg[1] step) are asserted through the
+    last-launch query; bias + ReLU epilogue; fp64 bound."""
+    N, H, W, Cin, Cout, auto = shape
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    monkeypatch.setenv('BGS_CONV_HALO', '1')
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        for splits in (1, 2):
+            outs = {}
+            for geom in (0, 1, 2):
+                BF.conv_bfx_tuning(halo_splits=splits, halo_geom=geom)
+                outs[geom] = BF.conv2d_nhwc(dev(x), dev(w), dev(b), pad=1, relu=True).cpu()
+                used = BF.conv_bfx_last_launch()
+                assert used['halo_variant'] == 4 and used['halo_geom'] == geom and used['halo_splits'] == splits, used
+            assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
+        BF.conv_bfx_tuning(halo_geom=3)                     # "fewest tiles per image"
+        BF.conv2d_nhwc(dev(x), dev(w), dev(b), pad=1, relu=True)
+        assert BF.conv_bfx_last_launch()['halo_geom'] == auto
+        BF.conv_bfx_tuning()                                # the default stays 8 x 16 (measured flat in the step)
+        BF.conv2d_nhwc(dev(x), dev(w), dev(b), pad=1, relu=True)
+        assert BF.conv_bfx_last_launch()['halo_geom'] == 0
+    finally:
+        BF.conv_bfx_tuning()
+        BF.set_conv_math(prev)
+    ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1))
+    err = float((outs[0].double() - ref.permute(0, 2, 3, 1)).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+
+
 def _wide_last():
     from balancedgroupsoftmax_amd import capi
     v = capi.load().bgs_conv_bfx_wide_last_launch()
