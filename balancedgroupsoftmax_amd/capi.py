@@ -177,6 +177,7 @@ SIGNATURES = {
     'bgs_nms_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     'bgs_nms_batched': (ctypes.c_int, [c_f32p, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                        ctypes.c_int, ctypes.c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'bgs_nms_merge_select': (ctypes.c_int, [c_f32p, c_ptr, c_ptr] + [ctypes.c_int] * 4 + [c_f32p, c_ptr, c_ptr]),
     'bgs_nms_gather': (ctypes.c_int, [c_f32p, c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_ptr]),
     'bgs_gather_boxes': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
                                         c_ptr, c_ptr]),

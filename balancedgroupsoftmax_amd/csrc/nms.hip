@@ -350,6 +350,83 @@ __global__ __launch_bounds__(256) void gather_boxes_kernel(const float* __restri
   valid[i] = scores[i] >= 0.f ? 1 : 0;
 }
 
+
+// The proposal tail of RPNHead.get_bboxes_single (rpn_head.py:99-103: `proposals = torch.cat(mlvl_proposals)`,
+// `scores.topk(num)`, `proposals[topk_inds]`) in ONE launch instead of eleven (gather of the kept boxes, a memset,
+// the eight launches of a 10,000-element radix select + sort, gather of the selected boxes: 83 us of the cfg[1]
+// step, profiles/r6y_detector_prof_summary.md).  Each level's kept boxes already ARE in descending score order
+// (NMS keeps positions of a score-sorted list in ascending order), so the per-image top `num` over the L levels
+// is an L-way merge: the output rank of kept entry (level l, slot j) is
+//     j + sum over l' != l of #{kept entries of l' that precede it},
+// "precede" = larger score, or equal score and smaller concatenated index (= lower level) — the order of
+// bgs_topk_sorted_f32's composites — found by a binary search of each other level's kept scores.  A workgroup
+// stages the L kept-score lists of its image in LDS (L * nmax floats) and ranks its share of the entries.
+// props [N, num, 5]: entries of rank < num, in rank order; slots past the number of kept boxes: zeros, valid = 0.
+__global__ __launch_bounds__(1024) void nms_merge_select_kernel(const float* __restrict__ boxes,
+                                                                const int* __restrict__ keep,
+                                                                const int* __restrict__ keep_n, int L, int nmax,
+                                                                int num, int parts, float* __restrict__ props,
+                                                                unsigned char* __restrict__ valid) {
+  extern __shared__ float s_sc[];                          // [L][nmax] kept scores of the image, descending per level
+  __shared__ int s_n[16];
+  const int n = blockIdx.x / parts, part = blockIdx.x - n * parts, tid = threadIdx.x;
+  if (tid < L) {
+    int c = keep_n[n * L + tid];
+    s_n[tid] = c < 0 ? 0 : (c > nmax ? nmax : c);
+  }
+  __syncthreads();
+  for (int e = tid; e < L * nmax; e += 1024) {
+    const int l = e / nmax, j = e - l * nmax;
+    float sc = -1.f;
+    if (j < s_n[l]) {
+      int k = keep[(size_t)(n * L + l) * nmax + j];
+      k = k < 0 ? 0 : (k > nmax - 1 ? nmax - 1 : k);
+      sc = boxes[((size_t)(n * L + l) * nmax + k) * 5 + 4];
+    }
+    s_sc[e] = sc;
+  }
+  __syncthreads();
+  int total = 0;
+  for (int l = 0; l < L; ++l) total += s_n[l];
+  // this workgroup's share of the (level, slot) entries
+  for (int e = part * 1024 + tid; e < L * nmax; e += parts * 1024) {
+    const int l = e / nmax, j = e - l * nmax;
+    if (j >= s_n[l]) continue;
+    const float sc = s_sc[e];
+    int rank = j;
+    for (int lo = 0; lo < L; ++lo) {
+      if (lo == l) continue;
+      const float* v = s_sc + lo * nmax;
+      // number of entries of level `lo` that precede: v is non-increasing; lower levels win ties
+      int a = 0, b = s_n[lo];
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        const float x = v[mid];
+        const bool before = lo < l ? (x >= sc) : (x > sc);
+        if (before) a = mid + 1;
+        else b = mid;
+      }
+      rank += a;
+    }
+    if (rank < num) {
+      int k = keep[(size_t)(n * L + l) * nmax + j];
+      k = k < 0 ? 0 : (k > nmax - 1 ? nmax - 1 : k);
+      const float* src = boxes + ((size_t)(n * L + l) * nmax + k) * 5;
+      float* dst = props + ((size_t)n * num + rank) * 5;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) dst[c] = src[c];
+      valid[(size_t)n * num + rank] = 1;
+    }
+  }
+  // slots nobody ranks into
+  for (int r = (total < num ? total : num) + part * 1024 + tid; r < num; r += parts * 1024) {
+    float* dst = props + ((size_t)n * num + r) * 5;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) dst[c] = 0.f;
+    valid[(size_t)n * num + r] = 0;
+  }
+}
+
 }  // namespace
 
 // boxes [R, nmax, 5], keep [R, nmax] / keep_count [R] of bgs_nms_batched -> out_boxes [R, nmax, 5] =
@@ -374,5 +451,23 @@ extern "C" int bgs_gather_boxes(const float* flat, const long long* idx, const f
   if ((long long)N * num > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(gather_boxes_kernel, dim3((unsigned)((N * num + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, flat, idx, scores, N, T, num, props, valid);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+// boxes [N * L, nmax, 5] (each row sorted by descending score: the decoded pre-NMS candidates of one image and
+// level), keep [N * L, nmax] / keep_count [N * L] of bgs_nms_batched -> props [N, num, 5] = the `num` best kept
+// boxes of each image over its L levels in descending score order (ties: lower level, then NMS order),
+// valid [N, num] uint8 (0 and a zero box past the number of kept boxes).  One launch; L <= 16, L * nmax * 4 bytes
+// of LDS (<= 64 KB).  Replaces bgs_nms_gather + bgs_topk_sorted_f32 + bgs_gather_boxes on the proposal path
+// (mmdet/models/anchor_heads/rpn_head.py:99-103).
+extern "C" int bgs_nms_merge_select(const float* boxes, const int* keep, const int* keep_count, int N, int L,
+                                    int nmax, int num, float* props, unsigned char* valid, bgs_stream_t stream) {
+  if (!boxes || !keep || !keep_count || !props || !valid || N <= 0 || L <= 0 || nmax <= 0 || num <= 0)
+    return BGS_ERR_INVALID_ARG;
+  if (L > 16 || (size_t)L * nmax * sizeof(float) > 64 * 1024) return BGS_ERR_UNSUPPORTED;
+  const int parts = (L * nmax + 1023) / 1024 < 8 ? (L * nmax + 1023) / 1024 : 8;
+  hipLaunchKernelGGL(nms_merge_select_kernel, dim3((unsigned)(N * parts)), dim3(1024),
+                     (size_t)L * nmax * sizeof(float), (hipStream_t)stream, boxes, keep, keep_count, L, nmax, num,
+                     parts, props, valid);
   BGS_RETURN_LAUNCH_STATUS();
 }

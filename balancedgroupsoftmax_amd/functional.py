@@ -1555,6 +1555,26 @@ def nms_gather(boxes, keep, keep_count):
     return out, sc
 
 
+def nms_merge_select(boxes, keep, keep_count, num_images, num):
+    """The proposal tail in one launch (``bgs_nms_merge_select``): ``boxes [N*L,nmax,5]`` (rows sorted by
+    descending score), ``keep`` / ``keep_count`` of :func:`nms_batched` -> ``(props [N,num,5], valid [N,num] bool)``:
+    the ``num`` best kept boxes of each image over its L levels, in descending score order."""
+    _require_cuda(boxes, keep, keep_count)
+    lib = capi.load()
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.dim() == 3 and boxes.shape[2] == 5
+    assert keep.dtype == torch.int32 and keep.is_contiguous() and keep_count.dtype == torch.int32
+    R, nmax, _ = boxes.shape
+    N = int(num_images)
+    assert R % N == 0
+    props = torch.empty((N, int(num), 5), dtype=torch.float32, device=boxes.device)
+    valid = torch.empty((N, int(num)), dtype=torch.uint8, device=boxes.device)
+    rc = lib.bgs_nms_merge_select(capi.ptr(boxes), capi.ptr(keep), capi.ptr(keep_count.contiguous()), N, R // N,
+                                  nmax, int(num), capi.ptr(props), capi.ptr(valid),
+                                  capi.current_stream(boxes.device))
+    capi.check('bgs_nms_merge_select', rc)
+    return props, valid.view(torch.bool)
+
+
 def gather_boxes(flat, idx, scores):
     """``props [N,num,5] = flat[n, idx[n,j]]``, ``valid [N,num] (bool) = scores >= 0``
     (``bgs_gather_boxes``: one launch)."""

@@ -17,6 +17,8 @@ Differences in *how*, not *what*:
 * proposals: the 5 levels x N images go through ONE batched on-device NMS launch pair
   (csrc/nms.hip) instead of 10 ``nms_cuda`` calls with a D2H copy each (rpn_head.py:92).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -293,12 +295,18 @@ class RPNHead(nn.Module):
         cnt = self._anchor_cache[ckey]
         keep, keep_n = BF.nms_batched(boxes.view(N * L, nmax, 5), cnt, cfg.nms_thr, iou_mode=0,
                                       max_keep=cfg.nms_post)
-        # kept boxes into fixed-shape rows (padding slots score -1), then the per-image top `max_num`
-        # over the levels: two gathers, one launch each (csrc/nms.hip)
+        num = min(cfg.max_num, L * nmax)
+        if os.environ.get('BGS_PROPOSAL_TAIL', 'merge') == 'merge' and L <= 16 and L * nmax <= 16384:
+            # every level's kept boxes are already in descending score order: the per-image top `max_num` over
+            # the levels is an L-way merge — ONE launch (csrc/nms.hip nms_merge_select_kernel) instead of the gather
+            # + radix select + sort + gather below (11 launches, 83 us of the cfg[1] step); same boxes, same order
+            props, valid = BF.nms_merge_select(boxes.view(N * L, nmax, 5), keep, keep_n, N, num)
+            return ProposalList(props, valid)
+        # (A/B arm, BGS_PROPOSAL_TAIL=topk) kept boxes into fixed-shape rows (padding slots score -1), then the
+        # per-image top `max_num` over the levels: two gathers, one launch each (csrc/nms.hip)
         kept, kept_scores = BF.nms_gather(boxes.view(N * L, nmax, 5), keep, keep_n)
         flat = kept.view(N, L * nmax, 5)
         flat_s = kept_scores.view(N, L * nmax)
-        num = min(cfg.max_num, L * nmax)
         if N > 64 or num > 4096:
             raise NotImplementedError('bgs_topk_sorted: <= 64 rows / <= 4096 selected (got %d, %d)'
                                       % (N, num))

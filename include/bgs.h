@@ -531,6 +531,14 @@ int bgs_nms_gather(const float* boxes, const int* keep, const int* keep_count, i
                    float* out_boxes, float* out_scores, bgs_stream_t stream);
 int bgs_gather_boxes(const float* flat, const long long* idx, const float* scores, int N, int T, int num,
                      float* props, unsigned char* valid, bgs_stream_t stream);
+/* The proposal tail in ONE launch (replaces bgs_nms_gather + bgs_topk_sorted_f32 + bgs_gather_boxes there;
+ *   mmdet/models/anchor_heads/rpn_head.py:99-103: cat of the levels, `scores.topk(num)`, gather): boxes
+ *   [N * L, nmax, 5] (rows sorted by descending score), keep [N * L, nmax] / keep_count [N * L] of bgs_nms_batched
+ *   -> props [N, num, 5] = the num best kept boxes of each image over its L levels in descending score order
+ *   (ties: lower level first, then NMS order — the order of bgs_topk_sorted_f32 on the concatenated rows),
+ *   valid [N, num] uint8 (0, with a zero box, past the number of kept boxes).  L <= 16, L * nmax <= 16384. */
+int bgs_nms_merge_select(const float* boxes, const int* keep, const int* keep_count, int N, int L, int nmax,
+                         int num, float* props, unsigned char* valid, bgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Target assignment without the [G, A] IoU matrix.  Replaces MaxIoUAssigner.assign /

@@ -314,6 +314,56 @@ def test_nms_properties_and_max_keep():
     np.testing.assert_array_equal(keep3[0, :10].cpu().numpy(), k[:10])
 
 
+@pytest.mark.parametrize('case', [
+    # (N, L, nmax, num, kept counts per (image, level), quantised scores -> ties across levels)
+    (2, 5, 2000, 2000, None, False),                     # the cfg[1] shape: ~10,000 kept of which 2000 are taken
+    (2, 5, 2000, 2000, None, True),                      # scores on a coarse grid: many exact ties across levels
+    (1, 3, 300, 1000, [[7, 0, 12]], False),              # fewer kept boxes than `num`: trailing invalid slots
+    (3, 4, 500, 64, None, True),
+], ids=['cfg1', 'cfg1_ties', 'short', 'small_num'])
+def test_proposal_tail_merge_equals_the_topk_tail(case):
+    """``bgs_nms_merge_select`` (the per-image top ``max_num`` over the levels as an L-way merge of the levels'
+    score-sorted kept lists: ONE launch) == ``bgs_nms_gather`` + ``bgs_topk_sorted_f32`` + ``bgs_gather_boxes``
+    (rpn_head.py:99-103 as eleven launches) — the same boxes in the same order, bit for bit, ties across levels
+    included (lower level first: the composite order of the radix select), ``valid`` identical."""
+    N, L, nmax, num, counts, ties = case
+    rs = np.random.RandomState(nmax + num + int(ties))
+    boxes = np.zeros((N * L, nmax, 5), np.float32)
+    for r in range(N * L):
+        d = det_oracle.make_boxes(nmax, seed=100 + r)
+        if ties:
+            d[:, 4] = np.round(d[:, 4] * 40) / 40
+        boxes[r] = d[np.argsort(-d[:, 4], kind='stable')]
+    cnt = torch.full((N * L,), nmax, dtype=torch.int32, device=DEV)
+    keep, kc = BF.nms_batched(dev(boxes), cnt, 0.7)
+    if counts is not None:
+        kc = torch.tensor(np.array(counts, np.int32).reshape(-1), device=DEV)
+    num = min(num, L * nmax)                              # as RPNHead._nms_and_select does
+    props, valid = BF.nms_merge_select(dev(boxes), keep, kc, N, num)
+    kept, kept_scores = BF.nms_gather(dev(boxes), keep, kc)
+    flat, flat_s = kept.view(N, L * nmax, 5), kept_scores.view(N, L * nmax)
+    top_s, top_i = BF.topk_sorted([flat_s], [num], num)
+    props0, valid0 = BF.gather_boxes(flat, top_i.view(N, num), top_s.view(N, num))
+    assert torch.equal(valid, valid0)
+    nv = valid.sum(1).cpu().numpy()
+    total = kc.view(N, L).sum(1).clamp(max=num).cpu().numpy()
+    np.testing.assert_array_equal(nv, total)
+    for n in range(N):
+        a, b = props[n, :nv[n]].cpu().numpy(), props0[n, :nv[n]].cpu().numpy()
+        assert (np.diff(a[:, 4]) <= 0).all()
+        np.testing.assert_array_equal(a[:, 4], b[:, 4])            # the same scores in the same order, always
+        # Which of several boxes EQUAL to the num-th score make the cut is unspecified in the radix select (arrival
+        # order of its collect pass, as in torch.topk); the merge takes them in concatenated order.  Everything above
+        # that last tie group must agree box for box; inside it the merge's choice must be the FIRST ones.
+        cut = int((a[:, 4] > a[-1, 4]).sum()) if nv[n] == num else nv[n]
+        np.testing.assert_array_equal(a[:cut], b[:cut])
+        if cut < nv[n]:
+            fs = flat_s[n].cpu().numpy()
+            first = np.nonzero(fs == a[-1, 4])[0][:nv[n] - cut]
+            np.testing.assert_array_equal(a[cut:], flat[n].cpu().numpy()[first])
+        assert float(props[n, nv[n]:].abs().max() if nv[n] < num else 0.0) == 0.0
+
+
 # ---------------------------------------------------------------- multiclass NMS (test-time path)
 def _mc_cases():
     import json
