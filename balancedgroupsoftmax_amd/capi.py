@@ -33,6 +33,7 @@ SIGNATURES = {
     'bgs_error_string': (ctypes.c_char_p, [ctypes.c_int]),
     'bgs_selftest_wave_reduce': (ctypes.c_int, [c_f32p, c_f32p, c_ptr]),
     'bgs_selftest_mfma_peak': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_f32p, c_ptr]),
+    'bgs_selftest_mfma_peak_bf16': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_ptr]),
     'bgs_gs_prepare': (ctypes.c_int, [c_i64p, c_i64p, c_f32p, ctypes.c_int, c_f32p, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                       ctypes.c_uint64, c_ptr, c_i64p, c_f32p, c_f32p, c_ptr]),

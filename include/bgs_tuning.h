@@ -19,9 +19,14 @@ extern "C" {
  * bgs_selftest_wave_reduce: in [64] float, out [4] float = {max, sum} by the build's wave64 reduction
  *   primitive (DPP) followed by {max, sum} by a ds_bpermute butterfly.
  * bgs_selftest_mfma_peak: `blocks` workgroups x 4 waves x (4 * iters) v_mfma_f32_32x32x2_f32 with register
- *   operands (4096 flop each) — the fp32 matrix rate the chip sustains under its power limit. */
+ *   operands (4096 flop each) — the fp32 matrix rate the chip sustains under its power limit.
+ * bgs_selftest_mfma_peak_bf16: the same with 24 x iters v_mfma_f32_32x32x16_bf16 per wave (32768 flop each) in the
+ *   product order of the bf16x6 kernels; random_operands != 0: pseudo-random operand registers (mixed sign and
+ *   mantissa, the three planes 2^-8 apart), 0: zero operands — the chip clocks to its power budget, the random
+ *   figure / 6 is what a memory-free bf16x6 loop sustains. */
 int bgs_selftest_wave_reduce(const float* in, float* out, bgs_stream_t stream);
 int bgs_selftest_mfma_peak(int blocks, int iters, float* out, bgs_stream_t stream);
+int bgs_selftest_mfma_peak_bf16(int blocks, int iters, int random_operands, float* out, bgs_stream_t stream);
 
 /* ---- launch census ------------------------------------------------------------------------------
  * How often a kernel family was launched by this process since the last reset — lets a test ASSERT that the
