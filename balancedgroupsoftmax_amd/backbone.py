@@ -385,6 +385,15 @@ class FPN(nn.Module):
         for i in range(n - 2, -1, -1):   # lateral_i + nearest_2x(lateral_{i+1}), fused
             lat[i] = BF.conv2d_autograd(inputs[i], *f['lat'][i], residual=lat[i + 1],
                                         residual_mode=2, out_dtype=torch.float32, mask_input=gate[i])
+        if n > 1 and lat[0].is_cuda and BF.level_fork_enabled():
+            # the small levels next to the P2 launch (functional.forked)
+            with BF.forked(lat[0].device) as fk:
+                small = [BF.conv2d_autograd(lat[i], *f['out'][i], pad=1) for i in range(1, n)]
+                for _ in range(self.num_outs - n):
+                    small.append(small[-1][:, ::2, ::2, :].contiguous())
+            outs = [BF.conv2d_autograd(lat[0], *f['out'][0], pad=1)] + small
+            fk.join()
+            return tuple(outs)
         outs = [BF.conv2d_autograd(lat[i], *f['out'][i], pad=1) for i in range(n)]
         for _ in range(self.num_outs - n):   # F.max_pool2d(x, 1, stride=2) == subsampling
             outs.append(outs[-1][:, ::2, ::2, :].contiguous())

@@ -141,10 +141,44 @@ __device__ __forceinline__ bool conv_epilogue_vec_ok(const ConvArgs& p) {
   return (p.Cout & 3) == 0 && (a & 15) == 0 && p.res_mode != 3;
 }
 
+// Residual row of GEMM row m for the vector epilogue (modes 1 and 2; no row map).
+__device__ __forceinline__ const float* conv_res_row(const ConvArgs& p, int m) {
+  if (p.res_mode == 1) return p.res + (size_t)m * p.Cout;
+  const int hw = p.Ho * p.Wo;
+  const int n = m / hw;
+  const int rem = m - n * hw;
+  const int ho = rem / p.Wo, wo = rem - (rem / p.Wo) * p.Wo;
+  return p.res + (((size_t)n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1)) * p.Cout;
+}
+
+// The residual values a thread adds in conv_store_tile_lds, loaded AHEAD of the K loop: the epilogue's residual
+// read is otherwise a third dependent HBM round trip in the life of a workgroup (operands -> MFMAs -> residual ->
+// store), and the short-K layers (K = 64 .. 256: 4 - 16 steps) have too few bytes in flight per CU to hide it.
+// Same addresses, same values, same arithmetic.  Returns false (nothing loaded) when the epilogue would not take
+// the vector path or the tile is a split-K slab / row-mapped.
 template <int MB, int NB>
-__device__ __forceinline__ void conv_store_tile_lds(const ConvArgs& p, const f32x16 (&acc)[MB][NB],
-                                                    int m0, int n0, int wm, int wn, int lane,
-                                                    float* scratch) {
+__device__ __forceinline__ bool conv_prefetch_residual(const ConvArgs& p, int m0, int n0,
+                                                       f32x4 (&pre)[64 * MB / (kThreads / (16 * NB))]) {
+  constexpr int BM = 64 * MB, BN = 64 * NB;
+  constexpr int TPR = BN / 4, RPP = kThreads / TPR;
+  if (!(p.res_mode == 1 || p.res_mode == 2) || p.partial || p.rowmap || !conv_epilogue_vec_ok(p)) return false;
+  const int tid = threadIdx.x;
+  const int c4 = (tid % TPR) * 4, r0 = tid / TPR;
+  const int j = n0 + c4;
+  const int jj = j < p.Cout ? j : 0;                     // (clamped, unconditional loads: no branch, all in flight)
+#pragma unroll
+  for (int ps = 0; ps < BM / RPP; ++ps) {
+    const int m = min(m0 + r0 + ps * RPP, p.M - 1);
+    pre[ps] = *reinterpret_cast<const f32x4*>(conv_res_row(p, m) + jj);
+  }
+  return true;
+}
+
+template <int MB, int NB, bool PRE>
+__device__ __forceinline__ void conv_store_tile_lds_impl(const ConvArgs& p, const f32x16 (&acc)[MB][NB],
+                                                         int m0, int n0, int wm, int wn, int lane,
+                                                         float* scratch,
+                                                         const f32x4 (&pre)[64 * MB / (kThreads / (16 * NB))]) {
   constexpr int BM = 64 * MB, BN = 64 * NB, LD = BN + 4;
   constexpr int TPR = BN / 4, RPP = kThreads / TPR;     // threads per row, rows per pass
 #pragma unroll
@@ -189,7 +223,9 @@ __device__ __forceinline__ void conv_store_tile_lds(const ConvArgs& p, const f32
     }
     f32x4 v = *reinterpret_cast<const f32x4*>(scratch + i * LD + c4);
     v += bias;
-    if (p.res_mode == 1) {
+    if (PRE) {
+      v += pre[ps];
+    } else if (p.res_mode == 1) {
       v += *reinterpret_cast<const f32x4*>(p.res + orow * p.Cout + j);
     } else if (p.res_mode == 2) {
       const int n = m / hw;
@@ -209,6 +245,14 @@ __device__ __forceinline__ void conv_store_tile_lds(const ConvArgs& p, const f32
     }
     *reinterpret_cast<f32x4*>(p.y + orow * p.Cout + j) = v;
   }
+}
+
+template <int MB, int NB>
+__device__ __forceinline__ void conv_store_tile_lds(const ConvArgs& p, const f32x16 (&acc)[MB][NB],
+                                                    int m0, int n0, int wm, int wn, int lane,
+                                                    float* scratch) {
+  const f32x4 none[64 * MB / (kThreads / (16 * NB))] = {};
+  conv_store_tile_lds_impl<MB, NB, false>(p, acc, m0, n0, wm, wn, lane, scratch, none);
 }
 
 }  // namespace bgs_conv

@@ -61,6 +61,7 @@ struct BfxArgs {
   ConvArgs c;
   const __bf16* ws;      // split weights [NS][KC][Cout][16]
   int KC;                // ceil(K / 16)
+  int res_prefetch;      // LDS-DMA ring: load the epilogue's residual tile ahead of the K loop
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -481,6 +482,11 @@ __global__ __launch_bounds__(kThreads, NS == 1 ? (DMA_NST == 3 ? 8 : 6) : (DMA_N
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
 
+  // residual tile of the epilogue, requested before the first operand stage (older than every DMA: the counted
+  // waits below are unaffected)
+  f32x4 res_pre[4];
+  const bool res_pf = q.res_prefetch && conv_prefetch_residual<1, 1>(p, m0, n0, res_pre);
+  asm volatile("" ::: "memory");
 #pragma unroll
   for (int i = 0; i < DMA_NST - 1; ++i) issue();
   f32x4 a0, a1;
@@ -537,7 +543,10 @@ __global__ __launch_bounds__(kThreads, NS == 1 ? (DMA_NST == 3 ? 8 : 6) : (DMA_N
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the (zero-page) tail DMAs
   if (conv_epilogue_vec_ok(p)) {                       // workgroup-uniform
     __syncthreads();                                   // every wave is done with the ring
-    conv_store_tile_lds<1, 1>(p, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(lds));
+    if (res_pf)
+      conv_store_tile_lds_impl<1, 1, true>(p, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(lds), res_pre);
+    else
+      conv_store_tile_lds<1, 1>(p, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(lds));
     return;
   }
   conv_store_tile<1, 1>(p, acc, m0, n0, wm, wn, lane);
@@ -1572,12 +1581,13 @@ int halo_bfx_plan(long long M, int tiles_m, int Cin, int Cout, int& nb) {
 }
 
 struct BfxKnobs {
-  int tile = 0, splitk = -1, dma = 1, nst = 0, ring8 = 1;
+  int tile = 0, splitk = -1, dma = 1, nst = 0, ring8 = 1, respf = 1;
   BfxKnobs() {
     if (const char* e = getenv("BGS_BFX_TILE")) tile = atoi(e);
     if (const char* e = getenv("BGS_BFX_SPLITK")) splitk = atoi(e);
     if (const char* e = getenv("BGS_BFX_NST")) nst = atoi(e);      // 3 | 4: ring depth of the 64 x 64 kernel
     if (const char* e = getenv("BGS_BF16_RING8")) ring8 = atoi(e);  // 0: bf16 mode on the 64 x 64 ring only
+    if (const char* e = getenv("BGS_BFX_RESPF")) respf = atoi(e);   // 0: residual read in the epilogue (A/B)
   }
 };
 BfxKnobs& bfx_knobs() {
@@ -1870,6 +1880,7 @@ extern "C" void bgs_conv_bfx_tuning(int tile, int splitk) {
   k.tile = tile & 0xff;               // bit 8 set: the register-staged 64x64 kernel instead of the
   k.dma = (tile & 0x100) ? 0 : 1;     // LDS-DMA ring (A/B runs and tests of both)
   k.nst = (tile & 0x400) ? 3 : ((tile & 0x800) ? 4 : 0);   // bit 10 / 11: force the 3- / 4-stage ring
+  k.respf = (tile & 0x1000) ? 0 : 1;  // bit 12: residual read in the epilogue instead of ahead of the K loop
   k.splitk = splitk;
 }
 
@@ -1911,6 +1922,7 @@ extern "C" int bgs_conv2d_nhwc_f32_bfx_ws(const float* x, const void* wsplit, co
   p.res_mode = residual_mode;
   q.ws = reinterpret_cast<const __bf16*>(wsplit);
   q.KC = bfx_kc(p.K);
+  q.res_prefetch = bfx_knobs().respf;
   return launch_conv_bfx(q, 1, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
@@ -1950,6 +1962,7 @@ extern "C" int bgs_conv2d_dgrad_nhwc_f32_bfx_ws(const float* dy, const void* wt_
   p.res_mode = residual_mode;
   q.ws = reinterpret_cast<const __bf16*>(wt_split);
   q.KC = bfx_kc(p.K);
+  q.res_prefetch = bfx_knobs().respf;
   if (stride == 2) {       // rows grouped by output-pixel parity: only the taps that meet non-zeros are multiplied
     const int rc = launch_conv_bfx_dgrad_parity(q, (hipStream_t)stream);
     if (rc >= 0) return rc;

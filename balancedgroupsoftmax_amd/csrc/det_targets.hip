@@ -20,6 +20,7 @@
 // All are tiny / latency-bound; the point is launch count (a few hundred launches fewer per
 // iteration) and zero host involvement.
 #include <math.h>
+#include <string.h>
 
 #include "bgs_common.h"
 
@@ -46,15 +47,30 @@ __device__ __forceinline__ float iou1(float ax1, float ay1, float ax2, float ay2
   return ov / (barea + aarea - ov);   // overlaps = gt x boxes: area1 = gt (b), area2 = box (a)
 }
 
-// pass 1: per box max / argmax over the gts; per gt max over the (valid) boxes.
+// w * h > 0 of iou1 (same expressions): false -> iou1 returns +0.0
+__device__ __forceinline__ bool iou_overlaps(float ax1, float ay1, float ax2, float ay2,
+                                             float bx1, float by1, float bx2, float by2) {
+#pragma clang fp contract(off)
+  const float w = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1) + 1.f, 0.f);
+  const float h = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1) + 1.f, 0.f);
+  return w * h > 0.f;
+}
+
+// pass 1: per box max / argmax over the gts -> the threshold part of the assignment (written here);
+// per gt the maximum over the (valid) boxes, globally (atomics) and per workgroup (`blk_max`, for pass 2).
+// Only maxima that can matter travel to the global table: pass 2 ignores a gt whose maximum is below
+// min_pos_iou, so a workgroup whose best IoU with a gt is below it keeps quiet (before: every workgroup sent
+// one atomicMax per gt, IoU 0 included — 21,000 same-address atomics per image were 2/3 of the 28 us launch).
 __global__ __launch_bounds__(256) void iou_gtmax_kernel(const float* __restrict__ boxes,
                                                         long long box_img_stride, int box_stride,
                                                         const uint8_t* __restrict__ valid,
                                                         const float* __restrict__ gt, ImgTable T,
-                                                        int A, int gmax_stride,
+                                                        int A, int gmax_stride, float pos_thr, float neg_lo,
+                                                        float neg_hi, int send_bits,
                                                         float* __restrict__ box_max,
-                                                        int* __restrict__ box_arg,
-                                                        int* __restrict__ gt_max_bits) {
+                                                        int* __restrict__ blk_max,
+                                                        int* __restrict__ gt_max_bits,
+                                                        int* __restrict__ assigned) {
   __shared__ float sgt[kGtChunk][4];
   __shared__ int smax[kGtChunk];     // per-gt maximum over this block's boxes (float bits)
   const int n = blockIdx.y;
@@ -71,6 +87,7 @@ __global__ __launch_bounds__(256) void iou_gtmax_kernel(const float* __restrict_
   const float area = (x2 - x1 + 1.f) * (y2 - y1 + 1.f);
   float best = -1.f;
   int barg = 0;
+  int* bm = blk_max + ((size_t)n * gridDim.x + blockIdx.x) * gmax_stride;
   for (int c0 = 0; c0 < G; c0 += kGtChunk) {
     const int cn = min(kGtChunk, G - c0);
     __syncthreads();
@@ -78,8 +95,11 @@ __global__ __launch_bounds__(256) void iou_gtmax_kernel(const float* __restrict_
     for (int t = threadIdx.x; t < cn; t += 256) smax[t] = (int)0xBF800000;   // -1.0f
     __syncthreads();
     for (int g = 0; g < cn; ++g) {
-      const float v = ok ? iou1(x1, y1, x2, y2, area, sgt[g][0], sgt[g][1], sgt[g][2], sgt[g][3])
-                         : -1.f;
+      // most waves of anchors miss a given gt entirely: overlap 0 -> IoU exactly +0.0 (0 / positive), and the
+      // ~25 instructions of the exact division are skipped wave-uniformly
+      float v = ok ? 0.f : -1.f;
+      if (__ballot(ok && iou_overlaps(x1, y1, x2, y2, sgt[g][0], sgt[g][1], sgt[g][2], sgt[g][3])))
+        v = ok ? iou1(x1, y1, x2, y2, area, sgt[g][0], sgt[g][1], sgt[g][2], sgt[g][3]) : -1.f;
       if (v > best) {   // first maximum wins (torch.max semantics on ties)
         best = v;
         barg = c0 + g;
@@ -97,63 +117,71 @@ __global__ __launch_bounds__(256) void iou_gtmax_kernel(const float* __restrict_
       }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < cn; t += 256)
-      if (smax[t] >= 0) atomicMax(&gt_max_bits[(size_t)n * gmax_stride + c0 + t], smax[t]);
+    for (int t = threadIdx.x; t < cn; t += 256) {
+      bm[c0 + t] = smax[t];
+      if (smax[t] >= send_bits) atomicMax(&gt_max_bits[(size_t)n * gmax_stride + c0 + t], smax[t]);
+    }
   }
-  if (live) {
-    box_max[(size_t)n * A + i] = best;
-    box_arg[(size_t)n * A + i] = barg;
+  if (!live) return;
+  if (box_max) box_max[(size_t)n * A + i] = best;
+  int a = -1;
+  if (ok) {
+    if (best >= neg_lo && best < neg_hi) a = 0;
+    if (best >= pos_thr) a = barg + 1;
   }
+  assigned[(size_t)n * A + i] = a;
 }
 
-// pass 2: thresholds + "every gt claims the boxes that attain its maximum" (later gts win).
+// pass 2: "every gt claims the boxes that attain its maximum" (later gts win).  A workgroup can only hold such
+// a box for the gts whose workgroup maximum equals the global one: all the others (all but ~G of the 1050 per
+// image) leave after comparing the two rows of maxima.
 __global__ __launch_bounds__(256) void iou_assign_kernel(
     const float* __restrict__ boxes, long long box_img_stride, int box_stride,
     const uint8_t* __restrict__ valid,
     const float* __restrict__ gt, ImgTable T, int A, int gmax_stride,
-    const float* __restrict__ box_max, const int* __restrict__ box_arg,
-    const int* __restrict__ gt_max_bits, float pos_thr, float neg_lo, float neg_hi,
+    const int* __restrict__ blk_max, const int* __restrict__ gt_max_bits,
     float min_pos_iou, int* __restrict__ assigned) {
   __shared__ float sgt[kGtChunk][4];
   __shared__ float sgmax[kGtChunk];
+  __shared__ int stie[kGtChunk];
   const int n = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int g0 = T.gt_off[n], G = T.gt_off[n + 1] - g0;
+  const int* bm = blk_max + ((size_t)n * gridDim.x + blockIdx.x) * gmax_stride;
   const bool live = i < A;
   const bool ok = live && (valid ? valid[(size_t)n * A + i] != 0 : true);
-  float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
-  if (live) {
-    const float* b = boxes + (size_t)n * box_img_stride + (size_t)i * box_stride;
-    x1 = b[0]; y1 = b[1]; x2 = b[2]; y2 = b[3];
-  }
-  const float area = (x2 - x1 + 1.f) * (y2 - y1 + 1.f);
+  float x1 = 0, y1 = 0, x2 = 0, y2 = 0, area = 0;
+  bool have_box = false;
   int winner = 0;
   for (int c0 = 0; c0 < G; c0 += kGtChunk) {
     const int cn = min(kGtChunk, G - c0);
-    __syncthreads();
+    int mine = 0;
+    for (int t = threadIdx.x; t < cn; t += 256) {
+      const int gm = gt_max_bits[(size_t)n * gmax_stride + c0 + t];
+      const int tie = (gm == bm[c0 + t] && __int_as_float(gm) >= min_pos_iou) ? 1 : 0;
+      stie[t] = tie;
+      sgmax[t] = __int_as_float(gm);
+      mine |= tie;
+    }
+    if (!__syncthreads_or(mine)) continue;       // (also orders the stie / sgmax writes)
     for (int t = threadIdx.x; t < cn * 4; t += 256) sgt[t >> 2][t & 3] = gt[(size_t)(g0 + c0) * 4 + t];
-    for (int t = threadIdx.x; t < cn; t += 256)
-      sgmax[t] = __int_as_float(gt_max_bits[(size_t)n * gmax_stride + c0 + t]);
+    if (!have_box && live) {
+      const float* b = boxes + (size_t)n * box_img_stride + (size_t)i * box_stride;
+      x1 = b[0]; y1 = b[1]; x2 = b[2]; y2 = b[3];
+      area = (x2 - x1 + 1.f) * (y2 - y1 + 1.f);
+      have_box = true;
+    }
     __syncthreads();
     if (ok) {
       for (int g = 0; g < cn; ++g) {
-        const float gm = sgmax[g];
-        if (gm >= min_pos_iou) {
-          const float v = iou1(x1, y1, x2, y2, area, sgt[g][0], sgt[g][1], sgt[g][2], sgt[g][3]);
-          if (v == gm) winner = c0 + g + 1;
-        }
+        if (!stie[g]) continue;
+        const float v = iou1(x1, y1, x2, y2, area, sgt[g][0], sgt[g][1], sgt[g][2], sgt[g][3]);
+        if (v == sgmax[g]) winner = c0 + g + 1;
       }
     }
+    __syncthreads();
   }
-  if (!live) return;
-  int a = -1;
-  if (ok) {
-    const float mx = box_max[(size_t)n * A + i];
-    if (mx >= neg_lo && mx < neg_hi) a = 0;
-    if (mx >= pos_thr) a = box_arg[(size_t)n * A + i] + 1;
-    if (winner > 0) a = winner;
-  }
-  assigned[(size_t)n * A + i] = a;
+  if (ok && winner > 0) assigned[(size_t)n * A + i] = winner;
 }
 
 __global__ void fill_i32_kernel(int* p, int v, size_t n) {
@@ -258,7 +286,7 @@ __global__ __launch_bounds__(256) void rpn_loss_kernel(LevelTable Lv, ImgTable T
 
 // loss_cls[l], loss_bbox[l] = weight * sum over images / (sum_n max(n_pos,1) + max(n_neg,1))
 __global__ __launch_bounds__(1024) void rpn_loss_finalize_kernel(const float* __restrict__ partial,
-                                                                int N, int blocks, int L,
+                                                                LevelTable Lv, int N, int blocks, int L,
                                                                 float w_cls, float w_bbox,
                                                                 float* __restrict__ loss_cls,
                                                                 float* __restrict__ loss_bbox,
@@ -267,11 +295,16 @@ __global__ __launch_bounds__(1024) void rpn_loss_finalize_kernel(const float* __
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // one wave per (image, level, quantity) triple, fixed summation order; 16 waves (the 40 triples
   // of cfg[1] on 4 waves were 33 us of dependent strided loads)
+  // Only the blocks whose 256 anchors reach into level l hold anything but +0.0 for it (rpn_loss_kernel writes
+  // exact zeros elsewhere), and x + 0.0 == x: every lane adds the same non-zero terms in the same order as a
+  // walk over all blocks would — 13 + 4 + 1 + 1 + 1 trips for the five levels of cfg[1] instead of 5 x 17.
   const int jobs = N * L * 4;
   for (int j = wave; j < jobs; j += 16) {
     const int q = j & 3, l = (j >> 2) % L, n = (j >> 2) / L;
+    const int b_lo = Lv.start[l] >> 8, b_hi = min(blocks - 1, (Lv.start[l + 1] - 1) >> 8);
     float s = 0.f;
-    for (int b = lane; b < blocks; b += 64) s += partial[(((size_t)n * blocks + b) * L + l) * 4 + q];
+    for (int b = (b_lo & ~63) + lane; b <= b_hi; b += 64)
+      if (b >= b_lo) s += partial[(((size_t)n * blocks + b) * L + l) * 4 + q];
     s = bgs::wave_sum(s);
     if (lane == 0) tot[n][l][q] = s;
   }
@@ -524,8 +557,9 @@ int fill_level_table(LevelTable* Lv, const float* const* host_outs, const int* h
 
 extern "C" size_t bgs_iou_assign_workspace_bytes(int N, int A, int G_total) {
   if (N <= 0 || A <= 0 || G_total < 0) return 0;
-  // box_max [N,A] f32 + box_arg [N,A] i32 + gt_max [N, G_total] i32
-  return (size_t)N * A * 8 + (size_t)N * (G_total > 0 ? G_total : 1) * 4;
+  // box_max [N,A] f32 + gt_max [N, G_total] i32 + per-workgroup gt maxima [N, ceil(A / 256), G_total] i32
+  const size_t g = (size_t)(G_total > 0 ? G_total : 1);
+  return (size_t)N * A * 4 + (size_t)N * g * 4 + (size_t)N * ((A + 255) / 256) * g * 4;
 }
 
 extern "C" int bgs_iou_assign(const float* boxes, long long box_img_stride, int box_stride,
@@ -542,19 +576,23 @@ extern "C" int bgs_iou_assign(const float* boxes, long long box_img_stride, int 
   const int Gt = T.gt_off[N];
   if (Gt <= 0) return BGS_ERR_INVALID_ARG;   // the reference raises ValueError('No gt or bboxes')
   hipStream_t st = (hipStream_t)stream;
-  float* box_max = max_overlaps_out ? max_overlaps_out : (float*)workspace;
-  int* box_arg = (int*)((char*)workspace + (size_t)N * A * 4);
-  int* gt_max = (int*)((char*)workspace + (size_t)N * A * 8);
+  float* box_max = max_overlaps_out;          // only materialised when the caller wants it
+  int* gt_max = (int*)((char*)workspace + (size_t)N * A * 4);
+  int* blk_max = gt_max + (size_t)N * Gt;
   const size_t ng = (size_t)N * Gt;
   hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, st, gt_max,
                      (int)0xBF800000 /* -1.0f */, ng);
   // gt_max rows are indexed by the gt's position inside its image: row stride = Gt is enough
   dim3 grid((unsigned)((A + 255) / 256), (unsigned)N);
+  // maxima below min_pos_iou never matter to pass 2 (IoUs are >= 0: positive floats order like their bits)
+  const float send = min_pos_iou > 0.f ? min_pos_iou : 0.f;
+  int send_bits;
+  memcpy(&send_bits, &send, sizeof(int));
   hipLaunchKernelGGL(iou_gtmax_kernel, grid, dim3(256), 0, st, boxes, box_img_stride, box_stride,
-                     valid, gt, T, A, Gt, box_max, box_arg, gt_max);
+                     valid, gt, T, A, Gt, pos_iou_thr, neg_iou_lo, neg_iou_hi, send_bits, box_max, blk_max,
+                     gt_max, assigned);
   hipLaunchKernelGGL(iou_assign_kernel, grid, dim3(256), 0, st, boxes, box_img_stride, box_stride,
-                     valid, gt, T, A, Gt, box_max, box_arg, gt_max, pos_iou_thr, neg_iou_lo, neg_iou_hi,
-                     min_pos_iou, assigned);
+                     valid, gt, T, A, Gt, blk_max, gt_max, min_pos_iou, assigned);
   BGS_RETURN_LAUNCH_STATUS();
 }
 
@@ -592,7 +630,7 @@ extern "C" int bgs_rpn_loss(const float* const* host_level_outs, const int* host
                      pos_mask, neg_mask, gt, cod, beta, pos_weight <= 0.f ? 1.f : pos_weight, A,
                      (float*)workspace);
   hipLaunchKernelGGL(rpn_loss_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)workspace,
-                     N, blocks, L, loss_weight_cls, loss_weight_bbox, loss_cls_out, loss_bbox_out,
+                     Lv, N, blocks, L, loss_weight_cls, loss_weight_bbox, loss_cls_out, loss_bbox_out,
                      num_total_out);
   BGS_RETURN_LAUNCH_STATUS();
 }

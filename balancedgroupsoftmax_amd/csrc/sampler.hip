@@ -217,11 +217,85 @@ __global__ __launch_bounds__(256) void sample_scan_kernel(const int* __restrict_
     if (s_base[1] + i < kCand) ln[s_base[1] + i] = s_ln[i];
 }
 
+// k-th smallest key (1-based) of a short list whose keys are all <= max_key: ONE 8192-bin histogram of the 13 bits
+// below max_key's leading zeros, a workgroup-wide scan for the bin that holds rank k, and a one-wave rank of the
+// (on average <= 1, at most 64) keys inside that bin.  *done = 0 when the bin holds more than 64 keys (the caller
+// falls back to the three-pass select).  The three-pass form cost ~3.5 us per pass (a one-wave walk over up to
+// 2048 bins) — 23 us for the two lists of an RPN image.
+constexpr int kBinsL = 8192;
+__device__ uint32_t kth_smallest_short(const uint32_t* __restrict__ keys, int n, int k, uint32_t max_key,
+                                       int* hist, int* s_tmp, uint32_t* s_small, int* done) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bits = 32 - __clz((int)(max_key | 1u));
+  const int shift = bits > 13 ? bits - 13 : 0;
+  for (int b = tid; b < kBinsL; b += kThreadsS) hist[b] = 0;
+  if (tid == 0) s_tmp[2] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += kThreadsS) atomicAdd(&hist[keys[i] >> shift], 1);
+  __syncthreads();
+  // scan: thread t owns bins 8t .. 8t + 7 (ascending keys)
+  int cnt[8], mine = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    cnt[j] = hist[tid * 8 + j];
+    mine += cnt[j];
+  }
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) s_tmp[8 + wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += s_tmp[8 + w];
+  incl += base;
+  const int excl = incl - mine;
+  if (excl < k && k <= incl) {                              // exactly one thread
+    int c = excl, bin = tid * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (k <= c + cnt[j]) {
+        bin = tid * 8 + j;
+        break;
+      }
+      c += cnt[j];
+    }
+    s_tmp[0] = bin;
+    s_tmp[1] = k - c;                                       // rank inside the bin, 1-based
+  }
+  __syncthreads();
+  const uint32_t bin = (uint32_t)s_tmp[0];
+  const int kin = s_tmp[1];
+  for (int i = tid; i < n; i += kThreadsS) {
+    const uint32_t key = keys[i];
+    if ((key >> shift) == bin) {
+      const int slot = atomicAdd(&s_tmp[2], 1);
+      if (slot < 64) s_small[slot] = key;
+    }
+  }
+  __syncthreads();
+  const int m = s_tmp[2];
+  if (m <= 64 && tid < 64) {
+    const uint32_t mykey = tid < m ? s_small[tid] : 0xffffffffu;
+    int rank = 0;
+    for (int j = 0; j < m; ++j) rank += s_small[j] < mykey;
+    if (tid < m && rank == kin - 1) s_tmp[3] = (int)mykey;   // keys are distinct: exactly one lane
+  }
+  __syncthreads();
+  *done = m <= 64;
+  const uint32_t r = (uint32_t)s_tmp[3];
+  __syncthreads();
+  return r;
+}
+
 __global__ __launch_bounds__(kThreadsS) void sample_select_kernel(
     const int* __restrict__ assigned_all, int A, int num, int n_exp_pos, float neg_pos_ub,
     uint32_t t0_neg, uint64_t seed, const long long* __restrict__ draw, SampleWs ws) {
-  __shared__ int hist[2048];
-  __shared__ int s_tmp[2];
+  __shared__ int hist[kBinsL];
+  __shared__ int s_tmp[8 + kThreadsS / 64];
+  __shared__ uint32_t s_small[64];
   const int n = blockIdx.x;
   const int* assigned = assigned_all + (size_t)n * A;
   const uint32_t offset = image_offset(seed, draw, n);
@@ -237,18 +311,26 @@ __global__ __launch_bounds__(kThreadsS) void sample_select_kernel(
   // thresholds (only when a strict subset is wanted)
   uint32_t thr_pos = 0xffffffffu, thr_neg = 0xffffffffu;
   if (k_pos > 0 && k_pos < n_pos) {
-    if (l_pos <= kCand)       // the list holds every positive's key
-      thr_pos = kth_smallest_key(ListKeys{ws.cand_pos + (size_t)n * kCand, l_pos}, k_pos, hist, s_tmp);
-    else
+    int done = 0;
+    if (l_pos <= kCand) {     // the list holds every positive's key
+      const uint32_t* lp = ws.cand_pos + (size_t)n * kCand;
+      thr_pos = kth_smallest_short(lp, l_pos, k_pos, 0xffffffffu, hist, s_tmp, s_small, &done);
+      if (!done) thr_pos = kth_smallest_key(ListKeys{lp, l_pos}, k_pos, hist, s_tmp);
+    } else {
       thr_pos = kth_smallest_key(AnchorKeys{assigned, A, 1, offset}, k_pos, hist, s_tmp);
+    }
   }
   if (k_neg > 0 && k_neg < n_neg) {
     // the list holds ALL negative keys <= t0_neg: its k-th smallest is the global one iff it has
     // at least k entries and none was dropped
-    if (l_neg <= kCand && (l_neg >= k_neg || t0_neg == 0xffffffffu))
-      thr_neg = kth_smallest_key(ListKeys{ws.cand_neg + (size_t)n * kCand, l_neg}, k_neg, hist, s_tmp);
-    else
+    if (l_neg <= kCand && (l_neg >= k_neg || t0_neg == 0xffffffffu)) {
+      const uint32_t* ln = ws.cand_neg + (size_t)n * kCand;
+      int done = 0;
+      thr_neg = kth_smallest_short(ln, l_neg, k_neg, t0_neg, hist, s_tmp, s_small, &done);
+      if (!done) thr_neg = kth_smallest_key(ListKeys{ln, l_neg}, k_neg, hist, s_tmp);
+    } else {
       thr_neg = kth_smallest_key(AnchorKeys{assigned, A, 0, offset}, k_neg, hist, s_tmp);
+    }
   }
   if (threadIdx.x == 0) {
     ctr[4] = (int)thr_pos;
@@ -358,8 +440,13 @@ __global__ __launch_bounds__(kThreadsS) void sample_rois_kernel(CandTable T, int
   if (tid < 2) s_cnt[tid] = 0;
   __syncthreads();
   // composite = class (0 pos, 1 neg, 2 other / padding) : 2 | key : 32 | index : 16 .. unique
+  // The network is sized to the next power of two >= the candidate count (cfg[1]: 2020 -> 2048, 66 stages of
+  // one compare-exchange per thread instead of 78 stages of two): the composites are unique and the padding
+  // is the largest value, so the first `A` sorted entries do not depend on the network size.
+  int P = 64;
+  while (P < A) P <<= 1;
   int c_pos = 0, c_neg = 0;
-  for (int i = tid; i < kMaxCand; i += kThreadsS) {
+  for (int i = tid; i < P; i += kThreadsS) {
     unsigned long long comp = ~0ull;
     if (i < A) {
       const int a = assigned[i];
@@ -378,10 +465,10 @@ __global__ __launch_bounds__(kThreadsS) void sample_rois_kernel(CandTable T, int
     atomicAdd(&s_cnt[1], c_neg);
   }
   __syncthreads();
-  // bitonic sort, ascending, kMaxCand composites (2 compare-exchanges per thread and stage)
-  for (int size = 2; size <= kMaxCand; size <<= 1) {
+  // bitonic sort, ascending
+  for (int size = 2; size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int j = tid; j < kMaxCand / 2; j += kThreadsS) {
+      for (int j = tid; j < P / 2; j += kThreadsS) {
         const int lo = 2 * j - (j & (stride - 1));
         const int hi = lo + stride;
         const bool asc = ((lo & size) == 0);

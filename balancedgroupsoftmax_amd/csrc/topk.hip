@@ -6,11 +6,12 @@
 // per image and level, then the 2000 best of the 10,000 NMS survivors per image.  The torch
 // library answers each of the six calls with its own multi-kernel radix select + sort (15-40
 // launches, 0.5 ms per iteration in total, profiles/r2v_detector_prof_summary.md); here ALL rows of
-// a call set (different lengths, different k) go through the same eight launches:
+// a call set (different lengths, different k) go through the same five launches:
 //
-//   3 x { hist   (G x P workgroups)  LDS histogram of the next 11 / 11 / 10 key bits of the
-//                                    elements that match the prefix found so far -> global bins
-//         pick   (P workgroups)      walk the bins from the top until k is covered: next digit }
+//   3 x hist     (G x P workgroups)  LDS histogram of the next 11 / 11 / 10 key bits of the
+//                                    elements that match the prefix found so far -> global bins; the
+//                                    digit of the PREVIOUS pass (bins walked from the top until k is
+//                                    covered) is found by every workgroup for itself first
 //   collect (G x P workgroups)       keys above the exact 32-bit threshold (and exactly as many
 //                                    equal to it as are still missing) -> a k-entry list
 //   sort    (P workgroups)           bitonic sort of the <= 4096 (key, index) composites in LDS,
@@ -20,7 +21,7 @@
 // sort larger values first and, among equal values, smaller indices first.  Which of several
 // elements EQUAL to the threshold value are taken is unspecified (as in torch.topk).
 // HBM-bound in principle (4 reads of the rows: 6.4 MB for the largest level of two images), in
-// practice latency-bound: ~8 short launches.
+// practice latency-bound: five short launches.
 #include "bgs_common.h"
 
 namespace {
@@ -49,7 +50,7 @@ __device__ __forceinline__ float topk_elem(const TopkProblems& pr, int p, const 
 }
 
 struct TopkWs {
-  int* hist;                    // [P, kBins]
+  int* hist;                    // [P, 3, kBins]: one histogram per pass
   unsigned* state;              // [P, kState]
   unsigned long long* list;     // [P, kmax]
 };
@@ -65,66 +66,99 @@ __device__ __forceinline__ float value_of(unsigned key) {
 __device__ __forceinline__ int shift_of(int pass) { return pass == 0 ? 21 : (pass == 1 ? 10 : 0); }
 __device__ __forceinline__ int bins_of(int pass) { return pass == 2 ? 1024 : 2048; }
 
-__global__ __launch_bounds__(256) void topk_hist_kernel(TopkProblems pr, TopkWs ws, int pass) {
-  __shared__ int h[kBins];
-  const int p = blockIdx.y, tid = threadIdx.x;
-  const int len = pr.len[p];
-  const int lo = blockIdx.x * kChunk;
-  if (lo >= len) return;                                  // workgroup-uniform
-  const int hi = min(len, lo + kChunk);
-  const int nb = bins_of(pass), shift = shift_of(pass);
-  for (int b = tid; b < nb; b += 256) h[b] = 0;
-  __syncthreads();
-  const unsigned prefix = ws.state[p * kState + 0], pmask = ws.state[p * kState + 1];
-  const float* row = pr.row[p];
-  for (int i = lo + tid; i < hi; i += 256) {
-    const unsigned key = key_of(topk_elem(pr, p, row, i));
-    if ((key & pmask) == prefix) atomicAdd(&h[(key >> shift) & (nb - 1)], 1);
-  }
-  __syncthreads();
-  int* g = ws.hist + (size_t)p * kBins;
-  for (int b = tid; b < nb; b += 256)
-    if (h[b]) atomicAdd(&g[b], h[b]);
-}
-
-// one wave per problem: bins are walked from the TOP (largest keys) until k_rem is covered
-__global__ __launch_bounds__(64) void topk_pick_kernel(TopkProblems pr, TopkWs ws, int pass) {
-  const int p = blockIdx.x, lane = threadIdx.x;
-  const int nb = bins_of(pass), shift = shift_of(pass);
-  int* g = ws.hist + (size_t)p * kBins;
-  unsigned* st = ws.state + p * kState;
-  int k_rem = pass == 0 ? min(pr.k[p], pr.len[p]) : (int)st[2];
-  const int per = nb / 64;                                 // bins per lane, lane 0 = top bins
+// The digit of one pass, by all 256 threads of a workgroup: the bins of `g` (the finished global histogram of
+// that pass) are walked from the TOP (largest keys) until k_rem is covered.  Returns the digit and the number
+// still to take inside it (>= 1).  Every workgroup of the NEXT launch does this for itself (2048 bins from the
+// L2, one scan) — the separate one-wave pick launches (3 x 6 us + boundaries) are gone.
+__device__ __forceinline__ void topk_pick(const int* __restrict__ g, int nb, int k_rem, int* s_wave, int* s_res,
+                                          int& digit, int& k_in) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = nb / 256;                                // bins per thread, thread 0 = top bins
+  int cnt[8];
   int mine = 0;
-  for (int j = 0; j < per; ++j) mine += g[nb - 1 - (lane * per + j)];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    cnt[j] = j < per ? g[nb - 1 - (tid * per + j)] : 0;
+    mine += cnt[j];
+  }
   int incl = mine;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const int t = __shfl_up(incl, off, 64);
     if (lane >= off) incl += t;
   }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += s_wave[w];
+  incl += base;
   const int excl = incl - mine;
-  if (k_rem > 0 && excl < k_rem && k_rem <= incl) {        // exactly one lane
-    int c = excl, digit = 0;
-    for (int j = 0; j < per; ++j) {
-      const int b = nb - 1 - (lane * per + j);
-      const int cnt = g[b];
-      if (k_rem <= c + cnt) {
-        digit = b;
-        break;
+  if (excl < k_rem && k_rem <= incl) {                     // exactly one thread (k_rem >= 1)
+    int c = excl, d = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < per) {
+        if (k_rem <= c + cnt[j]) {
+          d = nb - 1 - (tid * per + j);
+          break;
+        }
+        c += cnt[j];
       }
-      c += cnt;
     }
-    st[0] |= (unsigned)digit << shift;
-    st[1] |= (unsigned)(nb - 1) << shift;
-    st[2] = (unsigned)(k_rem - c);                         // still to take inside this digit (>= 1)
-  } else if (k_rem <= 0 && lane == 0) {
-    st[1] = 0xffffffffu;                                   // k == 0: nothing passes
-    st[0] = 0xffffffffu;
-    st[2] = 0u;
+    s_res[0] = d;
+    s_res[1] = k_rem - c;
   }
   __syncthreads();
-  for (int b = lane; b < kBins; b += 64) g[b] = 0;         // ready for the next pass
+  digit = s_res[0];
+  k_in = s_res[1];
+  __syncthreads();                                         // (s_wave / s_res may be reused)
+}
+
+// state words per problem: [0..2] prefix, mask, k_rem after the first digit (written by workgroup 0 of pass 1,
+// read by pass 2), [5..7] the same after the second digit (written by pass 2, read by collect); [3], [4] the
+// list counters of collect.  Workgroups of one launch never read what a sibling writes.
+__global__ __launch_bounds__(256) void topk_hist_kernel(TopkProblems pr, TopkWs ws, int pass) {
+  __shared__ int h[kBins];
+  __shared__ int s_wave[4], s_res[2];
+  const int p = blockIdx.y, tid = threadIdx.x;
+  const int len = pr.len[p];
+  const int lo = blockIdx.x * kChunk;
+  if (lo >= len) return;                                  // workgroup-uniform
+  const int hi = min(len, lo + kChunk);
+  const int k = min(pr.k[p], len);
+  if (k <= 0) return;                                     // nothing is selected from this row
+  const int nb = bins_of(pass), shift = shift_of(pass);
+  for (int b = tid; b < nb; b += 256) h[b] = 0;
+  unsigned* st = ws.state + p * kState;
+  unsigned prefix = 0, pmask = 0;
+  if (pass > 0) {
+    int k_rem = k;
+    if (pass == 2) {
+      prefix = st[0];
+      pmask = st[1];
+      k_rem = (int)st[2];
+    }
+    int digit, k_in;
+    topk_pick(ws.hist + ((size_t)p * 3 + (pass - 1)) * kBins, bins_of(pass - 1), k_rem, s_wave, s_res, digit, k_in);
+    prefix |= (unsigned)digit << shift_of(pass - 1);
+    pmask |= (unsigned)(bins_of(pass - 1) - 1) << shift_of(pass - 1);
+    if (blockIdx.x == 0 && tid == 0) {
+      unsigned* o = st + (pass == 1 ? 0 : 5);
+      o[0] = prefix;
+      o[1] = pmask;
+      o[2] = (unsigned)k_in;
+    }
+  }
+  __syncthreads();
+  const float* row = pr.row[p];
+  for (int i = lo + tid; i < hi; i += 256) {
+    const unsigned key = key_of(topk_elem(pr, p, row, i));
+    if ((key & pmask) == prefix) atomicAdd(&h[(key >> shift) & (nb - 1)], 1);
+  }
+  __syncthreads();
+  int* g = ws.hist + ((size_t)p * 3 + pass) * kBins;
+  for (int b = tid; b < nb; b += 256)
+    if (h[b]) atomicAdd(&g[b], h[b]);
 }
 
 __global__ __launch_bounds__(256) void topk_collect_kernel(TopkProblems pr, TopkWs ws, int kmax) {
@@ -135,11 +169,13 @@ __global__ __launch_bounds__(256) void topk_collect_kernel(TopkProblems pr, Topk
   const int hi = min(len, lo + kChunk);
   const int k = min(pr.k[p], len);
   unsigned* st = ws.state + p * kState;
-  const unsigned T = st[0];
-  const int need_eq = (int)st[2];
   unsigned long long* list = ws.list + (size_t)p * kmax;
   const float* row = pr.row[p];
   if (k <= 0) return;
+  __shared__ int s_wave[4], s_res[2];
+  int digit, need_eq;
+  topk_pick(ws.hist + ((size_t)p * 3 + 2) * kBins, bins_of(2), (int)st[7], s_wave, s_res, digit, need_eq);
+  const unsigned T = st[5] | ((unsigned)digit << shift_of(2));   // the exact 32-bit threshold key
   const int lane = tid & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
   // The selected elements of this chunk are collected in LDS (one LDS atomic per wave and list) and appended with
@@ -244,7 +280,7 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(TopkProblems pr, TopkWs
 
 extern "C" size_t bgs_topk_workspace_bytes(int P, int kmax) {
   if (P <= 0 || kmax <= 0) return 0;
-  return (size_t)P * (kBins * sizeof(int) + kState * sizeof(unsigned) +
+  return (size_t)P * (3 * kBins * sizeof(int) + kState * sizeof(unsigned) +
                       (size_t)kmax * sizeof(unsigned long long));
 }
 
@@ -280,17 +316,15 @@ extern "C" int bgs_topk_sorted_f32(const float* const* host_rows, const int* hos
   }
   TopkWs ws;
   ws.hist = reinterpret_cast<int*>(workspace);
-  ws.state = reinterpret_cast<unsigned*>(ws.hist + (size_t)P * kBins);
+  ws.state = reinterpret_cast<unsigned*>(ws.hist + (size_t)P * 3 * kBins);
   ws.list = reinterpret_cast<unsigned long long*>(ws.state + (size_t)P * kState);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(workspace, 0, (size_t)P * (kBins * sizeof(int) + kState * sizeof(unsigned)),
+  if (hipMemsetAsync(workspace, 0, (size_t)P * (3 * kBins * sizeof(int) + kState * sizeof(unsigned)),
                      st) != hipSuccess)
     return BGS_ERR_LAUNCH;
   const int G = maxlen > 0 ? (maxlen + kChunk - 1) / kChunk : 1;
-  for (int pass = 0; pass < 3; ++pass) {
+  for (int pass = 0; pass < 3; ++pass)
     hipLaunchKernelGGL(topk_hist_kernel, dim3(G, P), dim3(256), 0, st, pr, ws, pass);
-    hipLaunchKernelGGL(topk_pick_kernel, dim3(P), dim3(64), 0, st, pr, ws, pass);
-  }
   hipLaunchKernelGGL(topk_collect_kernel, dim3(G, P), dim3(256), 0, st, pr, ws, kmax);
   hipLaunchKernelGGL(topk_sort_kernel, dim3(P), dim3(1024), 0, st, pr, ws, kmax, out_val, out_idx);
   BGS_RETURN_LAUNCH_STATUS();

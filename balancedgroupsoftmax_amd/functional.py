@@ -33,6 +33,53 @@ def reset_workspaces():
     _WS.clear()
 
 
+_SIDE = {}
+
+
+def level_fork_enabled():
+    """Small pyramid levels on a side stream (FPN output convs, RPN head): ``BGS_LEVEL_FORK=0`` turns it off."""
+    return os.environ.get('BGS_LEVEL_FORK', '1') != '0'
+
+
+class forked(object):
+    """``with forked(device) as f: <launches>`` issues the block on the device's side stream, ordered after
+    everything enqueued on the current stream so far; ``f.join()`` makes the current stream wait for it.
+
+    Why: the stride-16 / 32 / 64 pyramid levels launch 168 / 48 / 16 workgroups on 256 CUs; next to the P2-level
+    launch of the same layer (2100 workgroups) they fill CUs that would idle in its tail instead of taking their
+    own serial slot (tools/stream_overlap_ab.py: 1.10 -> 1.02 ms for the five FPN output convs, eagerly and in
+    a replayed hipGraph).  Dependent chains of tiny kernels do NOT gain from a fork (an event edge costs more than
+    a back-to-back launch: 69 -> 139 us for two chains of 20), so only conv launches are forked.
+    Tensors allocated inside the block belong to the side stream's pool; they are consumed after ``join()`` and
+    freed after it, and the next block starts with an event recorded after those consumers: no reuse race."""
+
+    def __init__(self, device):
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        if key not in _SIDE:
+            _SIDE[key] = torch.cuda.Stream(device=device)
+        self.side = _SIDE[key]
+        self.device = device
+        self.done = None
+
+    def __enter__(self):
+        main = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.side.wait_event(ev)
+        self._ctx = torch.cuda.stream(self.side)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.done = torch.cuda.Event()
+        self.done.record(self.side)
+        self._ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        torch.cuda.current_stream(self.device).wait_event(self.done)
+
+
 def _require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -626,6 +673,15 @@ def bfx_split_weights(w2d, cache=True):
             _SPLIT_CACHE.pop(next(iter(_SPLIT_CACHE)))      # oldest entry (insertion order)
         _SPLIT_CACHE[key] = (w2d._version, (rows, K), w2d, out)
     return out
+
+
+def presplit(*weights):
+    """Fill the split cache for frozen conv filters ``[Cout,R,S,Cin]`` on the CURRENT stream — before a
+    :class:`forked` block whose launches (on two streams) share them."""
+    for w in weights:
+        if w is not None and w.is_cuda and w.dim() == 4 and not w.requires_grad and \
+                (_CONV_MATH[0] != 'f32' or bf16_storage_active()):
+            bfx_split_weights(w.view(w.shape[0], -1), cache=True)
 
 
 def bfx_split_weights_dgrad(w_krsc, cache=True):

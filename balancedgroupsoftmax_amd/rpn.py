@@ -139,12 +139,23 @@ class RPNHead(nn.Module):
     def forward(self, feats):
         """NHWC feature maps -> (cls_scores, bbox_preds): per level ``[N,H,W,A]``, ``[N,H,W,4A]``."""
         f = self._cache.get(self, self._build_fold)
-        cls_scores, bbox_preds, fused = [], [], []
+        cls_scores, bbox_preds = [], []
         na = self.num_anchors * self.cls_out_channels
-        for x in feats:
+
+        def level(x):
             h = BF.conv2d_autograd(x, f['conv'][0], f['conv'][1], pad=1, relu='consumers')
-            o = BF.conv2d_autograd(h, f['head'][0], f['head'][1], mask_input=True)
-            fused.append(o)
+            return BF.conv2d_autograd(h, f['head'][0], f['head'][1], mask_input=True)
+
+        if len(feats) > 1 and feats[0].is_cuda and BF.level_fork_enabled():
+            # the small levels next to the P2-level launches (functional.forked)
+            BF.presplit(f['conv'][0], f['head'][0])      # shared by both streams: cached before the fork
+            with BF.forked(feats[0].device) as fk:
+                small = [level(x) for x in feats[1:]]
+            fused = [level(feats[0])] + small
+            fk.join()
+        else:
+            fused = [level(x) for x in feats]
+        for o in fused:
             cls_scores.append(o[..., :na])
             bbox_preds.append(o[..., na:])
         self._fused = fused      # [N,H,W,A+4A] per level: what the fused loss / decode kernels read
