@@ -832,6 +832,7 @@ struct HaloBfxArgs {
   int tiles_y, tiles_x;
   int chunks_per_split;  // channel chunks per gridDim.z slice
   const unsigned* zero = nullptr;   // device zero page (DMA source of out-of-range rows, variant 4)
+  int flags = 0;         // experiments (bgs_conv3x3_halo_bfx_tuning bits 20..23)
 };
 
 // The halo kernels' epilogue through an LDS transpose (see conv_store_tile_lds): the 8 x 16 pixel x
@@ -1307,7 +1308,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxA
 // a cfg[1] forward (profiles/r2x_halo4_sweep.txt).  The patch keeps the register path (global
 // load, split, ds_write_b64): a DMA of a pre-split ("split-form") patch written by the producing
 // layer's epilogue was built and measured too — no faster, 1.5x the activation bytes: removed.
-// LDS: 24 KB filter double buffer + 1 KB scratch (dummy pieces) + 25.3 KB patch.
+// LDS: 24 KB filter double buffer + 1 KB scratch (dummy pieces) + 16.9 KB patch (8 x 16 tile; 25.3 KB otherwise).
 // (NS = 1: the bf16 mode — hi planes only, one MFMA per product.)
 // PF (variant 5): the A fragments of tap t + 1 are read from the patch DURING tap t's MFMAs — the
 // patch does not change inside a channel chunk, so those reads need not sit behind the step's
@@ -1316,7 +1317,11 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxA
 // (0, 0) and are never stored).  8 x 16 everywhere but on the small maps, where the tile that wastes the fewest
 // rows is chosen per layer (halo_bfx_geom: 50 x 84 -> 10 x 12: 35 tiles per image instead of 42; 25 x 42 -> 5 x 21:
 // 10 instead of 12).
-template <int NB, int NS = 3, bool PF = false, int GTH = 8, int GTW = 16>
+// Measured and not kept (profiles/r8h_halo_lds_layout_ring3_dma_ablation.txt): a ring of three filter slices with
+// counted waits (the slice gets two steps to land: 0.717 -> 0.744 ms on the P2 layer), ONE filter buffer with a
+// second barrier (four workgroups per CU: 0.92 ms).  What the step is co-limited by besides the matrix pipe is the
+// 12 KB filter slice per workgroup and tap itself (timing-only ablation: 0.77 ms with it, 0.52 ms without).
+template <int NB, int NS = 3, bool PF = false, int GTH = 8, int GTW = 16, bool PADDED = false>
 __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxArgs q) {
   const ConvArgs& p = q.c;
   constexpr int TH = GTH, TW = GTW, PH = TH + 2, PW = TW + 2, PROWS = PH * PW;      // (shadow the 8 x 16 default)
@@ -1324,9 +1329,20 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
   static_assert(TH * TW <= 128 && PROWS <= 180 && AQT <= 3, "patch no larger than the 8 x 16 tile's");
   constexpr int BN = 64 * NB;
   constexpr int B_PLANE = BN * 32, B_BUF = NS * B_PLANE;
-  constexpr int SCR = 2 * B_BUF;                         // 1 KB scratch: target of dummy pieces
-  constexpr int A_OFF = SCR + 1024;
-  constexpr int A_PLANE = PROWS * HLDR;
+  constexpr int SCR = 2 * B_BUF;                         // 1 KB scratch: target of dummy pieces (NB = 1 only)
+  constexpr int A_OFF = SCR + (NB == 1 ? 1024 : 0);
+  // Patch layout.  8 x 16 tile: 32 bytes per patch pixel (its 16 bf16, no padding); the two 16-byte k halves of
+  // pixel (r, c) are swapped when r + c is odd.  Every 16-lane group of the A-fragment ds_read_b128 (lanes
+  // {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}: eight pixels of patch row R and eight of row R + 1) then covers
+  // the 16 slots of the 256-byte bank row exactly once for every tap: the two rows' pixels that share a slot pair
+  // have columns of equal parity, i.e. r + c of opposite parity.  The 48-byte rows used before (and still for the
+  // other tiles) are conflict-free for 32 CONSECUTIVE pixels but not across the 18-pixel row wrap: every group
+  // 2-way, 24 of a wave's 72 LDS cycles per step — the 34 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of
+  // profiles/r5_pmc_final_tree.md — and the ds_write_b64 of the split (four pixels = 192 bytes per 16 lanes) was
+  // 2-way as well; 32-byte pixels make that store one 128-byte window per lane group.
+  constexpr bool SWZ = GTH == 8 && GTW == 16 && !PADDED;      // (PADDED: the 48-byte rows on the 8 x 16 tile, A/B only)
+  constexpr int HL = SWZ ? 32 : HLDR;
+  constexpr int A_PLANE = PROWS * HL;
   constexpr int OPER_BYTES = A_OFF + NS * A_PLANE, EPI_BYTES = 64 * (BN + 4) * 4;   // operands | epilogue tile
   __shared__ __attribute__((aligned(1024))) unsigned char lds[OPER_BYTES > EPI_BYTES ? OPER_BYTES : EPI_BYTES];
   const unsigned* __restrict__ zero_page = q.zero;
@@ -1359,8 +1375,13 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
     const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page);
     if (NB == 2) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s)
+      for (int s = 0; s < NS; ++s) {
+#ifdef BGS_ABLATE
+        if ((q.flags & 4) && s > 0) continue;                    // timing only: one of the three plane DMAs
+        if (q.flags & 8) continue;                               // timing only: no filter DMA at all
+#endif
         glds16(b_okd ? b_lane + s * b_plane + koff : zp, lds + buf_off + s * B_PLANE + wave * 1024);
+      }
     } else if (NS == 3) {
       const int s0 = wave >> 1;                                  // piece w: plane w / 2, half w % 2
       glds16(b_okd ? b_lane + s0 * b_plane + koff : zp, lds + buf_off + s0 * B_PLANE + (wave & 1) * 1024);
@@ -1387,7 +1408,8 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
     const bool in = a_use[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
     a_src[i] = in ? p.x + (((size_t)n * p.H + hi) * p.W + wi) * p.Cin + kq * 4
                   : reinterpret_cast<const float*>(g_zero_page);
-    a_dst[i] = (in ? 1 : 0) | ((prow * HLDR + kq * 8) << 1);   // bit 0: advances with the chunk
+    const int kq_off = SWZ ? ((((kq >> 1) ^ ((pr + pc) & 1)) << 4) + (kq & 1) * 8) : kq * 8;
+    a_dst[i] = (in ? 1 : 0) | ((prow * HL + kq_off) << 1);     // bit 0: advances with the chunk
   }
   auto load_a = [&](int chunk) {
 #pragma unroll
@@ -1409,12 +1431,15 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
 
   // ---- fragment roles: lane frow of sub-tile a owns pixel m = 64 wm + 32 a + frow
   const int frow = lane & 31, fk = lane >> 5;
-  int a_frag[2];
+  int a_frag[2][2];                                                       // [sub-tile][parity of the tap's dy + dx]
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     int m = wm * 64 + a * 32 + frow;
     if (TH * TW < 128 && m >= TH * TW) m = 0;                             // padding row: any valid patch pixel
-    a_frag[a] = A_OFF + ((m / TW) * PW + (m % TW)) * HLDR + fk * 16;      // patch row of tap (0, 0)
+    const int pr = m / TW, pc = m % TW;                                   // patch pixel of tap (0, 0)
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+      a_frag[a][par] = A_OFF + (pr * PW + pc) * HL + ((SWZ ? (fk ^ ((pr + pc + par) & 1)) : fk) << 4);
   }
   const int brow = wn * 32 * NB + frow;                           // + 32 b: same 8-row-group parity
   const int b_frag = brow * 32 + ((fk ^ ((brow >> 3) & 1)) << 4);
@@ -1427,6 +1452,13 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  if (q.flags & 2) {                                             // static priority = hardware wave slot on the SIMD
+    const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));   // HW_ID.WAVE_ID [3:0]
+    const unsigned pr = hwid & 3u;
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+  }
   load_a(c_begin);
   issue_b(c_begin, 0, 0);
   store_a();
@@ -1443,26 +1475,32 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
       if (tap < 8) issue_b(chunk, tap + 1, wr);                   // next filter slice: DMA in flight
       else if (!last_chunk) issue_b(chunk + 1, 0, wr);
       if (tap == 0 && !last_chunk) load_a(chunk + 1);             // next patch: held in registers
-      const int tap_off = ((tap / 3) * PW + (tap % 3)) * HLDR;    // compile-time constant
+      const int tap_off = ((tap / 3) * PW + (tap % 3)) * HL;      // compile-time constants
+      const int tap_par = (tap / 3 + tap % 3) & 1;
       bf16x8 fa[NS][2], fb[NS][NB];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           if (PF && tap > 0) fa[s][a] = fa_next[s][a];
-          else fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a] + tap_off + s * A_PLANE);
+          else fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a][tap_par] + tap_off + s * A_PLANE);
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b)
           fb[s][b] = *reinterpret_cast<const bf16x8*>(lds + rd + b_frag + s * B_PLANE + b * 32 * 32);
       }
       if (PF && tap < 8) {                                         // tap + 1's patch rows: in flight under the MFMAs
-        const int nxt_off = (((tap + 1) / 3) * PW + ((tap + 1) % 3)) * HLDR;
+        const int nxt_off = (((tap + 1) / 3) * PW + ((tap + 1) % 3)) * HL;
+        const int nxt_par = ((tap + 1) / 3 + (tap + 1) % 3) & 1;
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
           for (int a = 0; a < 2; ++a)
-            fa_next[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a] + nxt_off + s * A_PLANE);
+            fa_next[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a][nxt_par] + nxt_off + s * A_PLANE);
+      }
+      if (q.flags & 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
       }
 #pragma unroll
       for (int tt = NS - 1; tt >= 0; --tt)
@@ -1474,6 +1512,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
             for (int b = 0; b < NB; ++b)
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[tt - i][b], acc[a][b],
                                                                   0, 0, 0);
+      if (q.flags & 1) __builtin_amdgcn_s_setprio(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // next slice (and patch) landed
       __syncthreads();
       if (tap == 8 && !last_chunk) {                              // every wave is done with this patch
@@ -1523,7 +1562,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
 }
 
 int g_halo_last_nb = 0, g_halo_last_splits = 0, g_halo_last_variant = 0;
-int g_halo_force_splits = -1, g_halo_variant = 4, g_halo_pf = 0;
+int g_halo_force_splits = -1, g_halo_variant = 4, g_halo_pf = 0, g_halo_padded = 0, g_halo_flags = 1;
 
 // Pixel-tile geometry of the v4 kernel for an H x W map: the instantiated tile with the fewest tiles per image
 // (every tile costs the same 128 MFMA rows), 8 x 16 unless another one saves at least 5 % — mode 3; modes 0 / 1 / 2
@@ -1985,6 +2024,7 @@ extern "C" size_t bgs_conv3x3_halo_bfx_workspace_bytes(int N, int H, int W, int 
 
 extern "C" void bgs_conv3x3_halo_bfx_tuning(int splits, int variant) {
   g_ablate = (variant >> 8) & 0xff;          // timing-only ablation modes (-DBGS_ABLATE builds)
+  const int variant0 = variant;
   g_halo_geom = ((variant >> 16) & 0xf) - 1; // 0: default pixel tile | 1: 8 x 16 | 2: 10 x 12 | 3: 5 x 21 | 4: fewest tiles
   if (g_halo_geom > 3) g_halo_geom = -1;
   variant &= 0xff;
@@ -1993,6 +2033,11 @@ extern "C" void bgs_conv3x3_halo_bfx_tuning(int splits, int variant) {
   // filter slices), 4 (and 0 = the default) = filter slices by LDS-DMA
   g_halo_variant = variant == 1 ? 1 : (variant == 2 ? 2 : 4);
   g_halo_pf = variant == 5 ? 1 : 0;        // 5 = variant 4 + A-fragment prefetch across the barrier
+  // bits 20..23: 0 default (= 1) | 1: s_setprio 1 around the MFMA cluster | 2: static priority = hardware wave slot |
+  // 8: none (A/B);  -DBGS_ABLATE builds: 4 / 8 drop two / all of the filter-plane DMAs (timing only)
+  g_halo_flags = (variant0 >> 20) & 0xf;
+  if (g_halo_flags == 0) g_halo_flags = 1;
+  g_halo_padded = variant == 6 ? 1 : 0;    // 6 = variant 4 with the 48-byte patch rows (before the swizzled 32-byte pixels)
 }
 
 extern "C" int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits) {
@@ -2069,6 +2114,7 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wspl
   if (v4) {
     q.zero = zero_page_device();
     if (!q.zero) return BGS_ERR_LAUNCH;
+    q.flags = g_halo_flags;
     bgs_internal_census_bump(BGS_CENSUS_HALO_BFX4);
     if (q.ns == 1) {
       if (nb == 1) hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
@@ -2081,6 +2127,8 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wspl
       else hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, 3, false, 5, 21>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
     } else if (nb == 1) {
       hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, 3>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+    } else if (g_halo_padded) {
+      hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, 3, false, 8, 16, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
     } else if (g_halo_pf) {
       hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, 3, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);
     } else {

@@ -710,12 +710,13 @@ def bfx_split_weights_dgrad(w_krsc, cache=True):
     return out
 
 
-def conv_bfx_tuning(tile=0, splitk=-1, halo_splits=-1, halo_variant=0, halo_geom=-1):
+def conv_bfx_tuning(tile=0, splitk=-1, halo_splits=-1, halo_variant=0, halo_geom=-1, halo_flags=0):
     """Process-wide tuning / test hook of the bf16x6 kernels (see include/bgs_tuning.h).  ``halo_geom``: the
     pixel tile of the halo kernel, -1 default | 0: 8 x 16 | 1: 10 x 12 | 2: 5 x 21 | 3: fewest tiles per image."""
     lib = capi.load()
     lib.bgs_conv_bfx_tuning(int(tile), int(splitk))
-    lib.bgs_conv3x3_halo_bfx_tuning(int(halo_splits), int(halo_variant) | ((int(halo_geom) + 1) << 16))
+    lib.bgs_conv3x3_halo_bfx_tuning(int(halo_splits), int(halo_variant) | ((int(halo_geom) + 1) << 16) |
+                                    (int(halo_flags) << 20))
 
 
 def conv_bfx_last_launch():

@@ -22,33 +22,38 @@ def bench(fn, iters=30, warm=10):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-layers = [  # name, N, H, W, Cin, Cout, res_mode, count per step
-    ('l1.c3', 2, 200, 336, 64, 256, 1, 3), ('l2.c3', 2, 100, 168, 128, 512, 1, 4), ('l3.c3', 2, 50, 84, 256, 1024, 1, 6),
-    ('l4.c3', 2, 25, 42, 512, 2048, 1, 3), ('fpn.lat0', 2, 200, 336, 256, 256, 2, 1), ('fpn.lat1', 2, 100, 168, 512, 256, 2, 1),
-    ('fpn.lat2', 2, 50, 84, 1024, 256, 2, 1), ('odd', 3, 37, 29, 64, 132, 1, 0)]
-capi.load().bgs_conv_bfx_wide_tuning(0, 0, -1)       # the ring kernel on every layer
-tot = [0.0, 0.0]
-for name, N, H, W, Cin, Cout, rm, cnt in layers:
-    torch.manual_seed(1)
-    x = torch.randn(N, H, W, Cin, device=dev)
-    w = torch.randn(Cout, 1, 1, Cin, device=dev) * 0.05
-    b = torch.randn(Cout, device=dev)
-    res = torch.randn(N, H, W, Cout, device=dev) if rm == 1 else torch.randn(N, H // 2, W // 2, Cout, device=dev)
-    fn = lambda: BF.conv2d_nhwc(x, w, b, stride=1, pad=0, relu=True, residual=res, residual_mode=rm)  # noqa: E731
-    BF.conv_bfx_tuning(0x1000, -1)
-    y0 = fn().clone()
-    BF.conv_bfx_tuning(0, -1)
-    y1 = fn().clone()
-    eq = torch.equal(y0, y1)
-    t = [[], []]
-    for rep in range(3):
-        for arm, tile in ((0, 0x1000), (1, 0)):
-            BF.conv_bfx_tuning(tile, -1)
-            t[arm].append(bench(fn))
-    BF.conv_bfx_tuning(0, -1)
-    a, c = min(t[0]), min(t[1])
-    tot[0] += a * cnt
-    tot[1] += c * cnt
-    print('%-9s x%d | epilogue read %6.1f us | ahead of the K loop %6.1f us | equal %s | launch %s' %
-          (name, cnt, a, c, eq, BF.conv_bfx_last_launch()), flush=True)
-print('per step: %.1f -> %.1f us' % tuple(tot))
+def main():
+    layers = [  # name, N, H, W, Cin, Cout, res_mode, count per step
+        ('l1.c3', 2, 200, 336, 64, 256, 1, 3), ('l2.c3', 2, 100, 168, 128, 512, 1, 4), ('l3.c3', 2, 50, 84, 256, 1024, 1, 6),
+        ('l4.c3', 2, 25, 42, 512, 2048, 1, 3), ('fpn.lat0', 2, 200, 336, 256, 256, 2, 1), ('fpn.lat1', 2, 100, 168, 512, 256, 2, 1),
+        ('fpn.lat2', 2, 50, 84, 1024, 256, 2, 1), ('odd', 3, 37, 29, 64, 132, 1, 0)]
+    capi.load().bgs_conv_bfx_wide_tuning(0, 0, -1)       # the ring kernel on every layer
+    tot = [0.0, 0.0]
+    for name, N, H, W, Cin, Cout, rm, cnt in layers:
+        torch.manual_seed(1)
+        x = torch.randn(N, H, W, Cin, device=dev)
+        w = torch.randn(Cout, 1, 1, Cin, device=dev) * 0.05
+        b = torch.randn(Cout, device=dev)
+        res = torch.randn(N, H, W, Cout, device=dev) if rm == 1 else torch.randn(N, H // 2, W // 2, Cout, device=dev)
+        fn = lambda: BF.conv2d_nhwc(x, w, b, stride=1, pad=0, relu=True, residual=res, residual_mode=rm)  # noqa: E731
+        BF.conv_bfx_tuning(0x1000, -1)
+        y0 = fn().clone()
+        BF.conv_bfx_tuning(0, -1)
+        y1 = fn().clone()
+        eq = torch.equal(y0, y1)
+        t = [[], []]
+        for rep in range(3):
+            for arm, tile in ((0, 0x1000), (1, 0)):
+                BF.conv_bfx_tuning(tile, -1)
+                t[arm].append(bench(fn))
+        BF.conv_bfx_tuning(0, -1)
+        a, c = min(t[0]), min(t[1])
+        tot[0] += a * cnt
+        tot[1] += c * cnt
+        print('%-9s x%d | epilogue read %6.1f us | ahead of the K loop %6.1f us | equal %s | launch %s' %
+              (name, cnt, a, c, eq, BF.conv_bfx_last_launch()), flush=True)
+    print('per step: %.1f -> %.1f us' % tuple(tot))
+
+
+if __name__ == '__main__':
+    main()
