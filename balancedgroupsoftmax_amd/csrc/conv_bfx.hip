@@ -1320,7 +1320,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx3_kernel(HaloBfxA
 // Measured and not kept (profiles/r8h_halo_lds_layout_ring3_dma_ablation.txt): a ring of three filter slices with
 // counted waits (the slice gets two steps to land: 0.717 -> 0.744 ms on the P2 layer), ONE filter buffer with a
 // second barrier (four workgroups per CU: 0.92 ms).  What the step is co-limited by besides the matrix pipe is the
-// 12 KB filter slice per workgroup and tap itself (timing-only ablation: 0.77 ms with it, 0.52 ms without).
+// 12 KB filter slice per workgroup and tap itself (timing-only ablation: 0.77 ms with it, 0.52 ms without) — on
+// either path: a variant whose waves load their filter fragments straight from global memory into the MFMA's
+// registers (no filter LDS, no DMA, ONE barrier per channel chunk instead of ten, bit-identical) was 4.5 % slower.
 template <int NB, int NS = 3, bool PF = false, int GTH = 8, int GTW = 16, bool PADDED = false>
 __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxArgs q) {
   const ConvArgs& p = q.c;
