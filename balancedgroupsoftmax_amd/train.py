@@ -424,7 +424,14 @@ def wrap_fp16_model(model, math='bf16'):
     process-wide conv arithmetic for the duration of ``model(...)`` only, and every conv autograd
     node replays its backward in the mode its forward ran in — another model of the process (an
     fp32 teacher, an evaluation copy) keeps its own arithmetic.  Returns the conv math that stays
-    in force OUTSIDE the model (``unwrap_fp16_model`` removes the hooks)."""
+    in force OUTSIDE the model (``unwrap_fp16_model`` removes the hooks).
+
+    **Scope, read this:** the hooks fire on ``model(...)`` (``nn.Module.__call__``) ONLY.  Calling
+    ``model.forward_train`` / ``simple_test`` / ``extract_feat`` or a sub-module directly does NOT enter
+    the bf16 mode (it runs in whatever ``functional.conv_math()`` is in force, normally bf16x6) —
+    wrap such calls in ``with fp16_scope(model): ...``.  The return value is the OUTSIDE mode, not a
+    "previous mode" to restore: nothing needs restoring (round-2 callers that passed it back to
+    ``set_conv_math`` get the same end state)."""
     from . import functional as BF
     assert math in ('bf16',), math
     unwrap_fp16_model(model)
@@ -441,6 +448,28 @@ def wrap_fp16_model(model, math='bf16'):
     model._conv_math_hooks = (model.register_forward_pre_hook(_enter),
                               model.register_forward_hook(_exit, always_call=True))
     return BF.conv_math()
+
+
+class fp16_scope(object):
+    """``with fp16_scope(model): feats = model.extract_feat(img)`` — the arithmetic mode of a model wrapped by
+    :func:`wrap_fp16_model` for code that calls its methods or sub-modules directly instead of ``model(...)``.
+    A model that is not wrapped leaves the mode alone.  Restored on exit, also on error; re-entrant."""
+
+    def __init__(self, model):
+        self.math = getattr(model, '_conv_math', None)
+        self._prev = []
+
+    def __enter__(self):
+        from . import functional as BF
+        self._prev.append(BF.set_conv_math(self.math) if self.math else None)
+        return self
+
+    def __exit__(self, *exc):
+        from . import functional as BF
+        prev = self._prev.pop()
+        if prev is not None:
+            BF.set_conv_math(prev)
+        return False
 
 
 def unwrap_fp16_model(model):

@@ -217,6 +217,21 @@ def test_wrap_fp16_model_is_scoped_to_the_model():
     m(torch.zeros(1))
     other(torch.zeros(1))
     assert seen == ['bf16', outside] and BF.conv_math() == outside
+    # direct method / sub-module calls bypass the __call__ hooks; fp16_scope covers them
+    m.forward(torch.zeros(1))
+    assert seen[-1] == outside
+    with train.fp16_scope(m):
+        m.forward(torch.zeros(1))
+        assert seen[-1] == 'bf16'
+        with train.fp16_scope(other):          # not wrapped: leaves the mode alone
+            assert BF.conv_math() == 'bf16'
+    assert BF.conv_math() == outside
+    try:
+        with train.fp16_scope(m):
+            raise KeyError('x')
+    except KeyError:
+        pass
+    assert BF.conv_math() == outside
     train.unwrap_fp16_model(m)
     m(torch.zeros(1))
     assert seen[-1] == outside
