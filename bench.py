@@ -831,9 +831,11 @@ def roofline_step(out, args):
 
 def finish_line(out, args, dev, world):
     """Secondary measurements + per-kernel rooflines + CPU baseline, then the ONE JSON line."""
-    if world == 1 and not args.no_extras and args.selectp == 1 and not args.mask \
-            and not args.cascade and not args.htc:
-        out['also_measured'] = extras(dev, args)
+    # (per-kernel rooflines first: after the ~2 minutes of other configurations in `extras` the same launches
+    #  measure 8 - 15 % slower — rowwave kernel at N = 65536: 123 us alone, 141 us behind extras — the chip's
+    #  power state after sustained load, not the kernels; every measurement here is standalone)
+    run_extras = world == 1 and not args.no_extras and args.selectp == 1 and not args.mask \
+        and not args.cascade and not args.htc
     if not args.no_roofline:
         out['roofline'] = conv_roofline(dev, args.conv_math)
         if args.conv_math != 'f32':
@@ -849,6 +851,10 @@ def finish_line(out, args, dev, world):
         del big
         if world == 1:
             out['gs_head'] = gs_head_metric(gs_inp, 1024)
+        del gs_inp
+        torch.cuda.empty_cache()
+    if run_extras:
+        out['also_measured'] = extras(dev, args)
     if world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(1024, args.cpu_seconds)
         cb['note'] = ('GroupSoftmax loss()+backward() only: the reference cannot run the whole '
