@@ -80,14 +80,16 @@ constexpr int W_A_BYTES = 4 * W_A_WAVE;      // 8 KB
 // ABL (only instantiated != 0 under -DBGS_ABLATE, tools/wide_ablate.py): timing-only variants that drop one
 // component — 1: MFMAs, 2: DMA issue after the prologue, 4: the epilogue's global loads / stores, 8: the whole
 // epilogue, 16: the A split.
+// NBW = 4: 128 x 128 tile.  NBW = 2: 128 x 64 — twice the tiles (the stride-16 / 32 maps and the 64-channel layers,
+// where 128 x 128 leaves the chip half empty) at 0.7 of the ring's operand bytes per MFMA and half its A splits.
 template <int NBW, int NST, int ABL = 0>
-__global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_kernel(WideArgs q) {
+__global__ __launch_bounds__(kThreads, NBW == 2 ? (NST == 3 ? 3 : 5) : (NST == 3 ? 2 : 3)) void conv1x1_bfx_wide_kernel(WideArgs q) {
   const ConvArgs& p = q.c;
   constexpr int BN = 32 * NBW;
   constexpr int B_PLANE = BN * 32;                 // one bf16 plane of a K step: BN rows x 32 B
   constexpr int B_BYTES = 3 * B_PLANE;
-  constexpr int STAGE = W_A_BYTES + B_BYTES;       // NBW = 4: 20 KB
-  static_assert(NBW == 4, "one B piece = 32 rows: NBW = 4 gives every wave one piece per plane");
+  constexpr int STAGE = W_A_BYTES + B_BYTES;       // NBW = 4: 20 KB; NBW = 2: 14 KB
+  static_assert(NBW == 4 || NBW == 2, "one B piece = 32 rows: 12 (NBW = 4) or 6 (NBW = 2) pieces per stage");
   constexpr int EPI_BYTES = 64 * (BN + 4) * 4;
   constexpr int LDS_BYTES = NST * STAGE > EPI_BYTES ? NST * STAGE : EPI_BYTES;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
@@ -137,17 +139,25 @@ __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_k
     a_ptr[j] = p.x + (((size_t)n * p.H + (size_t)ho * p.stride) * p.W + (size_t)wo * p.stride) * p.Cin +
                (size_t)kt_begin * 16 + aq * 4;
   }
-  // ---- B DMA role: wave w carries rows 32 w .. 32 w + 31 of the three planes; halves swapped on odd 8-row groups
-  const __bf16* b_ptr;
-  {
-    const int row = wave * 32 + (lane >> 1);
+  // ---- B DMA role.  NBW = 4: wave w carries rows 32 w .. 32 w + 31 of the three planes (three pieces).  NBW = 2:
+  //      six pieces (plane j / 2, rows 32 (j % 2) ..): wave w takes piece w and, w < 2, piece w + 4.
+  //      Halves swapped on odd 8-row groups.
+  const size_t b_plane = (size_t)q.KC * p.Cout * 16;           // elements between planes
+  const size_t b_step = (size_t)p.Cout * 16;                   // elements between K steps
+  const int nb_mine = NBW == 4 ? 3 : (wave < 2 ? 2 : 1);       // wave-uniform
+  const __bf16* b_ptr[NBW == 4 ? 3 : 2];
+  int b_dst[NBW == 4 ? 3 : 2];
+#pragma unroll
+  for (int i = 0; i < (NBW == 4 ? 3 : 2); ++i) {
+    const int plane = NBW == 4 ? i : ((wave + 4 * i) >> 1);
+    const int rblk = NBW == 4 ? wave : (wave & 1);
+    const int row = rblk * 32 + (lane >> 1);
     const int half = (lane & 1) ^ ((row >> 3) & 1);
     int nrow = n0 + row;
     nrow = nrow < p.Cout ? nrow : p.Cout - 1;                  // clamped: columns past Cout are never stored
-    b_ptr = q.ws + ((size_t)kt_begin * p.Cout + nrow) * 16 + half * 8;
+    b_ptr[i] = q.ws + (size_t)(plane < 3 ? plane : 0) * b_plane + ((size_t)kt_begin * p.Cout + nrow) * 16 + half * 8;
+    b_dst[i] = W_A_BYTES + plane * B_PLANE + rblk * 1024;
   }
-  const size_t b_plane = (size_t)q.KC * p.Cout * 16;           // elements between planes
-  const size_t b_step = (size_t)p.Cout * 16;                   // elements between K steps
 
   auto issue_a = [&](int slot) {                               // the wave's two raw-A pieces of the next step
     unsigned char* dst = lds + slot * STAGE + wave * W_A_WAVE;
@@ -156,11 +166,27 @@ __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_k
     a_ptr[0] += 16;
     a_ptr[1] += 16;
   };
-  auto issue_b = [&](int slot) {                               // the wave's three filter pieces of the next step
-    unsigned char* dst = lds + slot * STAGE + W_A_BYTES + wave * 1024;
+  auto issue_b = [&](int slot) {                               // the wave's filter pieces of the next step
+    unsigned char* dst = lds + slot * STAGE;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) glds16(b_ptr + s * b_plane, dst + s * B_PLANE);
-    b_ptr += b_step;
+    for (int i = 0; i < (NBW == 4 ? 3 : 2); ++i) {
+      if (i < nb_mine) glds16(b_ptr[i], dst + b_dst[i]);
+      b_ptr[i] += b_step;
+    }
+  };
+  // s_waitcnt vmcnt(n_fixed + k * nb_mine) with the wave's own piece count
+  auto wait_vm = [&](int fixed, int kb) {
+    const int n = fixed + kb * nb_mine;
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
   };
 
   // ---- fragment roles
@@ -232,11 +258,11 @@ __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_k
     issue_a(0); issue_b(0);
     issue_a(1); issue_b(1);
     kt_a = kt_b = 2;
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // my A pieces of step 0 (the two oldest of ten)
+    wait_vm(2, 2);                                             // my A pieces of step 0 (the two oldest; 2 + 2 nb younger)
   } else {
     issue_a(0); issue_b(0); issue_a(1);
     kt_a = 2; kt_b = 1;
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");           // my A pieces of step 0
+    wait_vm(2, 1);                                             // my A pieces of step 0 (B(0) and A(1) younger)
   }
   {
     f32x4 r0, r1;
@@ -251,7 +277,8 @@ __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_k
     if (NST == 3) {
       // stage k complete, A of stage k + 1 landed (mine); lgkmcnt(0): the fragment reads of step k - 1 have
       // RETURNED before this wave arrives — behind the barrier other waves (and this one) refill what they read
-      asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      wait_vm(0, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                            // .. and everyone's: B(k) is visible; B(k - 1)'s slot is free
       asm volatile("" ::: "memory");
       s_cur = slot;
@@ -289,11 +316,11 @@ __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_k
     f32x4 r0, r1;
     read_b(s_cur, 0, fb0);
     read_raw(s_nxt, r0, r1);
-    read_b(s_cur, 1, fb1);
+    if (NBW == 4) read_b(s_cur, 1, fb1);
     mma(fa, fb0, 0);
     if (late_issue) issue_next();
     split_frag(r0, r1, fa_next);
-    mma(fa, fb1, 1);
+    if (NBW == 4) mma(fa, fb1, 1);
   };
   auto last_step = [&](int k, const bf16x8 (&fa)[3]) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -301,9 +328,9 @@ __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_k
     asm volatile("" ::: "memory");
     bf16x8 fb0[3][2], fb1[3][2];
     read_b(NST == 3 ? slot : (k & 1), 0, fb0);
-    read_b(NST == 3 ? slot : (k & 1), 1, fb1);
+    if (NBW == 4) read_b(NST == 3 ? slot : (k & 1), 1, fb1);
     mma(fa, fb0, 0);
-    mma(fa, fb1, 1);
+    if (NBW == 4) mma(fa, fb1, 1);
   };
 
   int k = 0;
@@ -388,6 +415,8 @@ __global__ __launch_bounds__(kThreads, NST == 3 ? 2 : 3) void conv1x1_bfx_wide_k
 
 int g_wide_mode = -1;        // -1: read BGS_BFX_WIDE once; 0 off; 1 auto; 2 every eligible layer
 int g_wide_nst = 0;          // 0 auto | 2 | 3
+int g_wide_nbw = 0;          // 0 auto | 2 (128 x 64 tile) | 4 (128 x 128)
+int g_wide_narrow = 1;       // automatic mode: 0 = never pick the 128 x 64 tile (BGS_BFX_WIDE_NARROW, A/B)
 int g_wide_splitk = -1;      // -1 auto | 1..16
 int g_wide_last = 0;         // bit 0: the wide kernel ran; bits 4..7: NST; bits 8..: K slices
 int g_wide_ablate = 0;       // -DBGS_ABLATE builds only
@@ -408,11 +437,12 @@ int bgs_internal_conv1x1_bfx_wide(const bgs_conv::ConvArgs& pc, const void* wspl
     g_wide_mode = e ? atoi(e) : 1;
     if (const char* n = getenv("BGS_BFX_WIDE_NST")) g_wide_nst = atoi(n);
     if (const char* s = getenv("BGS_BFX_WIDE_SPLITK")) g_wide_splitk = atoi(s);
+    if (const char* s = getenv("BGS_BFX_WIDE_NARROW")) g_wide_narrow = atoi(s);
   }
   g_wide_last = 0;
   if (!g_wide_mode || (forced_only && g_wide_mode != 2)) return -1;
   if (pc.R != 1 || pc.S != 1 || pc.pad != 0 || pc.rowmap) return -1;
-  if ((pc.K & 15) || pc.K < 64 || pc.Cout < 128 || pc.M < 128) return -1;
+  if ((pc.K & 15) || pc.K < 64 || pc.Cout < 64 || pc.M < 128) return -1;
   if (pc.res_mode == 3) return -1;
   const uintptr_t al = (uintptr_t)pc.y | (uintptr_t)pc.res | (uintptr_t)pc.mask | (uintptr_t)pc.bias |
                        (uintptr_t)pc.x | (uintptr_t)wsplit | (uintptr_t)workspace;
@@ -423,9 +453,11 @@ int bgs_internal_conv1x1_bfx_wide(const bgs_conv::ConvArgs& pc, const void* wspl
   q.ws = reinterpret_cast<const __bf16*>(wsplit);
   q.KC = KC;
   q.flags = g_wide_flags;
+  int nbw = g_wide_nbw == 2 ? 2 : 4;
+  if (p.Cout < 128) nbw = 2;
   p.tiles_m = (p.M + 127) / 128;
-  p.tiles_n = (p.Cout + 127) / 128;
-  const long long tiles = (long long)p.tiles_m * p.tiles_n;
+  p.tiles_n = (p.Cout + 32 * nbw - 1) / (32 * nbw);
+  long long tiles = (long long)p.tiles_m * p.tiles_n;
   const int nk = p.K >> 4;
   // K slices: one launch wants >= ~2 workgroups per CU; a slice keeps >= 8 K steps
   int want = 1;
@@ -436,9 +468,22 @@ int bgs_internal_conv1x1_bfx_wide(const bgs_conv::ConvArgs& pc, const void* wspl
     // profiles/r8d_wide_in_step.md): the large grids with a reduction of >= 256.  The deep reductions on the
     // stride-16 / 32 maps need K sliced to fill the chip and lose the gain to the slab reduction launch
     // (+11 us each in the step); K <= 128, the 528-tile K = 256 layers and the tiny grids stay on the ring.
-    const bool big = tiles >= 500 && (long long)p.K * tiles >= 256000 && p.K >= 256;
-    const bool deep = false;
-    if (!big && !deep) return -1;
+    const long long tiles4 = (long long)p.tiles_m * ((p.Cout + 127) / 128);
+    const bool big = p.Cout >= 128 && tiles4 >= 500 && (long long)p.K * tiles4 >= 256000 && p.K >= 256;
+    // 128 x 64 tiles, three-stage ring (three workgroups per CU): ahead of the 64 x 64 ring by 3 - 8 % where one
+    // launch still offers >= 500 of them with a deep reduction, or >= 1000 with K >= 256 (profiles/r8k_wide_narrow_ab.txt:
+    // l2.c1 39.7 -> 36.8 us, l4.b0.c1 / l4.ds 71.7 -> 67.4, l4.c3 41.7 -> 39.4, fc_reg 77.6 -> 71.6, l1.c1 39.9 -> 38.7,
+    // l3.c3 39.6 -> 38.8); behind it on K <= 128 and on the 264-tile layers.  The two-stage form (five per CU) loses
+    // everywhere.
+    const long long tiles2 = (long long)p.tiles_m * ((p.Cout + 63) / 64);
+    const bool narrow = !big && g_wide_narrow && g_wide_nbw != 4 &&
+                        ((tiles2 >= 500 && p.K >= 512) || (tiles2 >= 1000 && p.K >= 256));
+    if (!big && !narrow) return -1;
+    if (narrow) {
+      nbw = 2;
+      p.tiles_n = (p.Cout + 63) / 64;
+      tiles = tiles2;
+    }
   }
   if (tiles < 384) want = (int)((640 + tiles - 1) / tiles);
   if (want > nk / 8) want = nk / 8;
@@ -466,8 +511,9 @@ int bgs_internal_conv1x1_bfx_wide(const bgs_conv::ConvArgs& pc, const void* wspl
   dim3 grid((unsigned)(8 * p.chunk), 1u, (unsigned)splits);
   // ring depth: three stages (two workgroups per CU) unless the grid offers a third workgroup per CU
   int nst = tiles * splits > 512 ? 2 : 3;
+  if (nbw == 2) nst = 3;
   if (g_wide_nst == 2 || g_wide_nst == 3) nst = g_wide_nst;
-  g_wide_last = 1 | (nst << 4) | (splits << 8);
+  g_wide_last = 1 | (nst << 4) | (splits << 8) | (nbw == 2 ? 0x100000 : 0);
   bgs_internal_census_bump(BGS_CENSUS_BFX_WIDE);
 #ifdef BGS_ABLATE
   if (g_wide_ablate) {
@@ -477,7 +523,10 @@ int bgs_internal_conv1x1_bfx_wide(const bgs_conv::ConvArgs& pc, const void* wspl
 #undef ABL_W
   } else
 #endif
-  if (nst == 3) hipLaunchKernelGGL((conv1x1_bfx_wide_kernel<4, 3>), grid, dim3(kThreads), 0, st, q);
+  if (nbw == 2) {
+    if (nst == 3) hipLaunchKernelGGL((conv1x1_bfx_wide_kernel<2, 3>), grid, dim3(kThreads), 0, st, q);
+    else hipLaunchKernelGGL((conv1x1_bfx_wide_kernel<2, 2>), grid, dim3(kThreads), 0, st, q);
+  } else if (nst == 3) hipLaunchKernelGGL((conv1x1_bfx_wide_kernel<4, 3>), grid, dim3(kThreads), 0, st, q);
   else hipLaunchKernelGGL((conv1x1_bfx_wide_kernel<4, 2>), grid, dim3(kThreads), 0, st, q);
   if (splits > 1) {
     if (hipGetLastError() != hipSuccess) return BGS_ERR_LAUNCH;
@@ -488,8 +537,9 @@ int bgs_internal_conv1x1_bfx_wide(const bgs_conv::ConvArgs& pc, const void* wspl
 
 // workspace the wide kernel wants for a layer (0: none, or not eligible)
 size_t bgs_internal_conv1x1_bfx_wide_workspace(long long M, int Cout, int K) {
-  if (M < 128 || Cout < 128 || (K & 15) || K < 64) return 0;
-  const long long tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
+  if (M < 128 || Cout < 64 || (K & 15) || K < 64) return 0;
+  const int bn = (g_wide_nbw == 2 || Cout < 128) ? 64 : 128;
+  const long long tiles = ((M + 127) / 128) * ((Cout + bn - 1) / bn);
   const int nk = K >> 4;
   int want = 1;
   if (tiles < 384) want = (int)((640 + tiles - 1) / tiles);
@@ -506,7 +556,8 @@ extern "C" void bgs_conv_bfx_wide_tuning(int mode, int nst, int splitk) {
   g_wide_flags = (mode >> 16) & 0xff;          // WideArgs::flags
   mode &= 0xff;
   g_wide_mode = mode;
-  g_wide_nst = nst;
+  g_wide_nst = nst & 15;                      // bits 4..7 of `nst`: tile width, 0 auto | 2: 128 x 64 | 4: 128 x 128
+  g_wide_nbw = (nst >> 4) & 15;
   g_wide_splitk = splitk;
 }
 

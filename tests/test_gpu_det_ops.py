@@ -973,9 +973,10 @@ def test_halo_kernel_pixel_tile_geometries_are_bit_identical(shape, monkeypatch)
 def _wide_last():
     from balancedgroupsoftmax_amd import capi
     v = capi.load().bgs_conv_bfx_wide_last_launch()
-    return dict(ran=v & 1, nst=(v >> 4) & 15, splits=v >> 8)
+    return dict(ran=v & 1, nst=(v >> 4) & 15, splits=(v >> 8) & 0xfff, nbw=2 if v & 0x100000 else 4)
 
 
+@pytest.mark.parametrize('nbw', [4, 2])
 @pytest.mark.parametrize('nst', [2, 3])
 @pytest.mark.parametrize('shape', [
     # (N, H, W, Cin, Cout, stride, relu, residual mode)
@@ -986,8 +987,8 @@ def _wide_last():
     (256, 1, 1, 1024, 1236, 1, False, 0),     # fc_cls: Cout % 128 = 84: clamped filter rows
     (3, 17, 23, 128, 132, 1, True, 1),        # both edges ragged
 ], ids=lambda c: 'x'.join(str(int(v)) for v in c))
-def test_bfx_wide_tile_kernel_is_bit_identical_to_the_operand_ring(shape, nst):
-    """``conv1x1_bfx_wide_kernel`` (csrc/conv_bfx_wide.hip: 128 x 128 tile, four M-stacked waves, wave-private A,
+def test_bfx_wide_tile_kernel_is_bit_identical_to_the_operand_ring(shape, nst, nbw):
+    """``conv1x1_bfx_wide_kernel`` (csrc/conv_bfx_wide.hip: 128 x 128 or 128 x 64 tile, four M-stacked waves, wave-private A,
     rows / columns past the edge clamped instead of zero-filled) in both ring depths against the 64 x 64 operand
     ring on the 1x1 layers of mmdet/models/backbones/resnet.py:220-266, necks/fpn.py:101-141 and the FC heads:
     BIT-IDENTICAL outputs when K is not sliced (same products, same order), both within fp32 rounding of fp64
@@ -1013,11 +1014,11 @@ def test_bfx_wide_tile_kernel_is_bit_identical_to_the_operand_ring(shape, nst):
         ring = BF.conv2d_nhwc(dev(x), dev(w), dev(b), **kw).cpu()
         BF.conv_bfx_tuning(0, -1)
         assert not _wide_last()['ran']
-        lib.bgs_conv_bfx_wide_tuning(2, nst, 1)
+        lib.bgs_conv_bfx_wide_tuning(2, nst | (nbw << 4), 1)   # bits 4..7: tile width (2: 128 x 64)
         wide = BF.conv2d_nhwc(dev(x), dev(w), dev(b), **kw).cpu()
-        assert _wide_last() == dict(ran=1, nst=nst, splits=1)
+        assert _wide_last() == dict(ran=1, nst=nst, splits=1, nbw=nbw)
         assert torch.equal(wide, ring)
-        lib.bgs_conv_bfx_wide_tuning(2, nst, 2)        # K sliced two ways through the slab epilogue
+        lib.bgs_conv_bfx_wide_tuning(2, nst | (nbw << 4), 2)   # K sliced two ways through the slab epilogue
         sliced = BF.conv2d_nhwc(dev(x), dev(w), dev(b), **kw).cpu()
         assert _wide_last()['ran'] and _wide_last()['splits'] == 2
     finally:
@@ -1069,8 +1070,11 @@ def test_bfx_wide_tile_kernel_as_data_gradient_with_mask_and_in_the_automatic_mo
                                              l1c3=(2, 100, 168, 64, 256), lat1=(2, 100, 168, 512, 256)).items():
             BF.conv2d_nhwc(torch.randn(n, h, wd, ci, device=DEV), torch.randn(co, 1, 1, ci, device=DEV),
                            torch.zeros(co, device=DEV))
-            took[name] = _wide_last()['ran']
-        assert took == dict(lat0=1, l3c3=0, l1c3=0, lat1=1), took
+            u = _wide_last()
+            took[name] = (u['ran'], u['nbw'] if u['ran'] else 0)
+        # 128 x 128 on the large grids with K >= 256; 128 x 64 (three stages) where >= 1000 of them remain with
+        # K >= 256; the 64 x 64 ring on K = 64
+        assert took == dict(lat0=(1, 4), l3c3=(1, 2), l1c3=(0, 0), lat1=(1, 4)), took
     finally:
         lib.bgs_conv_bfx_wide_tuning(1, 0, -1)
         lib.bgs_conv1x1_bres_enable(1)

@@ -36,7 +36,7 @@ def wide(mode, nst=0, splitk=-1, flags=0):
 
 def last():
     v = capi.load().bgs_conv_bfx_wide_last_launch()
-    return dict(ran=v & 1, nst=(v >> 4) & 15, splits=v >> 8)
+    return dict(ran=v & 1, nst=(v >> 4) & 15, splits=(v >> 8) & 0xfff, nbw=2 if v & 0x100000 else 4)
 
 
 def correctness(dev):
@@ -193,12 +193,31 @@ def main():
     arms = [('ring', (0, 0, -1)), ('w-auto', (2, 0, -1)), ('w-n2', (2, 2, 1)), ('w-n3', (2, 3, 1))]
     if not quick:
         arms += [('w-k2', (2, 0, 2)), ('w-k4', (2, 0, 4))]
+    if '--narrow' in sys.argv:      # the 128 x 64 tile (bits 4..7 of nst = 2) against the ring and the 128 x 128 tile
+        arms = [('ring', (0, 0, -1)), ('w4-auto', (2, 0, -1)), ('w2-n2', (2, 2 | 0x20, 1)), ('w2-n3', (2, 3 | 0x20, 1)),
+                ('w2-auto', (2, 0x20, -1)), ('ring', (0, 0, -1)), ('w2-n2', (2, 2 | 0x20, 1))]
     tot = {a: 0.0 for a, _ in arms}
     tot['best'] = 0.0
+    if '--narrow' in sys.argv:      # bit-identity of the 128 x 64 tile first
+        for (N_, H_, W_, Ci, Co, st_, relu, rm) in [(2, 50, 84, 256, 1024, 1, True, 1), (1, 37, 29, 64, 64, 1, False, 0),
+                                                     (2, 100, 168, 256, 512, 2, False, 0), (3, 17, 23, 128, 132, 1, True, 1),
+                                                     (2, 50, 84, 512, 256, 1, False, 2)]:
+            x = torch.randn(N_, H_, W_, Ci, device=dev); w = torch.randn(Co, 1, 1, Ci, device=dev) * 0.05
+            b = torch.randn(Co, device=dev)
+            Ho, Wo = (H_ - 1) // st_ + 1, (W_ - 1) // st_ + 1
+            res = torch.randn(N_, Ho, Wo, Co, device=dev) if rm == 1 else (torch.randn(N_, Ho // 2, Wo // 2, Co, device=dev) if rm == 2 else None)
+            kw = dict(stride=st_, pad=0, relu=relu, residual=res, residual_mode=rm)
+            wide(0); BF.conv_bfx_tuning(0, 1); y0 = BF.conv2d_nhwc(x, w, b, **kw).clone(); BF.conv_bfx_tuning(0, -1)
+            for nst in (2, 3):
+                wide(2, nst | 0x20, 1)
+                y1 = BF.conv2d_nhwc(x, w, b, **kw)
+                u = last()
+                print('128x64 nst %d: N%d %dx%d %d->%d s%d res%d ran=%s nbw=%d equal=%s' % (
+                    nst, N_, H_, W_, Ci, Co, st_, rm, u['ran'], u['nbw'], bool(torch.equal(y0, y1))), flush=True)
     print('%-12s %7s %6s %5s %6s | %s' % ('layer', 'M', 'K', 'Cout', 'tiles', '  '.join('%9s' % a for a, _ in arms)))
     for name, H, W, Cin, Cout, R, stride, cnt in layers:
         Nn = 1024 if name.startswith('fc') else NIMG
-        if Cout < 128 or Cin % 16:
+        if Cout < (64 if '--narrow' in sys.argv else 128) or Cin % 16:
             continue
         x = torch.randn(Nn, H, W, Cin, device=dev)
         w = torch.randn(Cout, 1, 1, Cin, device=dev) * 0.05
