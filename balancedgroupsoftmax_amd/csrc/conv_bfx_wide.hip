@@ -465,7 +465,7 @@ int bgs_internal_conv1x1_bfx_wide(const bgs_conv::ConvArgs& pc, const void* wspl
     // auto: the layers where the wide tile was measured ahead of the 64 x 64 ring, per layer
     // (tools/wide_ab.py, profiles/r8a_wide_tile_ab.txt: fpn.lat0 147 -> 124 us, l2.b0.c1 77 -> 66, l2.ds 76 -> 64,
     // l3.b0.c1 / l3.ds / fpn.lat1 74 -> 67) AND inside the step (rocprofv3 of the graph-replayed cfg[1] step,
-    // profiles/r8d_wide_in_step.md): the large grids with a reduction of >= 256.  The deep reductions on the
+    // profiles/r8a_wide_tile_ab.txt, in-step note in DESIGN 4.20): the large grids with a reduction of >= 256.  The deep reductions on the
     // stride-16 / 32 maps need K sliced to fill the chip and lose the gain to the slab reduction launch
     // (+11 us each in the step); K <= 128, the 528-tile K = 256 layers and the tiny grids stay on the ring.
     const long long tiles4 = (long long)p.tiles_m * ((p.Cout + 127) / 128);
@@ -476,9 +476,12 @@ int bgs_internal_conv1x1_bfx_wide(const bgs_conv::ConvArgs& pc, const void* wspl
     // l3.c3 39.6 -> 38.8); behind it on K <= 128 and on the 264-tile layers.  The two-stage form (five per CU) loses
     // everywhere.
     const long long tiles2 = (long long)p.tiles_m * ((p.Cout + 63) / 64);
-    const bool narrow = !big && g_wide_narrow && g_wide_nbw != 4 &&
+    const bool narrow = !big && p.K < 8192 && g_wide_narrow && g_wide_nbw != 4 &&
                         ((tiles2 >= 500 && p.K >= 512) || (tiles2 >= 1000 && p.K >= 256));
-    if (!big && !narrow) return -1;
+    // the first shared FC (K = 12544, 64 tiles x 8 K slices): 170 -> 147 us against the register-staged 128 x 128
+    // kernel it ran on, both with their slab reduction (profiles/r8k_wide_narrow_ab.txt)
+    const bool deep = p.Cout >= 128 && p.K >= 8192 && tiles4 >= 32 && workspace != nullptr;
+    if (!big && !narrow && !deep) return -1;
     if (narrow) {
       nbw = 2;
       p.tiles_n = (p.Cout + 63) / 64;
