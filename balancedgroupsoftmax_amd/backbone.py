@@ -137,15 +137,21 @@ class Bottleneck(nn.Module):
     def run_bf16_storage(self, x, f):
         """The frozen block with bf16 activations in HBM (cfg[4] bf16 mode, csrc/conv_bf16s.hip):
         bf16 in, bf16 out, fp32 accumulate / bias / residual add / ReLU inside the kernels."""
-        identity = x
+        identity, fk = x, None
         if 'ds' in f:
-            identity = BF.conv2d_nhwc(x, f['ds'][0], f['ds'][1], stride=self.stride)
+            if x.is_cuda and BF.shortcut_fork_enabled():      # projection shortcut beside conv1 / conv2 (see run)
+                with BF.forked(x.device) as fk:
+                    identity = BF.conv2d_nhwc(x, f['ds'][0], f['ds'][1], stride=self.stride)
+            else:
+                identity = BF.conv2d_nhwc(x, f['ds'][0], f['ds'][1], stride=self.stride)
         out = BF.conv2d_nhwc(x, f['c1'][0], f['c1'][1], relu=True)
         if self.groups > 1:
             out = BF.grouped_conv3x3_nhwc(out, f['c2'][0], f['c2'][1], self.groups, stride=self.stride,
                                           relu=True)
         else:
             out = BF.conv2d_nhwc(out, f['c2'][0], f['c2'][1], stride=self.stride, pad=1, relu=True)
+        if fk is not None:
+            fk.join()
         return BF.conv2d_nhwc(out, f['c3'][0], f['c3'][1], relu=True, residual=identity)
 
     def run(self, x, f):
@@ -163,7 +169,15 @@ class Bottleneck(nn.Module):
         out_relu = 'consumers' if BF.fork_fusion_enabled() else True
         xin = x
         identity = x
-        if 'ds' in f:
+        fk = None
+        if 'ds' in f and not fuse and x.is_cuda and BF.shortcut_fork_enabled() and \
+                not (torch.is_grad_enabled() and any(t.requires_grad for t in f['ds'] if t is not None)):
+            # frozen block: the projection shortcut (a 1x1 / stride-s conv of the block input) is independent of
+            # conv1 -> conv2 and runs beside them on the side stream; conv3's epilogue consumes it after the join
+            # (the stride-16 / 32 stages launch 264 - 528 workgroups per conv: two launches fill the chip)
+            with BF.forked(x.device) as fk:
+                identity = BF.conv2d_nhwc(x, f['ds'][0], f['ds'][1], stride=self.stride)
+        elif 'ds' in f:
             if fuse:
                 identity, xin = BF.conv2d_autograd(x, f['ds'][0], f['ds'][1], stride=self.stride,
                                                    mask_input=tagged, passthrough=True)
@@ -181,6 +195,8 @@ class Bottleneck(nn.Module):
                 out, identity = out
             out = BF.grouped_conv3x3_nhwc(out, f['c2'][0], f['c2'][1], self.groups,
                                           stride=self.stride, relu=True)
+            if fk is not None:
+                fk.join()
             return BF.conv2d_autograd(out, f['c3'][0], f['c3'][1], relu=out_relu, residual=identity)
         out = BF.conv2d_autograd(xin, f['c1'][0], f['c1'][1], relu='consumers', mask_input=first_mask,
                                  passthrough=first_pt)
@@ -188,6 +204,8 @@ class Bottleneck(nn.Module):
             out, identity = out
         out = BF.conv2d_autograd(out, f['c2'][0], f['c2'][1], stride=self.stride, pad=1,
                                  relu='consumers', mask_input=True)
+        if fk is not None:
+            fk.join()
         return BF.conv2d_autograd(out, f['c3'][0], f['c3'][1], relu=out_relu, residual=identity,
                                   mask_input=True)
 
@@ -382,18 +400,26 @@ class FPN(nn.Module):
         gate = [bool(getattr(t, '_bgs_consumers_mask', False)) for t in inputs]
         lat[n - 1] = BF.conv2d_autograd(inputs[n - 1], *f['lat'][n - 1], out_dtype=torch.float32,
                                         mask_input=gate[n - 1])
+        if n > 1 and lat[n - 1].is_cuda and BF.level_fork_enabled():
+            # The output convs of the small levels (168 / 48 workgroups on 256 CUs) go to the side stream as soon as
+            # their lateral exists (functional.forked: each block waits for what the main stream has issued so
+            # far), beside the remaining laterals and the P2-level output conv on the main stream.
+            outs, fk = [None] * n, None
+            for i in range(n - 1, 0, -1):
+                with BF.forked(lat[i].device) as fk:
+                    outs[i] = BF.conv2d_autograd(lat[i], *f['out'][i], pad=1)
+                    if i == n - 1:
+                        extra = []
+                        for _ in range(self.num_outs - n):   # F.max_pool2d(x, 1, stride=2) == subsampling
+                            extra.append((extra[-1] if extra else outs[i])[:, ::2, ::2, :].contiguous())
+                lat[i - 1] = BF.conv2d_autograd(inputs[i - 1], *f['lat'][i - 1], residual=lat[i],
+                                                residual_mode=2, out_dtype=torch.float32, mask_input=gate[i - 1])
+            outs[0] = BF.conv2d_autograd(lat[0], *f['out'][0], pad=1)
+            fk.join()                                        # (the side stream is in order: its last block is its last work)
+            return tuple(outs + extra)
         for i in range(n - 2, -1, -1):   # lateral_i + nearest_2x(lateral_{i+1}), fused
             lat[i] = BF.conv2d_autograd(inputs[i], *f['lat'][i], residual=lat[i + 1],
                                         residual_mode=2, out_dtype=torch.float32, mask_input=gate[i])
-        if n > 1 and lat[0].is_cuda and BF.level_fork_enabled():
-            # the small levels next to the P2 launch (functional.forked)
-            with BF.forked(lat[0].device) as fk:
-                small = [BF.conv2d_autograd(lat[i], *f['out'][i], pad=1) for i in range(1, n)]
-                for _ in range(self.num_outs - n):
-                    small.append(small[-1][:, ::2, ::2, :].contiguous())
-            outs = [BF.conv2d_autograd(lat[0], *f['out'][0], pad=1)] + small
-            fk.join()
-            return tuple(outs)
         outs = [BF.conv2d_autograd(lat[i], *f['out'][i], pad=1) for i in range(n)]
         for _ in range(self.num_outs - n):   # F.max_pool2d(x, 1, stride=2) == subsampling
             outs.append(outs[-1][:, ::2, ::2, :].contiguous())

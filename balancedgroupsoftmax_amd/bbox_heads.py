@@ -311,8 +311,18 @@ class ConvFCBBoxHead(BBoxHead):
         for fc in self.reg_fcs:
             x_reg = fc_apply(fc, x_reg, True, False, h_reg)
             h_reg = True
+        # fc_cls (80 workgroups x 4 K slices) and fc_reg (312) both read the last hidden activation: a frozen fc_reg
+        # with no reg branch of its own runs beside fc_cls on the side stream (functional.forked)
+        fk = None
+        if self.with_cls and self.with_reg and not self.reg_fcs and BF.shortcut_fork_enabled() and \
+                not (torch.is_grad_enabled() and (x_reg.requires_grad or self.fc_reg.weight.requires_grad)):
+            with BF.forked(x_reg.device) as fk:
+                bbox_pred = fc_apply(self.fc_reg, x_reg, False, False, h_reg)
         cls_score = fc_apply(self.fc_cls, x_cls, False, False, h_cls) if self.with_cls else None
-        bbox_pred = fc_apply(self.fc_reg, x_reg, False, False, h_reg) if self.with_reg else None
+        if fk is not None:
+            fk.join()
+        else:
+            bbox_pred = fc_apply(self.fc_reg, x_reg, False, False, h_reg) if self.with_reg else None
         return cls_score, bbox_pred
 
 

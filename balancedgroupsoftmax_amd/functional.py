@@ -41,6 +41,12 @@ def level_fork_enabled():
     return os.environ.get('BGS_LEVEL_FORK', '1') != '0'
 
 
+def shortcut_fork_enabled():
+    """Projection shortcuts of frozen residual blocks on the side stream (backbone.Bottleneck.run):
+    ``BGS_SHORTCUT_FORK=0`` turns it off (``BGS_LEVEL_FORK=0`` turns every fork off)."""
+    return level_fork_enabled() and os.environ.get('BGS_SHORTCUT_FORK', '1') != '0'
+
+
 class forked(object):
     """``with forked(device) as f: <launches>`` issues the block on the device's side stream, ordered after
     everything enqueued on the current stream so far; ``f.join()`` makes the current stream wait for it.
