@@ -167,7 +167,7 @@ class TwoStageDetector(nn.Module):
         return rois, (labels, lw, bt, bw)
 
     # -- RPN part of a training iteration ------------------------------------------------------
-    def _rpn_forward_train(self, x, img_meta, gt_bboxes, proposals, samplers, losses):
+    def _rpn_forward_train(self, x, img_meta, gt_bboxes, proposals, samplers, losses, fork_loss=False):
         """RPN losses + the fixed-shape proposal list (two_stage.py:157-176).
 
         (Measured and dropped: launching the loss branch — anchor assignment, sampler, BCE +
@@ -178,8 +178,21 @@ class TwoStageDetector(nn.Module):
         if not self.with_rpn:
             return [(p, torch.ones(p.size(0), dtype=torch.bool, device=p.device)) for p in proposals]
         cls_scores, bbox_preds = self.rpn_head(x)
-        losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
-                                         self.train_cfg.rpn, samplers=samplers))
+        from . import functional as BF
+        self._rpn_loss_fork = None
+        if fork_loss and cls_scores[0].is_cuda and BF.rpn_loss_fork_enabled() and not samplers and \
+                not (torch.is_grad_enabled() and cls_scores[0].requires_grad):
+            # the RPN loss chain (anchor assignment, sampler, BCE + SmoothL1 sums: ~12 short launches that only
+            # read the RPN outputs) beside the proposal -> RoI-head chain; joined in forward_train before the
+            # losses are returned.  (Round 2 measured no gain: the step was 560 launches and eager launching was
+            # host-bound; at 150 launches it is not.)
+            with BF.forked(cls_scores[0].device) as fk:
+                losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
+                                                 self.train_cfg.rpn, samplers=samplers))
+            self._rpn_loss_fork = fk
+        else:
+            losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
+                                             self.train_cfg.rpn, samplers=samplers))
         proposal_cfg = self.train_cfg.get('rpn_proposal', None)
         if proposal_cfg is None:
             proposal_cfg = self.test_cfg.rpn
@@ -200,7 +213,8 @@ class TwoStageDetector(nn.Module):
                       gt_masks=None, proposals=None, samplers=None):
         x = self.extract_feat(img)
         losses = dict()
-        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, samplers, losses)
+        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, samplers, losses,
+                                                fork_loss=True)      # (joined below)
         if self.with_bbox:
             if not self.train_cfg.rcnn.assigner.get('gt_max_assign_all', True):
                 raise NotImplementedError('gt_max_assign_all=False')
@@ -210,6 +224,10 @@ class TwoStageDetector(nn.Module):
             losses.update(self.bbox_head.loss(cls_score, bbox_pred, *targets))
         if self.with_mask:
             losses.update(self._mask_forward_train(x, rois, targets[0], gt_masks, img.size(0)))
+        fk = getattr(self, '_rpn_loss_fork', None)
+        if fk is not None:
+            fk.join()
+            self._rpn_loss_fork = None
         return losses
 
     def _mask_forward_train(self, x, rois, labels, gt_masks, num_imgs):

@@ -47,6 +47,17 @@ def shortcut_fork_enabled():
     return level_fork_enabled() and os.environ.get('BGS_SHORTCUT_FORK', '1') != '0'
 
 
+def rpn_loss_fork_enabled():
+    """The RPN loss chain (~12 short dependent launches) on the side stream (detectors._rpn_forward_train).  Default
+    ``BGS_RPN_LOSS_FORK=auto``: when launching eagerly (two real streams: 6.45 -> 6.30 ms per step), not while a
+    hipGraph is being captured (inside a replayed graph the fork's event edges cost more than the overlap returns:
+    6.44 -> 6.49 ms); ``1`` / ``0`` force it."""
+    v = os.environ.get('BGS_RPN_LOSS_FORK', 'auto')
+    if v == 'auto':
+        return level_fork_enabled() and not torch.cuda.is_current_stream_capturing()
+    return level_fork_enabled() and v != '0'
+
+
 class forked(object):
     """``with forked(device) as f: <launches>`` issues the block on the device's side stream, ordered after
     everything enqueued on the current stream so far; ``f.join()`` makes the current stream wait for it.

@@ -747,7 +747,7 @@ def extras(dev, args):
         cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'detector', '--steps', '10',
                '--warmup', '3', '--imgs', str(args.imgs), '--no-extras', '--no-cpu-baseline',
                '--no-roofline'] + (['--conv-math', args.conv_math] if '--conv-math' not in flags else []) \
-            + flags + (['--no-graph'] if args.no_graph else [])
+            + flags + (['--no-graph'] if args.no_graph else []) + ['--launch', args.launch]
         try:
             out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420, env=env)
             line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')]
@@ -777,6 +777,7 @@ def run_graph_child(args):
     cmd += (['--mask'] if args.mask else []) + (['--cascade'] if args.cascade else [])
     cmd += ['--htc'] if args.htc else []
     cmd += ['--dist-graph'] if args.dist_graph else []
+    cmd += ['--launch', args.launch]
     try:
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')]
