@@ -1022,7 +1022,7 @@ def main_detector(args, rank, local, world, dev):
                                        (args.dist_graph and (rccl or self_group)))
     auto = can_graph and world == 1 and not self_group and args.launch == 'auto'
     if auto:
-        calib = dict(eager_ms=round(timed_loop(step, 8, 3, 1) * 1e3 / 8, 3))
+        calib = dict(eager_ms=round(timed_loop(step, 8, 6, 1) * 1e3 / 8, 3))      # (6 warm-up steps: lazy folds / splits / caches)
     if can_graph and args.launch != 'eager':
         # --dist-graph: the RCCL all-reduce is captured with the rest of the step (the communicator
         # is set up by the eager warm-up iterations inside try_graph)
