@@ -209,6 +209,13 @@ class TwoStageDetector(nn.Module):
         self.rpn_head._fused = None
         return proposal_list
 
+    def _join_rpn_loss(self):
+        """Make the current stream wait for the RPN loss chain launched beside it (see _rpn_forward_train)."""
+        fk = getattr(self, '_rpn_loss_fork', None)
+        if fk is not None:
+            fk.join()
+            self._rpn_loss_fork = None
+
     def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
                       gt_masks=None, proposals=None, samplers=None):
         x = self.extract_feat(img)
@@ -224,10 +231,7 @@ class TwoStageDetector(nn.Module):
             losses.update(self.bbox_head.loss(cls_score, bbox_pred, *targets))
         if self.with_mask:
             losses.update(self._mask_forward_train(x, rois, targets[0], gt_masks, img.size(0)))
-        fk = getattr(self, '_rpn_loss_fork', None)
-        if fk is not None:
-            fk.join()
-            self._rpn_loss_fork = None
+        self._join_rpn_loss()
         return losses
 
     def _mask_forward_train(self, x, rois, labels, gt_masks, num_imgs):
@@ -418,7 +422,7 @@ class CascadeRCNN(TwoStageDetector):
             raise NotImplementedError('CascadeRCNN.forward_train runs on the GPU path only')
         x = self.extract_feat(img)
         losses = dict()
-        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, samplers, losses)
+        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, samplers, losses, fork_loss=True)
         for i in range(self.num_stages):
             rc = self.train_cfg.rcnn[i]
             lw = self.train_cfg.stage_loss_weights[i]
@@ -436,6 +440,7 @@ class CascadeRCNN(TwoStageDetector):
             if i < self.num_stages - 1:       # refine (cascade_rcnn.py:291-296), fixed shape
                 proposal_list = self._refined_proposals(head, rois, targets[0], bbox_pred, img_meta,
                                                         rc.sampler.num)
+        self._join_rpn_loss()
         return losses
 
     def simple_test(self, img, img_meta, proposals=None, rescale=False):
@@ -559,7 +564,7 @@ class HybridTaskCascade(CascadeRCNN):
             raise ValueError('HTC needs gt_masks (per image a uint8 [G, H, W] tensor)')
         x = self.extract_feat(img)
         losses = dict()
-        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, samplers, losses)
+        proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, samplers, losses, fork_loss=True)
         semantic_feat = None
         if self.with_semantic:
             if gt_semantic_seg is None:
@@ -598,6 +603,7 @@ class HybridTaskCascade(CascadeRCNN):
                 losses['s{}.{}'.format(i, name)] = value * lw if 'loss' in name else value
             if refined is not None:
                 proposal_list = refined
+        self._join_rpn_loss()
         return losses
 
     # -- test time -----------------------------------------------------------------------------
