@@ -191,6 +191,60 @@ def test_training_iteration_vs_executed_reference_detector():
     assert not bad, bad
 
 
+def test_side_stream_forks_do_not_change_the_iteration(monkeypatch):
+    """functional.forked (small pyramid levels, projection shortcuts, fc_reg, the RPN loss chain on a side stream):
+    the same kernels on the same inputs — every loss term of a frozen-trunk iteration (selectp = 1, the shipped
+    regime, where all forks are live) is BIT-IDENTICAL with every fork off, with the default set, and with the RPN
+    loss chain forced onto the side stream; three repetitions per arm (a missing join or a reuse race would show as
+    run-to-run differences)."""
+    from balancedgroupsoftmax_amd import train, functional as BF
+    from tests.golden import make_golden_train as T
+    tmp = tempfile.mkdtemp(prefix='bgs_e2e_')
+    model_cfg, train_cfg = T.configs(tmp)
+    model = bgs.build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
+                               test_cfg=to_config_dict(G.TEST_CFG))
+    with torch.no_grad():
+        det_oracle.fill_detector(model.state_dict(), T.SEED)
+    model.to(DEV)
+    train.select_training_param(model, 1)
+    model.train()
+    boxes, labels = T.gt()
+    img = torch.from_numpy(G.image()).to(DEV)
+    gtb, gtl = [torch.from_numpy(boxes).to(DEV)], [torch.from_numpy(labels).to(DEV)]
+
+    def run():
+        for c in BF._KEY_COUNTERS.values():        # every repetition replays the same sampler draws
+            c.zero_()
+        model.bbox_head._draw.zero_()
+        losses = model(img, G.img_meta(), return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
+        loss, _ = train.parse_losses(losses)
+        loss.backward()
+        out = {}
+        for k, v in losses.items():
+            vs = v if isinstance(v, (list, tuple)) else [v]
+            out[k] = torch.stack([t.detach().float().reshape(-1).sum() for t in vs]).cpu()
+        out['fc_cls.grad'] = model.bbox_head.fc_cls.weight.grad.detach().clone().cpu()
+        model.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        return out
+
+    arms = {'off': dict(BGS_LEVEL_FORK='0'), 'default': {}, 'rpn_loss': dict(BGS_RPN_LOSS_FORK='1'),
+            'no_shortcut': dict(BGS_SHORTCUT_FORK='0')}
+    ref = None
+    for name, env in arms.items():
+        for k in ('BGS_LEVEL_FORK', 'BGS_RPN_LOSS_FORK', 'BGS_SHORTCUT_FORK'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for rep in range(3):
+            got = run()
+            if ref is None:
+                ref = got
+            assert got.keys() == ref.keys()
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), (name, rep, k)
+
+
 @pytest.mark.parametrize('mode', ['bf16x6', 'bf16x6-nohalo', 'f32', 'f32-nohalo'])
 def test_fullsize_training_iteration_vs_executed_reference(mode, monkeypatch):
     """BASELINE cfg[1] AT ITS REAL SIZE (2 x 3x800x1344, 20 GT/img) against the executed reference
