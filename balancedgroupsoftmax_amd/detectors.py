@@ -186,7 +186,7 @@ class TwoStageDetector(nn.Module):
             # read the RPN outputs) beside the proposal -> RoI-head chain; joined in forward_train before the
             # losses are returned.  (Round 2 measured no gain: the step was 560 launches and eager launching was
             # host-bound; at 150 launches it is not.)
-            with BF.forked(cls_scores[0].device) as fk:
+            with BF.forked(cls_scores[0].device, lane=1) as fk:
                 losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
                                                  self.train_cfg.rpn, samplers=samplers))
             self._rpn_loss_fork = fk
@@ -226,10 +226,23 @@ class TwoStageDetector(nn.Module):
             if not self.train_cfg.rcnn.assigner.get('gt_max_assign_all', True):
                 raise NotImplementedError('gt_max_assign_all=False')
             rois, targets = self._sample_rois_fused(proposal_list, gt_bboxes, gt_labels, samplers)
+            from . import functional as BF
+            mask_fk = None
+            if self.with_mask and rois.is_cuda and BF.rpn_loss_fork_enabled() and not (
+                    torch.is_grad_enabled() and any(p.requires_grad for p in self.mask_head.parameters())):
+                # frozen mask branch (mask RoIAlign, four convs, deconv, targets, BCE): independent of the box
+                # head — beside it on its own stream when the step is launched eagerly
+                with BF.forked(rois.device, lane=2) as mask_fk:
+                    mask_losses = self._mask_forward_train(x, rois, targets[0], gt_masks, img.size(0))
             bbox_feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
             cls_score, bbox_pred = self.bbox_head(bbox_feats, nhwc=True)
             losses.update(self.bbox_head.loss(cls_score, bbox_pred, *targets))
-        if self.with_mask:
+            if mask_fk is not None:
+                mask_fk.join()
+                losses.update(mask_losses)
+            elif self.with_mask:
+                losses.update(self._mask_forward_train(x, rois, targets[0], gt_masks, img.size(0)))
+        elif self.with_mask:
             losses.update(self._mask_forward_train(x, rois, targets[0], gt_masks, img.size(0)))
         self._join_rpn_loss()
         return losses

@@ -70,8 +70,11 @@ class forked(object):
     Tensors allocated inside the block belong to the side stream's pool; they are consumed after ``join()`` and
     freed after it, and the next block starts with an event recorded after those consumers: no reuse race."""
 
-    def __init__(self, device):
-        key = device.index if device.index is not None else torch.cuda.current_device()
+    def __init__(self, device, lane=0):
+        # lane 0: short forks that are joined before the next one opens; lanes 1, 2: long-lived branches (the RPN loss
+        # chain, the mask branch) that stay open across other forks — each lane is its own stream, so a short fork
+        # never queues behind a long one
+        key = (device.index if device.index is not None else torch.cuda.current_device(), int(lane))
         if key not in _SIDE:
             _SIDE[key] = torch.cuda.Stream(device=device)
         self.side = _SIDE[key]
