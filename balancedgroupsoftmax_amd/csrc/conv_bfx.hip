@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx_kernel(HaloBfxAr
 // tap's patch offset is an immediate of the ds_read, no per-step integer division — and (ii) the
 // filter slices stored UNPADDED (32-byte rows) with the two 16-byte halves of a row swapped on odd
 // 8-row groups (conflict-free ds_read_b128 without padding): 50.5 KB of LDS and <= 168 VGPRs ->
-// THREE workgroups per CU.  Measured on the P2 layer (profiles/r2f_pmc_bfx_halo.md): with two
+// THREE workgroups per CU.  Measured on the P2 layer (profiles/r2f_pmc_bfx_halo_raw.txt): with two
 // workgroups per CU the matrix pipe is busy 49 % of the time — the four waves of a workgroup sit
 // on four SIMDs, each shared with ONE wave of another workgroup, and every barrier couples them;
 // a third resident workgroup fills the gaps.  (A mid-step barrier / fragment read-ahead pipeline
