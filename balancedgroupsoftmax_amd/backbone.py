@@ -72,18 +72,43 @@ def _fold_conv_bn(conv, bn, pad_cin_to=None):
         return w.contiguous(), b.contiguous()
 
 
+def _tensor_ids(module):
+    """ids of every registered parameter / buffer object below ``module`` (direct walk of the registration dicts)."""
+    out = []
+    stack = [module]
+    while stack:
+        m = stack.pop()
+        for t in m._parameters.values():
+            out.append(id(t))
+        for t in m._buffers.values():
+            out.append(id(t))
+        stack.extend(m._modules.values())
+    return tuple(out)
+
+
 class _FoldCache(object):
     """Folded weights keyed by parameter version counters."""
 
     def __init__(self):
         self.key = None
         self.data = None
+        self.owner = None
+        self.ids = None
+        self.params = self.tensors = ()
 
     def get(self, module, build):
-        if _trainable(module):       # trained parameters: the fold must be on this step's tape
-            return build()
-        key = tuple((id(t), t._version, t.device) for t in
-                    list(module.parameters()) + list(module.buffers()))
+        # the module's tensors are listed once per set of tensor objects (module.parameters() / .buffers() walk the
+        # tree through generators with duplicate sets: a quarter of the host time of an eagerly launched step);
+        # _tensor_ids walks the same registration dicts directly, so a re-registered parameter or buffer is seen
+        ids = _tensor_ids(module)
+        if self.owner is not module or self.ids != ids:
+            self.owner, self.ids = module, ids
+            self.params = tuple(module.parameters())
+            self.tensors = self.params + tuple(module.buffers())
+            self.key = None
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.params):
+            return build()           # trained parameters: the fold must be on this step's tape
+        key = tuple((id(t), t._version, t.device) for t in self.tensors)
         if key != self.key:
             self.data = build()
             self.key = key
