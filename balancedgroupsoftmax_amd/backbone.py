@@ -92,7 +92,6 @@ class _FoldCache(object):
     def __init__(self):
         self.key = None
         self.data = None
-        self.owner = None
         self.ids = None
         self.params = self.tensors = ()
 
@@ -101,8 +100,8 @@ class _FoldCache(object):
         # tree through generators with duplicate sets: a quarter of the host time of an eagerly launched step);
         # _tensor_ids walks the same registration dicts directly, so a re-registered parameter or buffer is seen
         ids = _tensor_ids(module)
-        if self.owner is not module or self.ids != ids:
-            self.owner, self.ids = module, ids
+        if self.ids != ids:          # (not `module is`: callers may pass a fresh container of the same sub-modules)
+            self.ids = ids
             self.params = tuple(module.parameters())
             self.tensors = self.params + tuple(module.buffers())
             self.key = None
