@@ -85,17 +85,55 @@ __global__ __launch_bounds__(256) void iou_gtmax_kernel(const float* __restrict_
     x1 = b[0]; y1 = b[1]; x2 = b[2]; y2 = b[3];
   }
   const float area = (x2 - x1 + 1.f) * (y2 - y1 + 1.f);
-  float best = -1.f;
-  int barg = 0;
   int* bm = blk_max + ((size_t)n * gridDim.x + blockIdx.x) * gmax_stride;
+  // Bounding box of the workgroup's valid boxes: 256 consecutive anchors are 85 neighbouring locations of one
+  // pyramid level, so a gt that misses this box misses every one of them — min / max are exact and fp subtraction,
+  // addition and the product of non-negatives are monotone, so "the bounding box does not overlap" implies
+  // w * h == 0 for every lane (IoU exactly +0.0).  Such gts (~85 % of the (workgroup, gt) pairs on the fine levels)
+  // are not visited at all: their effect on the outputs — best = 0 / argmax = 0 for a valid box that overlaps
+  // nothing, a workgroup maximum of 0 — is what the initial values below already say.
+  __shared__ float sbb[4][4];
+  __shared__ int s_cnt[4];
+  __shared__ unsigned char slist[kGtChunk];
+  {
+    const float inf = __builtin_inff();
+    const float lx1 = bgs::wave_max(ok ? -x1 : -inf), ly1 = bgs::wave_max(ok ? -y1 : -inf);   // = -min
+    const float lx2 = bgs::wave_max(ok ? x2 : -inf), ly2 = bgs::wave_max(ok ? y2 : -inf);
+    if (lane == 0) {
+      const int w = threadIdx.x >> 6;
+      sbb[w][0] = lx1; sbb[w][1] = ly1; sbb[w][2] = lx2; sbb[w][3] = ly2;
+    }
+  }
+  __syncthreads();
+  const float bb_x1 = -fmaxf(fmaxf(sbb[0][0], sbb[1][0]), fmaxf(sbb[2][0], sbb[3][0]));
+  const float bb_y1 = -fmaxf(fmaxf(sbb[0][1], sbb[1][1]), fmaxf(sbb[2][1], sbb[3][1]));
+  const float bb_x2 = fmaxf(fmaxf(sbb[0][2], sbb[1][2]), fmaxf(sbb[2][2], sbb[3][2]));
+  const float bb_y2 = fmaxf(fmaxf(sbb[0][3], sbb[1][3]), fmaxf(sbb[2][3], sbb[3][3]));
+  const bool any_ok = bb_x2 > -__builtin_inff();           // workgroup-uniform
+  float best = ok ? 0.f : -1.f;                            // (= after a gt with IoU 0: first maximum, argmax 0)
+  int barg = 0;
   for (int c0 = 0; c0 < G; c0 += kGtChunk) {
     const int cn = min(kGtChunk, G - c0);
     __syncthreads();
     for (int t = threadIdx.x; t < cn * 4; t += 256) sgt[t >> 2][t & 3] = gt[(size_t)(g0 + c0) * 4 + t];
-    for (int t = threadIdx.x; t < cn; t += 256) smax[t] = (int)0xBF800000;   // -1.0f
+    for (int t = threadIdx.x; t < cn; t += 256) smax[t] = any_ok ? 0 : (int)0xBF800000;   // 0.0f / -1.0f
     __syncthreads();
-    for (int g = 0; g < cn; ++g) {
-      // most waves of anchors miss a given gt entirely: overlap 0 -> IoU exactly +0.0 (0 / positive), and the
+    // the gts of this chunk that touch the bounding box, in ascending order (thread t tests gt t)
+    {
+      const int t = threadIdx.x;
+      const bool touch = t < cn && iou_overlaps(bb_x1, bb_y1, bb_x2, bb_y2, sgt[t][0], sgt[t][1], sgt[t][2], sgt[t][3]);
+      const unsigned long long m = __ballot(touch);
+      if (lane == 0) s_cnt[t >> 6] = __popcll(m);
+      __syncthreads();
+      int off = 0;
+      for (int w = 0; w < (t >> 6); ++w) off += s_cnt[w];
+      if (touch) slist[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned char)t;
+      __syncthreads();
+    }
+    const int nt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    for (int k = 0; k < nt; ++k) {
+      const int g = slist[k];
+      // most waves of anchors still miss the gt: overlap 0 -> IoU exactly +0.0 (0 / positive), and the
       // ~25 instructions of the exact division are skipped wave-uniformly
       float v = ok ? 0.f : -1.f;
       if (__ballot(ok && iou_overlaps(x1, y1, x2, y2, sgt[g][0], sgt[g][1], sgt[g][2], sgt[g][3])))
@@ -108,8 +146,7 @@ __global__ __launch_bounds__(256) void iou_gtmax_kernel(const float* __restrict_
       // signed-int order == float order for the values used here: -1.0f (negative int) < any
       // IoU >= 0 (non-negative ints, monotone in the float value)
       // (the six-step wave reduction only when some lane beats the maximum seen so far — a same-address LDS
-      //  read is a broadcast and a racy LOWER bound of the running maximum, so skipping is exact: almost every
-      //  wave of anchors misses a given gt)
+      //  read is a broadcast and a racy LOWER bound of the running maximum, so skipping is exact)
       const float seen = __int_as_float(smax[g]);
       if (__ballot(v > seen)) {
         const float wm = bgs::wave_max(v);
