@@ -91,6 +91,11 @@ def init_dist(args):
     #  single-GPU box; the real runs use one GPU per rank over RCCL)
     if os.environ.get('BGS_BENCH_ONE_DEVICE'):
         local = 0
+        # two PROCESSES time-sharing one GPU, each with side streams: the device scheduler thrashes between the
+        # processes' queues at every event edge (185 ms per step instead of 15: profiles/r8q_dist2_onegpu*.json).
+        # One rank per GPU — the real configuration — has no second process on the device; the hook turns the
+        # side-stream forks off for itself.
+        os.environ.setdefault('BGS_LEVEL_FORK', '0')
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
