@@ -1112,7 +1112,7 @@ def main_detector(args, rank, local, world, dev):
         if ms_graph is not None:
             out['ms_per_step_graph'] = ms_graph
         if calib is not None:
-            out['launch_policy'] = dict(calib, note='untimed calibration of both launch policies (8 steps each) '
+            out['launch_calibration'] = dict(calib, note='untimed calibration of both launch policies (8 steps each) '
                                                     'before the timed region; the K timed steps ran under `chosen`')
         if world > 1:
             import torch.distributed as dist
