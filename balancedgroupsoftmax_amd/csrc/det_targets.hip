@@ -110,7 +110,10 @@ __global__ __launch_bounds__(256) void iou_gtmax_kernel(const float* __restrict_
   const float bb_x2 = fmaxf(fmaxf(sbb[0][2], sbb[1][2]), fmaxf(sbb[2][2], sbb[3][2]));
   const float bb_y2 = fmaxf(fmaxf(sbb[0][3], sbb[1][3]), fmaxf(sbb[2][3], sbb[3][3]));
   const bool any_ok = bb_x2 > -__builtin_inff();           // workgroup-uniform
-  float best = ok ? 0.f : -1.f;                            // (= after a gt with IoU 0: first maximum, argmax 0)
+  // (= after a gt with IoU 0: first maximum, argmax 0.  An image WITHOUT gts inside a batch that has some keeps
+  //  best = -1 -> every anchor "ignored" (-1), as before the bounding-box skip existed; the reference raises
+  //  'No gt or bboxes' for such an image, max_iou_assigner.py:83-84, so no sampled negatives may come from it)
+  float best = (ok && G > 0) ? 0.f : -1.f;
   int barg = 0;
   for (int c0 = 0; c0 < G; c0 += kGtChunk) {
     const int cn = min(kGtChunk, G - c0);

@@ -362,12 +362,17 @@ __global__ __launch_bounds__(256) void gather_boxes_kernel(const float* __restri
 // bgs_topk_sorted_f32's composites — found by a binary search of each other level's kept scores.  A workgroup
 // stages the L kept-score lists of its image in LDS (L * nmax floats) and ranks its share of the entries.
 // props [N, num, 5]: entries of rank < num, in rank order; slots past the number of kept boxes: zeros, valid = 0.
+__device__ __forceinline__ unsigned merge_key_of(float f) {   // == key_of of csrc/topk.hip
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 __global__ __launch_bounds__(1024) void nms_merge_select_kernel(const float* __restrict__ boxes,
                                                                 const int* __restrict__ keep,
                                                                 const int* __restrict__ keep_n, int L, int nmax,
                                                                 int num, int parts, float* __restrict__ props,
                                                                 unsigned char* __restrict__ valid) {
-  extern __shared__ float s_sc[];                          // [L][nmax] kept scores of the image, descending per level
+  extern __shared__ unsigned s_key[];                      // [L][nmax] kept scores of the image (as keys), descending per level
   __shared__ int s_n[16];
   const int n = blockIdx.x / parts, part = blockIdx.x - n * parts, tid = threadIdx.x;
   if (tid < L) {
@@ -383,7 +388,10 @@ __global__ __launch_bounds__(1024) void nms_merge_select_kernel(const float* __r
       k = k < 0 ? 0 : (k > nmax - 1 ? nmax - 1 : k);
       sc = boxes[((size_t)(n * L + l) * nmax + k) * 5 + 4];
     }
-    s_sc[e] = sc;
+    // ranked by the order-preserving uint32 image of the float (the order bgs_topk_sorted_f32 sorts by): a TOTAL
+    // order, so a NaN score (which sorts above +inf upstream) cannot make two entries claim one rank or leave a
+    // slot below `total` unwritten, as float comparisons (false both ways against a NaN) could
+    s_key[e] = merge_key_of(sc);
   }
   __syncthreads();
   int total = 0;
@@ -392,16 +400,16 @@ __global__ __launch_bounds__(1024) void nms_merge_select_kernel(const float* __r
   for (int e = part * 1024 + tid; e < L * nmax; e += parts * 1024) {
     const int l = e / nmax, j = e - l * nmax;
     if (j >= s_n[l]) continue;
-    const float sc = s_sc[e];
+    const unsigned sc = s_key[e];
     int rank = j;
     for (int lo = 0; lo < L; ++lo) {
       if (lo == l) continue;
-      const float* v = s_sc + lo * nmax;
+      const unsigned* v = s_key + lo * nmax;
       // number of entries of level `lo` that precede: v is non-increasing; lower levels win ties
       int a = 0, b = s_n[lo];
       while (a < b) {
         const int mid = (a + b) >> 1;
-        const float x = v[mid];
+        const unsigned x = v[mid];
         const bool before = lo < l ? (x >= sc) : (x > sc);
         if (before) a = mid + 1;
         else b = mid;

@@ -229,7 +229,11 @@ __device__ uint32_t kth_smallest_short(const uint32_t* __restrict__ keys, int n,
   const int bits = 32 - __clz((int)(max_key | 1u));
   const int shift = bits > 13 ? bits - 13 : 0;
   for (int b = tid; b < kBinsL; b += kThreadsS) hist[b] = 0;
-  if (tid == 0) s_tmp[2] = 0;
+  if (tid == 0) {
+    s_tmp[2] = 0;
+    s_tmp[3] = 0;
+    s_tmp[4] = 0;                                           // "found": exactly one lane matched the rank
+  }
   __syncthreads();
   for (int i = tid; i < n; i += kThreadsS) atomicAdd(&hist[keys[i] >> shift], 1);
   __syncthreads();
@@ -281,10 +285,16 @@ __device__ uint32_t kth_smallest_short(const uint32_t* __restrict__ keys, int n,
     const uint32_t mykey = tid < m ? s_small[tid] : 0xffffffffu;
     int rank = 0;
     for (int j = 0; j < m; ++j) rank += s_small[j] < mykey;
-    if (tid < m && rank == kin - 1) s_tmp[3] = (int)mykey;   // keys are distinct: exactly one lane
+    // distinct keys (mix32 is a bijection of the anchor index): exactly one lane.  A key source with duplicates
+    // would leave no lane at rank kin - 1 (ties share the lower rank): then `found` stays 0, *done = 0, and the
+    // caller's three-pass select — which handles duplicates — runs instead of a stale threshold being returned
+    if (tid < m && rank == kin - 1) {
+      s_tmp[3] = (int)mykey;
+      atomicAdd(&s_tmp[4], 1);
+    }
   }
   __syncthreads();
-  *done = m <= 64;
+  *done = (m <= 64 && s_tmp[4] == 1) ? 1 : 0;
   const uint32_t r = (uint32_t)s_tmp[3];
   __syncthreads();
   return r;

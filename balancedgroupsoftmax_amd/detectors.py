@@ -189,6 +189,10 @@ class TwoStageDetector(nn.Module):
             with BF.forked(cls_scores[0].device, lane=1) as fk:
                 losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
                                                  self.train_cfg.rpn, samplers=samplers))
+            # the chain reads the RPN outputs (main / lane-0 pools) long after this function has dropped its
+            # references (``_fused = None`` below, the return): held until ``_join_rpn_loss`` so that the caching
+            # allocator cannot hand their blocks to the RoI stage while ``rpn_loss_kernel`` is still reading them
+            fk.hold(cls_scores, bbox_preds, self.rpn_head._fused, gt_bboxes)
             self._rpn_loss_fork = fk
         else:
             losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_meta,
@@ -234,6 +238,7 @@ class TwoStageDetector(nn.Module):
                 # head — beside it on its own stream when the step is launched eagerly
                 with BF.forked(rois.device, lane=2) as mask_fk:
                     mask_losses = self._mask_forward_train(x, rois, targets[0], gt_masks, img.size(0))
+                mask_fk.hold(x, rois, targets, gt_masks)
             bbox_feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
             cls_score, bbox_pred = self.bbox_head(bbox_feats, nhwc=True)
             losses.update(self.bbox_head.loss(cls_score, bbox_pred, *targets))

@@ -68,7 +68,11 @@ class forked(object):
     a replayed hipGraph).  Dependent chains of tiny kernels do NOT gain from a fork (an event edge costs more than
     a back-to-back launch: 69 -> 139 us for two chains of 20), so only conv launches are forked.
     Tensors allocated inside the block belong to the side stream's pool; they are consumed after ``join()`` and
-    freed after it, and the next block starts with an event recorded after those consumers: no reuse race."""
+    freed after it, and the next block starts with an event recorded after those consumers: no reuse race.
+    Tensors allocated on the MAIN stream that the block only reads are a different matter: if the host drops its
+    last reference before ``join()``, the caching allocator may hand the block to a later main-stream allocation
+    that is not ordered against the side stream.  ``hold(*tensors)`` keeps such inputs alive until ``join()``
+    (which orders the main stream after the block) — every long-lived fork must hold what it reads."""
 
     def __init__(self, device, lane=0):
         # lane 0: short forks that are joined before the next one opens; lanes 1, 2: long-lived branches (the RPN loss
@@ -80,6 +84,14 @@ class forked(object):
         self.side = _SIDE[key]
         self.device = device
         self.done = None
+        self._held = None
+
+    def hold(self, *tensors):
+        """Keep main-stream tensors (or nests of them) that the forked block reads alive until ``join()``."""
+        if self._held is None:
+            self._held = []
+        self._held.extend(tensors)
+        return self
 
     def __enter__(self):
         main = torch.cuda.current_stream(self.device)
@@ -98,6 +110,8 @@ class forked(object):
 
     def join(self):
         torch.cuda.current_stream(self.device).wait_event(self.done)
+        # from here on every main-stream launch is ordered after the block: its inputs may be recycled
+        self._held = None
 
 
 def _require_cuda(*tensors):
@@ -1632,10 +1646,12 @@ def nms_gather(boxes, keep, keep_count):
     return out, sc
 
 
-def nms_merge_select(boxes, keep, keep_count, num_images, num):
+def nms_merge_select(boxes, keep, keep_count, num_images, num, out=None):
     """The proposal tail in one launch (``bgs_nms_merge_select``): ``boxes [N*L,nmax,5]`` (rows sorted by
     descending score), ``keep`` / ``keep_count`` of :func:`nms_batched` -> ``(props [N,num,5], valid [N,num] bool)``:
-    the ``num`` best kept boxes of each image over its L levels, in descending score order."""
+    the ``num`` best kept boxes of each image over its L levels, in descending score order.  Every slot is
+    written (ranks are a permutation under the kernel's total order; the slots past the kept total are zeroed).
+    ``out``: optional pre-allocated ``(props f32, valid u8)`` pair (tests poison it to prove full coverage)."""
     _require_cuda(boxes, keep, keep_count)
     lib = capi.load()
     assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.dim() == 3 and boxes.shape[2] == 5
@@ -1643,8 +1659,13 @@ def nms_merge_select(boxes, keep, keep_count, num_images, num):
     R, nmax, _ = boxes.shape
     N = int(num_images)
     assert R % N == 0
-    props = torch.empty((N, int(num), 5), dtype=torch.float32, device=boxes.device)
-    valid = torch.empty((N, int(num)), dtype=torch.uint8, device=boxes.device)
+    if out is None:
+        props = torch.empty((N, int(num), 5), dtype=torch.float32, device=boxes.device)
+        valid = torch.empty((N, int(num)), dtype=torch.uint8, device=boxes.device)
+    else:
+        props, valid = out
+        assert props.shape == (N, int(num), 5) and props.dtype == torch.float32 and props.is_contiguous()
+        assert valid.shape == (N, int(num)) and valid.dtype == torch.uint8 and valid.is_contiguous()
     rc = lib.bgs_nms_merge_select(capi.ptr(boxes), capi.ptr(keep), capi.ptr(keep_count.contiguous()), N, R // N,
                                   nmax, int(num), capi.ptr(props), capi.ptr(valid),
                                   capi.current_stream(boxes.device))

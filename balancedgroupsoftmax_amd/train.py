@@ -338,11 +338,12 @@ def _bump_versions(tensors):
     see; every cache in this package that is keyed on ``Parameter._version`` (split bf16 planes, folded BN,
     permuted fc1 weights, the mask / semantic / deconv head folds) must notice the update exactly as it would
     after ``torch.optim.SGD.step()``'s in-place ops.  ``increment_version`` is bookkeeping only — no launch,
-    legal under hipGraph capture."""
+    legal under hipGraph capture (both forms below)."""
     try:
         torch.autograd.graph.increment_version(tensors)
-    except (AttributeError, TypeError):                      # older torch: a zero-add per tensor list
-        torch._foreach_add_(tensors, 0)
+    except (AttributeError, TypeError):                      # older torch: the private per-tensor form
+        for t in tensors:
+            torch._C._increment_version(t)
 
 
 class DistOptimizerStep(object):

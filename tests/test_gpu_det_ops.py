@@ -364,6 +364,37 @@ def test_proposal_tail_merge_equals_the_topk_tail(case):
         assert float(props[n, nv[n]:].abs().max() if nv[n] < num else 0.0) == 0.0
 
 
+def test_proposal_tail_merge_with_nan_and_equal_scores_fills_every_slot():
+    """Ranks come from a TOTAL order (the uint32 key image of the score, as in bgs_topk_sorted_f32), so NaN scores
+    (sorted above +inf upstream) and runs of equal scores across levels cannot make two entries claim one output
+    slot or leave a slot below the kept total unwritten."""
+    N, L, nmax, num = 2, 4, 64, 200
+    boxes = np.zeros((N * L, nmax, 5), np.float32)
+    for r in range(N * L):
+        d = det_oracle.make_boxes(nmax, seed=300 + r)
+        d[:, 4] = np.round(d[:, 4] * 8) / 8                # eight distinct values: long tie runs across levels
+        d = d[np.argsort(-d[:, 4], kind='stable')]
+        if r % 2 == 0:
+            d[:3, 4] = np.nan                              # NaNs lead a descending list (key order)
+        boxes[r] = d
+        boxes[r, :, 0] = r * 1000 + np.arange(nmax)        # every box identifiable
+    keep = torch.arange(nmax, dtype=torch.int32, device=DEV).repeat(N * L, 1).contiguous()
+    kc = torch.tensor([50, 64, 0, 33, 64, 1, 17, 64], dtype=torch.int32, device=DEV)
+    props = torch.full((N, num, 5), -7.0, device=DEV)
+    valid = torch.full((N, num), 9, dtype=torch.uint8, device=DEV)
+    props, valid = BF.nms_merge_select(dev(boxes), keep, kc, N, num, out=(props, valid))
+    for n in range(N):
+        total = min(int(kc.view(N, L)[n].sum()), num)
+        v = valid[n].cpu().numpy()
+        assert (v[:total] == 1).all() and (v[total:] == 0).all()
+        ids = props[n, :total, 0].cpu().numpy()
+        assert len(set(ids.tolist())) == total and (ids >= 0).all()     # a permutation of kept boxes, none twice
+        sc = props[n, :total, 4].cpu().numpy()
+        lead = int(np.isnan(sc).sum())
+        assert np.isnan(sc[:lead]).all() and (np.diff(sc[lead:]) <= 0).all()
+        assert float(props[n, total:].abs().max()) == 0.0 if total < num else True
+
+
 # ---------------------------------------------------------------- multiclass NMS (test-time path)
 def _mc_cases():
     import json

@@ -251,6 +251,45 @@ def test_iou_assign_kernel_equals_tensor_form(thr):
         assert torch.equal(got2[i].cpu().long(), exp)
 
 
+def test_iou_assign_image_without_gts_inside_a_batch_is_all_ignored():
+    """A gt-free image next to images that have gts: every anchor of it stays -1 ("ignored"), no negatives are
+    invented for the sampler.  (The reference raises 'No gt or bboxes' for such an image,
+    max_iou_assigner.py:83-84; ADVICE round 4: the bounding-box skip had silently turned them into negatives.)"""
+    from balancedgroupsoftmax_amd import functional as BF
+    gts = [_rand_boxes(7, 1), _rand_boxes(0, 2), _rand_boxes(3, 3)]
+    offs = [0, 7, 7, 10]
+    boxes = _rand_boxes(3000, 11)
+    valid = (torch.rand(3, 3000, generator=torch.Generator().manual_seed(6)) > 0.2)
+    got, mo = BF.iou_assign(boxes.to(DEV), torch.cat(gts).to(DEV), offs, 0.7, 0.3, 0.3,
+                            valid=valid.to(torch.uint8).to(DEV), shared_boxes=True, return_max_overlaps=True)
+    assert (got[1] == -1).all()
+    assert (mo[1] == -1).all()
+    assert (got[0][valid[0].to(DEV)] >= 0).all() and (got[2][valid[2].to(DEV)] >= 0).all()
+    assert (got[0][~valid[0].to(DEV)] == -1).all()
+
+
+def test_side_stream_fork_holds_its_main_stream_inputs_until_join():
+    """``forked.hold``: tensors of the main stream's pool that a long-lived fork reads stay referenced until
+    ``join()`` (the RPN loss chain read RPN outputs whose last host reference was dropped before
+    the join, so the caching allocator could recycle them under the kernel)."""
+    import gc
+    import weakref
+    from balancedgroupsoftmax_amd import functional as BF
+    d = torch.device(DEV)
+    a = torch.ones(1 << 20, device=d)
+    wr = weakref.ref(a)
+    with BF.forked(d, lane=1) as fk:
+        s = a.sum()
+    fk.hold([a], (a,))
+    del a
+    gc.collect()
+    assert wr() is not None                       # still alive: the side stream may be reading it
+    fk.join()
+    gc.collect()
+    assert wr() is None                           # released once the main stream is ordered after the block
+    assert float(s) == float(1 << 20)
+
+
 def test_rpn_fused_loss_and_proposals_equal_tensor_form(tmp_path):
     model = _detector(tmp_path).to(DEV)
     for p in model.parameters():
