@@ -149,11 +149,63 @@ def select_training_param(model, selectp):
 
 
 def build_optimizer(params, cfg):
-    """``optimizer = dict(type='SGD', lr, momentum, weight_decay)`` (mmdet/apis/train.py:63-140,
-    plain branch without paramwise options)."""
+    """``optimizer = dict(type='SGD', lr, momentum, weight_decay[, paramwise_options])``
+    (mmdet/apis/train.py:63-140).
+
+    ``params``: a model (``nn.Module``, possibly wrapped with ``.module`` — the reference's own argument), an
+    iterable of ``(name, parameter)`` pairs, or a plain list of parameters (plain branch only: the paramwise
+    rules are keyed on parameter NAMES).
+
+    Plain branch (:95-100): the global settings for every parameter that requires a gradient.
+    ``paramwise_options`` (:101-140; none of ``configs/bags/*`` sets it): one param group per parameter —
+    ``(bn|gn)(\\d+)?.(weight|bias)`` names get ``weight_decay * norm_decay_mult``; other ``.bias`` names get
+    ``lr * bias_lr_mult`` and ``weight_decay * bias_decay_mult``; frozen parameters keep a group of their own
+    with the global settings (the reference keeps them "to align with model.parameters()" for its fp16 master
+    copies).  With more than one group ``DistOptimizerStep`` takes the ``clip_grad_norm_`` +
+    ``torch.optim.SGD.step`` route instead of the fused single-group kernels (``_fused_sgd_eligible``)."""
+    import re
     cfg = dict(cfg)
+    paramwise = cfg.pop('paramwise_options', None)
     typ = cfg.pop('type')
-    return getattr(torch.optim, typ)(params, **cfg)
+    named = None
+    if isinstance(params, torch.nn.Module):
+        model = params.module if hasattr(params, 'module') else params
+        named = list(model.named_parameters())
+        plain = [p for _, p in named if p.requires_grad]
+    else:
+        params = list(params)
+        if params and isinstance(params[0], (tuple, list)) and len(params[0]) == 2 \
+                and isinstance(params[0][0], str):
+            named = [(n, p) for n, p in params]
+            plain = [p for _, p in named if p.requires_grad]
+        else:
+            plain = params
+    if paramwise is None:
+        return getattr(torch.optim, typ)(plain, **cfg)
+    if not isinstance(paramwise, dict):
+        raise AssertionError('paramwise_options must be a dict')
+    if named is None:
+        raise TypeError('paramwise_options are keyed on parameter names: pass the model or (name, parameter) pairs')
+    base_lr = cfg['lr']
+    base_wd = cfg.get('weight_decay', None)
+    if 'bias_decay_mult' in paramwise or 'norm_decay_mult' in paramwise:
+        assert base_wd is not None, 'weight_decay must be given when a decay multiplier is'
+    bias_lr_mult = paramwise.get('bias_lr_mult', 1.)
+    bias_decay_mult = paramwise.get('bias_decay_mult', 1.)
+    norm_decay_mult = paramwise.get('norm_decay_mult', 1.)
+    groups = []
+    for name, param in named:
+        group = {'params': [param]}
+        if param.requires_grad:
+            if re.search(r'(bn|gn)(\d+)?.(weight|bias)', name):
+                if base_wd is not None:
+                    group['weight_decay'] = base_wd * norm_decay_mult
+            elif name.endswith('.bias'):
+                group['lr'] = base_lr * bias_lr_mult
+                if base_wd is not None:
+                    group['weight_decay'] = base_wd * bias_decay_mult
+        groups.append(group)
+    return getattr(torch.optim, typ)(groups, **cfg)
 
 
 _EXCHANGE_AT_ONE = [False]
@@ -247,11 +299,13 @@ class OverlappedGradExchange(object):
         iteration, waits for the collectives and writes the averaged gradients back."""
         if self.world_size == 1:
             return
+        filled = []
         for bi, left in enumerate(self._pending):
             if left > 0 and any(p.grad is not None for p in self.buckets[bi]):
                 for p in self.buckets[bi]:
                     if p.grad is None:
-                        p.grad = torch.zeros_like(p)
+                        p.grad = torch.zeros_like(p)          # keeps the bucket's flat layout equal on every rank
+                        filled.append(p)
                 self._launch(bi)
         for bi, flat, work in self._inflight:
             work.wait()
@@ -261,6 +315,11 @@ class OverlappedGradExchange(object):
                 n = p.numel()
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
+        # a parameter that received no gradient must look to the optimizer as it does in the reference
+        # (`_allreduce_coalesced` leaves it out, dist_utils.py:33-38, and SGD skips `grad is None`): with the zero
+        # placeholder left in place it would still be weight-decayed
+        for p in filled:
+            p.grad = None
         self._inflight = []
         self._pending = [len(b) for b in self.buckets]
 

@@ -171,3 +171,65 @@ def test_exchange_at_world_size_one_hook_runs_the_collective():
     the gradient exchange issues its flat all-reduce even in a 1-rank group, without it it does not."""
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_one_rank_worker, args=(1, port), nprocs=1, join=True)
+
+
+def _ws8_net():
+    torch.manual_seed(0)
+    # 12*20+20 + 20*20+20 + 20*7+7 + 7*3+3 floats: with 600-byte buckets the LAST bucket (the first layer's
+    # tensors, produced last by backward) is smaller than the others
+    net = torch.nn.Sequential(torch.nn.Linear(12, 20), torch.nn.Tanh(), torch.nn.Linear(20, 20), torch.nn.Tanh(),
+                              torch.nn.Linear(20, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
+    unused = torch.nn.Linear(5, 5)                          # trainable but never in the graph: no gradient
+    return net, unused
+
+
+def _ws8_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        net, unused = _ws8_net()
+        params = list(net.parameters()) + list(unused.parameters())
+        ex = train.OverlappedGradExchange(params, world, bucket_bytes=600)
+        sizes = [sum(p.numel() * 4 for p in b) for b in ex.buckets]
+        assert len(ex.buckets) >= 3 and sizes[-1] < max(sizes)
+        assert any(id(p) in ex._bucket_of and len(ex.buckets[ex._bucket_of[id(p)]]) > 2 for p in unused.parameters())
+        g = torch.Generator().manual_seed(300 + rank)
+        for it in range(2):                                  # the per-iteration state resets
+            for p in params:
+                p.grad = None
+            x = torch.randn(6, 12, generator=g)
+            net(x).pow(2).mean().backward()                  # hooks launch the bucket all-reduces
+            ex.finish()
+        assert all(p.grad is None for p in unused.parameters())
+        if rank in (0, world - 1):
+            torch.save([p.grad.clone() for p in net.parameters()], os.path.join(out_dir, 'ws8_rank%d.pt' % rank))
+        ex.remove()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_exchange_world_size_8_uneven_last_bucket_and_a_parameter_without_gradient(tmp_path):
+    """Eight ranks over gloo (the node size the data-parallel path is specified for, dist_utils.py:9-58): the
+    bucketed backward-overlapped exchange leaves on every rank the MEAN over the eight rank-local gradients,
+    with a short last bucket and with trainable parameters that receive no gradient (they are skipped, their
+    bucket still completes)."""
+    world = 8
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_ws8_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    first = torch.load(os.path.join(str(tmp_path), 'ws8_rank0.pt'))
+    last = torch.load(os.path.join(str(tmp_path), 'ws8_rank%d.pt' % (world - 1)))
+    net, _ = _ws8_net()
+    mean = [torch.zeros_like(p) for p in net.parameters()]
+    for rank in range(world):
+        g = torch.Generator().manual_seed(300 + rank)
+        for it in range(2):
+            x = torch.randn(6, 12, generator=g)
+        net.zero_grad()
+        net(x).pow(2).mean().backward()
+        for m, p in zip(mean, net.parameters()):
+            m += p.grad / world
+    for a, b, m in zip(first, last, mean):
+        assert torch.equal(a, b)                            # the same bits on every rank
+        assert torch.allclose(a, m, atol=1e-6, rtol=1e-5)

@@ -147,3 +147,69 @@ def test_halo_kernel_dispatch_policy(monkeypatch):
     assert not BF._use_halo_kernel(2 * 200 * 336, 256)
     monkeypatch.setenv('BGS_CONV_HALO', '1')
     assert BF._use_halo_kernel(10, 15)
+
+
+def _tiny_model():
+    import torch.nn as nn
+
+    class Blk(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 4, 3)
+            self.bn1 = nn.BatchNorm2d(4)
+            self.gn = nn.GroupNorm(2, 4)
+            self.fc_cls = nn.Linear(4, 5)
+            self.fc_frozen = nn.Linear(4, 2)
+            for p in self.fc_frozen.parameters():
+                p.requires_grad = False
+    return Blk()
+
+
+def test_build_optimizer_plain_and_paramwise_rules():
+    """mmdet/apis/train.py:63-140: plain branch = the trainable parameters under the global settings;
+    ``paramwise_options`` = one group per parameter with the norm / bias multipliers."""
+    from balancedgroupsoftmax_amd import train
+    m = _tiny_model()
+    cfg = dict(type='SGD', lr=0.02, momentum=0.9, weight_decay=1e-4)
+    opt = train.build_optimizer(m, cfg)
+    assert len(opt.param_groups) == 1
+    assert [id(p) for p in opt.param_groups[0]['params']] == [id(p) for p in m.parameters() if p.requires_grad]
+    assert cfg['type'] == 'SGD'                                          # the caller's dict is not consumed
+    opt = train.build_optimizer(m, dict(cfg, paramwise_options=dict(bias_lr_mult=2., bias_decay_mult=0.,
+                                                                    norm_decay_mult=0.5)))
+    by_name = {n: g for (n, _), g in zip(m.named_parameters(), opt.param_groups)}
+    assert len(opt.param_groups) == len(list(m.named_parameters()))
+    assert by_name['conv1.weight']['lr'] == 0.02 and by_name['conv1.weight']['weight_decay'] == 1e-4
+    assert by_name['conv1.bias']['lr'] == 0.04 and by_name['conv1.bias']['weight_decay'] == 0.
+    assert by_name['bn1.weight']['weight_decay'] == 5e-5 and by_name['bn1.bias']['weight_decay'] == 5e-5
+    assert by_name['bn1.bias']['lr'] == 0.02                              # norm rule wins over the bias rule
+    assert by_name['gn.weight']['weight_decay'] == 5e-5
+    assert by_name['fc_frozen.bias']['lr'] == 0.02 and by_name['fc_frozen.bias']['weight_decay'] == 1e-4
+    with pytest.raises(TypeError):
+        train.build_optimizer(list(m.parameters()), dict(cfg, paramwise_options=dict(bias_lr_mult=2.)))
+    with pytest.raises(AssertionError):
+        train.build_optimizer(m, dict(type='SGD', lr=0.1, paramwise_options=dict(norm_decay_mult=0.)))
+
+
+def test_build_optimizer_paramwise_equals_the_executed_reference():
+    from oracle import ref_import
+    if not ref_import.reference_available():
+        pytest.skip('reference tree not present')
+    ref_import.install_stubs()
+    try:
+        from mmdet.apis.train import build_optimizer as ref_build
+    except Exception as e:                                                # the apis module pulls mmcv.runner etc.
+        pytest.skip('reference apis.train not importable under the stubs: %r' % (e,))
+    from balancedgroupsoftmax_amd import train
+    from balancedgroupsoftmax_amd.config import to_config_dict
+    m = _tiny_model()
+    for pw in (None, dict(bias_lr_mult=2., bias_decay_mult=0., norm_decay_mult=0.5), dict(bias_lr_mult=3.)):
+        cfg = dict(type='SGD', lr=0.02, momentum=0.9, weight_decay=1e-4)
+        if pw is not None:
+            cfg['paramwise_options'] = pw
+        mine, ref = train.build_optimizer(m, cfg), ref_build(m, to_config_dict(cfg))
+        assert len(mine.param_groups) == len(ref.param_groups)
+        for a, b in zip(mine.param_groups, ref.param_groups):
+            assert [id(p) for p in a['params']] == [id(p) for p in b['params']]
+            for k in ('lr', 'momentum', 'weight_decay', 'dampening', 'nesterov'):
+                assert a[k] == b[k], k
