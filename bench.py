@@ -586,6 +586,162 @@ def kernel_roofline(inp, n, iters=300, kernel='fused'):
                                                      '(steady state, see _event_time_us)' if n >= 16384 else ''))
 
 
+def capture_head_inputs(dev, conv_math='bf16x6'):
+    """One eager cfg[1] iteration with spies on the RoI extractor and the RPN assigner: the REAL operands of the
+    HBM-bound helper kernels (sampled RoIs + the NHWC pyramid; anchors, inside flags, gts) for their standalone
+    rooflines and for tools/kernel_once.py (the PMC passes)."""
+    step = DetectorStep(dev, 0, 1, 2, 1, conv_math=conv_math)
+    cap = {}
+    ext = step.model.bbox_roi_extractor
+    orig = ext.forward
+
+    def spy(feats, rois, *a, **k):
+        cap['feats'] = [f.detach() for f in feats[:ext.num_inputs]]
+        cap['rois'] = rois.detach().clone()
+        cap['strides'] = list(ext.featmap_strides)
+        cap['out_size'], cap['sample_num'], cap['finest_scale'] = ext.out_size, ext.sample_num, ext.finest_scale
+        return orig(feats, rois, *a, **k)
+
+    ext.forward = spy
+    orig_assign = BF.iou_assign
+
+    def spy_assign(boxes, gt_cat, offs, pos, neg, minpos=0.0, valid=None, shared_boxes=False, **k):
+        if shared_boxes and 'anchors' not in cap:
+            cap['anchors'], cap['gt_cat'], cap['gt_offs'] = boxes, gt_cat.clone(), list(offs)
+            cap['assign_thr'] = (pos, neg, minpos)
+            cap['inside'] = valid
+        return orig_assign(boxes, gt_cat, offs, pos, neg, minpos, valid=valid, shared_boxes=shared_boxes, **k)
+
+    BF.iou_assign = spy_assign
+    try:
+        os.environ['BGS_RPN_LOSS_FORK'] = '0'
+        step()
+        torch.cuda.synchronize()
+    finally:
+        BF.iou_assign = orig_assign
+        ext.forward = orig
+        os.environ.pop('BGS_RPN_LOSS_FORK', None)
+    del step
+    return cap
+
+
+def roi_footprint_bytes(rois, shapes, strides, C, out_size=7, sample_num=2, finest_scale=56.0):
+    """the unique input footprint of every RoI, exactly, from the RoIs themselves — the set of
+    feature-map pixels its out x out x sample_num^2 bilinear sample points touch (level map single_level.py:69-72,
+    sample geometry and the clamping / out-of-bounds rules of roi_align_kernel.cu:16-61,86-118), x C x 4 bytes.
+    Returns (sum over RoIs of per-RoI footprints, bytes of the UNION over all RoIs, per-level RoI counts)."""
+    r = rois.detach().cpu().numpy().astype(np.float32)
+    L = len(strides)
+    f32 = np.float32
+    scale = np.sqrt((r[:, 3] - r[:, 1] + f32(1)) * (r[:, 4] - r[:, 2] + f32(1)))
+    lvl = np.clip(np.floor(np.log2(scale / f32(finest_scale) + f32(1e-6))), 0, L - 1).astype(np.int64)
+    per_roi = 0
+    union = [dict() for _ in range(L)]
+    g = (np.arange(out_size * sample_num, dtype=np.float32) + f32(0.5)) / f32(sample_num)   # sample offsets in bins
+    for k in range(r.shape[0]):
+        l = int(lvl[k])
+        n = int(r[k, 0])
+        H, W = shapes[l]
+        ss = f32(1.0 / strides[l])
+        x1, y1 = r[k, 1] * ss, r[k, 2] * ss
+        rw = max((r[k, 3] + f32(1)) * ss - x1, f32(0))
+        rh = max((r[k, 4] + f32(1)) * ss - y1, f32(0))
+        ys = y1 + g * (rh / f32(out_size))
+        xs = x1 + g * (rw / f32(out_size))
+
+        def axis(v, S):
+            ok = (v >= -1.0) & (v <= S)
+            v = np.maximum(v, 0)
+            lo = np.minimum(v.astype(np.int64), S - 1)
+            hi = np.minimum(lo + 1, S - 1)
+            return ok, lo, hi
+
+        oky, ylo, yhi = axis(ys, H)
+        okx, xlo, xhi = axis(xs, W)
+        rows = np.unique(np.concatenate([ylo[oky], yhi[oky]]))
+        cols = np.unique(np.concatenate([xlo[okx], xhi[okx]]))
+        per_roi += rows.size * cols.size
+        u = union[l].setdefault(n, np.zeros((H, W), dtype=bool))
+        if rows.size and cols.size:
+            u[np.ix_(rows, cols)] = True
+    union_px = sum(int(m.sum()) for d in union for m in d.values())
+    counts = [int((lvl == l).sum()) for l in range(L)]
+    return per_roi * C * 4, union_px * C * 4, counts
+
+
+def hbm_kernel_rooflines(dev, conv_math='bf16x6'):
+    """SURVEY.md 8(d)'s other HBM-bound kernels on the operands of a real cfg[1] iteration: RoIAlign forward,
+    `_merge_score` (R = 1000 as at test time, and R = 65,536 where the roofline applies), IoU / assignment of the
+    RPN's 268,569 anchors x 2 images.  hipEvent time of back-to-back launches; `traffic` from the committed PMC
+    passes (tools/pmc_hbm_kernels.sh -> profiles/pmc_traffic.json)."""
+    res = {}
+    cap = capture_head_inputs(dev, conv_math)
+    feats, rois = cap['feats'], cap['rois']
+    K, C = int(rois.shape[0]), int(feats[0].shape[3])
+    shapes = [(int(f.shape[1]), int(f.shape[2])) for f in feats]
+    out_bytes = K * cap['out_size'] ** 2 * C * 4
+    pyramid = sum(int(f.numel()) * 4 for f in feats)
+    fp_sum, fp_union, counts = roi_footprint_bytes(rois, shapes, cap['strides'], C, cap['out_size'],
+                                                   cap['sample_num'], cap['finest_scale'])
+    us = _event_time_us(lambda: BF.roi_align_nhwc(feats, rois, cap['strides'], cap['out_size'], cap['sample_num'],
+                                                  cap['finest_scale']), 50, settle=4)
+    alg = out_bytes + min(pyramid, fp_sum)
+    kname = 'roi_align_nhwc_kernel<2,false,1,false>'
+    tr, src = _pmc_traffic(kname, K)
+    res['roofline_roi_align'] = dict(
+        bound='hbm', achieved=round(alg / (us * 1e-6) / 1e9, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+        frac=round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), traffic=tr,
+        traffic_source=('committed PMC measurement, not collected in this run: %s' % src) if src else None,
+        kernel=kname, us_per_launch=round(us, 2), rois_per_launch=K, rois_per_level=counts,
+        algorithmic_bytes=alg, output_bytes=out_bytes, pyramid_bytes=pyramid,
+        sum_of_per_roi_footprints=fp_sum, union_of_footprints=fp_union,
+        bytes_issued_by_the_taps=K * cap['out_size'] ** 2 * cap['sample_num'] ** 2 * 4 * C * 4,
+        frac_with_union_footprint=round((out_bytes + fp_union) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+        note='SURVEY 8(d): bytes = output + min(pyramid, sum of per-RoI unique footprints), footprints computed '
+             'exactly from the sampled RoIs of a real iteration (roi_footprint_bytes); `union_of_footprints` is '
+             'what a perfect cache would fetch once')
+    del feats, cap['feats']
+    # _merge_score: read W*4 + write C*4 per RoI
+    tdir = __import__('tempfile').mkdtemp(prefix='bgs_tables_')
+    counts_t = gs_tables.synthetic_instance_counts(NUM_CLASSES, seed=0)
+    l2b, ps, _ = gs_tables.build_group_tables(counts_t)
+    c2c = gs_tables.class_to_column(l2b, ps).to(dev)
+    W = int(ps[:, 1].sum())
+    for R, iters in ((1000, 200), (65536, 30)):
+        z = torch.randn(R, W, device=dev)
+        us = _event_time_us(lambda: BF.gs_merge_score(z, ps, c2c, NUM_CLASSES), iters, settle=6 if R > 4096 else 0)
+        alg = R * (W * 4 + NUM_CLASSES * 4)
+        kname = 'gs_merge_rowwave_kernel'
+        tr, src = _pmc_traffic(kname, R)
+        res['roofline_merge_score' + ('' if R == 1000 else '_n%d' % R)] = dict(
+            bound='hbm', achieved=round(alg / (us * 1e-6) / 1e9, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+            frac=round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), traffic=tr,
+            traffic_source=('committed PMC measurement, not collected in this run: %s' % src) if src else None,
+            kernel=kname, us_per_launch=round(us, 2), rois_per_launch=R,
+            algorithmic_bytes_per_roi=W * 4 + NUM_CLASSES * 4,
+            note='includes the [R, 1231] output allocation of the wrapper (no launch)')
+        del z
+    # IoU + MaxIoUAssigner of the RPN: per image A anchors x (16 B box + 1 B inside flag) read, 4 B written
+    if 'anchors' in cap:
+        A = int(cap['anchors'].shape[0])
+        N = len(cap['gt_offs']) - 1
+        pos, neg, minpos = cap['assign_thr']
+        us = _event_time_us(lambda: BF.iou_assign(cap['anchors'], cap['gt_cat'], cap['gt_offs'], pos, neg, minpos,
+                                                  valid=cap['inside'], shared_boxes=True), 100)
+        alg = N * A * (16 + 1 + 4) + int(cap['gt_cat'].numel()) * 4
+        tr, src = _pmc_traffic('iou_gtmax_kernel+iou_assign_kernel', A)
+        res['roofline_iou_assign'] = dict(
+            bound='hbm', achieved=round(alg / (us * 1e-6) / 1e9, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+            frac=round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), traffic=tr,
+            traffic_source=('committed PMC measurement, not collected in this run: %s' % src) if src else None,
+            kernel='fill_i32_kernel + iou_gtmax_kernel + iou_assign_kernel (bgs_iou_assign: 3 launches)',
+            us_per_call=round(us, 2), anchors=A, images=N, gts=int(cap['gt_cat'].shape[0]),
+            algorithmic_bytes=alg,
+            note='HBM-bound by class (SURVEY 8d) but 11 MB per call: three dependent launches of ~5 us each are '
+                 'launch / latency bound, the figure to read is us_per_call')
+    return res
+
+
 def _cpu_time_threads(fn, n, seconds, cores):
     """median time of fn() per thread count; best of 1 / 8 / 32 / min(cores, 64)."""
     best, tried = None, {}
@@ -872,6 +1028,12 @@ def finish_line(out, args, dev, world):
             out['gs_head'] = gs_head_metric(gs_inp, 1024)
         del gs_inp
         torch.cuda.empty_cache()
+        if world == 1 and not args.mask and not args.cascade and not args.htc:
+            try:
+                out.update(hbm_kernel_rooflines(dev, args.conv_math))
+            except Exception as e:  # pragma: no cover  (never lose the line to a secondary measurement)
+                out['roofline_hbm_kernels_error'] = repr(e)[:300]
+            torch.cuda.empty_cache()
     if run_extras:
         out['also_measured'] = extras(dev, args)
     if world == 1 and not args.no_cpu_baseline:
@@ -982,6 +1144,55 @@ def run_dist_graph_children(args, rank, local, world):
     return res if rank == 0 else None
 
 
+def calibrate_dist_forks(step, world):
+    """N > 1, `--launch auto`: the side-stream forks (functional.forked) are worth 0.1 - 0.3 ms per step when a rank
+    has its GPU and a host core to itself, but they are also what made two processes on ONE device thrash (15 ->
+    185 ms per step, profiles/r8q_dist2_onegpu_forks.json) — and eight Python processes launching eagerly on one
+    host is a regime nobody has timed.  So both arms are calibrated UNTIMED here (8 steps each, eager launches, the
+    gradient exchange included; max over ranks decides, so every rank takes the same arm) and the K timed steps run
+    under the faster one.  The fork switches are read at every call (DESIGN 5, A/B switches)."""
+    import torch.distributed as dist
+    arms = {}
+    per_rank = {}
+    for name, val in (('forks_on', '1'), ('forks_off', '0')):
+        os.environ['BGS_LEVEL_FORK'] = val
+        dt = timed_loop(step, 8, 4 if name == 'forks_on' else 2, world)
+        arms[name] = round(dt * 1e3 / 8, 3)
+        mine = torch.tensor([timed_loop.last_local_dt * 1e3 / 8], dtype=torch.float64,
+                            device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank[name] = [round(float(t.item()), 3) for t in allr]
+    chosen = 'forks_on' if arms['forks_on'] <= 1.01 * arms['forks_off'] else 'forks_off'
+    os.environ['BGS_LEVEL_FORK'] = '1' if chosen == 'forks_on' else '0'
+    return dict(eager_forks_on_ms=arms['forks_on'], eager_forks_off_ms=arms['forks_off'], chosen=chosen,
+                ms_by_rank=per_rank,
+                note='untimed calibration on all ranks (8 eager steps per arm incl. the gradient exchange, max over '
+                     'ranks); the K timed steps ran under `chosen`; the whole-step-graph arm is `dist_graph_policy`')
+
+
+def n1_reference(args, rank, world, dev, ms_per_step_n):
+    """N > 1: the same step on ONE rank of the same node in the same invocation (rank 0 alone, eager launches, the
+    other ranks waiting at a barrier) so that the line carries the weak-scaling efficiency against a number taken
+    on this very box — the driver computes its own from separate runs; this one removes box-to-box spread."""
+    out = None
+    if rank == 0:
+        try:
+            one = DetectorStep(dev, 0, 1, args.imgs, args.selectp, args.mask, args.cascade, args.htc,
+                               conv_math=args.conv_math)
+            dt = timed_loop(one, args.steps, max(args.warmup, 4), 1)
+            ms1 = dt * 1e3 / args.steps
+            out = dict(n1_same_invocation=dict(ms_per_step=round(ms1, 3),
+                                               img_per_s=round(args.imgs * args.steps / dt, 3),
+                                               launch='eager launches, rank 0 alone, other ranks idle'),
+                       weak_scaling_eff=round(ms1 / ms_per_step_n, 4))
+            del one
+        except Exception as e:  # pragma: no cover
+            out = dict(n1_same_invocation=dict(error=repr(e)[:200]))
+    barrier(world)
+    return out
+
+
 def main_detector(args, rank, local, world, dev):
     fallback_note = None
     if world == 1 and not args.no_graph and not args.child:
@@ -1028,6 +1239,10 @@ def main_detector(args, rank, local, world, dev):
     auto = can_graph and world == 1 and not self_group and args.launch == 'auto'
     if auto:
         calib = dict(eager_ms=round(timed_loop(step, 8, 6, 1) * 1e3 / 8, 3))      # (6 warm-up steps: lazy folds / splits / caches)
+    dist_calib = None
+    if world > 1 and not args.child and args.launch == 'auto' and not args.dist_graph \
+            and not os.environ.get('BGS_BENCH_NO_DIST_CALIB'):
+        dist_calib = calibrate_dist_forks(step, world)
     if can_graph and args.launch != 'eager':
         # --dist-graph: the RCCL all-reduce is captured with the rest of the step (the communicator
         # is set up by the eager warm-up iterations inside try_graph)
@@ -1049,6 +1264,9 @@ def main_detector(args, rank, local, world, dev):
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rank_ms = [round(float(t.item()), 3) for t in allr]
+    n1 = None
+    if world > 1 and not args.child and not os.environ.get('BGS_BENCH_NO_N1_REFERENCE'):
+        n1 = n1_reference(args, rank, world, dev, ms_per_step)
     ms_eager = None
     ms_graph = None
     if graph is not None and fn is step:      # eager was the timed policy: the graph figure from the calibration
@@ -1124,6 +1342,10 @@ def main_detector(args, rank, local, world, dev):
                 out.update(diag)
             if dist_graph is not None:
                 out['dist_graph_policy'] = dist_graph
+            if dist_calib is not None:
+                out['launch_calibration'] = dist_calib
+            if n1 is not None:
+                out.update(n1)
         if self_group:
             out['config']['collective_backend'] = 'nccl (1-rank group: test hook BGS_BENCH_SELF_GROUP)'
         if fallback_note:

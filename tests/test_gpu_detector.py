@@ -252,16 +252,28 @@ def test_iou_assign_kernel_equals_tensor_form(thr):
 
 
 def test_iou_assign_image_without_gts_inside_a_batch_is_all_ignored():
-    """A gt-free image next to images that have gts: every anchor of it stays -1 ("ignored"), no negatives are
-    invented for the sampler.  (The reference raises 'No gt or bboxes' for such an image,
-    max_iou_assigner.py:83-84; ADVICE round 4: the bounding-box skip had silently turned them into negatives.)"""
-    from balancedgroupsoftmax_amd import functional as BF
+    """A gt-free image next to images that have gts.  The host wrapper refuses it like the reference does
+    ('No gt or bboxes', max_iou_assigner.py:83-84); a C-ABI caller that passes it anyway gets every anchor of that
+    image as -1 ("ignored") — no negatives are invented for the sampler (the bounding-box skip had
+    silently turned them into negatives)."""
+    from balancedgroupsoftmax_amd import capi, functional as BF
     gts = [_rand_boxes(7, 1), _rand_boxes(0, 2), _rand_boxes(3, 3)]
     offs = [0, 7, 7, 10]
-    boxes = _rand_boxes(3000, 11)
+    boxes = _rand_boxes(3000, 11).to(DEV).contiguous()
     valid = (torch.rand(3, 3000, generator=torch.Generator().manual_seed(6)) > 0.2)
-    got, mo = BF.iou_assign(boxes.to(DEV), torch.cat(gts).to(DEV), offs, 0.7, 0.3, 0.3,
-                            valid=valid.to(torch.uint8).to(DEV), shared_boxes=True, return_max_overlaps=True)
+    gt_cat = torch.cat(gts).to(DEV).contiguous()
+    with pytest.raises(ValueError):
+        BF.iou_assign(boxes, gt_cat, offs, 0.7, 0.3, 0.3, valid=valid.to(torch.uint8).to(DEV), shared_boxes=True)
+    lib = capi.load()
+    N, A = 3, 3000
+    v8 = valid.to(torch.uint8).to(DEV).contiguous()
+    got = torch.full((N, A), 77, dtype=torch.int32, device=DEV)
+    mo = torch.full((N, A), 77.0, dtype=torch.float32, device=DEV)
+    ws = torch.empty(lib.bgs_iou_assign_workspace_bytes(N, A, 10), dtype=torch.uint8, device=DEV)
+    rc = lib.bgs_iou_assign(capi.ptr(boxes), 0, 4, capi.ptr(v8), capi.ptr(gt_cat), BF._c_int_array(offs), N, A,
+                            0.7, 0.0, 0.3, 0.3, capi.ptr(got), capi.ptr(mo), capi.ptr(ws),
+                            capi.current_stream(torch.device(DEV)))
+    capi.check('bgs_iou_assign', rc)
     assert (got[1] == -1).all()
     assert (mo[1] == -1).all()
     assert (got[0][valid[0].to(DEV)] >= 0).all() and (got[2][valid[2].to(DEV)] >= 0).all()
