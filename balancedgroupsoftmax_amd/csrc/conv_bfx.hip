@@ -833,6 +833,10 @@ struct HaloBfxArgs {
   int chunks_per_split;  // channel chunks per gridDim.z slice
   const unsigned* zero = nullptr;   // device zero page (DMA source of out-of-range rows, variant 4)
   int flags = 0;         // experiments (bgs_conv3x3_halo_bfx_tuning bits 20..23)
+  // Tile window (variants 4 and 7): the launch covers tiles [tile_base, tile_base + tile_count) of the
+  // (pixel tile, Cout tile) list; tile_count == 0: all of them.  The two-launch schedule of variant 7 gives
+  // whole rounds of 256-pixel tiles to one launch and the remaining image rows to a variant-4 launch.
+  int tile_base = 0, tile_count = 0;
 };
 
 // The halo kernels' epilogue through an LDS transpose (see conv_store_tile_lds): the 8 x 16 pixel x
@@ -1352,8 +1356,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = bgs::uniform(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int vtile = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
-  if (vtile >= p.tiles_m * p.tiles_n) return;                  // workgroup-uniform
+  const int vlocal = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if (vlocal >= (q.tile_count ? q.tile_count : p.tiles_m * p.tiles_n)) return;   // workgroup-uniform
+  const int vtile = vlocal + q.tile_base;
   const int tm = vtile / p.tiles_n, tn = vtile - tm * p.tiles_n;
   const int n = tm / (q.tiles_y * q.tiles_x);
   const int trem = tm - n * (q.tiles_y * q.tiles_x);
@@ -1563,6 +1568,230 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
   }
 }
 
+
+// Variant 7 ("wide pixel tile", round 5): a 16 x 16 = 256-pixel x 128-channel output tile per workgroup — twice the
+// pixels per filter byte of variant 4.  Why: variant 4's step is co-limited by the matrix pipe and by the 12 KB
+// filter slice every workgroup pulls through the L2 -> LDS path per tap (three workgroups per CU: 36 KB per 2304
+// MFMA cycles = the ~16 B / clk / CU that `global_load_lds_dwordx4` delivers; timing-only ablation 0.77 -> 0.52 ms
+// without that DMA, profiles/r8h).  Here a wave owns 128 pixels x 64 channels (acc[4][2]: 128 accumulator
+// registers, two waves per SIMD = two workgroups per CU): 48 MFMAs per wave and step against the same 12 KB slice
+// (8 B / clk / CU), half the barriers per MFMA, an 18 x 18 patch (1.27x halo instead of 1.41x) and one read of it
+// per TWO of the old pixel tiles.  The accumulation order of every output element is variant 4's (chunk, tap,
+// plane products in the same sequence): the results are bit-identical.
+// What it costs is launch quantisation — 1092 units on 512 slots at the P2 level would be 2.13 rounds — and that is
+// the SCHEDULER's job (launch_halo_wide below): whole rounds of these units in one launch, the image rows that are
+// left over in a variant-4 launch of the old 128-pixel units (which fill a partial round far better).
+template <int NS>
+__device__ __forceinline__ void halo7_store_tile_lds(const ConvArgs& p, const f32x16 (&acc)[4][2], int n, int ty,
+                                                     int tx, int n0, int wm, int wn, int lane, float* scratch) {
+  constexpr int BN = 128, LD = BN + 4, TPR = BN / 4, RPP = kThreads / TPR;      // 32 threads per row, 8 rows per pass
+  const int tid = threadIdx.x;
+  const int c4 = (tid % TPR) * 4, r0 = tid / TPR;
+  const int j = n0 + c4;
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && j < p.Cout) bias = *reinterpret_cast<const f32x4*>(p.bias + j);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {                            // four quarters of 64 pixels: wave row h / 2, sub-tiles 2 (h % 2) + {0, 1}
+    if (wm == (h >> 1)) {
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = a2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            scratch[i * LD + wn * 64 + b * 32 + (lane & 31)] = acc[2 * (h & 1) + a2][b][r];
+          }
+    }
+    __syncthreads();
+    if (j < p.Cout) {
+#pragma unroll
+      for (int ps = 0; ps < 64 / RPP; ++ps) {
+        const int i = r0 + ps * RPP;
+        const int m = h * 64 + i;
+        const int ho = ty * 16 + (m >> 4), wo = tx * 16 + (m & 15);
+        if (ho >= p.H || wo >= p.W) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + i * LD + c4);
+        const size_t off = (((size_t)n * p.H + ho) * p.W + wo) * p.Cout + j;
+        v += bias;
+        if (p.relu) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+        }
+        if (p.mask) {      // data gradient: ReLU backward of the conv's input
+          const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + off);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = mk[t] > 0.f ? v[t] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(p.y + off) = v;
+      }
+    }
+    if (h < 3) __syncthreads();
+  }
+}
+
+template <int NS>
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx7_kernel(HaloBfxArgs q) {
+  const ConvArgs& p = q.c;
+  constexpr int PW = 18, PROWS = 18 * 18;                                   // 16 x 16 pixels + halo
+  constexpr int AQ = PROWS * 4, AQT = (AQ + kThreads - 1) / kThreads;       // 1296 fp32 quads: 6 per thread (the 6th: 16 threads)
+  constexpr int BN = 128, HL = 32;                                          // 32-byte patch pixels, k halves swapped on odd r + c
+  constexpr int B_PLANE = BN * 32, B_BUF = NS * B_PLANE;
+  constexpr int A_OFF = 2 * B_BUF;
+  constexpr int A_PLANE = PROWS * HL;
+  constexpr int A_SUB = 2 * PW * HL;                                        // sub-tile a -> a + 1: two patch rows down
+  constexpr int OPER_BYTES = A_OFF + NS * A_PLANE, EPI_BYTES = 64 * (BN + 4) * 4;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[OPER_BYTES > EPI_BYTES ? OPER_BYTES : EPI_BYTES];
+  const unsigned* __restrict__ zero_page = q.zero;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = bgs::uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int vlocal = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if (vlocal >= q.tile_count) return;                          // workgroup-uniform
+  const int vtile = vlocal + q.tile_base;
+  const int tm = vtile / p.tiles_n, tn = vtile - tm * p.tiles_n;
+  const int n = tm / (q.tiles_y * q.tiles_x);
+  const int trem = tm - n * (q.tiles_y * q.tiles_x);
+  const int ty = trem / q.tiles_x, tx = trem - ty * q.tiles_x;
+  const int h0 = ty * 16 - 1, w0 = tx * 16 - 1;                // input coords of patch (0, 0)
+  const int n0 = tn * BN;
+  const int cchunks = p.Cin / 16;
+
+  // ---- filter DMA roles (variant 4's, NB = 2): wave w carries rows 32 w .. 32 w + 31 of every plane
+  const int brow_d = wave * 32 + (lane >> 1);
+  const int bhalf_d = (lane & 1) ^ ((brow_d >> 3) & 1);
+  const bool b_okd = n0 + brow_d < p.Cout;
+  const __bf16* b_lane = q.ws + (size_t)(b_okd ? n0 + brow_d : 0) * 16 + bhalf_d * 8;
+  const size_t b_plane = (size_t)q.KC * p.Cout * 16;
+  auto issue_b = [&](int chunk, int tap, int buf_off) {
+    const size_t koff = (size_t)(tap * cchunks + chunk) * p.Cout * 16;
+    const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      glds16(b_okd ? b_lane + s * b_plane + koff : zp, lds + buf_off + s * B_PLANE + wave * 1024);
+  };
+
+  // ---- patch staging roles: patch quads idx = tid + 256 i; prow = idx / 4, kq = idx % 4
+  unsigned a_off[AQT];                                         // element offset of the quad in x (chunk 0)
+  int a_dst[AQT];                                              // bit 0: inside the image; bits 1..: LDS byte offset
+  f32x4 ra[AQT];
+#pragma unroll
+  for (int i = 0; i < AQT; ++i) {
+    const int idx = tid + kThreads * i;
+    const bool use = idx < AQ;
+    const int prow = use ? idx >> 2 : 0, kq = idx & 3;
+    const int pr = prow / PW, pc = prow - pr * PW;
+    const int hi = h0 + pr, wi = w0 + pc;
+    const bool in = use && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+    a_off[i] = in ? (unsigned)((((size_t)n * p.H + hi) * p.W + wi) * p.Cin + kq * 4) : 0u;
+    const int kq_off = (((kq >> 1) ^ ((pr + pc) & 1)) << 4) + (kq & 1) * 8;
+    a_dst[i] = (in ? 1 : 0) | (use ? 2 : 0) | ((prow * HL + kq_off) << 2);
+  }
+  auto load_a = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < AQT; ++i)
+      ra[i] = *reinterpret_cast<const f32x4*>((a_dst[i] & 1) ? p.x + a_off[i] + chunk * 16
+                                                              : reinterpret_cast<const float*>(g_zero_page));
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < AQT; ++i) {
+      if (!(a_dst[i] & 2)) continue;
+      u32x2 h, m, l;
+      split3(ra[i], h, m, l);
+      unsigned char* d = lds + A_OFF + (a_dst[i] >> 2);
+      *reinterpret_cast<u32x2*>(d) = h;
+      if (NS >= 2) *reinterpret_cast<u32x2*>(d + A_PLANE) = m;
+      if (NS >= 3) *reinterpret_cast<u32x2*>(d + 2 * A_PLANE) = l;
+    }
+  };
+
+  // ---- fragment roles: lane frow of sub-tile a (0..3) owns pixel m = 128 wm + 32 a + frow = patch (8 wm + 2 a + frow / 16,
+  //      frow % 16) of tap (0, 0); a -> a + 1 moves two patch rows down (same parity of r + c)
+  const int frow = lane & 31, fk = lane >> 5;
+  int a_frag[2];                                               // [parity of the tap's dy + dx], sub-tile 0
+  {
+    const int pr = wm * 8 + (frow >> 4), pc = frow & 15;
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+      a_frag[par] = A_OFF + (pr * PW + pc) * HL + ((fk ^ ((pr + pc + par) & 1)) << 4);
+  }
+  const int brow = wn * 64 + frow;                             // + 32 b: same 8-row-group parity
+  const int b_frag = brow * 32 + ((fk ^ ((brow >> 3) & 1)) << 4);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  load_a(0);
+  issue_b(0, 0, 0);
+  store_a();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0, nxt = B_BUF;                                    // byte offsets of the two B buffers
+  for (int chunk = 0; chunk < cchunks; ++chunk) {
+    const bool last_chunk = chunk + 1 >= cchunks;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int rd = (tap & 1) ? nxt : cur;                     // buffer of this step
+      const int wr = (tap & 1) ? cur : nxt;                     // buffer of the next step
+      if (tap < 8) issue_b(chunk, tap + 1, wr);                 // next filter slice: DMA in flight
+      else if (!last_chunk) issue_b(chunk + 1, 0, wr);
+      if (tap == 5 && !last_chunk) load_a(chunk + 1);           // next patch: held in registers over three steps
+      const int tap_off = ((tap / 3) * PW + (tap % 3)) * HL;    // compile-time constants
+      const int tap_par = (tap / 3 + tap % 3) & 1;
+      bf16x8 fb[NS][2];
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          fb[s][b] = *reinterpret_cast<const bf16x8*>(lds + rd + b_frag + s * B_PLANE + b * 32 * 32);
+#pragma unroll
+      for (int ah = 0; ah < 2; ++ah) {                          // two halves of the wave's 128 pixels: 24 fragment registers each
+        bf16x8 fa[NS][2];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+            fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[tap_par] + tap_off + (2 * ah + a) * A_SUB +
+                                                        s * A_PLANE);
+        if (q.flags & 1) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_setprio(1);
+        }
+#pragma unroll
+        for (int tt = NS - 1; tt >= 0; --tt)
+#pragma unroll
+          for (int i = 0; i <= tt; ++i)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < 2; ++b)
+                acc[2 * ah + a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[tt - i][b],
+                                                                             acc[2 * ah + a][b], 0, 0, 0);
+        if (q.flags & 1) __builtin_amdgcn_s_setprio(0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // next slice (and patch) landed
+      __syncthreads();
+      if (tap == 8 && !last_chunk) {                            // every wave is done with this patch
+        store_a();
+        __syncthreads();
+      }
+    }
+    // nine steps per chunk: the buffer roles swap from chunk to chunk
+    const int t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  // (the loop's last barrier is behind every wave's last fragment read)
+  halo7_store_tile_lds<NS>(p, acc, n, ty, tx, n0, wm, wn, lane, reinterpret_cast<float*>(lds));
+}
+
 int g_halo_last_nb = 0, g_halo_last_splits = 0, g_halo_last_variant = 0;
 int g_halo_force_splits = -1, g_halo_variant = 4, g_halo_pf = 0, g_halo_padded = 0, g_halo_flags = 1;
 
@@ -1602,6 +1831,23 @@ int halo_bfx_geom(int H, int W) {
   return best;
 }
 int g_halo_last_geom = 0;
+
+// Variant 7 (wide pixel tile) dispatch: -1 = unset (env BGS_HALO_WIDE, default 1) | 0 off | 1 automatic: layers with at
+// least one whole round of 512 wide units, Cout % 128 == 0, no channel-chunk split | 2 every eligible layer
+// (bgs_conv3x3_halo_bfx_tuning bits 24..27: value + 1).  g_halo_wide_tail: 0 = the left-over image rows as ONE variant-4
+// launch (default) | k > 1 = that launch split k ways over the channel chunks (+ the split-K epilogue).
+int g_halo_wide = -1;
+int g_halo_last_wide_units = 0, g_halo_last_tail_units = 0;
+int halo_wide_mode() {
+  if (g_halo_wide >= 0) return g_halo_wide;
+  static const int env = [] {
+    const char* e = getenv("BGS_HALO_WIDE");
+    if (!e) return 1;
+    const int v = atoi(e);
+    return v >= 0 && v <= 2 ? v : 1;
+  }();
+  return env;
+}
 
 int halo_bfx_plan(long long M, int tiles_m, int Cin, int Cout, int& nb) {
   nb = Cout <= 64 ? 1 : 2;
@@ -2040,6 +2286,16 @@ extern "C" void bgs_conv3x3_halo_bfx_tuning(int splits, int variant) {
   g_halo_flags = (variant0 >> 20) & 0xf;
   if (g_halo_flags == 0) g_halo_flags = 1;
   g_halo_padded = variant == 6 ? 1 : 0;    // 6 = variant 4 with the 48-byte patch rows (before the swizzled 32-byte pixels)
+  // bits 24..27: 0 leave as is | 1 wide pixel tile off | 2 automatic | 3 every eligible layer
+  const int wide = (variant0 >> 24) & 0xf;
+  if (wide >= 1 && wide <= 3) g_halo_wide = wide - 1;
+  else if (variant0 == 0 && splits < 0) g_halo_wide = -1;      // (the reset call: back to the environment's default)
+}
+
+extern "C" int bgs_conv3x3_halo_bfx_last_wide(int* wide_units, int* tail_units) {
+  if (wide_units) *wide_units = g_halo_last_wide_units;      // 256-pixel x 128-channel units of the variant-7 launch (0: it did not run)
+  if (tail_units) *tail_units = g_halo_last_tail_units;      // 128-pixel units of the variant-4 launch behind it
+  return BGS_OK;
 }
 
 extern "C" int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits) {
@@ -2110,6 +2366,57 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wspl
   p.chunk = (p.tiles_m * p.tiles_n + 7) / 8;
   g_halo_last_nb = nb;
   g_halo_last_splits = splits;
+  g_halo_last_wide_units = g_halo_last_tail_units = 0;
+  // ---- variant 7: whole rounds of 16 x 16-pixel units, then the left-over image rows on variant 4 (8 x 16 units)
+  if (g_halo_variant == 4 && geom == 0 && !g_halo_padded && !g_halo_pf && splits == 1 && nb == 2 && Cout % 128 == 0 &&
+      halo_wide_mode() > 0 && (long long)M * Cin < 0xffffffffLL) {
+    constexpr int kSlots = 512;                                 // two workgroups per CU
+    const int ty7 = (H + 15) / 16, tx7 = (W + 15) / 16;         // (tx7 == q.tiles_x: both tiles are 16 pixels wide)
+    const int tn7 = Cout / 128;
+    const long long units = (long long)N * ty7 * tx7 * tn7;
+    long long rows_a = (long long)N * ty7;                      // tile rows (image-major) given to the wide launch
+    if (halo_wide_mode() == 1) {
+      const long long full = units / kSlots * kSlots;           // whole rounds
+      rows_a = full / ((long long)tx7 * tn7);
+      // (whatever is left goes to the variant-4 launch, however little: inside the wide launch even ONE unit past a
+      //  whole round costs a full 144-step unit duration, ~3x what the 128-pixel units need for the same rows)
+    }
+    if (rows_a > 0 && (halo_wide_mode() == 2 || units >= kSlots)) {
+      q.zero = zero_page_device();
+      if (!q.zero) return BGS_ERR_LAUNCH;
+      q.flags = g_halo_flags;
+      HaloBfxArgs qa = q;
+      qa.tiles_y = ty7;
+      qa.tiles_x = tx7;
+      qa.c.tiles_m = N * ty7 * tx7;
+      qa.c.tiles_n = tn7;
+      qa.tile_base = 0;
+      qa.tile_count = (int)(rows_a * tx7 * tn7);
+      qa.c.chunk = (qa.tile_count + 7) / 8;
+      g_halo_last_variant = 7;
+      g_halo_last_wide_units = qa.tile_count;
+      bgs_internal_census_bump(BGS_CENSUS_HALO_WIDE);
+      if (q.ns == 1)
+        hipLaunchKernelGGL((conv3x3_halo_bfx7_kernel<1>), dim3((unsigned)(8 * qa.c.chunk)), dim3(kThreads), 0, (hipStream_t)stream, qa);
+      else
+        hipLaunchKernelGGL((conv3x3_halo_bfx7_kernel<3>), dim3((unsigned)(8 * qa.c.chunk)), dim3(kThreads), 0, (hipStream_t)stream, qa);
+      if (rows_a < (long long)N * ty7) {
+        // the rest: image n_a from pixel row 16 r_a on, and every later image — contiguous in variant 4's tile order
+        const int n_a = (int)(rows_a / ty7), r_a = (int)(rows_a - (long long)n_a * ty7);
+        const long long tm4_begin = ((long long)n_a * q.tiles_y + 2 * r_a) * q.tiles_x;
+        q.tile_base = (int)(tm4_begin * p.tiles_n);
+        q.tile_count = p.tiles_m * p.tiles_n - q.tile_base;
+        p.chunk = (q.tile_count + 7) / 8;
+        g_halo_last_tail_units = q.tile_count;
+        bgs_internal_census_bump(BGS_CENSUS_HALO_BFX4);
+        if (q.ns == 1)
+          hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, 1>), dim3((unsigned)(8 * p.chunk)), dim3(kThreads), 0, (hipStream_t)stream, q);
+        else
+          hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<2, 3>), dim3((unsigned)(8 * p.chunk)), dim3(kThreads), 0, (hipStream_t)stream, q);
+      }
+      BGS_RETURN_LAUNCH_STATUS();
+    }
+  }
   dim3 grid((unsigned)(8 * p.chunk), 1u, (unsigned)splits);
   const bool v4 = g_halo_variant == 4;
   g_halo_last_variant = v4 ? 4 : (g_halo_variant == 1 && q.ns == 3 ? 1 : 2);

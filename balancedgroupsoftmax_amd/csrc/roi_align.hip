@@ -26,6 +26,7 @@
 // grid) inside the wave and `accumulate` adds into the existing output: the 14x14 intermediate
 // (205 MB for 1024 RoIs), the pooling pass and the add pass never touch HBM.
 #include <math.h>
+#include <stdlib.h>
 
 #include "bgs_common.h"
 
@@ -96,9 +97,13 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(RoiLevels L,
                                                              const float* __restrict__ rois,
                                                              int K, int C, int PH, int PW,
                                                              float* __restrict__ out,
-                                                             int* __restrict__ lvl_out) {
+                                                             int* __restrict__ lvl_out, int xcd_chunk) {
   const int lane = threadIdx.x & 63;
-  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // xcd_chunk > 0 (A/B, BGS_ROI_XCD=1): workgroup b runs on XCD b % 8 and takes workgroup slot (b % 8) * chunk + b / 8,
+  // so that the 49 bins of a RoI (12.25 consecutive workgroups) and the RoIs next to it in the list share ONE L2
+  // instead of being dealt round-robin over the eight of them
+  const int wg = xcd_chunk > 0 ? (int)((blockIdx.x & 7) * xcd_chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int wave_global = wg * 4 + (threadIdx.x >> 6);
   const int bins = PH * PW;
   if (wave_global >= K * bins) return;
   const int k = wave_global / bins;
@@ -329,7 +334,16 @@ extern "C" int bgs_roi_align_nhwc_fwd_ex(const float* const* host_feats, const i
                              num_images, finest_scale, true);
   if (rc != BGS_OK) return rc;
   const long long waves = (long long)K * pooled_h * pooled_w;
-  const unsigned grid = (unsigned)((waves + 3) / 4);
+  unsigned grid = (unsigned)((waves + 3) / 4);
+  static const int xcd_mode = [] {
+    const char* e = getenv("BGS_ROI_XCD");
+    return e ? atoi(e) : 0;
+  }();
+  int xcd_chunk = 0;
+  if (xcd_mode > 0 && sample_num == 2 && grid >= 64) {
+    xcd_chunk = (int)((grid + 7) / 8);
+    grid = (unsigned)(8 * xcd_chunk);
+  }
   if (sample_num != 2) {      // every shipped config uses sample_num = 2; the rest of the interface runs the generic kernel
     if (accumulate) return BGS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((roi_align_nhwc_generic_kernel<float, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
@@ -338,7 +352,7 @@ extern "C" int bgs_roi_align_nhwc_fwd_ex(const float* const* host_feats, const i
   }
 #define BGS_ROI_FWD(POOL_, ACC_)                                                              \
   hipLaunchKernelGGL((roi_align_nhwc_kernel<2, false, POOL_, ACC_>), dim3(grid), dim3(256), 0,   \
-                     (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w, out, levels_out)
+                     (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w, out, levels_out, xcd_chunk)
   if (pool == 1 && !accumulate) BGS_ROI_FWD(1, false);
   else if (pool == 1) BGS_ROI_FWD(1, true);
   else if (!accumulate) BGS_ROI_FWD(2, false);
@@ -387,11 +401,11 @@ extern "C" int bgs_roi_align_nhwc_bwd_ex(float* const* host_dfeats, const int* h
   if (pool == 1)
     hipLaunchKernelGGL((roi_align_nhwc_kernel<2, true, 1, false>), dim3(grid), dim3(256), 0,
                        (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w,
-                       const_cast<float*>(dout), nullptr);
+                       const_cast<float*>(dout), nullptr, 0);
   else
     hipLaunchKernelGGL((roi_align_nhwc_kernel<2, true, 2, false>), dim3(grid), dim3(256), 0,
                        (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w,
-                       const_cast<float*>(dout), nullptr);
+                       const_cast<float*>(dout), nullptr, 0);
   BGS_RETURN_LAUNCH_STATUS();
 }
 

@@ -744,29 +744,33 @@ def bfx_split_weights_dgrad(w_krsc, cache=True):
     return out
 
 
-def conv_bfx_tuning(tile=0, splitk=-1, halo_splits=-1, halo_variant=0, halo_geom=-1, halo_flags=0):
+def conv_bfx_tuning(tile=0, splitk=-1, halo_splits=-1, halo_variant=0, halo_geom=-1, halo_flags=0, halo_wide=-1):
     """Process-wide tuning / test hook of the bf16x6 kernels (see include/bgs_tuning.h).  ``halo_geom``: the
-    pixel tile of the halo kernel, -1 default | 0: 8 x 16 | 1: 10 x 12 | 2: 5 x 21 | 3: fewest tiles per image."""
+    pixel tile of the halo kernel, -1 default | 0: 8 x 16 | 1: 10 x 12 | 2: 5 x 21 | 3: fewest tiles per image.
+    ``halo_wide``: the 16 x 16-pixel units of variant 7, -1 leave as is (the all-default call restores the
+    environment's default) | 0 off | 1 automatic | 2 every eligible layer."""
     lib = capi.load()
     lib.bgs_conv_bfx_tuning(int(tile), int(splitk))
     lib.bgs_conv3x3_halo_bfx_tuning(int(halo_splits), int(halo_variant) | ((int(halo_geom) + 1) << 16) |
-                                    (int(halo_flags) << 20))
+                                    (int(halo_flags) << 20) | ((int(halo_wide) + 1) << 24))
 
 
 def conv_bfx_last_launch():
-    """-> dict(tile, splits, halo_nb, halo_splits) of the last bf16x6 launches."""
+    """-> dict(tile, splits, halo_nb, halo_splits, ...) of the last bf16x6 launches.  ``halo_variant`` 7: the wide
+    pixel tile ran (``halo_wide_units`` 256-pixel units) followed by ``halo_tail_units`` 128-pixel units on variant 4."""
     import ctypes
     lib = capi.load()
-    a, c, d, e = (ctypes.c_int() for _ in range(4))
+    a, c, d, e, f, g = (ctypes.c_int() for _ in range(6))
     lib.bgs_conv_bfx_last_launch(ctypes.byref(a), ctypes.byref(c))
     lib.bgs_conv3x3_halo_bfx_last_launch(ctypes.byref(d), ctypes.byref(e))
+    lib.bgs_conv3x3_halo_bfx_last_wide(ctypes.byref(f), ctypes.byref(g))
     return dict(tile=a.value & ~0x400, ring_stages=3 if a.value & 0x400 else 4, splits=c.value,
                 halo_nb=d.value & 0xff, halo_variant=(d.value >> 8) & 0xff, halo_geom=d.value >> 16,
-                halo_splits=e.value)
+                halo_splits=e.value, halo_wide_units=f.value, halo_tail_units=g.value)
 
 
 CENSUS = dict(bf16_ring8=0, grouped_lds=1, halo_bfx4=2, dma_ring64=3, gs_head_fused=4, conv1x1_bres=5,
-              wgrad_bfx=6, roi_bwd_gather=7, bf16s=8, grouped_bf16s=9, bfx_wide=10, gs_scale_grad=11)
+              wgrad_bfx=6, roi_bwd_gather=7, bf16s=8, grouped_bf16s=9, bfx_wide=10, gs_scale_grad=11, halo_wide=12)
 
 
 def launch_census(reset=False):

@@ -45,6 +45,7 @@ int bgs_selftest_mfma_peak_bf16(int blocks, int iters, int random_operands, floa
 #define BGS_CENSUS_GROUPED_BF16S 9   /* grouped 3x3 conv with bf16 activations in HBM     */
 #define BGS_CENSUS_BFX_WIDE 10       /* conv1x1_bfx_wide_kernel (128 x 128, M-stacked waves) */
 #define BGS_CENSUS_GS_SCALE_GRAD 11   /* gs_head_scale_grad_kernel (a non-unit upstream gradient) */
+#define BGS_CENSUS_HALO_WIDE 12       /* conv3x3_halo_bfx7_kernel (16 x 16-pixel x 128-channel units) */
 #define BGS_CENSUS_FAMILIES 16
 int bgs_launch_census(int family, int reset);
 
@@ -75,7 +76,12 @@ int bgs_gs_head_variant_used(int N);
  *   tile of variant 4, 0 = default (8 x 16; env BGS_HALO_GEOM) | 1 = 8 x 16 | 2 = 10 x 12 | 3 = 5 x 21 | 4 = the
  *   tile with the fewest tiles per image;
  *   bgs_conv3x3_halo_bfx_last_launch reports the variant in bits 8..15 of *nb and the pixel tile in bits 16..
- *   (0: 8 x 16, 1: 10 x 12, 2: 5 x 21).
+ *   (0: 8 x 16, 1: 10 x 12, 2: 5 x 21).  Bits 24..27 of `variant` (round 5): the wide pixel tile (variant 7: 16 x 16
+ *   pixels x 128 channels per workgroup, whole rounds of 512 units in one launch + the left-over image rows in a
+ *   variant-4 launch; bit-identical to variant 4), 0 = leave as is | 1 = off | 2 = automatic (default; env
+ *   BGS_HALO_WIDE=0/1/2) | 3 = every eligible layer; bgs_conv3x3_halo_bfx_tuning(-1, 0) restores the default.
+ *   bgs_conv3x3_halo_bfx_last_wide: units of the variant-7 launch (0: it did not run) and of the variant-4 launch
+ *   behind it (last_launch then reports variant 7).
  * bgs_conv1x1_bres_enable (filter-resident 1x1, csrc/conv1x1_bres.hip): 1 (default) = where measured faster,
  *   2 = every layer it can run, 0 = never; bgs_conv1x1_bres_last_launch: 1 when the last call that could have
  *   taken it did.
@@ -89,6 +95,7 @@ void bgs_conv_bfx_tuning(int tile, int splitk);
 int bgs_conv_bfx_last_launch(int* tile, int* splits);
 void bgs_conv3x3_halo_bfx_tuning(int splits, int variant);
 int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits);
+int bgs_conv3x3_halo_bfx_last_wide(int* wide_units, int* tail_units);
 void bgs_conv1x1_bres_enable(int on);
 int bgs_conv1x1_bres_last_launch(void);
 void bgs_conv_dgrad_parity_enable(int on);

@@ -597,6 +597,76 @@ def test_halo_bfx_variants_bit_identical(monkeypatch, shape):
         BF.set_conv_math(prev)
 
 
+@pytest.mark.parametrize('case', [
+    # (N, H, W, Cin, Cout, relu, mode, math): mode 2 = every eligible layer on the wide units, 1 = the automatic schedule
+    (1, 16, 16, 16, 128, False, 2, 'bf16x6'),           # exactly one unit
+    (2, 23, 37, 64, 256, True, 2, 'bf16x6'),            # tiles hanging over both image edges, two Cout tiles, two images
+    (1, 50, 84, 256, 128, True, 2, 'bf16x6'),           # 16 channel chunks
+    (1, 40, 56, 32, 256, True, 2, 'bf16'),              # the bf16 mode's one-plane instantiation
+    (2, 200, 336, 16, 256, True, 1, 'bf16x6'),          # cfg[1]'s P2 map: 1092 units -> 1008 wide + the last rows on variant 4
+    (2, 200, 336, 16, 256, False, 1, 'bf16'),
+    (3, 136, 200, 32, 128, True, 1, 'bf16x6'),          # 351 px tiles x 1: below one round -> stays on variant 4
+], ids=lambda c: 'x'.join(str(v) for v in c))
+def test_halo_wide_pixel_tile_is_bit_identical_to_variant_4(case, monkeypatch):
+    """``conv3x3_halo_bfx7_kernel`` (round 5: 16 x 16 pixels x 128 channels per workgroup, half the filter bytes
+    per MFMA of the 8 x 16 tile; mmdet/models/necks/fpn.py:131-134 / anchor_heads/rpn_head.py:30-35 at the P2 level)
+    accumulates every output in variant 4's order: BIT-IDENTICAL, alone (mode 2) and under the two-launch schedule
+    (whole rounds of 512 wide units + the left-over image rows on variant 4), with the ReLU-backward mask of the
+    data-gradient call, and == fp64 within the kernel family's bound."""
+    N, H, W, Cin, Cout, relu, mode, math = case
+    g = torch.Generator().manual_seed(H * 13 + W + Cin)
+    x = torch.randn(N, H, W, Cin, generator=g) * torch.exp(torch.randn(N, H, W, Cin, generator=g))
+    w = torch.randn(Cout, 3, 3, Cin, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    monkeypatch.setenv('BGS_CONV_HALO', '1')
+    prev = BF.set_conv_math(math)
+    try:
+        xd, wd, bd = dev(x), dev(w), dev(b)
+        BF.conv_bfx_tuning(halo_wide=0)
+        y4 = BF.conv2d_nhwc(xd, wd, bd, pad=1, relu=relu)
+        u4 = BF.conv_bfx_last_launch()
+        assert u4['halo_variant'] == 4 and u4['halo_wide_units'] == 0
+        BF.launch_census(reset=True)
+        BF.conv_bfx_tuning(halo_wide=mode)
+        y7 = BF.conv2d_nhwc(xd, wd, bd, pad=1, relu=relu)
+        u7 = BF.conv_bfx_last_launch()
+        census = BF.launch_census()
+        ty, tx, tn = (H + 15) // 16, (W + 15) // 16, Cout // 128
+        units = N * ty * tx * tn
+        if mode == 2:
+            assert u7['halo_variant'] == 7 and u7['halo_wide_units'] == units and u7['halo_tail_units'] == 0, u7
+            assert census['halo_wide'] == 1 and census['halo_bfx4'] == 0
+        elif units >= 512:
+            rows = units // 512 * 512 // (tx * tn)
+            assert u7['halo_variant'] == 7 and u7['halo_wide_units'] == rows * tx * tn, u7
+            n_a, r_a = divmod(rows, ty)
+            ty4 = (H + 7) // 8
+            assert u7['halo_tail_units'] == (N * ty4 * tx - (n_a * ty4 + 2 * r_a) * tx) * tn, u7
+            assert census['halo_wide'] == 1 and census['halo_bfx4'] == (1 if u7['halo_tail_units'] else 0)
+        else:
+            assert u7['halo_variant'] == 4 and u7['halo_wide_units'] == 0
+        assert torch.equal(y7, y4)
+        if math == 'bf16x6':
+            exp = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double(), padding=1)
+            exp = (exp.relu() if relu else exp).permute(0, 2, 3, 1)
+            assert float((y7.cpu().double() - exp).abs().max()) <= 2e-6 * float(exp.abs().max())
+        if Cin % 128 == 0:
+            # the data-gradient call of the same kernel pair: mask epilogue (conv2d_dgrad_nhwc routes 3x3 / stride 1
+            # through the halo entry with the flipped, transposed filter; its output channels are the forward's Cin)
+            dy = dev(torch.randn(N, H, W, Cout, generator=g))
+            mask = dev(torch.randn(N, H, W, Cin, generator=g))
+            BF.conv_bfx_tuning(halo_wide=0)
+            a = BF.conv2d_dgrad_nhwc(dy, wd, (H, W), 1, 1, mask=mask)
+            assert BF.conv_bfx_last_launch()['halo_variant'] == 4
+            BF.conv_bfx_tuning(halo_wide=2)
+            bb = BF.conv2d_dgrad_nhwc(dy, wd, (H, W), 1, 1, mask=mask)
+            assert BF.conv_bfx_last_launch()['halo_variant'] == 7
+            assert torch.equal(a, bb)
+    finally:
+        BF.conv_bfx_tuning()
+        BF.set_conv_math(prev)
+
+
 @pytest.mark.parametrize('conv_math', MATHS, indirect=True)
 @pytest.mark.parametrize('shape', [(1, 8, 16, 16, 128, False), (2, 13, 21, 64, 256, True),
                                    (1, 25, 42, 256, 200, True), (2, 50, 84, 32, 64, False),
