@@ -167,6 +167,8 @@ SIGNATURES = {
     'bgs_mask_target': (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
                                        ctypes.c_int, c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, c_f32p,
                                        c_ptr]),
+    'bgs_mask_paste_u8': (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                         ctypes.c_float, ctypes.c_int, ctypes.c_int, c_ptr, c_ptr]),
     'bgs_mask_gt_logits': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, c_f32p, c_ptr]),
     'bgs_mask_bce_partials': (ctypes.c_int, [ctypes.c_int]),

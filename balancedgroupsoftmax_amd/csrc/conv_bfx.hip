@@ -2381,7 +2381,9 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wspl
       // (whatever is left goes to the variant-4 launch, however little: inside the wide launch even ONE unit past a
       //  whole round costs a full 144-step unit duration, ~3x what the 128-pixel units need for the same rows)
     }
-    if (rows_a > 0 && (halo_wide_mode() == 2 || units >= kSlots)) {
+    // (the bf16 mode, NS = 1: 1/6 of the MFMAs per filter byte-equivalent — its step is bound by patch staging and
+    //  barriers, which two waves per SIMD hide worse than three: 0.209 vs 0.186 ms at the P2 level, profiles/r9a)
+    if (rows_a > 0 && (halo_wide_mode() == 2 || (units >= kSlots && q.ns == 3))) {
       q.zero = zero_page_device();
       if (!q.zero) return BGS_ERR_LAUNCH;
       q.flags = g_halo_flags;

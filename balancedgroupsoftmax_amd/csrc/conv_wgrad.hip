@@ -520,7 +520,9 @@ WgradPlan plan_wgrad(int M, int Cout, int K, bool bfx = false) {
   // to begin with), never more than 128 slices (partial-sum traffic), and at most 2 when the
   // output alone already gives >= 256 tiles (fc1).
   long long splits = (2304 + tiles - 1) / tiles;
-  const long long min_rows = M >= 16384 ? 512 : 256;
+  // (M <= 2048 — the FC heads at 1024 RoIs: fc_cls of the shipped selectp = 1 step, 80 tiles: 8 slices of 128 rows
+  //  52.6 us, 4 of 256 68.4, 3 of 352 (the round-down below) 69.5; tools/fc_cls_wgrad_ab.py, profiles/r9a)
+  const long long min_rows = M >= 16384 ? 512 : (M <= 2048 ? 128 : 256);
   const long long max_splits = (M + min_rows - 1) / min_rows;
   if (splits > max_splits) splits = max_splits;
   if (splits > 128) splits = 128;

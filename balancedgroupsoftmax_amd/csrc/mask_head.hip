@@ -186,6 +186,102 @@ __global__ __launch_bounds__(256) void mask_gt_channel_kernel(
   }
 }
 
+
+// ---- test-time mask paste: FCNMaskHead.get_seg_masks (mmdet/models/mask_heads/fcn_mask_head.py:125-181) without the
+// RLE step.  Per detection k: bbox = (int32)(box / scale_factor) (truncation, :164), w = max(x2 - x1 + 1, 1),
+// h likewise; bbox_mask = mmcv.imresize(prob [S, S] float32, (w, h)) = cv2.resize(..., INTER_LINEAR) on float32
+// (OpenCV resize.cpp, float path: src coordinate fx = (float)((dx + 0.5) * scale - 0.5) with scale = 1 / (w / S) in
+// double, sx = floor(fx), fx -= sx; sx < 0 -> (0, 0); sx >= S - 1 -> (S - 1, 0); rows: sy = floor(fy), the two
+// source rows clamped to [0, S - 1] with fy kept; horizontal pass first (S[sx] * (1 - fx) + S[sx + 1] * fx, or S[sx]
+// alone where sx + 1 leaves the row), then vertical (row0 * (1 - fy) + row1 * fy), all in float32, each product and sum
+// rounded separately); (bbox_mask > thr) as uint8 goes to im_mask[y1 : y1 + h, x1 : x1 + w] of a zero [img_h, img_w]
+// image.  Here the whole uint8 [K, img_h, img_w] tensor is produced in one launch — a thread owns one aligned 4-byte
+// word of it (zeros outside the boxes: no separate fill) — and the part of a box that leaves the image is clipped
+// (numpy's slice assignment raises there; boxes are clipped to the image upstream, bbox_head.py:136-139).
+__device__ __forceinline__ void paste_axis(int d, double scale, int S, int& s0, int& s1, float& f, bool rows) {
+  float fx = (float)(((double)d + 0.5) * scale - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= (float)sx;
+  if (rows) {                                   // (resizeGeneric_Invoker: row indices clipped, weight kept)
+    s0 = min(max(sx, 0), S - 1);
+    s1 = min(max(sx + 1, 0), S - 1);
+    f = fx;
+    return;
+  }
+  if (sx < 0) {
+    fx = 0.f;
+    sx = 0;
+  }
+  if (sx >= S - 1) {
+    fx = 0.f;
+    sx = S - 1;
+  }
+  s0 = sx;
+  s1 = sx + 1 < S ? sx + 1 : -1;                // -1: the "D[dx] = S[sx] * ONE" tail of HResizeLinear
+  f = fx;
+}
+
+__global__ __launch_bounds__(256) void mask_paste_kernel(const float* __restrict__ probs,
+                                                         const float* __restrict__ boxes, int box_stride,
+                                                         int K, int S, float scale_factor, float thr, int img_h,
+                                                         int img_w, unsigned* __restrict__ out_words,
+                                                         long long total_bytes) {
+  const long long word = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long b0 = word * 4;
+  if (b0 >= total_bytes) return;
+  const long long plane = (long long)img_h * img_w;
+  unsigned packed = 0;
+  int k = -1, x1 = 0, y1 = 0, w = 1, h = 1;
+  double sx_scale = 1.0, sy_scale = 1.0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const long long b = b0 + t;
+    if (b >= total_bytes) break;
+    const int kk = (int)(b / plane);
+    const int rem = (int)(b - (long long)kk * plane);
+    const int y = rem / img_w, x = rem - y * img_w;
+    if (kk != k) {                               // (a word crosses a detection at most once)
+      k = kk;
+      const float* bx = boxes + (size_t)k * box_stride;
+      x1 = (int)(bx[0] / scale_factor);
+      y1 = (int)(bx[1] / scale_factor);
+      const int x2 = (int)(bx[2] / scale_factor), y2 = (int)(bx[3] / scale_factor);
+      w = max(x2 - x1 + 1, 1);
+      h = max(y2 - y1 + 1, 1);
+      sx_scale = 1.0 / ((double)w / (double)S);
+      sy_scale = 1.0 / ((double)h / (double)S);
+    }
+    const int dx = x - x1, dy = y - y1;
+    if (dx < 0 || dx >= w || dy < 0 || dy >= h) continue;
+    const float* pm = probs + (size_t)k * S * S;
+    float v;
+    if (w == S && h == S) {                      // cv2.resize returns the source when the size is unchanged
+      v = pm[dy * S + dx];
+    } else {
+      int c0, c1, r0, r1;
+      float fx, fy;
+      paste_axis(dx, sx_scale, S, c0, c1, fx, false);
+      paste_axis(dy, sy_scale, S, r0, r1, fy, true);
+      const float a0 = 1.f - fx, a1 = fx, bt0 = 1.f - fy, bt1 = fy;
+      float h0, h1;
+      if (c1 >= 0) {
+        h0 = __fadd_rn(__fmul_rn(pm[r0 * S + c0], a0), __fmul_rn(pm[r0 * S + c1], a1));
+        h1 = __fadd_rn(__fmul_rn(pm[r1 * S + c0], a0), __fmul_rn(pm[r1 * S + c1], a1));
+      } else {
+        h0 = pm[r0 * S + c0];
+        h1 = pm[r1 * S + c0];
+      }
+      v = __fadd_rn(__fmul_rn(h0, bt0), __fmul_rn(h1, bt1));
+    }
+    if (v > thr) packed |= 1u << (8 * t);
+  }
+  if (b0 + 4 <= total_bytes) {
+    out_words[word] = packed;
+  } else {                                       // the last, partial word
+    unsigned char* ob = reinterpret_cast<unsigned char*>(out_words) + b0;
+    for (int t = 0; b0 + t < total_bytes; ++t) ob[t] = (unsigned char)((packed >> (8 * t)) & 0xffu);
+  }
+}
 }  // namespace
 
 extern "C" int bgs_mask_target(const uint8_t* const* host_masks, const int* host_num_gt,
@@ -209,6 +305,23 @@ extern "C" int bgs_mask_target(const uint8_t* const* host_masks, const int* host
   }
   hipLaunchKernelGGL(mask_target_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, T, mask_h,
                      mask_w, rois, roi_stride, gt_inds, valid, mask_size, out);
+  BGS_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int bgs_mask_paste_u8(const float* probs, const float* boxes, int box_stride, int K, int S,
+                                 float scale_factor, float thr, int img_h, int img_w, unsigned char* out,
+                                 bgs_stream_t stream) {
+  if (K < 0 || S <= 0 || img_h <= 0 || img_w <= 0 || box_stride < 4 || !(scale_factor > 0.f))
+    return BGS_ERR_INVALID_ARG;
+  if (K == 0) return BGS_OK;
+  if (!probs || !boxes || !out) return BGS_ERR_INVALID_ARG;
+  if ((uintptr_t)out % 4 != 0) return BGS_ERR_UNSUPPORTED;
+  const long long total = (long long)K * img_h * img_w;
+  const long long words = (total + 3) / 4;
+  if (words > 0x7fffffffLL * 256LL || (long long)img_h * img_w > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(mask_paste_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     probs, boxes, box_stride, K, S, scale_factor, thr, img_h, img_w,
+                     reinterpret_cast<unsigned*>(out), total);
   BGS_RETURN_LAUNCH_STATUS();
 }
 

@@ -335,10 +335,8 @@ extern "C" int bgs_roi_align_nhwc_fwd_ex(const float* const* host_feats, const i
   if (rc != BGS_OK) return rc;
   const long long waves = (long long)K * pooled_h * pooled_w;
   unsigned grid = (unsigned)((waves + 3) / 4);
-  static const int xcd_mode = [] {
-    const char* e = getenv("BGS_ROI_XCD");
-    return e ? atoi(e) : 0;
-  }();
+  const char* xcd_env = getenv("BGS_ROI_XCD");                // (read at every call: A/B in one process)
+  const int xcd_mode = xcd_env ? atoi(xcd_env) : 0;
   int xcd_chunk = 0;
   if (xcd_mode > 0 && sample_num == 2 && grid >= 64) {
     xcd_chunk = (int)((grid + 7) / 8);

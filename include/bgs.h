@@ -701,6 +701,14 @@ int bgs_mask_target(const uint8_t* const* host_masks, const int* host_num_gt, in
 int bgs_mask_gt_logits(const float* feat, const float* weight, const float* bias,
                        const long long* labels, int P, int pixels, int C, int num_classes,
                        float* logits_out, bgs_stream_t stream);
+/* bgs_mask_paste_u8: the resize + threshold + paste of FCNMaskHead.get_seg_masks (fcn_mask_head.py:156-176; the RLE
+ *   encoding that follows needs pycocotools and stays on the host): probs [K, S, S] float = sigmoid of every
+ *   detection's own class channel; boxes [K, box_stride >= 4] float (x1, y1, x2, y2, ...), divided by scale_factor and
+ *   truncated to int32 as :164 does; out [K, img_h, img_w] uint8 in {0, 1} (every byte written; 4-byte aligned):
+ *   out[k, y1 : y1 + h, x1 : x1 + w] = cv2.resize(probs[k], (w, h), INTER_LINEAR) > thr, zero elsewhere; the part of a
+ *   box outside the image is clipped. */
+int bgs_mask_paste_u8(const float* probs, const float* boxes, int box_stride, int K, int S, float scale_factor,
+                      float thr, int img_h, int img_w, unsigned char* out, bgs_stream_t stream);
 int bgs_mask_bce_partials(int P);
 int bgs_mask_bce(const float* feat, const float* weight, const float* bias, const long long* labels,
                  const float* target, const uint8_t* valid, const float* norm, int P, int pixels,

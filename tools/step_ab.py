@@ -1,0 +1,51 @@
+"""Interleaved A/B of the whole cfg[1] training step (eager launches on the real side streams) between arms given as
+    name:KEY=val,KEY=val;name2:...
+KEY = an environment variable that the library reads at every call (BGS_LEVEL_FORK, BGS_ROI_XCD, ...), or
+HALO_WIDE = 0/1/2 (bgs_conv3x3_halo_bfx_tuning: the wide pixel tile of the halo kernel).
+python tools/step_ab.py "v4:HALO_WIDE=0;wide:HALO_WIDE=1" [rounds=5] [steps=20] [selectp=1] [extra bench flags...]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+argv = sys.argv[1:]
+sys.argv = sys.argv[:1]
+import torch
+import bench
+from balancedgroupsoftmax_amd import functional as BF
+
+spec = argv[0] if argv else 'v4:HALO_WIDE=0;wide:HALO_WIDE=1'
+rounds = int(argv[1]) if len(argv) > 1 else 5
+steps = int(argv[2]) if len(argv) > 2 else 20
+selectp = int(argv[3]) if len(argv) > 3 else 1
+flags = argv[4:]
+arms = []
+for part in spec.split(';'):
+    name, _, kv = part.partition(':')
+    arms.append((name, [tuple(x.split('=')) for x in kv.split(',') if x]))
+keys = sorted({k for _, kvs in arms for k, _ in kvs})
+
+
+def apply(kvs):
+    d = dict(kvs)
+    for k in keys:
+        if k == 'HALO_WIDE':
+            BF.conv_bfx_tuning(halo_wide=int(d.get(k, 1)))
+        elif k in d:
+            os.environ[k] = d[k]
+        else:
+            os.environ.pop(k, None)
+
+
+dev = torch.device('cuda', 0)
+step = bench.DetectorStep(dev, 0, 1, 2, selectp, mask='--mask' in flags, cascade='--cascade' in flags,
+                          htc='--htc' in flags, conv_math='bf16' if '--bf16' in flags else 'bf16x6')
+res = {n: [] for n, _ in arms}
+for n, kvs in arms:
+    apply(kvs)
+    bench.timed_loop(step, 4, 4, 1)
+for r in range(rounds):
+    for n, kvs in (arms if r % 2 == 0 else arms[::-1]):
+        apply(kvs)
+        res[n].append(bench.timed_loop(step, steps, 3, 1) * 1e3 / steps)
+BF.conv_bfx_tuning()
+for n, _ in arms:
+    v = res[n]
+    print('%-16s ms/step: min %.3f  median %.3f  all %s' % (n, min(v), sorted(v)[len(v) // 2], ' '.join('%.3f' % x for x in v)), flush=True)
