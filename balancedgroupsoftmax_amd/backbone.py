@@ -278,6 +278,7 @@ class ResNet(nn.Module):
             self.res_layers.append(name)
         self.feat_dim = inplanes
         self._cache = _FoldCache()
+        self._stem_split = _FoldCache()      # split planes of the fused stem kernel
         self._freeze_stages()
 
     def _freeze_stages(self):
@@ -334,13 +335,23 @@ class ResNet(nn.Module):
         # frozen_stages < 1: the fold is on the tape (resnet.py:483-494), the conv records its
         # weight / bias gradient (the image needs none) and the max-pool its routing
         stem = self._cache.get(nn.ModuleList([self.conv1, self.bn1]), self._build_stem)
-        x = self.to_nhwc4(img)
-        x = BF.conv2d_autograd(x, stem[0], stem[1], stride=2, pad=3, relu=True)
-        # cfg[4] bf16 mode with a frozen trunk: the activations of layer1..4 live in HBM as bf16
-        # (the storage side of wrap_fp16_model, mmdet/core/fp16/decorators.py:8-80)
-        storage = (BF.bf16_storage_active() and not x.requires_grad and
-                   not _trainable(*[getattr(self, n) for n in self.res_layers]))
-        x = BF.maxpool3x3s2_nhwc(x, out_dtype=torch.bfloat16 if storage else torch.float32)
+        frozen_stem = not (torch.is_grad_enabled() and (img.requires_grad or stem[0].requires_grad or
+                                                        stem[1].requires_grad))
+        if img.is_cuda and frozen_stem and img.shape[1] == 3 and tuple(stem[0].shape[:3]) == (64, 7, 7) \
+                and BF.stem_fused_enabled():
+            # round 5: conv1 + ReLU + max-pool in ONE launch straight from the NCHW image (csrc/stem_fused.hip): the
+            # [N, H/2, W/2, 64] conv map (137 MB at cfg[1]) and the NHWC copy of the image never reach HBM
+            ws = self._stem_split.get(nn.ModuleList([self.conv1, self.bn1]),
+                                      lambda: BF.stem_fused_split_weights(stem[0].detach()))
+            x = BF.stem_fused(img, ws, stem[1].detach())
+        else:
+            x = self.to_nhwc4(img)
+            x = BF.conv2d_autograd(x, stem[0], stem[1], stride=2, pad=3, relu=True)
+            # cfg[4] bf16 mode with a frozen trunk: the activations of layer1..4 live in HBM as bf16
+            # (the storage side of wrap_fp16_model, mmdet/core/fp16/decorators.py:8-80)
+            storage = (BF.bf16_storage_active() and not x.requires_grad and
+                       not _trainable(*[getattr(self, n) for n in self.res_layers]))
+            x = BF.maxpool3x3s2_nhwc(x, out_dtype=torch.bfloat16 if storage else torch.float32)
         outs = []
         for i, name in enumerate(self.res_layers):
             for blk in getattr(self, name):

@@ -167,6 +167,10 @@ SIGNATURES = {
     'bgs_mask_target': (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
                                        ctypes.c_int, c_ptr, c_ptr, ctypes.c_int, ctypes.c_int, c_f32p,
                                        c_ptr]),
+    'bgs_stem_fused_weight_bytes': (ctypes.c_size_t, []),
+    'bgs_stem_fused_split_weights': (ctypes.c_int, [c_f32p, ctypes.c_int, c_ptr, c_ptr]),
+    'bgs_stem_conv7x7s2_relu_maxpool_nchw_f32': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, c_f32p, ctypes.c_int,
+                                                                ctypes.c_int, ctypes.c_int, c_ptr]),
     'bgs_mask_paste_u8': (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                          ctypes.c_float, ctypes.c_int, ctypes.c_int, c_ptr, c_ptr]),
     'bgs_mask_gt_logits': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, ctypes.c_int, ctypes.c_int,

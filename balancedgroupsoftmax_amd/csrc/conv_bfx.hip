@@ -773,6 +773,9 @@ __global__ __launch_bounds__(256) void bfx_split_weights_kernel(const float* __r
     o[0] = h;
     if (NS >= 2) o[total] = m;
     if (NS >= 3) o[2 * total] = l;
+    // fourth section: the same [KC][rows][16] layout in fp32 (the halo kernels' FB32 form DMAs THIS — 2/3 of the
+    // bytes of the three planes — and splits a wave's fragment in registers: same split3, same planes, same bits)
+    if (NS >= 3) reinterpret_cast<f32x2*>(reinterpret_cast<unsigned*>(out) + 3 * total)[e] = f32x2{v0, v1};
   }
 }
 
@@ -808,6 +811,7 @@ __global__ __launch_bounds__(256) void bfx_split_weights_dgrad_kernel(const floa
     o[0] = h;
     o[total] = m;
     o[2 * total] = l;
+    reinterpret_cast<f32x2*>(o - e + 3 * total)[e] = f32x2{v[0], v[1]};      // (fp32 section, see above)
   }
 }
 
@@ -1630,13 +1634,24 @@ __device__ __forceinline__ void halo7_store_tile_lds(const ConvArgs& p, const f3
   }
 }
 
-template <int NS>
+// ABL (timing-only ablations, results are WRONG; tools/halo_wide_ablate.py): 1 = the second half's A fragments are
+// not read (half 0's are reused), 2 = the patch is staged once and never again, 4 = no filter DMA after the first.
+// FB32 (NS = 3): the filter slice travels as fp32 (the packed fourth section of the split-weight buffer: 8 KB per
+// tap instead of the 12 KB of three bf16 planes) and every wave splits ITS fragment rows in registers in front of
+// the MFMAs (split3 on the same values = the same planes: bit-identical).  Why: the launch is POWER-limited, and what
+// the L2 -> CU path moves costs clock — PMC on the two-round map (profiles/r9b): 1.60 GHz with the filter DMA, 1.95
+// GHz without it (timing-only ablation), while the cycle count moves by 8 % only.
+template <int NS, int ABL = 0, bool FB32 = false>
 __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx7_kernel(HaloBfxArgs q) {
   const ConvArgs& p = q.c;
   constexpr int PW = 18, PROWS = 18 * 18;                                   // 16 x 16 pixels + halo
   constexpr int AQ = PROWS * 4, AQT = (AQ + kThreads - 1) / kThreads;       // 1296 fp32 quads: 6 per thread (the 6th: 16 threads)
   constexpr int BN = 128, HL = 32;                                          // 32-byte patch pixels, k halves swapped on odd r + c
-  constexpr int B_PLANE = BN * 32, B_BUF = NS * B_PLANE;
+  static_assert(!FB32 || NS == 3, "the fp32 filter form is the fp32-faithful mode's");
+  // FB32: filter rows of 16 fp32 = 64 bytes, the four 16-byte quads of row r XOR-swizzled by (r >> 2) & 3 on the DMA's
+  // source side (the 16-lane groups of the fragment ds_read_b128 — rows {0-3, 12-15, 20-27} / ... — then cover the 64
+  // banks exactly once)
+  constexpr int B_PLANE = BN * 32, B_BUF = FB32 ? BN * 64 : NS * B_PLANE;
   constexpr int A_OFF = 2 * B_BUF;
   constexpr int A_PLANE = PROWS * HL;
   constexpr int A_SUB = 2 * PW * HL;                                        // sub-tile a -> a + 1: two patch rows down
@@ -1659,14 +1674,24 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx7_kernel(HaloBfxA
   const int cchunks = p.Cin / 16;
 
   // ---- filter DMA roles (variant 4's, NB = 2): wave w carries rows 32 w .. 32 w + 31 of every plane
-  const int brow_d = wave * 32 + (lane >> 1);
+  //      (FB32: two pieces of 16 fp32 rows each per wave, lane = 4 (row % 16) + quad slot)
+  const int brow_d = FB32 ? wave * 32 + (lane >> 2) : wave * 32 + (lane >> 1);
   const int bhalf_d = (lane & 1) ^ ((brow_d >> 3) & 1);
   const bool b_okd = n0 + brow_d < p.Cout;
+  const bool b_okd2 = n0 + brow_d + 16 < p.Cout;               // (FB32: the wave's second piece, rows + 16)
   const __bf16* b_lane = q.ws + (size_t)(b_okd ? n0 + brow_d : 0) * 16 + bhalf_d * 8;
   const size_t b_plane = (size_t)q.KC * p.Cout * 16;
+  // fp32 section behind the three planes; the lane's source quad = its LDS slot ^ ((row >> 2) & 3) (same for row + 16)
+  const float* b_lane32 = reinterpret_cast<const float*>(q.ws + 3 * b_plane) +
+                          (size_t)(b_okd ? n0 + brow_d : 0) * 16 + (((lane & 3) ^ ((brow_d >> 2) & 3)) << 2);
   auto issue_b = [&](int chunk, int tap, int buf_off) {
     const size_t koff = (size_t)(tap * cchunks + chunk) * p.Cout * 16;
     const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page);
+    if (FB32) {
+      glds16(b_okd ? b_lane32 + koff : reinterpret_cast<const float*>(zp), lds + buf_off + wave * 2048);
+      glds16(b_okd2 ? b_lane32 + koff + 16 * 16 : reinterpret_cast<const float*>(zp), lds + buf_off + wave * 2048 + 1024);
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s)
       glds16(b_okd ? b_lane + s * b_plane + koff : zp, lds + buf_off + s * B_PLANE + wave * 1024);
@@ -1719,6 +1744,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx7_kernel(HaloBfxA
   }
   const int brow = wn * 64 + frow;                             // + 32 b: same 8-row-group parity
   const int b_frag = brow * 32 + ((fk ^ ((brow >> 3) & 1)) << 4);
+  // FB32: the lane's eight k of row brow (+ 32 b: same (row >> 2) & 3) are quads 2 fk and 2 fk + 1 of the 64-byte row
+  const int b_frag32_0 = brow * 64 + (((2 * fk) ^ ((brow >> 2) & 3)) << 4);
+  const int b_frag32_1 = brow * 64 + (((2 * fk + 1) ^ ((brow >> 2) & 3)) << 4);
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -1728,6 +1756,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx7_kernel(HaloBfxA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  if (q.flags & 2) {
+    // static priority by the wave's hardware slot on its SIMD (two waves per SIMD, one of each co-resident workgroup):
+    // the odd slot always wins issue arbitration, the even one takes the matrix pipe whenever the odd one is between
+    // its MFMA clusters — the two workgroups of a CU cannot fall into lockstep (both fetching fragments at once, the
+    // pipe idle).  A/B: bgs_conv3x3_halo_bfx_tuning flags bit 1.
+    const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));   // HW_ID.WAVE_ID [3:0]
+    if (hwid & 1u) __builtin_amdgcn_s_setprio(3);
+  }
   load_a(0);
   issue_b(0, 0, 0);
   store_a();
@@ -1740,26 +1776,44 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx7_kernel(HaloBfxA
     for (int tap = 0; tap < 9; ++tap) {
       const int rd = (tap & 1) ? nxt : cur;                     // buffer of this step
       const int wr = (tap & 1) ? cur : nxt;                     // buffer of the next step
-      if (tap < 8) issue_b(chunk, tap + 1, wr);                 // next filter slice: DMA in flight
-      else if (!last_chunk) issue_b(chunk + 1, 0, wr);
-      if (tap == 5 && !last_chunk) load_a(chunk + 1);           // next patch: held in registers over three steps
+      if (!(ABL & 4)) {
+        if (tap < 8) issue_b(chunk, tap + 1, wr);               // next filter slice: DMA in flight
+        else if (!last_chunk) issue_b(chunk + 1, 0, wr);
+      }
+      if (tap == 5 && !last_chunk && !(ABL & 2)) load_a(chunk + 1);   // next patch: held in registers over three steps
       const int tap_off = ((tap / 3) * PW + (tap % 3)) * HL;    // compile-time constants
       const int tap_par = (tap / 3 + tap % 3) & 1;
       bf16x8 fb[NS][2];
+      if (FB32) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-          fb[s][b] = *reinterpret_cast<const bf16x8*>(lds + rd + b_frag + s * B_PLANE + b * 32 * 32);
-#pragma unroll
-      for (int ah = 0; ah < 2; ++ah) {                          // two halves of the wave's 128 pixels: 24 fragment registers each
-        bf16x8 fa[NS][2];
+        for (int b = 0; b < 2; ++b) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + rd + b_frag32_0 + b * 32 * 64);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + rd + b_frag32_1 + b * 32 * 64);
+          u32x2 h0, m0, l0, h1, m1, l1;
+          split3(v0, h0, m0, l0);
+          split3(v1, h1, m1, l1);
+          fb[0][b] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+          if (NS >= 2) fb[NS >= 2 ? 1 : 0][b] = __builtin_bit_cast(bf16x8, u32x4{m0[0], m0[1], m1[0], m1[1]});
+          if (NS >= 3) fb[NS >= 3 ? 2 : 0][b] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+        }
+      } else {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
-            fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[tap_par] + tap_off + (2 * ah + a) * A_SUB +
-                                                        s * A_PLANE);
+          for (int b = 0; b < 2; ++b)
+            fb[s][b] = *reinterpret_cast<const bf16x8*>(lds + rd + b_frag + s * B_PLANE + b * 32 * 32);
+      }
+      bf16x8 fa[NS][2];
+#pragma unroll
+      for (int ah = 0; ah < 2; ++ah) {                          // two halves of the wave's 128 pixels: 24 fragment registers each
+        if (!((ABL & 1) && ah == 1)) {
+#pragma unroll
+          for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+              fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[tap_par] + tap_off + (2 * ah + a) * A_SUB +
+                                                          s * A_PLANE);
+        }
         if (q.flags & 1) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_setprio(1);
@@ -1778,7 +1832,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx7_kernel(HaloBfxA
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // next slice (and patch) landed
       __syncthreads();
-      if (tap == 8 && !last_chunk) {                            // every wave is done with this patch
+      if (tap == 8 && !last_chunk && !(ABL & 2)) {              // every wave is done with this patch
         store_a();
         __syncthreads();
       }
@@ -1832,19 +1886,29 @@ int halo_bfx_geom(int H, int W) {
 }
 int g_halo_last_geom = 0;
 
-// Variant 7 (wide pixel tile) dispatch: -1 = unset (env BGS_HALO_WIDE, default 1) | 0 off | 1 automatic: layers with at
+// Variant 7 (wide pixel tile) dispatch: -1 = unset (env BGS_HALO_WIDE, default 0: see below) | 0 off | 1 automatic: layers with at
 // least one whole round of 512 wide units, Cout % 128 == 0, no channel-chunk split | 2 every eligible layer
 // (bgs_conv3x3_halo_bfx_tuning bits 24..27: value + 1).  g_halo_wide_tail: 0 = the left-over image rows as ONE variant-4
 // launch (default) | k > 1 = that launch split k ways over the channel chunks (+ the split-K epilogue).
 int g_halo_wide = -1;
 int g_halo_last_wide_units = 0, g_halo_last_tail_units = 0;
+// fp32 filter slices + in-register split (FB32): env BGS_HALO_FB32 (read at every call: A/B in one process), default 0
+int halo_fb32_mode() {
+  const char* e = getenv("BGS_HALO_FB32");
+  return e ? atoi(e) : 0;
+}
 int halo_wide_mode() {
   if (g_halo_wide >= 0) return g_halo_wide;
+  // Default OFF.  Measured (profiles/r9a, r9b, r9d): alone, the two-launch schedule takes the P2 layer from 0.741 to 0.710
+  // ms (whole rounds: 17 % more work per second than variant 4) — but inside the cfg[1] step the launches that the
+  // side streams place beside the P2 conv (small pyramid levels, functional.forked) already fill the slots variant 4
+  // leaves idle in its third round, and the 256-register workgroups of variant 7 leave them no room: 6.209 (v4) vs 6.234
+  // ms per step with the forks, 6.386 vs 6.334 without them.  The automatic mode stays for runs without side streams.
   static const int env = [] {
     const char* e = getenv("BGS_HALO_WIDE");
-    if (!e) return 1;
+    if (!e) return 0;
     const int v = atoi(e);
-    return v >= 0 && v <= 2 ? v : 1;
+    return v >= 0 && v <= 2 ? v : 0;
   }();
   return env;
 }
@@ -2119,7 +2183,8 @@ inline int bfx_kc(int K) { return 2 * ((K + 31) / 32); }
 
 extern "C" size_t bgs_conv_bfx_weight_bytes(int rows, int K) {
   if (rows <= 0 || K <= 0) return 0;
-  return (size_t)3 * bfx_kc(K) * rows * 16 * sizeof(__bf16);
+  // three bf16 planes + the packed fp32 copy [KC][rows][16] behind them
+  return (size_t)3 * bfx_kc(K) * rows * 16 * sizeof(__bf16) + (size_t)bfx_kc(K) * rows * 16 * sizeof(float);
 }
 
 extern "C" int bgs_conv_bfx_split_weights(const float* w, void* out, int rows, int K,
@@ -2398,10 +2463,18 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wspl
       g_halo_last_variant = 7;
       g_halo_last_wide_units = qa.tile_count;
       bgs_internal_census_bump(BGS_CENSUS_HALO_WIDE);
-      if (q.ns == 1)
+#define BGS_W7(A_) hipLaunchKernelGGL((conv3x3_halo_bfx7_kernel<3, A_>), dim3((unsigned)(8 * qa.c.chunk)), dim3(kThreads), 0, (hipStream_t)stream, qa)
+      if (q.ns == 3 && halo_fb32_mode() && !g_ablate)
+        hipLaunchKernelGGL((conv3x3_halo_bfx7_kernel<3, 0, true>), dim3((unsigned)(8 * qa.c.chunk)), dim3(kThreads), 0, (hipStream_t)stream, qa);
+      else if (q.ns == 1)
         hipLaunchKernelGGL((conv3x3_halo_bfx7_kernel<1>), dim3((unsigned)(8 * qa.c.chunk)), dim3(kThreads), 0, (hipStream_t)stream, qa);
-      else
-        hipLaunchKernelGGL((conv3x3_halo_bfx7_kernel<3>), dim3((unsigned)(8 * qa.c.chunk)), dim3(kThreads), 0, (hipStream_t)stream, qa);
+      else if (g_ablate == 1) BGS_W7(1);
+      else if (g_ablate == 2) BGS_W7(2);
+      else if (g_ablate == 4) BGS_W7(4);
+      else if (g_ablate == 6) BGS_W7(6);
+      else if (g_ablate == 7) BGS_W7(7);
+      else BGS_W7(0);
+#undef BGS_W7
       if (rows_a < (long long)N * ty7) {
         // the rest: image n_a from pixel row 16 r_a on, and every later image — contiguous in variant 4's tile order
         const int n_a = (int)(rows_a / ty7), r_a = (int)(rows_a - (long long)n_a * ty7);

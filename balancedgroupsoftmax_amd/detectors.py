@@ -319,16 +319,24 @@ class TwoStageDetector(nn.Module):
         return bbox_results, self.simple_test_mask(x, img_meta, det_bboxes, det_labels,
                                                    rescale=rescale)
 
-    def simple_test_mask(self, x, img_meta, det_bboxes, det_labels, rescale=False):
-        """test_mixins.py:153-180 up to the per-detection mask probabilities ``[k, 28, 28]`` of
-        each detection's own class (device tensor).  Pasting into the image + RLE encoding
-        (``get_seg_masks``, pycocotools) is evaluation tooling outside the hot path."""
+    def simple_test_mask(self, x, img_meta, det_bboxes, det_labels, rescale=False, paste=False, encode=None):
+        """test_mixins.py:153-180.  Default: the per-detection mask probabilities ``[k, 28, 28]`` of each
+        detection's own class (device tensor).  ``paste=True``: the reference's return value — ``cls_segms`` of
+        ``FCNMaskHead.get_seg_masks`` (per class the masks pasted into the ``ori_shape`` image, resized /
+        thresholded on the device; dense ``uint8`` unless ``encode`` produces RLEs, see ``get_seg_masks``)."""
         if det_bboxes.shape[0] == 0:
+            if paste:
+                return [[] for _ in range(self.mask_head.num_classes - 1)]
             return det_bboxes.new_zeros((0, 28, 28))
         boxes = det_bboxes[:, :4] * img_meta[0]['scale_factor'] if rescale else det_bboxes[:, :4]
         rois = torch.cat([boxes.new_zeros((boxes.size(0), 1)), boxes], dim=1)
         feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], rois)
-        return self.mask_head.get_mask_probs(self.mask_head.features(feats, nhwc=True), det_labels)
+        probs = self.mask_head.get_mask_probs(self.mask_head.features(feats, nhwc=True), det_labels)
+        if not paste:
+            return probs
+        return self.mask_head.get_seg_masks(probs, boxes, det_labels, self.test_cfg.rcnn,
+                                            img_meta[0]['ori_shape'], img_meta[0]['scale_factor'], rescale,
+                                            encode=encode)
 
     def forward_test(self, imgs, img_metas, **kwargs):
         """base.py forward_test: one scale only (aug_test / TTA is not on the BAGS path)."""

@@ -770,7 +770,7 @@ def conv_bfx_last_launch():
 
 
 CENSUS = dict(bf16_ring8=0, grouped_lds=1, halo_bfx4=2, dma_ring64=3, gs_head_fused=4, conv1x1_bres=5,
-              wgrad_bfx=6, roi_bwd_gather=7, bf16s=8, grouped_bf16s=9, bfx_wide=10, gs_scale_grad=11, halo_wide=12)
+              wgrad_bfx=6, roi_bwd_gather=7, bf16s=8, grouped_bf16s=9, bfx_wide=10, gs_scale_grad=11, halo_wide=12, stem_fused=13)
 
 
 def launch_census(reset=False):
@@ -1376,6 +1376,41 @@ def nchw_to_nhwc4(img):
     out = torch.empty((N, H, W, 4), dtype=torch.float32, device=x.device)
     rc = lib.bgs_nchw_to_nhwc4_f32(capi.ptr(x), capi.ptr(out), N, C, H, W, capi.current_stream(x.device))
     capi.check('bgs_nchw_to_nhwc4_f32', rc)
+    return out
+
+
+def stem_fused_enabled():
+    """The one-launch stem (conv 7x7 / s2 + ReLU + max-pool from the NCHW image, csrc/stem_fused.hip):
+    ``BGS_STEM_FUSED=0`` keeps the three-launch chain (A/B; read at every call)."""
+    return os.environ.get('BGS_STEM_FUSED', '1') != '0' and _CONV_MATH[0] == 'bf16x6'
+
+
+def stem_fused_split_weights(w_krsc):
+    """Folded stem filter ``[64, 7, 7, >=3]`` -> the split planes ``bgs_stem_conv7x7s2_relu_maxpool_nchw_f32`` reads."""
+    _require_cuda(w_krsc)
+    lib = capi.load()
+    w = _f32c(w_krsc)
+    assert w.dim() == 4 and tuple(w.shape[:3]) == (64, 7, 7) and w.shape[3] >= 3, tuple(w.shape)
+    out = torch.empty(lib.bgs_stem_fused_weight_bytes(), dtype=torch.uint8, device=w.device)
+    rc = lib.bgs_stem_fused_split_weights(capi.ptr(w), int(w.shape[3]), capi.ptr(out), capi.current_stream(w.device))
+    capi.check('bgs_stem_fused_split_weights', rc)
+    return out
+
+
+def stem_fused(img, wsplit, bias):
+    """``relu(conv7x7s2(img) + bias)`` max-pooled 3x3 / s2 / p1 in ONE launch: ``img [N, 3, H, W]`` (NCHW, as the
+    reference hands it over) -> ``[N, PH, PW, 64]`` NHWC fp32.  Forward only (the frozen stem of the BAGS configs)."""
+    _require_cuda(img, wsplit, bias)
+    lib = capi.load()
+    x = img.detach().to(torch.float32).contiguous()
+    N, C, H, W = x.shape
+    assert C == 3
+    CH, CW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    PH, PW = (CH - 1) // 2 + 1, (CW - 1) // 2 + 1
+    out = torch.empty((N, PH, PW, 64), dtype=torch.float32, device=x.device)
+    rc = lib.bgs_stem_conv7x7s2_relu_maxpool_nchw_f32(capi.ptr(x), capi.ptr(wsplit), capi.ptr(_f32c(bias)),
+                                                      capi.ptr(out), N, H, W, capi.current_stream(x.device))
+    capi.check('bgs_stem_conv7x7s2_relu_maxpool_nchw_f32', rc)
     return out
 
 
@@ -2037,6 +2072,26 @@ def mask_target(gt_masks, rois, gt_inds, valid, mask_size):
                              capi.ptr(gt_inds), capi.ptr(v8), P, int(mask_size), capi.ptr(out),
                              capi.current_stream(rois.device))
     capi.check('bgs_mask_target', rc)
+    return out
+
+
+def mask_paste(probs, boxes, scale_factor, thr, img_h, img_w):
+    """``FCNMaskHead.get_seg_masks`` without the RLE step (fcn_mask_head.py:156-176) in one launch
+    (``bgs_mask_paste_u8``): ``probs [K, S, S]`` float = sigmoid of each detection's own class channel,
+    ``boxes [K, >=4]`` -> dense ``uint8 [K, img_h, img_w]``: the box (divided by ``scale_factor``, truncated to int as
+    the reference does) receives ``cv2.resize(prob, (w, h), INTER_LINEAR) > thr``, everything else is 0."""
+    _require_cuda(probs, boxes)
+    lib = capi.load()
+    probs, boxes = _f32c(probs), _f32c(boxes)
+    K, S, S2 = probs.shape
+    assert S == S2 and boxes.dim() == 2 and boxes.shape[0] == K and boxes.shape[1] >= 4
+    out = torch.empty((K, int(img_h), int(img_w)), dtype=torch.uint8, device=probs.device)
+    if K == 0:
+        return out
+    rc = lib.bgs_mask_paste_u8(capi.ptr(probs), capi.ptr(boxes), int(boxes.shape[1]), K, S, float(scale_factor),
+                               float(thr), int(img_h), int(img_w), capi.ptr(out),
+                               capi.current_stream(probs.device))
+    capi.check('bgs_mask_paste_u8', rc)
     return out
 
 

@@ -151,6 +151,42 @@ class FCNMaskHead(nn.Module):
                           self._channel(labels), mask_targets.reshape(P, H * W), valid)
         return dict(loss_mask=val * self.loss_mask.loss_weight)
 
+    def get_seg_masks_dense(self, mask_pred, det_bboxes, det_labels, rcnn_test_cfg, ori_shape, scale_factor,
+                            rescale):
+        """The reference's ``get_seg_masks`` (fcn_mask_head.py:125-181) up to the RLE encoding, on the device:
+        ``uint8 [n, img_h, img_w]`` with every detection's thresholded mask pasted at its (rescaled, int-truncated)
+        box.  ``mask_pred``: ``[n, S, S]`` probabilities of each detection's class (``get_mask_probs``) or the
+        reference's ``[n, num_classes, S, S]`` logits (the detection's channel is gathered and squashed here)."""
+        import numpy as np
+        if mask_pred.dim() == 4:
+            ch = self._channel(det_labels + 1)
+            mask_pred = torch.sigmoid(mask_pred[torch.arange(mask_pred.size(0), device=mask_pred.device), ch])
+        if rescale:
+            img_h, img_w = int(ori_shape[0]), int(ori_shape[1])
+        else:           # (:158-161: np.round = half to even; the boxes are already in the network's scale)
+            img_h = int(np.round(ori_shape[0] * scale_factor).astype(np.int32))
+            img_w = int(np.round(ori_shape[1] * scale_factor).astype(np.int32))
+            scale_factor = 1.0
+        return BF.mask_paste(mask_pred.float(), det_bboxes[:, :4], float(scale_factor),
+                             float(rcnn_test_cfg.mask_thr_binary), img_h, img_w)
+
+    def get_seg_masks(self, mask_pred, det_bboxes, det_labels, rcnn_test_cfg, ori_shape, scale_factor, rescale,
+                      encode=None):
+        """Reference signature and return structure (fcn_mask_head.py:125-181): ``cls_segms[label]`` = the masks of
+        that class in detection order.  The resize / threshold / paste runs on the device
+        (``get_seg_masks_dense``); ``encode`` turns one dense ``uint8 [img_h, img_w]`` numpy mask into what the
+        caller stores — pass ``lambda m: pycocotools.mask.encode(np.asfortranarray(m[:, :, None]))[0]`` for the
+        reference's RLEs (pycocotools is evaluation tooling and not a dependency of this package); the default
+        keeps the dense masks (views of one device tensor)."""
+        dense = self.get_seg_masks_dense(mask_pred, det_bboxes, det_labels, rcnn_test_cfg, ori_shape,
+                                         scale_factor, rescale)
+        cls_segms = [[] for _ in range(self.num_classes - 1)]
+        labels = det_labels.cpu().tolist()
+        host = dense.cpu().numpy() if encode is not None else None
+        for i, lab in enumerate(labels):
+            cls_segms[int(lab)].append(encode(host[i]) if encode is not None else dense[i])
+        return cls_segms
+
     def get_mask_probs(self, feats, det_labels):
         """Test time: sigmoid of the detection's own class channel, ``[n, S, S]`` (the input of
         ``get_seg_masks``' per-detection resize; RLE encoding needs pycocotools: out of scope)."""

@@ -400,6 +400,18 @@ int bgs_grouped_conv3x3_wgrad_nhwc_f32(const float* x, const float* dy, float* d
  * channel axis zero-padded: the 16-byte-pixel input of the stem conv (one launch instead of pad + copy). */
 int bgs_nchw_to_nhwc4_f32(const float* x, float* y, int N, int C, int H, int W, bgs_stream_t stream);
 
+/* The ResNet stem in one launch (csrc/stem_fused.hip; mmdet/models/backbones/resnet.py:522-533: conv1 7x7 / stride 2 /
+ * pad 3 (3 -> 64, eval-BN folded by the caller) -> ReLU -> MaxPool2d(3, 2, 1)), bf16x6 arithmetic (fp32-faithful),
+ * reading the NCHW image directly: img [N, 3, H, W] float -> out [N, PH, PW, 64] NHWC float, PH = floor((CH - 1) / 2) + 1
+ * with CH = floor((H - 1) / 2) + 1 (likewise W).  wsplit: bgs_stem_fused_split_weights of the folded filter
+ * [64][7][7][cin_stride >= 3] (channels 0..2 are used), bgs_stem_fused_weight_bytes() bytes, 16-byte aligned; bias [64]
+ * or NULL.  Replaces the chain bgs_nchw_to_nhwc4_f32 -> bgs_conv2d_nhwc_f32_bfx_ws -> bgs_maxpool3x3s2_nhwc_f32 for a
+ * frozen stem (no backward): the [N, CH, CW, 64] conv map never reaches HBM. */
+size_t bgs_stem_fused_weight_bytes(void);
+int bgs_stem_fused_split_weights(const float* w, int cin_stride, void* out, bgs_stream_t stream);
+int bgs_stem_conv7x7s2_relu_maxpool_nchw_f32(const float* img, const void* wsplit, const float* bias, float* out,
+                                             int N, int H, int W, bgs_stream_t stream);
+
 /* 3x3 / stride 2 / pad 1 max pooling, NHWC (ResNet stem, resnet.py:452). C % 4 == 0.
  * y [N, (H-1)/2+1, (W-1)/2+1, C]. */
 int bgs_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C,

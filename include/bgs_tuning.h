@@ -46,6 +46,7 @@ int bgs_selftest_mfma_peak_bf16(int blocks, int iters, int random_operands, floa
 #define BGS_CENSUS_BFX_WIDE 10       /* conv1x1_bfx_wide_kernel (128 x 128, M-stacked waves) */
 #define BGS_CENSUS_GS_SCALE_GRAD 11   /* gs_head_scale_grad_kernel (a non-unit upstream gradient) */
 #define BGS_CENSUS_HALO_WIDE 12       /* conv3x3_halo_bfx7_kernel (16 x 16-pixel x 128-channel units) */
+#define BGS_CENSUS_STEM_FUSED 13      /* stem_conv7x7s2_relu_maxpool_kernel (conv + ReLU + max-pool, NCHW in) */
 #define BGS_CENSUS_FAMILIES 16
 int bgs_launch_census(int family, int reset);
 
@@ -78,8 +79,8 @@ int bgs_gs_head_variant_used(int N);
  *   bgs_conv3x3_halo_bfx_last_launch reports the variant in bits 8..15 of *nb and the pixel tile in bits 16..
  *   (0: 8 x 16, 1: 10 x 12, 2: 5 x 21).  Bits 24..27 of `variant` (round 5): the wide pixel tile (variant 7: 16 x 16
  *   pixels x 128 channels per workgroup, whole rounds of 512 units in one launch + the left-over image rows in a
- *   variant-4 launch; bit-identical to variant 4), 0 = leave as is | 1 = off | 2 = automatic (default; env
- *   BGS_HALO_WIDE=0/1/2) | 3 = every eligible layer; bgs_conv3x3_halo_bfx_tuning(-1, 0) restores the default.
+ *   variant-4 launch; bit-identical to variant 4), 0 = leave as is | 1 = off (default; env BGS_HALO_WIDE=0/1/2) | 2 = automatic |
+ *   3 = every eligible layer; bgs_conv3x3_halo_bfx_tuning(-1, 0) restores the default.
  *   bgs_conv3x3_halo_bfx_last_wide: units of the variant-7 launch (0: it did not run) and of the variant-4 launch
  *   behind it (last_launch then reports variant 7).
  * bgs_conv1x1_bres_enable (filter-resident 1x1, csrc/conv1x1_bres.hip): 1 (default) = where measured faster,

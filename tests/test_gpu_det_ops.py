@@ -237,6 +237,69 @@ def test_linear_autograd_vs_torch():
     assert float((wd2.grad.cpu().double() - expw).abs().max()) < 5e-5 * float(expw.abs().max())
 
 
+@pytest.mark.parametrize('shape', [(1, 96, 160), (2, 67, 93), (1, 33, 31), (2, 224, 320)],
+                         ids=lambda c: 'x'.join(str(v) for v in c))
+def test_fused_stem_conv_relu_maxpool_vs_torch_fp64_and_the_three_launch_chain(shape):
+    """``bgs_stem_conv7x7s2_relu_maxpool_nchw_f32`` (round 5: mmdet/models/backbones/resnet.py:522-533 conv1 -> BN
+    (folded) -> ReLU -> MaxPool2d(3, 2, 1) in one launch from the NCHW image) == torch-CPU fp64 within the bf16x6
+    family's bound and == the chain nchw_to_nhwc4 -> conv2d (K = 7 * 7 * 4) -> maxpool3x3s2 it replaces (same
+    products, another summation order); odd sizes: tiles hanging over the pooled map, conv rows / columns that exist
+    only as pool padding."""
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H * 3 + W)
+    img = torch.randn(N, 3, H, W, generator=g) * torch.exp(0.5 * torch.randn(N, 3, H, W, generator=g))
+    w = torch.randn(64, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5
+    b = torch.randn(64, generator=g) * 0.5
+    exp = F.max_pool2d(F.relu(F.conv2d(img.double(), w.double(), b.double(), stride=2, padding=3)), 3, 2, 1)
+    exp = exp.permute(0, 2, 3, 1)
+    wk = torch.nn.functional.pad(w.permute(0, 2, 3, 1), (0, 1)).contiguous()        # [64, 7, 7, 4] as the fold hands it over
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        BF.launch_census(reset=True)
+        ws = BF.stem_fused_split_weights(dev(wk))
+        got = BF.stem_fused(dev(img), ws, dev(b))
+        assert BF.launch_census()['stem_fused'] == 1
+        chain = BF.maxpool3x3s2_nhwc(BF.conv2d_nhwc(BF.nchw_to_nhwc4(dev(img)), dev(wk), dev(b), stride=2, pad=3,
+                                                    relu=True))
+    finally:
+        BF.set_conv_math(prev)
+    scale = float(exp.abs().max())
+    assert tuple(got.shape) == tuple(exp.shape) == tuple(chain.shape)
+    assert float((got.cpu().double() - exp).abs().max()) <= 2e-6 * scale
+    assert float((got - chain).abs().max()) <= 1e-5 * scale
+    assert float(got.min()) >= 0.0
+
+
+def test_resnet_stem_takes_the_fused_kernel_when_frozen_and_the_chain_otherwise(monkeypatch):
+    """Dispatch: a frozen stem under bf16x6 launches the fused kernel once (no NHWC image copy, no max-pool launch);
+    ``BGS_STEM_FUSED=0``, the fp32-MFMA arithmetic and a trainable stem keep the chain; same feature maps."""
+    import balancedgroupsoftmax_amd as bgs
+    from balancedgroupsoftmax_amd.config import to_config_dict
+    torch.manual_seed(3)
+    net = bgs.build_backbone(to_config_dict(dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3),
+                                                 frozen_stages=1, style='pytorch'))).to(DEV).eval()
+    img = torch.randn(1, 3, 128, 160, device=DEV)
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        with torch.no_grad():
+            BF.launch_census(reset=True)
+            a = net(img)
+            assert BF.launch_census()['stem_fused'] == 1
+            monkeypatch.setenv('BGS_STEM_FUSED', '0')
+            BF.launch_census(reset=True)
+            b = net(img)
+            assert BF.launch_census()['stem_fused'] == 0
+            monkeypatch.delenv('BGS_STEM_FUSED')
+            BF.set_conv_math('f32')
+            BF.launch_census(reset=True)
+            net(img)
+            assert BF.launch_census()['stem_fused'] == 0
+        for u, v in zip(a, b):
+            assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max())
+    finally:
+        BF.set_conv_math(prev)
+
+
 def test_maxpool3x3s2():
     rs = np.random.RandomState(6)
     for (N, H, W, C) in [(2, 17, 23, 8), (1, 64, 96, 64)]:

@@ -191,6 +191,73 @@ def _mask_rcnn(tmp_path):
                               test_cfg=to_config_dict(test_cfg))
 
 
+@pytest.mark.parametrize('case', [
+    # (K, S, img_h, img_w, scale_factor): total bytes not a multiple of 4, odd widths, a scale that moves the boxes
+    (9, 28, 97, 131, 1.37), (5, 28, 800, 1333, 1.0), (3, 14, 61, 67, 0.5), (1, 28, 33, 35, 2.0)],
+    ids=lambda c: 'x'.join(str(v) for v in c))
+def test_mask_paste_kernel_equals_the_oracle_of_get_seg_masks(case):
+    """``bgs_mask_paste_u8`` (FCNMaskHead.get_seg_masks, fcn_mask_head.py:156-176, without the RLE step: int
+    truncation of box / scale_factor, cv2's float32 INTER_LINEAR resize of the 28 x 28 probabilities to the box,
+    > thr, paste into a zero image) == ``oracle.mask_oracle.seg_masks_dense`` — pinned against the EXECUTED
+    reference method in tests/test_mask_cpu.py — byte for byte: the same float32 operations in the same order;
+    boxes that leave the image are clipped, degenerate boxes become 1 x 1, every output byte is written."""
+    K, S, ih, iw, sf = case
+    rs = np.random.RandomState(K * 7 + iw)
+    probs = (1.0 / (1.0 + np.exp(-rs.standard_normal((K, S, S)) * 2))).astype(np.float32)
+    boxes = np.zeros((K, 5), np.float32)
+    for i in range(K):
+        x1, y1 = rs.rand() * iw * sf * 0.8, rs.rand() * ih * sf * 0.8
+        boxes[i] = [x1, y1, x1 + 1 + rs.rand() * iw * sf * 0.5, y1 + 1 + rs.rand() * ih * sf * 0.5, rs.rand()]
+    boxes[0, :4] = [0, 0, (iw - 0.1) * sf, (ih - 0.1) * sf]              # the whole image
+    if K > 1:
+        boxes[1, :4] = [10.2 * sf, 7.7 * sf, 10.3 * sf, 7.9 * sf]         # 1 x 1 after truncation
+    if K > 2:
+        boxes[2, :4] = [(iw - 9) * sf, (ih - 5) * sf, (iw + 14) * sf, (ih + 8) * sf]     # leaves the image: clipped
+    if K > 3:
+        boxes[3, :4] = [20 * sf, 30 * sf, (20 + S - 1) * sf + 0.2, (30 + S - 1) * sf + 0.2]   # S x S: no resize
+    if K > 4:
+        boxes[4, :4] = [5 * sf, 5 * sf, 3 * sf, 4 * sf]                   # x2 < x1: w = h = 1
+    out = torch.full((K, ih, iw), 7, dtype=torch.uint8, device=DEV)
+    got = BF.mask_paste(torch.from_numpy(probs).to(DEV), torch.from_numpy(boxes).to(DEV), sf, 0.5, ih, iw)
+    exp, margin = mask_oracle.seg_masks_dense(probs, boxes, sf, 0.5, ih, iw, return_margin=True)
+    g = got.cpu().numpy()
+    assert g.shape == exp.shape and g.dtype == np.uint8 and set(np.unique(g).tolist()) <= {0, 1}
+    diff = g != exp
+    assert not diff.any(), (int(diff.sum()), float(margin[diff].max()))
+    assert exp[0].sum() > 0 and exp.sum() < exp.size
+    del out
+
+
+def test_fcn_mask_head_get_seg_masks_structure_and_4d_logits():
+    """The reference signature: ``[n, num_classes, S, S]`` logits in, ``cls_segms`` (per class, detection order)
+    out; == the oracle on the sigmoid of each detection's channel; ``encode`` receives host numpy masks."""
+    C, n, S = 6, 8, 28
+    head = _head(C).to(DEV)
+    rs = np.random.RandomState(5)
+    logits = torch.from_numpy((rs.standard_normal((n, C, S, S)) * 2).astype(np.float32)).to(DEV)
+    labels = torch.from_numpy(rs.randint(0, C - 1, n).astype(np.int64)).to(DEV)
+    boxes = np.zeros((n, 5), np.float32)
+    for i in range(n):
+        x1, y1 = rs.rand() * 150, rs.rand() * 100
+        boxes[i] = [x1, y1, x1 + 3 + rs.rand() * 80, y1 + 3 + rs.rand() * 60, rs.rand()]
+    cfg = to_config_dict(dict(mask_thr_binary=0.5))
+    ori_shape, sf = (120, 180, 3), 1.5
+    probs = torch.sigmoid(logits)[torch.arange(n), labels + 1].cpu().numpy()
+    for rescale in (True, False):
+        segms = head.get_seg_masks(logits, torch.from_numpy(boxes).to(DEV), labels, cfg, ori_shape, sf, rescale)
+        ih, iw, s = (120, 180, sf) if rescale else (int(np.round(120 * sf)), int(np.round(180 * sf)), 1.0)
+        exp = mask_oracle.seg_masks_dense(probs, boxes, s, 0.5, ih, iw)
+        assert len(segms) == C - 1 and sum(len(c) for c in segms) == n
+        seen = [0] * (C - 1)
+        for i, lab in enumerate(labels.cpu().tolist()):
+            m = segms[lab][seen[lab]]
+            seen[lab] += 1
+            assert np.array_equal(m.cpu().numpy(), exp[i]), (rescale, i)
+    enc = head.get_seg_masks(logits, torch.from_numpy(boxes).to(DEV), labels, cfg, ori_shape, sf, True,
+                             encode=lambda m: (type(m).__name__, int(m.sum())))
+    assert all(e[0] == 'ndarray' for c in enc for e in c)
+
+
 @pytest.mark.parametrize('selectp', [1, 0])
 def test_mask_rcnn_training_iteration(tmp_path, selectp):
     torch.manual_seed(0)

@@ -103,3 +103,72 @@ def test_mask_rcnn_builds_from_reference_config(tmp_path):
     assert model.mask_roi_extractor.out_size == 14 and not model.share_roi_extractor
     assert tuple(model.mask_head.conv_logits.weight.shape) == (1231, 256, 1, 1)
     assert cfg.train_cfg.rcnn.mask_size == 28 and cfg.test_cfg.rcnn.mask_thr_binary == 0.5
+
+
+def test_resize_linear_f32_properties():
+    """cv2.resize(float32, INTER_LINEAR) restatement: identity size returns the source, a constant image stays
+    constant to within one rounding, upsampling a ramp is monotone, borders replicate."""
+    rs = np.random.RandomState(3)
+    src = rs.rand(28, 28).astype(np.float32)
+    assert np.array_equal(mask_oracle.resize_linear_f32(src, (28, 28)), src)
+    c = np.full((28, 28), 0.37, np.float32)
+    for size in ((5, 9), (61, 17), (14, 14), (300, 211)):
+        out = mask_oracle.resize_linear_f32(c, size)
+        assert out.shape == (size[1], size[0]) and np.abs(out - np.float32(0.37)).max() <= 6e-8
+    ramp = np.tile(np.linspace(0, 1, 28, dtype=np.float32), (28, 1))
+    up = mask_oracle.resize_linear_f32(ramp, (113, 40))
+    assert (np.diff(up, axis=1) >= -1e-7).all() and up[:, 0].max() == 0.0 and up[:, -1].min() == 1.0
+    out = mask_oracle.resize_linear_f32(src, (56, 56))
+    assert out[0, 0] == src[0, 0] and out[-1, -1] == src[-1, -1]
+
+
+def test_seg_masks_dense_equals_the_executed_reference_get_seg_masks():
+    """``oracle.mask_oracle.seg_masks_dense`` (the checker of ``bgs_mask_paste_u8``) against the EXECUTED
+    ``FCNMaskHead.get_seg_masks`` (fcn_mask_head.py:125-181) with ``mmcv.imresize`` := the oracle's float32 resize
+    and ``mask_util.encode`` := identity: box truncation, w / h, the class channel, threshold, placement and the
+    per-class bucketing are the reference's own code; only the cv2 resize is the restatement."""
+    if not ref_import.reference_available():
+        pytest.skip('reference tree absent')
+    ref_import.install_stubs()
+    import mmdet.models.mask_heads.fcn_mask_head as ref_mod
+    from balancedgroupsoftmax_amd.config import to_config_dict
+    rs = np.random.RandomState(11)
+    n, C, S = 7, 6, 28
+    ref = ref_mod.FCNMaskHead(num_convs=1, in_channels=8, conv_out_channels=8, num_classes=C)
+    logits = torch.from_numpy((rs.standard_normal((n, C, S, S)) * 2).astype(np.float32))
+    ori_shape, scale = (97, 131, 3), 1.37
+    boxes = np.zeros((n, 5), np.float32)
+    for i in range(n):
+        x1, y1 = rs.rand() * 100 * scale, rs.rand() * 70 * scale
+        boxes[i] = [x1, y1, x1 + 2 + rs.rand() * 60, y1 + 2 + rs.rand() * 50, rs.rand()]
+    boxes[0, :4] = [0, 0, 130.9 * scale, 96.9 * scale]            # the whole image
+    boxes[1, :4] = [50.2, 40.7, 50.9, 41.1]                        # a 1 x 1 box
+    labels = torch.from_numpy(rs.randint(0, C - 1, n).astype(np.int64))
+    cfg = to_config_dict(dict(mask_thr_binary=0.5))
+    saved = (ref_mod.mmcv.imresize, ref_mod.mask_util.encode)
+    ref_mod.mmcv.imresize = lambda img, size: mask_oracle.resize_linear_f32(img, size)
+    ref_mod.mask_util.encode = lambda arr: [np.array(arr[:, :, 0])]
+    try:
+        for rescale in (True, False):
+            # (rescale: boxes live in the network's scale and the masks go to ori_shape; else both in the network's)
+            bx = boxes.copy()
+            if not rescale:
+                bx[:, :4] = np.minimum(bx[:, :4], [[round(131 * scale) - 1, round(97 * scale) - 1] * 2])
+            else:
+                bx[:, :4] = np.minimum(bx[:, :4], [[131 * scale - 0.01, 97 * scale - 0.01] * 2])
+            segms = ref.get_seg_masks(logits, torch.from_numpy(bx), labels, cfg, ori_shape, scale, rescale)
+            probs = torch.sigmoid(logits)[torch.arange(n), labels + 1].numpy()
+            if rescale:
+                ih, iw, sf = 97, 131, scale
+            else:
+                ih, iw, sf = int(np.round(97 * scale)), int(np.round(131 * scale)), 1.0
+            dense = mask_oracle.seg_masks_dense(probs, bx, sf, 0.5, ih, iw)
+            seen = [0] * (C - 1)
+            for i in range(n):
+                lab = int(labels[i])
+                m = segms[lab][seen[lab]]
+                seen[lab] += 1
+                assert m.shape == (ih, iw) and np.array_equal(m, dense[i]), (rescale, i)
+            assert dense.sum() > 0
+    finally:
+        ref_mod.mmcv.imresize, ref_mod.mask_util.encode = saved
