@@ -522,7 +522,11 @@ WgradPlan plan_wgrad(int M, int Cout, int K, bool bfx = false) {
   long long splits = (2304 + tiles - 1) / tiles;
   // (M <= 2048 — the FC heads at 1024 RoIs: fc_cls of the shipped selectp = 1 step, 80 tiles: 8 slices of 128 rows
   //  52.6 us, 4 of 256 68.4, 3 of 352 (the round-down below) 69.5; tools/fc_cls_wgrad_ab.py, profiles/r9a)
-  const long long min_rows = M >= 16384 ? 512 : (M <= 2048 ? 128 : 256);
+  long long min_rows = M >= 16384 ? 512 : (M <= 2048 ? 128 : 256);
+  if (const char* e = getenv("BGS_WGRAD_MINROWS")) {            // A/B
+    const int f = atoi(e);
+    if (f >= 16) min_rows = f;
+  }
   const long long max_splits = (M + min_rows - 1) / min_rows;
   if (splits > max_splits) splits = max_splits;
   if (splits > 128) splits = 128;

@@ -922,6 +922,15 @@ def extras(dev, args):
                         'loss': d['last_losses']['loss'], 'launch': d['config']['launch']}
         except Exception as e:  # pragma: no cover
             res[key] = {'error': repr(e)[:200]}
+    # test time (informational): simple_test on one 800 x 1344 image, 1000 proposals, score_thr = 0, 1230 classes
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'infer_time.py'), '20'],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')]
+        res['inference_simple_test'] = json.loads(line[-1]) if out.returncode == 0 and line else \
+            {'error': 'rc=%d %s' % (out.returncode, out.stderr.decode()[-160:])}
+    except Exception as e:  # pragma: no cover
+        res['inference_simple_test'] = {'error': repr(e)[:200]}
     return res
 
 
