@@ -991,6 +991,64 @@ STEP_GFLOP = {
 }
 
 
+def step_layer_floor(imgs, conv_math):
+    """Per-layer floor of the selectp = 1 cfg[1] step: sum over the conv / linear layers of
+    max(flops / matrix-pipe peak, algorithmic bytes / 8 TB/s) — a K = 64 layer of ResNet layer1 is priced by the
+    bytes it must move (input + output + residual + filter), not by its MFMAs.  Layer shapes: resnet.py:220-266,
+    522-533 (stem 7x7 / s2 + max-pool, stages 3-4-6-3), fpn.py:101-141, rpn_head.py:30-35, convfc_bbox_head.py:
+    132-168, at 800 x 1344.  Returns (floor_ms, mfma_part_ms, hbm_bound_ms, n_layers, hbm_bound_layers)."""
+    peak = {'bf16x6': 2500.0 / 6.0, 'f32': 157.3, 'bf16': 2500.0}[conv_math] * 1e12
+    hbm = HBM_PEAK_GBS * 1e9
+    N = imgs
+    layers = []     # (name, M = output pixels, K, Cout, input bytes, extra bytes (residual), count)
+
+    def conv(name, H, W, Cin, Cout, R, stride, count=1, residual=False):
+        Ho, Wo = H // stride, W // stride
+        M = N * Ho * Wo
+        inb = N * H * W * Cin * 4
+        layers.append((name, M, R * R * Cin, Cout, inb, M * Cout * 4 if residual else 0, count))
+
+    conv('stem', 800, 1344, 3, 64, 7, 2)            # (+ max-pool: its 34 MB output is what leaves)
+    H1, W1 = 200, 336
+    conv('l1.c1(64)', H1, W1, 64, 64, 1, 1)
+    conv('l1.c1(256)', H1, W1, 256, 64, 1, 1, 2)
+    conv('l1.c2', H1, W1, 64, 64, 3, 1, 3)
+    conv('l1.c3', H1, W1, 64, 256, 1, 1, 3, residual=True)
+    conv('l1.ds', H1, W1, 64, 256, 1, 1)
+    for pl, (hi, wi), nb in ((128, (200, 336), 4), (256, (100, 168), 6), (512, (50, 84), 3)):
+        ho, wo = hi // 2, wi // 2
+        conv('c1', hi, wi, pl * 2, pl, 1, 1)
+        conv('c2s2', hi, wi, pl, pl, 3, 2)
+        conv('ds', hi, wi, pl * 2, pl * 4, 1, 2)
+        conv('c1', ho, wo, pl * 4, pl, 1, 1, nb - 1)
+        conv('c2', ho, wo, pl, pl, 3, 1, nb - 1)
+        conv('c3', ho, wo, pl, pl * 4, 1, 1, nb, residual=True)
+    for (h, w, c) in ((200, 336, 256), (100, 168, 512), (50, 84, 1024), (25, 42, 2048)):
+        conv('fpn.lat', h, w, c, 256, 1, 1, residual=(h != 25))     # (top-down add fused in the lateral's epilogue)
+        conv('fpn.out', h, w, 256, 256, 3, 1)
+    for (h, w) in ((200, 336), (100, 168), (50, 84), (25, 42), (13, 21)):
+        conv('rpn.conv', h, w, 256, 256, 3, 1)
+        conv('rpn.head', h, w, 256, 15, 1, 1)
+    R = 512 * N
+    for name, K, Cout in (('fc1', 12544, 1024), ('fc2', 1024, 1024), ('fc_cls', 1024, 1236), ('fc_reg', 1024, 4924)):
+        layers.append((name, R, K, Cout, R * K * 4, 0, 1))
+    layers.append(('fc_cls.dW', 1236, R, 1024, R * (1236 + 1024) * 4, 0, 1))
+    floor = mfma_ms = hbm_ms = 0.0
+    nl = nh = 0
+    for name, M, K, Cout, inb, extra, count in layers:
+        flops = 2.0 * M * K * Cout
+        outb = M * Cout * 4 if name != 'stem' else M * Cout          # (the stem's map is pooled 4:1 before it leaves)
+        byts = inb + outb + extra + K * Cout * 4
+        t_m, t_b = flops / peak, byts / hbm
+        floor += count * max(t_m, t_b)
+        mfma_ms += count * t_m
+        nl += count
+        if t_b > t_m:
+            nh += count
+            hbm_ms += count * t_b
+    return floor * 1e3, mfma_ms * 1e3, hbm_ms * 1e3, nl, nh
+
+
 def roofline_step(out, args):
     """The WHOLE step against the matrix-pipe ceiling (the line's `roofline` describes the best
     layer of the dominant kernel only): algorithmic GFLOP per step / ms_per_step / ceiling, plus the
@@ -1005,6 +1063,14 @@ def roofline_step(out, args):
              note='algorithmic flops of the whole iteration (conv + FC; SURVEY.md 8d) per GPU / wall '
                   'time per step / the arithmetic mode\'s matrix-pipe ceiling; the step also holds '
                   'HBM- and latency-bound kernels (targets, NMS, RoIAlign, losses, optimizer)')
+    if args.selectp == 1:
+        fl, mm, hb, nl, nh = step_layer_floor(args.imgs, args.conv_math)
+        r['per_layer_floor'] = dict(
+            floor_ms=round(fl, 3), frac=round(fl / out['ms_per_step'], 4), mfma_only_ms=round(mm, 3),
+            hbm_bound_layers=nh, layers=nl, hbm_bound_ms=round(hb, 3),
+            note='sum over the %d conv / linear launches of max(flops / %.1f TFLOP/s, algorithmic bytes / 8 TB/s); '
+                 '%d of them (ResNet layer1, the stem, the RPN heads, fc_cls dW) are priced by their bytes; frac = '
+                 'floor / ms_per_step' % (nl, peak, nh))
     try:
         with open(os.path.join(ROOT, 'profiles', 'step_families.json')) as f:
             fam = json.load(f)

@@ -10,7 +10,7 @@ import sys
 
 CATS = [('conv: halo 3x3', ('conv3x3_halo',)), ('conv: implicit GEMM', ('conv_igemm', 'conv_bf16s', 'conv1x1_bres', 'conv1x1_bfx_wide')),
         ('conv: split-K epilogue', ('conv_splitk',)), ('conv: weight split / wgrad / grouped / pool',
-                                                       ('bfx_split', 'conv_wgrad', 'grouped_conv', 'maxpool', 'fold_', 'wgrad_reduce', 'nchw_to')),
+                                                       ('bfx_split', 'conv_wgrad', 'grouped_conv', 'maxpool', 'fold_', 'wgrad_reduce', 'nchw_to', 'stem_')),
         ('torch glue (elementwise / copy / cat / reduce / index)', ('at::native', 'rocclr', 'at::cuda', 'cub::', 'rocprim', 'hipcub')),
         ('optimizer (fused clip + SGD)', ('sgd_',)),
         ('GroupSoftmax + box loss', ('gs_', 'bbox_sl1', 'reduce_partials')),
@@ -46,11 +46,16 @@ def categories(rows, steps):
     print()
 
 
-def steady_steps(rows, marker='maxpool3x3s2'):
+def steady_steps(rows, markers=('stem_conv7x7s2_relu_maxpool', 'maxpool3x3s2')):
     """The kernels of the LAST complete steps of the trace (between occurrences of a kernel that
-    runs once per step): warm-up work (BN folding, filter splits, allocator fills) is excluded."""
+    runs once per step — the fused stem kernel, or the stem's max-pool of the three-launch chain): warm-up work (BN
+    folding, filter splits, allocator fills) is excluded."""
     rows = sorted(rows, key=lambda r: int(r['Start_Timestamp']))
-    marks = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
+    marks = []
+    for marker in markers:
+        marks = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
+        if len(marks) >= 3:
+            break
     if len(marks) < 3:
         return rows, 0
     n = min(4, len(marks) - 1)
