@@ -29,21 +29,5 @@ for C in ['FETCH_SIZE', 'WRITE_SIZE']:
             print('%-48s grid %-9s %-11s n=%d avg=%.1f KB' % (name, grid, C, len(v), sum(v) / len(v)))
 json.dump(res, open('$OUT/pmc_hbm_kernels.json', 'w'), indent=1)
 PY
-import csv, glob, collections, json
-want = ('roi_align_nhwc_kernel', 'gs_merge_rowwave_kernel', 'iou_gtmax_kernel', 'iou_assign_kernel')
-res = collections.defaultdict(dict)
-for C in ['FETCH_SIZE', 'WRITE_SIZE']:
-    for f in glob.glob('$OUT/%s/**/*counter_collection.csv' % C, recursive=True):
-        agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            name = r.get('Kernel_Name', '')
-            if any(w in name for w in want) and r.get('Counter_Name') == C:
-                agg[(name.split('(')[0][-60:], r.get('Grid_Size'))].append(float(r.get('Counter_Value', 0)))
-        for (name, grid), v in sorted(agg.items()):
-            v = v[len(v) // 3:]                       # drop the first third (cold caches)
-            res['%s grid=%s' % (name, grid)][C] = dict(n=len(v), avg_kb=sum(v) / len(v))
-            print('%-70s grid %-9s %-11s n=%d avg=%.1f KB' % (name, grid, C, len(v), sum(v) / len(v)))
-json.dump(res, open('$OUT/pmc_hbm_kernels.json', 'w'), indent=1)
-PY
 find $OUT -name "*.csv" -size +8M -delete
 du -sh $OUT
