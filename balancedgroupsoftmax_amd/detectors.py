@@ -220,9 +220,17 @@ class TwoStageDetector(nn.Module):
             fk.join()
             self._rpn_loss_fork = None
 
+    def trunk_is_frozen(self):
+        """True when no parameter of the backbone / neck trains (the shipped ``selectp = 1`` / ``3``): their features
+        are a pure function of the image, so a training loop may compute the NEXT batch's features while this batch's
+        heads, losses, backward and optimizer step run (``train.TrunkPipeline``)."""
+        mods = [self.backbone] + ([self.neck] if self.with_neck else [])
+        return not any(p.requires_grad for m in mods for p in m.parameters())
+
     def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
-                      gt_masks=None, proposals=None, samplers=None):
-        x = self.extract_feat(img)
+                      gt_masks=None, proposals=None, samplers=None, feats=None):
+        # ``feats``: the output of ``extract_feat(img)`` computed ahead of this call (train.TrunkPipeline)
+        x = self.extract_feat(img) if feats is None else feats
         losses = dict()
         proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, samplers, losses,
                                                 fork_loss=True)      # (joined below)
@@ -443,10 +451,10 @@ class CascadeRCNN(TwoStageDetector):
             return ProposalList(boxes.view(n_img, num, 4), keep)
 
     def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
-                      gt_masks=None, proposals=None, samplers=None):
+                      gt_masks=None, proposals=None, samplers=None, feats=None):
         if not img.is_cuda:
             raise NotImplementedError('CascadeRCNN.forward_train runs on the GPU path only')
-        x = self.extract_feat(img)
+        x = self.extract_feat(img) if feats is None else feats
         losses = dict()
         proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, samplers, losses, fork_loss=True)
         for i in range(self.num_stages):
@@ -583,12 +591,12 @@ class HybridTaskCascade(CascadeRCNN):
         return head.loss_from_features(feats, mask_targets, pos_labels, valid)
 
     def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
-                      gt_masks=None, gt_semantic_seg=None, proposals=None, samplers=None):
+                      gt_masks=None, gt_semantic_seg=None, proposals=None, samplers=None, feats=None):
         if not img.is_cuda:
             raise NotImplementedError('HybridTaskCascade.forward_train runs on the GPU path only')
         if gt_masks is None:
             raise ValueError('HTC needs gt_masks (per image a uint8 [G, H, W] tensor)')
-        x = self.extract_feat(img)
+        x = self.extract_feat(img) if feats is None else feats
         losses = dict()
         proposal_list = self._rpn_forward_train(x, img_meta, gt_bboxes, proposals, samplers, losses, fork_loss=True)
         semantic_feat = None

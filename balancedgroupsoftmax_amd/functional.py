@@ -47,6 +47,9 @@ def shortcut_fork_enabled():
     return level_fork_enabled() and os.environ.get('BGS_SHORTCUT_FORK', '1') != '0'
 
 
+_PIPELINE_ACTIVE = [0]      # number of train.TrunkPipeline objects with features in flight
+
+
 def rpn_loss_fork_enabled():
     """The RPN loss chain (~12 short dependent launches) on the side stream (detectors._rpn_forward_train).  Default
     ``BGS_RPN_LOSS_FORK=auto``: when launching eagerly (two real streams: 6.45 -> 6.30 ms per step), not while a
@@ -54,7 +57,9 @@ def rpn_loss_fork_enabled():
     6.44 -> 6.49 ms); ``1`` / ``0`` force it."""
     v = os.environ.get('BGS_RPN_LOSS_FORK', 'auto')
     if v == 'auto':
-        return level_fork_enabled() and not torch.cuda.is_current_stream_capturing()
+        # (not beside train.TrunkPipeline either: with the next batch's trunk already running next to the head stage, a
+        #  third concurrent chain of tiny launches costs more than it hides — 6.05 vs 5.75 ms per step, profiles/r9h)
+        return level_fork_enabled() and not _PIPELINE_ACTIVE[0] and not torch.cuda.is_current_stream_capturing()
     return level_fork_enabled() and v != '0'
 
 
@@ -78,7 +83,11 @@ class forked(object):
         # lane 0: short forks that are joined before the next one opens; lanes 1, 2: long-lived branches (the RPN loss
         # chain, the mask branch) that stay open across other forks — each lane is its own stream, so a short fork
         # never queues behind a long one
-        key = (device.index if device.index is not None else torch.cuda.current_device(), int(lane))
+        # (one set of lanes PER PARENT stream: the trunk stage of train.TrunkPipeline forks its small pyramid levels from
+        #  its own stream while the head stage forks from the main one — sharing a lane would queue the two stages'
+        #  unrelated forks behind each other)
+        key = (device.index if device.index is not None else torch.cuda.current_device(), int(lane),
+               torch.cuda.current_stream(device).cuda_stream)
         if key not in _SIDE:
             _SIDE[key] = torch.cuda.Stream(device=device)
         self.side = _SIDE[key]

@@ -457,6 +457,56 @@ class DistOptimizerStep(object):
         self.exchange_and_update()
 
 
+class TrunkPipeline(object):
+    """Two-stage software pipeline of a training loop whose trunk is FROZEN (the shipped ``selectp = 1`` / ``3``,
+    tools/train.py:49-57: only ``fc_cls`` trains).  ``extract_feat`` of batch i + 1 (backbone + FPN: ~100 large
+    launches that fill the chip) is launched on its own HIP stream while batch i's RPN losses, proposal / NMS / target
+    chain (~0.4 ms of single-workgroup launches during which the chip idles), RoI heads, GroupSoftmax loss, backward,
+    gradient exchange and optimizer step run on the main stream.  The features do not depend on anything the optimizer
+    updates, so every step computes exactly what the sequential loop computes — same losses, same weights, bit for
+    bit (tests/test_gpu_detector.py) — and each loop iteration still holds one trunk pass and one head pass.
+
+        pipe = TrunkPipeline(model)
+        pipe.prefetch(first_batch_img)
+        for batch in loader:                       # `next_img`: the following batch's images (a prefetching loader)
+            feats = pipe.take()
+            pipe.prefetch(next_img)
+            losses = model(batch.img, batch.meta, return_loss=True, ..., feats=feats)
+            ...backward, DistOptimizerStep...
+
+    Raises if the trunk trains (``selectp = 0``): its features then depend on the previous step's update."""
+
+    def __init__(self, model, lane=3):
+        if not model.trunk_is_frozen():
+            raise ValueError('TrunkPipeline needs a frozen backbone / neck (selectp = 1 or 3); with a trainable trunk '
+                             'the next batch\'s features depend on this step\'s update')
+        self.model = model
+        self.lane = lane
+        self._fk = None
+        self._feats = None
+
+    def prefetch(self, img):
+        """Launch ``extract_feat(img)`` on the pipeline's stream, ordered after everything enqueued on the current
+        stream so far (the previous step's consumers of the previous features included)."""
+        from . import functional as BF
+        assert self._fk is None, 'take() the previous features first'
+        with torch.no_grad():
+            with BF.forked(img.device, lane=self.lane) as fk:
+                feats = self.model.extract_feat(img)
+        fk.hold(img)                      # (read by the side stream: keep it alive until the join)
+        self._fk, self._feats = fk, feats
+        BF._PIPELINE_ACTIVE[0] += 1       # (functional.rpn_loss_fork_enabled: no third concurrent chain beside the two stages)
+
+    def take(self):
+        """The prefetched features, with the current stream ordered after their producers."""
+        assert self._fk is not None, 'prefetch() first'
+        from . import functional as BF
+        self._fk.join()
+        feats, self._fk, self._feats = self._feats, None, None
+        BF._PIPELINE_ACTIVE[0] = max(0, BF._PIPELINE_ACTIVE[0] - 1)
+        return feats
+
+
 def backward_unit(loss):
     """``loss.backward()`` with the library's cached unit gradient as the root gradient (same values; saves
     autograd's ones_like fill, and the loss edges of this package pass it down by identity — see

@@ -327,10 +327,13 @@ class DetectorStep(object):
             self.extra['gt_semantic_seg'] = seg.to(dev)
         self.last = None
 
-    def compute(self):
+    def compute(self, feats=None):
         """forward + losses + backward: free of host synchronisation -> hipGraph-capturable."""
+        kw = dict(self.extra)
+        if feats is not None:
+            kw['feats'] = feats
         losses = self.model(self.img, self.metas, return_loss=True, gt_bboxes=self.gt_bboxes,
-                            gt_labels=self.gt_labels, gt_masks=self.gt_masks, **self.extra)
+                            gt_labels=self.gt_labels, gt_masks=self.gt_masks, **kw)
         loss, log_vars = self.train.parse_losses(losses)
         # grads set to None: backward then STORES each gradient (AccumulateGrad takes the tensor)
         # instead of a zero fill + an add per parameter — 2 x 160 launches of the selectp=0 step.
@@ -351,6 +354,29 @@ class DetectorStep(object):
     def __call__(self):
         self.compute()
         self.apply()
+
+    # -- two-stage software pipeline (train.TrunkPipeline): frozen trunk only ---------------------------------------
+    def can_pipeline(self):
+        return self.selectp in (1, 3) and self.model.trunk_is_frozen()
+
+    def pipelined(self):
+        """-> a step function in which the trunk (backbone + FPN) of the NEXT batch is launched on its own stream
+        before this batch's heads / losses / backward / exchange / optimizer step: every call still issues one trunk
+        pass and one head pass; the first call consumes the features that ``start_pipeline`` launched."""
+        pipe = self.train.TrunkPipeline(self.model)
+        pipe.prefetch(self.img)
+
+        def step():
+            feats = pipe.take()
+            pipe.prefetch(self.img)            # (the synthetic loader hands out the same batch: the work is the next batch's)
+            self.compute(feats)
+            self.apply()
+
+        def drain():
+            pipe.take()
+
+        step.drain = drain
+        return step
 
 
 CONV_MATH_NOTE = {
@@ -1223,15 +1249,25 @@ def calibrate_dist_forks(step, world):
     """N > 1, `--launch auto`: the side-stream forks (functional.forked) are worth 0.1 - 0.3 ms per step when a rank
     has its GPU and a host core to itself, but they are also what made two processes on ONE device thrash (15 ->
     185 ms per step, profiles/r8q_dist2_onegpu_forks.json) — and eight Python processes launching eagerly on one
-    host is a regime nobody has timed.  So both arms are calibrated UNTIMED here (8 steps each, eager launches, the
+    host is a regime nobody has timed.  So the arms are calibrated UNTIMED here (8 steps each, eager launches, the
     gradient exchange included; max over ranks decides, so every rank takes the same arm) and the K timed steps run
-    under the faster one.  The fork switches are read at every call (DESIGN 5, A/B switches)."""
+    under the fastest one: forks on, forks off, and (round 5, frozen trunk only) the two-stage pipeline of
+    train.TrunkPipeline with the forks on.  The fork switches are read at every call (DESIGN 5, A/B switches).
+    Returns (record for the line, step function to time)."""
     import torch.distributed as dist
     arms = {}
     per_rank = {}
-    for name, val in (('forks_on', '1'), ('forks_off', '0')):
+    fns = {}
+    names = [('forks_on', '1', False), ('forks_off', '0', False)]
+    if step.can_pipeline() and not os.environ.get('BGS_BENCH_NO_PIPELINE'):
+        names.append(('pipelined', '1', True))
+    for name, val, pipe in names:
         os.environ['BGS_LEVEL_FORK'] = val
-        dt = timed_loop(step, 8, 4 if name == 'forks_on' else 2, world)
+        fn = step.pipelined() if pipe else step
+        dt = timed_loop(fn, 8, 4 if name == 'forks_on' else 2, world)
+        if pipe:
+            fn.drain()
+            torch.cuda.synchronize()
         arms[name] = round(dt * 1e3 / 8, 3)
         mine = torch.tensor([timed_loop.last_local_dt * 1e3 / 8], dtype=torch.float64,
                             device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
@@ -1239,14 +1275,18 @@ def calibrate_dist_forks(step, world):
         dist.all_gather(allr, mine)
         per_rank[name] = [round(float(t.item()), 3) for t in allr]
     chosen = 'forks_on' if arms['forks_on'] <= 1.01 * arms['forks_off'] else 'forks_off'
-    os.environ['BGS_LEVEL_FORK'] = '1' if chosen == 'forks_on' else '0'
-    return dict(eager_forks_on_ms=arms['forks_on'], eager_forks_off_ms=arms['forks_off'], chosen=chosen,
-                ms_by_rank=per_rank,
-                note='untimed calibration on all ranks (8 eager steps per arm incl. the gradient exchange, max over '
-                     'ranks); the K timed steps ran under `chosen`; the whole-step-graph arm is `dist_graph_policy`')
+    if 'pipelined' in arms and arms['pipelined'] < 0.99 * arms[chosen]:
+        chosen = 'pipelined'
+    os.environ['BGS_LEVEL_FORK'] = '0' if chosen == 'forks_off' else '1'
+    rec = dict(chosen=chosen, ms_by_rank=per_rank,
+               note='untimed calibration on all ranks (8 eager steps per arm incl. the gradient exchange, max over '
+                    'ranks); the K timed steps ran under `chosen`; the whole-step-graph arm is `dist_graph_policy`')
+    for name in arms:
+        rec['eager_%s_ms' % name] = arms[name]
+    return rec, (step.pipelined() if chosen == 'pipelined' else step), chosen == 'pipelined'
 
 
-def n1_reference(args, rank, world, dev, ms_per_step_n):
+def n1_reference(args, rank, world, dev, ms_per_step_n, pipelined=False):
     """N > 1: the same step on ONE rank of the same node in the same invocation (rank 0 alone, eager launches, the
     other ranks waiting at a barrier) so that the line carries the weak-scaling efficiency against a number taken
     on this very box — the driver computes its own from separate runs; this one removes box-to-box spread."""
@@ -1255,11 +1295,16 @@ def n1_reference(args, rank, world, dev, ms_per_step_n):
         try:
             one = DetectorStep(dev, 0, 1, args.imgs, args.selectp, args.mask, args.cascade, args.htc,
                                conv_math=args.conv_math)
-            dt = timed_loop(one, args.steps, max(args.warmup, 4), 1)
+            fn1 = one.pipelined() if (pipelined and one.can_pipeline()) else one      # (the policy the N ranks were timed under)
+            dt = timed_loop(fn1, args.steps, max(args.warmup, 4), 1)
+            if fn1 is not one:
+                fn1.drain()
+                torch.cuda.synchronize()
             ms1 = dt * 1e3 / args.steps
             out = dict(n1_same_invocation=dict(ms_per_step=round(ms1, 3),
                                                img_per_s=round(args.imgs * args.steps / dt, 3),
-                                               launch='eager launches, rank 0 alone, other ranks idle'),
+                                               launch='eager launches%s, rank 0 alone, other ranks idle'
+                                                      % (' (two-stage pipeline)' if fn1 is not one else '')),
                        weak_scaling_eff=round(ms1 / ms_per_step_n, 4))
             del one
         except Exception as e:  # pragma: no cover
@@ -1312,12 +1357,20 @@ def main_detector(args, rank, local, world, dev):
     can_graph = not args.no_graph and ((world == 1 and not self_group) or
                                        (args.dist_graph and (rccl or self_group)))
     auto = can_graph and world == 1 and not self_group and args.launch == 'auto'
+    pipe_fn = None
     if auto:
         calib = dict(eager_ms=round(timed_loop(step, 8, 6, 1) * 1e3 / 8, 3))      # (6 warm-up steps: lazy folds / splits / caches)
-    dist_calib = None
+        if step.can_pipeline() and not os.environ.get('BGS_BENCH_NO_PIPELINE'):
+            # third policy (round 5): eager launches with the NEXT batch's frozen trunk on its own stream beside this
+            # batch's heads / losses / backward / optimizer step (train.TrunkPipeline: bit-identical training)
+            pipe_fn = step.pipelined()
+            calib['eager_pipelined_ms'] = round(timed_loop(pipe_fn, 8, 3, 1) * 1e3 / 8, 3)
+            pipe_fn.drain()
+            torch.cuda.synchronize()
+    dist_calib, dist_fn, dist_pipelined = None, None, False
     if world > 1 and not args.child and args.launch == 'auto' and not args.dist_graph \
             and not os.environ.get('BGS_BENCH_NO_DIST_CALIB'):
-        dist_calib = calibrate_dist_forks(step, world)
+        dist_calib, dist_fn, dist_pipelined = calibrate_dist_forks(step, world)
     if can_graph and args.launch != 'eager':
         # --dist-graph: the RCCL all-reduce is captured with the rest of the step (the communicator
         # is set up by the eager warm-up iterations inside try_graph)
@@ -1328,7 +1381,19 @@ def main_detector(args, rank, local, world, dev):
         if calib['eager_ms'] < 0.99 * calib['graph_ms']:
             fn = step
         calib['chosen'] = 'eager' if fn is step else 'graph'
+    pipelined = False
+    if dist_fn is not None and graph is None:
+        fn, pipelined = dist_fn, dist_pipelined
+    if auto and pipe_fn is not None:
+        best = min(calib['eager_ms'], calib.get('graph_ms', 1e9))
+        if calib['eager_pipelined_ms'] < 0.99 * best:
+            fn = step.pipelined()              # (a fresh pipeline: its first features are launched here, untimed)
+            pipelined = True
+            calib['chosen'] = 'eager_pipelined'
     dt = timed_loop(fn, args.steps, args.warmup, world)
+    if pipelined:
+        fn.drain()                             # (the features launched by the last timed call: consumed by nobody)
+        torch.cuda.synchronize()
     ms_per_step = dt * 1e3 / args.steps
     imgs_per_s = args.imgs * world * args.steps / dt
     rank_ms = None
@@ -1341,12 +1406,14 @@ def main_detector(args, rank, local, world, dev):
         rank_ms = [round(float(t.item()), 3) for t in allr]
     n1 = None
     if world > 1 and not args.child and not os.environ.get('BGS_BENCH_NO_N1_REFERENCE'):
-        n1 = n1_reference(args, rank, world, dev, ms_per_step)
+        n1 = n1_reference(args, rank, world, dev, ms_per_step, pipelined)
     ms_eager = None
     ms_graph = None
-    if graph is not None and fn is step:      # eager was the timed policy: the graph figure from the calibration
+    if graph is not None and (fn is step or pipelined):      # eager was the timed policy: the graph figure from the calibration
         ms_graph = calib['graph_ms']
         graph = None                           # (the line's `launch` describes what was timed)
+    if pipelined:
+        ms_eager = calib['eager_ms']
     elif graph is not None:     # every rank: the same step launched eagerly, for the graph-vs-eager figure
         ms_eager = round(timed_loop(step, 5, 2, world) * 1e3 / 5, 3)
     cfg_name = 'gs_faster_rcnn_r50_fpn_1x_lvis_with0_bg8 (cfg[1])'
@@ -1390,7 +1457,11 @@ def main_detector(args, rank, local, world, dev):
                        'imgs_per_gpu': args.imgs, 'rois_per_img': 512,
                        'launch': ('hipGraph replay of the whole step (forward+losses+backward+'
                                   + ('RCCL all-reduce+' if (world > 1 or self_group) else '') +
-                                  'clip+SGD)') if graph else 'eager launches',
+                                  'clip+SGD)') if graph else
+                       ('eager launches, two-stage software pipeline (train.TrunkPipeline): the frozen trunk '
+                        '(backbone + FPN) of batch i+1 on its own stream beside batch i\'s RPN / proposal chain / RoI '
+                        'heads / losses / backward / optimizer step; one trunk pass + one head pass per timed step, '
+                        'bit-identical training (tests/test_gpu_e2e.py)' if pipelined else 'eager launches'),
                        'parallelism': 'dp%d (one process per GPU; flat fp32 all-reduce of the '
                                       '%d trainable grads over RCCL)'
                                       % (world, sum(p.numel() for p in step.params)),

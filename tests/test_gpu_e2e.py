@@ -286,6 +286,78 @@ def test_side_stream_forks_do_not_change_the_iteration(monkeypatch):
                 assert torch.equal(got[k], ref[k]), (name, rep, k)
 
 
+def test_trunk_pipeline_reproduces_the_sequential_training_loop():
+    """``train.TrunkPipeline`` (round 5): with a frozen trunk (the shipped selectp = 1) the features of batch i + 1 are
+    computed on their own stream while batch i's heads / losses / backward / optimizer step run.  Four optimizer steps
+    over two alternating batches, sequential vs pipelined from the same initial state and sampler counters: every loss
+    term of every step and the final ``fc_cls`` parameters are BIT-IDENTICAL (a missing join, a reuse race on the
+    feature maps or a trunk that saw an updated parameter would all show); a trainable trunk is refused."""
+    from balancedgroupsoftmax_amd import train, functional as BF
+    from tests.golden import make_golden_train as T
+    tmp = tempfile.mkdtemp(prefix='bgs_e2e_')
+    model_cfg, train_cfg = T.configs(tmp)
+    model = bgs.build_detector(to_config_dict(model_cfg), train_cfg=to_config_dict(train_cfg),
+                               test_cfg=to_config_dict(G.TEST_CFG))
+    with torch.no_grad():
+        det_oracle.fill_detector(model.state_dict(), T.SEED)
+    model.to(DEV)
+    params = train.select_training_param(model, 1)
+    model.train()
+    assert model.trunk_is_frozen()
+    init = [p.detach().clone() for p in params]
+    boxes, labels = T.gt()
+    img_a = torch.from_numpy(G.image()).to(DEV)
+    img_b = torch.flip(img_a, dims=[3]).contiguous() * 0.9 + 0.05
+    gtb, gtl = [torch.from_numpy(boxes).to(DEV)], [torch.from_numpy(labels).to(DEV)]
+    batches = [img_a, img_b, img_a, img_b]
+
+    def run(pipelined):
+        with torch.no_grad():
+            for p, v in zip(params, init):
+                p.copy_(v)
+        for c in BF._KEY_COUNTERS.values():
+            c.zero_()
+        model.bbox_head._draw.zero_()
+        opt = train.build_optimizer(params, dict(type='SGD', lr=0.02, momentum=0.9, weight_decay=1e-4))
+        step = train.DistOptimizerStep(params, opt, dict(max_norm=35, norm_type=2), world_size=1)
+        pipe = train.TrunkPipeline(model) if pipelined else None
+        if pipe:
+            pipe.prefetch(batches[0])
+        out = []
+        for i, img in enumerate(batches):
+            feats = None
+            if pipe:
+                feats = pipe.take()
+                if i + 1 < len(batches):
+                    pipe.prefetch(batches[i + 1])
+            losses = model(img, G.img_meta(), return_loss=True, gt_bboxes=gtb, gt_labels=gtl, feats=feats)
+            loss, _ = train.parse_losses(losses)
+            step(loss)
+            rec = {}
+            for k, v in losses.items():
+                vs = v if isinstance(v, (list, tuple)) else [v]
+                rec[k] = torch.stack([t.detach().float().reshape(-1).sum() for t in vs]).cpu()
+            out.append(rec)
+        torch.cuda.synchronize()
+        return out, [p.detach().clone().cpu() for p in params]
+
+    seq, wseq = run(False)
+    for rep in range(2):
+        pip, wpip = run(True)
+        for i, (a, b) in enumerate(zip(seq, pip)):
+            assert a.keys() == b.keys()
+            for k in a:
+                assert torch.equal(a[k], b[k]), (rep, i, k)
+        for a, b in zip(wseq, wpip):
+            assert torch.equal(a, b)
+    assert not torch.equal(wseq[0], init[0].cpu())                 # the steps did update fc_cls
+    assert not torch.equal(seq[0]['loss_bbox'], seq[1]['loss_bbox'])          # and the two batches differ
+    next(model.backbone.layer4.parameters()).requires_grad = True       # a trunk that trains: refused
+    assert not model.trunk_is_frozen()
+    with pytest.raises(ValueError):
+        train.TrunkPipeline(model)
+
+
 @pytest.mark.parametrize('mode', ['bf16x6', 'bf16x6-nohalo', 'f32', 'f32-nohalo'])
 def test_fullsize_training_iteration_vs_executed_reference(mode, monkeypatch):
     """BASELINE cfg[1] AT ITS REAL SIZE (2 x 3x800x1344, 20 GT/img) against the executed reference

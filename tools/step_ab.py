@@ -20,7 +20,7 @@ arms = []
 for part in spec.split(';'):
     name, _, kv = part.partition(':')
     arms.append((name, [tuple(x.split('=')) for x in kv.split(',') if x]))
-keys = sorted({k for _, kvs in arms for k, _ in kvs} - {'MAIN_PRIO'})
+keys = sorted({k for _, kvs in arms for k, _ in kvs} - {'MAIN_PRIO', 'PIPE'})
 
 
 def apply(kvs):
@@ -42,13 +42,24 @@ hi = torch.cuda.Stream(device=dev, priority=-1)          # MAIN_PRIO=1: the whol
 
 
 def run(kvs, k, w):
-    if dict(kvs).get('MAIN_PRIO') == '1':
+    d = dict(kvs)
+
+    def body():
+        if d.get('PIPE') == '1':            # train.TrunkPipeline: next batch's frozen trunk beside this batch's heads
+            fn = step.pipelined()
+            t = bench.timed_loop(fn, k, w, 1)
+            fn.drain()
+            torch.cuda.synchronize()
+            return t
+        return bench.timed_loop(step, k, w, 1)
+
+    if d.get('MAIN_PRIO') == '1':
         hi.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(hi):
-            t = bench.timed_loop(step, k, w, 1)
+            t = body()
         torch.cuda.current_stream().wait_stream(hi)
         return t
-    return bench.timed_loop(step, k, w, 1)
+    return body()
 
 
 for n, kvs in arms:
