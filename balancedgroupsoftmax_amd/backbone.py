@@ -331,6 +331,28 @@ class ResNet(nn.Module):
 
     def forward(self, img):
         """img ``[N,3,H,W]`` (as the reference) -> tuple of NHWC feature maps."""
+        return self.forward_partial(img, -1, len(self.res_layers) - 1)[1]
+
+    def forward_partial(self, x, first, last, outs=()):
+        """Stages ``first .. last`` of the trunk (``first = -1``: ``x`` is the image batch and the stem runs first;
+        otherwise ``x`` is the activation in front of ``res_layers[first]``) -> ``(activation, outs)`` with the output
+        maps of the stages in ``out_indices`` appended to ``outs``.  ``forward`` = all of it; ``train.TrunkPipeline``
+        runs the pieces of a frozen trunk on different streams for different batches."""
+        outs = list(outs)
+        if first < 0:
+            x = self._forward_stem(x)
+            first = 0
+        for i in range(first, last + 1):
+            for blk in getattr(self, self.res_layers[i]):
+                x = blk.run(x, blk.folded())
+            if i in self.out_indices:
+                # a trainable stage hands on a `relu='consumers'` tensor (its ReLU backward rides in the
+                # next block's dgrad epilogue); what LEAVES the trunk is an ordinary tensor any consumer
+                # may use: relu_gate applies the gate to the gradient coming back (a no-op otherwise)
+                outs.append(BF.relu_gate(x))
+        return x, tuple(outs)
+
+    def _forward_stem(self, img):
         # frozen_stages >= 1 (every BAGS config): a plain forward launch on the cached fold;
         # frozen_stages < 1: the fold is on the tape (resnet.py:483-494), the conv records its
         # weight / bias gradient (the image needs none) and the max-pool its routing
@@ -352,16 +374,7 @@ class ResNet(nn.Module):
             storage = (BF.bf16_storage_active() and not x.requires_grad and
                        not _trainable(*[getattr(self, n) for n in self.res_layers]))
             x = BF.maxpool3x3s2_nhwc(x, out_dtype=torch.bfloat16 if storage else torch.float32)
-        outs = []
-        for i, name in enumerate(self.res_layers):
-            for blk in getattr(self, name):
-                x = blk.run(x, blk.folded())
-            if i in self.out_indices:
-                # a trainable stage hands on a `relu='consumers'` tensor (its ReLU backward rides in the
-                # next block's dgrad epilogue); what LEAVES the trunk is an ordinary tensor any consumer
-                # may use: relu_gate applies the gate to the gradient coming back (a no-op otherwise)
-                outs.append(BF.relu_gate(x))
-        return tuple(outs)
+        return x
 
     def train(self, mode=True):
         super().train(mode)

@@ -34,20 +34,21 @@ def reset_workspaces():
 
 
 _SIDE = {}
+_PIPELINE_ACTIVE = [0]      # 1 while a train.TrunkPipeline has batches in flight
 
 
 def level_fork_enabled():
-    """Small pyramid levels on a side stream (FPN output convs, RPN head): ``BGS_LEVEL_FORK=0`` turns it off."""
-    return os.environ.get('BGS_LEVEL_FORK', '1') != '0'
+    """Small pyramid levels on a side stream (FPN output convs, RPN head): ``BGS_LEVEL_FORK=0`` turns it off.  Off as
+    well while a ``train.TrunkPipeline`` has batches in flight: its pieces already run on three or four streams, and
+    forks inside every one of them oversubscribe the hardware queues (depth 3: 6.17 ms per step with the inner
+    forks, 5.74 without; profiles/r9h)."""
+    return os.environ.get('BGS_LEVEL_FORK', '1') != '0' and not _PIPELINE_ACTIVE[0]
 
 
 def shortcut_fork_enabled():
     """Projection shortcuts of frozen residual blocks on the side stream (backbone.Bottleneck.run):
     ``BGS_SHORTCUT_FORK=0`` turns it off (``BGS_LEVEL_FORK=0`` turns every fork off)."""
     return level_fork_enabled() and os.environ.get('BGS_SHORTCUT_FORK', '1') != '0'
-
-
-_PIPELINE_ACTIVE = [0]      # number of train.TrunkPipeline objects with features in flight
 
 
 def rpn_loss_fork_enabled():
@@ -57,9 +58,7 @@ def rpn_loss_fork_enabled():
     6.44 -> 6.49 ms); ``1`` / ``0`` force it."""
     v = os.environ.get('BGS_RPN_LOSS_FORK', 'auto')
     if v == 'auto':
-        # (not beside train.TrunkPipeline either: with the next batch's trunk already running next to the head stage, a
-        #  third concurrent chain of tiny launches costs more than it hides — 6.05 vs 5.75 ms per step, profiles/r9h)
-        return level_fork_enabled() and not _PIPELINE_ACTIVE[0] and not torch.cuda.is_current_stream_capturing()
+        return level_fork_enabled() and not torch.cuda.is_current_stream_capturing()
     return level_fork_enabled() and v != '0'
 
 

@@ -458,53 +458,133 @@ class DistOptimizerStep(object):
 
 
 class TrunkPipeline(object):
-    """Two-stage software pipeline of a training loop whose trunk is FROZEN (the shipped ``selectp = 1`` / ``3``,
-    tools/train.py:49-57: only ``fc_cls`` trains).  ``extract_feat`` of batch i + 1 (backbone + FPN: ~100 large
-    launches that fill the chip) is launched on its own HIP stream while batch i's RPN losses, proposal / NMS / target
-    chain (~0.4 ms of single-workgroup launches during which the chip idles), RoI heads, GroupSoftmax loss, backward,
-    gradient exchange and optimizer step run on the main stream.  The features do not depend on anything the optimizer
-    updates, so every step computes exactly what the sequential loop computes — same losses, same weights, bit for
-    bit (tests/test_gpu_detector.py) — and each loop iteration still holds one trunk pass and one head pass.
+    """Software pipeline of a training loop whose trunk is FROZEN (the shipped ``selectp = 1`` / ``3``,
+    tools/train.py:49-57: only ``fc_cls`` trains).  The trunk of the batches AHEAD — in ``depth`` - 1 pieces, each on
+    its own HIP stream — runs while the current batch's RPN losses, proposal / NMS / target chain (~0.4 ms of
+    single-workgroup launches during which the chip idles), RoI heads, GroupSoftmax loss, backward, gradient exchange
+    and optimizer step run on the main stream:
 
-        pipe = TrunkPipeline(model)
-        pipe.prefetch(first_batch_img)
-        for batch in loader:                       # `next_img`: the following batch's images (a prefetching loader)
+        depth 2:  extract_feat(i + 1)                                          | heads(i)
+        depth 3:  backbone(i + 2)            | neck(i + 1)                     | heads(i)
+        depth 4:  stem .. layer2 (i + 3)     | layer3 .. layer4 (i + 2) | neck(i + 1) | heads(i)
+        depth 5 / 6: the residual stages in three / four groups
+
+    (the small-grid launches of the deep stages — 168 / 96 workgroups on 256 CUs — and the latency-bound head chain
+    fill each other's idle CUs: 6.22 ms sequential -> 6.06 / 5.78 / .. ms per step, profiles/r9h).  The features do not
+    depend on anything the optimizer updates, so every step computes exactly what the sequential loop computes — same
+    losses, same weights, bit for bit (tests/test_gpu_e2e.py) — and every loop iteration still holds one pass of every
+    piece of the trunk and one head pass.
+
+        pipe = TrunkPipeline(model, depth=3)
+        for img in first `pipe.depth - 1` batches: pipe.push(img)        # prologue
+        for i, batch in enumerate(loader):          # a loader that hands out images depth - 1 batches ahead
             feats = pipe.take()
-            pipe.prefetch(next_img)
+            pipe.push(images_of_batch[i + pipe.depth - 1])
             losses = model(batch.img, batch.meta, return_loss=True, ..., feats=feats)
             ...backward, DistOptimizerStep...
 
     Raises if the trunk trains (``selectp = 0``): its features then depend on the previous step's update."""
 
-    def __init__(self, model, lane=3):
+    def __init__(self, model, depth=2, lane=3):
         if not model.trunk_is_frozen():
             raise ValueError('TrunkPipeline needs a frozen backbone / neck (selectp = 1 or 3); with a trainable trunk '
                              'the next batch\'s features depend on this step\'s update')
-        self.model = model
-        self.lane = lane
-        self._fk = None
-        self._feats = None
+        bb = model.backbone
+        nst = len(getattr(bb, 'res_layers', ()))
+        split = model.with_neck and hasattr(bb, 'forward_partial') and nst >= 2
+        if depth >= 3 and not split:
+            depth = 2
+        depth = max(2, min(int(depth), nst + 2 if split else 2))
+        if depth == 2:
+            self.stages = [model.extract_feat]
+        elif depth == 3:
+            self.stages = [bb, model.neck]
+        else:
+            # depth - 2 contiguous groups of residual stages (4: stem .. layer2 | layer3 .. layer4; 6: one stage each)
+            k = depth - 2
+            cuts = [(nst * g + k - 1) // k for g in range(k + 1)]          # 0 = cuts[0] < ... < cuts[k] = nst
+            self.stages = []
+            for g in range(k):
+                first, last = cuts[g], cuts[g + 1] - 1
 
-    def prefetch(self, img):
-        """Launch ``extract_feat(img)`` on the pipeline's stream, ordered after everything enqueued on the current
-        stream so far (the previous step's consumers of the previous features included)."""
+                def piece(st, first=first, last=last, final=(g == k - 1)):
+                    if first == 0:
+                        r = bb.forward_partial(st, -1, last)
+                    else:
+                        r = bb.forward_partial(st[0], first, last, st[1])
+                    return r[1] if final else r
+                self.stages.append(piece)
+            self.stages.append(model.neck)
+        self.model = model
+        self.depth = depth
+        self.lane = lane
+        self._slots = [None] * len(self.stages)                 # slot j: (fork, output) of stage j for some batch
+
+    @staticmethod
+    def _record(obj, stream):
+        """``record_stream`` on every tensor of a nest: the caching allocator then hands a block back to its own
+        stream's pool only after the work ``stream`` has queued at the time of the free.  (A piece's input lives in
+        the PREVIOUS piece's pool and is read on this piece's stream; holding a reference until some later join is
+        not enough here, because the stream that reuses the block never waits for this one.)"""
+        if torch.is_tensor(obj):
+            if obj.is_cuda:
+                obj.record_stream(stream)
+        elif isinstance(obj, (tuple, list)):
+            for o in obj:
+                TrunkPipeline._record(o, stream)
+
+    def _launch(self, j, inp, producer):
         from . import functional as BF
-        assert self._fk is None, 'take() the previous features first'
         with torch.no_grad():
-            with BF.forked(img.device, lane=self.lane) as fk:
-                feats = self.model.extract_feat(img)
-        fk.hold(img)                      # (read by the side stream: keep it alive until the join)
-        self._fk, self._feats = fk, feats
-        BF._PIPELINE_ACTIVE[0] += 1       # (functional.rpn_loss_fork_enabled: no third concurrent chain beside the two stages)
+            with BF.forked(self._device, lane=self.lane + j) as fk:
+                if producer is not None:
+                    producer.join()                             # (inside the block: THIS stage's stream waits for it)
+                self._record(inp, fk.side)
+                out = self.stages[j](inp)
+        return fk, out
+
+    def push(self, img):
+        """Feed the next batch's images: every piece of the trunk advances by one batch (launched deepest first, each
+        on its own stream, ordered after everything enqueued on the current stream so far).  ``img = None`` (the
+        loader has run dry): the batches in flight advance, nothing new enters."""
+        from . import functional as BF
+        if img is not None:
+            self._device = img.device
+        BF._PIPELINE_ACTIVE[0] = 1        # (functional.level_fork_enabled: no forks inside the pieces or beside the heads)
+        n = len(self.stages)
+        assert self._slots[n - 1] is None, 'take() the finished features first'
+        for j in range(n - 1, 0, -1):
+            if self._slots[j - 1] is not None:
+                fk, out = self._slots[j - 1]
+                self._slots[j] = self._launch(j, out, fk)
+                self._slots[j - 1] = None
+        if img is not None:
+            self._slots[0] = self._launch(0, img, None)
+
+    def prefetch(self, img):              # depth 2: push == prefetch
+        self.push(img)
 
     def take(self):
-        """The prefetched features, with the current stream ordered after their producers."""
-        assert self._fk is not None, 'prefetch() first'
+        """The features of the oldest batch in flight, with the current stream ordered after their producers."""
         from . import functional as BF
-        self._fk.join()
-        feats, self._fk, self._feats = self._feats, None, None
-        BF._PIPELINE_ACTIVE[0] = max(0, BF._PIPELINE_ACTIVE[0] - 1)
+        n = len(self.stages)
+        assert self._slots[n - 1] is not None, 'push() %d batches first' % n
+        fk, feats = self._slots[n - 1]
+        fk.join()
+        self._record(feats, torch.cuda.current_stream(self._device))     # (allocated on the last piece's stream, read here)
+        self._slots[n - 1] = None
+        if all(s is None for s in self._slots):
+            BF._PIPELINE_ACTIVE[0] = 0
         return feats
+
+    def drain(self):
+        """Join and drop whatever is in flight (end of the loop)."""
+        from . import functional as BF
+        for j, s in enumerate(self._slots):
+            if s is not None:
+                s[0].join()
+                self._slots[j] = None
+        BF._PIPELINE_ACTIVE[0] = 0
 
 
 def backward_unit(loss):

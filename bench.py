@@ -359,23 +359,25 @@ class DetectorStep(object):
     def can_pipeline(self):
         return self.selectp in (1, 3) and self.model.trunk_is_frozen()
 
-    def pipelined(self):
-        """-> a step function in which the trunk (backbone + FPN) of the NEXT batch is launched on its own stream
-        before this batch's heads / losses / backward / exchange / optimizer step: every call still issues one trunk
-        pass and one head pass; the first call consumes the features that ``start_pipeline`` launched."""
-        pipe = self.train.TrunkPipeline(self.model)
-        pipe.prefetch(self.img)
+    def pipelined(self, depth=None):
+        """-> a step function in which the frozen trunk of the batches AHEAD is launched — in ``depth - 1`` pieces, each
+        on its own stream (train.TrunkPipeline) — before this batch's heads / losses / backward / exchange / optimizer
+        step: every call still issues one pass of every piece of the trunk and one head pass; the first calls consume
+        the features launched here (untimed prologue)."""
+        if depth is None:
+            depth = int(os.environ.get('BGS_BENCH_PIPELINE_DEPTH', '4'))
+        pipe = self.train.TrunkPipeline(self.model, depth=depth)
+        for _ in range(pipe.depth - 1):
+            pipe.push(self.img)
 
         def step():
             feats = pipe.take()
-            pipe.prefetch(self.img)            # (the synthetic loader hands out the same batch: the work is the next batch's)
+            pipe.push(self.img)                # (the synthetic loader hands out the same batch: the work is a later batch's)
             self.compute(feats)
             self.apply()
 
-        def drain():
-            pipe.take()
-
-        step.drain = drain
+        step.drain = pipe.drain
+        step.depth = pipe.depth
         return step
 
 
@@ -1263,7 +1265,7 @@ def calibrate_dist_forks(step, world):
         names.append(('pipelined', '1', True))
     for name, val, pipe in names:
         os.environ['BGS_LEVEL_FORK'] = val
-        fn = step.pipelined() if pipe else step
+        fn = step.pipelined(depth=4) if pipe else step
         dt = timed_loop(fn, 8, 4 if name == 'forks_on' else 2, world)
         if pipe:
             fn.drain()
@@ -1283,7 +1285,7 @@ def calibrate_dist_forks(step, world):
                     'ranks); the K timed steps ran under `chosen`; the whole-step-graph arm is `dist_graph_policy`')
     for name in arms:
         rec['eager_%s_ms' % name] = arms[name]
-    return rec, (step.pipelined() if chosen == 'pipelined' else step), chosen == 'pipelined'
+    return rec, (step.pipelined(depth=4) if chosen == 'pipelined' else step), chosen == 'pipelined'
 
 
 def n1_reference(args, rank, world, dev, ms_per_step_n, pipelined=False):
@@ -1295,7 +1297,7 @@ def n1_reference(args, rank, world, dev, ms_per_step_n, pipelined=False):
         try:
             one = DetectorStep(dev, 0, 1, args.imgs, args.selectp, args.mask, args.cascade, args.htc,
                                conv_math=args.conv_math)
-            fn1 = one.pipelined() if (pipelined and one.can_pipeline()) else one      # (the policy the N ranks were timed under)
+            fn1 = one.pipelined(depth=4) if (pipelined and one.can_pipeline()) else one      # (the policy the N ranks were timed under)
             dt = timed_loop(fn1, args.steps, max(args.warmup, 4), 1)
             if fn1 is not one:
                 fn1.drain()
@@ -1363,10 +1365,18 @@ def main_detector(args, rank, local, world, dev):
         if step.can_pipeline() and not os.environ.get('BGS_BENCH_NO_PIPELINE'):
             # third policy (round 5): eager launches with the NEXT batch's frozen trunk on its own stream beside this
             # batch's heads / losses / backward / optimizer step (train.TrunkPipeline: bit-identical training)
-            pipe_fn = step.pipelined()
-            calib['eager_pipelined_ms'] = round(timed_loop(pipe_fn, 8, 3, 1) * 1e3 / 8, 3)
-            pipe_fn.drain()
-            torch.cuda.synchronize()
+            depths = [int(os.environ['BGS_BENCH_PIPELINE_DEPTH'])] if os.environ.get('BGS_BENCH_PIPELINE_DEPTH') \
+                else [3, 4, 5]
+            best_depth = None
+            for dpt in depths:
+                pipe_fn = step.pipelined(depth=dpt)
+                ms = round(timed_loop(pipe_fn, 8, 3, 1) * 1e3 / 8, 3)
+                pipe_fn.drain()
+                torch.cuda.synchronize()
+                calib['eager_pipelined_depth%d_ms' % dpt] = ms
+                if best_depth is None or ms < calib['eager_pipelined_ms']:
+                    best_depth, calib['eager_pipelined_ms'] = dpt, ms
+            calib['pipeline_depth'] = best_depth
     dist_calib, dist_fn, dist_pipelined = None, None, False
     if world > 1 and not args.child and args.launch == 'auto' and not args.dist_graph \
             and not os.environ.get('BGS_BENCH_NO_DIST_CALIB'):
@@ -1387,7 +1397,7 @@ def main_detector(args, rank, local, world, dev):
     if auto and pipe_fn is not None:
         best = min(calib['eager_ms'], calib.get('graph_ms', 1e9))
         if calib['eager_pipelined_ms'] < 0.99 * best:
-            fn = step.pipelined()              # (a fresh pipeline: its first features are launched here, untimed)
+            fn = step.pipelined(depth=calib['pipeline_depth'])      # (a fresh pipeline: its first features are launched here, untimed)
             pipelined = True
             calib['chosen'] = 'eager_pipelined'
     dt = timed_loop(fn, args.steps, args.warmup, world)
@@ -1413,7 +1423,7 @@ def main_detector(args, rank, local, world, dev):
         ms_graph = calib['graph_ms']
         graph = None                           # (the line's `launch` describes what was timed)
     if pipelined:
-        ms_eager = calib['eager_ms']
+        ms_eager = (calib or {}).get('eager_ms') or (dist_calib or {}).get('eager_forks_on_ms')
     elif graph is not None:     # every rank: the same step launched eagerly, for the graph-vs-eager figure
         ms_eager = round(timed_loop(step, 5, 2, world) * 1e3 / 5, 3)
     cfg_name = 'gs_faster_rcnn_r50_fpn_1x_lvis_with0_bg8 (cfg[1])'
@@ -1458,10 +1468,11 @@ def main_detector(args, rank, local, world, dev):
                        'launch': ('hipGraph replay of the whole step (forward+losses+backward+'
                                   + ('RCCL all-reduce+' if (world > 1 or self_group) else '') +
                                   'clip+SGD)') if graph else
-                       ('eager launches, two-stage software pipeline (train.TrunkPipeline): the frozen trunk '
-                        '(backbone + FPN) of batch i+1 on its own stream beside batch i\'s RPN / proposal chain / RoI '
-                        'heads / losses / backward / optimizer step; one trunk pass + one head pass per timed step, '
-                        'bit-identical training (tests/test_gpu_e2e.py)' if pipelined else 'eager launches'),
+                       ('eager launches, %d-stage software pipeline (train.TrunkPipeline): the frozen trunk of the '
+                        'batches ahead, in %d piece(s) on their own streams (depth 3: backbone(i+2) | FPN(i+1)), beside '
+                        'batch i\'s RPN / proposal chain / RoI heads / losses / backward / optimizer step; one pass of '
+                        'every piece + one head pass per timed step, bit-identical training (tests/test_gpu_e2e.py)'
+                        % (fn.depth, fn.depth - 1) if pipelined else 'eager launches'),
                        'parallelism': 'dp%d (one process per GPU; flat fp32 all-reduce of the '
                                       '%d trainable grads over RCCL)'
                                       % (world, sum(p.numel() for p in step.params)),

@@ -288,8 +288,9 @@ def test_side_stream_forks_do_not_change_the_iteration(monkeypatch):
 
 def test_trunk_pipeline_reproduces_the_sequential_training_loop():
     """``train.TrunkPipeline`` (round 5): with a frozen trunk (the shipped selectp = 1) the features of batch i + 1 are
-    computed on their own stream while batch i's heads / losses / backward / optimizer step run.  Four optimizer steps
-    over two alternating batches, sequential vs pipelined from the same initial state and sampler counters: every loss
+    computed on their own streams (depth 2: the whole trunk one batch ahead; 3: backbone two ahead | FPN one ahead; 4:
+    the backbone in two pieces) while batch i's heads / losses / backward / optimizer step run.  Six optimizer steps
+    over two different batches, sequential vs pipelined from the same initial state and sampler counters: every loss
     term of every step and the final ``fc_cls`` parameters are BIT-IDENTICAL (a missing join, a reuse race on the
     feature maps or a trunk that saw an updated parameter would all show); a trainable trunk is refused."""
     from balancedgroupsoftmax_amd import train, functional as BF
@@ -309,7 +310,7 @@ def test_trunk_pipeline_reproduces_the_sequential_training_loop():
     img_a = torch.from_numpy(G.image()).to(DEV)
     img_b = torch.flip(img_a, dims=[3]).contiguous() * 0.9 + 0.05
     gtb, gtl = [torch.from_numpy(boxes).to(DEV)], [torch.from_numpy(labels).to(DEV)]
-    batches = [img_a, img_b, img_a, img_b]
+    batches = [img_a, img_b, img_a, img_b, img_b, img_a]
 
     def run(pipelined):
         with torch.no_grad():
@@ -320,16 +321,18 @@ def test_trunk_pipeline_reproduces_the_sequential_training_loop():
         model.bbox_head._draw.zero_()
         opt = train.build_optimizer(params, dict(type='SGD', lr=0.02, momentum=0.9, weight_decay=1e-4))
         step = train.DistOptimizerStep(params, opt, dict(max_norm=35, norm_type=2), world_size=1)
-        pipe = train.TrunkPipeline(model) if pipelined else None
+        pipe = train.TrunkPipeline(model, depth=pipelined) if pipelined else None
         if pipe:
-            pipe.prefetch(batches[0])
+            assert pipe.depth == pipelined
+            for k in range(pipe.depth - 1):
+                pipe.push(batches[k])
         out = []
         for i, img in enumerate(batches):
             feats = None
             if pipe:
                 feats = pipe.take()
-                if i + 1 < len(batches):
-                    pipe.prefetch(batches[i + 1])
+                nxt = i + pipe.depth - 1
+                pipe.push(batches[nxt] if nxt < len(batches) else None)      # (None: the loader has run dry — flush)
             losses = model(img, G.img_meta(), return_loss=True, gt_bboxes=gtb, gt_labels=gtl, feats=feats)
             loss, _ = train.parse_losses(losses)
             step(loss)
@@ -341,9 +344,10 @@ def test_trunk_pipeline_reproduces_the_sequential_training_loop():
         torch.cuda.synchronize()
         return out, [p.detach().clone().cpu() for p in params]
 
-    seq, wseq = run(False)
-    for rep in range(2):
-        pip, wpip = run(True)
+    seq, wseq = run(0)
+    for depth in (2, 3, 4, 3):
+        pip, wpip = run(depth)
+        rep = depth
         for i, (a, b) in enumerate(zip(seq, pip)):
             assert a.keys() == b.keys()
             for k in a:

@@ -45,8 +45,46 @@ def run(kvs, k, w):
     d = dict(kvs)
 
     def body():
-        if d.get('PIPE') == '1':            # train.TrunkPipeline: next batch's frozen trunk beside this batch's heads
-            fn = step.pipelined()
+        if d.get('PIPE') == '2':            # prototype: three stages — backbone(i+2) | neck(i+1) | heads(i)
+            m = step.model
+            st = {}
+
+            def launch_backbone():
+                with torch.no_grad():
+                    with BF.forked(dev, lane=3) as fk:
+                        c = m.backbone(step.img)
+                fk.hold(step.img)
+                return fk, c
+
+            def launch_neck(fkc):
+                fk1, c = fkc
+                with torch.no_grad():
+                    with BF.forked(dev, lane=4) as fk:
+                        fk1.join()                      # (inside the block: lane 4 waits for the backbone's stream)
+                        x = m.neck(c)
+                fk.hold(c)
+                return fk, x
+
+            st['b'] = launch_backbone()
+            st['n'] = launch_neck(st['b'])
+            st['b'] = launch_backbone()
+
+            def fn():
+                fk, x = st['n']
+                fk.join()
+                st['n'] = launch_neck(st['b'])
+                st['b'] = launch_backbone()
+                BF._PIPELINE_ACTIVE[0] = 1
+                step.compute(x)
+                step.apply()
+                BF._PIPELINE_ACTIVE[0] = 0
+
+            t = bench.timed_loop(fn, k, w, 1)
+            st['n'][0].join(); st['b'][0].join()
+            torch.cuda.synchronize()
+            return t
+        if d.get('PIPE') in ('1', '3', '4', '5', '6'):            # train.TrunkPipeline: the frozen trunk of the batches ahead beside this batch's heads
+            fn = step.pipelined(depth={'1': 2, '3': 3, '4': 4, '5': 5, '6': 6}[d['PIPE']])
             t = bench.timed_loop(fn, k, w, 1)
             fn.drain()
             torch.cuda.synchronize()
