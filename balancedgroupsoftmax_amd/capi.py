@@ -118,6 +118,7 @@ SIGNATURES = {
     'bgs_conv3x3_halo_bfx_tuning': (None, [ctypes.c_int] * 2),
     'bgs_conv3x3_halo_bfx_last_launch': (ctypes.c_int, [c_ptr, c_ptr]),
     'bgs_conv3x3_halo_bfx_last_wide': (ctypes.c_int, [c_ptr, c_ptr]),
+    'bgs_conv3x3_halo_bfx_wide': (ctypes.c_int, [ctypes.c_int]),
     'bgs_grouped_conv3x3_nhwc_f32': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 7
                                      + [c_ptr]),
     'bgs_grouped_conv3x3_nhwc_bf16ops': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 7

@@ -2357,6 +2357,15 @@ extern "C" void bgs_conv3x3_halo_bfx_tuning(int splits, int variant) {
   else if (variant0 == 0 && splits < 0) g_halo_wide = -1;      // (the reset call: back to the environment's default)
 }
 
+// mode -1 = back to the environment's default | 0 off | 1 automatic | 2 every eligible layer; returns the previous mode
+// (-1 when it was unset).  What train.TrunkPipeline switches while it has batches in flight: without side-stream forks
+// beside the P2 convs the two-launch schedule of variant 7 is the faster one (5.14 -> 5.10 ms per step, profiles/r9h).
+extern "C" int bgs_conv3x3_halo_bfx_wide(int mode) {
+  const int prev = g_halo_wide;
+  g_halo_wide = (mode >= 0 && mode <= 2) ? mode : -1;
+  return prev;
+}
+
 extern "C" int bgs_conv3x3_halo_bfx_last_wide(int* wide_units, int* tail_units) {
   if (wide_units) *wide_units = g_halo_last_wide_units;      // 256-pixel x 128-channel units of the variant-7 launch (0: it did not run)
   if (tail_units) *tail_units = g_halo_last_tail_units;      // 128-pixel units of the variant-4 launch behind it

@@ -763,6 +763,12 @@ def conv_bfx_tuning(tile=0, splitk=-1, halo_splits=-1, halo_variant=0, halo_geom
                                     (int(halo_flags) << 20) | ((int(halo_wide) + 1) << 24))
 
 
+def set_halo_wide(mode):
+    """The wide-pixel-tile mode of the halo 3x3 kernel alone (``bgs_conv3x3_halo_bfx_wide``): -1 environment default |
+    0 off | 1 automatic schedule | 2 every eligible layer; returns the previous mode."""
+    return capi.load().bgs_conv3x3_halo_bfx_wide(int(mode))
+
+
 def conv_bfx_last_launch():
     """-> dict(tile, splits, halo_nb, halo_splits, ...) of the last bf16x6 launches.  ``halo_variant`` 7: the wide
     pixel tile ran (``halo_wide_units`` 256-pixel units) followed by ``halo_tail_units`` 128-pixel units on variant 4."""

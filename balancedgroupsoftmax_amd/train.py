@@ -550,7 +550,13 @@ class TrunkPipeline(object):
         from . import functional as BF
         if img is not None:
             self._device = img.device
-        BF._PIPELINE_ACTIVE[0] = 1        # (functional.level_fork_enabled: no forks inside the pieces or beside the heads)
+        if not BF._PIPELINE_ACTIVE[0]:
+            BF._PIPELINE_ACTIVE[0] = 1    # (functional.level_fork_enabled: no forks inside the pieces or beside the heads)
+            # ... and without forks beside them the P2 halo convs take the whole-rounds schedule of variant 7
+            # (bit-identical), unless the caller has chosen a mode of his own
+            self._wide_prev = BF.set_halo_wide(1)
+            if self._wide_prev >= 0:
+                BF.set_halo_wide(self._wide_prev)
         n = len(self.stages)
         assert self._slots[n - 1] is None, 'take() the finished features first'
         for j in range(n - 1, 0, -1):
@@ -574,8 +580,15 @@ class TrunkPipeline(object):
         self._record(feats, torch.cuda.current_stream(self._device))     # (allocated on the last piece's stream, read here)
         self._slots[n - 1] = None
         if all(s is None for s in self._slots):
-            BF._PIPELINE_ACTIVE[0] = 0
+            self._deactivate()
         return feats
+
+    def _deactivate(self):
+        from . import functional as BF
+        if BF._PIPELINE_ACTIVE[0]:
+            BF._PIPELINE_ACTIVE[0] = 0
+            if getattr(self, '_wide_prev', 0) < 0:
+                BF.set_halo_wide(-1)
 
     def drain(self):
         """Join and drop whatever is in flight (end of the loop)."""
@@ -584,7 +597,7 @@ class TrunkPipeline(object):
             if s is not None:
                 s[0].join()
                 self._slots[j] = None
-        BF._PIPELINE_ACTIVE[0] = 0
+        self._deactivate()
 
 
 def backward_unit(loss):

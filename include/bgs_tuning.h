@@ -97,6 +97,7 @@ int bgs_conv_bfx_last_launch(int* tile, int* splits);
 void bgs_conv3x3_halo_bfx_tuning(int splits, int variant);
 int bgs_conv3x3_halo_bfx_last_launch(int* nb, int* splits);
 int bgs_conv3x3_halo_bfx_last_wide(int* wide_units, int* tail_units);
+int bgs_conv3x3_halo_bfx_wide(int mode);      /* set the wide-pixel-tile mode alone (-1 = environment default); returns the previous one */
 void bgs_conv1x1_bres_enable(int on);
 int bgs_conv1x1_bres_last_launch(void);
 void bgs_conv_dgrad_parity_enable(int on);
