@@ -583,6 +583,12 @@ class TrunkPipeline(object):
             self._deactivate()
         return feats
 
+    def __del__(self):
+        try:                     # (a pipeline dropped with batches in flight must not leave the process-wide switches set)
+            self._deactivate()
+        except Exception:
+            pass
+
     def _deactivate(self):
         from . import functional as BF
         if BF._PIPELINE_ACTIVE[0]:
