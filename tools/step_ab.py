@@ -25,7 +25,13 @@ keys = sorted({k for _, kvs in arms for k, _ in kvs} - {'MAIN_PRIO', 'PIPE'})
 
 def apply(kvs):
     d = dict(kvs)
+    if 'SPLITK' in keys or 'HALO_WIDE' in keys:
+        # SPLITK=1: no K slicing anywhere (conv ring / wide kernels and the halo kernel's channel-chunk split)
+        sk = int(d.get('SPLITK', -1))
+        BF.conv_bfx_tuning(0, sk, halo_splits=(1 if sk == 1 else -1), halo_wide=int(d.get('HALO_WIDE', -1)))
     for k in keys:
+        if k in ('HALO_WIDE', 'SPLITK'):
+            continue
         if k == 'HALO_WIDE':
             BF.conv_bfx_tuning(halo_wide=int(d.get(k, 1)))
         elif k in d:
