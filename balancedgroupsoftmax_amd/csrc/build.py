@@ -25,6 +25,9 @@ VARIANTS = {
 # conv loops with one component removed (tools/ablate.py); never loaded by the product
 EXTRA_VARIANTS = {
     'ablate': dict(name='libbgs_ablate.so', flags=['-DBGS_ABLATE']),
+    # the operand split's residual by shift / mask + subtraction instead of v_dot2c_f32_bf16 (csrc/bfx_split.h): the A/B
+    # arm of tools/split_ab.sh, loaded through BGS_LIB_PATH
+    'splitsub': dict(name='libbgs_splitsub.so', flags=['-DBGS_SPLIT_SUB']),
 }
 
 

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "conv_args.h"
+#include "bfx_split.h"
 
 using namespace bgs_conv;
 
@@ -76,11 +77,11 @@ __device__ __forceinline__ float bf16_hi(unsigned u) {
 // x (4 consecutive k) -> three planes of 4 packed bf16 each
 __device__ __forceinline__ void split3(const f32x4 v, u32x2& hi, u32x2& mid, u32x2& lo) {
   hi = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-  const f32x4 r = {v[0] - bf16_lo(hi[0]), v[1] - bf16_hi(hi[0]), v[2] - bf16_lo(hi[1]),
-                   v[3] - bf16_hi(hi[1])};
+  const f32x4 r = {bfx_resid_lo(hi[0], v[0]), bfx_resid_hi(hi[0], v[1]), bfx_resid_lo(hi[1], v[2]),
+                   bfx_resid_hi(hi[1], v[3])};
   mid = u32x2{pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3])};
-  const f32x4 r2 = {r[0] - bf16_lo(mid[0]), r[1] - bf16_hi(mid[0]), r[2] - bf16_lo(mid[1]),
-                    r[3] - bf16_hi(mid[1])};
+  const f32x4 r2 = {bfx_resid_lo(mid[0], r[0]), bfx_resid_hi(mid[0], r[1]), bfx_resid_lo(mid[1], r[2]),
+                    bfx_resid_hi(mid[1], r[3])};
   lo = u32x2{pack_bf16(r2[0], r2[1]), pack_bf16(r2[2], r2[3])};
 }
 
@@ -766,9 +767,9 @@ __global__ __launch_bounds__(256) void bfx_split_weights_kernel(const float* __r
     const float v0 = k < K ? w[(size_t)row * K + k] : 0.f;
     const float v1 = k + 1 < K ? w[(size_t)row * K + k + 1] : 0.f;
     const unsigned h = pack_bf16(v0, v1);
-    const float r0 = v0 - bf16_lo(h), r1 = v1 - bf16_hi(h);
+    const float r0 = bfx_resid_lo(h, v0), r1 = bfx_resid_hi(h, v1);
     const unsigned m = pack_bf16(r0, r1);
-    const unsigned l = pack_bf16(r0 - bf16_lo(m), r1 - bf16_hi(m));
+    const unsigned l = pack_bf16(bfx_resid_lo(m, r0), bfx_resid_hi(m, r1));
     unsigned* o = reinterpret_cast<unsigned*>(out) + e;
     o[0] = h;
     if (NS >= 2) o[total] = m;
@@ -804,9 +805,9 @@ __global__ __launch_bounds__(256) void bfx_split_weights_dgrad_kernel(const floa
       }
     }
     const unsigned h = pack_bf16(v[0], v[1]);
-    const float r0 = v[0] - bf16_lo(h), r1 = v[1] - bf16_hi(h);
+    const float r0 = bfx_resid_lo(h, v[0]), r1 = bfx_resid_hi(h, v[1]);
     const unsigned m = pack_bf16(r0, r1);
-    const unsigned l = pack_bf16(r0 - bf16_lo(m), r1 - bf16_hi(m));
+    const unsigned l = pack_bf16(bfx_resid_lo(m, r0), bfx_resid_hi(m, r1));
     unsigned* o = reinterpret_cast<unsigned*>(out) + e;
     o[0] = h;
     o[total] = m;

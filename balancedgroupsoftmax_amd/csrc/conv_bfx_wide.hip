@@ -33,6 +33,7 @@
 #include <stdlib.h>
 
 #include "conv_args.h"
+#include "bfx_split.h"
 
 using namespace bgs_conv;
 
@@ -54,11 +55,11 @@ __device__ __forceinline__ float bf16_hi(unsigned u) {
 // x (4 consecutive k) -> three planes of 4 packed bf16 each (conv_bfx.hip's split3: same values, same bits)
 __device__ __forceinline__ void split3(const f32x4 v, u32x2& hi, u32x2& mid, u32x2& lo) {
   hi = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-  const f32x4 r = {v[0] - bf16_lo(hi[0]), v[1] - bf16_hi(hi[0]), v[2] - bf16_lo(hi[1]),
-                   v[3] - bf16_hi(hi[1])};
+  const f32x4 r = {bfx_resid_lo(hi[0], v[0]), bfx_resid_hi(hi[0], v[1]), bfx_resid_lo(hi[1], v[2]),
+                   bfx_resid_hi(hi[1], v[3])};
   mid = u32x2{pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3])};
-  const f32x4 r2 = {r[0] - bf16_lo(mid[0]), r[1] - bf16_hi(mid[0]), r[2] - bf16_lo(mid[1]),
-                    r[3] - bf16_hi(mid[1])};
+  const f32x4 r2 = {bfx_resid_lo(mid[0], r[0]), bfx_resid_hi(mid[0], r[1]), bfx_resid_lo(mid[1], r[2]),
+                    bfx_resid_hi(mid[1], r[3])};
   lo = u32x2{pack_bf16(r2[0], r2[1]), pack_bf16(r2[2], r2[3])};
 }
 __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {

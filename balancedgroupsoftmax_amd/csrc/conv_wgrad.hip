@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "bgs_common.h"
+#include "bfx_split.h"
 
 namespace {
 
@@ -260,11 +261,11 @@ __device__ __forceinline__ float wg_bf16_lo(unsigned u) { return __builtin_bit_c
 __device__ __forceinline__ float wg_bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 __device__ __forceinline__ void wg_split3(const f32x4 v, u32x2& hi, u32x2& mid, u32x2& lo) {
   hi = u32x2{wg_pack_bf16(v[0], v[1]), wg_pack_bf16(v[2], v[3])};
-  const f32x4 r = {v[0] - wg_bf16_lo(hi[0]), v[1] - wg_bf16_hi(hi[0]), v[2] - wg_bf16_lo(hi[1]),
-                   v[3] - wg_bf16_hi(hi[1])};
+  const f32x4 r = {bfx_resid_lo(hi[0], v[0]), bfx_resid_hi(hi[0], v[1]), bfx_resid_lo(hi[1], v[2]),
+                   bfx_resid_hi(hi[1], v[3])};
   mid = u32x2{wg_pack_bf16(r[0], r[1]), wg_pack_bf16(r[2], r[3])};
-  const f32x4 r2 = {r[0] - wg_bf16_lo(mid[0]), r[1] - wg_bf16_hi(mid[0]), r[2] - wg_bf16_lo(mid[1]),
-                    r[3] - wg_bf16_hi(mid[1])};
+  const f32x4 r2 = {bfx_resid_lo(mid[0], r[0]), bfx_resid_hi(mid[0], r[1]), bfx_resid_lo(mid[1], r[2]),
+                    bfx_resid_hi(mid[1], r[3])};
   lo = u32x2{wg_pack_bf16(r2[0], r2[1]), wg_pack_bf16(r2[2], r2[3])};
 }
 

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include "bgs_common.h"
+#include "bfx_split.h"
 
 namespace {
 
@@ -65,9 +66,9 @@ __device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast
 // x (4 consecutive k) -> three planes of 4 packed bf16 each (the split of csrc/conv_bfx.hip)
 __device__ __forceinline__ void split3(const f32x4 v, u32x2& hi, u32x2& mid, u32x2& lo) {
   hi = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-  const f32x4 r = {v[0] - bf16_lo(hi[0]), v[1] - bf16_hi(hi[0]), v[2] - bf16_lo(hi[1]), v[3] - bf16_hi(hi[1])};
+  const f32x4 r = {bfx_resid_lo(hi[0], v[0]), bfx_resid_hi(hi[0], v[1]), bfx_resid_lo(hi[1], v[2]), bfx_resid_hi(hi[1], v[3])};
   mid = u32x2{pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3])};
-  const f32x4 r2 = {r[0] - bf16_lo(mid[0]), r[1] - bf16_hi(mid[0]), r[2] - bf16_lo(mid[1]), r[3] - bf16_hi(mid[1])};
+  const f32x4 r2 = {bfx_resid_lo(mid[0], r[0]), bfx_resid_hi(mid[0], r[1]), bfx_resid_lo(mid[1], r[2]), bfx_resid_hi(mid[1], r[3])};
   lo = u32x2{pack_bf16(r2[0], r2[1]), pack_bf16(r2[2], r2[3])};
 }
 
@@ -87,9 +88,9 @@ __global__ __launch_bounds__(256) void stem_split_weights_kernel(const float* __
     v[u] = (kx < 7 && c < 3) ? w[((size_t)(cout * 7 + ky) * 7 + kx) * cin_stride + c] : 0.f;
   }
   const unsigned h = pack_bf16(v[0], v[1]);
-  const float r0 = v[0] - bf16_lo(h), r1 = v[1] - bf16_hi(h);
+  const float r0 = bfx_resid_lo(h, v[0]), r1 = bfx_resid_hi(h, v[1]);
   const unsigned m = pack_bf16(r0, r1);
-  const unsigned l = pack_bf16(r0 - bf16_lo(m), r1 - bf16_hi(m));
+  const unsigned l = pack_bf16(bfx_resid_lo(m, r0), bfx_resid_hi(m, r1));
   out[e] = h;
   out[total + e] = m;
   out[2 * total + e] = l;

@@ -172,6 +172,47 @@ def test_conv_bfx_every_instantiation(inst):
         BF.set_conv_math(prev)
 
 
+def _bf16_rne(x):
+    """fp32 array -> (bf16 bits, that bf16 as fp32): round to nearest even, subnormals kept (v_cvt_pk_bf16_f32)."""
+    b = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+    r = ((b + 0x7fff + ((b >> 16) & 1)) >> 16).astype(np.uint16)
+    return r, (r.astype(np.uint32) << 16).view(np.float32)
+
+
+def test_bfx_split_planes_match_the_numpy_restatement():
+    """The exact three-way split every bf16x6 kernel applies to its operands (csrc/bfx_split.h: hi = bf16(x), mid =
+    bf16(x - hi), lo = bf16(x - hi - mid); the residuals formed by v_dot2c_f32_bf16 on the packed pair), observed through
+    ``bgs_conv_bfx_split_weights``: all three planes equal the numpy restatement bit for bit — both elements of a
+    packed pair (the inline-constant encoding of the multiplier got the low element wrong), large and tiny magnitudes,
+    rounding ties, fp32 subnormals (kept, not flushed) — and hi + mid + lo == x exactly (|x| > 1e-30)."""
+    g = np.random.default_rng(0)
+    n = 1 << 14
+    cases = [
+        (g.standard_normal(n) * np.exp2(g.integers(-30, 31, n))),
+        np.maximum(g.standard_normal(n), 0),
+        np.concatenate([np.exp2(g.integers(-20, 20, n // 2)) * (1 + np.exp2(-8.0)), np.exp2(g.integers(-40, 40, n // 2))]),
+        g.uniform(1, 3, n) * np.exp2(g.integers(100, 127, n)),
+        g.uniform(1, 2, n) * np.exp2(g.integers(-125, -100, n)),
+        g.uniform(0, 1, n) * 1.1e-38,
+        g.standard_normal(37),                                          # K % 16 != 0: zero-padded tail
+    ]
+    for x in cases:
+        x = (x * np.where(g.integers(0, 2, x.size) > 0, 1, -1)).astype(np.float32)
+        K = x.size
+        KC = 2 * ((K + 31) // 32)                          # planes [3][KC][rows][16], K padded to 32
+        buf = BF.bfx_split_weights(torch.from_numpy(x).to('cuda:0').view(1, K), cache=False)
+        raw = buf.cpu().numpy()[:3 * KC * 32].view(np.uint16).reshape(3, KC * 16)
+        h, hf = _bf16_rne(x)
+        r = x - hf
+        m, mf = _bf16_rne(r)
+        lo, lf = _bf16_rne(r - mf)
+        for got, want in zip(raw, (h, m, lo)):
+            assert np.array_equal(got[:K], want) and not got[K:].any()
+        big = (np.abs(x) > 1e-30) | (x == 0)              # below that the low plane runs out of bf16 exponent range
+        assert np.array_equal((hf.astype(np.float64) + mf.astype(np.float64) + lf.astype(np.float64))[big],
+                              x.astype(np.float64)[big])
+
+
 def test_bfx_error_not_above_f32_mfma():
     """The bf16x6 kernels are not a reduced-precision mode: against an fp64 reference their error
     (normalised by sum |a||b|, the fp32 rounding scale of the reduction) is at the level of the
