@@ -59,9 +59,10 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true',
                     help='skip the per-kernel roofline timings (used by the extras sub-runs)')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches, not hipGraph replay')
-    ap.add_argument('--launch', choices=('auto', 'graph', 'eager'), default='auto',
-                    help='one GPU: auto = calibrate hipGraph replay and eager launches untimed and time the faster '
-                         '(default) | graph | eager')
+    ap.add_argument('--launch', choices=('auto', 'graph', 'eager', 'pipelined'), default='auto',
+                    help='one GPU: auto = calibrate hipGraph replay, eager launches and the trunk pipeline untimed and '
+                         'time the fastest (default) | graph | eager | pipelined (train.TrunkPipeline without '
+                         'calibration, depth BGS_BENCH_PIPELINE_DEPTH or 5: for traces)')
     ap.add_argument('--dist-graph', action='store_true',
                     help='N > 1 over RCCL: capture the WHOLE step, gradient all-reduce included, into '
                          'one hipGraph per rank (default for N > 1: eager launches)')
@@ -396,7 +397,7 @@ CONV_MATH_NOTE = {
 }
 
 
-def conv_roofline(dev, math, iters=20):
+def conv_roofline(dev, math, iters=20, wide=0):
     """Dominant kernel of the detector step: the 3x3 halo convolution.  Timed on the largest single
     layer (FPN output conv on P2: 2x200x336 pixels, 3x3, 256->256 = 158.5 algorithmic GFLOP) with
     HIP events on the launch stream.  `achieved` = ALGORITHMIC flops / time.  Peaks
@@ -404,6 +405,8 @@ def conv_roofline(dev, math, iters=20):
     kernel spends SIX bf16 MFMA passes per algorithmic fp32 multiply-add, so its matrix-pipe
     ceiling in algorithmic flops is 2500 / 6 = 416.7 TFLOP/s (frac = matrix-pipe busy fraction)."""
     prev = BF.set_conv_math(math)
+    prev_wide = BF.set_halo_wide(1) if wide else None
+    used = {}
     try:
         x = torch.randn(2, 200, 336, 256, device=dev)
         w = torch.randn(256, 3, 3, 256, device=dev) * 0.02
@@ -421,8 +424,11 @@ def conv_roofline(dev, math, iters=20):
             BF.conv2d_nhwc(x, w, b, pad=1, out=out)
         e1.record()
         torch.cuda.synchronize()
+        used = BF.conv_bfx_last_launch() if math != 'f32' else {}
     finally:
         BF.set_conv_math(prev)
+        if wide:
+            BF.set_halo_wide(prev_wide)
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * 2 * 200 * 336 * 256 * 256 * 9
     tf = flops / (ms * 1e-3) / 1e12
@@ -431,6 +437,14 @@ def conv_roofline(dev, math, iters=20):
         kdesc = kname + (' (halo-resident A operand split to 3 bf16 planes in LDS, filter slices by '
                          'LDS-DMA, v_mfma_f32_32x32x16_bf16 x 6)')
         peak, passes = 2500.0 / 6.0, 6
+        if wide and used.get('halo_wide_units'):
+            # the two-launch schedule the trunk pipeline switches on (bgs_conv3x3_halo_bfx_wide(1)): whole rounds of
+            # 16 x 16-pixel units (two workgroups per CU) + the left-over rows on the 8 x 16-pixel kernel
+            kname = 'conv3x3_halo_bfx7_kernel<3>+conv3x3_halo_bfx4_kernel<2>'
+            kdesc = ('conv3x3_halo_bfx7_kernel<3> on %d units of 16 x 16 pixels x 128 channels (two workgroups per CU, '
+                     'whole rounds of 512) + conv3x3_halo_bfx4_kernel<2> on the %d left-over 8 x 16-pixel units: two '
+                     'launches per layer, bit-identical to the one-launch form (tests/test_gpu_det_ops.py); '
+                     'ms_per_launch is the PAIR' % (used['halo_wide_units'], used['halo_tail_units']))
     elif math == 'bf16':
         kname = 'conv3x3_halo_bfx3_kernel<2,1>'
         kdesc = kname + ' (operands rounded to bf16, v_mfma_f32_32x32x16_bf16 x 1)'
@@ -1118,6 +1132,10 @@ def finish_line(out, args, dev, world):
         out['roofline'] = conv_roofline(dev, args.conv_math)
         if args.conv_math != 'f32':
             out['roofline_f32_mfma_kernel'] = conv_roofline(dev, 'f32')
+        if args.conv_math == 'bf16x6' and (out.get('launch_calibration') or {}).get('chosen') == 'eager_pipelined':
+            # the timed steps ran through train.TrunkPipeline, which switches the halo kernel's wide schedule on:
+            # the same layer under THAT schedule (`roofline` above is the one-launch form the rocprofv3 summary holds)
+            out['roofline_wide_schedule'] = conv_roofline(dev, args.conv_math, wide=1)
         rs = roofline_step(out, args)
         if rs:
             out['roofline_step'] = rs
@@ -1381,7 +1399,7 @@ def main_detector(args, rank, local, world, dev):
     if world > 1 and not args.child and args.launch == 'auto' and not args.dist_graph \
             and not os.environ.get('BGS_BENCH_NO_DIST_CALIB'):
         dist_calib, dist_fn, dist_pipelined = calibrate_dist_forks(step, world)
-    if can_graph and args.launch != 'eager':
+    if can_graph and args.launch not in ('eager', 'pipelined'):
         # --dist-graph: the RCCL all-reduce is captured with the rest of the step (the communicator
         # is set up by the eager warm-up iterations inside try_graph)
         graph = try_graph(step)
@@ -1400,6 +1418,8 @@ def main_detector(args, rank, local, world, dev):
             fn = step.pipelined(depth=calib['pipeline_depth'])      # (a fresh pipeline: its first features are launched here, untimed)
             pipelined = True
             calib['chosen'] = 'eager_pipelined'
+    if args.launch == 'pipelined' and world == 1 and step.can_pipeline():
+        fn, pipelined = step.pipelined(depth=int(os.environ.get('BGS_BENCH_PIPELINE_DEPTH', 5))), True
     dt = timed_loop(fn, args.steps, args.warmup, world)
     if pipelined:
         fn.drain()                             # (the features launched by the last timed call: consumed by nobody)
