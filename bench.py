@@ -728,7 +728,7 @@ def hbm_kernel_rooflines(dev, conv_math='bf16x6'):
     us = _event_time_us(lambda: BF.roi_align_nhwc(feats, rois, cap['strides'], cap['out_size'], cap['sample_num'],
                                                   cap['finest_scale']), 50, settle=4)
     alg = out_bytes + min(pyramid, fp_sum)
-    kname = 'roi_align_nhwc_kernel<2,false,1,false>'
+    kname = 'roi_align_fwd_grid_kernel<1,false>'      # (round 5: every distinct pixel of a bin loaded once)
     tr, src = _pmc_traffic(kname, K)
     res['roofline_roi_align'] = dict(
         bound='hbm', achieved=round(alg / (us * 1e-6) / 1e9, 1), peak=HBM_PEAK_GBS, unit='GB/s',

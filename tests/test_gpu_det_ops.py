@@ -375,6 +375,39 @@ def test_roi_align_multilevel_vs_oracle(C):
     assert not out[0].any()
 
 
+@pytest.mark.parametrize('pool', [1, 2])
+def test_roi_align_tap_grid_kernel_equals_the_sample_at_a_time_kernel_bit_for_bit(pool):
+    """The forward kernel that loads every distinct feature pixel of a bin once (``roi_align_fwd_grid_kernel``, default)
+    and the one that walks the 2 x 2 sample points one after the other (``BGS_ROI_DEDUP=0``): same weights, same products,
+    same summation order — identical bits, on RoIs of every level incl. ones that stick out of the image, are degenerate
+    or lie completely outside, with and without accumulation into ``out``, C a multiple of 256 or not."""
+    rs = np.random.RandomState(31 + pool)
+    strides = [4, 8, 16, 32]
+    for C in ((256, 64) if pool == 1 else (256,)):
+        feats = [dev(rs.standard_normal((2, 200 // (s // 4), 336 // (s // 4), C)).astype(np.float32)) for s in strides]
+        K = 600
+        wh = np.exp(rs.uniform(np.log(4), np.log(900), (K, 2)))
+        xy = np.stack([rs.uniform(-60, 1340, K), rs.uniform(-60, 800, K)], 1)
+        rois = np.concatenate([rs.randint(0, 2, (K, 1)), xy, xy + wh], 1).astype(np.float32)
+        rois[0] = [0, 5000, 5000, 5100, 5100]
+        rois[1] = [1, 10, 10, 5, 5]
+        rois[2] = [0, 1300, 780, 1400, 900]
+        rois[3] = [1, 100.25, 50.5, 100.25, 50.5]            # a single point: every sample in one pixel cell
+        r = dev(rois)
+        base = dev(rs.standard_normal((K, 7, 7, C)).astype(np.float32))
+        got = {}
+        try:
+            for mode in ('0', '1'):
+                os.environ['BGS_ROI_DEDUP'] = mode
+                acc = base.clone()
+                got[mode] = (BF.roi_align_nhwc(feats, r, strides, out_size=7, pool=pool),
+                             BF.roi_align_nhwc(feats, r, strides, out_size=7, pool=pool, out=acc))
+        finally:
+            os.environ.pop('BGS_ROI_DEDUP', None)
+        assert torch.equal(got['0'][0], got['1'][0]) and torch.equal(got['0'][1], got['1'][1])
+        assert got['1'][0].abs().sum() > 0 and not got['1'][0][0].any()
+
+
 @pytest.mark.parametrize('mode', [0, 1])
 def test_nms_batched_vs_oracle_and_reference(mode):
     counts = [2000, 1337, 64, 65, 1, 0, 500]

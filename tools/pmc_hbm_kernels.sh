@@ -9,12 +9,12 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 3 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -o k -- python $R/tools/kernel_once.py 10 > $OUT/$C.log 2> $OUT/$C.err
+  timeout -k 3 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -o k -- python $R/tools/kernel_once.py 10 ${KERNELS:-} > $OUT/$C.log 2> $OUT/$C.err
   echo "$C rc=$?"; tail -1 $OUT/$C.log
 done
 python - <<PY
 import csv, glob, collections, json, re
-pat = re.compile(r'(roi_align_nhwc_kernel<[^>]*>|gs_merge_rowwave_kernel|iou_gtmax_kernel|iou_assign_kernel)')
+pat = re.compile(r'(roi_align_nhwc_kernel<[^>]*>|roi_align_fwd_grid_kernel<[^>]*>|gs_merge_rowwave_kernel|iou_gtmax_kernel|iou_assign_kernel)')
 res = collections.defaultdict(dict)
 for C in ['FETCH_SIZE', 'WRITE_SIZE']:
     for f in glob.glob('$OUT/%s/**/*counter_collection.csv' % C, recursive=True):

@@ -29,7 +29,9 @@ def put(kernel, key, ents, extra=None):
 for k, ent in d.items():
     name, grid = k.split(' grid=')
     grid = int(grid)
-    if name.startswith('roi_align_nhwc_kernel<2,false,1,false>'):
+    if name.startswith('roi_align_fwd_grid_kernel<1,false>'):
+        put('roi_align_fwd_grid_kernel<1,false>', grid // 64 // 49, [ent])
+    elif name.startswith('roi_align_nhwc_kernel<2,false,1,false>'):
         put('roi_align_nhwc_kernel<2,false,1,false>', grid // 64 // 49, [ent])
     elif name.startswith('roi_align_nhwc_kernel<2,true,1,false>'):
         put('roi_align_nhwc_kernel<2,true,1,false>', grid // 64 // 49, [ent])
