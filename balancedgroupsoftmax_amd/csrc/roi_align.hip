@@ -366,6 +366,115 @@ __global__ __launch_bounds__(256) void roi_align_fwd_grid_kernel(RoiLevels L, co
 }
 
 
+// ---- backward, sample_num = 2, on the same 4 x 4 tap grid: the weights of the taps that fall on one pixel are summed
+// first (wave-uniform scalars), so a bin issues one atomic per DISTINCT pixel and channel instead of one per tap (9.1
+// instead of 16 on the RoIs of a cfg[1] step).  fp32 atomics accumulate in arbitrary order anyway, so the result is
+// the reference's up to the rounding of a sum — the same statement the one-atomic-per-tap kernel makes.
+template <int POOL>
+__global__ __launch_bounds__(256) void roi_align_bwd_grid_kernel(RoiLevels L, const float* __restrict__ rois, int K,
+                                                                 int C, int PH, int PW, const float* __restrict__ dout) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  const int bins = PH * PW;
+  if (wave_global >= K * bins) return;
+  const int k = wave_global / bins;
+  const int bin = wave_global - k * bins;
+  const int ph = bin / PW, pw = bin - (bin / PW) * PW;
+  const float* roi = rois + (size_t)k * 5;
+  const int n = min(max((int)roi[0], 0), L.num_images - 1);
+  const float x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
+  const float scale = sqrtf((x2 - x1 + 1.f) * (y2 - y1 + 1.f));
+  float lf = floorf(log2f(scale / L.finest_scale + 1e-6f));
+  lf = fminf(fmaxf(lf, 0.f), (float)(L.num_levels - 1));
+  const int lvl = __builtin_amdgcn_readfirstlane((int)lf);
+  const int H = L.H[lvl], W = L.W[lvl];
+  const float ss = L.scale[lvl];
+  float* dfeat = const_cast<float*>(L.feat[lvl]) + (size_t)n * H * W * C;
+  const float roi_start_w = x1 * ss, roi_start_h = y1 * ss;
+  const float roi_end_w = (x2 + 1.f) * ss, roi_end_h = (y2 + 1.f) * ss;
+  const float roi_width = fmaxf(roi_end_w - roi_start_w, 0.f);
+  const float roi_height = fmaxf(roi_end_h - roi_start_h, 0.f);
+  const float bin_size_h = roi_height / (PH * POOL), bin_size_w = roi_width / (PW * POOL);
+  const float* o = dout + ((size_t)k * bins + bin) * C;
+#pragma unroll 1
+  for (int sub = 0; sub < POOL * POOL; ++sub) {
+    const int fh = ph * POOL + sub / POOL, fw = pw * POOL + sub % POOL;
+    AxisTap ty[2], tx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ty[i] = make_axis_tap(roi_start_h + fh * bin_size_h + (i + .5f) * bin_size_h / 2.f, H);
+      tx[i] = make_axis_tap(roi_start_w + fw * bin_size_w + (i + .5f) * bin_size_w / 2.f, W);
+    }
+    int row[4] = {ty[0].lo, ty[0].hi, ty[1].lo, ty[1].hi};
+    int col[4] = {tx[0].lo, tx[0].hi, tx[1].lo, tx[1].hi};
+    int rsrc[4], csrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      row[i] = __builtin_amdgcn_readfirstlane(row[i]);
+      col[i] = __builtin_amdgcn_readfirstlane(col[i]);
+      rsrc[i] = csrc[i] = i;
+#pragma unroll
+      for (int j = i - 1; j >= 0; --j) {
+        if (row[j] == row[i]) rsrc[i] = j;
+        if (col[j] == col[i]) csrc[i] = j;
+      }
+    }
+    // the 4 x 4 table of tap weights (make_tap's hy*hx, hy*lx, ly*hx, ly*lx per sample; 0 for a sample out of range)
+    float wg[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wg[r][q] = 0.f;
+#pragma unroll
+    for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < 2; ++ix) {
+        const bool ok = ty[iy].ok && tx[ix].ok;
+        const float wy0 = ty[iy].h, wy1 = ty[iy].l, wx0 = tx[ix].h, wx1 = tx[ix].l;
+        wg[2 * iy][2 * ix] = ok ? wy0 * wx0 : 0.f;
+        wg[2 * iy][2 * ix + 1] = ok ? wy0 * wx1 : 0.f;
+        wg[2 * iy + 1][2 * ix] = ok ? wy1 * wx0 : 0.f;
+        wg[2 * iy + 1][2 * ix + 1] = ok ? wy1 * wx1 : 0.f;
+      }
+    // every entry (r, q) of the table is one tap of one sample (sample (r >> 1, q >> 1)); two entries name the same
+    // pixel iff their rows and their columns are equal, so folding duplicate columns and then duplicate rows onto
+    // their first occurrence sums exactly the taps that land on one pixel
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 3; q >= 1; --q)
+#pragma unroll
+        for (int j = 0; j < q; ++j)
+          if (csrc[q] == j) {
+            wg[r][j] += wg[r][q];
+            wg[r][q] = 0.f;
+          }
+#pragma unroll
+    for (int r = 3; r >= 1; --r)
+#pragma unroll
+      for (int j = 0; j < r; ++j)
+        if (rsrc[r] == j) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            wg[j][q] += wg[r][q];
+            wg[r][q] = 0.f;
+          }
+        }
+    for (int c = lane; c < C; c += 64) {
+      const float g = o[c] / (float)(4 * POOL * POOL);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float w = wg[r][q];
+          if (w == 0.f) continue;
+          unsafeAtomicAdd(dfeat + (size_t)(row[r] * W + col[q]) * C + c, g * w);
+        }
+    }
+  }
+}
+
+
 // ---- any sample_num (0 = the reference's adaptive grid: ceil(roi_size / pooled_size) samples per bin and axis,
 // roi_align_kernel.cu:95-99) and fp16 tensors (AT_DISPATCH_FLOATING_TYPES_AND_HALF, roi_align_kernel.cu:136):
 // the rest of the `roi_align_cuda` interface.  Same wave-per-bin mapping; the taps of a sample point are
@@ -577,7 +686,16 @@ extern "C" int bgs_roi_align_nhwc_bwd_ex(float* const* host_dfeats, const int* h
                        L, rois, K, C, pooled_h, pooled_w, sample_num, const_cast<float*>(dout), nullptr);
     BGS_RETURN_LAUNCH_STATUS();
   }
-  if (pool == 1)
+  // BGS_ROI_DEDUP=0: one atomic per tap; default: one per distinct pixel of a bin (roi_align_bwd_grid_kernel)
+  const char* dd_env = getenv("BGS_ROI_DEDUP");
+  const bool dedup = !(dd_env && atoi(dd_env) == 0);
+  if (dedup && pool == 1)
+    hipLaunchKernelGGL((roi_align_bwd_grid_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, L, rois, K, C,
+                       pooled_h, pooled_w, dout);
+  else if (dedup)
+    hipLaunchKernelGGL((roi_align_bwd_grid_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, L, rois, K, C,
+                       pooled_h, pooled_w, dout);
+  else if (pool == 1)
     hipLaunchKernelGGL((roi_align_nhwc_kernel<2, true, 1, false>), dim3(grid), dim3(256), 0,
                        (hipStream_t)stream, L, rois, K, C, pooled_h, pooled_w,
                        const_cast<float*>(dout), nullptr, 0);

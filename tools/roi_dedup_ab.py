@@ -46,6 +46,43 @@ print('K = %d RoIs x 49 bins x %d channels; identical bits: True' % (rois.shape[
 for m, name in (('0', 'sample-at-a-time'), ('1', 'tap grid')):
     v = sorted(res[m])
     print('%-18s us / launch: min %.1f  median %.1f  all %s' % (name, v[0], v[len(v) // 2], ' '.join('%.1f' % x for x in res[m])))
+# backward (selectp=0): one atomic per tap against one per distinct pixel
+dout = torch.randn_like(outs['1'])
+dfe = {m: [torch.zeros_like(x) for x in feats] for m in ('0', '1')}
+
+
+def timed_bwd(m):
+    os.environ['BGS_ROI_DEDUP'] = m
+    fn = lambda: BF.roi_align_nhwc_bwd(dout, rois, dfe[m], cap['strides'], cap['sample_num'], cap['finest_scale'])
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 50 * 1e3
+
+
+resb = {'0': [], '1': []}
+for rnd in range(4):
+    for m in (('0', '1') if rnd % 2 == 0 else ('1', '0')):
+        resb[m].append(timed_bwd(m))
+os.environ.pop('BGS_ROI_DEDUP')
+for m in ('0', '1'):
+    for x in dfe[m]:
+        x.zero_()
+    os.environ['BGS_ROI_DEDUP'] = m
+    BF.roi_align_nhwc_bwd(dout, rois, dfe[m], cap['strides'], cap['sample_num'], cap['finest_scale'])
+os.environ.pop('BGS_ROI_DEDUP')
+err = max(float((a - b).abs().max()) for a, b in zip(dfe['0'], dfe['1']))
+ref = max(float(a.abs().max()) for a in dfe['0'])
+for m, name in (('0', 'bwd, atomic per tap'), ('1', 'bwd, per distinct px')):
+    v = sorted(resb[m])
+    print('%-22s us / launch: min %.1f  median %.1f  all %s' % (name, v[0], v[len(v) // 2], ' '.join('%.1f' % x for x in resb[m])))
+print('backward: max |difference| between the two %.3g (max |gradient| %.3g)' % (err, ref))
 # distinct taps per bin on these RoIs (host restatement of the row / column equality)
 r = rois.cpu().numpy().astype(np.float64)
 strides = np.asarray(cap['strides'], dtype=np.float64)
