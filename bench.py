@@ -1278,12 +1278,12 @@ def calibrate_dist_forks(step, world):
     arms = {}
     per_rank = {}
     fns = {}
-    names = [('forks_on', '1', False), ('forks_off', '0', False)]
+    names = [('forks_on', '1', 0), ('forks_off', '0', 0)]
     if step.can_pipeline() and not os.environ.get('BGS_BENCH_NO_PIPELINE'):
-        names.append(('pipelined', '1', True))
+        names += [('pipelined', '1', 4), ('pipelined_depth5', '1', 5)]       # (the two depths that win at N = 1)
     for name, val, pipe in names:
         os.environ['BGS_LEVEL_FORK'] = val
-        fn = step.pipelined(depth=4) if pipe else step
+        fn = step.pipelined(depth=pipe) if pipe else step
         dt = timed_loop(fn, 8, 4 if name == 'forks_on' else 2, world)
         if pipe:
             fn.drain()
@@ -1295,15 +1295,20 @@ def calibrate_dist_forks(step, world):
         dist.all_gather(allr, mine)
         per_rank[name] = [round(float(t.item()), 3) for t in allr]
     chosen = 'forks_on' if arms['forks_on'] <= 1.01 * arms['forks_off'] else 'forks_off'
-    if 'pipelined' in arms and arms['pipelined'] < 0.99 * arms[chosen]:
-        chosen = 'pipelined'
+    depth = 0
+    if 'pipelined' in arms:
+        best = 'pipelined' if arms['pipelined'] <= arms['pipelined_depth5'] else 'pipelined_depth5'
+        if arms[best] < 0.99 * arms[chosen]:
+            chosen, depth = 'pipelined', (4 if best == 'pipelined' else 5)
     os.environ['BGS_LEVEL_FORK'] = '0' if chosen == 'forks_off' else '1'
     rec = dict(chosen=chosen, ms_by_rank=per_rank,
                note='untimed calibration on all ranks (8 eager steps per arm incl. the gradient exchange, max over '
                     'ranks); the K timed steps ran under `chosen`; the whole-step-graph arm is `dist_graph_policy`')
     for name in arms:
         rec['eager_%s_ms' % name] = arms[name]
-    return rec, (step.pipelined(depth=4) if chosen == 'pipelined' else step), chosen == 'pipelined'
+    if depth:
+        rec['pipeline_depth'] = depth
+    return rec, (step.pipelined(depth=depth) if depth else step), depth
 
 
 def n1_reference(args, rank, world, dev, ms_per_step_n, pipelined=False):
@@ -1315,7 +1320,8 @@ def n1_reference(args, rank, world, dev, ms_per_step_n, pipelined=False):
         try:
             one = DetectorStep(dev, 0, 1, args.imgs, args.selectp, args.mask, args.cascade, args.htc,
                                conv_math=args.conv_math)
-            fn1 = one.pipelined(depth=4) if (pipelined and one.can_pipeline()) else one      # (the policy the N ranks were timed under)
+            fn1 = one.pipelined(depth=int(pipelined) if int(pipelined) > 1 else 4) \
+                if (pipelined and one.can_pipeline()) else one      # (the policy the N ranks were timed under)
             dt = timed_loop(fn1, args.steps, max(args.warmup, 4), 1)
             if fn1 is not one:
                 fn1.drain()
@@ -1324,7 +1330,7 @@ def n1_reference(args, rank, world, dev, ms_per_step_n, pipelined=False):
             out = dict(n1_same_invocation=dict(ms_per_step=round(ms1, 3),
                                                img_per_s=round(args.imgs * args.steps / dt, 3),
                                                launch='eager launches%s, rank 0 alone, other ranks idle'
-                                                      % (' (two-stage pipeline)' if fn1 is not one else '')),
+                                                      % ((' (%d-stage pipeline)' % fn1.depth) if fn1 is not one else '')),
                        weak_scaling_eff=round(ms1 / ms_per_step_n, 4))
             del one
         except Exception as e:  # pragma: no cover
