@@ -286,6 +286,20 @@ def test_side_stream_forks_do_not_change_the_iteration(monkeypatch):
                 assert torch.equal(got[k], ref[k]), (name, rep, k)
 
 
+def test_trunk_pipeline_soak_at_full_size_without_host_synchronisation():
+    """tools/pipe_soak.py: 60 optimizer steps of the bench's full-size cfg[1] step over two alternating batches with NO
+    host synchronisation inside the loop — sequential loop vs ``train.TrunkPipeline`` at depths 4, 5, 3, 5 — end in
+    bit-identical ``fc_cls`` parameters and last-step losses (the six-step test below reads the losses back every step,
+    which also orders the streams; this one leaves the caching allocator and the piece streams to themselves)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'pipe_soak.py'), '60'], capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    assert r.returncode == 0 and 'SOAK OK' in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+    assert r.stdout.count('identical parameters and last losses: True') == 4
+
+
 def test_trunk_pipeline_reproduces_the_sequential_training_loop():
     """``train.TrunkPipeline`` (round 5): with a frozen trunk (the shipped selectp = 1) the features of batch i + 1 are
     computed on their own streams (depth 2: the whole trunk one batch ahead; 3: backbone two ahead | FPN one ahead; 4:
