@@ -72,42 +72,62 @@ def _fold_conv_bn(conv, bn, pad_cin_to=None):
         return w.contiguous(), b.contiguous()
 
 
-def _tensor_ids(module):
-    """ids of every registered parameter / buffer object below ``module`` (direct walk of the registration dicts)."""
-    out = []
-    stack = [module]
+def _tensor_slots(mods):
+    """(registration dict, name) of every parameter / buffer below the modules ``mods`` (direct walk of the registration
+    dicts), and those dicts themselves (parameters, buffers and sub-modules of every module seen, empty ones included)."""
+    slots, dicts = [], []
+    stack = list(mods)[::-1]
     while stack:
         m = stack.pop()
-        for t in m._parameters.values():
-            out.append(id(t))
-        for t in m._buffers.values():
-            out.append(id(t))
+        for d in (m._parameters, m._buffers):
+            dicts.append(d)
+            for k in d:
+                slots.append((d, k))
+        dicts.append(m._modules)
         stack.extend(m._modules.values())
-    return tuple(out)
+    return slots, dicts
 
 
 class _FoldCache(object):
-    """Folded weights keyed by parameter version counters."""
+    """Folded weights keyed by the identity, version counter and storage address of the tensors they were built from.
+
+    ``get(mods, build)``: ``mods`` is a module or a tuple of modules.  The host cost of the check is on the launch path of
+    every frozen layer (a quarter of the launching thread's time once, a tenth before round 5), so it reads the CURRENT
+    tensor objects through the registration dicts listed once (a re-registered parameter or buffer is a new object under
+    the same name: seen), compares (id, _version, data_ptr) and re-lists the dicts only when a name disappears, the number
+    of registered names (parameters, buffers, sub-modules) changes or another set of modules is passed."""
 
     def __init__(self):
         self.key = None
         self.data = None
-        self.ids = None
-        self.params = self.tensors = ()
+        self.mods = None
+        self.slots = None
+        self.count = -1
+
+    def _list(self, mods):
+        self.mods = tuple(id(m) for m in mods)
+        self.slots, self.dicts = _tensor_slots(mods)
+        self.count = sum(len(d) for d in self.dicts)
+        self.key = None
 
     def get(self, module, build):
-        # the module's tensors are listed once per set of tensor objects (module.parameters() / .buffers() walk the
-        # tree through generators with duplicate sets: a quarter of the host time of an eagerly launched step);
-        # _tensor_ids walks the same registration dicts directly, so a re-registered parameter or buffer is seen
-        ids = _tensor_ids(module)
-        if self.ids != ids:          # (not `module is`: callers may pass a fresh container of the same sub-modules)
-            self.ids = ids
-            self.params = tuple(module.parameters())
-            self.tensors = self.params + tuple(module.buffers())
-            self.key = None
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.params):
-            return build()           # trained parameters: the fold must be on this step's tape
-        key = tuple((id(t), t._version, t.device) for t in self.tensors)
+        mods = module if isinstance(module, tuple) else (module,)
+        if self.slots is None or self.mods != tuple(id(m) for m in mods) or \
+                self.count != sum(len(d) for d in self.dicts):
+            self._list(mods)
+        try:
+            tensors = [d[k] for d, k in self.slots]
+        except KeyError:                                   # a name was removed: list again
+            self._list(mods)
+            tensors = [d[k] for d, k in self.slots]
+        grad = torch.is_grad_enabled()
+        key = []
+        for t in tensors:
+            if t is None:
+                continue
+            if grad and t.requires_grad:
+                return build()       # trained parameters: the fold must be on this step's tape
+            key.append((id(t), t._version, t.data_ptr()))
         if key != self.key:
             self.data = build()
             self.key = key
@@ -122,7 +142,7 @@ def cached_fold(conv, bn=None, pad_cin_to=None):
     cache = conv.__dict__.get('_bgs_fold_cache')
     if cache is None:
         cache = conv.__dict__['_bgs_fold_cache'] = _FoldCache()
-    mods = nn.ModuleList([conv] + ([bn] if bn is not None else []))
+    mods = (conv, bn) if bn is not None else (conv,)
     return cache.get(mods, lambda: _fold_conv_bn(conv, bn, pad_cin_to=pad_cin_to))
 
 
@@ -356,14 +376,14 @@ class ResNet(nn.Module):
         # frozen_stages >= 1 (every BAGS config): a plain forward launch on the cached fold;
         # frozen_stages < 1: the fold is on the tape (resnet.py:483-494), the conv records its
         # weight / bias gradient (the image needs none) and the max-pool its routing
-        stem = self._cache.get(nn.ModuleList([self.conv1, self.bn1]), self._build_stem)
+        stem = self._cache.get((self.conv1, self.bn1), self._build_stem)
         frozen_stem = not (torch.is_grad_enabled() and (img.requires_grad or stem[0].requires_grad or
                                                         stem[1].requires_grad))
         if img.is_cuda and frozen_stem and img.shape[1] == 3 and tuple(stem[0].shape[:3]) == (64, 7, 7) \
                 and BF.stem_fused_enabled():
             # round 5: conv1 + ReLU + max-pool in ONE launch straight from the NCHW image (csrc/stem_fused.hip): the
             # [N, H/2, W/2, 64] conv map (137 MB at cfg[1]) and the NHWC copy of the image never reach HBM
-            ws = self._stem_split.get(nn.ModuleList([self.conv1, self.bn1]),
+            ws = self._stem_split.get((self.conv1, self.bn1),
                                       lambda: BF.stem_fused_split_weights(stem[0].detach()))
             x = BF.stem_fused(img, ws, stem[1].detach())
         else:

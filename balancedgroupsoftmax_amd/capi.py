@@ -278,6 +278,24 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def current_stream(device=None):
+_RAW_STREAM = []
+
+
+def raw_stream(device=None):
+    """The current HIP stream of ``device`` as an integer handle (``torch._C._cuda_getCurrentRawStream``: no Stream
+    object, no device-index normalisation — the Python-level ``torch.cuda.current_stream`` cost ~2 us per launch, one
+    tenth of the launching thread's time in an eagerly launched step)."""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    if not _RAW_STREAM:
+        _RAW_STREAM.append(getattr(torch._C, '_cuda_getCurrentRawStream', None))
+    idx = getattr(device, 'index', None) if device is not None else None
+    if idx is None:
+        idx = torch.cuda.current_device()
+    fn = _RAW_STREAM[0]
+    if fn is None:       # (an older torch: the public API)
+        return torch.cuda.current_stream(idx).cuda_stream
+    return fn(idx)
+
+
+def current_stream(device=None):
+    return ctypes.c_void_p(raw_stream(device))

@@ -18,7 +18,7 @@ _WS = {}
 
 def _workspace(nbytes, device):
     """Per (device, stream) scratch buffer; kernels of one stream are serialised."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, capi.raw_stream(device))
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

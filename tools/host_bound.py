@@ -2,7 +2,7 @@
 time until the LAST launch of n steps is enqueued (no synchronisation inside), wall time until the GPU has finished, and
 the CPU time the launching thread spent (time.thread_time).  enqueue ~ total and cpu ~ enqueue  => the host is the
 bottleneck; enqueue << total => the GPU is.
-python tools/host_bound.py [steps=40]"""
+python tools/host_bound.py [steps=40] [--cascade] [--bf16]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 argv = sys.argv[1:]
@@ -12,8 +12,12 @@ import bench
 from balancedgroupsoftmax_amd import functional as BF
 
 n = int(argv[0]) if argv else 40
+flags = argv[1:]                                   # e.g. --cascade --bf16
 dev = torch.device('cuda', 0)
-step = bench.DetectorStep(dev, 0, 1, 2, 1, conv_math='bf16x6')
+if '--bf16' in flags:
+    BF.set_conv_math('bf16')
+step = bench.DetectorStep(dev, 0, 1, 2, 3 if '--cascade' in flags else 1, cascade='--cascade' in flags,
+                          conv_math='bf16' if '--bf16' in flags else 'bf16x6')
 
 
 def measure(fn, name):
