@@ -288,9 +288,12 @@ def raw_stream(device=None):
     import torch
     if not _RAW_STREAM:
         _RAW_STREAM.append(getattr(torch._C, '_cuda_getCurrentRawStream', None))
-    idx = getattr(device, 'index', None) if device is not None else None
+    idx = device if isinstance(device, int) else getattr(device, 'index', None)
     if idx is None:
-        idx = torch.cuda.current_device()
+        if isinstance(device, str):
+            idx = torch.device(device).index
+        if idx is None:
+            idx = torch.cuda.current_device()
     fn = _RAW_STREAM[0]
     if fn is None:       # (an older torch: the public API)
         return torch.cuda.current_stream(idx).cuda_stream
