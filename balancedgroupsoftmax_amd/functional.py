@@ -34,7 +34,7 @@ def reset_workspaces():
 
 
 _SIDE = {}
-_PIPELINE_ACTIVE = [0]      # 1 while a train.TrunkPipeline has batches in flight
+_PIPELINE_ACTIVE = [0]      # non-zero (the id of the owning train.TrunkPipeline) while one has batches in flight
 
 
 def level_fork_enabled():

@@ -551,7 +551,7 @@ class TrunkPipeline(object):
         if img is not None:
             self._device = img.device
         if not BF._PIPELINE_ACTIVE[0]:
-            BF._PIPELINE_ACTIVE[0] = 1    # (functional.level_fork_enabled: no forks inside the pieces or beside the heads)
+            BF._PIPELINE_ACTIVE[0] = id(self)    # (functional.level_fork_enabled: no forks inside the pieces or beside the heads; the value names the owner)
             # ... and without forks beside them the P2 halo convs take the whole-rounds schedule of variant 7
             # (bit-identical), unless the caller has chosen a mode of his own
             self._wide_prev = BF.set_halo_wide(1)
@@ -591,8 +591,8 @@ class TrunkPipeline(object):
 
     def _deactivate(self):
         from . import functional as BF
-        if BF._PIPELINE_ACTIVE[0]:
-            BF._PIPELINE_ACTIVE[0] = 0
+        if BF._PIPELINE_ACTIVE[0] == id(self):       # (only the pipeline that set the switches clears them: a dropped
+            BF._PIPELINE_ACTIVE[0] = 0               #  pipeline's __del__ must not touch a live one's)
             if getattr(self, '_wide_prev', 0) < 0:
                 BF.set_halo_wide(-1)
 

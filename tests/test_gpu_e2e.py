@@ -370,6 +370,17 @@ def test_trunk_pipeline_reproduces_the_sequential_training_loop():
             assert torch.equal(a, b)
     assert not torch.equal(wseq[0], init[0].cpu())                 # the steps did update fc_cls
     assert not torch.equal(seq[0]['loss_bbox'], seq[1]['loss_bbox'])          # and the two batches differ
+    # the process-wide switches belong to the pipeline that set them: another instance (or its __del__) leaves them alone
+    p1 = train.TrunkPipeline(model, depth=2)
+    p1.push(img_a)
+    p2 = train.TrunkPipeline(model, depth=2)
+    assert BF._PIPELINE_ACTIVE[0] == id(p1) and not BF.level_fork_enabled()
+    p2._deactivate()
+    del p2
+    assert BF._PIPELINE_ACTIVE[0] == id(p1)
+    p1.drain()
+    assert BF._PIPELINE_ACTIVE[0] == 0
+    torch.cuda.synchronize()
     next(model.backbone.layer4.parameters()).requires_grad = True       # a trunk that trains: refused
     assert not model.trunk_is_frozen()
     with pytest.raises(ValueError):
