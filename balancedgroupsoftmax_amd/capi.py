@@ -274,8 +274,9 @@ def host_i64(a):
 
 
 def ptr(t):
-    """Device (or host) address of a tensor, NULL for None."""
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """Device (or host) address of a tensor as a plain integer, None (= NULL) for None: every pointer parameter of the
+    library is declared ``c_void_p``, which converts both (no ``c_void_p`` object per argument on the launch path)."""
+    return None if t is None else t.data_ptr()
 
 
 _RAW_STREAM = []
@@ -301,4 +302,5 @@ def raw_stream(device=None):
 
 
 def current_stream(device=None):
-    return ctypes.c_void_p(raw_stream(device))
+    """The ``bgs_stream_t`` argument of a launch on ``device``'s current stream (an integer handle, see :func:`ptr`)."""
+    return raw_stream(device)

@@ -2,7 +2,7 @@
 time until the LAST launch of n steps is enqueued (no synchronisation inside), wall time until the GPU has finished, and
 the CPU time the launching thread spent (time.thread_time).  enqueue ~ total and cpu ~ enqueue  => the host is the
 bottleneck; enqueue << total => the GPU is.
-python tools/host_bound.py [steps=40] [--cascade] [--bf16]"""
+python tools/host_bound.py [steps=40] [--cascade | --htc | --mask] [--bf16]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 argv = sys.argv[1:]
@@ -16,8 +16,9 @@ flags = argv[1:]                                   # e.g. --cascade --bf16
 dev = torch.device('cuda', 0)
 if '--bf16' in flags:
     BF.set_conv_math('bf16')
-step = bench.DetectorStep(dev, 0, 1, 2, 3 if '--cascade' in flags else 1, cascade='--cascade' in flags,
-                          conv_math='bf16' if '--bf16' in flags else 'bf16x6')
+x101 = '--cascade' in flags or '--htc' in flags
+step = bench.DetectorStep(dev, 0, 1, 2, 3 if x101 else 1, mask='--mask' in flags, cascade='--cascade' in flags,
+                          htc='--htc' in flags, conv_math='bf16' if '--bf16' in flags else 'bf16x6')
 
 
 def measure(fn, name):

@@ -13,9 +13,10 @@ flags = argv[1:]
 dev = torch.device('cuda', 0)
 if '--bf16' in flags:
     BF.set_conv_math('bf16')
-step = bench.DetectorStep(dev, 0, 1, 2, 3 if '--cascade' in flags else 1, cascade='--cascade' in flags,
-                          conv_math='bf16' if '--bf16' in flags else 'bf16x6')
-fn = step if '--seq' in flags else step.pipelined(depth=3 if '--cascade' in flags else 5)
+x101 = '--cascade' in flags or '--htc' in flags
+step = bench.DetectorStep(dev, 0, 1, 2, 3 if x101 else 1, mask='--mask' in flags, cascade='--cascade' in flags,
+                          htc='--htc' in flags, conv_math='bf16' if '--bf16' in flags else 'bf16x6')
+fn = step if '--seq' in flags else step.pipelined(depth=3 if x101 else 5)
 for _ in range(8):
     fn()
 torch.cuda.synchronize()
@@ -27,5 +28,5 @@ pr.disable()
 torch.cuda.synchronize()
 for key in ('tottime', 'cumtime'):
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(28)
-    print('\n'.join(l[:150] for l in s.getvalue().split('\n')[:45]))
+    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(40)
+    print('\n'.join(l[:150] for l in s.getvalue().split('\n')[:58]))
