@@ -94,3 +94,21 @@ def test_head_kernel_variant_rule_is_a_host_decision():
         assert lib.bgs_gs_head_variant_used(1024) == 0
     finally:
         lib.bgs_gs_head_variant(-1)
+
+
+def test_pointer_parameters_are_void_pointers_so_plain_integer_addresses_convert():
+    """``capi.ptr`` / ``capi.current_stream`` hand ctypes plain integers (``tensor.data_ptr()``, the raw stream handle)
+    and ``None`` for NULL — no ``c_void_p`` object per argument on the launch path.  That is only valid while every
+    pointer-like parameter in ``capi.SIGNATURES`` is declared ``c_void_p``: a typed ``POINTER(...)`` would refuse an int."""
+    import ctypes
+    import torch
+    scalars = (ctypes.c_int, ctypes.c_uint, ctypes.c_long, ctypes.c_ulong, ctypes.c_longlong, ctypes.c_ulonglong,
+               ctypes.c_size_t, ctypes.c_float, ctypes.c_double, ctypes.c_uint64, ctypes.c_int64, ctypes.c_uint32,
+               ctypes.c_int32, ctypes.c_bool)
+    for name, (_res, args) in capi.SIGNATURES.items():
+        for a in args:
+            assert a is ctypes.c_void_p or a in scalars, (name, a)
+    t = torch.arange(6, dtype=torch.float32)
+    assert capi.ptr(None) is None and capi.ptr(t) == t.data_ptr() and isinstance(capi.ptr(t), int)
+    ctypes.c_void_p.from_param(capi.ptr(t))                  # (what a c_void_p argtype does with it: accepted)
+    ctypes.c_void_p.from_param(None)
