@@ -312,11 +312,12 @@ class TwoStageDetector(nn.Module):
                                                 rcnn_test_cfg.nms, rcnn_test_cfg.max_per_img)
         return det_bboxes, det_labels, scores
 
-    def simple_test(self, img, img_meta, proposals=None, rescale=False):
-        """two_stage.py:267-289 (bbox branch): list of ``num_classes-1`` ``[k_c, 5]`` arrays."""
+    def simple_test(self, img, img_meta, proposals=None, rescale=False, feats=None):
+        """two_stage.py:267-289 (bbox branch): list of ``num_classes-1`` ``[k_c, 5]`` arrays.
+        ``feats``: ``extract_feat(img)`` computed ahead of this call (``train.TrunkPipeline(inference=True)``)."""
         from .post_processing import bbox2result
         assert self.with_bbox, 'Bbox head must be implemented.'
-        x = self.extract_feat(img)
+        x = self.extract_feat(img) if feats is None else feats
         proposal_list = (self.simple_test_rpn(x, img_meta, self.test_cfg.rpn)
                          if proposals is None else proposals)
         det_bboxes, det_labels, _ = self.simple_test_bboxes(x, img_meta, proposal_list,
@@ -477,11 +478,11 @@ class CascadeRCNN(TwoStageDetector):
         self._join_rpn_loss()
         return losses
 
-    def simple_test(self, img, img_meta, proposals=None, rescale=False):
+    def simple_test(self, img, img_meta, proposals=None, rescale=False, feats=None):
         """cascade_rcnn.py:300-393 (bbox branch, ensemble result): every stage re-regresses the
         1000 RoIs with its arg-max class, the class logits are averaged over the stages."""
         from .post_processing import bbox2result, multiclass_nms
-        x = self.extract_feat(img)
+        x = self.extract_feat(img) if feats is None else feats      # (ahead: train.TrunkPipeline(inference=True))
         proposal_list = (self.simple_test_rpn(x, img_meta, self.test_cfg.rpn)
                          if proposals is None else proposals)
         props, valid = proposal_list[0] if isinstance(proposal_list[0], tuple) \
@@ -641,7 +642,7 @@ class HybridTaskCascade(CascadeRCNN):
         return losses
 
     # -- test time -----------------------------------------------------------------------------
-    def simple_test(self, img, img_meta, proposals=None, rescale=False):
+    def simple_test(self, img, img_meta, proposals=None, rescale=False, feats=None):
         """htc.py:313-432 with ``keep_all_stages=False``: the ensemble boxes (stage-averaged class
         logits) and, per detection, the mean over stages of its class's mask probability
         ``[k, 28, 28]`` (``merge_aug_masks`` without weights; pasting / RLE is evaluation tooling)."""
@@ -654,7 +655,7 @@ class HybridTaskCascade(CascadeRCNN):
         from .post_processing import multiclass_nms
         if self.test_cfg.get('keep_all_stages', False):
             raise NotImplementedError('keep_all_stages=True (per-stage results) is not built')
-        x = self.extract_feat(img)
+        x = self.extract_feat(img) if feats is None else feats      # (ahead: train.TrunkPipeline(inference=True))
         proposal_list = (self.simple_test_rpn(x, img_meta, self.test_cfg.rpn)
                          if proposals is None else proposals)
         semantic_feat = self.semantic_head(x)[1] if self.with_semantic else None

@@ -483,10 +483,15 @@ class TrunkPipeline(object):
             losses = model(batch.img, batch.meta, return_loss=True, ..., feats=feats)
             ...backward, DistOptimizerStep...
 
-    Raises if the trunk trains (``selectp = 0``): its features then depend on the previous step's update."""
+    Raises if the trunk trains (``selectp = 0``): its features then depend on the previous step's update.
 
-    def __init__(self, model, depth=2, lane=3):
-        if not model.trunk_is_frozen():
+    Test time (``inference=True``): the same pieces ahead of ``simple_test(img, meta, feats=pipe.take())`` — the next
+    image's trunk beside this image's RPN / NMS / RoI head / 1230-class NMS and the D2H copy of its result."""
+
+    def __init__(self, model, depth=2, lane=3, inference=False):
+        # ``inference=True``: a test loop (``model(img, meta, return_loss=False, feats=pipe.take())``) — nothing updates
+        # the parameters between batches, so the frozen-trunk condition does not apply
+        if not inference and not model.trunk_is_frozen():
             raise ValueError('TrunkPipeline needs a frozen backbone / neck (selectp = 1 or 3); with a trainable trunk '
                              'the next batch\'s features depend on this step\'s update')
         bb = model.backbone

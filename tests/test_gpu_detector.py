@@ -408,6 +408,23 @@ def test_simple_test_matches_stepwise_oracle(tmp_path):
     assert isinstance(result, list) and len(result) == 1230
     assert sum(r.shape[0] for r in result) == 300
     assert all(r.dtype == np.float32 and r.shape[1] == 5 for r in result)
+    # the test loop with the NEXT image's trunk launched ahead (train.TrunkPipeline(inference=True), ``feats=``): the same
+    # detections, image by image, for two different images and both pipeline depths
+    from balancedgroupsoftmax_amd import train
+    img_b = torch.flip(img, dims=[3]).contiguous() * 0.8
+    seq = [model(im, metas, return_loss=False, rescale=True) for im in (img, img_b, img_b, img)]
+    for depth in (2, 3):
+        pipe = train.TrunkPipeline(model, depth=depth, inference=True)
+        ims = [img, img_b, img_b, img]
+        for k in range(pipe.depth - 1):
+            pipe.push(ims[k])
+        for i, im in enumerate(ims):
+            feats = pipe.take()
+            nxt = i + pipe.depth - 1
+            pipe.push(ims[nxt] if nxt < len(ims) else None)
+            got = model(im, metas, return_loss=False, rescale=True, feats=feats)
+            assert all(np.array_equal(a_, b_) for a_, b_ in zip(seq[i], got)), (depth, i)
+    assert not all(np.array_equal(a_, b_) for a_, b_ in zip(seq[0], seq[1]))
     # stepwise: the same network pieces; numpy oracles for the score merge and the 1230-class NMS
     with torch.no_grad():
         x = model.extract_feat(img)

@@ -42,6 +42,30 @@ def main():
         res = model(img, metas, return_loss=False, rescale=True)      # ends in a D2H copy
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
+    # the same loop with the NEXT image's trunk launched ahead on its own streams (train.TrunkPipeline(inference=True)):
+    # same detections, the trunk of image i + 1 beside image i's RPN / NMS / RoI head / 1230-class NMS / D2H copy
+    from balancedgroupsoftmax_amd import train
+    import numpy as np
+    piped = {}
+    for depth in (2, 3):
+        pipe = train.TrunkPipeline(model, depth=depth, inference=True)
+        for _ in range(pipe.depth - 1):
+            pipe.push(img)
+        for _ in range(3):
+            feats = pipe.take()
+            pipe.push(img)
+            res2 = model(img, metas, return_loss=False, rescale=True, feats=feats)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            feats = pipe.take()
+            pipe.push(img)
+            res2 = model(img, metas, return_loss=False, rescale=True, feats=feats)
+        torch.cuda.synchronize()
+        piped[depth] = (time.perf_counter() - t0) / iters * 1e3
+        pipe.drain()
+        torch.cuda.synchronize()
+        assert len(res2) == len(res) and all(np.array_equal(a, b) for a, b in zip(res, res2)), 'pipelined detections differ'
     # device-only portion of the post-processing
     from balancedgroupsoftmax_amd.post_processing import multiclass_nms
     with torch.no_grad():
@@ -57,8 +81,13 @@ def main():
         multiclass_nms(boxes, scores, 0.0, dict(type='nms', iou_thr=0.5), 300)
     torch.cuda.synchronize()
     ms_nms = (time.perf_counter() - t0) / iters * 1e3
+    best = min(piped.values())
     print('{"simple_test_ms_per_img": %.3f, "img_per_s": %.2f, "multiclass_nms_1230x1000_ms": %.3f, '
-          '"dets": %d}' % (ms, 1e3 / ms, ms_nms, sum(r.shape[0] for r in res)))
+          '"dets": %d, "pipelined_ms_per_img": %.3f, "pipelined_img_per_s": %.2f, "pipelined_by_depth": %s, '
+          '"pipelined_note": "train.TrunkPipeline(inference=True): the next image\'s trunk on its own streams beside this '
+          'image\'s RPN / NMS / RoI head / multiclass NMS / D2H copy; identical detections (asserted)"}'
+          % (ms, 1e3 / ms, ms_nms, sum(r.shape[0] for r in res), best, 1e3 / best,
+             str({k: round(v, 3) for k, v in piped.items()}).replace("'", '"').replace('2:', '"2":').replace('3:', '"3":')))
 
 
 if __name__ == '__main__':
