@@ -647,10 +647,10 @@ class HybridTaskCascade(CascadeRCNN):
         logits) and, per detection, the mean over stages of its class's mask probability
         ``[k, 28, 28]`` (``merge_aug_masks`` without weights; pasting / RLE is evaluation tooling)."""
         from .post_processing import bbox2result
-        det_bboxes, det_labels, masks = self.simple_test_dets(img, img_meta, proposals, rescale)
+        det_bboxes, det_labels, masks = self.simple_test_dets(img, img_meta, proposals, rescale, feats=feats)
         return bbox2result(det_bboxes, det_labels, self.bbox_head[-1].num_classes), masks
 
-    def simple_test_dets(self, img, img_meta, proposals=None, rescale=False):
+    def simple_test_dets(self, img, img_meta, proposals=None, rescale=False, feats=None):
         """-> ``(det_bboxes [k,5], det_labels [k], mask_probs [k,28,28])`` device tensors."""
         from .post_processing import multiclass_nms
         if self.test_cfg.get('keep_all_stages', False):

@@ -281,6 +281,10 @@ def test_cascade_rcnn_training_iteration_and_test(tmp_path):
             h.fc_cls.weight.mul_(30.0)
     res = model(img[:1], metas[:1], return_loss=False, rescale=False)
     assert len(res) == 1230 and sum(r.shape[0] for r in res) == 300
+    with torch.no_grad():       # features handed in (train.TrunkPipeline(inference=True)): the same detections
+        ahead = model.extract_feat(img[:1])
+    res2 = model(img[:1], metas[:1], return_loss=False, rescale=False, feats=ahead)
+    assert all(np.array_equal(a_, b_) for a_, b_ in zip(res, res2))
 
 
 @pytest.mark.parametrize('agnostic', [True, False])

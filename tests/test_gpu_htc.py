@@ -262,6 +262,11 @@ def test_htc_simple_test_ensemble(tmp_path):
     assert len(bbox_res) == 1230 and sum(r.shape[0] for r in bbox_res) == 100
     assert tuple(masks.shape) == (100, 28, 28)
     assert float(masks.min()) >= 0.0 and float(masks.max()) <= 1.0 and torch.isfinite(masks).all()
+    # features computed ahead of the call (train.TrunkPipeline(inference=True) hands them in as ``feats=``): same result
+    with torch.no_grad():
+        ahead = model.extract_feat(img[:1])
+    bbox_res2, masks2 = model(img[:1], metas[:1], return_loss=False, rescale=False, feats=ahead)
+    assert all(np.array_equal(a_, b_) for a_, b_ in zip(bbox_res, bbox_res2)) and torch.equal(masks, masks2)
     # the mask ensemble is the mean of the three stages' probabilities of each detection's class:
     # recompute it from the heads with the reference-signature forward
     model.mask_info_flow = False
