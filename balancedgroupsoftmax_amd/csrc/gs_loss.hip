@@ -34,7 +34,11 @@ namespace {
 constexpr int kBlock = 256;   // generic fallback + helper kernels
 constexpr int kWaves = kBlock / BGS_WAVE;
 constexpr int kMaxGrid = 2048;
-int g_rowwave_pf = 3;        // bgs_gs_loss_tuning: 0 = no next-row prefetch | 1 = prefetch | 2 / 3 / 4 = prefetch + non-temporal
+// workspace = [BGS_MAX_BINS][<= kMaxGrid] partial sums, then one int: the grid that wrote them (the main kernels
+// record it, bgs_gs_loss_reduce reads it — the row-per-wave kernel's grid is not a function of N alone)
+constexpr int kGridSlot = kMaxGrid * BGS_MAX_BINS;
+int g_rowwave_pf = 5;        // bgs_gs_loss_tuning: 5 (default) = row-per-wave kernel for 4096 <= N < 12288 rows, mode 3 elsewhere | 6 / 7 = row-per-wave
+                             // for every N >= the row threshold with plain / non-temporal row loads | 0 = no next-row prefetch | 1 = prefetch | 2 / 3 / 4 = prefetch + non-temporal
                              // loads / stores / both (A/B; 3 = default: profiles/r8e_gs_rowwave_prefetch_ab.txt)
 
 // PF (rows of at most 2 * 256 * VEC floats — W <= 2048 for the 16-byte path: every LVIS table): the NEXT row of the
@@ -140,6 +144,103 @@ __global__ __launch_bounds__(kBlock) void gs_loss_rowwave_kernel(
   // bin b lives in wave b % kWaves, lane b: no cross-wave reduction needed
   if (lane < B && (lane % kWaves) == wave)
     partial[(size_t)lane * gridDim.x + blockIdx.x] = lacc;
+  if (blockIdx.x == 0 && tid == 0) reinterpret_cast<int*>(partial)[kGridSlot] = gridDim.x;
+}
+
+// Round 6: a row per WAVE, the LDS row private to it (gs_rowwave.h, wave_phase) — no workgroup barrier anywhere in
+// the row loop.  The 4-wave-per-row kernel above parks a whole workgroup twice per row (row staged -> sweeps ->
+// gradient out) and its 8 workgroups per CU keep 8 rows in flight; here 32 independent waves per CU each hold a
+// row in LDS and the next one in registers, every wave streams at its own pace, and the sweeps of one wave hide
+// under the loads and stores of the 31 others.  KV = 16-byte pieces of a row per lane (W <= 256 * KV).  Per-bin
+// arithmetic is bin_loss_registers, unchanged: the gradient is bit-identical to the kernel above; a bin's loss is
+// the same terms summed in a different order (wave w of workgroup g takes rows 4 g + w, + 4 * grid, ...; the four
+// waves' sums are added in wave order at the end).
+template <int KV, bool WRITE_GRAD, bool NTL = false>
+__global__ __launch_bounds__(kBlock) void gs_loss_wavepriv_kernel(
+    const float* __restrict__ logits, const int32_t* __restrict__ bin_labels,
+    const float* __restrict__ weights, const float* __restrict__ avg, bgs::BinGeom geom, int N,
+    int B, int W, int wpad, float* __restrict__ partial, float* __restrict__ dlogits) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [kWaves][wpad] + read slack (launcher)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = bgs::uniform(tid >> 6);
+  float* row = smem + (size_t)wave * wpad;
+  const int nw = gridDim.x * kWaves;
+  const int nq = W >> 2;                                   // 16-byte pieces of a row (W % 4 == 0)
+
+  float my_inv_avg = 0.f;
+  if (lane < B) my_inv_avg = 1.f / (avg ? avg[lane] : fmaxf((float)N, 1.f));
+  float lacc = 0.f;                                        // lane b: the loss of bin b over this wave's rows
+
+  float pf[KV][4];
+  int pf_bl = 0;
+  float pf_w = 1.f;
+  auto prefetch = [&](int r) {
+    const float* g = logits + (size_t)r * W;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      const int q = lane + BGS_WAVE * k;
+      if (q < nq) {
+        if (NTL) bgs::load_vec_nt<4>(g + 4 * q, pf[k]);
+        else bgs::load_vec<4>(g + 4 * q, pf[k]);
+      }
+    }
+    if (lane < B) {
+      pf_bl = bin_labels[(size_t)lane * N + r];
+      pf_w = weights ? weights[(size_t)lane * N + r] : 1.f;
+    }
+  };
+  int r = blockIdx.x * kWaves + wave;
+  if (r < N) prefetch(r);
+  for (; r < N; r += nw) {
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      const int q = lane + BGS_WAVE * k;
+      if (q < nq) bgs::store_vec<4>(row + 4 * q, pf[k]);
+    }
+    const int my_bl = pf_bl;
+    const float my_coef = lane < B ? pf_w * my_inv_avg : 0.f;
+    if (r + nw < N) prefetch(r + nw);                      // in flight under this row's sweeps
+    bgs::wave_phase();
+    for (int b = 0; b < B; ++b) {
+      const int s = geom.start[b], n = geom.len[b];
+      const float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_coef), b));
+      const int tgt = min(max(__builtin_amdgcn_readlane(my_bl, b), 0), n - 1);
+      float* seg = row + s;
+      if (coef == 0.f) {                                   // wave-uniform: no weight -> zero gradient
+        if (WRITE_GRAD)
+          for (int j = lane; j < n; j += BGS_WAVE) seg[j] = 0.f;
+        continue;
+      }
+      const float term = bgs::bin_loss_registers<WRITE_GRAD>(seg, n, lane, coef, tgt);
+      if (lane == b) lacc += term;
+    }
+    if (WRITE_GRAD) {
+      bgs::wave_phase();
+      float* g = dlogits + (size_t)r * W;
+#pragma unroll
+      for (int k = 0; k < KV; ++k) {
+        const int q = lane + BGS_WAVE * k;
+        if (q < nq) {
+          float t[4];
+          bgs::load_vec<4>(row + 4 * q, t);
+          bgs::store_vec_nt<4>(g + 4 * q, t);
+        }
+      }
+      bgs::wave_phase();
+    }
+  }
+  // the four waves' sums of a bin, added in wave order (fixed: bitwise reproducible)
+  __syncthreads();
+  if (lane < B) smem[wave * BGS_MAX_BINS + lane] = lacc;
+  __syncthreads();
+  if (tid < B) {
+    float s = smem[tid];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) s += smem[w * BGS_MAX_BINS + tid];
+    partial[(size_t)tid * gridDim.x + blockIdx.x] = s;
+  }
+  if (blockIdx.x == 0 && tid == 0) reinterpret_cast<int*>(partial)[kGridSlot] = gridDim.x;
 }
 
 __device__ __forceinline__ float block_max(float v, float* sm) {
@@ -207,6 +308,7 @@ __global__ __launch_bounds__(kBlock) void gs_loss_generic_kernel(
   }
   __syncthreads();
   if (tid < B) partial[(size_t)tid * gridDim.x + blockIdx.x] = acc[tid];
+  if (blockIdx.x == 0 && tid == 0) reinterpret_cast<int*>(partial)[kGridSlot] = gridDim.x;
 }
 
 // loss[b] = sum_g partial[b, g] in a fixed order.  1024 threads: all loads of a bin are issued
@@ -217,6 +319,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
                                                                float scale) {
   __shared__ float sm[BGS_MAX_BINS][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (G < 0) G = reinterpret_cast<const int*>(partial)[kGridSlot];     // recorded by the kernel that wrote the partials
   float acc[BGS_MAX_BINS];
 #pragma unroll
   for (int b = 0; b < BGS_MAX_BINS; ++b) {
@@ -1128,7 +1231,7 @@ void launch_rowwave(bool grad, int grid, hipStream_t st, const float* logits, co
   if (grad && pf && g_rowwave_pf >= 2) {
 #define GS_NT(NT_) case NT_: hipLaunchKernelGGL((gs_loss_rowwave_kernel<VEC, true, true, NT_>), dim3(grid), dim3(kBlock), lds, st, \
                                                 logits, bl, w, avg, geom, N, B, W, wpad, partial, dlogits); break;
-    switch (g_rowwave_pf - 1) { GS_NT(1) GS_NT(2) default: GS_NT(3) }
+    switch (g_rowwave_pf >= 5 ? 2 : g_rowwave_pf - 1) { GS_NT(1) GS_NT(2) default: GS_NT(3) }   // modes 5 - 7 below their row threshold: mode 3
 #undef GS_NT
   } else if (grad && pf)
     hipLaunchKernelGGL((gs_loss_rowwave_kernel<VEC, true, true>), dim3(grid), dim3(kBlock), lds, st,
@@ -1144,11 +1247,71 @@ void launch_rowwave(bool grad, int grid, hipStream_t st, const float* logits, co
 // one workgroup per row; at most kMaxGrid workgroups (grid-stride beyond)
 inline int loss_grid(int N) { return N <= 0 ? 1 : (N < kMaxGrid ? N : kMaxGrid); }
 
+// Row-per-wave kernel (modes 5 - 7): eligible for 16-byte rows of at most 2048 floats whose bins fit the register sweep.
+// Where it pays (profiles/r10a / r10c_gs_stream_ab.txt, two boxes): 4096 rows 8.6 vs 8.9 - 9.2 us, 8192 rows 14.2 vs 16.4 -
+// 17.1 us (-15 %); from 16,384 rows the 4-wave-per-row kernel (mode 3) is the faster one again (28.0 vs 30.0 us; at
+// 65,536 rows 122 vs 126 us — both AT the rate of a hipMemcpyAsync D2D of the same 324 + 324 MB on the same box,
+// 5.3 - 5.4 TB/s).  Default (mode 5): rows in [kWavePrivMinRows, kWavePrivMaxRows); modes 6 / 7 ignore the upper bound.
+// Grid: every workgroup resident at once (LDS: 4 rows + read slack each), rows dealt round-robin.
+constexpr int kWavePrivMinRows = 4096;
+constexpr int kWavePrivMaxRows = 12288;
+int g_wavepriv_min_rows = kWavePrivMinRows;
+
+inline bool wavepriv_eligible(const bgs::BinGeom& geom, int B, int W, int vec) {
+  if (vec != 4 || W > 2048) return false;
+  for (int b = 0; b < B; ++b)
+    if (geom.len[b] > BGS_WAVE * bgs::kSweep) return false;
+  return true;
+}
+
+inline int wavepriv_grid(int N, size_t lds) {
+  int per_cu = (int)((160u * 1024u) / lds);
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu < 1) per_cu = 1;
+  const int cap = 256 * per_cu;
+  const int want = (N + kWaves - 1) / kWaves;
+  return want < cap ? want : cap;
+}
+
+// returns the grid it launched (the number of per-bin partial sums in the workspace)
+int launch_wavepriv(bool grad, hipStream_t st, const float* logits, const int32_t* bl, const float* w,
+                    const float* avg, const bgs::BinGeom& geom, int N, int B, int W, float* partial,
+                    float* dlogits) {
+  const int wpad = W;                                      // W % 4 == 0
+  const size_t lds = sizeof(float) * ((size_t)kWaves * wpad + bgs::row_read_slack(geom, B, W));
+  const int grid = wavepriv_grid(N, lds);
+  const int kv = (W / 4 + BGS_WAVE - 1) / BGS_WAVE;
+  // Non-temporal row loads (mode 7, A/B only): a plain copy of this working set gains 10 - 15 % from the hint on BOTH
+  // sides once read + written bytes exceed the 256 MB Infinity Cache (324 + 324 MB: 5.4 -> 6.2 - 6.5 TB/s,
+  // tools/hbm_copy_bench.hip, profiles/r10b_hbm_copy_bench.txt) — inside this kernel and the 4-wave one it LOSES 2 - 20 %
+  // at every size (profiles/r10c_gs_stream_ab.txt), so no default mode uses it.
+  const bool ntl = g_rowwave_pf == 7;
+#define GS_WP(KV_)                                                                                          \
+  do {                                                                                                      \
+    if (grad && ntl)                                                                                        \
+      hipLaunchKernelGGL((gs_loss_wavepriv_kernel<KV_, true, true>), dim3(grid), dim3(kBlock), lds, st,     \
+                         logits, bl, w, avg, geom, N, B, W, wpad, partial, dlogits);                        \
+    else if (grad)                                                                                          \
+      hipLaunchKernelGGL((gs_loss_wavepriv_kernel<KV_, true>), dim3(grid), dim3(kBlock), lds, st, logits,   \
+                         bl, w, avg, geom, N, B, W, wpad, partial, dlogits);                                \
+    else                                                                                                    \
+      hipLaunchKernelGGL((gs_loss_wavepriv_kernel<KV_, false>), dim3(grid), dim3(kBlock), lds, st, logits,  \
+                         bl, w, avg, geom, N, B, W, wpad, partial, dlogits);                                \
+  } while (0)
+  if (kv <= 2) GS_WP(2);
+  else if (kv <= 5) GS_WP(5);
+  else GS_WP(8);
+#undef GS_WP
+  return grid;
+}
+
 }  // namespace
 
 // tuning / test hook: 0 = the round-3 kernel | 1 = next row fetched ahead | 2 / 3 / 4 = .. + non-temporal row loads /
 // gradient stores / both (3 = default)
-extern "C" void bgs_gs_loss_tuning(int prefetch) { g_rowwave_pf = prefetch < 0 ? 0 : (prefetch > 4 ? 4 : prefetch); }
+extern "C" void bgs_gs_loss_tuning(int prefetch) { g_rowwave_pf = prefetch < 0 ? 0 : (prefetch > 7 ? 5 : prefetch); }
+// rows from which mode 5 applies (< 0: back to the default); a test / A/B hook like the one above
+extern "C" void bgs_gs_loss_wavepriv_min_rows(int rows) { g_wavepriv_min_rows = rows < 0 ? kWavePrivMinRows : rows; }
 
 extern "C" size_t bgs_gs_loss_workspace_bytes(int N, int B) {
   (void)N;
@@ -1177,7 +1340,7 @@ extern "C" int bgs_gs_loss_fwd_bwd(const float* logits, const int32_t* bin_label
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
   const bool grad = dlogits != nullptr;
-  const int grid = loss_grid(N);
+  int grid = loss_grid(N);
   if (N == 0) {
     (void)hipMemsetAsync(partial, 0, sizeof(float) * B, st);
   } else {
@@ -1187,7 +1350,10 @@ extern "C" int bgs_gs_loss_fwd_bwd(const float* logits, const int32_t* bin_label
     else if (W % 2 == 0 && al % 8 == 0) vec = 2;
     // wave kernel: bins must tile [0, W) (true for tables built by tools/lvis_analyse.py) and
     // two staged rows must fit the 64 KB default LDS window
-    if (!force_generic() && tiles && W <= 7936) {
+    if (!force_generic() && tiles && g_rowwave_pf >= 5 && N >= g_wavepriv_min_rows &&
+        (g_rowwave_pf > 5 || N < kWavePrivMaxRows) && wavepriv_eligible(geom, B, W, vec)) {
+      grid = launch_wavepriv(grad, st, logits, bin_labels, weights, avg, geom, N, B, W, partial, dlogits);
+    } else if (!force_generic() && tiles && W <= 7936) {
       if (vec == 4) launch_rowwave<4>(grad, grid, st, logits, bin_labels, weights, avg, geom, N, B, W, partial, dlogits);
       else if (vec == 2) launch_rowwave<2>(grad, grid, st, logits, bin_labels, weights, avg, geom, N, B, W, partial, dlogits);
       else launch_rowwave<1>(grad, grid, st, logits, bin_labels, weights, avg, geom, N, B, W, partial, dlogits);
@@ -1470,7 +1636,7 @@ extern "C" int bgs_gs_loss_reduce(const void* workspace, int N, int B, float* lo
                                   bgs_stream_t stream) {
   if (N < 0 || B <= 0 || B > BGS_MAX_BINS || !workspace || !loss_out) return BGS_ERR_INVALID_ARG;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream,
-                     (const float*)workspace, loss_grid(N), B, loss_out, 1.0f);
+                     (const float*)workspace, N == 0 ? 1 : -1, B, loss_out, 1.0f);
   BGS_RETURN_LAUNCH_STATUS();
 }
 

@@ -158,6 +158,58 @@ __device__ __forceinline__ void bin_scale_inplace(float* __restrict__ seg, int n
   }
 }
 
+// ---- row-per-wave-PRIVATE form (round 6) --------------------------------------------------------
+// A wave owns a row end to end: its LDS row is touched by no other wave, so the only ordering the
+// phases need is the wave's own program order (the LDS serves one wave's instructions in issue
+// order).  wave_phase() keeps the COMPILER from moving a lane's LDS accesses across the point where
+// other lanes' data is consumed; it emits no instruction that waits on another wave.
+__device__ __forceinline__ void wave_phase() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Floats a wave reads past the end of ITS row in bin_loss_registers / bin_probs_registers (the sweep
+// always issues kSweep reads of 64 lanes from a bin's start): the next wave's row absorbs them inside
+// a workgroup, the last wave's row needs this much slack behind it.
+inline int row_read_slack(const BinGeom& g, int B, int W) {
+  int over = 0;
+  for (int b = 0; b < B; ++b) {
+    const int end = g.start[b] + BGS_WAVE * kSweep;
+    if (g.len[b] > 0 && end - W > over) over = end - W;
+  }
+  return (over + 3) & ~3;
+}
+
+// One bin (at most 64*kSweep columns) of a row in LDS -> its softmax, in place: p = exp(z - m) * (1 / S) with the
+// operations and their order of bin_softmax_inplace + bin_scale_inplace (bit-identical probabilities), but the
+// bin is read ONCE and written ONCE.
+__device__ __forceinline__ void bin_probs_registers(float* __restrict__ seg, int n, int lane) {
+  float x[kSweep];
+  bool ok[kSweep];
+#pragma unroll
+  for (int u = 0; u < kSweep; ++u) {
+    const int j = lane + BGS_WAVE * u;
+    ok[u] = j < n;
+    x[u] = seg[j];
+  }
+  float pm = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < kSweep; ++u) pm = fmaxf(pm, ok[u] ? x[u] : -INFINITY);
+  const float m = wave_max(pm);
+  float ps = 0.f;
+#pragma unroll
+  for (int u = 0; u < kSweep; ++u) {
+    x[u] = __builtin_amdgcn_exp2f((x[u] - m) * kLog2e);
+    if (ok[u]) ps += x[u];
+  }
+  const float k = 1.f / wave_sum(ps);
+#pragma unroll
+  for (int u = 0; u < kSweep; ++u) {
+    if (ok[u]) seg[lane + BGS_WAVE * u] = x[u] * k;
+  }
+}
+
 // global row -> LDS row, cooperatively by `nthreads` threads (VEC floats per thread per step)
 template <int VEC>
 __device__ __forceinline__ void stage_row(const float* __restrict__ g, float* __restrict__ row,

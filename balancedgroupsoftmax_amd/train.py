@@ -282,9 +282,18 @@ class OverlappedGradExchange(object):
             for p in self.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
-    def _launch(self, bi):
+    def _launch(self, bi, had_grad=None):
+        """Packs bucket ``bi`` and starts its all-reduce.  Behind the gradients ride ``len(bucket)`` flags — 1 where this
+        rank HAD a gradient for the parameter, 0 where ``finish()`` put a zero placeholder — so that after the SUM every
+        rank knows, per parameter, whether ANY rank contributed (the layout is the same on every rank whether the bucket
+        was completed by the hooks or flushed by ``finish()``)."""
         bucket = self.buckets[bi]
-        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+        dev = bucket[0].grad.device
+        if had_grad is None:
+            flags = torch.ones(len(bucket), dtype=bucket[0].grad.dtype, device=dev)
+        else:
+            flags = torch.tensor(had_grad, dtype=bucket[0].grad.dtype, device=dev)
+        flat = torch.cat([p.grad.reshape(-1) for p in bucket] + [flags])
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._inflight.append((bi, flat, work))
 
@@ -295,31 +304,44 @@ class OverlappedGradExchange(object):
             self._launch(bi)
 
     def finish(self):
-        """Call after ``backward()``: flushes buckets whose parameters received no gradient this
-        iteration, waits for the collectives and writes the averaged gradients back."""
+        """Call after ``backward()``: flushes the buckets the hooks did not complete (a parameter without a gradient
+        this iteration), waits for the collectives and writes the averaged gradients back.
+
+        Every incomplete bucket is flushed on every rank — also one in which THIS rank has no gradient at all — with a
+        zero placeholder for each missing gradient, so the ranks issue the same collectives with the same layout.  A
+        placeholder is dropped again (``p.grad = None``: the reference's ``_allreduce_coalesced`` leaves such a
+        parameter out, dist_utils.py:33-38, and SGD then skips it — no weight decay) only where NO rank contributed;
+        where another rank did, every rank keeps the same averaged gradient, so the replicas cannot drift apart.
+        (Ranks must still complete the same buckets through the hooks in the same order — the usual data-parallel
+        contract; the reference has it too.)"""
         if self.world_size == 1:
             return
-        filled = []
+        filled = {}
         for bi, left in enumerate(self._pending):
-            if left > 0 and any(p.grad is not None for p in self.buckets[bi]):
+            if left > 0:
+                had = []
                 for p in self.buckets[bi]:
+                    had.append(0.0 if p.grad is None else 1.0)
                     if p.grad is None:
                         p.grad = torch.zeros_like(p)          # keeps the bucket's flat layout equal on every rank
-                        filled.append(p)
-                self._launch(bi)
+                        filled[id(p)] = p
+                self._launch(bi, had)
         for bi, flat, work in self._inflight:
             work.wait()
+            bucket = self.buckets[bi]
+            nb = len(bucket)
+            contributed = None
+            if any(id(p) in filled for p in bucket):
+                contributed = flat[flat.numel() - nb:].tolist()   # host read only on this (rare) path
             flat.div_(self.world_size)
             off = 0
-            for p in self.buckets[bi]:
+            for k, p in enumerate(bucket):
                 n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                if contributed is not None and id(p) in filled and contributed[k] == 0.0:
+                    p.grad = None                             # no rank had a gradient: as in the reference
+                else:
+                    p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
-        # a parameter that received no gradient must look to the optimizer as it does in the reference
-        # (`_allreduce_coalesced` leaves it out, dist_utils.py:33-38, and SGD skips `grad is None`): with the zero
-        # placeholder left in place it would still be weight-decayed
-        for p in filled:
-            p.grad = None
         self._inflight = []
         self._pending = [len(b) for b in self.buckets]
 

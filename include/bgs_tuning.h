@@ -119,6 +119,16 @@ int bgs_conv_bfx_wide_last_launch(void);
  * current row's sweeps | 2 / 3 / 4 = 1 + non-temporal row loads / gradient stores / both.  3 is the default
  * (N = 65,536: 4.5 -> 5.3 TB/s).  Bit-identical results in every mode. */
 void bgs_gs_loss_tuning(int prefetch);
+/* Round 6: prefetch 5 (the default) = the row-per-WAVE kernel (gs_loss_wavepriv_kernel: a wave owns a row in a private
+ * LDS row, no workgroup barrier in the row loop) for 4096 <= N < 12288 rows of 16-byte-aligned tables whose bins fit the
+ * register sweep (8192 rows: 16.4 -> 14.2 us), mode 3 elsewhere (faster again from 16,384 rows); 6 / 7 = row-per-wave for
+ * every N >= the threshold with plain / non-temporal row loads (A/B).  Gradient bit-identical to modes 0 - 4, the per-bin
+ * losses are the same terms summed in a different order.  bgs_gs_loss_wavepriv_min_rows: the row threshold (< 0: default).
+ * bgs_gs_merge_tuning (csrc/gs_merge.hip, _merge_score gs_bbox_head_with0.py:239-273): mode 1 (default) = 2 = row-per-wave
+ * kernel with 16-byte score stores for N >= min_rows (< 0: default 4096; R = 65,536: 184 -> 124 - 132 us) | 3 = .. with
+ * non-temporal row loads (A/B) | 0 = the 4-wave-per-row kernel.  Bit-identical scores in every mode. */
+void bgs_gs_loss_wavepriv_min_rows(int rows);
+void bgs_gs_merge_tuning(int mode, int min_rows);
 
 #ifdef __cplusplus
 }

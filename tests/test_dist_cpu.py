@@ -233,3 +233,66 @@ def test_overlapped_exchange_world_size_8_uneven_last_bucket_and_a_parameter_wit
     for a, b, m in zip(first, last, mean):
         assert torch.equal(a, b)                            # the same bits on every rank
         assert torch.allclose(a, m, atol=1e-6, rtol=1e-5)
+
+
+def _uneven_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Linear(6, 4)
+        extra = torch.nn.Linear(4, 4)                       # in the graph of rank 0 only
+        unused = torch.nn.Linear(3, 3)                      # in no rank's graph
+        params = list(net.parameters()) + list(extra.parameters()) + list(unused.parameters())
+        ex = train.OverlappedGradExchange(params, world, bucket_bytes=1 << 20)   # ONE bucket: never completed by hooks
+        assert len(ex.buckets) == 1
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(40 + rank))
+        for it in range(2):
+            for p in params:
+                p.grad = None
+            y = net(x)
+            if rank == 0:
+                y = extra(y)
+            y.pow(2).mean().backward()
+            ex.finish()
+        assert all(p.grad is None for p in unused.parameters())           # nobody contributed: dropped, as in the reference
+        assert all(p.grad is not None for p in extra.parameters())        # rank 0 contributed: EVERY rank keeps the mean
+        torch.save([p.grad.clone() for p in list(net.parameters()) + list(extra.parameters())],
+                   os.path.join(out_dir, 'uneven_rank%d.pt' % rank))
+        ex.remove()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_exchange_keeps_ranks_consistent_when_only_one_rank_has_a_gradient(tmp_path):
+    """a parameter with a gradient on rank 0 and none on rank 1.  The zero placeholder of rank 1 takes
+    part in the SUM; afterwards BOTH ranks must hold the same averaged gradient (rank 1 used to reset its copy to
+    ``None`` and the replicas drifted apart), while a parameter without a gradient on every rank is ``None`` again
+    on every rank (dist_utils.py:33-38 leaves it out; SGD skips it)."""
+    world = 2
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_uneven_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a = torch.load(os.path.join(str(tmp_path), 'uneven_rank0.pt'))
+    b = torch.load(os.path.join(str(tmp_path), 'uneven_rank1.pt'))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # expected: mean over ranks, rank 1 contributing zero to `extra`
+    torch.manual_seed(0)
+    net = torch.nn.Linear(6, 4)
+    extra = torch.nn.Linear(4, 4)
+    mean = [torch.zeros_like(p) for p in list(net.parameters()) + list(extra.parameters())]
+    for rank in range(world):
+        net.zero_grad()
+        extra.zero_grad()
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(40 + rank))
+        y = net(x)
+        if rank == 0:
+            y = extra(y)
+        y.pow(2).mean().backward()
+        for m, p in zip(mean, list(net.parameters()) + list(extra.parameters())):
+            if p.grad is not None:
+                m += p.grad / world
+    for x, m in zip(a, mean):
+        assert torch.allclose(x, m, atol=1e-6, rtol=1e-5)

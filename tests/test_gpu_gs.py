@@ -239,6 +239,86 @@ def test_rowwave_next_row_prefetch_is_bit_identical(N):
         np.testing.assert_array_equal(out[0][1], o[1])
 
 
+@pytest.mark.parametrize('N', [1, 3, 6, 257, 8192, 8195, 65536])
+@pytest.mark.parametrize('table', ['lvis5', 'bins9'])
+def test_row_per_wave_loss_kernel_vs_row_per_workgroup_kernel(N, table):
+    """``gs_loss_wavepriv_kernel`` (round 6: a wave owns a row in a private LDS row, no workgroup barrier; mode 5, the
+    default from 8192 rows — here forced on from the first row through ``bgs_gs_loss_wavepriv_min_rows``) against the
+    round-3 kernel (mode 0): the whole gradient bit for bit (same per-bin arithmetic), the per-bin losses to 2e-6
+    relative (the same terms in another summation order) and to the fp64 oracle within the 1e-4 of the north star;
+    ragged sizes: fewer rows than waves (1, 3), rows that are not a multiple of the 4 waves of a workgroup (6, 257,
+    8195).  The 9-bin table has bins of other widths and starts (16-byte pieces that straddle three bins)."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    counts = gs_tables.synthetic_instance_counts(C, seed=0)
+    if table == 'lvis5':
+        l2b, ps, _ = gs_tables.build_group_tables(counts)
+    else:
+        l2b, ps, _ = gs_tables.build_group_tables(counts, thresholds=(3, 10, 30, 100, 300, 1000, 3000))
+    W = int(ps[:, 1].sum())
+    B = ps.shape[0]
+    if W % 4:
+        pytest.skip('table width %d is not a multiple of 4: the row-per-wave kernel does not apply' % W)
+    batch = gs_oracle.make_roi_batch(N, W, C, seed=N + B)
+    bl_dev, w, avg = BF.gs_prepare(dev(batch['labels']), dev(l2b), 8.0, seed=9)
+    out = []
+    try:
+        lib.bgs_gs_loss_wavepriv_min_rows(0)
+        for mode in (6, 7, 0):                               # plain / non-temporal row loads (5 picks by footprint) | round 3
+            lib.bgs_gs_loss_tuning(mode)
+            z = dev(batch['logits']).requires_grad_(True)
+            losses = BF.group_softmax_loss(z, bl_dev, ps, w, avg)
+            losses.sum().backward()
+            out.append((losses.detach().cpu().numpy(), z.grad.cpu().numpy()))
+    finally:
+        lib.bgs_gs_loss_tuning(5)
+        lib.bgs_gs_loss_wavepriv_min_rows(-1)
+    np.testing.assert_array_equal(out[0][1], out[2][1])
+    np.testing.assert_array_equal(out[1][1], out[2][1])
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_allclose(out[0][0], out[2][0], rtol=2e-6, atol=1e-7)
+    if N <= 8195:
+        bl = gs_oracle.remap_labels(batch['labels'], l2b)
+        ol, od = gs_oracle.group_softmax_loss(batch['logits'], bl, w.cpu().numpy(), avg.cpu().numpy(), ps)
+        np.testing.assert_allclose(out[0][0], ol, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(out[0][1], od, rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize('N', [1, 2, 3, 4, 5, 1000, 4099, 65536])
+@pytest.mark.parametrize('shift', [0, 1, 2, 3])
+def test_row_per_wave_merge_kernel_is_bit_identical(N, shift):
+    """``gs_merge_wavepriv_kernel`` (round 6; 16-byte stores of the ALIGNED pieces of the flat [N, 1231] output plus
+    dword stores of the at most 3 + 3 floats at a row's ends) == the 4-wave-per-row kernel, bit for bit, for every
+    alignment of the output buffer (``shift`` floats off a 16-byte boundary: with C = 1231 the rows then start at
+    every phase), rows fewer than waves, and nothing written outside [N, C] (guard floats either side)."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    counts = gs_tables.synthetic_instance_counts(C, seed=0)
+    l2b, ps, _ = gs_tables.build_group_tables(counts)
+    W = int(ps[:, 1].sum())
+    c2c = gs_tables.class_to_column(l2b, ps).to(DEV)
+    z = torch.randn(N, W, device=DEV) * 3
+    ps_keep, ps_ptr = capi.host_i64(np.ascontiguousarray(ps))
+    st = capi.current_stream(z.device)
+    outs = []
+    try:
+        for mode in (2, 3, 0):                               # plain / non-temporal row loads (1 picks by footprint) | round 5
+            lib.bgs_gs_merge_tuning(mode, 0)
+            buf = torch.full((N * C + 64,), -7.0, device=DEV)
+            view = buf[32 + shift: 32 + shift + N * C]
+            rc = lib.bgs_gs_merge_score(capi.ptr(z), ps_ptr, capi.ptr(c2c), N, C, ps.shape[0], W,
+                                        view.data_ptr(), st)
+            assert rc == 0
+            torch.cuda.synchronize()
+            outs.append(buf.cpu().numpy())
+    finally:
+        lib.bgs_gs_merge_tuning(1, -1)
+    np.testing.assert_array_equal(outs[0], outs[2])
+    np.testing.assert_array_equal(outs[1], outs[2])
+    assert (outs[0][:32 + shift] == -7.0).all() and (outs[0][32 + shift + N * C:] == -7.0).all()
+    assert (outs[0][32 + shift: 32 + shift + N * C] != -7.0).all()
+
+
 # ---------------------------------------------------------------------------------------
 # device-side _remap_labels / _sample_others
 # ---------------------------------------------------------------------------------------
