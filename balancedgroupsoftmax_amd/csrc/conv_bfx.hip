@@ -851,7 +851,7 @@ struct HaloBfxArgs {
 template <int NB, int GTH = 8, int GTW = 16>
 __device__ __forceinline__ void halo_store_tile_lds(const ConvArgs& p, const f32x16 (&acc)[2][NB], int n,
                                                     int ty, int tx, int n0, int wm, int wn, int lane,
-                                                    float* scratch) {
+                                                    float* scratch, bool nt_store = false) {
   constexpr int TH = GTH, TW = GTW;                       // pixel tile (shadows the 8 x 16 default)
   constexpr int BN = 64 * NB, LD = BN + 4, TPR = BN / 4, RPP = kThreads / TPR;
   const int tid = threadIdx.x;
@@ -896,7 +896,8 @@ __device__ __forceinline__ void halo_store_tile_lds(const ConvArgs& p, const f32
             for (int t = 0; t < 4; ++t) v[t] = mk[t] > 0.f ? v[t] : 0.f;
           }
         }
-        *reinterpret_cast<f32x4*>(dst + off) = v;
+        if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + off));
+        else *reinterpret_cast<f32x4*>(dst + off) = v;
       }
     }
     if (h == 0) __syncthreads();
@@ -1423,10 +1424,13 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
     const int kq_off = SWZ ? ((((kq >> 1) ^ ((pr + pc) & 1)) << 4) + (kq & 1) * 8) : kq * 8;
     a_dst[i] = (in ? 1 : 0) | ((prow * HL + kq_off) << 1);     // bit 0: advances with the chunk
   }
+  const bool nt_load = (q.flags & 16) != 0;                      // BGS_HALO_NT bit 0 (A/B): patch loads non-temporal
   auto load_a = [&](int chunk) {
 #pragma unroll
-    for (int i = 0; i < AQT; ++i)
-      ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + ((a_dst[i] & 1) ? chunk * 16 : 0));
+    for (int i = 0; i < AQT; ++i) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(a_src[i] + ((a_dst[i] & 1) ? chunk * 16 : 0));
+      ra[i] = nt_load ? __builtin_nontemporal_load(src) : *src;
+    }
   };
   auto store_a = [&]() {
 #pragma unroll
@@ -1540,7 +1544,8 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
 
   // (the loop's last barrier is behind every wave's last fragment read)
   if (sizeof(lds) >= (size_t)64 * (BN + 4) * 4 && conv_epilogue_vec_ok(p)) {
-    halo_store_tile_lds<NB, GTH, GTW>(p, acc, n, ty, tx, n0, wm, wn, lane, reinterpret_cast<float*>(lds));
+    halo_store_tile_lds<NB, GTH, GTW>(p, acc, n, ty, tx, n0, wm, wn, lane, reinterpret_cast<float*>(lds),
+                                      (q.flags & 32) != 0);
     return;
   }
   // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -1588,7 +1593,8 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
 // left over in a variant-4 launch of the old 128-pixel units (which fill a partial round far better).
 template <int NS>
 __device__ __forceinline__ void halo7_store_tile_lds(const ConvArgs& p, const f32x16 (&acc)[4][2], int n, int ty,
-                                                     int tx, int n0, int wm, int wn, int lane, float* scratch) {
+                                                     int tx, int n0, int wm, int wn, int lane, float* scratch,
+                                                     bool nt_store = false) {
   constexpr int BN = 128, LD = BN + 4, TPR = BN / 4, RPP = kThreads / TPR;      // 32 threads per row, 8 rows per pass
   const int tid = threadIdx.x;
   const int c4 = (tid % TPR) * 4, r0 = tid / TPR;
@@ -1628,7 +1634,8 @@ __device__ __forceinline__ void halo7_store_tile_lds(const ConvArgs& p, const f3
 #pragma unroll
           for (int t = 0; t < 4; ++t) v[t] = mk[t] > 0.f ? v[t] : 0.f;
         }
-        *reinterpret_cast<f32x4*>(p.y + off) = v;
+        if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.y + off));
+        else *reinterpret_cast<f32x4*>(p.y + off) = v;
       }
     }
     if (h < 3) __syncthreads();
@@ -1714,11 +1721,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx7_kernel(HaloBfxA
     const int kq_off = (((kq >> 1) ^ ((pr + pc) & 1)) << 4) + (kq & 1) * 8;
     a_dst[i] = (in ? 1 : 0) | (use ? 2 : 0) | ((prow * HL + kq_off) << 2);
   }
+  const bool nt_load = (q.flags & 16) != 0;                      // BGS_HALO_NT bit 0 (A/B)
   auto load_a = [&](int chunk) {
 #pragma unroll
-    for (int i = 0; i < AQT; ++i)
-      ra[i] = *reinterpret_cast<const f32x4*>((a_dst[i] & 1) ? p.x + a_off[i] + chunk * 16
-                                                              : reinterpret_cast<const float*>(g_zero_page));
+    for (int i = 0; i < AQT; ++i) {
+      const f32x4* src = reinterpret_cast<const f32x4*>((a_dst[i] & 1) ? p.x + a_off[i] + chunk * 16
+                                                                        : reinterpret_cast<const float*>(g_zero_page));
+      ra[i] = nt_load ? __builtin_nontemporal_load(src) : *src;
+    }
   };
   auto store_a = [&]() {
 #pragma unroll
@@ -1844,11 +1854,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx7_kernel(HaloBfxA
     nxt = t;
   }
   // (the loop's last barrier is behind every wave's last fragment read)
-  halo7_store_tile_lds<NS>(p, acc, n, ty, tx, n0, wm, wn, lane, reinterpret_cast<float*>(lds));
+  halo7_store_tile_lds<NS>(p, acc, n, ty, tx, n0, wm, wn, lane, reinterpret_cast<float*>(lds), (q.flags & 32) != 0);
 }
 
 int g_halo_last_nb = 0, g_halo_last_splits = 0, g_halo_last_variant = 0;
 int g_halo_force_splits = -1, g_halo_variant = 4, g_halo_pf = 0, g_halo_padded = 0, g_halo_flags = 1;
+// BGS_HALO_NT (A/B, read once): bit 0 = the patch loads, bit 1 = the output stores carry the non-temporal hint — the
+// activations stream through once while every workgroup re-reads the filter slices from L2 (kernel flag bits 4 / 5)
+int g_halo_nt = -1;
+int halo_nt_flags() {
+  if (g_halo_nt < 0) {
+    const char* e = getenv("BGS_HALO_NT");
+    g_halo_nt = e ? (atoi(e) & 3) : 0;
+  }
+  return g_halo_nt << 4;
+}
 
 // Pixel-tile geometry of the v4 kernel for an H x W map: the instantiated tile with the fewest tiles per image
 // (every tile costs the same 128 MFMA rows), 8 x 16 unless another one saves at least 5 % — mode 3; modes 0 / 1 / 2
@@ -2461,7 +2481,7 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wspl
     if (rows_a > 0 && (halo_wide_mode() == 2 || (units >= kSlots && q.ns == 3))) {
       q.zero = zero_page_device();
       if (!q.zero) return BGS_ERR_LAUNCH;
-      q.flags = g_halo_flags;
+      q.flags = g_halo_flags | halo_nt_flags();
       HaloBfxArgs qa = q;
       qa.tiles_y = ty7;
       qa.tiles_x = tx7;
@@ -2508,7 +2528,7 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wspl
   if (v4) {
     q.zero = zero_page_device();
     if (!q.zero) return BGS_ERR_LAUNCH;
-    q.flags = g_halo_flags;
+    q.flags = g_halo_flags | halo_nt_flags();
     bgs_internal_census_bump(BGS_CENSUS_HALO_BFX4);
     if (q.ns == 1) {
       if (nb == 1) hipLaunchKernelGGL((conv3x3_halo_bfx4_kernel<1, 1>), grid, dim3(kThreads), 0, (hipStream_t)stream, q);

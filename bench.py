@@ -29,6 +29,8 @@ sys.path.insert(0, ROOT)
 from balancedgroupsoftmax_amd import capi  # noqa: E402
 from balancedgroupsoftmax_amd import functional as BF  # noqa: E402
 from balancedgroupsoftmax_amd import gs_tables  # noqa: E402
+import bench_dist  # noqa: E402
+from bench_dist import barrier, timed_loop  # noqa: E402,F401  (the timed-region contract lives there: one copy for N = 1 and N > 1)
 
 NUM_CLASSES = 1231
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290
@@ -102,7 +104,11 @@ def init_dist(args):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('BGS_DIST_BACKEND', 'nccl')                   # nccl = RCCL on ROCm
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        # a collective that one rank never joins raises after this long instead of holding the job for torch's default
+        # 10 minutes (the watchdogs of bench_dist.run print the line earlier still)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get('BGS_BENCH_COLL_TIMEOUT', '150'))))
     elif os.environ.get('BGS_BENCH_SELF_GROUP'):
         # test hook: a 1-rank RCCL group whose all-reduce really runs, so that the N > 1 launch
         # policies (eager exchange, --dist-graph) can be exercised on a single-GPU box
@@ -116,15 +122,6 @@ def init_dist(args):
                                 world_size=1)
         BT.exchange_at_world_size_one(True)
     return rank, local, world
-
-
-def barrier(world):
-    if world > 1:
-        import torch.distributed as dist
-        if dist.get_backend() == 'nccl':
-            dist.barrier(device_ids=[torch.cuda.current_device()])
-        else:
-            dist.barrier()
 
 
 def make_inputs(n, seed, dev):
@@ -486,28 +483,6 @@ def conv_roofline(dev, math, iters=20, wide=0):
                            'passes; against the fp32-MFMA peak (157.3) the same launch is %.2fx'
                            % (tf / 157.3))
     return r
-
-
-def timed_loop(fn, steps, warmup, world):
-    for _ in range(warmup):
-        fn()
-    torch.cuda.synchronize()
-    barrier(world)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
-    torch.cuda.synchronize()
-    barrier(world)
-    t1 = time.perf_counter()
-    dt = t1 - t0
-    timed_loop.last_local_dt = dt
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
 
 
 def try_graph(step):
@@ -1171,53 +1146,6 @@ def finish_line(out, args, dev, world):
     print(json.dumps(out), flush=True)
 
 
-def exchange_check(step, world):
-    """the N-rank exchanged gradient == the mean of the N single-rank
-    gradients on the same per-rank inputs.  One untimed iteration: forward + backward, keep the
-    local gradients, run the product's exchange (train.allreduce_grads: flat SUM all-reduce / world,
-    mmdet/core/utils/dist_utils.py:9-41), all-gather the local ones and compare."""
-    import torch.distributed as dist
-    if step.step_fn.overlap is not None:
-        return dict(checked=False, why='bucketed exchange overlapped with backward (selectp=0): the '
-                                       'local gradients are replaced bucket by bucket')
-    step.compute()
-    params = [p for p in step.params if p.grad is not None]
-    local = torch.cat([p.grad.reshape(-1) for p in params]).float().clone()
-    step.train.allreduce_grads(step.params, world)
-    got = torch.cat([p.grad.reshape(-1) for p in params]).float()
-    if dist.get_backend() != 'nccl':      # (gloo test hook: collectives of host tensors)
-        local, got = local.cpu(), got.cpu()
-    gathered = [torch.empty_like(local) for _ in range(world)]
-    dist.all_gather(gathered, local)
-    mean = torch.stack(gathered).sum(0) / world
-    diff = float((got - mean).abs().max())
-    scale = float(mean.abs().max())
-    differ = float((gathered[0] - gathered[-1]).abs().max()) if world > 1 else 0.0
-    step.step_fn.optimizer.zero_grad(set_to_none=False)
-    ok = diff <= 1e-5 * scale + 1e-12
-    return dict(checked=True, ok=bool(ok), max_abs_diff=diff, max_abs_grad=scale,
-                ranks_see_different_data=bool(differ > 0), elements=int(local.numel()),
-                what='allreduce_grads(fc_cls grads) vs mean of the all-gathered per-rank gradients')
-
-
-def allreduce_us(step, world, iters=10):
-    """hipEvent time of the gradient exchange alone (flat fp32 all-reduce + /world + unflatten)."""
-    for p in step.params:
-        if p.grad is None:
-            p.grad = torch.zeros_like(p)
-    for _ in range(3):
-        step.train.allreduce_grads(step.params, world)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        step.train.allreduce_grads(step.params, world)
-    e1.record()
-    torch.cuda.synchronize()
-    step.step_fn.optimizer.zero_grad(set_to_none=False)
-    return round(e0.elapsed_time(e1) * 1e3 / iters, 2)
-
-
 def run_dist_graph_children(args, rank, local, world):
     """N > 1: the whole-step hipGraph policy (RCCL all-reduce captured with the rest of the step)
     measured in CHILD processes — one per rank, forming their own process group on another port —
@@ -1265,78 +1193,103 @@ def run_dist_graph_children(args, rank, local, world):
     return res if rank == 0 else None
 
 
-def calibrate_dist_forks(step, world):
-    """N > 1, `--launch auto`: the side-stream forks (functional.forked) are worth 0.1 - 0.3 ms per step when a rank
-    has its GPU and a host core to itself, but they are also what made two processes on ONE device thrash (15 ->
-    185 ms per step, profiles/r8q_dist2_onegpu_forks.json) — and eight Python processes launching eagerly on one
-    host is a regime nobody has timed.  So the arms are calibrated UNTIMED here (8 steps each, eager launches, the
-    gradient exchange included; max over ranks decides, so every rank takes the same arm) and the K timed steps run
-    under the fastest one: forks on, forks off, and (round 5, frozen trunk only) the two-stage pipeline of
-    train.TrunkPipeline with the forks on.  The fork switches are read at every call (DESIGN 5, A/B switches).
-    Returns (record for the line, step function to time)."""
+def detector_line(args, step, world, imgs_per_s, ms_per_step, graph, pipelined, depth, self_group=False):
+    """The fields of the detector JSON line that describe WHAT was timed (shared by the N = 1 and N > 1 paths)."""
+    cfg_name = 'gs_faster_rcnn_r50_fpn_1x_lvis_with0_bg8 (cfg[1])'
+    if args.htc:
+        cfg_name = 'gs_htc_x101_64x4d_fpn_20e_16gpu_lvis (cfg[4], HTC)'
+    elif args.cascade:
+        cfg_name = 'gs_cascade_rcnn_x101_64x4d_fpn_1x_lvis (cfg[4])'
+    elif args.mask:
+        cfg_name = 'gs_mask_rcnn_r50_fpn_1x_lvis (cfg[3])'
+    lv = {k: round(float(v), 5) for k, v in step.last.items()}
+    return {
+        'metric': 'img/s fwd+bwd R50-FPN+BAGS 1333x800, 512 RoI (BASELINE metric: img/s/GPU '
+                  'fwd+bwd R50-FPN+BAGS 1333x800, 512 RoI; GroupSoftmax us/RoI)',
+        'value': round(imgs_per_s, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': {'f32': 'f32', 'bf16': 'bf16 (conv/linear operands rounded to bf16, fp32 accumulate; %s; '
+                                               'fp32 master weights and losses)'
+                                               % ('bf16 storage of the frozen trunk activations'
+                                                  if os.environ.get('BGS_BF16_STORAGE', '1') != '0'
+                                                  else 'fp32 storage'),
+                  'bf16x6': 'f32 (conv/linear products on the bf16 MFMA from exact 3-way bf16 '
+                            'splits, fp32 accumulate: fp32-faithful)'}[args.conv_math],
+        'data': 'synthetic',
+        'config': {'conv_math_mode': args.conv_math, 'conv_math': CONV_MATH_NOTE[args.conv_math],
+                   'workload': cfg_name + ' training '
+                               'iteration %s, grad all-reduce, clip 35, SGD): '
+                               '%d img/GPU, 3x800x1344 (1333x800 padded /32), 20 GT/img, '
+                               '512 RoI/img, 1231 classes, 5 bins; random-init weights'
+                               % (('as shipped (selectp=1: full forward incl. RPN '
+                                   'losses/proposals/NMS/assign/sample/RoIAlign/FC heads/'
+                                   'GroupSoftmax loss, backward through fc_cls')
+                                  if args.selectp == 1 else
+                                  ('with selectp=0 (train everything but the frozen stem + '
+                                   'layer1: full forward and full backward through heads, '
+                                   'RoIAlign, RPN, FPN, ResNet layer2-4'), args.imgs),
+                   'selectp': args.selectp, 'mask_branch': bool(args.mask),
+                   'cascade_x101': bool(args.cascade), 'htc_x101': bool(args.htc),
+                   'trainable_params': int(sum(p.numel() for p in step.params)),
+                   'imgs_per_gpu': args.imgs, 'rois_per_img': 512,
+                   'launch': ('hipGraph replay of the whole step (forward+losses+backward+'
+                              + ('RCCL all-reduce+' if (world > 1 or self_group) else '') +
+                              'clip+SGD)') if graph else
+                   ('eager launches, %d-stage software pipeline (train.TrunkPipeline): the frozen trunk of the '
+                    'batches ahead, in %d piece(s) on their own streams (depth 3: backbone(i+2) | FPN(i+1)), beside '
+                    'batch i\'s RPN / proposal chain / RoI heads / losses / backward / optimizer step; one pass of '
+                    'every piece + one head pass per timed step, bit-identical training (tests/test_gpu_e2e.py)'
+                    % (depth, depth - 1) if pipelined else 'eager launches'),
+                   'parallelism': 'dp%d (one process per GPU; flat fp32 all-reduce of the '
+                                  '%d trainable grads over RCCL)'
+                                  % (world, sum(p.numel() for p in step.params)),
+                   'ranks': world,
+                   'collective_backend': (__import__('torch.distributed').distributed.get_backend()
+                                          if world > 1 else None)},
+        'img_per_s_per_gpu': round(imgs_per_s / world, 3),
+        'last_losses': lv,
+    }
+
+
+def main_detector_dist(args, rank, local, world, dev, step, dist_graph):
+    """N > 1 (one process per GPU, launched by torch.distributed.run): calibration, the K timed steps and the
+    diagnostics run through bench_dist.run — headline first, every diagnostic guarded and bounded (its docstring)."""
     import torch.distributed as dist
-    arms = {}
-    per_rank = {}
-    fns = {}
-    names = [('forks_on', '1', 0), ('forks_off', '0', 0)]
-    if step.can_pipeline() and not os.environ.get('BGS_BENCH_NO_PIPELINE'):
-        names += [('pipelined', '1', 4), ('pipelined_depth5', '1', 5)]       # (the two depths that win at N = 1)
-    for name, val, pipe in names:
-        os.environ['BGS_LEVEL_FORK'] = val
-        fn = step.pipelined(depth=pipe) if pipe else step
-        dt = timed_loop(fn, 8, 4 if name == 'forks_on' else 2, world)
-        if pipe:
-            fn.drain()
-            torch.cuda.synchronize()
-        arms[name] = round(dt * 1e3 / 8, 3)
-        mine = torch.tensor([timed_loop.last_local_dt * 1e3 / 8], dtype=torch.float64,
-                            device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
-        allr = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank[name] = [round(float(t.item()), 3) for t in allr]
-    chosen = 'forks_on' if arms['forks_on'] <= 1.01 * arms['forks_off'] else 'forks_off'
-    depth = 0
-    if 'pipelined' in arms:
-        best = 'pipelined' if arms['pipelined'] <= arms['pipelined_depth5'] else 'pipelined_depth5'
-        if arms[best] < 0.99 * arms[chosen]:
-            chosen, depth = 'pipelined', (4 if best == 'pipelined' else 5)
-    os.environ['BGS_LEVEL_FORK'] = '0' if chosen == 'forks_off' else '1'
-    rec = dict(chosen=chosen, ms_by_rank=per_rank,
-               note='untimed calibration on all ranks (8 eager steps per arm incl. the gradient exchange, max over '
-                    'ranks); the K timed steps ran under `chosen`; the whole-step-graph arm is `dist_graph_policy`')
-    for name in arms:
-        rec['eager_%s_ms' % name] = arms[name]
-    if depth:
-        rec['pipeline_depth'] = depth
-    return rec, (step.pipelined(depth=depth) if depth else step), depth
 
+    def make_one_rank_step():
+        return DetectorStep(dev, 0, 1, args.imgs, args.selectp, args.mask, args.cascade, args.htc,
+                            conv_math=args.conv_math)
 
-def n1_reference(args, rank, world, dev, ms_per_step_n, pipelined=False):
-    """N > 1: the same step on ONE rank of the same node in the same invocation (rank 0 alone, eager launches, the
-    other ranks waiting at a barrier) so that the line carries the weak-scaling efficiency against a number taken
-    on this very box — the driver computes its own from separate runs; this one removes box-to-box spread."""
-    out = None
-    if rank == 0:
-        try:
-            one = DetectorStep(dev, 0, 1, args.imgs, args.selectp, args.mask, args.cascade, args.htc,
-                               conv_math=args.conv_math)
-            fn1 = one.pipelined(depth=int(pipelined) if int(pipelined) > 1 else 4) \
-                if (pipelined and one.can_pipeline()) else one      # (the policy the N ranks were timed under)
-            dt = timed_loop(fn1, args.steps, max(args.warmup, 4), 1)
-            if fn1 is not one:
-                fn1.drain()
-                torch.cuda.synchronize()
-            ms1 = dt * 1e3 / args.steps
-            out = dict(n1_same_invocation=dict(ms_per_step=round(ms1, 3),
-                                               img_per_s=round(args.imgs * args.steps / dt, 3),
-                                               launch='eager launches%s, rank 0 alone, other ranks idle'
-                                                      % ((' (%d-stage pipeline)' % fn1.depth) if fn1 is not one else '')),
-                       weak_scaling_eff=round(ms1 / ms_per_step_n, 4))
-            del one
-        except Exception as e:  # pragma: no cover
-            out = dict(n1_same_invocation=dict(error=repr(e)[:200]))
-    barrier(world)
-    return out
+    def emit(f):
+        if 'ms_per_step' not in f:              # the watchdog fired before the timed region finished
+            print(json.dumps({'metric': 'img/s fwd+bwd R50-FPN+BAGS 1333x800, 512 RoI', 'value': None, 'unit': 'img/s',
+                              'n_gpus': world, 'error': f.get('error', 'no measurement')}), flush=True)
+            return
+        depth = f['pipeline_depth']
+        out = detector_line(args, step, world, args.imgs * world * args.steps / f['dt'], f['ms_per_step'], None,
+                            bool(depth), depth)
+        out['rccl_ranks'] = world if dist.get_backend() == 'nccl' else 0
+        out['launch_policy'] = 'eager launches (the RCCL all-reduce between backward and the optimizer)'
+        out['ms_per_step_by_rank'] = dict(min=min(f['rank_ms']), max=max(f['rank_ms']), all=f['rank_ms'])
+        calib = f.get('launch_calibration')
+        if calib is not None:
+            out['launch_calibration'] = calib
+            if depth and calib.get('eager_forks_on_ms') is not None:
+                out['ms_per_step_eager'] = calib['eager_forks_on_ms']
+        for k, v in (f.get('diagnostics') or {}).items():
+            out[k] = v
+        if dist_graph is not None:
+            out['dist_graph_policy'] = dist_graph
+        if f.get('watchdog'):
+            # printed from the watchdog thread while the main thread may be stuck in a collective: no GPU work here
+            out['watchdog'] = f['watchdog']
+            print(json.dumps(out), flush=True)
+            return
+        finish_line(out, args, dev, world)
+
+    bench_dist.run(step, args, rank, world, make_one_rank_step, emit,
+                   launch_auto=args.launch == 'auto' and not os.environ.get('BGS_BENCH_NO_DIST_CALIB'))
 
 
 def main_detector(args, rank, local, world, dev):
@@ -1352,15 +1305,13 @@ def main_detector(args, rank, local, world, dev):
         os._exit(134)
     dist_graph = None
     if world > 1 and not args.child and not args.no_graph and not args.dist_graph \
-            and not os.environ.get('BGS_BENCH_NO_DIST_GRAPH_CHILD'):
+            and os.environ.get('BGS_BENCH_DIST_GRAPH_CHILD'):
+        # opt-in (round 6): the whole-step hipGraph with the RCCL all-reduce captured, in child processes (up to 180 s)
         dist_graph = run_dist_graph_children(args, rank, local, world)
     step = DetectorStep(dev, rank, world, args.imgs, args.selectp, args.mask, args.cascade,
                         args.htc, conv_math=args.conv_math)
-    diag = None
-    if world > 1 and not args.child:
-        diag = dict(grad_exchange_check=exchange_check(step, world))
-        if step.step_fn.overlap is None:
-            diag['allreduce_us'] = allreduce_us(step, world)
+    if world > 1 and not args.child and not args.dist_graph:
+        return main_detector_dist(args, rank, local, world, dev, step, dist_graph)
     # Launch policy.  The iteration is free of host synchronisation, so on ONE GPU the whole
     # step (forward, losses, backward, clip, SGD: ~560 launches) is captured into a single
     # hipGraph and replayed.  The graph must own the ENTIRE step: on ROCm 7.2 a large graph whose
@@ -1368,8 +1319,9 @@ def main_detector(args, rank, local, world, dev):
     # philox bookkeeping of torch.randint inside a captured region) faults after a few dozen
     # replays (tools/two_graphs_repro.py reproduces it: "variants plain" vs "variants whole";
     # DESIGN.md §5).  With N > 1 the gradient all-reduce (RCCL) sits between backward and the
-    # optimizer, so multi-GPU runs launch eagerly — the step is GPU-bound and eager launches
-    # cost nothing measurable (10.99 vs 10.96 ms).
+    # optimizer, so multi-GPU runs launch eagerly (main_detector_dist above) — the step is GPU-bound and eager launches
+    # cost nothing measurable (10.99 vs 10.96 ms); what is left here for N > 1 is `--dist-graph` (the whole step incl.
+    # the collective in one hipGraph per rank) and its measurement children.
     graph = None
     self_group = bool(os.environ.get('BGS_BENCH_SELF_GROUP'))
     rccl = world > 1 and __import__('torch.distributed').distributed.get_backend() == 'nccl'
@@ -1401,10 +1353,6 @@ def main_detector(args, rank, local, world, dev):
                 if best_depth is None or ms < calib['eager_pipelined_ms']:
                     best_depth, calib['eager_pipelined_ms'] = dpt, ms
             calib['pipeline_depth'] = best_depth
-    dist_calib, dist_fn, dist_pipelined = None, None, False
-    if world > 1 and not args.child and args.launch == 'auto' and not args.dist_graph \
-            and not os.environ.get('BGS_BENCH_NO_DIST_CALIB'):
-        dist_calib, dist_fn, dist_pipelined = calibrate_dist_forks(step, world)
     if can_graph and args.launch not in ('eager', 'pipelined'):
         # --dist-graph: the RCCL all-reduce is captured with the rest of the step (the communicator
         # is set up by the eager warm-up iterations inside try_graph)
@@ -1416,8 +1364,6 @@ def main_detector(args, rank, local, world, dev):
             fn = step
         calib['chosen'] = 'eager' if fn is step else 'graph'
     pipelined = False
-    if dist_fn is not None and graph is None:
-        fn, pipelined = dist_fn, dist_pipelined
     if auto and pipe_fn is not None:
         best = min(calib['eager_ms'], calib.get('graph_ms', 1e9))
         if calib['eager_pipelined_ms'] < 0.99 * best:
@@ -1434,80 +1380,19 @@ def main_detector(args, rank, local, world, dev):
     imgs_per_s = args.imgs * world * args.steps / dt
     rank_ms = None
     if world > 1:       # every rank's own wall time of the timed region (the line reports the max)
-        import torch.distributed as dist
-        mine = torch.tensor([timed_loop.last_local_dt * 1e3 / args.steps], dtype=torch.float64,
-                            device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
-        allr = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        rank_ms = [round(float(t.item()), 3) for t in allr]
-    n1 = None
-    if world > 1 and not args.child and not os.environ.get('BGS_BENCH_NO_N1_REFERENCE'):
-        n1 = n1_reference(args, rank, world, dev, ms_per_step, pipelined)
+        rank_ms = [round(t, 3) for t in bench_dist.gather_scalar(timed_loop.last_local_dt * 1e3 / args.steps, world)]
     ms_eager = None
     ms_graph = None
     if graph is not None and (fn is step or pipelined):      # eager was the timed policy: the graph figure from the calibration
         ms_graph = calib['graph_ms']
         graph = None                           # (the line's `launch` describes what was timed)
     if pipelined:
-        ms_eager = (calib or {}).get('eager_ms') or (dist_calib or {}).get('eager_forks_on_ms')
+        ms_eager = (calib or {}).get('eager_ms')
     elif graph is not None:     # every rank: the same step launched eagerly, for the graph-vs-eager figure
         ms_eager = round(timed_loop(step, 5, 2, world) * 1e3 / 5, 3)
-    cfg_name = 'gs_faster_rcnn_r50_fpn_1x_lvis_with0_bg8 (cfg[1])'
-    if args.htc:
-        cfg_name = 'gs_htc_x101_64x4d_fpn_20e_16gpu_lvis (cfg[4], HTC)'
-    elif args.cascade:
-        cfg_name = 'gs_cascade_rcnn_x101_64x4d_fpn_1x_lvis (cfg[4])'
-    elif args.mask:
-        cfg_name = 'gs_mask_rcnn_r50_fpn_1x_lvis (cfg[3])'
     if rank == 0:
-        lv = {k: round(float(v), 5) for k, v in step.last.items()}
-        out = {
-            'metric': 'img/s fwd+bwd R50-FPN+BAGS 1333x800, 512 RoI (BASELINE metric: img/s/GPU '
-                      'fwd+bwd R50-FPN+BAGS 1333x800, 512 RoI; GroupSoftmax us/RoI)',
-            'value': round(imgs_per_s, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'f32': 'f32', 'bf16': 'bf16 (conv/linear operands rounded to bf16, fp32 accumulate; %s; '
-                                                   'fp32 master weights and losses)'
-                                                   % ('bf16 storage of the frozen trunk activations'
-                                                      if os.environ.get('BGS_BF16_STORAGE', '1') != '0'
-                                                      else 'fp32 storage'),
-                      'bf16x6': 'f32 (conv/linear products on the bf16 MFMA from exact 3-way bf16 '
-                                'splits, fp32 accumulate: fp32-faithful)'}[args.conv_math],
-            'data': 'synthetic',
-            'config': {'conv_math_mode': args.conv_math, 'conv_math': CONV_MATH_NOTE[args.conv_math],
-                       'workload': cfg_name + ' training '
-                                   'iteration %s, grad all-reduce, clip 35, SGD): '
-                                   '%d img/GPU, 3x800x1344 (1333x800 padded /32), 20 GT/img, '
-                                   '512 RoI/img, 1231 classes, 5 bins; random-init weights'
-                                   % (('as shipped (selectp=1: full forward incl. RPN '
-                                       'losses/proposals/NMS/assign/sample/RoIAlign/FC heads/'
-                                       'GroupSoftmax loss, backward through fc_cls')
-                                      if args.selectp == 1 else
-                                      ('with selectp=0 (train everything but the frozen stem + '
-                                       'layer1: full forward and full backward through heads, '
-                                       'RoIAlign, RPN, FPN, ResNet layer2-4'), args.imgs),
-                       'selectp': args.selectp, 'mask_branch': bool(args.mask),
-                       'cascade_x101': bool(args.cascade), 'htc_x101': bool(args.htc),
-                       'trainable_params': int(sum(p.numel() for p in step.params)),
-                       'imgs_per_gpu': args.imgs, 'rois_per_img': 512,
-                       'launch': ('hipGraph replay of the whole step (forward+losses+backward+'
-                                  + ('RCCL all-reduce+' if (world > 1 or self_group) else '') +
-                                  'clip+SGD)') if graph else
-                       ('eager launches, %d-stage software pipeline (train.TrunkPipeline): the frozen trunk of the '
-                        'batches ahead, in %d piece(s) on their own streams (depth 3: backbone(i+2) | FPN(i+1)), beside '
-                        'batch i\'s RPN / proposal chain / RoI heads / losses / backward / optimizer step; one pass of '
-                        'every piece + one head pass per timed step, bit-identical training (tests/test_gpu_e2e.py)'
-                        % (fn.depth, fn.depth - 1) if pipelined else 'eager launches'),
-                       'parallelism': 'dp%d (one process per GPU; flat fp32 all-reduce of the '
-                                      '%d trainable grads over RCCL)'
-                                      % (world, sum(p.numel() for p in step.params)),
-                       'ranks': world,
-                       'collective_backend': (__import__('torch.distributed').distributed.get_backend()
-                                              if world > 1 else None)},
-            'img_per_s_per_gpu': round(imgs_per_s / world, 3),
-            'last_losses': lv,
-        }
+        out = detector_line(args, step, world, imgs_per_s, ms_per_step, graph, pipelined,
+                            fn.depth if pipelined else 0, self_group)
         if ms_eager is not None:
             out['ms_per_step_eager'] = ms_eager
         if ms_graph is not None:
@@ -1521,14 +1406,6 @@ def main_detector(args, rank, local, world, dev):
             out['launch_policy'] = 'hipGraph replay incl. the RCCL all-reduce' if graph else \
                 'eager launches (the RCCL all-reduce between backward and the optimizer)'
             out['ms_per_step_by_rank'] = dict(min=min(rank_ms), max=max(rank_ms), all=rank_ms)
-            if diag:
-                out.update(diag)
-            if dist_graph is not None:
-                out['dist_graph_policy'] = dist_graph
-            if dist_calib is not None:
-                out['launch_calibration'] = dist_calib
-            if n1 is not None:
-                out.update(n1)
         if self_group:
             out['config']['collective_backend'] = 'nccl (1-rank group: test hook BGS_BENCH_SELF_GROUP)'
         if fallback_note:

@@ -72,6 +72,54 @@ def match_boxes(got, exp, tol_px=0.05, tol_score=2e-4):
     return float(((d < tol_px) & (s < tol_score)).any(axis=1).mean())
 
 
+def _iou_legacy(a, b):
+    a, b = a[:, None, :4].astype(np.float64), b[None, :, :4].astype(np.float64)
+    iw = np.clip(np.minimum(a[..., 2], b[..., 2]) - np.maximum(a[..., 0], b[..., 0]) + 1, 0, None)
+    ih = np.clip(np.minimum(a[..., 3], b[..., 3]) - np.maximum(a[..., 1], b[..., 1]) + 1, 0, None)
+    inter = iw * ih
+    area = lambda t: (t[..., 2] - t[..., 0] + 1) * (t[..., 3] - t[..., 1] + 1)      # noqa: E731
+    return inter / (area(a) + area(b) - inter)
+
+
+def proposal_miss_taxonomy(got, exp, tol_px=0.05, tol_score=2e-4, nms_thr=0.7):
+    """Why a reference proposal has no HIP proposal within tolerance (printed when the reproduced fraction is below
+    1): ``loose`` = a HIP row within 10x the tolerance (arithmetic noise on a coordinate or score), ``nms_tie`` = a kept
+    HIP box overlaps it with an IoU within 2e-3 of the NMS threshold (the suppression decision sits on the threshold),
+    ``topk_tie`` = its score is within the score tolerance of the lowest reference score (the cut of nms_pre / max_num),
+    ``other`` = none of these — a real difference."""
+    d = np.abs(got[None, :, :4] - exp[:, None, :4]).max(axis=2)
+    sc = np.abs(got[None, :, 4] - exp[:, None, 4])
+    hit = ((d < tol_px) & (sc < tol_score)).any(axis=1)
+    out = dict(missing=int((~hit).sum()), loose=0, nms_tie=0, topk_tie=0, other=0)
+    if hit.all():
+        return out
+    miss = np.where(~hit)[0]
+    iou = _iou_legacy(exp[miss], got)
+    lo = float(exp[:, 4].min())
+    for k, m in enumerate(miss):
+        if ((d[m] < 10 * tol_px) & (sc[m] < 10 * tol_score)).any():
+            out['loose'] += 1
+        elif (np.abs(iou[k] - nms_thr) < 2e-3).any():
+            out['nms_tie'] += 1
+        elif abs(float(exp[m, 4]) - lo) < tol_score:
+            out['topk_tie'] += 1
+        else:
+            out['other'] += 1
+    return out
+
+
+def assert_proposals_reproduced(got, exp, image, min_frac=0.999):
+    """The HIP RPN reproduces the executed reference's proposals: every full-size run so far logged 1.0000, so the bound is
+    0.999 (2 of 2000 — a top-k / NMS tie may flip; 0.97 would have let a real regression of 3 % through), and a miss
+    prints its taxonomy."""
+    frac = match_boxes(got, exp, tol_px=0.05, tol_score=2e-4)
+    print('image %d: %.4f of the reference proposals reproduced by the HIP RPN' % (image, frac))
+    if frac < 1.0:
+        print('image %d: misses by cause: %s' % (image, proposal_miss_taxonomy(got, exp)))
+    assert frac >= min_frac, (frac, proposal_miss_taxonomy(got, exp))
+    return frac
+
+
 def match_iou(got, exp, thr=0.9):
     """fraction of rows of ``exp [n,>=4]`` that overlap a row of ``got`` with IoU >= thr (legacy +1 areas): the
     size-relative match for arithmetic modes that move box coordinates by more than a fixed pixel tolerance."""
@@ -746,9 +794,7 @@ def test_fullsize_iteration_with_the_shipped_sampler_sizes_and_the_references_re
             for i, (p, v) in enumerate(own):
                 ref = torch.from_numpy(z['proposals%d' % i]).to(DEV)
                 assert tuple(ref.shape) == tuple(p.shape), (ref.shape, p.shape)
-                frac = match_boxes(p[v].cpu().numpy(), z['proposals%d' % i], tol_px=0.05, tol_score=2e-4)
-                print('image %d: %.4f of the reference proposals reproduced by the HIP RPN' % (i, frac))
-                assert frac >= 0.97, frac
+                assert_proposals_reproduced(p[v].cpu().numpy(), z['proposals%d' % i], i)
                 out.append((ref.contiguous(), torch.ones(ref.shape[0], dtype=torch.bool, device=DEV)))
             return out
 
@@ -857,9 +903,7 @@ def test_mask_rcnn_fullsize_iteration_with_the_shipped_samplers_vs_executed_refe
             for i, (p, v) in enumerate(own):
                 ref = torch.from_numpy(z['proposals%d' % i]).to(DEV)
                 assert tuple(ref.shape) == tuple(p.shape), (ref.shape, p.shape)
-                frac = match_boxes(p[v].cpu().numpy(), z['proposals%d' % i], tol_px=0.05, tol_score=2e-4)
-                print('image %d: %.4f of the reference proposals reproduced by the HIP RPN' % (i, frac))
-                assert frac >= 0.97, frac
+                assert_proposals_reproduced(p[v].cpu().numpy(), z['proposals%d' % i], i)
                 out.append((ref.contiguous(), torch.ones(ref.shape[0], dtype=torch.bool, device=DEV)))
             return out
 
@@ -956,7 +1000,10 @@ def test_htc_x101_fullsize_iteration_vs_executed_reference(math):
                 frac = match_boxes(p[v].cpu().numpy(), z['proposals%d' % i], tol_px=0.05, tol_score=2e-4)
                 print('image %d: %.4f of the reference proposals reproduced by the HIP RPN' % (i, frac))
                 if math == 'bf16x6':
-                    assert frac >= 0.97, frac
+                    if frac < 1.0:
+                        print('image %d: misses by cause: %s'
+                              % (i, proposal_miss_taxonomy(p[v].cpu().numpy(), z['proposals%d' % i])))
+                    assert frac >= 0.999, (frac, proposal_miss_taxonomy(p[v].cpu().numpy(), z['proposals%d' % i]))
                 else:        # bf16 operands move boxes / scores by more than that tolerance: a widened match
                     wide = match_iou(p[v].cpu().numpy(), z['proposals%d' % i], BF16_PROP_IOU)
                     print('image %d (bf16): %.4f of the reference proposals have a HIP proposal with IoU >= %.1f'
