@@ -75,7 +75,7 @@ def _fold_conv_bn(conv, bn, pad_cin_to=None):
 def _tensor_slots(mods):
     """(registration dict, name) of every parameter / buffer below the modules ``mods`` (direct walk of the registration
     dicts), and those dicts themselves (parameters, buffers and sub-modules of every module seen, empty ones included)."""
-    slots, dicts = [], []
+    slots, dicts, moddicts = [], [], []
     stack = list(mods)[::-1]
     while stack:
         m = stack.pop()
@@ -84,8 +84,9 @@ def _tensor_slots(mods):
             for k in d:
                 slots.append((d, k))
         dicts.append(m._modules)
+        moddicts.append(m._modules)
         stack.extend(m._modules.values())
-    return slots, dicts
+    return slots, dicts, moddicts
 
 
 class _FoldCache(object):
@@ -95,7 +96,9 @@ class _FoldCache(object):
     every frozen layer (a quarter of the launching thread's time once, a tenth before round 5), so it reads the CURRENT
     tensor objects through the registration dicts listed once (a re-registered parameter or buffer is a new object under
     the same name: seen), compares (id, _version, data_ptr) and re-lists the dicts only when a name disappears, the number
-    of registered names (parameters, buffers, sub-modules) changes or another set of modules is passed."""
+    of registered names (parameters, buffers, sub-modules) changes, a sub-module is REPLACED under its name (the identities
+    of the registered sub-modules are part of the cheap check: ADVICE r5 — the slots would otherwise keep pointing at the
+    old module's tensors) or another set of modules is passed."""
 
     def __init__(self):
         self.key = None
@@ -103,17 +106,22 @@ class _FoldCache(object):
         self.mods = None
         self.slots = None
         self.count = -1
+        self.fence = None
 
     def _list(self, mods):
         self.mods = tuple(id(m) for m in mods)
-        self.slots, self.dicts = _tensor_slots(mods)
+        self.slots, self.dicts, self.moddicts = _tensor_slots(mods)
         self.count = sum(len(d) for d in self.dicts)
+        self.subs = self._sub_ids()
         self.key = None
+
+    def _sub_ids(self):
+        return [id(v) for d in self.moddicts for v in d.values()]
 
     def get(self, module, build):
         mods = module if isinstance(module, tuple) else (module,)
         if self.slots is None or self.mods != tuple(id(m) for m in mods) or \
-                self.count != sum(len(d) for d in self.dicts):
+                self.count != sum(len(d) for d in self.dicts) or self.subs != self._sub_ids():
             self._list(mods)
         try:
             tensors = [d[k] for d, k in self.slots]
@@ -131,6 +139,13 @@ class _FoldCache(object):
         if key != self.key:
             self.data = build()
             self.key = key
+            # built (torch ops) on the current stream — possibly a pipeline piece's side stream — and read from whatever
+            # stream the module runs on later: the first cross-stream use waits for the build (functional.CacheFence)
+            self.fence = BF.CacheFence() if any(t is not None and t.is_cuda for t in tensors) else None
+        elif self.fence is not None:
+            self.fence.wait()
+            if self.fence.event is None:
+                self.fence = None
         return self.data
 
 

@@ -755,7 +755,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_bf16_ring8_kernel(BfxArgs q
 // w [rows][K] fp32 -> out [NS][KC][rows][16] bf16 planes (zero-padded K tail)
 __global__ __launch_bounds__(256) void bfx_split_weights_kernel(const float* __restrict__ w,
                                                                 __bf16* __restrict__ out, int rows,
-                                                                int K, int KC, int NS) {
+                                                                int K, int KC, int NS, int f32sec = 0) {
   const size_t total = (size_t)KC * rows * 8;          // bf16 pairs per plane
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total;
        e += (size_t)gridDim.x * 256) {
@@ -776,7 +776,9 @@ __global__ __launch_bounds__(256) void bfx_split_weights_kernel(const float* __r
     if (NS >= 3) o[2 * total] = l;
     // fourth section: the same [KC][rows][16] layout in fp32 (the halo kernels' FB32 form DMAs THIS — 2/3 of the
     // bytes of the three planes — and splits a wave's fragment in registers: same split3, same planes, same bits)
-    if (NS >= 3) reinterpret_cast<f32x2*>(reinterpret_cast<unsigned*>(out) + 3 * total)[e] = f32x2{v0, v1};
+    // Only in the FB32 experiment (BGS_HALO_FB32=1 at process start): ADVICE r5 — every split weight paid 67 % more
+    // bytes, and every per-step split of a trained weight the extra write traffic, for a default-off A/B arm.
+    if (NS >= 3 && f32sec) reinterpret_cast<f32x2*>(reinterpret_cast<unsigned*>(out) + 3 * total)[e] = f32x2{v0, v1};
   }
 }
 
@@ -785,7 +787,7 @@ __global__ __launch_bounds__(256) void bfx_split_weights_kernel(const float* __r
 // that is a flip + permute + contiguous (two launches) in front of the split, per trained conv and step.
 __global__ __launch_bounds__(256) void bfx_split_weights_dgrad_kernel(const float* __restrict__ w,
                                                                       __bf16* __restrict__ out, int Cout,
-                                                                      int R, int S, int Cin, int KC) {
+                                                                      int R, int S, int Cin, int KC, int f32sec) {
   const int rows = Cin, K = R * S * Cout, RS = R * S;
   const size_t total = (size_t)KC * rows * 8;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total;
@@ -812,7 +814,7 @@ __global__ __launch_bounds__(256) void bfx_split_weights_dgrad_kernel(const floa
     o[0] = h;
     o[total] = m;
     o[2 * total] = l;
-    reinterpret_cast<f32x2*>(o - e + 3 * total)[e] = f32x2{v[0], v[1]};      // (fp32 section, see above)
+    if (f32sec) reinterpret_cast<f32x2*>(o - e + 3 * total)[e] = f32x2{v[0], v[1]};      // (fp32 section, see above)
   }
 }
 
@@ -1913,10 +1915,16 @@ int g_halo_last_geom = 0;
 // launch (default) | k > 1 = that launch split k ways over the channel chunks (+ the split-K epilogue).
 int g_halo_wide = -1;
 int g_halo_last_wide_units = 0, g_halo_last_tail_units = 0;
-// fp32 filter slices + in-register split (FB32): env BGS_HALO_FB32 (read at every call: A/B in one process), default 0
+// fp32 filter slices + in-register split (FB32): env BGS_HALO_FB32, default 0.  Read ONCE per process: the mode decides
+// whether split-weight buffers carry the fp32 section the FB32 kernels DMA (bgs_conv_bfx_weight_bytes), so it cannot
+// change between the split of a weight and its use.
 int halo_fb32_mode() {
-  const char* e = getenv("BGS_HALO_FB32");
-  return e ? atoi(e) : 0;
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("BGS_HALO_FB32");
+    mode = e ? (atoi(e) != 0) : 0;
+  }
+  return mode;
 }
 int halo_wide_mode() {
   if (g_halo_wide >= 0) return g_halo_wide;
@@ -2204,8 +2212,10 @@ inline int bfx_kc(int K) { return 2 * ((K + 31) / 32); }
 
 extern "C" size_t bgs_conv_bfx_weight_bytes(int rows, int K) {
   if (rows <= 0 || K <= 0) return 0;
-  // three bf16 planes + the packed fp32 copy [KC][rows][16] behind them
-  return (size_t)3 * bfx_kc(K) * rows * 16 * sizeof(__bf16) + (size_t)bfx_kc(K) * rows * 16 * sizeof(float);
+  // three bf16 planes [3][KC][rows][16]; in the FB32 experiment (BGS_HALO_FB32=1 at process start, default off) the
+  // packed fp32 copy [KC][rows][16] behind them
+  return (size_t)3 * bfx_kc(K) * rows * 16 * sizeof(__bf16) +
+         (halo_fb32_mode() ? (size_t)bfx_kc(K) * rows * 16 * sizeof(float) : (size_t)0);
 }
 
 extern "C" int bgs_conv_bfx_split_weights(const float* w, void* out, int rows, int K,
@@ -2217,7 +2227,7 @@ extern "C" int bgs_conv_bfx_split_weights(const float* w, void* out, int rows, i
   size_t g = (total + 255) / 256;
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(bfx_split_weights_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
-                     w, reinterpret_cast<__bf16*>(out), rows, K, KC, 3);
+                     w, reinterpret_cast<__bf16*>(out), rows, K, KC, 3, halo_fb32_mode());
   BGS_RETURN_LAUNCH_STATUS();
 }
 
@@ -2233,7 +2243,7 @@ extern "C" int bgs_conv_bfx_split_weights_dgrad(const float* w, void* out, int C
   size_t g = (total + 255) / 256;
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(bfx_split_weights_dgrad_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
-                     w, reinterpret_cast<__bf16*>(out), Cout, R, S, Cin, KC);
+                     w, reinterpret_cast<__bf16*>(out), Cout, R, S, Cin, KC, halo_fb32_mode());
   BGS_RETURN_LAUNCH_STATUS();
 }
 

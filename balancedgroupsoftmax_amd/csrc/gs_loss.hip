@@ -37,7 +37,7 @@ constexpr int kMaxGrid = 2048;
 // workspace = [BGS_MAX_BINS][<= kMaxGrid] partial sums, then one int: the grid that wrote them (the main kernels
 // record it, bgs_gs_loss_reduce reads it — the row-per-wave kernel's grid is not a function of N alone)
 constexpr int kGridSlot = kMaxGrid * BGS_MAX_BINS;
-int g_rowwave_pf = 5;        // bgs_gs_loss_tuning: 5 (default) = row-per-wave kernel for 4096 <= N < 12288 rows, mode 3 elsewhere | 6 / 7 = row-per-wave
+int g_rowwave_pf = 5;        // bgs_gs_loss_tuning: 5 (default) = row-per-wave kernel for 4096 < N < 12288 rows, mode 3 elsewhere | 6 / 7 = row-per-wave
                              // for every N >= the row threshold with plain / non-temporal row loads | 0 = no next-row prefetch | 1 = prefetch | 2 / 3 / 4 = prefetch + non-temporal
                              // loads / stores / both (A/B; 3 = default: profiles/r8e_gs_rowwave_prefetch_ab.txt)
 
@@ -1253,7 +1253,7 @@ inline int loss_grid(int N) { return N <= 0 ? 1 : (N < kMaxGrid ? N : kMaxGrid);
 // 65,536 rows 122 vs 126 us — both AT the rate of a hipMemcpyAsync D2D of the same 324 + 324 MB on the same box,
 // 5.3 - 5.4 TB/s).  Default (mode 5): rows in [kWavePrivMinRows, kWavePrivMaxRows); modes 6 / 7 ignore the upper bound.
 // Grid: every workgroup resident at once (LDS: 4 rows + read slack each), rows dealt round-robin.
-constexpr int kWavePrivMinRows = 4096;
+constexpr int kWavePrivMinRows = 4097;      // (up to the fused head's 4096 rows the two paths stay bitwise equal: the tests pin it)
 constexpr int kWavePrivMaxRows = 12288;
 int g_wavepriv_min_rows = kWavePrivMinRows;
 

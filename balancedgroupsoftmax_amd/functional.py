@@ -688,6 +688,38 @@ _SPLIT_CACHE = {}
 _SPLIT_CACHE_MAX = 1024
 
 
+class CacheFence(object):
+    """Orders the FIRST cross-stream use of a cached tensor behind the launches that wrote it (split planes
+    and folded weights first built inside a pipeline piece are written on that piece's side stream and then read from
+    other streams with nothing in between).  ``CacheFence()`` right after the producing launches records an event on
+    the current stream; ``wait()`` before a use makes the current stream wait for it when it is another stream and
+    the event has not completed — and forgets the event once it has, so a warm cache costs one attribute test.  Under
+    stream capture it does nothing (a captured step is ordered by its own fork / join edges)."""
+    __slots__ = ('event', 'stream')
+
+    def __init__(self, device=None):
+        self.event = None
+        self.stream = None
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            st = torch.cuda.current_stream(device)
+            self.event = torch.cuda.Event()
+            self.event.record(st)
+            self.stream = st.cuda_stream
+
+    def wait(self, device=None):
+        ev = self.event
+        if ev is None:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if ev.query():
+            self.event = None
+            return
+        st = torch.cuda.current_stream(device)
+        if st.cuda_stream != self.stream:
+            st.wait_event(ev)
+
+
 def clear_split_cache():
     _SPLIT_CACHE.clear()
 
@@ -705,6 +737,7 @@ def bfx_split_weights(w2d, cache=True):
     if cacheable:
         hit = _SPLIT_CACHE.get(key)
         if hit is not None and hit[0] == w2d._version and hit[1] == (rows, K):
+            hit[4].wait(w2d.device)
             return hit[3]
     out = torch.empty(lib.bgs_conv_bfx_weight_bytes(rows, K), dtype=torch.uint8, device=w2d.device)
     rc = lib.bgs_conv_bfx_split_weights(capi.ptr(w2d), capi.ptr(out), rows, K,
@@ -713,7 +746,7 @@ def bfx_split_weights(w2d, cache=True):
     if cacheable:
         if key not in _SPLIT_CACHE and len(_SPLIT_CACHE) >= _SPLIT_CACHE_MAX:
             _SPLIT_CACHE.pop(next(iter(_SPLIT_CACHE)))      # oldest entry (insertion order)
-        _SPLIT_CACHE[key] = (w2d._version, (rows, K), w2d, out)
+        _SPLIT_CACHE[key] = (w2d._version, (rows, K), w2d, out, CacheFence(w2d.device))
     return out
 
 
@@ -739,6 +772,7 @@ def bfx_split_weights_dgrad(w_krsc, cache=True):
     if cacheable:
         hit = _SPLIT_CACHE.get(key)
         if hit is not None and hit[0] == w_krsc._version and hit[1] == (Cout, R, S, Cin):
+            hit[4].wait(w_krsc.device)
             return hit[3]
     out = torch.empty(lib.bgs_conv_bfx_weight_bytes(Cin, R * S * Cout), dtype=torch.uint8,
                       device=w_krsc.device)
@@ -748,7 +782,7 @@ def bfx_split_weights_dgrad(w_krsc, cache=True):
     if cacheable:
         if key not in _SPLIT_CACHE and len(_SPLIT_CACHE) >= _SPLIT_CACHE_MAX:
             _SPLIT_CACHE.pop(next(iter(_SPLIT_CACHE)))
-        _SPLIT_CACHE[key] = (w_krsc._version, (Cout, R, S, Cin), w_krsc, out)
+        _SPLIT_CACHE[key] = (w_krsc._version, (Cout, R, S, Cin), w_krsc, out, CacheFence(w_krsc.device))
     return out
 
 

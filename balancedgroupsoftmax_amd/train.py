@@ -546,6 +546,7 @@ class TrunkPipeline(object):
         self.depth = depth
         self.lane = lane
         self._slots = [None] * len(self.stages)                 # slot j: (fork, output) of stage j for some batch
+        self._device = next(model.parameters()).device          # (also before the first image: push(None) on an empty pipeline)
 
     @staticmethod
     def _record(obj, stream):
@@ -577,7 +578,11 @@ class TrunkPipeline(object):
         from . import functional as BF
         if img is not None:
             self._device = img.device
+        elif all(s is None for s in self._slots):
+            return                               # nothing in flight and nothing new: the process-wide switches stay as they are
         if not BF._PIPELINE_ACTIVE[0]:
+            # (armed only when a slot is or becomes occupied — a trailing push(None) after the last take() used
+            #  to re-arm the switches with nothing in flight and leave them set until drain() / __del__)
             BF._PIPELINE_ACTIVE[0] = id(self)    # (functional.level_fork_enabled: no forks inside the pieces or beside the heads; the value names the owner)
             # ... and without forks beside them the P2 halo convs take the whole-rounds schedule of variant 7
             # (bit-identical), unless the caller has chosen a mode of his own
@@ -593,6 +598,8 @@ class TrunkPipeline(object):
                 self._slots[j - 1] = None
         if img is not None:
             self._slots[0] = self._launch(0, img, None)
+        elif all(s is None for s in self._slots):
+            self._deactivate()
 
     def prefetch(self, img):              # depth 2: push == prefetch
         self.push(img)

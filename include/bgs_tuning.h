@@ -120,7 +120,7 @@ int bgs_conv_bfx_wide_last_launch(void);
  * (N = 65,536: 4.5 -> 5.3 TB/s).  Bit-identical results in every mode. */
 void bgs_gs_loss_tuning(int prefetch);
 /* Round 6: prefetch 5 (the default) = the row-per-WAVE kernel (gs_loss_wavepriv_kernel: a wave owns a row in a private
- * LDS row, no workgroup barrier in the row loop) for 4096 <= N < 12288 rows of 16-byte-aligned tables whose bins fit the
+ * LDS row, no workgroup barrier in the row loop) for 4096 < N < 12288 rows of 16-byte-aligned tables whose bins fit the
  * register sweep (8192 rows: 16.4 -> 14.2 us), mode 3 elsewhere (faster again from 16,384 rows); 6 / 7 = row-per-wave for
  * every N >= the threshold with plain / non-temporal row loads (A/B).  Gradient bit-identical to modes 0 - 4, the per-bin
  * losses are the same terms summed in a different order.  bgs_gs_loss_wavepriv_min_rows: the row threshold (< 0: default).

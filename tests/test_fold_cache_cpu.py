@@ -79,3 +79,29 @@ def test_fold_cache_relists_when_the_set_of_registered_names_changes():
     assert cache.get(conv, build) == 3
     other, _ = _pair()
     assert cache.get(other, build) == 4 and cache.get((other,), build) == 4     # another module; tuple form
+
+
+def test_fold_cache_sees_a_sub_module_replaced_under_the_same_name():
+    """``m[0] = new_conv`` keeps the number of registered names; the cached slots pointed at the OLD module's
+    ``_parameters`` and a stale fold came back.  The identities of the registered sub-modules are part of the check."""
+    m = torch.nn.Sequential(torch.nn.Conv2d(4, 4, 1, bias=False), torch.nn.BatchNorm2d(4))
+    for p in m.parameters():
+        p.requires_grad = False
+    cache = B._FoldCache()
+    build = lambda: float(m[0].weight.sum())                      # noqa: E731  (what a fold would read)
+    first = cache.get(m, build)
+    assert cache.get(m, build) == first
+    new_conv = torch.nn.Conv2d(4, 4, 1, bias=False)
+    for p in new_conv.parameters():
+        p.requires_grad = False
+    m[0] = new_conv                                               # same name '0', same count
+    second = cache.get(m, build)
+    assert second == float(new_conv.weight.sum()) and second != first
+    assert cache.get(m, build) == second
+    blk = B.Bottleneck(8, 2)                                      # the product's user: Bottleneck.folded()
+    for p in blk.parameters():
+        p.requires_grad = False
+    blk.eval()
+    w_old = blk.folded()['c1'][0].clone()
+    blk.conv1 = torch.nn.Conv2d(8, 2, 1, bias=False).requires_grad_(False)
+    assert not torch.equal(blk.folded()['c1'][0], w_old)

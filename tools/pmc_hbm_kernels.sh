@@ -14,7 +14,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python - <<PY
 import csv, glob, collections, json, re
-pat = re.compile(r'(roi_align_nhwc_kernel<[^>]*>|roi_align_fwd_grid_kernel<[^>]*>|gs_merge_rowwave_kernel|iou_gtmax_kernel|iou_assign_kernel)')
+pat = re.compile(r'(roi_align_nhwc_kernel<[^>]*>|roi_align_fwd_grid_kernel<[^>]*>|gs_merge_rowwave_kernel|gs_merge_wavepriv_kernel<[^>]*>|iou_gtmax_kernel|iou_assign_kernel)')
 res = collections.defaultdict(dict)
 for C in ['FETCH_SIZE', 'WRITE_SIZE']:
     for f in glob.glob('$OUT/%s/**/*counter_collection.csv' % C, recursive=True):
