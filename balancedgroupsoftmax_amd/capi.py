@@ -106,6 +106,7 @@ SIGNATURES = {
     'bgs_conv3x3_halo_nhwc_f32_bfx_ex': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, c_f32p, c_f32p]
                                          + [ctypes.c_int] * 7 + [c_ptr, ctypes.c_size_t, c_ptr]),
     'bgs_gs_loss_tuning': (None, [ctypes.c_int]),
+    'bgs_gs_head_fold': (None, [ctypes.c_int]),
     'bgs_gs_loss_wavepriv_min_rows': (None, [ctypes.c_int]),
     'bgs_gs_merge_tuning': (None, [ctypes.c_int, ctypes.c_int]),
     'bgs_conv_bfx_wide_tuning': (None, [ctypes.c_int] * 3),

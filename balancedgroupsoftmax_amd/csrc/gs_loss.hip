@@ -420,6 +420,12 @@ struct GsHeadArgs {
   int R;
   float beta, box_w;
   unsigned long long* tstamps;   // debug (bgs_gs_head_debug_timestamps): [gridDim.x][8] s_memtime marks, or null
+  // round 6: the reduction of the partials INSIDE the main launch, by the workgroup that arrives last (null: the separate
+  // gs_head_reduce_kernel launch).  ticket: a zeroed device word, left zero by the last workgroup.
+  unsigned* ticket;
+  float* fold_out;               // [B + 1] loss terms
+  float* fold_total;             // [1] or null
+  uint64_t* fold_counter;        // the draw counter to advance, or null
 };
 
 // v_writelane_b32 with a run-time lane (hipcc has no builtin for it).  gfx9 VALU instructions read ONE SGPR
@@ -837,7 +843,71 @@ __global__ __launch_bounds__(kBlock) void gs_head_fused_kernel(GsHeadArgs a) {
 // real: the "real" plane is known in closed form (no ballots, no popcount pass).
 __host__ __device__ inline size_t gs_head_multi_lds_bytes(int N, int C, int wpad, int rpar) {
   return sizeof(float) * ((size_t)rpar * wpad + BGS_WAVE * bgs::kSweep) + 2 * (size_t)((N + 63) & ~63) +
-         2 * (size_t)((C + 7) & ~7) + sizeof(float) * 4 * rpar;
+         2 * (size_t)((C + 7) & ~7) + sizeof(float) * 4 * rpar + sizeof(float) * (BGS_MAX_BINS + 2);
+}
+
+// ---- the reduction folded into the main launch (round 6) --------------------------------------------------------
+// Every workgroup publishes its partials WRITE-THROUGH (agent-scope relaxed atomic stores: `global_store ... sc1`),
+// drains them (`s_waitcnt vmcnt(0)` in every storing wave), and one lane takes a ticket (a returning agent-scope
+// atomic add).  The workgroup that draws the last ticket reads ALL partials back with agent-scope relaxed atomic
+// loads (`sc1`: served past its own L1; the producers' stores went through their L2s, so neither a fence nor an L2
+// write-back is needed — cdna_hip_programming.md, Guideline 16, form R1) and finishes exactly as
+// gs_head_reduce_kernel does: one wave per row of partials, the same lanes adding the same values in the same order,
+// one DPP sum — bitwise the two-launch result whichever workgroup happens to be last.  It then advances the draw
+// counter (every workgroup read it at its start: all of them have arrived) and zeroes the ticket for the next launch.
+__device__ __forceinline__ void gs_store_partial(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float gs_load_partial(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// all threads of the workgroup call it after their partial stores; `scratch`: BGS_MAX_BINS + 2 floats of LDS nobody
+// else touches; nwaves = waves of the workgroup; draw0 = the counter value this launch started from
+__device__ __forceinline__ void gs_head_fold_tail(const GsHeadArgs& a, int G, bool has_box, float n_real_f,
+                                                  uint64_t draw0, float* scratch, int nwaves) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int gw = bgs::uniform(tid >> 6);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores have left
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    scratch[BGS_MAX_BINS + 1] = old == gridDim.x - 1 ? 1.f : 0.f;
+  }
+  __syncthreads();
+  if (scratch[BGS_MAX_BINS + 1] == 0.f) return;             // workgroup-uniform
+  const int B = a.B;
+  const int rows = B + (has_box ? 1 : 0);
+  for (int row = gw; row <= B; row += nwaves) {              // (gs_head_reduce_kernel: wave `row` of B + 1 waves)
+    float acc = 0.f;
+    if (row < rows) {
+      // (no index clamp: one base address + immediate offsets.  Reads past the row's end stay inside the workspace —
+      //  (B + 1) rows of G <= 2048 floats in kMaxGrid * (BGS_MAX_BINS + 1) — and are masked out of the sum.)
+      const float* src = a.partial + (size_t)row * G + lane;
+      for (int g0 = 0; g0 < G; g0 += BGS_WAVE * 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = gs_load_partial(src + g0 + BGS_WAVE * u);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += (g0 + lane + BGS_WAVE * u < G) ? v[u] : 0.f;
+      }
+    }
+    float sum = bgs::wave_sum(acc);
+    if (row == B && has_box) sum *= a.box_w / n_real_f;      // avg[0] = max(#real rows, 1)
+    if (lane == 0) {
+      scratch[row] = sum;
+      a.fold_out[row] = sum;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int b = 0; b <= B; ++b) t += scratch[b];
+    if (a.fold_total) a.fold_total[0] = t;
+    if (a.fold_counter) a.fold_counter[0] = draw0 + 1ull;
+    __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // sum over the wave of values that are zero outside lanes 0..15: four DPP steps inside row 0 (every lane of the row
@@ -890,7 +960,7 @@ __device__ __forceinline__ float gs_bin_loss_direct(const float* __restrict__ se
 }
 
 template <int VEC, bool WRITE_GRAD, bool BOX, int RPAR, bool DIRECT>
-__global__ __launch_bounds__(kBlock * RPAR) void gs_head_multi_kernel(GsHeadArgs a) {
+__global__ __launch_bounds__(kBlock * RPAR, 6) void gs_head_multi_kernel(GsHeadArgs a) {   // (6 waves per SIMD: the 80 registers it had before the folded tail)
   constexpr int T = kBlock * RPAR;
   constexpr int RP = kFusedRowsPerPass / RPAR;      // label rows per thread and pass (a pass = 1024 rows)
   static_assert(RP >= 1, "RPAR <= 4");
@@ -902,6 +972,7 @@ __global__ __launch_bounds__(kBlock * RPAR) void gs_head_multi_kernel(GsHeadArgs
       reinterpret_cast<unsigned long long*>(smem + (size_t)RPAR * wpad + BGS_WAVE * bgs::kSweep);   // [16][NW]
   unsigned short* sh_cbits = reinterpret_cast<unsigned short*>(sh_pl) + ((N + 63) & ~63);
   float* sh_box = reinterpret_cast<float*>(sh_cbits + cpad);                                        // [RPAR][4]
+  float* sh_fold = sh_box + 4 * RPAR;               // [BGS_MAX_BINS + 2]: the folded reduction's scratch
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int gw = bgs::uniform(tid >> 6);            // wave of the workgroup
@@ -912,7 +983,8 @@ __global__ __launch_bounds__(kBlock * RPAR) void gs_head_multi_kernel(GsHeadArgs
   const bool has_row = r < N;
   const int rc0 = has_row ? r : 0;
   uint64_t seed = a.seed;
-  if (a.seed_offset) seed += 0x2545F4914F6CDD1Dull * a.seed_offset[0];
+  const uint64_t draw0 = a.seed_offset ? a.seed_offset[0] : 0ull;
+  if (a.seed_offset) seed += 0x2545F4914F6CDD1Dull * draw0;
   const bool all_real = a.row_weights == nullptr;
   // (a load behind a branch is waited for where it is issued: without row weights the same load reads the labels'
   //  bytes and its value is ignored)
@@ -1133,9 +1205,15 @@ __global__ __launch_bounds__(kBlock * RPAR) void gs_head_multi_kernel(GsHeadArgs
         drow[c] = (pos_row && c == (int)slot) ? gp : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // partials per ROW: [B + 1][N]
-    if (lane < B && (lane % kWaves) == wave) a.partial[(size_t)lane * N + r] = lacc;
-    if (BOX && wave == kWaves - 1 && lane == 0) a.partial[(size_t)B * N + r] = box_acc;
+    if (a.ticket) {                           // (kernel-argument uniform) write-through: read back by the last workgroup
+      if (lane < B && (lane % kWaves) == wave) gs_store_partial(a.partial + (size_t)lane * N + r, lacc);
+      if (BOX && wave == kWaves - 1 && lane == 0) gs_store_partial(a.partial + (size_t)B * N + r, box_acc);
+    } else {
+      if (lane < B && (lane % kWaves) == wave) a.partial[(size_t)lane * N + r] = lacc;
+      if (BOX && wave == kWaves - 1 && lane == 0) a.partial[(size_t)B * N + r] = box_acc;
+    }
   }
+  if (a.ticket) gs_head_fold_tail(a, N, BOX, fmaxf((float)n_real, 1.f), draw0, sh_fold, T / BGS_WAVE);
 }
 
 // out[b] = sum_g partial[b][g] for b < B (loss weights are already inside), out[B] = box loss
@@ -1379,6 +1457,54 @@ namespace {
 // shared launcher of the fused head kernel; returns the grid in *grid_out
 unsigned long long* g_gs_tstamps = nullptr;
 
+// Tickets of the folded reduction (gs_head_fold_tail): a small pool of zeroed device words per device, handed out
+// round-robin — two head launches in flight at once (other streams, other graphs) take different words; the last
+// workgroup of a launch leaves its word zero.  Allocated on first use; a first use under stream capture (hipMalloc is
+// not capturable) falls back to the separate reduce launch for that call.
+constexpr int kTicketPool = 64, kTicketDevices = 16;
+unsigned* g_ticket_pool[kTicketDevices] = {};
+unsigned g_ticket_next = 0;
+// bgs_gs_head_fold / BGS_GS_HEAD_FOLD: 0 (default) = the separate reduce launch | 1 = the reduction inside the main launch.
+// MEASURED (profiles/r10h_gs_head_fold_ab.txt, hipGraph replay of the whole head step, interleaved): N = 1024 16.6 us folded
+// vs 14.7 us as two launches, N = 512 15.3 vs 14.5, N = 2048 26.0 vs 24.5 — the fold LOSES 1 - 2 us: 256 - 512 arrivals on
+// one ticket word cost 3 - 4 us (the guide's `fanin` row), every workgroup drains its gradient stores before it may
+// arrive, and the last workgroup's read-back of the 24 KB of partials is a second memory round trip on the launch's only
+// path — more than the ~1.5 us launch boundary + the 4.9 us reduce kernel it replaces, whose own loads start the
+// moment the main kernel retires.  Kept as a tested, bit-identical A/B arm ("or prove by A/B why not").
+int g_head_fold = -1;
+
+bool head_fold_enabled() {
+  if (g_head_fold < 0) {
+    const char* e = getenv("BGS_GS_HEAD_FOLD");
+    g_head_fold = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  return g_head_fold != 0;
+}
+
+unsigned* take_ticket(hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kTicketDevices) return nullptr;
+  if (!g_ticket_pool[dev]) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, sizeof(unsigned) * kTicketPool) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    if (hipMemset(p, 0, sizeof(unsigned) * kTicketPool) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(p);
+      return nullptr;
+    }
+    g_ticket_pool[dev] = p;
+  }
+  return g_ticket_pool[dev] + (g_ticket_next++ % kTicketPool);
+}
+
 // Rows per workgroup of the fused head kernel.  Every workgroup recounts the N labels (flags, per-bin
 // counts) before its first row; with R rows per workgroup that prologue is paid N / R times instead of
 // N times, against fewer workgroups to hide latency with.  0 = default; BGS_GS_HEAD_ROWS / the tuning
@@ -1470,6 +1596,7 @@ int launch_gs_head(GsHeadArgs& a, const int64_t* host_pred_slice, const float* h
 #undef BGS_MULTI_LAUNCH2
     return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
   }
+  a.ticket = nullptr;                       // (one row per workgroup, N > 2048: the separate reduce launch)
   const bool planes = variant >= 1;
 #define BGS_HEAD_LAUNCH(VEC_, GRAD_, BOX_)                                                              \
   do {                                                                                                  \
@@ -1559,8 +1686,14 @@ extern "C" int bgs_gs_head_step(const float* logits, const int64_t* labels,
   a.bbox_pred = bbox_pred; a.bbox_targets = bbox_targets; a.bbox_weights = bbox_weights;
   a.dbbox = dbbox_pred; a.R = num_reg_classes; a.beta = beta; a.box_w = box_loss_weight;
   int grid = 0;
+  if (loss_out && head_fold_enabled()) {    // the reduction inside the main launch (N <= 2048: launch_gs_head keeps it)
+    a.ticket = take_ticket((hipStream_t)stream);
+    a.fold_out = loss_out;
+    a.fold_total = total_out;
+    a.fold_counter = draw_counter;
+  }
   const int rc = launch_gs_head(a, host_pred_slice, host_bin_loss_weight, (hipStream_t)stream, &grid);
-  if (rc != BGS_OK || !loss_out) return rc;
+  if (rc != BGS_OK || !loss_out || a.ticket) return rc;
   hipLaunchKernelGGL(gs_head_reduce_kernel, dim3(1), dim3((unsigned)(BGS_WAVE * (a.B + 1))), 0, (hipStream_t)stream, a.partial,
                      grid, B, bbox_pred ? 1 : 0, box_loss_weight, avg_out, loss_out, total_out,
                      draw_counter);
@@ -1595,6 +1728,10 @@ extern "C" void bgs_gs_head_variant(int variant) {      // < 0: back to the defa
 }
 
 extern "C" int bgs_gs_head_variant_used(int N) { return head_variant_for(N); }
+
+// 0 (default; < 0 restores it) = the separate gs_head_reduce_kernel launch | 1 = bgs_gs_head_step reduces its partials
+// inside the main launch for N <= 2048 (the workgroup that arrives last; bitwise the two-launch result; 1 - 2 us slower)
+extern "C" void bgs_gs_head_fold(int on) { g_head_fold = on < 0 ? 0 : (on ? 1 : 0); }
 
 extern "C" void bgs_gs_head_tuning(int rows_per_workgroup) {
   g_head_rows = (rows_per_workgroup >= 0 && rows_per_workgroup <= 64) ? rows_per_workgroup : 0;

@@ -61,6 +61,12 @@ int bgs_launch_census(int family, int reset);
  *   launch with N rows takes. */
 void bgs_gs_head_debug_timestamps(unsigned long long* buf);
 void bgs_gs_head_tuning(int rows_per_workgroup);
+/* Round 6: bgs_gs_head_fold(1) (default 0; < 0 restores it; env BGS_GS_HEAD_FOLD=1 starts with it on): for N <= 2048
+ * bgs_gs_head_step reduces its per-row partials INSIDE the main launch — the workgroup that takes the last ticket reads
+ * them back and writes loss_out / total_out / the draw counter exactly as gs_head_reduce_kernel does (bitwise the
+ * two-launch result): ONE launch per head step.  Measured 1 - 2 us SLOWER than the two launches (N = 1024: 16.6 vs 14.7
+ * us; profiles/r10h_gs_head_fold_ab.txt), hence off by default: a tested A/B arm. */
+void bgs_gs_head_fold(int on);
 void bgs_gs_head_variant(int variant);
 int bgs_gs_head_variant_used(int N);
 

@@ -319,6 +319,55 @@ def test_row_per_wave_merge_kernel_is_bit_identical(N, shift):
     assert (outs[0][32 + shift: 32 + shift + N * C] != -7.0).all()
 
 
+@pytest.mark.parametrize('N', [1, 5, 64, 1000, 1024, 1500, 2048, 2049, 4096])
+@pytest.mark.parametrize('box', [False, True])
+def test_head_step_reduction_inside_the_main_launch_is_bitwise_the_two_launch_step(N, box):
+    """``bgs_gs_head_fold`` (round 6; measured 1 - 2 us slower than the two launches, so off by default): for N <= 2048 the workgroup that takes the last ticket reduces the
+    per-row partials INSIDE the main launch (write-through partial stores, a returning agent-scope ticket, agent-scope
+    loads in the last workgroup — no second launch).  Same six terms, total, gradients and draw counter, bit for bit,
+    as the main + ``gs_head_reduce_kernel`` pair, call after call (the ticket is left zero; the counter advances by one
+    per call, so every call draws another "others" sample); padding rows; N > 2048 takes the two-launch path in both
+    arms.  Launch counts by the census."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    counts = gs_tables.synthetic_instance_counts(C, seed=0)
+    l2b, ps, _ = gs_tables.build_group_tables(counts)
+    W = int(ps[:, 1].sum())
+    batch = gs_oracle.make_roi_batch(N, W, C, seed=31 + N, with_bbox=True)
+    labels, l2b_t = dev(batch['labels']), dev(l2b)
+    rw = torch.ones(N, device=DEV)
+    if N >= 5:
+        rw[N // 2::7] = 0.0                                           # padding rows (ragged batch)
+    kw = {}
+    if box:
+        kw = dict(bbox_pred=dev(batch['bbox_pred']), bbox_targets=dev(batch['bbox_targets']),
+                  bbox_weights=dev(batch['bbox_weights']), num_reg_classes=C, beta=1.0, box_loss_weight=1.0)
+    runs = {}
+    try:
+        for fold in (1, 0):
+            lib.bgs_gs_head_fold(fold)
+            ctr = torch.full((1,), 7, dtype=torch.int64, device=DEV)
+            outs = []
+            for call in range(3):
+                z = dev(batch['logits']).requires_grad_(True)
+                terms, total, avg = BF.gs_head_step(z, labels, l2b_t, ps, 8.0, 4321, draw_counter=ctr,
+                                                    row_weights=rw if N >= 5 else None, **kw)
+                total.backward()
+                torch.cuda.synchronize()
+                outs.append((terms.detach().cpu().numpy().copy(), total.detach().cpu().numpy().copy(),
+                             avg.cpu().numpy().copy(), z.grad.cpu().numpy().copy(), int(ctr.item())))
+            runs[fold] = outs
+    finally:
+        lib.bgs_gs_head_fold(-1)
+    for a, b in zip(runs[1], runs[0]):
+        for x, y in zip(a[:4], b[:4]):
+            np.testing.assert_array_equal(x, y)
+        assert a[4] == b[4]
+    assert [o[4] for o in runs[1]] == [8, 9, 10]                       # the counter advanced once per call
+    if N >= 1000:                                                      # another draw every call
+        assert not np.array_equal(runs[1][0][3], runs[1][1][3])
+
+
 # ---------------------------------------------------------------------------------------
 # device-side _remap_labels / _sample_others
 # ---------------------------------------------------------------------------------------
