@@ -84,6 +84,8 @@ def conv_roofline(dev, math, iters=20, wide=0):
                                'pmc_traffic.json')) as f:
             ent = json.load(f)[kname]['fpn_p2_out_2x200x336_3x3_256_256']
         traffic, src = ent['traffic_bytes_per_launch'], ent['source']
+        if ent.get('tree'):
+            src = '%s; tree %s' % (src, ent['tree'])
     except Exception:
         pass
     r = dict(bound='mfma', achieved=round(tf, 2), peak=round(peak, 1), unit='TFLOP/s',
@@ -142,7 +144,10 @@ def _pmc_traffic(kernel, n):
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
             ent = json.load(f)[kernel][str(n)]
-        return ent['traffic_bytes_per_launch'], ent.get('source')
+        src = ent.get('source')
+        if src and ent.get('tree'):          # the tree the PMC pass ran on (commit that added its summary to profiles/)
+            src = '%s; tree %s' % (src, ent['tree'])
+        return ent['traffic_bytes_per_launch'], src
     except Exception:
         return None, None
 
