@@ -261,6 +261,13 @@ class Bottleneck(nn.Module):
                                  passthrough=first_pt)
         if first_pt:
             out, identity = out
+        if not fuse and BF.fused_c3_eligible(out, f['c2'][0], f['c3'][0], self.stride, identity):
+            # frozen 64 -> 64 -> 256 block on a large map (ResNet-50 layer1): conv2 -> conv3 + residual + ReLU in one
+            # launch, the 64-channel intermediate stays in LDS (csrc/conv_bfx.hip, round 6; bit-identical)
+            if fk is not None:
+                fk.join()
+            return BF.conv3x3_c3_fused_nhwc(out, f['c2'][0], f['c2'][1], f['c3'][0], f['c3'][1], residual=identity,
+                                            relu3=True)
         out = BF.conv2d_autograd(out, f['c2'][0], f['c2'][1], stride=self.stride, pad=1,
                                  relu='consumers', mask_input=True)
         if fk is not None:

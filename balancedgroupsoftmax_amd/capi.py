@@ -101,6 +101,8 @@ SIGNATURES = {
     'bgs_conv2d_dgrad_nhwc_f32_bfx_ws': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, c_f32p, c_f32p]
                                          + [ctypes.c_int] * 11 + [c_ptr, ctypes.c_size_t, c_ptr]),
     'bgs_conv3x3_halo_bfx_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 5),
+    'bgs_conv3x3_c3_fused_nhwc_f32_bfx': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, c_ptr, c_f32p, c_f32p, c_f32p]
+                                          + [ctypes.c_int] * 6 + [c_ptr]),
     'bgs_conv3x3_halo_nhwc_f32_bfx': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, c_f32p]
                                       + [ctypes.c_int] * 7 + [c_ptr, ctypes.c_size_t, c_ptr]),
     'bgs_conv3x3_halo_nhwc_f32_bfx_ex': (ctypes.c_int, [c_f32p, c_ptr, c_f32p, c_f32p, c_f32p]

@@ -1581,6 +1581,325 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Round 6: the second half of a frozen ResNet bottleneck in ONE launch — conv2 (3x3 / stride 1, Cmid = 64 -> 64, folded
+// BN, ReLU) -> conv3 (1x1, 64 -> 256, folded BN) + residual + ReLU (mmdet/models/backbones/resnet.py:239-266) — for the
+// stride-4 map of layer1, where the two launches are a 66 us MFMA-bound halo conv followed by a 64 us HBM-bound 1x1
+// (34 MB written and read back for the 64-channel intermediate, and the 1x1's operands delivered to 8400 workgroups).
+//   phase 1  = conv3x3_halo_bfx4_kernel<1, 3> unchanged (8 x 16 pixels, patch split once per 16-channel chunk, filter
+//              slices by LDS-DMA): the conv2 tile in acc[2][1] per wave;
+//   phase 2  = its epilogue (bias, ReLU) through the LDS transpose — but instead of leaving for HBM every value is split
+//              into its three bf16 planes and written to LDS as the A operand of conv3: [plane][k chunk][pixel][32 B],
+//              halves swapped on odd 8-pixel groups (the B layout: conflict-free ds_read_b128);
+//   phase 3  = conv3 on the workgroup's 128 pixels x ALL 256 output channels: wave w owns channels 64 w .. 64 w + 63
+//              (acc3[4][2]: 128 accumulator registers), A fragments from LDS, the filter fragments of a k step straight
+//              from L2 into registers (the 98 KB filter is shared by every workgroup; 24 16-byte loads per lane in all);
+//   phase 4  = bias3 + residual + ReLU through the LDS transpose in two halves of 64 pixels, 16-byte loads / stores.
+// Arithmetic: the planes of phase 2 are split3 of the SAME fp32 values the unfused conv2 stores, the k steps and the six
+// plane products of phase 3 come in the ring kernel's order, the epilogue adds bias, then the residual, then clamps:
+// the output is BIT-IDENTICAL to the two-launch chain (tests/test_gpu_det_ops.py).  LDS: operands 29.9 KB (later the
+// phase-2 scratch) | planes 48 KB; the phase-4 scratch (65 KB) overlays both: 78 KB -> two workgroups per CU.
+struct FusedC3Args {
+  HaloBfxArgs h;          // conv2: x = [N,H,W,64], ws = its split filter, bias, relu
+  const __bf16* ws3;      // conv3 split filter [3][KC3][Cout3][16]
+  const float* bias3;     // [Cout3] or null
+  const float* res;       // residual [N,H,W,Cout3] or null
+  float* y;               // [N,H,W,Cout3]
+  int Cout3, KC3, relu3;
+};
+
+__global__ __launch_bounds__(kThreads, 3) void conv3x3_c3_fused_bfx_kernel(FusedC3Args g) {
+  const HaloBfxArgs& q = g.h;
+  const ConvArgs& p = q.c;
+  constexpr int NS = 3, TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, PROWS = PH * PW;
+  constexpr int AQ = PROWS * 4, AQT = (AQ + kThreads - 1) / kThreads;
+  constexpr int BN = 64, CO3 = 256, KC3 = 4;
+  constexpr int B_PLANE = BN * 32, B_BUF = NS * B_PLANE;
+  constexpr int SCR = 2 * B_BUF;
+  constexpr int A_OFF = SCR + 1024;
+  constexpr int HL = 32, A_PLANE = PROWS * HL;
+  constexpr int OPER_BYTES = A_OFF + NS * A_PLANE;                  // 30,592
+  constexpr int P3_CHUNK = 64 * 32, P3_PLANE = KC3 * P3_CHUNK;      // (64 pixels:) 2 KB per k chunk, 8 KB per plane
+  constexpr int LD2 = BN + 4, LD4 = CO3 + 4;
+  constexpr int S2_BYTES = 64 * LD2 * 4;                            // phase-2 transpose tile: 17,408
+  constexpr int Y_OFF = (S2_BYTES + 1023) & ~1023;                  // conv3's A planes, behind it: 18,432 .. 43,008
+  constexpr int Q4_BYTES = 32 * LD4 * 4;                            // phase-4 quarter tile: 33,280 (overlays both)
+  constexpr int LDS_BYTES = (Y_OFF + NS * P3_PLANE) > OPER_BYTES ? (Y_OFF + NS * P3_PLANE) : OPER_BYTES;
+  static_assert(Q4_BYTES <= LDS_BYTES && S2_BYTES <= Y_OFF, "scratch tiles overlay dead regions");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+  const unsigned* __restrict__ zero_page = q.zero;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = bgs::uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int vtile = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if (vtile >= p.tiles_m) return;                                   // workgroup-uniform (one channel tile)
+  const int n = vtile / (q.tiles_y * q.tiles_x);
+  const int trem = vtile - n * (q.tiles_y * q.tiles_x);
+  const int ty = trem / q.tiles_x, tx = trem - ty * q.tiles_x;
+  const int h0 = ty * TH - 1, w0 = tx * TW - 1;
+  const int cchunks = p.Cin / 16;
+
+  // ---- phase 1: conv2, the loop of conv3x3_halo_bfx4_kernel<1, 3> (filter DMA roles: six pieces, wave w takes piece w
+  //      and, w < 2, piece w + 4; a dummy piece into the scratch block otherwise)
+  const int brow_d = (wave & 1) * 32 + (lane >> 1);
+  const int bhalf_d = (lane & 1) ^ ((brow_d >> 3) & 1);
+  const bool b_okd = brow_d < p.Cout;
+  const __bf16* b_lane = q.ws + (size_t)(b_okd ? brow_d : 0) * 16 + bhalf_d * 8;
+  const size_t b_plane = (size_t)q.KC * p.Cout * 16;
+  auto issue_b = [&](int chunk, int tap, int buf_off) {
+    const size_t koff = (size_t)(tap * cchunks + chunk) * p.Cout * 16;
+    const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page);
+    const int s0 = wave >> 1;
+    glds16(b_okd ? b_lane + s0 * b_plane + koff : zp, lds + buf_off + s0 * B_PLANE + (wave & 1) * 1024);
+    if (wave < 2) glds16(b_okd ? b_lane + 2 * b_plane + koff : zp, lds + buf_off + 2 * B_PLANE + wave * 1024);
+    else glds16(zp, lds + SCR);
+  };
+  const float* a_src[AQT];
+  int a_dst[AQT];
+  bool a_use[AQT];
+  f32x4 ra[AQT];
+#pragma unroll
+  for (int i = 0; i < AQT; ++i) {
+    const int idx = tid + kThreads * i;
+    a_use[i] = idx < AQ;
+    const int prow = a_use[i] ? idx >> 2 : 0, kq = idx & 3;
+    const int pr = prow / PW, pc = prow - pr * PW;
+    const int hi = h0 + pr, wi = w0 + pc;
+    const bool in = a_use[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+    a_src[i] = in ? p.x + (((size_t)n * p.H + hi) * p.W + wi) * p.Cin + kq * 4
+                  : reinterpret_cast<const float*>(g_zero_page);
+    const int kq_off = (((kq >> 1) ^ ((pr + pc) & 1)) << 4) + (kq & 1) * 8;
+    a_dst[i] = (in ? 1 : 0) | ((prow * HL + kq_off) << 1);
+  }
+  auto load_a = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < AQT; ++i)
+      ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + ((a_dst[i] & 1) ? chunk * 16 : 0));
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < AQT; ++i) {
+      if (!a_use[i]) continue;
+      u32x2 hh, mm, ll;
+      split3(ra[i], hh, mm, ll);
+      unsigned char* d = lds + A_OFF + (a_dst[i] >> 1);
+      *reinterpret_cast<u32x2*>(d) = hh;
+      *reinterpret_cast<u32x2*>(d + A_PLANE) = mm;
+      *reinterpret_cast<u32x2*>(d + 2 * A_PLANE) = ll;
+    }
+  };
+  const int frow = lane & 31, fk = lane >> 5;
+  int a_frag[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int m = wm * 64 + a * 32 + frow;
+    const int pr = m / TW, pc = m % TW;
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+      a_frag[a][par] = A_OFF + (pr * PW + pc) * HL + ((fk ^ ((pr + pc + par) & 1)) << 4);
+  }
+  const int brow = wn * 32 + frow;
+  const int b_frag = brow * 32 + ((fk ^ ((brow >> 3) & 1)) << 4);
+  f32x16 acc[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  load_a(0);
+  issue_b(0, 0, 0);
+  store_a();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0, nxt = B_BUF;
+  for (int chunk = 0; chunk < cchunks; ++chunk) {
+    const bool last_chunk = chunk + 1 >= cchunks;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int rd = (tap & 1) ? nxt : cur;
+      const int wr = (tap & 1) ? cur : nxt;
+      if (tap < 8) issue_b(chunk, tap + 1, wr);
+      else if (!last_chunk) issue_b(chunk + 1, 0, wr);
+      if (tap == 0 && !last_chunk) load_a(chunk + 1);
+      const int tap_off = ((tap / 3) * PW + (tap % 3)) * HL;
+      const int tap_par = (tap / 3 + tap % 3) & 1;
+      bf16x8 fa[NS][2], fb[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+          fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a][tap_par] + tap_off + s * A_PLANE);
+        fb[s] = *reinterpret_cast<const bf16x8*>(lds + rd + b_frag + s * B_PLANE);
+      }
+      if (q.flags & 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+      }
+#pragma unroll
+      for (int tt = NS - 1; tt >= 0; --tt)
+#pragma unroll
+        for (int i = 0; i <= tt; ++i)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+            acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[tt - i], acc[a], 0, 0, 0);
+      if (q.flags & 1) __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tap == 8 && !last_chunk) {
+        store_a();
+        __syncthreads();
+      }
+    }
+    const int t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+
+  // ---- phases 2 - 4, once per HALF of the tile (64 pixels: the conv2 accumulators of the waves wm == h).  Per half:
+  //      conv2 epilogue -> split planes of 64 pixels (24 KB) -> conv3 on 64 pixels x 256 channels (wave w: channels
+  //      64 w .. 64 w + 63, acc3[2][2]) -> bias3 + residual + ReLU in two quarters of 32 pixels.  LDS never holds more
+  //      than scratch2 (17 KB) + planes (24 KB) or a 33 KB quarter tile: 41.5 KB, three workgroups per CU.
+  // Buffer addressing (`buffer_load / store_dwordx4 v, voffset, srsrc, soffset offen`): a resource descriptor in four
+  // SGPRs, ONE 32-bit lane offset, the per-load constant as the scalar offset.  With flat pointers hipcc kept a 64-bit
+  // vector address per load alive across the half loop (24 for the filter fragments alone) and spilled 49 - 65
+  // registers to fit the three workgroups per CU.  Reads past the end of a descriptor return 0: a NULL residual is a
+  // descriptor of 0 bytes, and rows below the image need no clamp.
+  const int b3_lane = ((wave * 64 + frow) * 16 + fk * 8) * 2;       // bytes
+  const __amdgpu_buffer_rsrc_t b3_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(g.ws3), 0, NS * KC3 * CO3 * 16 * 2, 0x00020000);
+  auto load_b3 = [&](int kc, bf16x8 (&dst)[NS][2]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        dst[s][b] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   b3_rsrc, b3_lane, (((s * KC3 + kc) * CO3 + 32 * b) * 16) * 2, 0));
+  };
+  const size_t img_base = (size_t)n * p.H * p.W * CO3;              // wave-uniform
+  const int img_bytes = p.H * p.W * CO3 * 4;                        // < 2^31 (checked by the launcher)
+  const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.res ? g.res + img_base : reinterpret_cast<const float*>(g_zero_page)), 0,
+      g.res ? img_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(g.y + img_base, 0, img_bytes, 0x00020000);
+  float* scratch = reinterpret_cast<float*>(lds);
+  const int c2_4 = (tid & 15) * 4, r2_0 = tid >> 4;                 // phase 2: 16 threads per pixel row, 16 rows per pass
+  f32x4 bias2 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias2 = *reinterpret_cast<const f32x4*>(p.bias + c2_4);
+  const int kc2 = c2_4 >> 4, kq2 = (c2_4 & 15) >> 2;
+  const int c4 = (tid & 63) * 4, r0 = tid >> 6;                     // phase 4: 64 threads per pixel row, 4 rows per pass
+  f32x4 bias3 = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias3) bias3 = *reinterpret_cast<const f32x4*>(g.bias3 + c4);
+  int a3_frag[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int m = a * 32 + frow;
+    a3_frag[a] = Y_OFF + m * 32 + ((fk ^ ((m >> 3) & 1)) << 4);
+  }
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    bf16x8 fb3[NS][2];
+    load_b3(0, fb3);                                                // in flight under phase 2
+    // ---- phase 2
+    if (wm == h) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          scratch[i * LD2 + wn * 32 + (lane & 31)] = acc[a][r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int i = r2_0 + ps * 16;                                 // pixel of the half
+      f32x4 v = *reinterpret_cast<const f32x4*>(scratch + i * LD2 + c2_4);
+      v += bias2;
+      if (p.relu) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+      }
+      u32x2 hh, mm, ll;
+      split3(v, hh, mm, ll);
+      unsigned char* d = lds + Y_OFF + kc2 * P3_CHUNK + i * 32 + (((kq2 >> 1) ^ ((i >> 3) & 1)) << 4) + (kq2 & 1) * 8;
+      *reinterpret_cast<u32x2*>(d) = hh;
+      *reinterpret_cast<u32x2*>(d + P3_PLANE) = mm;
+      *reinterpret_cast<u32x2*>(d + 2 * P3_PLANE) = ll;
+    }
+    __syncthreads();
+    // ---- phase 3
+    f32x16 acc3[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[a][b][r] = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < KC3; ++kc) {
+      bf16x8 fa3[NS][2];
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+          fa3[s][a] = *reinterpret_cast<const bf16x8*>(lds + a3_frag[a] + kc * P3_CHUNK + s * P3_PLANE);
+#pragma unroll
+      for (int tt = NS - 1; tt >= 0; --tt)
+#pragma unroll
+        for (int i = 0; i <= tt; ++i)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              acc3[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa3[i][a], fb3[tt - i][b], acc3[a][b], 0, 0, 0);
+      // the next k chunk's filter fragments into the same registers, behind this chunk's MFMAs (a second register
+      // set for them costs the third workgroup per CU; the other workgroups' MFMAs cover the L2 latency)
+      if (kc + 1 < KC3) load_b3(kc + 1, fb3);
+    }
+    __syncthreads();                                                // every wave is done with the planes
+    // ---- phase 4: two quarters of 32 pixels
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      // the quarter's residual values: 8 unconditional 16-byte loads per thread (clamped coordinates / the zero page),
+      // in flight under the scratch writes and the barrier (a load behind the bounds branch is waited for where it is
+      // issued: 32 dependent HBM round trips per workgroup in the first version of this kernel)
+      f32x4 rs[8];
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int m = h * 64 + a * 32 + r0 + ps * 4;
+        const int ho = ty * TH + m / TW, wo = tx * TW + m % TW;     // (a column past the image reads a pixel nobody stores)
+        rs[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, ((ho * p.W + wo) * CO3 + c4) * 4,
+                                                                                 0, 0));
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          scratch[i * LD4 + wave * 64 + b * 32 + (lane & 31)] = acc3[a][b][r];
+        }
+      __syncthreads();
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int i = r0 + ps * 4;
+        const int m = h * 64 + a * 32 + i;
+        const int ho = ty * TH + m / TW, wo = tx * TW + m % TW;
+        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + i * LD4 + c4);
+        v += bias3;
+        if (g.res) v += rs[ps];                                    // (kept conditional: v + 0 could turn a -0 into +0)
+        if (g.relu3) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+        }
+        if (ho < p.H && wo < p.W)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, ((ho * p.W + wo) * CO3 + c4) * 4, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+
 // Variant 7 ("wide pixel tile", round 5): a 16 x 16 = 256-pixel x 128-channel output tile per workgroup — twice the
 // pixels per filter byte of variant 4.  Why: variant 4's step is co-limited by the matrix pipe and by the 12 KB
 // filter slice every workgroup pulls through the L2 -> LDS path per tap (three workgroups per CU: 36 KB per 2304
@@ -2421,6 +2740,53 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx(const float* x, const void* wsplit,
                                              size_t workspace_bytes, bgs_stream_t stream) {
   return bgs_conv3x3_halo_nhwc_f32_bfx_ex(x, wsplit, bias, nullptr, y, N, H, W, Cin, Cout, relu, planes,
                                           workspace, workspace_bytes, stream);
+}
+
+// conv2 (3x3 / s1 / p1, Cmid -> Cmid, bias2, ReLU) -> conv3 (1x1, Cmid -> Cout3, bias3) + residual + ReLU in one
+// launch (conv3x3_c3_fused_bfx_kernel): x [N,H,W,Cmid], w2split / w3split = bgs_conv_bfx_split_weights of the folded
+// filters [Cmid][9 Cmid] / [Cout3][Cmid], residual [N,H,W,Cout3] or NULL, y [N,H,W,Cout3].  Supported: Cmid = 64,
+// Cout3 = 256 (ResNet-50 layer1), fp32-faithful planes; BGS_ERR_UNSUPPORTED otherwise (callers run the two launches).
+// Bit-identical to bgs_conv3x3_halo_nhwc_f32_bfx followed by bgs_conv2d_nhwc_f32_bfx_ws.
+extern "C" int bgs_conv3x3_c3_fused_nhwc_f32_bfx(const float* x, const void* w2split, const float* bias2,
+                                                 const void* w3split, const float* bias3, const float* residual,
+                                                 float* y, int N, int H, int W, int Cmid, int Cout3, int relu3,
+                                                 bgs_stream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || !x || !w2split || !w3split || !y) return BGS_ERR_INVALID_ARG;
+  if (Cmid != 64 || Cout3 != 256) return BGS_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)w2split | (uintptr_t)w3split | (uintptr_t)y | (uintptr_t)residual |
+       (uintptr_t)bias2 | (uintptr_t)bias3) % 16 != 0)
+    return BGS_ERR_UNSUPPORTED;
+  const long long M = (long long)N * H * W;
+  if (M > 0x7fffffffLL || (long long)H * W * Cout3 > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;   // 32-bit offsets inside an image
+  FusedC3Args g;
+  HaloBfxArgs& q = g.h;
+  q.ns = 3;
+  ConvArgs& p = q.c;
+  p.x = x; p.w = nullptr; p.bias = bias2; p.res = nullptr; p.mask = nullptr; p.y = nullptr;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cmid; p.Cout = Cmid; p.R = 3; p.S = 3; p.stride = 1; p.pad = 1;
+  p.Ho = H; p.Wo = W; p.M = (int)M; p.K = 9 * Cmid; p.relu = 1; p.res_mode = 0;
+  p.partial = nullptr; p.kt_per_split = 0;
+  q.ws = reinterpret_cast<const __bf16*>(w2split);
+  q.KC = bfx_kc(p.K);
+  q.tiles_y = (H + 7) / 8;
+  q.tiles_x = (W + 15) / 16;
+  p.tiles_m = N * q.tiles_y * q.tiles_x;
+  p.tiles_n = 1;
+  p.chunk = (p.tiles_m + 7) / 8;
+  q.chunks_per_split = Cmid / 16;
+  q.zero = zero_page_device();
+  if (!q.zero) return BGS_ERR_LAUNCH;
+  q.flags = g_halo_flags;
+  g.ws3 = reinterpret_cast<const __bf16*>(w3split);
+  g.bias3 = bias3;
+  g.res = residual;
+  g.y = y;
+  g.Cout3 = Cout3;
+  g.KC3 = bfx_kc(Cmid);
+  g.relu3 = relu3;
+  bgs_internal_census_bump(BGS_CENSUS_FUSED_C3);
+  hipLaunchKernelGGL(conv3x3_c3_fused_bfx_kernel, dim3((unsigned)(8 * p.chunk)), dim3(kThreads), 0, (hipStream_t)stream, g);
+  BGS_RETURN_LAUNCH_STATUS();
 }
 
 // ... with `mask` [N,H,W,Cout] or NULL: y = mask > 0 ? y : 0 in the epilogue — the DATA GRADIENT of a

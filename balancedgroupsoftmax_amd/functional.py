@@ -818,7 +818,7 @@ def conv_bfx_last_launch():
 
 
 CENSUS = dict(bf16_ring8=0, grouped_lds=1, halo_bfx4=2, dma_ring64=3, gs_head_fused=4, conv1x1_bres=5,
-              wgrad_bfx=6, roi_bwd_gather=7, bf16s=8, grouped_bf16s=9, bfx_wide=10, gs_scale_grad=11, halo_wide=12, stem_fused=13)
+              wgrad_bfx=6, roi_bwd_gather=7, bf16s=8, grouped_bf16s=9, bfx_wide=10, gs_scale_grad=11, halo_wide=12, stem_fused=13, fused_c3=14)
 
 
 def launch_census(reset=False):
@@ -866,6 +866,55 @@ def _use_halo_kernel(M, Cout):
     if env == '0':
         return False
     return M >= 100000 and Cout % 128 == 0
+
+
+_FUSED_C3 = [os.environ.get('BGS_FUSED_C3', '1') != '0']
+
+
+def set_fused_c3(on):
+    """-> previous value.  ``BGS_FUSED_C3=0`` / ``set_fused_c3(False)``: a frozen bottleneck runs conv2 and conv3 as two
+    launches (the A/B arm; bit-identical)."""
+    prev = _FUSED_C3[0]
+    _FUSED_C3[0] = bool(on)
+    return prev
+
+
+def fused_c3_eligible(x, w2, w3, stride, residual):
+    """conv2 -> conv3 of a frozen bottleneck in one launch (``bgs_conv3x3_c3_fused_nhwc_f32_bfx``, round 6): fp32 NHWC
+    activations under the fp32-faithful arithmetic, 3x3 / stride 1, 64 -> 64 -> 256 channels (ResNet-50 layer1), the map
+    large enough for the halo kernel, nothing that needs a gradient."""
+    env = os.environ.get('BGS_FUSED_C3')              # (read at every call: tools/step_ab.py switches it between arms)
+    on = _FUSED_C3[0] if env is None else env != '0'
+    return (on and _CONV_MATH[0] == 'bf16x6' and x.is_cuda and x.dtype == torch.float32 and stride == 1
+            and tuple(w2.shape[:3]) == (64, 3, 3) and w2.shape[3] == 64 and tuple(w3.shape) == (256, 1, 1, 64)
+            and x.shape[3] == 64 and _use_halo_bfx(x.shape[0] * x.shape[1] * x.shape[2], 64)
+            # (>= 700 pixel tiles: below that the unfused conv2 splits its channel chunks over gridDim.z — another
+            #  summation order — and a short grid gains nothing from the fusion; csrc/conv_bfx.hip halo_bfx_plan)
+            and x.shape[0] * ((x.shape[1] + 7) // 8) * ((x.shape[2] + 15) // 16) >= 700
+            and not (torch.is_grad_enabled() and (x.requires_grad or w2.requires_grad or w3.requires_grad or
+                                                  (residual is not None and residual.requires_grad))))
+
+
+def conv3x3_c3_fused_nhwc(x, w2_krsc, bias2, w3_krsc, bias3, residual=None, relu3=True, out=None):
+    """``y = act(conv1x1(relu(conv3x3(x, w2) + bias2), w3) + bias3 + residual)`` in ONE launch (the second half of a frozen
+    bottleneck, resnet.py:239-266); bit-identical to the two ``conv2d_nhwc`` calls it replaces."""
+    _require_cuda(x, w2_krsc, bias2, w3_krsc, bias3, residual)
+    lib = capi.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    N, H, W, Cmid = x.shape
+    Cout3 = w3_krsc.shape[0]
+    assert tuple(w2_krsc.shape) == (Cmid, 3, 3, Cmid) and tuple(w3_krsc.shape) == (Cout3, 1, 1, Cmid)
+    if residual is not None:
+        assert tuple(residual.shape) == (N, H, W, Cout3) and residual.is_contiguous() and residual.dtype == torch.float32
+    if out is None:
+        out = torch.empty((N, H, W, Cout3), dtype=torch.float32, device=x.device)
+    w2s = bfx_split_weights(w2_krsc.view(Cmid, 9 * Cmid), cache=True)
+    w3s = bfx_split_weights(w3_krsc.view(Cout3, Cmid), cache=True)
+    rc = lib.bgs_conv3x3_c3_fused_nhwc_f32_bfx(capi.ptr(x), capi.ptr(w2s), capi.ptr(bias2), capi.ptr(w3s),
+                                               capi.ptr(bias3), capi.ptr(residual), capi.ptr(out), N, H, W, Cmid,
+                                               Cout3, int(bool(relu3)), capi.current_stream(x.device))
+    capi.check('bgs_conv3x3_c3_fused_nhwc_f32_bfx', rc)
+    return out
 
 
 def conv2d_nhwc(x, w_krsc, bias=None, stride=1, pad=0, relu=False, residual=None,

@@ -344,6 +344,18 @@ int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wsplit, const f
                                      const float* mask, float* y, int N, int H, int W, int Cin,
                                      int Cout, int relu, int planes, void* workspace,
                                      size_t workspace_bytes, bgs_stream_t stream);
+/* Round 6.  The second half of a frozen ResNet bottleneck (mmdet/models/backbones/resnet.py:239-266) in ONE launch:
+ * conv2 (3x3 / stride 1 / pad 1, Cmid -> Cmid, folded BN bias2, ReLU) -> conv3 (1x1, Cmid -> Cout3, folded BN bias3)
+ * + residual + ReLU (relu3).  x [N,H,W,Cmid] fp32 NHWC; w2split / w3split = bgs_conv_bfx_split_weights of the folded
+ * filters viewed as [Cmid][9 Cmid] / [Cout3][Cmid]; residual [N,H,W,Cout3] or NULL; y [N,H,W,Cout3].  The 64-channel
+ * intermediate never reaches HBM.  Supported: Cmid = 64, Cout3 = 256 (ResNet-50 layer1), 16-byte aligned pointers;
+ * BGS_ERR_UNSUPPORTED otherwise (run the two launches).  BIT-IDENTICAL to bgs_conv3x3_halo_nhwc_f32_bfx followed by
+ * bgs_conv2d_nhwc_f32_bfx_ws with the residual. */
+int bgs_conv3x3_c3_fused_nhwc_f32_bfx(const float* x, const void* w2split, const float* bias2,
+                                      const void* w3split, const float* bias3, const float* residual,
+                                      float* y, int N, int H, int W, int Cmid, int Cout3, int relu3,
+                                      bgs_stream_t stream);
+
 
 /* Grouped 3x3 convolution (pad 1, stride 1 or 2) + bias + ReLU, NHWC: conv2 of the ResNeXt
  * bottleneck (mmdet/models/backbones/resnext.py:47-57, cfg 5 = X101-64x4d).  x [N,H,W,C],

@@ -47,6 +47,7 @@ int bgs_selftest_mfma_peak_bf16(int blocks, int iters, int random_operands, floa
 #define BGS_CENSUS_GS_SCALE_GRAD 11   /* gs_head_scale_grad_kernel (a non-unit upstream gradient) */
 #define BGS_CENSUS_HALO_WIDE 12       /* conv3x3_halo_bfx7_kernel (16 x 16-pixel x 128-channel units) */
 #define BGS_CENSUS_STEM_FUSED 13      /* stem_conv7x7s2_relu_maxpool_kernel (conv + ReLU + max-pool, NCHW in) */
+#define BGS_CENSUS_FUSED_C3 14        /* conv3x3_c3_fused_bfx_kernel (conv2 -> conv3 + residual + ReLU of a frozen bottleneck) */
 #define BGS_CENSUS_FAMILIES 16
 int bgs_launch_census(int family, int reset);
 

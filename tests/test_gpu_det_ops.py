@@ -1628,3 +1628,90 @@ def test_stride2_data_gradient_parity_rows_equal_the_zero_upsampled_form(case, m
         float((outs[0] - outs[1]).abs().max()) / scale
     tol = 2e-5 if math == 'bf16x6' else 3e-2
     assert np.abs(outs[0].numpy() - edx).max() <= tol * np.abs(edx).max()
+
+
+@pytest.mark.parametrize('case', [
+    # N, H, W, residual, relu3
+    (1, 8, 16, True, True),             # exactly one tile
+    (1, 13, 21, True, True),            # ragged in both directions (tile rows / columns past the image)
+    (2, 40, 56, False, True),           # no residual
+    (2, 40, 56, True, False),           # no final ReLU
+    (2, 200, 336, True, True),          # ResNet-50 layer1 at the BASELINE size (2100 tiles)
+], ids=lambda c: 'x'.join(str(int(v)) for v in c))
+def test_fused_conv2_conv3_bottleneck_tail_is_bit_identical_to_the_two_launches(case, monkeypatch):
+    """``conv3x3_c3_fused_bfx_kernel`` (round 6): conv2 (3x3, 64 -> 64, folded BN, ReLU) -> conv3 (1x1, 64 -> 256, folded
+    BN) + residual + ReLU of a frozen bottleneck (mmdet/models/backbones/resnet.py:239-266) in ONE launch, the 64-channel
+    intermediate kept in LDS as split bf16 planes.  Every output is accumulated in the unfused kernels' order (the halo
+    kernel's taps / chunks, the ring kernel's k steps and plane products, bias then residual then clamp): BIT-IDENTICAL
+    to ``conv2d_nhwc(3x3)`` + ``conv2d_nhwc(1x1, residual=)``, and within the family's bound of fp64."""
+    N, H, W, with_res, relu3 = case
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.relu(torch.randn(N, H, W, 64, generator=g) * torch.exp(torch.randn(N, H, W, 64, generator=g)))
+    w2 = torch.randn(64, 3, 3, 64, generator=g) * (2.0 / (9 * 64)) ** 0.5
+    b2 = torch.randn(64, generator=g) * 0.5
+    w3 = torch.randn(256, 1, 1, 64, generator=g) * (2.0 / 64) ** 0.5
+    b3 = torch.randn(256, generator=g) * 0.5
+    res = torch.randn(N, H, W, 256, generator=g) if with_res else None
+    monkeypatch.setenv('BGS_CONV_HALO', '1')
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        xd, w2d, b2d, w3d, b3d = dev(x), dev(w2), dev(b2), dev(w3), dev(b3)
+        rd = dev(res) if with_res else None
+        BF.conv_bfx_tuning(halo_splits=1, halo_wide=0)
+        t2 = BF.conv2d_nhwc(xd, w2d, b2d, pad=1, relu=True)
+        ref = BF.conv2d_nhwc(t2, w3d, b3d, relu=relu3, residual=rd)
+        out = BF.conv3x3_c3_fused_nhwc(xd, w2d, b2d, w3d, b3d, residual=rd, relu3=relu3)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), float((out - ref).abs().max())
+        # fp64 reference of the chain (the fp32 intermediate rounded as the kernels round it)
+        t2_64 = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w2.double().permute(0, 3, 1, 2), b2.double(),
+                                           padding=1).relu().float().double()
+        y64 = torch.nn.functional.conv2d(t2_64, w3.double().permute(0, 3, 1, 2), b3.double())
+        if with_res:
+            y64 = y64 + res.double().permute(0, 3, 1, 2)
+        if relu3:
+            y64 = y64.relu()
+        err = (out.cpu().double() - y64.permute(0, 2, 3, 1)).abs().max().item()
+        assert err < 2e-4 * max(1.0, y64.abs().max().item()), err
+    finally:
+        BF.conv_bfx_tuning()
+        BF.set_conv_math(prev)
+
+
+def test_frozen_layer1_bottleneck_takes_the_fused_tail_and_keeps_its_bits(monkeypatch):
+    """``backbone.Bottleneck.run`` on a frozen 64 -> 64 -> 256 block over a map large enough for the halo kernel: the fused
+    conv2 -> conv3 launch (default) == the three-launch block (``BGS_FUSED_C3`` off), bit for bit, with and without the
+    projection shortcut."""
+    from balancedgroupsoftmax_amd import backbone as B
+    monkeypatch.setenv('BGS_CONV_HALO', '1')
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        for ds, inpl in ((True, 64), (False, 256)):
+            torch.manual_seed(5 + inpl)
+            blk = B.Bottleneck(inpl, 64, stride=1, downsample=ds).to(DEV).eval()
+            with torch.no_grad():
+                for m in blk.modules():
+                    if isinstance(m, torch.nn.BatchNorm2d):
+                        m.running_mean.normal_(0, 0.1)
+                        m.running_var.uniform_(0.5, 1.5)
+                        m.weight.normal_(1, 0.1)
+                        m.bias.normal_(0, 0.1)
+            for p_ in blk.parameters():
+                p_.requires_grad = False
+            x = torch.relu(torch.randn(2, 160, 288, inpl, device=DEV))       # 720 pixel tiles: the fused path's range
+            assert BF.fused_c3_eligible(torch.empty(2, 160, 288, 64, device=DEV), blk.folded()['c2'][0],
+                                        blk.folded()['c3'][0], 1, None)
+            with torch.no_grad():
+                f = blk.folded()
+                on = BF.set_fused_c3(True)
+                BF.launch_census(reset=True)
+                y1 = blk.run(x, f)
+                assert BF.launch_census()['fused_c3'] == 1
+                BF.set_fused_c3(False)
+                BF.launch_census(reset=True)
+                y0 = blk.run(x, f)
+                assert BF.launch_census()['fused_c3'] == 0
+                BF.set_fused_c3(on)
+            assert torch.equal(y1, y0)
+    finally:
+        BF.set_conv_math(prev)
