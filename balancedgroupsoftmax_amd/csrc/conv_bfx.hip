@@ -1615,7 +1615,10 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_c3_fused_bfx_kernel(Fused
   constexpr int AQ = PROWS * 4, AQT = (AQ + kThreads - 1) / kThreads;
   constexpr int BN = 64, CO3 = 256, KC3 = 4;
   constexpr int B_PLANE = BN * 32, B_BUF = NS * B_PLANE;
-  constexpr int SCR = 2 * B_BUF;
+  // filter slices in a THREE-deep ring (the halo kernel keeps two): with 64 output channels a step is 12 MFMAs per wave
+  // (384 cycles) — less than the L2 -> LDS round trip of the next slice, which a two-deep ring issues only one step ahead
+  constexpr int BR = 3;
+  constexpr int SCR = BR * B_BUF;
   constexpr int A_OFF = SCR + 1024;
   constexpr int HL = 32, A_PLANE = PROWS * HL;
   constexpr int OPER_BYTES = A_OFF + NS * A_PLANE;                  // 30,592
@@ -1708,19 +1711,23 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_c3_fused_bfx_kernel(Fused
     for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
   load_a(0);
   issue_b(0, 0, 0);
+  issue_b(0, 1, B_BUF);
   store_a();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int cur = 0, nxt = B_BUF;
   for (int chunk = 0; chunk < cchunks; ++chunk) {
     const bool last_chunk = chunk + 1 >= cchunks;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int rd = (tap & 1) ? nxt : cur;
-      const int wr = (tap & 1) ? cur : nxt;
-      if (tap < 8) issue_b(chunk, tap + 1, wr);
-      else if (!last_chunk) issue_b(chunk + 1, 0, wr);
-      if (tap == 0 && !last_chunk) load_a(chunk + 1);
+      // slice (chunk, tap) sits in ring slot tap % 3 (nine taps per chunk: the slot of a tap is the same in every chunk);
+      // slice + 2 goes to the slot slice - 1 was read from (its readers passed the barrier of the previous step)
+      const int rd = (tap % BR) * B_BUF;
+      const int wr = ((tap + 2) % BR) * B_BUF;
+      const bool more = tap + 2 < 9 || !last_chunk;                 // a slice two steps ahead exists
+      if (tap + 2 < 9) issue_b(chunk, tap + 2, wr);
+      else if (!last_chunk) issue_b(chunk + 1, tap + 2 - 9, wr);
+      const bool patch = tap == 0 && !last_chunk;
+      if (patch) load_a(chunk + 1);
       const int tap_off = ((tap / 3) * PW + (tap % 3)) * HL;
       const int tap_par = (tap / 3 + tap % 3) & 1;
       bf16x8 fa[NS][2], fb[NS];
@@ -1743,16 +1750,17 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_c3_fused_bfx_kernel(Fused
           for (int a = 0; a < 2; ++a)
             acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[tt - i], acc[a], 0, 0, 0);
       if (q.flags & 1) __builtin_amdgcn_s_setprio(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the NEXT step's slice has landed once only this step's issues are still in flight: 2 DMAs per wave (+ the 3
+      // patch loads behind them at tap 0); the last two steps issue nothing
+      if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (patch) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       __syncthreads();
       if (tap == 8 && !last_chunk) {
         store_a();
         __syncthreads();
       }
     }
-    const int t = cur;
-    cur = nxt;
-    nxt = t;
   }
 
   // ---- phases 2 - 4, once per HALF of the tile (64 pixels: the conv2 accumulators of the waves wm == h).  Per half:
