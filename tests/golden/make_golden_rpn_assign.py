@@ -18,7 +18,11 @@ reference directly:
 * ``pos{i}`` / ``neg{i}`` int32: the anchors the reference's numpy sampler drew (recorded, replayed in the test);
 * ``loss_rpn_cls`` / ``loss_rpn_bbox`` float32 [5]: the per-level losses of ``RPNHead.loss``;
 * ``grad_sum{l}`` / ``grad_abs{l}`` float64 and ``grad_probe{l}`` float32: sum, sum of |.| and every 1009th element of
-  d(sum of the ten losses) / d(head output of level l) in the kernels' [N, H, W, A + 4A] layout.
+  d(sum of the ten losses) / d(head output of level l) in the kernels' [N, H, W, A + 4A] layout;
+* RoI stage (``rcnn_inputs()``: 2000 proposals + 20 GT per image): ``rcnn_assigned{i}`` int8 [2000] = the assigner on the
+  proposals (0.5 / 0.5 / 0.5), ``rcnn_pos{i}`` / ``rcnn_neg{i}`` = the 512 indices the numpy RandomSampler drew (numbering
+  of cat([gt, proposals]): ``add_gt_as_proposals``), ``rcnn_rois`` / ``rcnn_labels`` / ``rcnn_label_weights`` /
+  ``rcnn_bbox_targets`` / ``rcnn_bbox_weights`` = ``bbox_target`` (bbox_target.py:7-61) on them, [1024, .].
 
 Inputs are regenerated from seeds by ``inputs()`` on both sides (numpy RandomState: platform-stable).
 
@@ -79,6 +83,69 @@ def inputs():
         cls.append((rs.standard_normal((IMGS, A, h, w)) * 2.0 - 1.0).astype(np.float32))
         reg.append((rs.standard_normal((IMGS, 4 * A, h, w)) * 0.3).astype(np.float32))
     return boxes, cls, reg
+
+
+RCNN_TRAIN = dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, ignore_iof_thr=-1),
+                  sampler=dict(type='RandomSampler', num=512, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True),
+                  pos_weight=-1, debug=False)
+RCNN_MEANS, RCNN_STDS = [0., 0., 0., 0.], [0.1, 0.1, 0.2, 0.2]
+NPROP = 2000
+
+
+def rcnn_inputs():
+    """-> (gt boxes, gt labels, proposals [2000, 5]) per image for the RoI-stage part of the fixture: the GT boxes of
+    ``inputs()``, labels 1..1230, 2000 proposals of which 400 are jittered copies of GT boxes (IoUs on both sides of the
+    0.5 threshold) and the rest uniform; scores descending as the RPN hands them over."""
+    boxes, _, _ = inputs()
+    rs = np.random.RandomState(SEED + 1)
+    labels, props = [], []
+    for b in boxes:
+        labels.append(rs.randint(1, 1231, size=NGT).astype(np.int64))
+        wh = np.exp(rs.uniform(np.log(8), np.log(500), size=(NPROP, 2)))
+        xy = rs.uniform(0, 1, size=(NPROP, 2)) * np.maximum(np.array([1333., 800.]) - wh - 1, 1)
+        p = np.concatenate([xy, xy + wh], 1)
+        src = b[np.arange(400) % NGT]
+        scale = (src[:, 2:] - src[:, :2]).repeat(2).reshape(-1, 4)[:, [0, 1, 0, 1]]
+        p[:400] = src + rs.standard_normal((400, 4)) * scale * rs.choice([0.02, 0.1, 0.25], size=(400, 1))
+        p[:, 2:] = np.maximum(p[:, 2:], p[:, :2] + 1)
+        score = np.sort(rs.rand(NPROP))[::-1]
+        props.append(np.concatenate([p, score[:, None]], 1).astype(np.float32))
+    return boxes, labels, props
+
+
+def rcnn_part(rec):
+    """The RoI stage on the executed reference: MaxIoUAssigner (0.5 / 0.5 / 0.5) on the proposals, RandomSampler
+    (512, 0.25, add_gt_as_proposals) with its numpy draws recorded, bbox_target (mmdet/core/bbox/bbox_target.py:7-61)."""
+    from mmdet.core.bbox.assigners.max_iou_assigner import MaxIoUAssigner
+    from mmdet.core.bbox.samplers.random_sampler import RandomSampler
+    from mmdet.core.bbox.bbox_target import bbox_target
+    from balancedgroupsoftmax_amd.config import to_config_dict
+    boxes, labels, props = rcnn_inputs()
+    ac, sc = dict(RCNN_TRAIN['assigner']), dict(RCNN_TRAIN['sampler'])
+    ac.pop('type')
+    sc.pop('type')
+    assigner, sampler = MaxIoUAssigner(**ac), RandomSampler(**sc)
+    res = []
+    for i in range(IMGS):
+        gtb, gtl = torch.from_numpy(boxes[i]), torch.from_numpy(labels[i])
+        pr = torch.from_numpy(props[i][:, :4])
+        ar = assigner.assign(pr, gtb, None, gtl)
+        rec['rcnn_assigned%d' % i] = ar.gt_inds.numpy().astype(np.int8)          # proposals only (before add_gt_)
+        sr = sampler.sample(ar, pr, gtb, gtl)
+        rec['rcnn_pos%d' % i] = sr.pos_inds.numpy().astype(np.int32)             # numbering of cat([gt, proposals])
+        rec['rcnn_neg%d' % i] = sr.neg_inds.numpy().astype(np.int32)
+        res.append(sr)
+        assert len(sr.pos_inds) + len(sr.neg_inds) == 512
+    lab, lw, bt, bw = bbox_target([r.pos_bboxes for r in res], [r.neg_bboxes for r in res],
+                                  [r.pos_gt_bboxes for r in res], [r.pos_gt_labels for r in res],
+                                  to_config_dict(RCNN_TRAIN), 1, RCNN_MEANS, RCNN_STDS)
+    rec['rcnn_labels'] = lab.numpy().astype(np.int16)
+    rec['rcnn_label_weights'] = lw.numpy().astype(np.float32)
+    rec['rcnn_bbox_targets'] = bt.numpy().astype(np.float32)
+    rec['rcnn_bbox_weights'] = bw.numpy().astype(np.float32)
+    rec['rcnn_rois'] = torch.cat([torch.cat([r.pos_bboxes, r.neg_bboxes]) for r in res]).numpy().astype(np.float32)
+    print('rcnn: positives per image %s, labels > 0: %d of %d'
+          % ([len(r.pos_inds) for r in res], int((lab > 0).sum()), lab.numel()))
 
 
 def main():
@@ -150,6 +217,7 @@ def main():
         rec['grad_sum%d' % l] = np.array([g.astype(np.float64).sum()])
         rec['grad_abs%d' % l] = np.array([np.abs(g.astype(np.float64)).sum()])
         rec['grad_probe%d' % l] = g[::PROBE].copy()
+    rcnn_part(rec)
     np.savez_compressed(OUT, **rec)
     for i in range(IMGS):
         a = rec['assigned%d' % i]

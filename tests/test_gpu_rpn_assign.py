@@ -84,3 +84,41 @@ def test_rpn_loss_kernel_equals_the_executed_reference_loss_on_the_recorded_samp
         np.testing.assert_allclose(g[::G.PROBE], z['grad_probe%d' % l], rtol=1e-5, atol=1e-9)
         np.testing.assert_allclose(g.astype(np.float64).sum(), z['grad_sum%d' % l][0], rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(np.abs(g.astype(np.float64)).sum(), z['grad_abs%d' % l][0], rtol=1e-5, atol=1e-9)
+
+
+def test_rcnn_assign_and_targets_kernels_equal_the_executed_reference_roi_stage():
+    """RoI stage (a8 / a14), directly: ``bgs_iou_assign`` on the 2000 proposals == the executed ``MaxIoUAssigner``
+    (0.5 / 0.5 / 0.5) bit for bit, and ``bgs_rcnn_targets`` on the 512 RoIs per image the reference's numpy
+    ``RandomSampler`` drew (recorded; ``add_gt_as_proposals`` numbering) == the executed ``bbox_target``
+    (mmdet/core/bbox/bbox_target.py:7-61): RoIs, labels and both weight tensors exactly, deltas to 1e-5."""
+    z = np.load(GOLD)
+    boxes, labels, props = G.rcnn_inputs()
+    gt_cat, offs = _gts(boxes)
+    ac = G.RCNN_TRAIN['assigner']
+    pr = torch.from_numpy(np.stack([p[:, :4] for p in props])).to(DEV).contiguous()          # [N, 2000, 4]
+    assigned = BF.iou_assign(pr, gt_cat, offs, ac['pos_iou_thr'], ac['neg_iou_thr'], ac['min_pos_iou'],
+                             shared_boxes=False).cpu().numpy()
+    for i in range(G.IMGS):
+        ref = z['rcnn_assigned%d' % i].astype(np.int32)
+        bad = np.nonzero(assigned[i] != ref)[0]
+        assert bad.size == 0, (i, bad[:5], assigned[i][bad[:5]], ref[bad[:5]])
+        assert 50 < int((ref > 0).sum()) < 1500
+    # candidates = [gt boxes; proposals] (add_gt_as_proposals: a GT row is assigned to itself, assign_result.add_gt_)
+    cand, asg, inds, gtl = [], [], [], []
+    for i in range(G.IMGS):
+        cand.append(torch.from_numpy(np.concatenate([boxes[i], props[i][:, :4]])).to(DEV).contiguous())
+        full = np.concatenate([np.arange(1, G.NGT + 1, dtype=np.int32), z['rcnn_assigned%d' % i].astype(np.int32)])
+        asg.append(torch.from_numpy(full).to(DEV))
+        sel = np.concatenate([z['rcnn_pos%d' % i], z['rcnn_neg%d' % i]]).astype(np.int64)
+        assert sel.size == 512
+        inds.append(torch.from_numpy(sel).to(DEV))
+        gtl.append(torch.from_numpy(labels[i]).to(DEV))
+    rois, lab, lw, bt, bw = BF.rcnn_targets(cand, asg, inds, [None] * G.IMGS, gtl, gt_cat, offs, 512, G.RCNN_MEANS,
+                                            G.RCNN_STDS, G.RCNN_TRAIN['pos_weight'])
+    np.testing.assert_array_equal(rois[:, 1:].cpu().numpy(), z['rcnn_rois'])
+    np.testing.assert_array_equal(rois[:, 0].cpu().numpy(), np.repeat(np.arange(G.IMGS, dtype=np.float32), 512))
+    np.testing.assert_array_equal(lab.cpu().numpy(), z['rcnn_labels'].astype(np.int64))
+    np.testing.assert_array_equal(lw.cpu().numpy(), z['rcnn_label_weights'])
+    np.testing.assert_array_equal(bw.cpu().numpy(), z['rcnn_bbox_weights'])
+    np.testing.assert_allclose(bt.cpu().numpy(), z['rcnn_bbox_targets'], rtol=1e-5, atol=1e-6)
+    assert int((lab > 0).sum()) == 256
