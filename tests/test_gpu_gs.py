@@ -286,16 +286,24 @@ def test_row_per_wave_loss_kernel_vs_row_per_workgroup_kernel(N, table):
 
 @pytest.mark.parametrize('N', [1, 2, 3, 4, 5, 1000, 4099, 65536])
 @pytest.mark.parametrize('shift', [0, 1, 2, 3])
-def test_row_per_wave_merge_kernel_is_bit_identical(N, shift):
+@pytest.mark.parametrize('table', ['lvis5', 'bins9', 'bins3'])
+def test_row_per_wave_merge_kernel_is_bit_identical(N, shift, table):
     """``gs_merge_wavepriv_kernel`` (round 6; 16-byte stores of the ALIGNED pieces of the flat [N, 1231] output plus
     dword stores of the at most 3 + 3 floats at a row's ends) == the 4-wave-per-row kernel, bit for bit, for every
     alignment of the output buffer (``shift`` floats off a 16-byte boundary: with C = 1231 the rows then start at
     every phase), rows fewer than waves, and nothing written outside [N, C] (guard floats either side)."""
     from balancedgroupsoftmax_amd import capi
     lib = capi.load()
+    if table != 'lvis5' and (N > 4099 or shift in (1, 3)):
+        pytest.skip('the other tables on a subset of the sizes / phases')
     counts = gs_tables.synthetic_instance_counts(C, seed=0)
-    l2b, ps, _ = gs_tables.build_group_tables(counts)
+    thr = dict(lvis5=(10, 100, 1000), bins9=(3, 10, 30, 100, 300, 1000, 3000), bins3=(100,))[table]
+    l2b, ps, _ = gs_tables.build_group_tables(counts, thresholds=thr)
     W = int(ps[:, 1].sum())
+    if W % 4 or int(ps[:, 1].max()) > 384:
+        # (a bin wider than the register sweep or a row that is not a multiple of 16 bytes: the dispatcher keeps the
+        #  4-wave-per-row kernel — both arms then run the same kernel, which is what this asserts)
+        pass
     c2c = gs_tables.class_to_column(l2b, ps).to(DEV)
     z = torch.randn(N, W, device=DEV) * 3
     ps_keep, ps_ptr = capi.host_i64(np.ascontiguousarray(ps))
