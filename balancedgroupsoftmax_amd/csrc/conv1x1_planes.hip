@@ -1,0 +1,280 @@
+// 1x1 convolution / linear layer on the bf16 matrix cores with the A-operand split taken OUT of the MFMA loop
+// (round 6).  Same contract and arithmetic as the 1x1 instantiations of conv_bfx.hip
+// (mmdet/models/backbones/resnet.py:220-266 conv1 / conv3 / downsample, necks/fpn.py:118-127 lateral convs): fp32 NHWC in,
+// fp32 out, every product from the exact three-way bf16 split of both operands, fp32 accumulate, bias / residual / ReLU.
+//
+// What the existing kernels do: the 64 x 64 operand ring and the 128 x 128 wide kernel deliver A as fp32 and split it in
+// registers when a wave reads its fragment — 44 VALU instructions beside 6 (ring) or 24 (wide) MFMAs, repeated by every
+// workgroup that covers the same pixels for another slice of the output channels (2 - 16 of them), and VALU and MFMA time
+// add on a SIMD (profiles/r9c).  Here a workgroup owns 64 pixels x 256 output channels:
+//   * per 64-deep K chunk the [64 pixels x 64 k] fp32 tile is loaded ONCE (16-byte buffer loads, the next chunk in flight
+//     under this chunk's MFMAs), split ONCE (4 split3 per thread) and written to LDS as three bf16 planes in the B
+//     layout ([plane][k step][pixel][32 B], halves swapped on odd 8-pixel groups: conflict-free ds_read_b128), double
+//     buffered, ONE barrier per chunk;
+//   * the MFMA phase of a chunk is fragments + MFMAs only: wave w owns all 64 pixels x channels 64 w .. 64 w + 63
+//     (acc[2][2]), A fragments from LDS, the filter fragments of a k step straight from L2 into registers by buffer loads
+//     (one k step ahead); the filter never passes through LDS;
+//   * epilogue through the LDS transpose in two quarters of 32 pixels: bias, then the residual (same shape, or the
+//     nearest-2x-upsampled coarser map of the FPN top-down path), then the clamp — 16-byte loads / stores.
+// k steps ascend and the six plane products of a step come in the ring kernel's order, so every output is BIT-IDENTICAL to
+// conv_igemm_bfx_dma_kernel / conv1x1_bfx_wide_kernel (tests/test_gpu_det_ops.py).  LDS 48 KB, <= 168 VGPRs: three
+// workgroups per CU.  Eligible: 1x1 / stride 1 or 2 / no padding, Cin % 64 == 0, Cout % 256 == 0, no split-K, no ReLU mask,
+// tensors below 2 GB (32-bit buffer offsets).
+#include <stdlib.h>
+
+#include "conv_args.h"
+#include "bfx_split.h"
+
+using namespace bgs_conv;
+
+namespace {
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);   // v_cvt_pk_bf16_f32 (RNE)
+  return __builtin_bit_cast(unsigned, h);
+}
+
+// x (4 consecutive k) -> three planes of 4 packed bf16 each: conv_bfx.hip's split3, verbatim
+__device__ __forceinline__ void split3p(const f32x4 v, u32x2& hi, u32x2& mid, u32x2& lo) {
+  hi = u32x2{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])};
+  const f32x4 r = {bfx_resid_lo(hi[0], v[0]), bfx_resid_hi(hi[0], v[1]), bfx_resid_lo(hi[1], v[2]),
+                   bfx_resid_hi(hi[1], v[3])};
+  mid = u32x2{pk_bf16(r[0], r[1]), pk_bf16(r[2], r[3])};
+  const f32x4 r2 = {bfx_resid_lo(mid[0], r[0]), bfx_resid_hi(mid[0], r[1]), bfx_resid_lo(mid[1], r[2]),
+                    bfx_resid_hi(mid[1], r[3])};
+  lo = u32x2{pk_bf16(r2[0], r2[1]), pk_bf16(r2[2], r2[3])};
+}
+
+struct PlanesArgs {
+  ConvArgs c;
+  const __bf16* ws;      // split weights [3][KC][Cout][16]
+  int KC;                // K / 16
+};
+
+__global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesArgs g) {
+  const ConvArgs& p = g.c;
+  constexpr int NS = 3, KCH = 4;                                    // k steps per 64-deep chunk
+  constexpr int CH = 64 * 32, PL = KCH * CH, BUF = NS * PL;         // 2 KB per k step, 8 KB per plane, 24 KB per buffer
+  constexpr int CO = 256, LD4 = CO + 4;
+  constexpr int LDS_BYTES = 2 * BUF;                                // 49,152 (>= the 33,280-byte quarter tile)
+  static_assert(32 * LD4 * 4 <= LDS_BYTES, "epilogue tile overlays the operand buffers");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = bgs::uniform(tid >> 6);
+  const int frow = lane & 31, fk = lane >> 5;
+  const int vtile = p.chunk ? (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if (vtile >= p.tiles_m * p.tiles_n) return;                       // workgroup-uniform
+  const int tm = vtile / p.tiles_n, tn = vtile - tm * p.tiles_n;
+  const int m0 = tm * 64, n0 = tn * CO;
+  const int nchunks = p.Cin >> 6;
+
+  // ---- A loader: 16 threads per pixel row (64 k = 16 quads), 16 rows per pass, 4 passes; rows past M re-read row M - 1
+  const int c4 = (tid & 15) * 4, r0 = tid >> 4;
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
+  int a_off[4];
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int m = min(m0 + r0 + 16 * ps, p.M - 1);
+    int src = m;                                                    // input pixel of output pixel m
+    if (p.stride != 1) {                                            // (projection shortcuts: 1x1 / stride 2)
+      const int hw_o = p.Ho * p.Wo;
+      const int n = m / hw_o, rem = m - n * hw_o;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      src = (n * p.H + ho * p.stride) * p.W + wo * p.stride;
+    }
+    a_off[ps] = (src * p.Cin + c4) * 4;
+  }
+  f32x4 ra[4];
+  auto load_a = [&](int chunk) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps)
+      ra[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, a_off[ps], chunk * 256, 0));
+  };
+  const int kcs_w = c4 >> 4, kq_w = (c4 & 15) >> 2;
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int i = r0 + 16 * ps;
+      u32x2 hh, mm, ll;
+      split3p(ra[ps], hh, mm, ll);
+      unsigned char* d = lds + buf * BUF + kcs_w * CH + i * 32 + (((kq_w >> 1) ^ ((i >> 3) & 1)) << 4) + (kq_w & 1) * 8;
+      *reinterpret_cast<u32x2*>(d) = hh;
+      *reinterpret_cast<u32x2*>(d + PL) = mm;
+      *reinterpret_cast<u32x2*>(d + 2 * PL) = ll;
+    }
+  };
+
+  // ---- B fragments: buffer loads (descriptor in SGPRs, one 32-bit lane offset, the per-load constant as scalar offset)
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(g.ws), 0, (int)((size_t)NS * g.KC * p.Cout * 32), 0x00020000);
+  const int b_lane = ((n0 + wave * 64 + frow) * 16 + fk * 8) * 2;   // bytes
+  const int b_plane = g.KC * p.Cout * 32;                           // bytes per plane
+  auto load_b = [&](int kc, bf16x8 (&dst)[NS][2]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        dst[s][b] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   b_rsrc, b_lane, s * b_plane + (kc * p.Cout + 32 * b) * 32, 0));
+  };
+
+  int a_frag[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int m = a * 32 + frow;
+    a_frag[a] = m * 32 + ((fk ^ ((m >> 3) & 1)) << 4);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  bf16x8 fb[NS][2];
+  load_a(0);
+  load_b(0, fb);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int buf = chunk & 1;
+    store_a(buf);                                                   // (waits for this chunk's A loads)
+    if (chunk + 1 < nchunks) load_a(chunk + 1);                     // in flight under this chunk's MFMAs
+    // one barrier per chunk: buffer `buf` was last read in chunk - 2, and every wave has passed the barrier of chunk - 1
+    // (behind its chunk - 2 reads) before any wave writes it again
+    __syncthreads();
+#pragma unroll
+    for (int kcs = 0; kcs < KCH; ++kcs) {
+      const int kc = chunk * KCH + kcs;
+      bf16x8 fbn[NS][2];
+      if (kc + 1 < g.KC) load_b(kc + 1, fbn);
+      bf16x8 fa[NS][2];
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+          fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + buf * BUF + a_frag[a] + kcs * CH + s * PL);
+#pragma unroll
+      for (int tt = NS - 1; tt >= 0; --tt)
+#pragma unroll
+        for (int i = 0; i <= tt; ++i)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[tt - i][b], acc[a][b], 0, 0, 0);
+      if (kc + 1 < g.KC) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) fb[s][b] = fbn[s][b];
+      }
+    }
+  }
+  __syncthreads();                                                  // every wave is done with the operand buffers
+
+  // ---- epilogue: two quarters of 32 pixels through the LDS transpose; bias, then residual, then clamp
+  float* scratch = reinterpret_cast<float*>(lds);
+  const int e4 = (tid & 63) * 4, er0 = tid >> 6;                    // 64 threads per pixel row, 4 rows per pass
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n0 + e4);
+  const int hw = p.Ho * p.Wo;
+  size_t res_bytes = 0;
+  if (p.res_mode == 1) res_bytes = (size_t)p.M * p.Cout * 4;
+  else if (p.res_mode == 2) res_bytes = (size_t)p.N * (p.Ho >> 1) * (p.Wo >> 1) * p.Cout * 4;
+  const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.res_mode ? p.res : p.x), 0, (int)res_bytes, 0x00020000);      // 0 bytes: every read is 0
+  const __amdgpu_buffer_rsrc_t y_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    f32x4 rs[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int m = min(m0 + a * 32 + er0 + ps * 4, p.M - 1);
+      int row = m;
+      if (p.res_mode == 2) {
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        row = (n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1);
+      }
+      rs[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, (row * p.Cout + n0 + e4) * 4, 0, 0));
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        scratch[i * LD4 + wave * 64 + b * 32 + (lane & 31)] = acc[a][b][r];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int i = er0 + ps * 4;
+      const int m = m0 + a * 32 + i;
+      f32x4 v = *reinterpret_cast<const f32x4*>(scratch + i * LD4 + e4);
+      v += bias;
+      if (p.res_mode) v += rs[ps];
+      if (p.relu) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+      }
+      if (m < p.M)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, (m * p.Cout + n0 + e4) * 4, 0, 0);
+    }
+    __syncthreads();
+  }
+}
+
+int g_planes_mode = -1;       // BGS_BFX_PLANES / bgs_conv1x1_planes_enable: 0 off | 1 automatic | 2 every eligible layer
+int g_planes_last = 0;
+
+}  // namespace
+
+extern "C" void bgs_conv1x1_planes_enable(int mode) { g_planes_mode = mode < 0 ? -1 : (mode > 2 ? 2 : mode); }
+extern "C" int bgs_conv1x1_planes_last_launch(void) { return g_planes_last; }
+void bgs_internal_conv1x1_planes_clear_last() { g_planes_last = 0; }
+
+// -1: not eligible (the caller goes on to the wide / ring kernels)
+int bgs_internal_conv1x1_planes(const bgs_conv::ConvArgs& pc, const void* wsplit, int KC, hipStream_t st) {
+  int mode = g_planes_mode;                 // the hook's value, else the environment (read at every call: tools/step_ab.py)
+  if (mode < 0) {
+    const char* e = getenv("BGS_BFX_PLANES");
+    mode = e ? atoi(e) : 1;
+    if (mode < 0 || mode > 2) mode = 1;
+  }
+  if (mode == 0) return -1;
+  const ConvArgs& p = pc;
+  if (p.R != 1 || p.S != 1 || (p.stride != 1 && p.stride != 2) || p.pad != 0 || p.mask || p.rowmap) return -1;      // (p.partial: set by the caller's plan later)
+  if ((p.Cin & 63) || (p.Cout & 255) || KC != p.Cin / 16) return -1;
+  if (p.res_mode < 0 || p.res_mode > 2 || (p.res_mode && !p.res)) return -1;
+  if (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)wsplit) & 15) return -1;
+  const long long lim = 0x7fffffffLL;
+  if ((long long)p.N * p.H * p.W * p.Cin * 4 > lim || (long long)p.M * p.Cout * 4 > lim || (long long)3 * KC * p.Cout * 32 > lim) return -1;
+  if (mode == 1) {
+    // automatic: where it was measured ahead of the default dispatch (profiles/r10q_planes_ab.txt, every eligible 1x1
+    // layer of a cfg[1] step, interleaved): 6 - 13 % on the stride-4 / -8 / -16 maps (l1.c3 73.5 -> 67.0 us, l2.c3 44.4 ->
+    // 38.7, l3.c3 39.8 -> 34.9, l3.c1 45.6 -> 42.9, fpn.lat0 136.3 -> 121.0, lat1 67.8 -> 60.3).  Not where the default plan
+    // slices K over gridDim.z to fill the chip (M = 2100: 27 - 43 us against 72 - 73 — this kernel has no split-K), nor
+    // on the one M = 8400 shape with K = 1024 and 512 output channels (67.4 vs 69.9 us).
+    if (p.M < 8192 || p.Cin > 1024 || (p.Cin == 1024 && p.Cout > 256)) return -1;
+  }
+  PlanesArgs g;
+  g.c = p;
+  g.ws = reinterpret_cast<const __bf16*>(wsplit);
+  g.KC = KC;
+  g.c.tiles_m = (p.M + 63) / 64;
+  g.c.tiles_n = p.Cout / 256;
+  g.c.chunk = (g.c.tiles_m * g.c.tiles_n + 7) / 8;
+  g.c.partial = nullptr;
+  g_planes_last = 1;
+  hipLaunchKernelGGL(conv1x1_planes_bfx_kernel, dim3((unsigned)(8 * g.c.chunk)), dim3(kThreads), 0, st, g);
+  return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
+}

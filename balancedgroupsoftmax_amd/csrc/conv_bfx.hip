@@ -53,6 +53,9 @@ int bgs_internal_conv1x1_bfx_wide(const bgs_conv::ConvArgs& p, const void* wspli
                                   size_t workspace_bytes, int forced_only, hipStream_t st);
 void bgs_internal_conv1x1_bfx_wide_clear_last();
 size_t bgs_internal_conv1x1_bfx_wide_workspace(long long M, int Cout, int K);
+// conv1x1_planes.hip (round 6): 64 pixels x 256 channels per workgroup, A split once per tile into LDS planes (-1: not eligible)
+int bgs_internal_conv1x1_planes(const bgs_conv::ConvArgs& p, const void* wsplit, int KC, hipStream_t st);
+void bgs_internal_conv1x1_planes_clear_last();
 
 namespace {
 
@@ -2357,7 +2360,17 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
   if (!q.zero) return BGS_ERR_LAUNCH;
   const BfxKnobs& knobs = bfx_knobs();
   bgs_internal_conv1x1_bfx_wide_clear_last();
+  bgs_internal_conv1x1_planes_clear_last();
   const bool wide_ok = up == 1 && q.ns == 3 && knobs.tile == 0 && knobs.splitk < 0 && knobs.dma;
+  if (wide_ok) {            // (the same preconditions: forward 1x1 layers of the fp32-faithful mode, no forced tile / split)
+    const int rc = bgs_internal_conv1x1_planes(p, q.ws, q.KC, st);
+    if (rc >= 0) {
+      g_last_tile = 0x8000;        // bit 15: the planes-in-LDS 1x1 kernel ran
+      g_last_splits = 1;
+      g_last_dma = 0;
+      return rc;
+    }
+  }
   for (int pass = 0; pass < 2; ++pass) {
     // wide-N 1x1 layers: 128 x 128 tile with four M-stacked waves (conv_bfx_wide.hip); -1 = not eligible.
     // Pass 0 (ahead of the filter-resident kernel) only under its "every eligible layer" mode.

@@ -119,6 +119,13 @@ void bgs_conv_bf16s_tuning(int variant);
  * last_launch: bit 0 = the last bf16x6 1x1 launch took it; bits 4..7 ring stages; bits 8.. K slices. */
 void bgs_conv_bfx_wide_tuning(int mode, int nst, int splitk);
 int bgs_conv_bfx_wide_last_launch(void);
+/* Round 6: the planes-in-LDS 1x1 kernel (csrc/conv1x1_planes.hip: 64 pixels x 256 channels per workgroup, the A tile split
+ * ONCE per K chunk into bf16 planes in LDS, the MFMA phase free of VALU work, filter fragments by buffer loads; bit-identical
+ * to the ring / wide kernels).  mode 0 off | 1 automatic (default; env BGS_BFX_PLANES) | 2 every eligible layer (1x1, stride
+ * 1, Cin % 64 == 0, Cout % 256 == 0, fp32-faithful planes, no mask / split-K, tensors < 2 GB) | < 0: back to the
+ * environment's value.  bgs_conv1x1_planes_last_launch: 1 when the last bf16x6 conv launch took it. */
+void bgs_conv1x1_planes_enable(int mode);
+int bgs_conv1x1_planes_last_launch(void);
 
 /* Row-per-workgroup GroupSoftmax loss kernel (csrc/gs_loss.hip, bgs_gs_loss_fwd_bwd; the bandwidth-bound form
  * of gs_bbox_head_with0.py:147-186 for N beyond the fused head's 4096 rows): prefetch 0 = every row pays its own
