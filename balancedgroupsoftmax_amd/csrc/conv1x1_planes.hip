@@ -17,7 +17,7 @@
 //   * epilogue through the LDS transpose in two quarters of 32 pixels: bias, then the residual (same shape, or the
 //     nearest-2x-upsampled coarser map of the FPN top-down path), then the clamp — 16-byte loads / stores.
 // k steps ascend and the six plane products of a step come in the ring kernel's order, so every output is BIT-IDENTICAL to
-// conv_igemm_bfx_dma_kernel / conv1x1_bfx_wide_kernel (tests/test_gpu_det_ops.py).  LDS 48 KB, <= 168 VGPRs: three
+// conv_igemm_bfx_dma_kernel / conv1x1_bfx_wide_kernel (tests/test_gpu_det_ops.py).  LDS 51 KB, <= 168 VGPRs: three
 // workgroups per CU.  Eligible: 1x1 / stride 1 or 2 / no padding, Cin % 64 == 0, Cout % 256 == 0, no split-K, no ReLU mask,
 // tensors below 2 GB (32-bit buffer offsets).
 #include <stdlib.h>
@@ -56,12 +56,19 @@ struct PlanesArgs {
   int KC;                // K / 16
 };
 
+// ABL: timing-only ablations (tools/planes_ablate.py; results are WRONG for ABL != 0): 1 = filter fragments loaded once,
+// 2 = activation tile loaded once, 4 = no output stores, 8 = no MFMAs
+template <int ABL>
 __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesArgs g) {
   const ConvArgs& p = g.c;
   constexpr int NS = 3, KCH = 4;                                    // k steps per 64-deep chunk
-  constexpr int CH = 64 * 32, PL = KCH * CH, BUF = NS * PL;         // 2 KB per k step, 8 KB per plane, 24 KB per buffer
+  // 2 KB per k step + 64 B of padding: the 16 lanes that write one pixel row's 64 k cover FOUR k steps, and a stride of
+  // 2048 B would put the four on the same 8 banks (measured: SQ_LDS_BANK_CONFLICT = 43 % of SQ_LDS_IDX_ACTIVE); planes
+  // padded to a multiple of 512 B (ds_write2st64_b64 pairs)
+  constexpr int CH = 64 * 32 + 64, PL = KCH * CH + 256, BUF = NS * PL;
   constexpr int CO = 256, LD4 = CO + 4;
-  constexpr int LDS_BYTES = 2 * BUF;                                // 49,152 (>= the 33,280-byte quarter tile)
+  constexpr int LDS_BYTES = 2 * BUF;                                // 52,224 (>= the 33,280-byte quarter tile)
+  static_assert(PL % 512 == 0 && 3 * LDS_BYTES <= 160 * 1024, "three workgroups per CU");
   static_assert(32 * LD4 * 4 <= LDS_BYTES, "epilogue tile overlays the operand buffers");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
@@ -139,43 +146,64 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  bf16x8 fb[NS][2];
+  // Loop shape: every prefetch is UNCONDITIONAL (a buffer load past the end of the tensor returns 0 and is never used), so
+  // a chunk is one basic block; the filter fragments ping-pong between two register sets (no copies); the next chunk's
+  // activation loads are issued BEHIND the first filter prefetch of the chunk — vmcnt retires in order, so a wait for
+  // filter fragments also waits for every load issued before them: this order gives the HBM loads two k steps of cover.
+  bf16x8 fb0[NS][2], fb1[NS][2];
   load_a(0);
-  load_b(0, fb);
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const int buf = chunk & 1;
-    store_a(buf);                                                   // (waits for this chunk's A loads)
-    if (chunk + 1 < nchunks) load_a(chunk + 1);                     // in flight under this chunk's MFMAs
-    // one barrier per chunk: buffer `buf` was last read in chunk - 2, and every wave has passed the barrier of chunk - 1
-    // (behind its chunk - 2 reads) before any wave writes it again
-    __syncthreads();
+  load_b(0, fb0);
+  auto kstep = [&](int buf, int kcs, const bf16x8 (&fbu)[NS][2]) {
+    bf16x8 fa[NS][2];
 #pragma unroll
-    for (int kcs = 0; kcs < KCH; ++kcs) {
-      const int kc = chunk * KCH + kcs;
-      bf16x8 fbn[NS][2];
-      if (kc + 1 < g.KC) load_b(kc + 1, fbn);
-      bf16x8 fa[NS][2];
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + buf * BUF + a_frag[a] + kcs * CH + s * PL);
+#pragma unroll
+    for (int tt = NS - 1; tt >= 0; --tt)
+#pragma unroll
+      for (int i = 0; i <= tt; ++i)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            if (!(ABL & 8)) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fbu[tt - i][b], acc[a][b], 0, 0, 0);
+    if (ABL & 8) {
 #pragma unroll
       for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-          fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + buf * BUF + a_frag[a] + kcs * CH + s * PL);
-#pragma unroll
-      for (int tt = NS - 1; tt >= 0; --tt)
-#pragma unroll
-        for (int i = 0; i <= tt; ++i)
-#pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[tt - i][b], acc[a][b], 0, 0, 0);
-      if (kc + 1 < g.KC) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) fb[s][b] = fbn[s][b];
-      }
+        for (int a = 0; a < 2; ++a) {
+          asm volatile("" ::"v"(fa[s][a]));
+          asm volatile("" ::"v"(fbu[s][a]));
+        }
     }
+  };
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int buf = chunk & 1;
+    const int kc = chunk * KCH;
+    store_a(buf);                                                   // (waits for this chunk's A loads)
+    // one barrier per chunk: buffer `buf` was last read in chunk - 2, and every wave has passed the barrier of chunk - 1
+    // (behind its chunk - 2 reads) before any wave writes it again
+    __syncthreads();
+    // (sched_barrier: the scheduler otherwise sinks every prefetch to just above its first use to save registers)
+    if (!(ABL & 1)) load_b(kc + 1, fb1);
+    if (!(ABL & 2)) load_a(chunk + 1);                              // in flight under this chunk's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    kstep(buf, 0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(ABL & 1)) load_b(kc + 2, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    kstep(buf, 1, (ABL & 1) ? fb0 : fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(ABL & 1)) load_b(kc + 3, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    kstep(buf, 2, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(ABL & 1)) load_b(kc + 4, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    kstep(buf, 3, (ABL & 1) ? fb0 : fb1);
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();                                                  // every wave is done with the operand buffers
 
@@ -226,7 +254,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesA
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
       }
-      if (m < p.M)
+      if (m < p.M && (!(ABL & 4) || v[0] == 1.2345e-30f))
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, (m * p.Cout + n0 + e4) * 4, 0, 0);
     }
     __syncthreads();
@@ -275,6 +303,22 @@ int bgs_internal_conv1x1_planes(const bgs_conv::ConvArgs& pc, const void* wsplit
   g.c.chunk = (g.c.tiles_m * g.c.tiles_n + 7) / 8;
   g.c.partial = nullptr;
   g_planes_last = 1;
-  hipLaunchKernelGGL(conv1x1_planes_bfx_kernel, dim3((unsigned)(8 * g.c.chunk)), dim3(kThreads), 0, st, g);
+  static int abl = -1;                      // BGS_BFX_PLANES_ABLATE: timing-only, see the kernel's ABL
+  if (abl < 0) {
+    const char* e = getenv("BGS_BFX_PLANES_ABLATE");
+    abl = e ? atoi(e) : 0;
+  }
+  const dim3 grid((unsigned)(8 * g.c.chunk)), block(kThreads);
+  switch (abl) {
+    case 1: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<1>, grid, block, 0, st, g); break;
+    case 2: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<2>, grid, block, 0, st, g); break;
+    case 3: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<3>, grid, block, 0, st, g); break;
+    case 4: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<4>, grid, block, 0, st, g); break;
+    case 7: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<7>, grid, block, 0, st, g); break;
+    case 8: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<8>, grid, block, 0, st, g); break;
+    case 12: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<12>, grid, block, 0, st, g); break;
+    case 15: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<15>, grid, block, 0, st, g); break;
+    default: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<0>, grid, block, 0, st, g); break;
+  }
   return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
 }
