@@ -1495,7 +1495,10 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
       const int wr = (tap & 1) ? cur : nxt;                       // buffer of the next step
       if (tap < 8) issue_b(chunk, tap + 1, wr);                   // next filter slice: DMA in flight
       else if (!last_chunk) issue_b(chunk + 1, 0, wr);
-      if (tap == 0 && !last_chunk) load_a(chunk + 1);             // next patch: held in registers
+      if (tap == 0 && !last_chunk) {                              // next patch: held in registers
+        __builtin_amdgcn_sched_barrier(0);                        // (behind the slice DMAs: see the counted wait below)
+        load_a(chunk + 1);
+      }
       const int tap_off = ((tap / 3) * PW + (tap % 3)) * HL;      // compile-time constants
       const int tap_par = (tap / 3 + tap % 3) & 1;
       bf16x8 fa[NS][2], fb[NS][NB];
@@ -1534,7 +1537,10 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[tt - i][b], acc[a][b],
                                                                   0, 0, 0);
       if (q.flags & 1) __builtin_amdgcn_s_setprio(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // next slice (and patch) landed
+      // next slice landed.  vmcnt retires in order: in the step that issued the patch loads (AQT per lane, BEHIND the
+      // slice DMAs) the counted wait lets them fly one step longer (flag 64: BGS_HALO_NT bit 2, A/B)
+      if (tap == 0 && !last_chunk && (q.flags & 64)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AQT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tap == 8 && !last_chunk) {                              // every wave is done with this patch
         store_a();
@@ -2123,7 +2129,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx7_kernel(HaloBfxA
         if (tap < 8) issue_b(chunk, tap + 1, wr);               // next filter slice: DMA in flight
         else if (!last_chunk) issue_b(chunk + 1, 0, wr);
       }
-      if (tap == 5 && !last_chunk && !(ABL & 2)) load_a(chunk + 1);   // next patch: held in registers over three steps
+      if (tap == 5 && !last_chunk && !(ABL & 2)) {                // next patch: held in registers over three steps
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(chunk + 1);
+      }
       const int tap_off = ((tap / 3) * PW + (tap % 3)) * HL;    // compile-time constants
       const int tap_par = (tap / 3 + tap % 3) & 1;
       bf16x8 fb[NS][2];
@@ -2173,7 +2182,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_bfx7_kernel(HaloBfxA
                                                                              acc[2 * ah + a][b], 0, 0, 0);
         if (q.flags & 1) __builtin_amdgcn_s_setprio(0);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // next slice (and patch) landed
+      if (tap == 5 && !last_chunk && !(ABL & 2) && (q.flags & 64))   // (as in variant 4: the patch loads fly one step longer)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AQT) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // next slice (and patch) landed
       __syncthreads();
       if (tap == 8 && !last_chunk && !(ABL & 2)) {              // every wave is done with this patch
         store_a();
@@ -2197,7 +2209,7 @@ int g_halo_nt = -1;
 int halo_nt_flags() {
   if (g_halo_nt < 0) {
     const char* e = getenv("BGS_HALO_NT");
-    g_halo_nt = e ? (atoi(e) & 3) : 0;
+    g_halo_nt = e ? (atoi(e) & 7) : 0;                // (bit 2: counted wait behind the patch loads)
   }
   return g_halo_nt << 4;
 }

@@ -1087,6 +1087,18 @@ def test_conv_bf16_mode_large_layers_run_the_8_wave_128x128_ring(monkeypatch, ca
         BF.set_conv_math(prev)
 
 
+@pytest.fixture
+def planes_kernel_off():
+    """The dispatch-asserting tests of the kernels BEHIND conv1x1_planes_bfx_kernel in launch_conv_bfx's order: the
+    planes kernel (round 6; first choice for the layers it takes) is switched off for the test."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    lib.bgs_conv1x1_planes_enable(0)
+    yield
+    lib.bgs_conv1x1_planes_enable(-1)
+
+
+@pytest.mark.usefixtures('planes_kernel_off')
 @pytest.mark.parametrize('shape', [
     # (N, H, W, Cin, Cout, stride, residual mode)
     (1, 67, 75, 256, 256, 1, 0),      # M = 5025: last tile has 1 row
@@ -1215,6 +1227,7 @@ def _wide_last():
     return dict(ran=v & 1, nst=(v >> 4) & 15, splits=(v >> 8) & 0xfff, nbw=2 if v & 0x100000 else 4)
 
 
+@pytest.mark.usefixtures('planes_kernel_off')
 @pytest.mark.parametrize('nbw', [4, 2])
 @pytest.mark.parametrize('nst', [2, 3])
 @pytest.mark.parametrize('shape', [
@@ -1277,6 +1290,7 @@ def test_bfx_wide_tile_kernel_is_bit_identical_to_the_operand_ring(shape, nst, n
         assert err < 2e-6, err
 
 
+@pytest.mark.usefixtures('planes_kernel_off')
 def test_bfx_wide_tile_kernel_as_data_gradient_with_mask_and_in_the_automatic_mode():
     """(i) the wide kernel under ``bgs_conv2d_dgrad_nhwc_f32_bfx_ws`` (the data gradient of a 1x1 conv is a 1x1 conv
     with the transposed filter) with the ReLU-backward mask and a residual gradient in the epilogue == the ring,
