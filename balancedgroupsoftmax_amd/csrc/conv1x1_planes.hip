@@ -58,7 +58,9 @@ struct PlanesArgs {
 
 // ABL: timing-only ablations (tools/planes_ablate.py; results are WRONG for ABL != 0): 1 = filter fragments loaded once,
 // 2 = activation tile loaded once, 4 = no output stores, 8 = no MFMAs
-template <int ABL>
+// NB: 32-channel fragments per wave: 2 = 256 output channels per workgroup, 1 = 128 (the 128-channel layers, and the
+// 256-channel layers on the small maps whose 64-pixel tiles alone leave half the CUs without a workgroup)
+template <int ABL, int NB>
 __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesArgs g) {
   const ConvArgs& p = g.c;
   constexpr int NS = 3, KCH = 4;                                    // k steps per 64-deep chunk
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesA
   // 2048 B would put the four on the same 8 banks (measured: SQ_LDS_BANK_CONFLICT = 43 % of SQ_LDS_IDX_ACTIVE); planes
   // padded to a multiple of 512 B (ds_write2st64_b64 pairs)
   constexpr int CH = 64 * 32 + 64, PL = KCH * CH + 256, BUF = NS * PL;
-  constexpr int CO = 256, LD4 = CO + 4;
+  constexpr int CO = 128 * NB, LD4 = CO + 4;
   constexpr int LDS_BYTES = 2 * BUF;                                // 52,224 (>= the 33,280-byte quarter tile)
   static_assert(PL % 512 == 0 && 3 * LDS_BYTES <= 160 * 1024, "three workgroups per CU");
   static_assert(32 * LD4 * 4 <= LDS_BYTES, "epilogue tile overlays the operand buffers");
@@ -121,13 +123,13 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesA
   // ---- B fragments: buffer loads (descriptor in SGPRs, one 32-bit lane offset, the per-load constant as scalar offset)
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<__bf16*>(g.ws), 0, (int)((size_t)NS * g.KC * p.Cout * 32), 0x00020000);
-  const int b_lane = ((n0 + wave * 64 + frow) * 16 + fk * 8) * 2;   // bytes
+  const int b_lane = ((n0 + wave * 32 * NB + frow) * 16 + fk * 8) * 2;   // bytes
   const int b_plane = g.KC * p.Cout * 32;                           // bytes per plane
-  auto load_b = [&](int kc, bf16x8 (&dst)[NS][2]) {
+  auto load_b = [&](int kc, bf16x8 (&dst)[NS][NB]) {
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NB; ++b)
         dst[s][b] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
                                                    b_rsrc, b_lane, s * b_plane + (kc * p.Cout + 32 * b) * 32, 0));
   };
@@ -138,11 +140,11 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesA
     const int m = a * 32 + frow;
     a_frag[a] = m * 32 + ((fk ^ ((m >> 3) & 1)) << 4);
   }
-  f32x16 acc[2][2];
+  f32x16 acc[2][NB];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -150,10 +152,10 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesA
   // a chunk is one basic block; the filter fragments ping-pong between two register sets (no copies); the next chunk's
   // activation loads are issued BEHIND the first filter prefetch of the chunk — vmcnt retires in order, so a wait for
   // filter fragments also waits for every load issued before them: this order gives the HBM loads two k steps of cover.
-  bf16x8 fb0[NS][2], fb1[NS][2];
+  bf16x8 fb0[NS][NB], fb1[NS][NB];
   load_a(0);
   load_b(0, fb0);
-  auto kstep = [&](int buf, int kcs, const bf16x8 (&fbu)[NS][2]) {
+  auto kstep = [&](int buf, int kcs, const bf16x8 (&fbu)[NS][NB]) {
     bf16x8 fa[NS][2];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesA
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
+          for (int b = 0; b < NB; ++b)
             if (!(ABL & 8)) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fbu[tt - i][b], acc[a][b], 0, 0, 0);
     if (ABL & 8) {
 #pragma unroll
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesA
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           asm volatile("" ::"v"(fa[s][a]));
-          asm volatile("" ::"v"(fbu[s][a]));
+          asm volatile("" ::"v"(fbu[s][a % NB]));
         }
     }
   };
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesA
 
   // ---- epilogue: two quarters of 32 pixels through the LDS transpose; bias, then residual, then clamp
   float* scratch = reinterpret_cast<float*>(lds);
-  const int e4 = (tid & 63) * 4, er0 = tid >> 6;                    // 64 threads per pixel row, 4 rows per pass
+  constexpr int TPR = CO / 4, RPP = kThreads / TPR, EP = 32 / RPP;  // threads per pixel row, rows per pass, passes per quarter
+  const int e4 = (tid % TPR) * 4, er0 = tid / TPR;
   f32x4 bias = {0.f, 0.f, 0.f, 0.f};
   if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n0 + e4);
   const int hw = p.Ho * p.Wo;
@@ -222,10 +225,10 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesA
       __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
-    f32x4 rs[8];
+    f32x4 rs[EP];
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int m = min(m0 + a * 32 + er0 + ps * 4, p.M - 1);
+    for (int ps = 0; ps < EP; ++ps) {
+      const int m = min(m0 + a * 32 + er0 + ps * RPP, p.M - 1);
       int row = m;
       if (p.res_mode == 2) {
         const int n = m / hw;
@@ -236,16 +239,16 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesA
       rs[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, (row * p.Cout + n0 + e4) * 4, 0, 0));
     }
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        scratch[i * LD4 + wave * 64 + b * 32 + (lane & 31)] = acc[a][b][r];
+        scratch[i * LD4 + wave * 32 * NB + b * 32 + (lane & 31)] = acc[a][b][r];
       }
     __syncthreads();
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int i = er0 + ps * 4;
+    for (int ps = 0; ps < EP; ++ps) {
+      const int i = er0 + ps * RPP;
       const int m = m0 + a * 32 + i;
       f32x4 v = *reinterpret_cast<const f32x4*>(scratch + i * LD4 + e4);
       v += bias;
@@ -281,44 +284,65 @@ int bgs_internal_conv1x1_planes(const bgs_conv::ConvArgs& pc, const void* wsplit
   if (mode == 0) return -1;
   const ConvArgs& p = pc;
   if (p.R != 1 || p.S != 1 || (p.stride != 1 && p.stride != 2) || p.pad != 0 || p.mask || p.rowmap) return -1;      // (p.partial: set by the caller's plan later)
-  if ((p.Cin & 63) || (p.Cout & 255) || KC != p.Cin / 16) return -1;
+  if ((p.Cin & 63) || (p.Cout & 127) || KC != p.Cin / 16) return -1;
   if (p.res_mode < 0 || p.res_mode > 2 || (p.res_mode && !p.res)) return -1;
   if (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)wsplit) & 15) return -1;
   const long long lim = 0x7fffffffLL;
   if ((long long)p.N * p.H * p.W * p.Cin * 4 > lim || (long long)p.M * p.Cout * 4 > lim || (long long)3 * KC * p.Cout * 32 > lim) return -1;
+  // channels per workgroup: 256 on the large grids; 128 on the 128-channel layers and where the 64-pixel tiles x
+  // 256-channel slabs do not fill one round of 3 workgroups per CU (or barely two with a short K): half-size workgroups
+  // then pack better (profiles/r11d_planes_channels_per_workgroup.txt: l3.c3 35.4 -> 33.0 us, fpn.lat1 59.8 -> 57.4,
+  // l4.c3 38.8 -> 33.4, l2.c3 39.4 -> 37.1; the other way on the 2100-tile grids: l1.c3 71.1 vs 75.7, fpn.lat0 114 vs
+  // 127).  BGS_BFX_PLANES_NB = 1 / 2 forces one (A/B).
+  static int nb_env = -1;
+  if (nb_env < 0) {
+    const char* e = getenv("BGS_BFX_PLANES_NB");
+    nb_env = e ? atoi(e) : 0;
+  }
+  const int tiles_m = (p.M + 63) / 64;
+  int nb = (p.Cout & 255) ? 1 : 2;
+  if (nb == 2) {
+    const long long tiles2 = (long long)tiles_m * (p.Cout / 256);
+    if (nb_env == 1 || (nb_env == 0 && (tiles2 <= 768 || (tiles2 <= 1100 && p.Cin <= 128)))) nb = 1;
+  }
   if (mode == 1) {
-    // automatic: where it was measured ahead of the default dispatch (profiles/r10q_planes_ab.txt, every eligible 1x1
-    // layer of a cfg[1] step, interleaved): 6 - 13 % on the stride-4 / -8 / -16 maps (l1.c3 73.5 -> 67.0 us, l2.c3 44.4 ->
-    // 38.7, l3.c3 39.8 -> 34.9, l3.c1 45.6 -> 42.9, fpn.lat0 136.3 -> 121.0, lat1 67.8 -> 60.3).  Not where the default plan
-    // slices K over gridDim.z to fill the chip (M = 2100: 27 - 43 us against 72 - 73 — this kernel has no split-K), nor
-    // on the one M = 8400 shape with K = 1024 and 512 output channels (67.4 vs 69.9 us).
-    if (p.M < 8192 || p.Cin > 1024 || (p.Cin == 1024 && p.Cout > 256)) return -1;
+    // automatic: where it was measured ahead of the default dispatch (profiles/r11d, every eligible 1x1 layer of a
+    // cfg[1] step, interleaved): 5 - 20 % wherever the grid has at least one workgroup per CU.  Below that the default
+    // plan slices K over gridDim.z to fill the chip and this kernel (no split-K) loses: l4.c1 (132 workgroups) 49.9 vs
+    // 44.7 us, fpn.lat3 (66) 47.9 vs 28.4.
+    if ((long long)tiles_m * (p.Cout / (128 * nb)) < 256) return -1;
   }
   PlanesArgs g;
   g.c = p;
   g.ws = reinterpret_cast<const __bf16*>(wsplit);
   g.KC = KC;
-  g.c.tiles_m = (p.M + 63) / 64;
-  g.c.tiles_n = p.Cout / 256;
+  g.c.tiles_m = tiles_m;
+  g.c.tiles_n = p.Cout / (128 * nb);
   g.c.chunk = (g.c.tiles_m * g.c.tiles_n + 7) / 8;
   g.c.partial = nullptr;
-  g_planes_last = 1;
   static int abl = -1;                      // BGS_BFX_PLANES_ABLATE: timing-only, see the kernel's ABL
   if (abl < 0) {
     const char* e = getenv("BGS_BFX_PLANES_ABLATE");
     abl = e ? atoi(e) : 0;
   }
   const dim3 grid((unsigned)(8 * g.c.chunk)), block(kThreads);
+#define BGS_PL(A_) \
+  do { \
+    if (nb == 2) hipLaunchKernelGGL((conv1x1_planes_bfx_kernel<A_, 2>), grid, block, 0, st, g); \
+    else hipLaunchKernelGGL((conv1x1_planes_bfx_kernel<A_, 1>), grid, block, 0, st, g); \
+  } while (0)
   switch (abl) {
-    case 1: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<1>, grid, block, 0, st, g); break;
-    case 2: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<2>, grid, block, 0, st, g); break;
-    case 3: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<3>, grid, block, 0, st, g); break;
-    case 4: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<4>, grid, block, 0, st, g); break;
-    case 7: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<7>, grid, block, 0, st, g); break;
-    case 8: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<8>, grid, block, 0, st, g); break;
-    case 12: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<12>, grid, block, 0, st, g); break;
-    case 15: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<15>, grid, block, 0, st, g); break;
-    default: hipLaunchKernelGGL(conv1x1_planes_bfx_kernel<0>, grid, block, 0, st, g); break;
+    case 1: BGS_PL(1); break;
+    case 2: BGS_PL(2); break;
+    case 3: BGS_PL(3); break;
+    case 4: BGS_PL(4); break;
+    case 7: BGS_PL(7); break;
+    case 8: BGS_PL(8); break;
+    case 12: BGS_PL(12); break;
+    case 15: BGS_PL(15); break;
+    default: BGS_PL(0); break;
   }
+#undef BGS_PL
+  g_planes_last = nb;
   return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
 }

@@ -119,11 +119,14 @@ void bgs_conv_bf16s_tuning(int variant);
  * last_launch: bit 0 = the last bf16x6 1x1 launch took it; bits 4..7 ring stages; bits 8.. K slices. */
 void bgs_conv_bfx_wide_tuning(int mode, int nst, int splitk);
 int bgs_conv_bfx_wide_last_launch(void);
-/* Round 6: the planes-in-LDS 1x1 kernel (csrc/conv1x1_planes.hip: 64 pixels x 256 channels per workgroup, the A tile split
- * ONCE per K chunk into bf16 planes in LDS, the MFMA phase free of VALU work, filter fragments by buffer loads; bit-identical
- * to the ring / wide kernels).  mode 0 off | 1 automatic (default; env BGS_BFX_PLANES) | 2 every eligible layer (1x1, stride
- * 1, Cin % 64 == 0, Cout % 256 == 0, fp32-faithful planes, no mask / split-K, tensors < 2 GB) | < 0: back to the
- * environment's value.  bgs_conv1x1_planes_last_launch: 1 when the last bf16x6 conv launch took it. */
+/* Round 6: the planes-in-LDS 1x1 kernel (csrc/conv1x1_planes.hip: 64 pixels x 256 or 128 channels per workgroup, the A
+ * tile split ONCE per K chunk into bf16 planes in LDS, the MFMA phase free of VALU work, filter fragments by buffer loads;
+ * bit-identical to the ring / wide kernels).  mode 0 off | 1 automatic (default; env BGS_BFX_PLANES, read at every call:
+ * every eligible layer whose grid has at least one workgroup per CU) | 2 every eligible layer (1x1, stride 1 or 2, Cin %
+ * 64 == 0, Cout % 128 == 0, fp32-faithful planes, no mask / split-K, tensors < 2 GB) | < 0: back to the environment's
+ * value.  bgs_conv1x1_planes_last_launch: 0, or the channels per workgroup / 128 (1 | 2) when the last bf16x6 conv launch
+ * took it.  Environment, read once: BGS_BFX_PLANES_NB = 1 / 2 forces the channels per workgroup, BGS_BFX_PLANES_ABLATE =
+ * timing-only arms (tools/planes_ablate.py). */
 void bgs_conv1x1_planes_enable(int mode);
 int bgs_conv1x1_planes_last_launch(void);
 

@@ -34,7 +34,7 @@ def main():
     tot = {0: 0.0, 2: 0.0}
     print('%-12s %8s %6s %6s %4s | %10s %10s | %s' % ('layer', 'M', 'K', 'Cout', 'res', 'default us', 'planes us', 'x count'))
     for name, H, W, Cin, Cout, R, stride, cnt in LAYERS:
-        if R != 1 or stride not in (1, 2) or Cin % 64 or Cout % 256:
+        if R != 1 or stride not in (1, 2) or Cin % 64 or Cout % 128:
             continue
         # residual as in the model: conv3 of a bottleneck adds the block input (mode 1), FPN laterals below the top add the
         # upsampled coarser level (mode 2), the rest none
