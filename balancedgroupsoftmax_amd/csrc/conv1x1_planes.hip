@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesA
   // 2048 B would put the four on the same 8 banks (measured: SQ_LDS_BANK_CONFLICT = 43 % of SQ_LDS_IDX_ACTIVE); planes
   // padded to a multiple of 512 B (ds_write2st64_b64 pairs)
   constexpr int CH = 64 * 32 + 64, PL = KCH * CH + 256, BUF = NS * PL;
-  constexpr int CO = 128 * NB, LD4 = CO + 4;
+  constexpr int CO = 128 * NB, LD4 = CO + 8;      // (4 rows apart = 32 banks: the two half-waves of the transpose write never share a bank)
   constexpr int LDS_BYTES = 2 * BUF;                                // 52,224 (>= the 33,280-byte quarter tile)
   static_assert(PL % 512 == 0 && 3 * LDS_BYTES <= 160 * 1024, "three workgroups per CU");
   static_assert(32 * LD4 * 4 <= LDS_BYTES, "epilogue tile overlays the operand buffers");

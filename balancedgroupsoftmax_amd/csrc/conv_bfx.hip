@@ -1497,6 +1497,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
       else if (!last_chunk) issue_b(chunk + 1, 0, wr);
       if (tap == 0 && !last_chunk) {                              // next patch: held in registers
         __builtin_amdgcn_sched_barrier(0);                        // (behind the slice DMAs: see the counted wait below)
+#ifdef BGS_ABLATE
+        if (!(q.flags & 0x100))
+#endif
         load_a(chunk + 1);
       }
       const int tap_off = ((tap / 3) * PW + (tap % 3)) * HL;      // compile-time constants
@@ -1542,6 +1545,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
       if (tap == 0 && !last_chunk && (q.flags & 64)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AQT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+#ifdef BGS_ABLATE
+      if (!(q.flags & 0x200))
+#endif
       if (tap == 8 && !last_chunk) {                              // every wave is done with this patch
         store_a();
         __syncthreads();
@@ -1553,6 +1559,12 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_halo_bfx4_kernel(HaloBfxA
     nxt = t;
   }
 
+#ifdef BGS_ABLATE
+  if (q.flags & 0x400) {                                         // timing only: no epilogue
+    if (acc[0][0][0] + acc[1][0][5] + acc[0][NB - 1][9] + acc[1][NB - 1][13] == 1.2345e-30f) p.y[0] = 1.f;
+    return;
+  }
+#endif
   // (the loop's last barrier is behind every wave's last fragment read)
   if (sizeof(lds) >= (size_t)64 * (BN + 4) * 4 && conv_epilogue_vec_ok(p)) {
     halo_store_tile_lds<NB, GTH, GTW>(p, acc, n, ty, tx, n0, wm, wn, lane, reinterpret_cast<float*>(lds),
@@ -2210,6 +2222,12 @@ int halo_nt_flags() {
   if (g_halo_nt < 0) {
     const char* e = getenv("BGS_HALO_NT");
     g_halo_nt = e ? (atoi(e) & 7) : 0;                // (bit 2: counted wait behind the patch loads)
+#ifdef BGS_ABLATE
+    // timing-only (tools/halo_ablate2.py): BGS_HALO_ABL bit 0 = patch loaded once, bit 1 = patch split / stored once (and
+    // no second barrier at the chunk boundary), bit 2 = no epilogue -> kernel flags 0x100 / 0x200 / 0x400
+    const char* a = getenv("BGS_HALO_ABL");
+    if (a) g_halo_nt |= (atoi(a) & 7) << 4;
+#endif
   }
   return g_halo_nt << 4;
 }

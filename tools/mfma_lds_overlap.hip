@@ -77,7 +77,10 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int DELIV>
+// SAME: every workgroup walks the slices in the same order from the same start (the real launch: all co-resident
+// workgroups are at the same (chunk, tap) at about the same time and pull the SAME 12 KB from the L2) instead of from
+// a start of its own
+template <int DELIV, bool SAME = false>
 __global__ __launch_bounds__(256, 3) void halo_step(int iters, const unsigned char* __restrict__ w, int wbytes, float* sink) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[(DELIV == 2 ? 36 : 24) * 1024 + 18 * 1024];
   constexpr int A_OFF = (DELIV == 2 ? 36 : 24) * 1024;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256, 3) void halo_step(int iters, const unsigned ch
   const int wm = wave >> 1, wn = wave & 1;
   // slice s of this workgroup: a different 12 KB window per step, different start per workgroup
   const int nsl = wbytes / 12288;
-  int sl = (int)(blockIdx.x * 37u) % nsl;
+  int sl = SAME ? (int)(blockIdx.x & 1) * 144 : (int)(blockIdx.x * 37u) % nsl;
   auto issue = [&](int slice, int buf) {                         // wave w carries rows 32 w .. of the three planes
 #pragma unroll
     for (int p = 0; p < 3; ++p)
@@ -150,17 +153,17 @@ __global__ __launch_bounds__(256, 3) void halo_step(int iters, const unsigned ch
   if (s == 123.456f) sink[0] = s;
 }
 
-template <int DELIV>
+template <int DELIV, bool SAME = false>
 float run_halo(int wgs, int iters, const unsigned char* w, int wbytes) {
   float* sink;
   hipMalloc(&sink, 4);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL(halo_step<DELIV>, dim3(wgs), dim3(256), 0, 0, iters, w, wbytes, sink);
+  hipLaunchKernelGGL((halo_step<DELIV, SAME>), dim3(wgs), dim3(256), 0, 0, iters, w, wbytes, sink);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL(halo_step<DELIV>, dim3(wgs), dim3(256), 0, 0, iters, w, wbytes, sink);
+  hipLaunchKernelGGL((halo_step<DELIV, SAME>), dim3(wgs), dim3(256), 0, 0, iters, w, wbytes, sink);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0.f;
@@ -219,7 +222,10 @@ int main() {
     t[1] = run_halo<1>(wgs, iters, w, wbytes);
     t[2] = run_halo<2>(wgs, iters, w, wbytes);
     t[3] = run_halo<3>(wgs, iters, w, wbytes);
+    const float ts1 = run_halo<1, true>(wgs, iters, w, wbytes), ts3 = run_halo<3, true>(wgs, iters, w, wbytes);
     printf("halo step, %d workgroup(s) per CU:\n", wg);
+    printf("  %-50s %8.1f ns per step = %6.1f ns per workgroup step per CU\n", "LDS-DMA, every workgroup on the SAME slice", ts1 * 1e6f / iters, ts1 * 1e6f / iters / wg);
+    printf("  %-50s %8.1f ns per step = %6.1f ns per workgroup step per CU\n", "L2 -> registers, every workgroup on the SAME slice", ts3 * 1e6f / iters, ts3 * 1e6f / iters / wg);
     for (int m = 0; m < 4; ++m)
       printf("  %-50s %8.1f ns per step = %6.1f ns per workgroup step per CU\n", dn[m], t[m] * 1e6f / iters, t[m] * 1e6f / iters / wg);
   }
