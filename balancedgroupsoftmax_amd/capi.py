@@ -115,6 +115,8 @@ SIGNATURES = {
     'bgs_conv_bfx_wide_last_launch': (ctypes.c_int, []),
     'bgs_conv1x1_planes_enable': (None, [ctypes.c_int]),
     'bgs_conv1x1_planes_last_launch': (ctypes.c_int, []),
+    'bgs_conv3x3_planes_enable': (None, [ctypes.c_int]),
+    'bgs_conv3x3_planes_last_launch': (ctypes.c_int, []),
     'bgs_conv1x1_bres_enable': (None, [ctypes.c_int]),
     'bgs_conv1x1_bres_last_launch': (ctypes.c_int, []),
     'bgs_launch_census': (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),

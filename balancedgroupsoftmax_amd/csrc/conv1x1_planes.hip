@@ -344,5 +344,6 @@ int bgs_internal_conv1x1_planes(const bgs_conv::ConvArgs& pc, const void* wsplit
   }
 #undef BGS_PL
   g_planes_last = nb;
+  bgs_internal_census_bump(BGS_CENSUS_PLANES_1X1);
   return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
 }

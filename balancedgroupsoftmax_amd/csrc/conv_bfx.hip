@@ -56,6 +56,8 @@ size_t bgs_internal_conv1x1_bfx_wide_workspace(long long M, int Cout, int K);
 // conv1x1_planes.hip (round 6): 64 pixels x 256 channels per workgroup, A split once per tile into LDS planes (-1: not eligible)
 int bgs_internal_conv1x1_planes(const bgs_conv::ConvArgs& p, const void* wsplit, int KC, hipStream_t st);
 void bgs_internal_conv1x1_planes_clear_last();
+int bgs_internal_conv3x3_planes(const bgs_conv::ConvArgs& p, const void* wsplit, int KC, hipStream_t st);   // conv3x3_planes.hip
+void bgs_internal_conv3x3_planes_clear_last();
 
 namespace {
 
@@ -2865,6 +2867,19 @@ extern "C" int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wspl
   p.partial = nullptr; p.kt_per_split = 0;
   q.ws = reinterpret_cast<const __bf16*>(wsplit);
   q.KC = bfx_kc(p.K);
+  // the small maps (where the plan below would slice K): 8 x 8-pixel workgroups that own the whole reduction, patch
+  // planes in LDS, ONE barrier per 32-channel chunk (conv3x3_planes.hip); -1 = not eligible / declined.  Not under a
+  // forced slice count / variant / pixel tile (the tuning hook's A/B arms and the tests that assert them).
+  bgs_internal_conv3x3_planes_clear_last();
+  if (q.ns == 3 && g_halo_force_splits < 0 && g_halo_variant == 4 && !g_halo_pf && !g_halo_padded && g_halo_geom < 0 && !g_ablate) {
+    const int rc = bgs_internal_conv3x3_planes(p, q.ws, q.KC, (hipStream_t)stream);
+    if (rc >= 0) {
+      g_halo_last_variant = 9;
+      g_halo_last_nb = 0;
+      g_halo_last_splits = 1;
+      return rc;
+    }
+  }
   const int geom = (g_halo_variant == 4 && q.ns == 3) ? halo_bfx_geom(H, W) : 0;   // (the bf16 mode keeps 8 x 16)
   int gth, gtw;
   halo_geom_dims(geom, gth, gtw);

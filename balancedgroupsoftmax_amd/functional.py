@@ -818,7 +818,8 @@ def conv_bfx_last_launch():
 
 
 CENSUS = dict(bf16_ring8=0, grouped_lds=1, halo_bfx4=2, dma_ring64=3, gs_head_fused=4, conv1x1_bres=5,
-              wgrad_bfx=6, roi_bwd_gather=7, bf16s=8, grouped_bf16s=9, bfx_wide=10, gs_scale_grad=11, halo_wide=12, stem_fused=13, fused_c3=14)
+              wgrad_bfx=6, roi_bwd_gather=7, bf16s=8, grouped_bf16s=9, bfx_wide=10, gs_scale_grad=11, halo_wide=12, stem_fused=13, fused_c3=14,
+              planes_3x3=15, planes_1x1=16)
 
 
 def launch_census(reset=False):

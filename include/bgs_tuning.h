@@ -48,7 +48,9 @@ int bgs_selftest_mfma_peak_bf16(int blocks, int iters, int random_operands, floa
 #define BGS_CENSUS_HALO_WIDE 12       /* conv3x3_halo_bfx7_kernel (16 x 16-pixel x 128-channel units) */
 #define BGS_CENSUS_STEM_FUSED 13      /* stem_conv7x7s2_relu_maxpool_kernel (conv + ReLU + max-pool, NCHW in) */
 #define BGS_CENSUS_FUSED_C3 14        /* conv3x3_c3_fused_bfx_kernel (conv2 -> conv3 + residual + ReLU of a frozen bottleneck) */
-#define BGS_CENSUS_FAMILIES 16
+#define BGS_CENSUS_PLANES_3X3 15      /* conv3x3_planes_bfx_kernel (8 x 8 pixels, whole reduction per workgroup) */
+#define BGS_CENSUS_PLANES_1X1 16      /* conv1x1_planes_bfx_kernel (A split once per K chunk into LDS planes)    */
+#define BGS_CENSUS_FAMILIES 20
 int bgs_launch_census(int family, int reset);
 
 /* ---- fused GroupSoftmax head (csrc/gs_loss.hip) ---------------------------------------------------
@@ -129,6 +131,16 @@ int bgs_conv_bfx_wide_last_launch(void);
  * timing-only arms (tools/planes_ablate.py). */
 void bgs_conv1x1_planes_enable(int mode);
 int bgs_conv1x1_planes_last_launch(void);
+/* Round 6: the 3x3 sibling for the small maps (csrc/conv3x3_planes.hip: 8 x 8 output pixels x 256 or 128 channels per
+ * workgroup, the whole reduction in one workgroup — no K slices, no reduction launch; 10 x 10 patch planes in LDS per
+ * 32-channel chunk, one barrier per 18 k steps, filter fragments by buffer loads; bit-identical to the halo kernel with ONE
+ * K slice, i.e. within fp32 summation order of the sliced default).  First choice of bgs_conv3x3_halo_nhwc_f32_bfx unless
+ * the halo tuning hook forces a slice count / variant / pixel tile.  mode 0 off | 1 automatic (env BGS_BFX_PLANES3, read
+ * at every call: the layers whose halo plan slices K and whose own grid has a workgroup per CU) | 2 every eligible layer
+ * (3x3 / stride 1 / pad 1, Cin % 32 == 0, Cout % 128 == 0, fp32-faithful planes, no mask, tensors < 2 GB) | < 0: back to
+ * the environment's value.  last_launch: 0, or the channels per workgroup / 128 of the last 3x3 launch that took it. */
+void bgs_conv3x3_planes_enable(int mode);
+int bgs_conv3x3_planes_last_launch(void);
 
 /* Row-per-workgroup GroupSoftmax loss kernel (csrc/gs_loss.hip, bgs_gs_loss_fwd_bwd; the bandwidth-bound form
  * of gs_bbox_head_with0.py:147-186 for N beyond the fused head's 4096 rows): prefetch 0 = every row pays its own

@@ -1089,13 +1089,16 @@ def test_conv_bf16_mode_large_layers_run_the_8_wave_128x128_ring(monkeypatch, ca
 
 @pytest.fixture
 def planes_kernel_off():
-    """The dispatch-asserting tests of the kernels BEHIND conv1x1_planes_bfx_kernel in launch_conv_bfx's order: the
-    planes kernel (round 6; first choice for the layers it takes) is switched off for the test."""
+    """The dispatch-asserting tests of the kernels BEHIND conv1x1_planes_bfx_kernel / conv3x3_planes_bfx_kernel in the
+    launch order of the bf16x6 entry points: the planes kernels (round 6; first choice for the layers they take) are
+    switched off for the test."""
     from balancedgroupsoftmax_amd import capi
     lib = capi.load()
     lib.bgs_conv1x1_planes_enable(0)
+    lib.bgs_conv3x3_planes_enable(0)
     yield
     lib.bgs_conv1x1_planes_enable(-1)
+    lib.bgs_conv3x3_planes_enable(-1)
 
 
 @pytest.mark.usefixtures('planes_kernel_off')
@@ -1176,6 +1179,7 @@ def test_conv1x1_filter_resident_kernel_as_data_gradient_with_mask():
         BF.set_conv_math(prev)
 
 
+@pytest.mark.usefixtures('planes_kernel_off')
 @pytest.mark.parametrize('shape', [
     # (N, H, W, Cin, Cout, pixel tile the fewest-tiles mode takes: 0 = 8 x 16, 1 = 10 x 12, 2 = 5 x 21)
     (2, 50, 84, 256, 256, 1),      # stride-16 maps (layer3 conv2, P4): 35 tiles per image instead of 42
@@ -1793,5 +1797,58 @@ def test_planes_in_lds_1x1_kernel_is_bit_identical_to_the_ring_and_wide_kernels(
         assert (y1.cpu().double() - y64.permute(0, 2, 3, 1)).abs().max().item() < 1e-6 * scale
     finally:
         lib.bgs_conv1x1_planes_enable(-1)
+        BF.conv_bfx_tuning()
+        BF.set_conv_math(prev)
+
+
+@pytest.mark.parametrize('case', [
+    # N, H, W, Cin, Cout, relu
+    (2, 50, 84, 256, 256, True),          # layer3 conv2 / the stride-16 pyramid level at the BASELINE size
+    (2, 25, 42, 512, 512, True),          # layer4 conv2: ragged tiles (25 = 3 x 8 + 1, 42 = 5 x 8 + 2)
+    (2, 100, 168, 128, 128, True),        # layer2 conv2: the 128-channel workgroup
+    (2, 31, 37, 256, 256, False),         # ragged in both directions, no ReLU
+    (2, 37, 29, 64, 384, False),          # three 128-channel slabs, two 32-channel chunks
+    (32, 9, 8, 32, 128, True),            # ONE chunk, tiles of one partial row
+], ids=lambda c: 'x'.join(str(int(v)) for v in c))
+def test_planes_3x3_kernel_is_bit_identical_to_the_unsliced_halo_kernel(case):
+    """``conv3x3_planes_bfx_kernel`` (csrc/conv3x3_planes.hip, round 6: 8 x 8 output pixels x 128 / 256 channels per
+    workgroup, the whole reduction inside the workgroup, patch planes in LDS per 32-channel chunk; the 3x3 / stride-1 convs of
+    mmdet/models/backbones/resnet.py:239-252, necks/fpn.py:129-141, anchor_heads/rpn_head.py:30-35 on the small maps)
+    accumulates the 16-channel chunks, the nine taps of a chunk and the six plane products of a k step in the halo kernel's
+    order: BIT-IDENTICAL to ``conv3x3_halo_bfx4_kernel`` with ONE K slice (every pixel incl. the zero-padded border and the
+    ragged last tiles), within fp32 summation order of the sliced default, and within the family's bound of fp64."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    N, H, W, Cin, Cout, relu = case
+    g = torch.Generator().manual_seed(H * 17 + Cin)
+    x = torch.randn(N, H, W, Cin, generator=g) * torch.exp(torch.randn(N, H, W, Cin, generator=g))
+    w = torch.randn(Cout, 3, 3, Cin, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        xd, wd, bd = dev(x), dev(w), dev(b)
+        lib.bgs_conv3x3_planes_enable(0)
+        BF.conv_bfx_tuning(halo_splits=1)              # the halo kernel, one K slice (a forced slice count also keeps the
+        y0 = BF.conv2d_nhwc(xd, wd, bd, pad=1, relu=relu)        # planes kernel out of the way)
+        assert BF.conv_bfx_last_launch()['halo_variant'] == 4 and not lib.bgs_conv3x3_planes_last_launch()
+        BF.conv_bfx_tuning()
+        yd = BF.conv2d_nhwc(xd, wd, bd, pad=1, relu=relu)        # the default plan (K sliced on these grids)
+        lib.bgs_conv3x3_planes_enable(2)
+        y1 = BF.conv2d_nhwc(xd, wd, bd, pad=1, relu=relu)
+        assert lib.bgs_conv3x3_planes_last_launch() in (1, 2)          # = channels per workgroup / 128
+        assert BF.conv_bfx_last_launch()['halo_variant'] == 9
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y1), float((y0 - y1).abs().max())
+        y64 = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double(),
+                                         padding=1)
+        if relu:
+            y64 = y64.clamp(min=0)
+        y64 = y64.permute(0, 2, 3, 1)
+        scale = float(y64.abs().max())
+        tol = 2e-6 * max(1.0, (9 * Cin / 2304.0) ** 0.5)           # fp32 accumulation over K = 9 Cin terms (heavy-tailed x)
+        e1, ed = float((y1.cpu().double() - y64).abs().max()) / scale, float((yd.cpu().double() - y64).abs().max()) / scale
+        assert e1 < tol and ed < tol, (e1, ed, tol)
+    finally:
+        lib.bgs_conv3x3_planes_enable(-1)
         BF.conv_bfx_tuning()
         BF.set_conv_math(prev)
