@@ -213,10 +213,11 @@ def finish_line(out, args, dev, world):
         out['roofline'] = conv_roofline(dev, args.conv_math)
         if args.conv_math != 'f32':
             out['roofline_f32_mfma_kernel'] = conv_roofline(dev, 'f32')
-        if args.conv_math == 'bf16x6' and (out.get('launch_calibration') or {}).get('chosen') == 'eager_pipelined':
-            # the timed steps ran through train.TrunkPipeline, which switches the halo kernel's wide schedule on:
-            # the same layer under THAT schedule (`roofline` above is the one-launch form the rocprofv3 summary holds)
-            out['roofline_wide_schedule'] = conv_roofline(dev, args.conv_math, wide=1)
+        if args.conv_math == 'bf16x6':
+            # the halo kernels the planes kernel of `roofline` replaced on this layer (round 6), same layer, same box: the
+            # one-launch form and the two-launch wide schedule (what the pipelined steps of rounds 4 - 5 ran)
+            out['roofline_halo_kernel'] = conv_roofline(dev, args.conv_math, planes3=False)
+            out['roofline_wide_schedule'] = conv_roofline(dev, args.conv_math, wide=1, planes3=False)
         rs = roofline_step(out, args)
         if rs:
             out['roofline_step'] = rs

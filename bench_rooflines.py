@@ -20,8 +20,10 @@ from bench_workloads import NUM_CLASSES, HBM_PEAK_GBS, DetectorStep, make_inputs
 from bench_dist import timed_loop  # noqa: E402
 
 
-def conv_roofline(dev, math, iters=20, wide=0):
-    """Dominant kernel of the detector step: the 3x3 halo convolution.  Timed on the largest single
+def conv_roofline(dev, math, iters=20, wide=0, planes3=True):
+    """Dominant kernel of the detector step: the 3x3 convolution of the largest pyramid level — since round 6 the 8 x 8-pixel
+    planes kernel (csrc/conv3x3_planes.hip) under the default dispatch; ``planes3=False`` times the halo kernels it
+    replaced (``wide``: their two-launch schedule) on the same layer for comparison.  Timed on the largest single
     layer (FPN output conv on P2: 2x200x336 pixels, 3x3, 256->256 = 158.5 algorithmic GFLOP) with
     HIP events on the launch stream.  `achieved` = ALGORITHMIC flops / time.  Peaks
     (MI355X_MICROARCH.md): fp32 matrix 157.3 TFLOP/s; bf16 matrix 2500 TFLOP/s dense — the bf16x6
@@ -29,7 +31,11 @@ def conv_roofline(dev, math, iters=20, wide=0):
     ceiling in algorithmic flops is 2500 / 6 = 416.7 TFLOP/s (frac = matrix-pipe busy fraction)."""
     prev = BF.set_conv_math(math)
     prev_wide = BF.set_halo_wide(1) if wide else None
+    lib = capi.load()
+    if not planes3:
+        lib.bgs_conv3x3_planes_enable(0)
     used = {}
+    took_planes3 = 0
     try:
         x = torch.randn(2, 200, 336, 256, device=dev)
         w = torch.randn(256, 3, 3, 256, device=dev) * 0.02
@@ -48,10 +54,13 @@ def conv_roofline(dev, math, iters=20, wide=0):
         e1.record()
         torch.cuda.synchronize()
         used = BF.conv_bfx_last_launch() if math != 'f32' else {}
+        took_planes3 = lib.bgs_conv3x3_planes_last_launch() if math == 'bf16x6' else 0
     finally:
         BF.set_conv_math(prev)
         if wide:
             BF.set_halo_wide(prev_wide)
+        if not planes3:
+            lib.bgs_conv3x3_planes_enable(-1)
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * 2 * 200 * 336 * 256 * 256 * 9
     tf = flops / (ms * 1e-3) / 1e12
@@ -60,7 +69,13 @@ def conv_roofline(dev, math, iters=20, wide=0):
         kdesc = kname + (' (halo-resident A operand split to 3 bf16 planes in LDS, filter slices by '
                          'LDS-DMA, v_mfma_f32_32x32x16_bf16 x 6)')
         peak, passes = 2500.0 / 6.0, 6
-        if wide and used.get('halo_wide_units'):
+        if took_planes3:
+            kname = 'conv3x3_planes_bfx_kernel<%d>' % took_planes3
+            kdesc = kname + (' (8 x 8 output pixels x %d channels per workgroup, the whole reduction in the workgroup; the '
+                             '10 x 10 patch of a 32-channel chunk split once to 3 bf16 planes in LDS, one barrier per 18 k '
+                             'steps; filter fragments by buffer loads from L2; v_mfma_f32_32x32x16_bf16 x 6)'
+                             % (128 * took_planes3))
+        elif wide and used.get('halo_wide_units'):
             # the two-launch schedule the trunk pipeline switches on (bgs_conv3x3_halo_bfx_wide(1)): whole rounds of
             # 16 x 16-pixel units (two workgroups per CU) + the left-over rows on the 8 x 16-pixel kernel
             kname = 'conv3x3_halo_bfx7_kernel<3>+conv3x3_halo_bfx4_kernel<2>'
