@@ -223,6 +223,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesA
       const_cast<float*>(p.res_mode ? p.res : p.x), 0, (int)res_bytes, 0x00020000);      // 0 bytes: every read is 0
   const __amdgpu_buffer_rsrc_t y_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
+  // ReLU-backward mask of the data-gradient form (y = mask > 0 ? y : 0, [M, Cout] like y)
+  const __amdgpu_buffer_rsrc_t mk_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.mask ? p.mask : p.x), 0, p.mask ? (int)((size_t)p.M * p.Cout * 4) : 0, 0x00020000);
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     f32x4 rs[EP];
@@ -257,6 +260,12 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_planes_bfx_kernel(PlanesA
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
       }
+      if (p.mask) {      // (loaded here: the residual prefetch already holds EP registers quads across the transpose)
+        const f32x4 mk = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       mk_rsrc, (min(m, p.M - 1) * p.Cout + n0 + e4) * 4, 0, 0));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = mk[t] > 0.f ? v[t] : 0.f;
+      }
       if (m < p.M && (!(ABL & 4) || v[0] == 1.2345e-30f))
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, (m * p.Cout + n0 + e4) * 4, 0, 0);
     }
@@ -283,10 +292,10 @@ int bgs_internal_conv1x1_planes(const bgs_conv::ConvArgs& pc, const void* wsplit
   }
   if (mode == 0) return -1;
   const ConvArgs& p = pc;
-  if (p.R != 1 || p.S != 1 || (p.stride != 1 && p.stride != 2) || p.pad != 0 || p.mask || p.rowmap) return -1;      // (p.partial: set by the caller's plan later)
+  if (p.R != 1 || p.S != 1 || (p.stride != 1 && p.stride != 2) || p.pad != 0 || p.rowmap) return -1;      // (p.partial: set by the caller's plan later)
   if ((p.Cin & 63) || (p.Cout & 127) || KC != p.Cin / 16) return -1;
   if (p.res_mode < 0 || p.res_mode > 2 || (p.res_mode && !p.res)) return -1;
-  if (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)wsplit) & 15) return -1;
+  if (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.mask | (uintptr_t)wsplit) & 15) return -1;
   const long long lim = 0x7fffffffLL;
   if ((long long)p.N * p.H * p.W * p.Cin * 4 > lim || (long long)p.M * p.Cout * 4 > lim || (long long)3 * KC * p.Cout * 32 > lim) return -1;
   // channels per workgroup: 256 on the large grids; 128 on the 128-channel layers and where the 64-pixel tiles x

@@ -2,7 +2,7 @@
 // conv1x1_planes.hip applied to the halo convolution.  Same contract and arithmetic as conv3x3_halo_bfx4_kernel
 // (mmdet/models/backbones/resnet.py:239-252 conv2, necks/fpn.py:129-141 fpn_convs, anchor_heads/rpn_head.py:30-35
 // rpn_conv): fp32 NHWC in / out, every product from the exact three-way bf16 split of both operands, fp32 accumulate,
-// bias / ReLU in the epilogue.
+// bias / ReLU / the ReLU-backward mask of the data-gradient form in the epilogue.
 //
 // Why a second 3x3 kernel: it was written for the small maps — on the stride-16 / -32 maps (and the 128-channel stride-8
 // layers) the halo kernel's 128-pixel x 128-channel workgroups number 70 - 570, so its plan slices K over gridDim.z to
@@ -207,8 +207,21 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_planes_bfx_kernel(Planes3
   if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n0 + e4);
   const __amdgpu_buffer_rsrc_t y_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
+  // ReLU-backward mask of the data-gradient form (y = mask > 0 ? y : 0, [N,H,W,Cout] like y): prefetched per half
+  const __amdgpu_buffer_rsrc_t mk_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.mask ? p.mask : p.x), 0, p.mask ? (int)((size_t)p.M * p.Cout * 4) : 0, 0x00020000);
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
+    f32x4 mk[EP];
+    if (p.mask) {
+#pragma unroll
+      for (int ps = 0; ps < EP; ++ps) {
+        const int m = a * 32 + er0 + ps * RPP;
+        const int ho = min(ty * 8 + (m >> 3), p.H - 1), wo = min(tx * TW + (m & 7), p.W - 1);
+        mk[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               mk_rsrc, (((n * p.H + ho) * p.W + wo) * p.Cout + n0 + e4) * 4, 0, 0));
+      }
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -227,6 +240,10 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_planes_bfx_kernel(Planes3
       if (p.relu) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+      }
+      if (p.mask) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = mk[ps][t] > 0.f ? v[t] : 0.f;
       }
       if (ho < p.H && wo < p.W)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc,
@@ -255,9 +272,9 @@ int bgs_internal_conv3x3_planes(const bgs_conv::ConvArgs& pc, const void* wsplit
   }
   if (mode == 0) return -1;
   const ConvArgs& p = pc;
-  if (p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || p.mask || p.rowmap || p.res_mode != 0) return -1;
+  if (p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || p.rowmap || p.res_mode != 0) return -1;
   if ((p.Cin & 31) || (p.Cout & 127) || KC != 9 * (p.Cin / 16)) return -1;
-  if (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.bias | (uintptr_t)wsplit) & 15) return -1;
+  if (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.bias | (uintptr_t)p.mask | (uintptr_t)wsplit) & 15) return -1;
   const long long lim = kOob;
   if ((long long)p.N * p.H * p.W * p.Cin * 4 >= lim || (long long)p.M * p.Cout * 4 >= lim || (long long)3 * KC * p.Cout * 32 >= lim) return -1;
   const int tiles_y = (p.H + 7) / 8, tiles_x = (p.W + 7) / 8;

@@ -125,7 +125,8 @@ int bgs_conv_bfx_wide_last_launch(void);
  * tile split ONCE per K chunk into bf16 planes in LDS, the MFMA phase free of VALU work, filter fragments by buffer loads;
  * bit-identical to the ring / wide kernels).  mode 0 off | 1 automatic (default; env BGS_BFX_PLANES, read at every call:
  * every eligible layer whose grid has at least one workgroup per CU) | 2 every eligible layer (1x1, stride 1 or 2, Cin %
- * 64 == 0, Cout % 128 == 0, fp32-faithful planes, no mask / split-K, tensors < 2 GB) | < 0: back to the environment's
+ * 64 == 0, Cout % 128 == 0, fp32-faithful planes, no split-K, tensors < 2 GB; the ReLU-backward mask and the residual of the
+ * data-gradient form are in its epilogue) | < 0: back to the environment's
  * value.  bgs_conv1x1_planes_last_launch: 0, or the channels per workgroup / 128 (1 | 2) when the last bf16x6 conv launch
  * took it.  Environment, read once: BGS_BFX_PLANES_NB = 1 / 2 forces the channels per workgroup, BGS_BFX_PLANES_ABLATE =
  * timing-only arms (tools/planes_ablate.py). */
@@ -137,7 +138,8 @@ int bgs_conv1x1_planes_last_launch(void);
  * K slice, i.e. within fp32 summation order of the sliced default).  First choice of bgs_conv3x3_halo_nhwc_f32_bfx unless
  * the halo tuning hook forces a slice count / variant / pixel tile.  mode 0 off | 1 automatic (env BGS_BFX_PLANES3, read
  * at every call: the layers whose halo plan slices K and whose own grid has a workgroup per CU) | 2 every eligible layer
- * (3x3 / stride 1 / pad 1, Cin % 32 == 0, Cout % 128 == 0, fp32-faithful planes, no mask, tensors < 2 GB) | < 0: back to
+ * (3x3 / stride 1 / pad 1, Cin % 32 == 0, Cout % 128 == 0, fp32-faithful planes, tensors < 2 GB; the ReLU-backward mask
+ * of the data-gradient form is in its epilogue) | < 0: back to
  * the environment's value.  last_launch: 0, or the channels per workgroup / 128 of the last 3x3 launch that took it. */
 void bgs_conv3x3_planes_enable(int mode);
 int bgs_conv3x3_planes_last_launch(void);

@@ -1852,3 +1852,53 @@ def test_planes_3x3_kernel_is_bit_identical_to_the_unsliced_halo_kernel(case):
         lib.bgs_conv3x3_planes_enable(-1)
         BF.conv_bfx_tuning()
         BF.set_conv_math(prev)
+
+
+@pytest.mark.parametrize('case', [
+    # R, N, H, W, Cin_fwd, Cout_fwd, residual
+    (1, 2, 50, 84, 1024, 256, True),      # layer3 conv1 backward: 256 -> 1024 channels, the skip connection's gradient added
+    (1, 2, 100, 168, 128, 512, False),    # layer2 conv3 backward: 512 -> 128 channels (the 128-channel workgroup)
+    (3, 2, 50, 84, 256, 256, False),      # layer3 conv2 backward
+    (3, 1, 100, 168, 128, 128, False),    # layer2 conv2 backward, one image
+], ids=lambda c: 'x'.join(str(int(v)) for v in c))
+def test_planes_kernels_as_data_gradients_with_the_relu_mask_are_bit_identical(case):
+    """The data gradient of a stride-1 conv is the same conv of ``dy`` with the flipped / transposed filter, gated by the
+    ReLU-backward mask of the conv's input (``bgs_conv2d_dgrad_nhwc_f32_bfx_ws``; the backward of
+    mmdet/models/backbones/resnet.py:220-266 under ``selectp = 0``): with the mask (and the residual gradient) in their
+    epilogues the planes kernels take these launches too — BIT-IDENTICAL to the kernels behind them (1x1: the default
+    dispatch unsliced; 3x3: the halo kernel with one K slice), and both within fp32 rounding of fp64 torch."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    R, N, H, W, Cin, Cout, with_res = case
+    g = torch.Generator().manual_seed(R * 100 + Cin)
+    dy = torch.randn(N, H, W, Cout, generator=g)
+    w = torch.randn(Cout, R, R, Cin, generator=g) * (2.0 / (R * R * Cout)) ** 0.5
+    mask = torch.randn(N, H, W, Cin, generator=g)
+    res = torch.randn(N, H, W, Cin, generator=g) if with_res else None
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        kw = dict(pad=R // 2, residual=None if res is None else dev(res), mask=dev(mask))
+        lib.bgs_conv1x1_planes_enable(0)
+        lib.bgs_conv3x3_planes_enable(0)
+        BF.conv_bfx_tuning(0, 1, halo_splits=1)          # reference arm: no K slices anywhere
+        d0 = BF.conv2d_dgrad_nhwc(dev(dy), dev(w), (H, W), **kw)
+        BF.conv_bfx_tuning()
+        lib.bgs_conv1x1_planes_enable(2)
+        lib.bgs_conv3x3_planes_enable(2)
+        d1 = BF.conv2d_dgrad_nhwc(dev(dy), dev(w), (H, W), **kw)
+        took = lib.bgs_conv1x1_planes_last_launch() if R == 1 else lib.bgs_conv3x3_planes_last_launch()
+        assert took in (1, 2), took
+        torch.cuda.synchronize()
+        assert torch.equal(d0, d1), float((d0 - d1).abs().max())
+    finally:
+        lib.bgs_conv1x1_planes_enable(-1)
+        lib.bgs_conv3x3_planes_enable(-1)
+        BF.conv_bfx_tuning()
+        BF.set_conv_math(prev)
+    ref = torch.nn.functional.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=R // 2)
+    ref = ref.permute(0, 2, 3, 1)
+    if res is not None:
+        ref = ref + res.double()
+    ref = torch.where(mask > 0, ref, torch.zeros_like(ref))
+    err = float((d1.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
