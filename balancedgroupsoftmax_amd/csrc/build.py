@@ -28,6 +28,11 @@ EXTRA_VARIANTS = {
     # the operand split's residual by shift / mask + subtraction instead of v_dot2c_f32_bf16 (csrc/bfx_split.h): the A/B
     # arm of tools/split_ab.sh, loaded through BGS_LIB_PATH
     'splitsub': dict(name='libbgs_splitsub.so', flags=['-DBGS_SPLIT_SUB']),
+    # cache-policy bits on the activation loads / output stores of the 3x3 planes kernel (A/B, tools/planes3_nt_ab.sh):
+    # aux 2 = non-temporal
+    'p3nta': dict(name='libbgs_p3nta.so', flags=['-DBGS_P3_A_AUX=2']),
+    'p3nty': dict(name='libbgs_p3nty.so', flags=['-DBGS_P3_Y_AUX=2']),
+    'p3ntay': dict(name='libbgs_p3ntay.so', flags=['-DBGS_P3_A_AUX=2', '-DBGS_P3_Y_AUX=2']),
 }
 
 

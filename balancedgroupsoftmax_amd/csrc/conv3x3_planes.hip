@@ -27,6 +27,12 @@
 // rounding).  LDS 45 KB, three workgroups per CU.
 #include <stdlib.h>
 
+#ifndef BGS_P3_A_AUX
+#define BGS_P3_A_AUX 0
+#endif
+#ifndef BGS_P3_Y_AUX
+#define BGS_P3_Y_AUX 0
+#endif
 #include "conv_args.h"
 #include "bfx_split.h"
 
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_planes_bfx_kernel(Planes3
   auto load_a = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, a_off[i], chunk * 128, 0));
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, a_off[i], chunk * 128, BGS_P3_A_AUX));
   };
   auto store_a = [&](int buf) {
 #pragma unroll
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_planes_bfx_kernel(Planes3
       }
       if (ho < p.H && wo < p.W)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc,
-                                               (((n * p.H + ho) * p.W + wo) * p.Cout + n0 + e4) * 4, 0, 0);
+                                               (((n * p.H + ho) * p.W + wo) * p.Cout + n0 + e4) * 4, 0, BGS_P3_Y_AUX);
     }
     __syncthreads();
   }
