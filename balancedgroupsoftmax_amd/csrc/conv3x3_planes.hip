@@ -259,6 +259,183 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_planes_bfx_kernel(Planes3
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The stride-2 sibling (the three `layerN.0.conv2` launches of a ResNet: mmdet/models/backbones/resnet.py:239-252 with
+// conv2_stride = 2; on the 64 x 64 operand ring before): 8 x 8 OUTPUT pixels x 128 / 256 channels per workgroup, the
+// whole reduction in the workgroup.  The 17 x 17 input patch of a 16-channel chunk is stored as FOUR parity sub-grids
+// ((row & 1, column & 1): 9 rows of 12 slots each), so that tap (dy, dx) reads sub-grid (dy & 1, dx & 1) at unit stride
+// — the access pattern, and with it the conflict-free layout (k halves swapped on odd sub-grid rows), of the stride-1
+// kernel.  One chunk = 9 k steps (the taps) = 41.5 KB of planes: single-buffered (three workgroups per CU), the next
+// chunk's patch travels in registers under the MFMAs, two barriers per chunk.  Accumulation order: 16-channel chunks
+// ascending, nine taps inside a chunk (the halo kernels' order; the operand ring sums tap-major — same products,
+// another fp32 summation order).
+template <int NB>
+__global__ __launch_bounds__(kThreads, 3) void conv3x3s2_planes_bfx_kernel(Planes3Args g) {
+  const ConvArgs& p = g.c;
+  constexpr int NS = 3;
+  constexpr int PW = 17, PS = 12, SG = 9 * PS * 32;                 // 17 x 17 patch; a sub-grid: 9 rows x 12 slots x 32 B = 3456 B
+  constexpr int AQ = PW * PW * 4, AQT = (AQ + kThreads - 1) / kThreads;   // 1156 fp32 quads per chunk: 5 per thread
+  constexpr int PL = 4 * SG, BUF = NS * PL;                         // 13,824 B per plane, 41,472 per chunk
+  constexpr int CO = 128 * NB, LD4 = CO + 8;
+  static_assert(3 * BUF <= 160 * 1024, "three workgroups per CU");
+  static_assert(32 * LD4 * 4 <= BUF, "epilogue tile overlays the operand buffer");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = bgs::uniform(tid >> 6);
+  const int frow = lane & 31, fk = lane >> 5;
+  const int vtile = (int)((blockIdx.x & 7) * p.chunk + (blockIdx.x >> 3));
+  if (vtile >= p.tiles_m * p.tiles_n) return;                       // workgroup-uniform
+  const int tm = vtile / p.tiles_n, tn = vtile - tm * p.tiles_n;
+  const int per_img = g.tiles_y * g.tiles_x;
+  const int n = tm / per_img, trem = tm - n * per_img;
+  const int ty = trem / g.tiles_x, tx = trem - ty * g.tiles_x;
+  const int h0 = ty * 16 - 1, w0 = tx * 16 - 1;                     // input coordinates of patch (0, 0)
+  const int n0 = tn * CO;
+  const int cch16 = p.Cin >> 4;
+
+  // ---- patch loader: quad q = tid + 256 i: patch pixel q / 4, channels 4 (q % 4) .. of the chunk
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
+  int a_off[AQT], a_dst[AQT];
+#pragma unroll
+  for (int i = 0; i < AQT; ++i) {
+    const int q = tid + kThreads * i;
+    const bool use = q < AQ;
+    const int pix = use ? q >> 2 : 0, quad = q & 3;
+    const int ppy = pix / PW, ppx = pix - ppy * PW;
+    const int hi = h0 + ppy, wi = w0 + ppx;
+    const bool in = use && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+    a_off[i] = in ? (((n * p.H + hi) * p.W + wi) * p.Cin + quad * 4) * 4 : kOob;
+    const int iy = ppy >> 1, ix = ppx >> 1;
+    a_dst[i] = use ? ((ppy & 1) * 2 + (ppx & 1)) * SG + (iy * PS + ix) * 32 + (((quad >> 1) ^ (iy & 1)) << 4) + (quad & 1) * 8 : -1;
+  }
+  f32x4 ra[AQT];
+  auto load_a = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < AQT; ++i)
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, a_off[i], chunk * 64, 0));
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < AQT; ++i) {
+      if (a_dst[i] < 0) continue;
+      u32x2 hh, mm, ll;
+      split3p(ra[i], hh, mm, ll);
+      unsigned char* d = lds + a_dst[i];
+      *reinterpret_cast<u32x2*>(d) = hh;
+      *reinterpret_cast<u32x2*>(d + PL) = mm;
+      *reinterpret_cast<u32x2*>(d + 2 * PL) = ll;
+    }
+  };
+
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(g.ws), 0, (int)((size_t)NS * g.KC * p.Cout * 32), 0x00020000);
+  const int b_lane = ((n0 + wave * 32 * NB + frow) * 16 + fk * 8) * 2;   // bytes
+  const int b_plane = g.KC * p.Cout * 32;                                // bytes per plane
+  auto load_b = [&](int kc, bf16x8 (&dst)[NS][NB]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        dst[s][b] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   b_rsrc, b_lane, s * b_plane + (kc * p.Cout + 32 * b) * 32, 0));
+  };
+
+  // ---- A fragments: output pixel m = 32 a + frow = (py, px); tap (dy, dx) reads patch pixel (2 py + dy, 2 px + dx) =
+  //      sub-grid (dy & 1, dx & 1), row py + (dy >> 1), column px + (dx >> 1)
+  int a_frag[2][2];                                                 // [sub-tile][dy >> 1]
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int m = a * 32 + frow;
+    const int py = m >> 3, px = m & 7;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) a_frag[a][par] = (py * PS + px) * 32 + ((fk ^ ((py + par) & 1)) << 4);
+  }
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  bf16x8 fb0[NS][NB], fb1[NS][NB];
+  load_a(0);
+  load_b(0, fb0);                                                   // (tap 0, chunk 0)
+  for (int c2 = 0; c2 < cch16; c2 += 2) {                           // two chunks per trip: 18 k steps, the ping-pong closes
+#pragma unroll
+    for (int t = 0; t < 18; ++t) {
+      const int chunk = c2 + t / 9, tap = t % 9, dy = tap / 3, dx = tap % 3;
+      if (tap == 0) {
+        __syncthreads();                                            // every wave is done with the previous chunk's planes
+        store_a();                                                  // (waits for this chunk's patch loads)
+        __syncthreads();
+      }
+      const int kc_next = tap < 8 ? (tap + 1) * cch16 + chunk : chunk + 1;
+      if (t & 1) load_b(kc_next, fb0);
+      else load_b(kc_next, fb1);
+      if (tap == 0) load_a(chunk + 1);                              // in flight under this chunk's MFMAs (past the end: unused)
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8 (&fbu)[NS][NB] = (t & 1) ? fb1 : fb0;
+      bf16x8 fa[NS][2];
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+          fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + s * PL + ((dy & 1) * 2 + (dx & 1)) * SG + a_frag[a][dy >> 1] +
+                                                      ((dy >> 1) * PS + (dx >> 1)) * 32);
+#pragma unroll
+      for (int tt = NS - 1; tt >= 0; --tt)
+#pragma unroll
+        for (int i = 0; i <= tt; ++i)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fbu[tt - i][b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();                                                  // every wave is done with the operand buffer
+
+  // ---- epilogue: two halves of 32 output pixels through the LDS transpose; bias, clamp, 16-byte stores
+  float* scratch = reinterpret_cast<float*>(lds);
+  constexpr int TPR = CO / 4, RPP = kThreads / TPR, EP = 32 / RPP;
+  const int e4 = (tid % TPR) * 4, er0 = tid / TPR;
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n0 + e4);
+  const __amdgpu_buffer_rsrc_t y_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        scratch[i * LD4 + wave * 32 * NB + b * 32 + (lane & 31)] = acc[a][b][r];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < EP; ++ps) {
+      const int i = er0 + ps * RPP;
+      const int m = a * 32 + i;
+      const int ho = ty * 8 + (m >> 3), wo = tx * 8 + (m & 7);
+      f32x4 v = *reinterpret_cast<const f32x4*>(scratch + i * LD4 + e4);
+      v += bias;
+      if (p.relu) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+      }
+      if (ho < p.Ho && wo < p.Wo)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc,
+                                               (((n * p.Ho + ho) * p.Wo + wo) * p.Cout + n0 + e4) * 4, 0, 0);
+    }
+    __syncthreads();
+  }
+}
+
 int g_planes3_mode = -1;      // BGS_BFX_PLANES3 / bgs_conv3x3_planes_enable: 0 off | 1 automatic | 2 every eligible layer
 int g_planes3_last = 0;
 
@@ -314,6 +491,49 @@ int bgs_internal_conv3x3_planes(const bgs_conv::ConvArgs& pc, const void* wsplit
   if (nb == 2) hipLaunchKernelGGL((conv3x3_planes_bfx_kernel<2>), grid, block, 0, st, g);
   else hipLaunchKernelGGL((conv3x3_planes_bfx_kernel<1>), grid, block, 0, st, g);
   g_planes3_last = nb;
+  bgs_internal_census_bump(BGS_CENSUS_PLANES_3X3);
+  return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
+}
+
+// the stride-2 form (forward 3x3 / stride 2 / pad 1 layers; called from launch_conv_bfx ahead of the operand ring)
+int bgs_internal_conv3x3s2_planes(const bgs_conv::ConvArgs& pc, const void* wsplit, int KC, hipStream_t st) {
+  int mode = g_planes3_mode;
+  if (mode < 0) {
+    const char* e = getenv("BGS_BFX_PLANES3");
+    mode = e ? atoi(e) : 1;
+    if (mode < 0 || mode > 2) mode = 1;
+  }
+  static int s2_env = -1;                   // BGS_BFX_PLANES3_S2=0: the stride-2 form alone off (A/B)
+  if (s2_env < 0) {
+    const char* e = getenv("BGS_BFX_PLANES3_S2");
+    s2_env = e ? atoi(e) : 1;
+  }
+  if (mode == 0 || !s2_env) return -1;
+  const ConvArgs& p = pc;
+  if (p.R != 3 || p.S != 3 || p.stride != 2 || p.pad != 1 || p.mask || p.rowmap || p.res_mode != 0) return -1;
+  if ((p.Cin & 31) || (p.Cout & 127) || KC != 9 * (p.Cin / 16)) return -1;
+  if (p.Ho != (p.H - 1) / 2 + 1 || p.Wo != (p.W - 1) / 2 + 1) return -1;
+  if (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.bias | (uintptr_t)wsplit) & 15) return -1;
+  const long long lim = kOob;
+  if ((long long)p.N * p.H * p.W * p.Cin * 4 >= lim || (long long)p.M * p.Cout * 4 >= lim || (long long)3 * KC * p.Cout * 32 >= lim) return -1;
+  const int tiles_y = (p.Ho + 7) / 8, tiles_x = (p.Wo + 7) / 8;
+  const long long tiles_px = (long long)p.N * tiles_y * tiles_x;
+  const int nb = 1;                         // (128 channels per workgroup: with 256 the five patch quads in flight per thread spill)
+  const long long wgs = tiles_px * (p.Cout / (128 * nb));
+  if (mode == 1 && wgs < 256) return -1;      // (layer4.0 conv2, 192 workgroups: 93.2 vs 93.5 us on the ring — left there)
+  Planes3Args g;
+  g.c = p;
+  g.ws = reinterpret_cast<const __bf16*>(wsplit);
+  g.KC = KC;
+  g.tiles_y = tiles_y;
+  g.tiles_x = tiles_x;
+  g.c.tiles_m = (int)tiles_px;
+  g.c.tiles_n = p.Cout / (128 * nb);
+  g.c.chunk = (int)((wgs + 7) / 8);
+  g.c.partial = nullptr;
+  const dim3 grid((unsigned)(8 * g.c.chunk)), block(kThreads);
+  hipLaunchKernelGGL((conv3x3s2_planes_bfx_kernel<1>), grid, block, 0, st, g);
+  g_planes3_last = nb | 0x10;               // bit 4: the stride-2 form
   bgs_internal_census_bump(BGS_CENSUS_PLANES_3X3);
   return hipGetLastError() == hipSuccess ? BGS_OK : BGS_ERR_LAUNCH;
 }

@@ -57,6 +57,7 @@ size_t bgs_internal_conv1x1_bfx_wide_workspace(long long M, int Cout, int K);
 int bgs_internal_conv1x1_planes(const bgs_conv::ConvArgs& p, const void* wsplit, int KC, hipStream_t st);
 void bgs_internal_conv1x1_planes_clear_last();
 int bgs_internal_conv3x3_planes(const bgs_conv::ConvArgs& p, const void* wsplit, int KC, hipStream_t st);   // conv3x3_planes.hip
+int bgs_internal_conv3x3s2_planes(const bgs_conv::ConvArgs& p, const void* wsplit, int KC, hipStream_t st);
 void bgs_internal_conv3x3_planes_clear_last();
 
 namespace {
@@ -2398,6 +2399,16 @@ int launch_conv_bfx(BfxArgs& q, int up, hipStream_t st, void* workspace, size_t 
     const int rc = bgs_internal_conv1x1_planes(p, q.ws, q.KC, st);
     if (rc >= 0) {
       g_last_tile = 0x8000;        // bit 15: the planes-in-LDS 1x1 kernel ran
+      g_last_splits = 1;
+      g_last_dma = 0;
+      return rc;
+    }
+  }
+  if (wide_ok && p.R == 3 && p.stride == 2) {     // forward 3x3 / stride 2: 8 x 8 output pixels per workgroup, parity sub-grids in LDS
+    bgs_internal_conv3x3_planes_clear_last();
+    const int rc = bgs_internal_conv3x3s2_planes(p, q.ws, q.KC, st);
+    if (rc >= 0) {
+      g_last_tile = 0x8000;
       g_last_splits = 1;
       g_last_dma = 0;
       return rc;

@@ -140,7 +140,10 @@ int bgs_conv1x1_planes_last_launch(void);
  * at every call: the layers whose halo plan slices K and whose own grid has a workgroup per CU) | 2 every eligible layer
  * (3x3 / stride 1 / pad 1, Cin % 32 == 0, Cout % 128 == 0, fp32-faithful planes, tensors < 2 GB; the ReLU-backward mask
  * of the data-gradient form is in its epilogue) | < 0: back to
- * the environment's value.  last_launch: 0, or the channels per workgroup / 128 of the last 3x3 launch that took it. */
+ * the environment's value.  last_launch: 0, or the channels per workgroup / 128 of the last 3x3 launch that took it
+ * (| 0x10: the stride-2 form, conv3x3s2_planes_bfx_kernel: forward 3x3 / stride 2 / pad 1 layers ahead of the operand ring —
+ * the 17 x 17 patch as four parity sub-grids in LDS; same products as the ring in another fp32 summation order;
+ * BGS_BFX_PLANES3_S2=0 switches that form alone off). */
 void bgs_conv3x3_planes_enable(int mode);
 int bgs_conv3x3_planes_last_launch(void);
 

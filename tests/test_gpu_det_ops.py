@@ -1153,6 +1153,7 @@ def test_conv1x1_filter_resident_kernel_is_bit_identical_to_the_operand_ring(sha
     assert err < 2e-6, err
 
 
+@pytest.mark.usefixtures('planes_kernel_off')
 def test_conv1x1_filter_resident_kernel_as_data_gradient_with_mask():
     """The same kernel under ``bgs_conv2d_dgrad_nhwc_f32_bfx_ws`` (1x1, stride 1: the data gradient of
     a 1x1 conv is a 1x1 conv with the transposed filter) with the ReLU-backward mask and a residual
@@ -1902,3 +1903,49 @@ def test_planes_kernels_as_data_gradients_with_the_relu_mask_are_bit_identical(c
     ref = torch.where(mask > 0, ref, torch.zeros_like(ref))
     err = float((d1.cpu().double() - ref).abs().max() / ref.abs().max())
     assert err < 2e-6, err
+
+
+@pytest.mark.parametrize('case', [
+    # N, H, W, Cin, Cout, relu
+    (2, 200, 336, 128, 128, True),        # layer2.0 conv2 at the BASELINE size
+    (2, 100, 168, 256, 256, True),        # layer3.0 conv2
+    (2, 50, 84, 512, 512, True),          # layer4.0 conv2: ragged output tiles (25 x 42)
+    (1, 37, 29, 64, 384, False),          # odd input sizes (Ho = 19, Wo = 15), three 128-channel slabs
+    (3, 16, 18, 32, 128, True),           # two chunks only, even sizes (the last input row / column is never read)
+], ids=lambda c: 'x'.join(str(int(v)) for v in c))
+def test_planes_3x3_stride2_kernel_vs_the_operand_ring_and_fp64(case):
+    """``conv3x3s2_planes_bfx_kernel`` (csrc/conv3x3_planes.hip: the 17 x 17 input patch of 8 x 8 output pixels as four
+    parity sub-grids in LDS; the stride-2 conv2 of mmdet/models/backbones/resnet.py:239-252) against the 64 x 64 operand
+    ring it replaces: the same products in another fp32 summation order (chunk-major / tap-major), so equality within
+    fp32 rounding, and both within the family's bound of fp64 torch (every pixel incl. the zero-padded border)."""
+    from balancedgroupsoftmax_amd import capi
+    lib = capi.load()
+    N, H, W, Cin, Cout, relu = case
+    g = torch.Generator().manual_seed(H * 13 + Cin)
+    x = torch.randn(N, H, W, Cin, generator=g) * torch.exp(torch.randn(N, H, W, Cin, generator=g))
+    w = torch.randn(Cout, 3, 3, Cin, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    prev = BF.set_conv_math('bf16x6')
+    try:
+        xd, wd, bd = dev(x), dev(w), dev(b)
+        lib.bgs_conv3x3_planes_enable(0)
+        y0 = BF.conv2d_nhwc(xd, wd, bd, stride=2, pad=1, relu=relu)
+        assert not lib.bgs_conv3x3_planes_last_launch()
+        lib.bgs_conv3x3_planes_enable(2)
+        y1 = BF.conv2d_nhwc(xd, wd, bd, stride=2, pad=1, relu=relu)
+        assert lib.bgs_conv3x3_planes_last_launch() == 0x11          # stride-2 form, 128 channels per workgroup
+        torch.cuda.synchronize()
+    finally:
+        lib.bgs_conv3x3_planes_enable(-1)
+        BF.set_conv_math(prev)
+    y64 = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double(),
+                                     stride=2, padding=1)
+    if relu:
+        y64 = y64.clamp(min=0)
+    y64 = y64.permute(0, 2, 3, 1)
+    assert tuple(y1.shape) == tuple(y64.shape)
+    scale = float(y64.abs().max())
+    tol = 2e-6 * max(1.0, (9 * Cin / 2304.0) ** 0.5)
+    e0, e1 = float((y0.cpu().double() - y64).abs().max()) / scale, float((y1.cpu().double() - y64).abs().max()) / scale
+    assert e0 < tol and e1 < tol, (e0, e1, tol)
+    assert float((y0 - y1).abs().max()) / scale < tol
