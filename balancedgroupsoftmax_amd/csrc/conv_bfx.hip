@@ -1638,14 +1638,13 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_c3_fused_bfx_kernel(Fused
   constexpr int NS = 3, TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, PROWS = PH * PW;
   constexpr int AQ = PROWS * 4, AQT = (AQ + kThreads - 1) / kThreads;
   constexpr int BN = 64, CO3 = 256, KC3 = 4;
-  constexpr int B_PLANE = BN * 32, B_BUF = NS * B_PLANE;
-  // filter slices in a THREE-deep ring (the halo kernel keeps two): with 64 output channels a step is 12 MFMAs per wave
-  // (384 cycles) — less than the L2 -> LDS round trip of the next slice, which a two-deep ring issues only one step ahead
-  constexpr int BR = 3;
-  constexpr int SCR = BR * B_BUF;
-  constexpr int A_OFF = SCR + 1024;
+  // phase 1 keeps NO filter slices in LDS (round 6, after conv3x3_planes.hip): with 64 output channels a step is 12 MFMAs
+  // per wave (384 cycles) — a DMA ring needed a `vmcnt` + workgroup barrier per step to hand each 6 KB slice over; the
+  // waves now load their three 32-channel fragments per step straight from L2 into registers one step ahead, and the
+  // only barriers left are the two around the patch store of a 16-channel chunk
+  constexpr int A_OFF = 0;
   constexpr int HL = 32, A_PLANE = PROWS * HL;
-  constexpr int OPER_BYTES = A_OFF + NS * A_PLANE;                  // 30,592
+  constexpr int OPER_BYTES = A_OFF + NS * A_PLANE;                  // 17,280
   constexpr int P3_CHUNK = 64 * 32, P3_PLANE = KC3 * P3_CHUNK;      // (64 pixels:) 2 KB per k chunk, 8 KB per plane
   constexpr int LD2 = BN + 4, LD4 = CO3 + 4;
   constexpr int S2_BYTES = 64 * LD2 * 4;                            // phase-2 transpose tile: 17,408
@@ -1667,20 +1666,16 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_c3_fused_bfx_kernel(Fused
   const int h0 = ty * TH - 1, w0 = tx * TW - 1;
   const int cchunks = p.Cin / 16;
 
-  // ---- phase 1: conv2, the loop of conv3x3_halo_bfx4_kernel<1, 3> (filter DMA roles: six pieces, wave w takes piece w
-  //      and, w < 2, piece w + 4; a dummy piece into the scratch block otherwise)
-  const int brow_d = (wave & 1) * 32 + (lane >> 1);
-  const int bhalf_d = (lane & 1) ^ ((brow_d >> 3) & 1);
-  const bool b_okd = brow_d < p.Cout;
-  const __bf16* b_lane = q.ws + (size_t)(b_okd ? brow_d : 0) * 16 + bhalf_d * 8;
-  const size_t b_plane = (size_t)q.KC * p.Cout * 16;
-  auto issue_b = [&](int chunk, int tap, int buf_off) {
-    const size_t koff = (size_t)(tap * cchunks + chunk) * p.Cout * 16;
-    const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page);
-    const int s0 = wave >> 1;
-    glds16(b_okd ? b_lane + s0 * b_plane + koff : zp, lds + buf_off + s0 * B_PLANE + (wave & 1) * 1024);
-    if (wave < 2) glds16(b_okd ? b_lane + 2 * b_plane + koff : zp, lds + buf_off + 2 * B_PLANE + wave * 1024);
-    else glds16(zp, lds + SCR);
+  // ---- phase 1: conv2 = the accumulation order of conv3x3_halo_bfx4_kernel<1, 3> (16-channel chunks ascending, nine taps
+  //      per chunk); wave (wm, wn) owns pixels 64 wm .. and channels 32 wn ..: its filter fragments by buffer loads
+  const __amdgpu_buffer_rsrc_t b2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(q.ws), 0, (int)((size_t)NS * q.KC * p.Cout * 32), 0x00020000);
+  const int b2_lane = (((wave & 1) * 32 + (lane & 31)) * 16 + (lane >> 5) * 8) * 2;   // bytes
+  const int b2_plane = q.KC * p.Cout * 32;
+  auto load_b2 = [&](int kc, bf16x8 (&dst)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      dst[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b2_rsrc, b2_lane, s * b2_plane + kc * p.Cout * 32, 0));
   };
   const float* a_src[AQT];
   int a_dst[AQT];
@@ -1726,46 +1721,35 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_c3_fused_bfx_kernel(Fused
     for (int par = 0; par < 2; ++par)
       a_frag[a][par] = A_OFF + (pr * PW + pc) * HL + ((fk ^ ((pr + pc + par) & 1)) << 4);
   }
-  const int brow = wn * 32 + frow;
-  const int b_frag = brow * 32 + ((fk ^ ((brow >> 3) & 1)) << 4);
   f32x16 acc[2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  bf16x8 fbA[NS], fbB[NS];
   load_a(0);
-  issue_b(0, 0, 0);
-  issue_b(0, 1, B_BUF);
-  store_a();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int chunk = 0; chunk < cchunks; ++chunk) {
-    const bool last_chunk = chunk + 1 >= cchunks;
+  load_b2(0, fbA);                                                  // (tap 0, chunk 0)
+  for (int c2 = 0; c2 < cchunks; c2 += 2) {                         // two chunks per trip: 18 steps, the ping-pong closes
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      // slice (chunk, tap) sits in ring slot tap % 3 (nine taps per chunk: the slot of a tap is the same in every chunk);
-      // slice + 2 goes to the slot slice - 1 was read from (its readers passed the barrier of the previous step)
-      const int rd = (tap % BR) * B_BUF;
-      const int wr = ((tap + 2) % BR) * B_BUF;
-      const bool more = tap + 2 < 9 || !last_chunk;                 // a slice two steps ahead exists
-      if (tap + 2 < 9) issue_b(chunk, tap + 2, wr);
-      else if (!last_chunk) issue_b(chunk + 1, tap + 2 - 9, wr);
-      const bool patch = tap == 0 && !last_chunk;
-      if (patch) load_a(chunk + 1);
+    for (int t = 0; t < 18; ++t) {
+      const int chunk = c2 + t / 9, tap = t % 9;
+      if (tap == 0) {
+        __syncthreads();                                            // every wave is done with the previous chunk's patch
+        store_a();                                                  // (waits for this chunk's patch loads)
+        __syncthreads();
+      }
+      load_b2(tap < 8 ? (tap + 1) * cchunks + chunk : chunk + 1, (t & 1) ? fbA : fbB);    // (past the end: unused)
+      if (tap == 0 && chunk + 1 < cchunks) load_a(chunk + 1);       // next patch: in registers under this chunk's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8 (&fb)[NS] = (t & 1) ? fbB : fbA;
       const int tap_off = ((tap / 3) * PW + (tap % 3)) * HL;
       const int tap_par = (tap / 3 + tap % 3) & 1;
-      bf16x8 fa[NS][2], fb[NS];
+      bf16x8 fa[NS][2];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
+      for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
           fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + a_frag[a][tap_par] + tap_off + s * A_PLANE);
-        fb[s] = *reinterpret_cast<const bf16x8*>(lds + rd + b_frag + s * B_PLANE);
-      }
-      if (q.flags & 1) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
-      }
 #pragma unroll
       for (int tt = NS - 1; tt >= 0; --tt)
 #pragma unroll
@@ -1773,19 +1757,10 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_c3_fused_bfx_kernel(Fused
 #pragma unroll
           for (int a = 0; a < 2; ++a)
             acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fb[tt - i], acc[a], 0, 0, 0);
-      if (q.flags & 1) __builtin_amdgcn_s_setprio(0);
-      // the NEXT step's slice has landed once only this step's issues are still in flight: 2 DMAs per wave (+ the 3
-      // patch loads behind them at tap 0); the last two steps issue nothing
-      if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (patch) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      __syncthreads();
-      if (tap == 8 && !last_chunk) {
-        store_a();
-        __syncthreads();
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+  __syncthreads();                                                  // every wave is done with the patch (phase 2 overlays it)
 
   // ---- phases 2 - 4, once per HALF of the tile (64 pixels: the conv2 accumulators of the waves wm == h).  Per half:
   //      conv2 epilogue -> split planes of 64 pixels (24 KB) -> conv3 on 64 pixels x 256 channels (wave w: channels
