@@ -33,6 +33,9 @@
 #ifndef BGS_P3_Y_AUX
 #define BGS_P3_Y_AUX 0
 #endif
+#ifndef BGS_P3_ABL
+#define BGS_P3_ABL 0             // timing-only ablations (build variants p3abl1 / p3abl2 / p3abl3; results are WRONG)
+#endif
 #include "conv_args.h"
 #include "bfx_split.h"
 
@@ -179,9 +182,19 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_planes_bfx_kernel(Planes3
       const int kcs = t / 9, tap = t % 9, dy = tap / 3, dx = tap % 3;
       const int t1 = t + 1;
       const int kc_next = t1 < 18 ? (t1 % 9) * cch16 + chunk * 2 + t1 / 9 : (chunk + 1) * 2;
+#if BGS_P3_ABL & 1                                               // timing only: filter fragments loaded twice per chunk
+      if (t < 2) {
+#endif
       if (t & 1) load_b(kc_next, fb0);
       else load_b(kc_next, fb1);
+#if BGS_P3_ABL & 1
+      }
+#endif
+#if BGS_P3_ABL & 2                                               // timing only: the patch loaded once
+      if (t == 0 && chunk == 0) load_a(chunk + 1);
+#else
       if (t == 0) load_a(chunk + 1);                                // in flight under this chunk's MFMAs (past the end: 0)
+#endif
       __builtin_amdgcn_sched_barrier(0);
       const bf16x8 (&fbu)[NS][NB] = (t & 1) ? fb1 : fb0;
       bf16x8 fa[NS][2];
