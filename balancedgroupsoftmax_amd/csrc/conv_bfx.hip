@@ -58,6 +58,9 @@ int bgs_internal_conv1x1_planes(const bgs_conv::ConvArgs& p, const void* wsplit,
 void bgs_internal_conv1x1_planes_clear_last();
 int bgs_internal_conv3x3_planes(const bgs_conv::ConvArgs& p, const void* wsplit, int KC, hipStream_t st);   // conv3x3_planes.hip
 int bgs_internal_conv3x3s2_planes(const bgs_conv::ConvArgs& p, const void* wsplit, int KC, hipStream_t st);
+int bgs_internal_bottleneck_tail_planes(const float* x, const void* w2split, const float* bias2, const void* w3split,
+                                        const float* bias3, const float* residual, float* y, int N, int H, int W,
+                                        int relu3, hipStream_t st);     // bottleneck_tail_planes.hip
 void bgs_internal_conv3x3_planes_clear_last();
 
 namespace {
@@ -2797,6 +2800,19 @@ extern "C" int bgs_conv3x3_c3_fused_nhwc_f32_bfx(const float* x, const void* w2s
     return BGS_ERR_UNSUPPORTED;
   const long long M = (long long)N * H * W;
   if (M > 0x7fffffffLL || (long long)H * W * Cout3 > 0x7fffffffLL) return BGS_ERR_UNSUPPORTED;   // 32-bit offsets inside an image
+  {
+    // the planes form (bottleneck_tail_planes.hip: 8 x 8-pixel workgroups, the whole 64-channel patch staged once);
+    // BGS_FUSED_C3_PLANES=0 keeps the 8 x 16-pixel kernel below (A/B, read at every call); bit-identical
+    const char* e = getenv("BGS_FUSED_C3_PLANES");
+    if (!e || atoi(e) != 0) {
+      const int rc = bgs_internal_bottleneck_tail_planes(x, w2split, bias2, w3split, bias3, residual, y, N, H, W, relu3,
+                                                         (hipStream_t)stream);
+      if (rc >= 0) {
+        bgs_internal_census_bump(BGS_CENSUS_FUSED_C3);
+        return rc;
+      }
+    }
+  }
   FusedC3Args g;
   HaloBfxArgs& q = g.h;
   q.ns = 3;
