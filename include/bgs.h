@@ -350,8 +350,9 @@ int bgs_conv3x3_halo_nhwc_f32_bfx_ex(const float* x, const void* wsplit, const f
  * filters viewed as [Cmid][9 Cmid] / [Cout3][Cmid]; residual [N,H,W,Cout3] or NULL; y [N,H,W,Cout3].  The 64-channel
  * intermediate never reaches HBM.  Supported: Cmid = 64, Cout3 = 256 (ResNet-50 layer1), 16-byte aligned pointers;
  * BGS_ERR_UNSUPPORTED otherwise (run the two launches).  BIT-IDENTICAL to bgs_conv3x3_halo_nhwc_f32_bfx followed by
- * bgs_conv2d_nhwc_f32_bfx_ws with the residual.  * Since round 6 the launch is bottleneck_tail_planes_kernel (8 x 8-pixel workgroups, the whole 64-channel patch staged
- * once; csrc/bottleneck_tail_planes.hip); BGS_FUSED_C3_PLANES=0 keeps the first form (8 x 16 pixels).  Same results, bit for bit. */
+ * bgs_conv2d_nhwc_f32_bfx_ws with the residual.  The launch is bottleneck_tail_planes_kernel (8 x 8-pixel workgroups,
+ * the whole 64-channel patch staged once; csrc/bottleneck_tail_planes.hip); BGS_FUSED_C3_PLANES=0 keeps the first form
+ * (conv3x3_c3_fused_bfx_kernel, 8 x 16 pixels).  Same results, bit for bit. */
 int bgs_conv3x3_c3_fused_nhwc_f32_bfx(const float* x, const void* w2split, const float* bias2,
                                       const void* w3split, const float* bias3, const float* residual,
                                       float* y, int N, int H, int W, int Cmid, int Cout3, int relu3,

@@ -8,7 +8,7 @@ import csv
 import sys
 
 
-CATS = [('conv: fused bottleneck tail (3x3 -> 1x1 + residual)', ('conv3x3_c3_fused',)), ('conv: 3x3 (planes / halo kernels)', ('conv3x3_halo', 'conv3x3_planes', 'conv3x3s2_planes')), ('conv: implicit GEMM', ('conv_igemm', 'conv_bf16s', 'conv1x1_bres', 'conv1x1_bfx_wide', 'conv1x1_planes')),
+CATS = [('conv: fused bottleneck tail (3x3 -> 1x1 + residual)', ('conv3x3_c3_fused', 'bottleneck_tail_planes')), ('conv: 3x3 (planes / halo kernels)', ('conv3x3_halo', 'conv3x3_planes', 'conv3x3s2_planes')), ('conv: implicit GEMM', ('conv_igemm', 'conv_bf16s', 'conv1x1_bres', 'conv1x1_bfx_wide', 'conv1x1_planes')),
         ('conv: split-K epilogue', ('conv_splitk',)), ('conv: weight split / wgrad / grouped / pool',
                                                        ('bfx_split', 'conv_wgrad', 'grouped_conv', 'maxpool', 'fold_', 'wgrad_reduce', 'nchw_to', 'stem_')),
         ('torch glue (elementwise / copy / cat / reduce / index)', ('at::native', 'rocclr', 'at::cuda', 'cub::', 'rocprim', 'hipcub')),
