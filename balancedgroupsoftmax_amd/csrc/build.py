@@ -35,6 +35,7 @@ EXTRA_VARIANTS = {
     'p3ntay': dict(name='libbgs_p3ntay.so', flags=['-DBGS_P3_A_AUX=2', '-DBGS_P3_Y_AUX=2']),
     # timing-only ablations of the 3x3 planes kernel: 1 = filter fragments from L2 twice per chunk instead of 18 times,
     # 2 = the patch loaded once, 3 = both (results are wrong; tools/planes3_ablate.sh)
+    'p3prio': dict(name='libbgs_p3prio.so', flags=['-DBGS_P3_PRIO=1']),
     'p3abl1': dict(name='libbgs_p3abl1.so', flags=['-DBGS_P3_ABL=1']),
     'p3abl2': dict(name='libbgs_p3abl2.so', flags=['-DBGS_P3_ABL=2']),
     'p3abl3': dict(name='libbgs_p3abl3.so', flags=['-DBGS_P3_ABL=3']),

@@ -33,6 +33,9 @@
 #ifndef BGS_P3_Y_AUX
 #define BGS_P3_Y_AUX 0
 #endif
+#ifndef BGS_P3_PRIO
+#define BGS_P3_PRIO 0            // s_setprio 1 around the MFMA cluster of a k step (build variant p3prio): 2 % SLOWER on the P2 layer (0.735 vs 0.721 ms)
+#endif
 #ifndef BGS_P3_ABL
 #define BGS_P3_ABL 0             // timing-only ablations (build variants p3abl1 / p3abl2 / p3abl3; results are WRONG)
 #endif
@@ -204,6 +207,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_planes_bfx_kernel(Planes3
         for (int a = 0; a < 2; ++a)
           fa[s][a] = *reinterpret_cast<const bf16x8*>(lds + buf * BUF + s * PL + kcs * KS + a_frag[a][dy & 1] +
                                                       (dy * PS + dx) * 32);
+#if BGS_P3_PRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int tt = NS - 1; tt >= 0; --tt)
 #pragma unroll
@@ -213,6 +219,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_planes_bfx_kernel(Planes3
 #pragma unroll
             for (int b = 0; b < NB; ++b)
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][a], fbu[tt - i][b], acc[a][b], 0, 0, 0);
+#if BGS_P3_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   }
